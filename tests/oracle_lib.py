@@ -1,0 +1,123 @@
+"""ctypes binding for oracle/liboracle.so -- TEST INFRASTRUCTURE (see oracle/calitas_oracle.cpp header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+DEFAULT_COSTS = (-120, -260, -122, -121)  # guideMismatch, pamMismatch, genomeGap, guideGap net costs (SGA:17-22)
+
+GA_COLUMNS = ["strand", "start", "end", "gstart", "gend", "score", "cigar", "guide", "padded_guide", "padded_alignment",
+              "padded_target", "mismatches", "gap_bases", "guide_mm", "guide_gaps", "pam_mm", "pam_gaps", "chrom"]
+_GA_INT = {"start", "end", "gstart", "gend", "score", "mismatches", "gap_bases", "guide_mm", "guide_gaps", "pam_mm", "pam_gaps"}
+
+_lib = None
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "calitas_oracle.cpp")
+    if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIB_PATH)
+        for name in ["oracle_align", "oracle_align_best", "oracle_align_to_ref", "oracle_guide_alignment", "oracle_windows",
+                     "oracle_search_reference", "oracle_search_memory"]:
+            getattr(L, name).restype = ctypes.c_void_p
+        L.oracle_free.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _take(ptr):
+    s = ctypes.string_at(ptr).decode()
+    lib().oracle_free(ptr)
+    if s.startswith("ERROR\t"):
+        raise RuntimeError(s[6:])
+    return s
+
+
+def _costs(costs):
+    return (ctypes.c_int * 4)(*costs)
+
+
+def _rows(text):
+    out = []
+    for line in text.splitlines():
+        f = line.split("\t")
+        d = dict(zip(GA_COLUMNS, f))
+        for k in _GA_INT:
+            d[k] = int(d[k])
+        out.append(d)
+    return out
+
+
+def align(guide, target, d, g, p, D, O=0, off=0, aux=(), name="n/a", costs=DEFAULT_COSTS, switches=0):
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    ptr = lib().oracle_align(guide.encode(), ",".join(aux).encode(), t, len(t), name.encode(), off, d, g, p, D, O, _costs(costs), switches)
+    return _rows(_take(ptr))
+
+
+def align_best(guide, target, aux=(), g=3, costs=DEFAULT_COSTS, switches=0):
+    t = target.encode()
+    ptr = lib().oracle_align_best(guide.encode(), ",".join(aux).encode(), t, len(t), g, _costs(costs), switches)
+    return _rows(_take(ptr))[0]
+
+
+def align_to_ref_best(guide, chrom, contig, pos, window_size=0, g=3, costs=DEFAULT_COSTS, switches=0):
+    c = contig.encode()
+    ptr = lib().oracle_align_to_ref(guide.encode(), chrom.encode(), c, len(c), pos, window_size, 1, 0, g, 0, 0, 0, _costs(costs), switches)
+    return _rows(_take(ptr))[0]
+
+
+def guide_alignment(pg, pa, pt, start, end, strand):
+    ptr = lib().oracle_guide_alignment(pg.encode(), pa.encode(), pt.encode(), start, end, ctypes.c_char(strand.encode()))
+    return [int(x) for x in _take(ptr).split()]
+
+
+def windows(fasta, window, step, chrom=""):
+    ptr = lib().oracle_windows(fasta.encode(), window, step, chrom.encode())
+    out = []
+    for line in _take(ptr).splitlines():
+        n, s, e, ln = line.split("\t")
+        out.append((n, int(s), int(e), int(ln)))
+    return out
+
+
+def _iparams(window_size=1000, d=5, p=1, g=3, D=-1, O=10, m=-120, M=-260, b=-122, B=-121, max_variants=16, threads=1, switches=0):
+    return (ctypes.c_int * 13)(window_size, d, p, g, D, O, m, M, b, B, max_variants, threads, switches)
+
+
+def search_reference(fasta, guide, guide_id="a", aux=(), chrom="", **kw):
+    """Returns (header, rows) of the hits.txt the reference algorithm produces for this FASTA."""
+    nwin = ctypes.c_long(0)
+    ptr = lib().oracle_search_reference(fasta.encode(), guide.encode(), guide_id.encode(), ",".join(aux).encode(), _iparams(**kw),
+                                        chrom.encode(), ctypes.byref(nwin))
+    lines = _take(ptr).splitlines()
+    header = lines[0].split("\t")
+    rows = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
+    return header, rows, nwin.value
+
+
+def search_memory(names, seqs, guide, guide_id="a", aux=(), **kw):
+    """seqs: list of bytes objects (ASCII bases)."""
+    n = len(names)
+    c_names = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+    c_seqs = (ctypes.c_char_p * n)(*seqs)
+    c_lens = (ctypes.c_long * n)(*[len(s) for s in seqs])
+    nwin = ctypes.c_long(0)
+    ptr = lib().oracle_search_memory(n, c_names, c_seqs, c_lens, guide.encode(), guide_id.encode(), ",".join(aux).encode(),
+                                     _iparams(**kw), ctypes.byref(nwin))
+    lines = _take(ptr).splitlines()
+    header = lines[0].split("\t")
+    rows = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
+    return header, rows, nwin.value

@@ -1,0 +1,118 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own unit tests hold for the hot path
+(K1-K26 SequentialGuideAlignerTest, G1-G6 GuideAlignmentTest, E1-E3/E5 SearchReferenceTest).
+Runs under both settings of the two switches the vectors cannot distinguish (U1, U2)."""
+import json
+import os
+
+import pytest
+
+import oracle_lib as O
+from fasta_util import expand, write_fasta
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SGA = json.load(open(os.path.join(GOLD, "kat_sga.json")))
+GA = json.load(open(os.path.join(GOLD, "kat_ga.json")))
+SR = json.load(open(os.path.join(GOLD, "kat_sr.json")))
+
+SWITCHES = [0, 1, 2, 3]
+
+
+def rc(s):
+    comp = dict(zip("ACGTacgtNn", "TGCAtgcaNn"))
+    return "".join(comp[c] for c in reversed(s))
+
+
+@pytest.mark.parametrize("sw", SWITCHES)
+@pytest.mark.parametrize("case", SGA["align"], ids=lambda c: c["id"])
+def test_align_kats(case, sw):
+    alns = O.align(case["guide"], case["target"], case["d"], case["g"], case["p"], case["D"], O=case.get("O", 0),
+                   off=case.get("off", 0), switches=sw)
+    e = case["expect"]
+    if "size" in e:
+        assert len(alns) == e["size"]
+        if e["size"] == 0:
+            return
+    a = alns[0]
+    for k in ("strand", "start", "end", "gstart", "gend", "cigar", "padded_guide", "padded_target"):
+        if k in e:
+            assert a[k] == e[k], (case["id"], k, a)
+
+
+@pytest.mark.parametrize("sw", SWITCHES)
+def test_revcomp_symmetry_k11(sw):
+    c = SGA["revcomp_symmetry"]
+    for t in c["targets"]:
+        f = O.align_best(c["guide"], t, switches=sw)
+        r = O.align_best(rc(c["guide"]), rc(t), switches=sw)
+        for k in ("score", "guide_mm", "guide_gaps", "pam_mm", "pam_gaps"):
+            assert f[k] == r[k], (t, k, f, r)
+
+
+@pytest.mark.parametrize("sw", SWITCHES)
+@pytest.mark.parametrize("case", SGA["align_best"], ids=lambda c: c["id"])
+def test_align_best_kats(case, sw):
+    a = O.align_best(case["guide"], case["target"], aux=case.get("aux", ()), switches=sw)
+    e = case["expect"]
+    for k in ("score", "guide", "cigar", "start", "mismatches", "gap_bases"):
+        if k in e:
+            assert a[k] == e[k], (case["id"], k, a)
+    if "pam_mms_plus_gaps" in e:
+        assert a["pam_mm"] + a["pam_gaps"] == e["pam_mms_plus_gaps"]
+
+
+@pytest.mark.parametrize("sw", SWITCHES)
+def test_align_to_ref_best_kats(sw):
+    got = {}
+    for case in SGA["align_to_ref_best"]:
+        contig = SGA["contigs"][case["chrom"]]
+        a = O.align_to_ref_best(case["guide"], case["chrom"], contig, case["pos"], switches=sw)
+        got[case["id"]] = a
+        e = case["expect"]
+        for k in ("start", "end", "gstart", "gend", "strand", "padded_alignment", "mismatches", "gap_bases"):
+            if k in e:
+                assert a[k] == e[k], (case["id"], k, a)
+        if e.get("all_match"):
+            assert set(a["padded_alignment"]) == {"|"}
+        if e.get("padded_guide_equals_target"):
+            assert a["padded_guide"] == a["padded_target"]
+        if "score_ge" in e:
+            assert a["score"] >= e["score_ge"]
+        if "same_score_and_alignment_as" in e:
+            o = got[e["same_score_and_alignment_as"]]
+            assert a["score"] == o["score"] and a["padded_alignment"] == o["padded_alignment"]
+        assert a["chrom"] == case["chrom"]
+
+
+@pytest.mark.parametrize("case", GA["cases"], ids=lambda c: c["id"])
+def test_guide_alignment_counters(case):
+    assert O.guide_alignment(case["pg"], case["pa"], case["pt"], case["start"], case["end"], case["strand"]) == case["expect"]
+
+
+def _fasta(tmp_path, key):
+    contigs = [(name, expand(spec)) for name, spec in SR[key]["contigs"]]
+    return write_fasta(str(tmp_path / (key + ".fa")), contigs)
+
+
+@pytest.mark.parametrize("sw", SWITCHES)
+@pytest.mark.parametrize("case", SR["cases"], ids=lambda c: c["id"])
+def test_search_reference_kats(case, sw, tmp_path):
+    fa = _fasta(tmp_path, case["fasta"])
+    header, rows, _ = O.search_reference(fa, case["guide"], switches=sw)
+    e = case["expect"]
+    assert len(header) == 34
+    assert len(rows) == e["n"]
+    for k in ("chromosome", "padded_alignment"):
+        if k in e:
+            assert [r[k] for r in rows] == e[k]
+    for k in ("coordinate_start", "total_mm_plus_gaps"):
+        if k in e:
+            assert [int(r[k]) for r in rows] == e[k]
+
+
+def test_window_iterator_e5(tmp_path):
+    w = SR["window_iterator"]
+    fa = _fasta(tmp_path, w["fasta"])
+    wins = O.windows(fa, w["window"], w["step"])
+    assert len(wins) == 59  # Range(0, 24999, 426)
+    assert wins[0] == ("chr1", 1, 451, 451)
+    assert wins[-1][2] == 25000
