@@ -1,0 +1,3 @@
+"""calitas_amd -- MI355X-native CALITAS SearchReference hot path (HIP kernels behind a C ABI)."""
+from .aligner import (Alignment, CalitasError, Context, Defaults, Guide, SearchReference, make_params, read_hits,  # noqa: F401
+                      window_filter)

@@ -1,0 +1,486 @@
+// api.cpp -- C ABI of libcalitas_hip.so (include/calitas_hip.h): context, reference upload, the search pipeline.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/calitas_hip.h"
+#include "common.hpp"
+#include "fasta.hpp"
+#include "kernels.hpp"
+#include "post.hpp"
+#include "refpack.hpp"
+
+using namespace calitas;
+
+struct calitas_ctx {
+  int device = -1;
+  std::string err;
+  PackedRef ref;
+  bool has_ref = false;
+  // device state
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* d_codes = nullptr;
+  uint32_t* d_mask = nullptr;
+  Run* d_runs = nullptr;
+  ContigInfo* d_contigs = nullptr;
+  TileInfo* d_tiles = nullptr;
+  GuideDev* d_guides = nullptr;
+  ScanRecord* d_recs = nullptr;
+  RawAln* d_raw = nullptr;
+  uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies
+  uint32_t* h_counters = nullptr;   // pinned
+  uint32_t rec_cap = 0, raw_cap = 0;
+  calitas_timing_t timing{};
+};
+
+static std::string g_create_error;
+
+static int fail(calitas_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                         \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) return fail(ctx, CALITAS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+static void free_reference_device(calitas_ctx* c) {
+  if (c->device < 0) return;
+  (void)hipFree(c->d_codes); (void)hipFree(c->d_mask); (void)hipFree(c->d_runs); (void)hipFree(c->d_contigs); (void)hipFree(c->d_tiles);
+  c->d_codes = c->d_mask = nullptr; c->d_runs = nullptr; c->d_contigs = nullptr; c->d_tiles = nullptr;
+}
+
+extern "C" {
+
+const char* calitas_version(void) { return "calitas-hip 0.1 (gfx950)"; }
+
+const char* calitas_last_error(const calitas_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void calitas_free(void* p) { std::free(p); }
+
+int calitas_create(int device_id, calitas_ctx** out) {
+  if (!out) return fail(nullptr, CALITAS_EINVAL, "out is NULL");
+  *out = nullptr;
+  calitas_ctx* c = new calitas_ctx();
+  c->device = device_id;
+  if (device_id >= 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      delete c;
+      return fail(nullptr, CALITAS_ENODEV, "no HIP device available (the product path has no CPU fallback)");
+    }
+    if (device_id >= n) { delete c; return fail(nullptr, CALITAS_ENODEV, "device index out of range"); }
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+      std::string m = hipGetErrorString(e);
+      delete c;
+      return fail(nullptr, CALITAS_EHIP, "device init failed: " + m);
+    }
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    (void)hipMalloc((void**)&c->d_counters, 4 * sizeof(uint32_t));
+    (void)hipHostMalloc((void**)&c->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault);
+    (void)hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES);
+    // The aligner kernel's wavefront relies on the DPP wave shift; verify it on this device once.
+    int* d = nullptr;
+    int h[64];
+    bool ok = hipMalloc((void**)&d, sizeof(h)) == hipSuccess && launch_dpp_selftest(d, c->stream) == hipSuccess &&
+              hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+              hipStreamSynchronize(c->stream) == hipSuccess;
+    (void)hipFree(d);
+    for (int i = 1; ok && i < 64; i++) ok = h[i] == (i - 1) * 7 + 3;
+    if (!ok || !c->d_counters || !c->h_counters || !c->d_guides) {
+      calitas_destroy(c);
+      return fail(nullptr, CALITAS_EHIP, "device self-test failed (DPP wave_shr / allocation)");
+    }
+  } else if (device_id != -1) {
+    delete c;
+    return fail(nullptr, CALITAS_EINVAL, "device_id must be >= 0 or -1");
+  }
+  *out = c;
+  return CALITAS_OK;
+}
+
+void calitas_destroy(calitas_ctx* c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    (void)hipSetDevice(c->device);
+    free_reference_device(c);
+    (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const* names, const uint64_t* lengths,
+                          const uint8_t* const* bases, const char* genome_build) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (n_contigs <= 0 || !names || !lengths || !bases) return fail(ctx, CALITAS_EINVAL, "bad contig arguments");
+  for (int i = 0; i < n_contigs; i++)
+    if (lengths[i] > 0x7FFFFFFFull) return fail(ctx, CALITAS_EINVAL, "contigs longer than 2^31-1 bases are not supported (the reference uses Int coordinates)");
+  try {
+    pack_reference(ctx->ref, n_contigs, names, lengths, bases, genome_build, 0);
+  } catch (std::exception& e) {
+    ctx->has_ref = false;
+    return fail(ctx, CALITAS_EINVAL, e.what());
+  }
+  ctx->has_ref = true;
+  if (ctx->device >= 0) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    free_reference_device(ctx);
+    const PackedRef& r = ctx->ref;
+    size_t nruns = std::max<size_t>(1, r.runs.size());
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_codes, r.codes.size() * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mask, r.mask.size() * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_runs, nruns * sizeof(Run)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_contigs, r.contigs.size() * sizeof(ContigInfo)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, r.tiles.size() * sizeof(TileInfo)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_codes, r.codes.data(), r.codes.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mask, r.mask.data(), r.mask.size() * 4, hipMemcpyHostToDevice));
+    if (!r.runs.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_runs, r.runs.data(), r.runs.size() * sizeof(Run), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_contigs, r.contigs.data(), r.contigs.size() * sizeof(ContigInfo), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tiles, r.tiles.data(), r.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice));
+  }
+  return CALITAS_OK;
+}
+
+int calitas_set_reference_fasta(calitas_ctx* ctx, const char* fasta_path) {
+  if (!ctx || !fasta_path) return CALITAS_EINVAL;
+  FastaData fd;
+  std::string e = read_fasta(fasta_path, fd);
+  if (!e.empty()) return fail(ctx, CALITAS_EIO, e);
+  std::vector<const char*> names;
+  std::vector<uint64_t> lens;
+  std::vector<const uint8_t*> bases;
+  for (size_t i = 0; i < fd.names.size(); i++) {
+    names.push_back(fd.names[i].c_str());
+    lens.push_back(fd.seqs[i].size());
+    bases.push_back(reinterpret_cast<const uint8_t*>(fd.seqs[i].data()));
+  }
+  return calitas_set_reference(ctx, (int32_t)names.size(), names.data(), lens.data(), bases.data(), fd.genome_build.c_str());
+}
+
+int calitas_reference_info(const calitas_ctx* ctx, int32_t* n_contigs, uint64_t* total_bases, uint64_t* packed_bytes) {
+  if (!ctx || !ctx->has_ref) return CALITAS_ESTATE;
+  if (n_contigs) *n_contigs = (int32_t)ctx->ref.contigs.size();
+  if (total_bases) *total_bases = ctx->ref.total_bases;
+  if (packed_bytes) *packed_bytes = (ctx->ref.total_bases + 3) / 4;
+  return CALITAS_OK;
+}
+
+int calitas_contig_name(const calitas_ctx* ctx, int32_t i, const char** name, uint64_t* length) {
+  if (!ctx || !ctx->has_ref || i < 0 || i >= (int32_t)ctx->ref.contigs.size()) return CALITAS_EINVAL;
+  if (name) *name = ctx->ref.names[i].c_str();
+  if (length) *length = ctx->ref.contigs[i].len;
+  return CALITAS_OK;
+}
+
+int calitas_fetch_bases(const calitas_ctx* ctx, int32_t i, uint64_t start, uint32_t len, char* out) {
+  if (!ctx || !ctx->has_ref || i < 0 || i >= (int32_t)ctx->ref.contigs.size() || !out) return CALITAS_EINVAL;
+  const ContigInfo& c = ctx->ref.contigs[i];
+  if (start + len > c.len) return CALITAS_EINVAL;
+  for (uint32_t k = 0; k < len; k++) out[k] = ctx->ref.base_upper(c.gbase + start + k);
+  return CALITAS_OK;
+}
+
+int calitas_window_table(const calitas_ctx* ctx, int32_t window_size, int32_t step, int32_t min_length, int32_t chrom_index,
+                         int32_t** out, uint64_t* n_windows) {
+  if (!ctx || !ctx->has_ref || !out || !n_windows || step <= 0 || window_size <= 0) return CALITAS_EINVAL;
+  const PackedRef& r = ctx->ref;
+  std::vector<int32_t> rows;
+  for (size_t c = 0; c < r.contigs.size(); c++) {
+    if (chrom_index >= 0 && (int)c != chrom_index) continue;
+    uint64_t nw = window_count(r.contigs[c].len, step);
+    for (uint64_t k = 0; k < nw; k++) {
+      int64_t a, b;
+      if (!window_bounds(r.runs.data(), (int64_t)r.runs.size(), r.contigs[c].gbase, r.contigs[c].len, window_size, step, k, a, b)) continue;
+      if (b - a < min_length) continue;
+      rows.push_back((int32_t)c); rows.push_back((int32_t)a); rows.push_back((int32_t)b);
+    }
+  }
+  *n_windows = rows.size() / 3;
+  *out = (int32_t*)std::malloc(std::max<size_t>(1, rows.size()) * sizeof(int32_t));
+  if (!rows.empty()) std::memcpy(*out, rows.data(), rows.size() * sizeof(int32_t));
+  return CALITAS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// search
+// -------------------------------------------------------------------------------------------------------------------
+
+static std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, GuideDev& gd) {
+  std::memset(&gd, 0, sizeof(gd));
+  const int L = (int)gh.q.size();
+  gd.L = L;
+  gd.n_pams = (int)gh.pams_q.size();
+  gd.cli_length = gh.cli_length;
+  gd.min_guide_score = sc.match * L + sc.worst_guide_diff * p.max_guide_diffs;       // SGA:239-243
+  const int budget = sc.match * L - gd.min_guide_score;                              // = |worst| * d
+  // score(all matches) - score(path) = sum of per-edit costs: mismatch |m|, guide-only base |b|, genome-only base |B|
+  const int c_mm = iabs(p.guide_mismatch_net_cost), c_ins = iabs(p.genome_gap_net_cost), c_del = iabs(p.guide_gap_net_cost);
+  const int c_min = std::min(c_mm, std::min(c_ins, c_del));
+  if (c_min <= 0 || c_del <= 0) return "net costs of 0 are not supported (the candidate filter needs every edit to cost something)";
+  gd.scan_max_edits = budget / c_min;
+  const int max_del = budget / c_del;
+  gd.span = L + max_del;
+  if (gd.span + 1 + 16 > STRIP_MAX_COLS || gd.span + 1 > RAW_MAX_OPS)
+    return "max-guide-diffs too large for this protospacer (strip wider than the aligner kernel supports)";
+  if (L + gd.scan_max_edits > 64) return "max-guide-diffs too large for the scan warm-up";
+  for (int code = 0; code < 4; code++) {
+    uint32_t v = 0;
+    for (int i = 0; i < L; i++) if (iupac_mask((unsigned char)gh.q[i]) & (1 << code)) v |= 1u << (32 - L + i);
+    gd.peq_a[code] = v;
+  }
+  uint32_t all = 0;
+  for (int i = 0; i < L; i++) all |= 1u << (32 - L + i);
+  gd.peq_a[4] = 0; gd.peq_a[5] = all; gd.peq_a[6] = 0; gd.peq_a[7] = 0;
+  for (int code = 0; code < 4; code++) gd.peq_b[code] = gd.peq_a[3 - code];
+  for (int k = 4; k < 8; k++) gd.peq_b[k] = gd.peq_a[k];
+  for (int i = 0; i < L; i++) gd.qmask[i] = (uint8_t)iupac_mask((unsigned char)gh.q[i]);
+  for (int pi = 0; pi < gd.n_pams; pi++) {
+    gd.pam_len[pi] = (uint8_t)gh.pams_q[pi].size();
+    for (size_t k = 0; k < gh.pams_q[pi].size(); k++) gd.pam_mask[pi][k] = (uint8_t)iupac_mask((unsigned char)gh.pams_q[pi][k]);
+  }
+  return "";
+}
+
+static int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap) {
+  if (rec_cap > ctx->rec_cap) {
+    (void)hipFree(ctx->d_recs); ctx->d_recs = nullptr; ctx->rec_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_recs, (size_t)rec_cap * sizeof(ScanRecord)));
+    ctx->rec_cap = rec_cap;
+  }
+  if (raw_cap > ctx->raw_cap) {
+    (void)hipFree(ctx->d_raw); ctx->d_raw = nullptr; ctx->raw_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_raw, (size_t)raw_cap * sizeof(RawAln)));
+    ctx->raw_cap = raw_cap;
+  }
+  return CALITAS_OK;
+}
+
+int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                   calitas_aln_t** out, uint64_t* n_out) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!out || !n_out || !guides || !params) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *out = nullptr; *n_out = 0;
+  if (ctx->device < 0) return fail(ctx, CALITAS_ENODEV, "host-only context: calitas_search needs a GPU (there is no CPU fallback)");
+  if (!ctx->has_ref) return fail(ctx, CALITAS_ESTATE, "calitas_set_reference has not been called");
+  if (n_guides <= 0 || n_guides > MAX_GUIDES) return fail(ctx, CALITAS_EINVAL, "n_guides must be 1..64");
+  const calitas_params_t& p = *params;
+  if (p.window_size <= 0 || p.window_size > 60000) return fail(ctx, CALITAS_EINVAL, "window-size must be 1..60000");
+  if (p.max_guide_diffs < 0 || p.max_pam_mismatches < 0 || p.max_gaps_between_guide_and_pam < 0 || p.max_gaps_between_guide_and_pam > 16)
+    return fail(ctx, CALITAS_EINVAL, "limits out of range (max-gaps-between-guide-and-pam must be 0..16)");
+  const PackedRef& ref = ctx->ref;
+  if (p.chrom_index >= (int)ref.contigs.size()) return fail(ctx, CALITAS_EINVAL, "chrom_index out of range");
+  const Scores sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
+  const int max_total = p.max_total_diffs >= 0 ? p.max_total_diffs : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;
+
+  std::vector<GuideHost> gh(n_guides);
+  std::vector<GuideDev> gd(n_guides);
+  int step = 0;
+  for (int i = 0; i < n_guides; i++) {
+    std::string e = make_guide_host(guides[i], gh[i]);
+    if (e.empty()) e = build_guide_dev(gh[i], p, sc, gd[i]);
+    if (!e.empty()) return fail(ctx, CALITAS_EINVAL, "guide " + std::to_string(i) + ": " + e);
+    // SR:529-530: the window step depends on the CLI guide length; one pass shares one tiling
+    int overlap = gh[i].cli_length + p.max_guide_diffs + p.max_gaps_between_guide_and_pam - 1;
+    int s = p.window_size - overlap;
+    if (s <= 0) return fail(ctx, CALITAS_EINVAL, "window-size is not larger than guide length + max-guide-diffs + max-gaps - 1");
+    if (i == 0) step = s;
+    else if (s != step) return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
+    if ((gd[i].L + gd[i].scan_max_edits + 15) / 16 > ref.chunk / 16) return fail(ctx, CALITAS_EINVAL, "scan warm-up exceeds the lane chunk");
+  }
+
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, ref.total_bases / 8 + 1024));
+    int rc = ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want));
+    if (rc) return rc;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, gd.data(), sizeof(GuideDev) * n_guides, hipMemcpyHostToDevice, ctx->stream));
+
+  calitas_timing_t tm{};
+  tm.bases_scanned = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
+  tm.packed_bytes = (tm.bases_scanned + 3) / 4;
+  const uint32_t n_tiles = (uint32_t)ref.tiles.size();
+  uint32_t n_rec = 0, n_raw = 0;
+  for (;;) {
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+    ScanArgs sa{};
+    sa.codes = ctx->d_codes; sa.mask = ctx->d_mask; sa.tiles = ctx->d_tiles; sa.guides = ctx->d_guides;
+    sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap; sa.first_tile = 0;
+    sa.n_guides = n_guides; sa.chrom_index = p.chrom_index;
+    AlignArgs aa{};
+    aa.codes = ctx->d_codes; aa.mask = ctx->d_mask; aa.runs = ctx->d_runs; aa.n_runs = (int64_t)ref.runs.size();
+    aa.contigs = ctx->d_contigs; aa.tiles = ctx->d_tiles; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
+    aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
+    aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap; aa.tile_words = (uint32_t)(ref.tile / 16);
+    aa.sp.window_size = p.window_size; aa.sp.step = step; aa.sp.n_guides = n_guides;
+    aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
+    aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
+    aa.sp.max_diffs_filtering = p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;   // SGA:249
+    aa.sp.match = sc.match; aa.sp.mismatch = sc.mismatch; aa.sp.pam_match = sc.pam_match; aa.sp.pam_mismatch = sc.pam_mismatch;
+    aa.sp.query_gap = sc.query_gap; aa.sp.target_gap = sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score; aa.sp.chrom_index = p.chrom_index;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    HIP_TRY(ctx, launch_scan(sa, ref.chunk, n_tiles, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
+    if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
+    if (n_rec > ctx->rec_cap || n_raw > ctx->raw_cap) {
+      tm.retries++;
+      uint64_t nr = n_rec > ctx->rec_cap ? (uint64_t)n_rec + n_rec / 4 : ctx->rec_cap;
+      uint64_t nw = n_raw > ctx->raw_cap ? (uint64_t)n_raw * 2 : ctx->raw_cap;
+      if (n_rec > ctx->rec_cap) nw = std::max<uint64_t>(nw, nr);   // the raw count was cut short as well
+      if (nr > 0xFFFFFFF0ull || nw > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
+      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw);
+      if (rc) return rc;
+      continue;
+    }
+    break;
+  }
+  std::vector<RawAln> raw(n_raw);
+  if (n_raw) HIP_TRY(ctx, hipMemcpyAsync(raw.data(), ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); tm.scan_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); tm.align_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); tm.gpu_total_ms = ms;
+  tm.scan_records = n_rec;
+  tm.raw_alignments = n_raw;
+
+  // ---- host: restore the reference's enumeration order, then the per-window filter (SGA:315-320) ----
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<uint32_t> order(n_raw);
+  std::iota(order.begin(), order.end(), 0u);
+  auto list_of = [&](const RawAln& r) { return gh[r.guide].pam5 ? (r.dir == 1 ? 0 : 1) : (r.dir == 0 ? 0 : 1); };  // 0 = forward-strand list
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    const RawAln &a = raw[x], &b = raw[y];
+    if (a.guide != b.guide) return a.guide < b.guide;
+    if (a.contig != b.contig) return a.contig < b.contig;
+    if (a.window_k != b.window_k) return a.window_k < b.window_k;
+    int la = list_of(a), lb = list_of(b);
+    if (la != lb) return la < lb;
+    if (a.t_end_guide != b.t_end_guide) return a.t_end_guide < b.t_end_guide;   // fgbio emits ascending end column
+    return a.pam < b.pam;                                                       // then PAM order (SGA:455)
+  });
+  std::vector<calitas_aln_t> result;
+  result.reserve(n_raw / 2 + 16);
+  std::vector<calitas_aln_t> win;
+  std::vector<int> kept;
+  size_t i = 0;
+  while (i < order.size()) {
+    const RawAln& f = raw[order[i]];
+    size_t j = i;
+    while (j < order.size() && raw[order[j]].guide == f.guide && raw[order[j]].contig == f.contig && raw[order[j]].window_k == f.window_k) j++;
+    int64_t wa = 0, wb = 0;
+    window_bounds(ref.runs.data(), (int64_t)ref.runs.size(), ref.contigs[f.contig].gbase, ref.contigs[f.contig].len, p.window_size, step,
+                  f.window_k, wa, wb);
+    win.resize(j - i);
+    for (size_t k = i; k < j; k++) raw_to_aln(raw[order[k]], gh[f.guide], wa, wb, win[k - i]);
+    window_filter(win.data(), (int)win.size(), max_total, p.max_overlap, kept);
+    for (int k : kept) result.push_back(win[k]);
+    i = j;
+  }
+  tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  tm.accepted_alignments = result.size();
+  {  // candidate columns = set bits of the scan records; counted from the raw stream would miss rejected ones, so
+     // report what the aligner was asked to evaluate: unavailable on the host without copying the records back; leave
+     // the record count and let bench.py request the detailed number via CALITAS_COUNT_CANDIDATES when it wants it.
+    tm.candidate_columns = 0;
+    if (std::getenv("CALITAS_COUNT_CANDIDATES") && n_rec) {
+      std::vector<ScanRecord> recs(n_rec);
+      if (hipMemcpy(recs.data(), ctx->d_recs, (size_t)n_rec * sizeof(ScanRecord), hipMemcpyDeviceToHost) == hipSuccess)
+        for (auto& r : recs) tm.candidate_columns += (uint64_t)__builtin_popcount(r.info & 0xFFFFu);
+    }
+  }
+  ctx->timing = tm;
+
+  *n_out = result.size();
+  *out = (calitas_aln_t*)std::malloc(std::max<size_t>(1, result.size()) * sizeof(calitas_aln_t));
+  if (!*out) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  if (!result.empty()) std::memcpy(*out, result.data(), result.size() * sizeof(calitas_aln_t));
+  return CALITAS_OK;
+}
+
+int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out) {
+  if (!ctx || !out) return CALITAS_EINVAL;
+  *out = ctx->timing;
+  return CALITAS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// host-side stages
+// -------------------------------------------------------------------------------------------------------------------
+
+int calitas_window_filter(const calitas_aln_t* alns, int32_t n, int32_t max_total_diffs, int32_t max_overlap, int32_t* order,
+                          int32_t* n_kept) {
+  if (!alns || n < 0 || !order || !n_kept) return CALITAS_EINVAL;
+  // forward-strand list first, then reverse-strand list, each in the order given
+  std::vector<calitas_aln_t> v;
+  std::vector<int> src;
+  for (int s = 0; s < 2; s++)
+    for (int i = 0; i < n; i++) if ((alns[i].strand == '-') == (s == 1)) { v.push_back(alns[i]); src.push_back(i); }
+  std::vector<int> kept;
+  window_filter(v.data(), (int)v.size(), max_total_diffs, max_overlap, kept);
+  for (size_t i = 0; i < kept.size(); i++) order[i] = src[kept[i]];
+  *n_kept = (int32_t)kept.size();
+  return CALITAS_OK;
+}
+
+int calitas_hits_tsv(const calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                     const calitas_aln_t* alns, uint64_t n_alns, const char* aligner_version, const char* time_stamp, char** tsv,
+                     uint64_t* n_rows) {
+  if (!ctx || !guide || !params || !tsv || (n_alns && !alns)) return CALITAS_EINVAL;
+  calitas_ctx* c = const_cast<calitas_ctx*>(ctx);
+  if (!ctx->has_ref) return fail(c, CALITAS_ESTATE, "calitas_set_reference has not been called");
+  GuideHost gh;
+  std::string e = make_guide_host(*guide, gh);
+  if (!e.empty()) return fail(c, CALITAS_EINVAL, e);
+  std::string version = aligner_version ? aligner_version : "";
+  std::string stamp = time_stamp ? time_stamp : "";
+  if (version.empty()) {  // EditasMetric.Version without a jar manifest: unknown-YYYY-MM-DD
+    char b[32]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
+    std::strftime(b, sizeof b, "unknown-%Y-%m-%d", &tmv); version = b;
+  }
+  if (stamp.empty()) {    // RH:169-173 "EEE MMM dd HH:mm:ss z yyyy" in UTC
+    char b[64]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
+    std::strftime(b, sizeof b, "%a %b %d %H:%M:%S UTC %Y", &tmv); stamp = b;
+  }
+  std::string s = hits_tsv(ctx->ref, gh, guide_id ? guide_id : "", *params, alns, n_alns, version, stamp, n_rows);
+  *tsv = (char*)std::malloc(s.size() + 1);
+  if (!*tsv) return fail(c, CALITAS_EINVAL, "out of memory");
+  std::memcpy(*tsv, s.c_str(), s.size() + 1);
+  return CALITAS_OK;
+}
+
+int calitas_padded_strings(const calitas_ctx* ctx, const calitas_guide_t* guide, const calitas_aln_t* aln, char* padded_guide,
+                           char* padded_alignment, char* padded_target) {
+  if (!ctx || !ctx->has_ref || !guide || !aln || !padded_guide || !padded_alignment || !padded_target) return CALITAS_EINVAL;
+  GuideHost gh;
+  std::string e = make_guide_host(*guide, gh);
+  if (!e.empty()) return fail(const_cast<calitas_ctx*>(ctx), CALITAS_EINVAL, e);
+  std::string pg, pa, pt;
+  padded_strings(ctx->ref, gh, *aln, pg, pa, pt);
+  std::strcpy(padded_guide, pg.c_str()); std::strcpy(padded_alignment, pa.c_str()); std::strcpy(padded_target, pt.c_str());
+  return CALITAS_OK;
+}
+
+}  // extern "C"

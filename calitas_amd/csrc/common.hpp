@@ -1,0 +1,140 @@
+// common.hpp -- data layout shared by the host code and the HIP kernels of libcalitas_hip.
+//
+// Packed reference ("packed space"):
+//   * every contig starts at a multiple of TILE bases (TILE = 256 lanes x chunk bases, chosen at set_reference time) and
+//     is followed by at least one chunk of padding, so a scan tile never spans two contigs and a tile's halo never
+//     sees another contig's real bases;
+//   * codes[]: 2 bits per base, 16 bases per uint32, base i of a word at bits [2i, 2i+1]; A=0 C=1 G=2 T/U=3;
+//   * mask[]:  1 bit per base, 32 bases per uint32; 1 = "exception" (non-ACGT byte or padding). For an exception base
+//     the 2-bit code says what kind: 0 = can never match (N, n, padding, unknown bytes; GuideAlignmentScorer forces a
+//     mismatch for N/n, SequentialGuideAligner.scala:144), 1 = IUPAC ambiguity code other than N (the scan treats it
+//     as a wildcard, the aligner kernel looks the exact code up in runs[]);
+//   * runs[]: maximal runs of identical non-ACGT bytes, sorted by packed position, original byte kept so the
+//     windowing code can tell upper-case 'N' (trimmed, SearchReference.scala:58-59) from everything else;
+//   * tile_info[]: per scan tile the contig it belongs to and a flag (0 = plain, 1 = has exception bases in the tile
+//     or its halo, 2 = nothing but upper-case N / padding in tile and halo => no window can contain any of its bases).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#if defined(__HIPCC__)
+#define CAL_HD __host__ __device__
+#else
+#define CAL_HD
+#endif
+
+namespace calitas {
+
+constexpr int LANES_PER_TILE = 256;
+constexpr int MAX_L = 32;            // protospacer rows of the scan bit-vector
+constexpr int MAX_PAMS = 8;
+constexpr int MAX_PAM_LEN = 16;
+constexpr int MAX_GUIDES = 64;
+constexpr int STRIP_MAX_COLS = 64;   // columns of one aligner-kernel strip (16 candidate columns + span + 1)
+constexpr int RAW_MAX_OPS = 48;      // guide-part ops of one raw alignment (L + max extra genome bases)
+
+struct Run {             // exception run in packed space
+  uint64_t start;        // packed position of the first base
+  uint32_t len;
+  uint8_t ch;            // original byte ('N', 'n', 'R', ...); 0 = padding
+  uint8_t pad[3];
+};
+
+struct ContigInfo {
+  uint64_t gbase;        // packed position of base 0
+  uint64_t len;
+};
+
+struct TileInfo {
+  uint32_t contig;
+  uint32_t flag;         // see header comment
+};
+
+// IUPAC set of a byte as a 4-bit mask A=1 C=2 G=4 T=8; 0 for anything that is not an IUPAC letter.
+CAL_HD inline int iupac_mask(unsigned char b) {
+  switch (b & 0xDF) {  // ASCII upper-case fold (letters only; other bytes fall to default)
+    case 'A': return 1;  case 'C': return 2;  case 'G': return 4;  case 'T': return 8;  case 'U': return 8;
+    case 'M': return 3;  case 'R': return 5;  case 'W': return 9;  case 'S': return 6;  case 'Y': return 10;  case 'K': return 12;
+    case 'V': return 7;  case 'H': return 11; case 'D': return 13; case 'B': return 14; case 'N': return 15;
+    default: return 0;
+  }
+}
+
+// Target-side "tmask" used by the aligner kernel: bits 0-3 IUPAC set, bit 4 = pairing is forced to a mismatch
+// (target N/n, padding, unknown byte).  For N the set bits stay 15 so that '='/'X' by compatibility
+// still sees N as compatible.
+CAL_HD inline int target_mask(unsigned char b) {
+  int m = iupac_mask(b);
+  if ((b & 0xDF) == 'N') return 15 | 16;
+  if (m == 0) return 16;
+  return m;
+}
+
+// Scoring derived from the four net costs (SequentialGuideAligner.scala:192-208,213).
+struct Scores {
+  int match, mismatch, pam_match, pam_mismatch, query_gap, target_gap, worst_guide_diff;
+};
+inline int iabs(int x) { return x < 0 ? -x : x; }
+inline Scores derive_scores(int mmNet, int pamNet, int genomeGapNet, int guideGapNet) {
+  Scores s;
+  s.match = iabs(mmNet) / 2;
+  s.mismatch = -(iabs(mmNet) - s.match);
+  s.query_gap = -iabs(guideGapNet);
+  s.target_gap = -iabs(genomeGapNet) + s.match;
+  s.pam_match = iabs(pamNet) / 2;
+  s.pam_mismatch = -(iabs(pamNet) - s.pam_match);
+  int w = -iabs(mmNet);
+  if (-iabs(genomeGapNet) < w) w = -iabs(genomeGapNet);
+  if (-iabs(guideGapNet) < w) w = -iabs(guideGapNet);
+  s.worst_guide_diff = w;
+  return s;
+}
+
+// Per-guide constants uploaded to the device for one search.
+struct GuideDev {
+  uint32_t peq_a[8];      // scan, left-to-right pass: Eq vector per (exception<<2 | code), guide rows top-aligned in 32 bits
+  uint32_t peq_b[8];      // scan, right-to-left pass (target is read complemented)
+  uint8_t qmask[MAX_L];   // IUPAC set of each row of the aligner-space query (guideFw, or guideRc for a 5' PAM)
+  uint8_t pam_mask[MAX_PAMS][MAX_PAM_LEN];  // IUPAC sets of the aligner-space PAMs (pamFw or pamRc)
+  uint8_t pam_len[MAX_PAMS];
+  int32_t L;
+  int32_t n_pams;         // 0 for a PAM-less guide
+  int32_t scan_max_edits; // E: a bottom-row score >= min_guide_score implies <= E edits
+  int32_t min_guide_score;
+  int32_t span;           // L + max genome-only bases of any alignment scoring >= min_guide_score
+  int32_t cli_length;
+};
+
+struct SearchDev {        // scalar parameters of one search
+  int32_t window_size, step, n_guides;
+  int32_t max_guide_diffs, max_pam_mismatches, max_gaps, max_diffs_filtering;
+  int32_t match, mismatch, pam_match, pam_mismatch, query_gap, target_gap;
+  int32_t eqx_by_score;
+  int32_t chrom_index;
+};
+
+// One 16-base group with candidate end columns, written by the scan kernel.
+struct ScanRecord {
+  uint32_t gword;         // packed position / 16
+  uint32_t info;          // bits 0-15 candidate mask (bit k = base k of the word), bit 16 direction (0 = A, 1 = B), bits 17-23 guide
+};
+
+// One alignment after PAM extension (output of extendAndFilterRight), in aligner space.
+struct RawAln {
+  uint32_t contig;
+  uint32_t window_k;      // index k of the window (start = k * step) on its contig
+  int32_t score;
+  uint16_t t_start;       // 1-based first target column, strand space
+  uint16_t t_end_guide;   // 1-based last target column of the guide part
+  uint8_t dir;            // 0 = A (target as is), 1 = B (reverse-complemented target)
+  uint8_t guide;
+  int8_t pam;             // PAM index or -1
+  uint8_t offset;         // genome bases skipped between guide and PAM
+  uint8_t n_ops;          // guide-part ops
+  uint8_t pad;
+  uint16_t pam_x;         // bit i set = PAM position i is 'X'
+  uint8_t ops[RAW_MAX_OPS / 4];  // 2 bits per op in traceback (reverse) order: 0 '=', 1 'X', 2 'I', 3 'D'
+};
+
+}  // namespace calitas

@@ -1,0 +1,430 @@
+// kernels.hip -- the two hand-written gfx950 kernels of the SearchReference hot path.
+//
+//  scan_kernel   exact filter for "bottom-row glocal score >= minGuideScore" (the enumeration rule of
+//                fgbio Aligner.align(query, target, minScore), SequentialGuideAligner.scala:261,278,295,299).
+//                With the reference's linear gap costs a bottom-row score >= minGuideScore implies at most E edits
+//                (SearchReference.scala:432-441), so the filter is Myers' bit-vector edit distance: one 32-bit
+//                column vector per lane, the protospacer rows top-aligned so the row-L delta falls out of the
+//                shift as a carry.  Every lane owns CHUNK consecutive bases of a 256-lane tile that the workgroup
+//                streams from HBM into LDS with coalesced 16-byte loads; it runs the tile once left-to-right
+//                (target as is) and once right-to-left (reverse-complemented target) with 32 warm-up columns.
+//                Integer VALU work; no MFMA.  Emits one record per 16-base word that holds a candidate column.
+//  align_kernel  the glocal DP itself on the strips the scan flagged: three score matrices (Diag/Left/Up) with
+//                fgbio's tie rules, antidiagonal wavefront with one lane per query row, neighbours exchanged with
+//                DPP wave shifts, trace matrix staged in LDS, then traceback, '='/'X' ops, and the PAM extension
+//                of extendAndFilterRight (SequentialGuideAligner.scala:433-492), one lane per candidate column.
+//                Only columns [j - span - 1, j] are filled: by the locality argument in DESIGN.md this reproduces
+//                the value and the trace of every cell on the optimal path of a candidate (L, j) bit for bit.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "refpack.hpp"
+#include "kernels.hpp"
+
+namespace calitas {
+
+// ------------------------------------------------------------------------------------------------------------------
+// scan_kernel
+// ------------------------------------------------------------------------------------------------------------------
+
+// One column of Myers' bit-vector algorithm (search variant: free start in the text, so no carry into row 1).
+// Guide rows occupy the top L bits; the padding bits below keep Pv=1, Mv=0 as long as eq has them clear.
+__device__ __forceinline__ void myers_step(uint32_t eq, uint32_t& pv, uint32_t& mv, int& score) {
+  uint32_t xv = eq | mv;
+  uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+  uint32_t ph = mv | ~(xh | pv);
+  uint32_t mh = pv & xh;
+  score += (int)(ph >> 31);
+  score -= (int)(mh >> 31);
+  ph <<= 1;
+  mh <<= 1;
+  pv = mh | ~(xv | ph);
+  mv = ph & xv;
+}
+
+template <int CHUNK>
+__global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
+  constexpr int WPC = CHUNK / 16;           // code words per lane chunk
+  constexpr int MPC = CHUNK / 32;           // mask words per lane chunk
+  constexpr int CSTR = WPC + 1;             // padded strides: lane l reads word l*CSTR + k -> conflict-free banks
+  constexpr int MSTR = MPC + 1;
+  constexpr int NV = LANES_PER_TILE + 2;    // virtual chunks: left halo, 256 lanes, right halo
+  __shared__ uint32_t s_codes[NV * CSTR];
+  __shared__ uint32_t s_mask[NV * MSTR];
+  __shared__ uint32_t s_eq[MAX_GUIDES * 16];
+
+  const uint32_t tile = a.first_tile + blockIdx.x;
+  const TileInfo ti = a.tiles[tile];
+  if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
+  if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;
+  const bool masked = ti.flag != 0u;
+  const int tid = threadIdx.x;
+
+  // ---- stream the tile (+ one halo chunk each side) into LDS: 16-byte coalesced loads, padded scatter ----
+  const uint64_t w0 = (uint64_t)tile * (LANES_PER_TILE * WPC);  // first code word of the tile
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.codes + (w0 - WPC));
+    constexpr int NQ = NV * WPC / 4;
+    for (int q = tid; q < NQ; q += LANES_PER_TILE) {
+      uint4 v = src[q];
+      int i = q * 4;
+      int vc = i / WPC, k = i % WPC;  // WPC is a multiple of 4, so the four words stay in one chunk
+      uint32_t* d = &s_codes[vc * CSTR + k];
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  if (masked) {
+    const uint32_t* src = a.mask + (w0 / 2 - MPC);
+    constexpr int NM = NV * MPC;
+    for (int i = tid; i < NM; i += LANES_PER_TILE) s_mask[(i / MPC) * MSTR + (i % MPC)] = src[i];
+  }
+  for (int i = tid; i < a.n_guides * 16; i += LANES_PER_TILE) {
+    const GuideDev& g = a.guides[i >> 4];
+    s_eq[i] = (i & 8) ? g.peq_b[i & 7] : g.peq_a[i & 7];
+  }
+  __syncthreads();
+
+  const int vc = tid + 1;
+  const uint32_t* cw = &s_codes[vc * CSTR];
+  const uint32_t* mw = &s_mask[vc * MSTR];
+  const uint32_t gword0 = (uint32_t)(w0 + (uint64_t)tid * WPC);
+
+  for (int gi = 0; gi < a.n_guides; gi++) {
+    const GuideDev& g = a.guides[gi];
+    const int L = g.L, E = g.scan_max_edits;
+    const int warm = (L + E + 15) >> 4;  // warm-up words (host guarantees warm <= WPC)
+    const uint32_t* eqA = &s_eq[gi * 16];
+    const uint32_t* eqB = eqA + 8;
+
+    // ---- pass A: left to right, target as is ----
+    {
+      uint32_t pv = 0xFFFFFFFFu, mv = 0u;
+      int score = L;
+      for (int w = -warm; w < WPC; w++) {
+        // w < 0 reads the tail of the left neighbour's chunk: cw[w - 1] skips the pad word
+        const uint32_t word = (w >= 0) ? cw[w] : cw[w - 1];
+        uint32_t mbits = 0;
+        if (masked) {
+          int mwi = (w >= 0) ? (w >> 1) : ((w >> 1) - 1);
+          mbits = (mw[mwi] >> ((w & 1) * 16)) & 0xFFFFu;
+        }
+        uint32_t hm = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          uint32_t idx = ((word >> (2 * k)) & 3u) | (((mbits >> k) & 1u) << 2);
+          myers_step(eqA[idx], pv, mv, score);
+          hm = (hm << 1) | (uint32_t)(score <= E);
+        }
+        if (w >= 0 && hm != 0) {
+          uint32_t slot = atomicAdd(a.rec_count, 1u);
+          if (slot < a.rec_capacity) {
+            ScanRecord r;
+            r.gword = gword0 + (uint32_t)w;
+            r.info = (__brev(hm) >> 16) | ((uint32_t)gi << 17);
+            a.recs[slot] = r;
+          }
+        }
+      }
+    }
+    // ---- pass B: right to left, target complemented (= left to right over the reverse complement) ----
+    {
+      uint32_t pv = 0xFFFFFFFFu, mv = 0u;
+      int score = L;
+      for (int w = WPC - 1 + warm; w >= 0; w--) {
+        // w >= WPC reads the head of the right neighbour's chunk: skip the pad word
+        const uint32_t word = (w < WPC) ? cw[w] : cw[w + 1];
+        uint32_t mbits = 0;
+        if (masked) {
+          int mwi = (w < WPC) ? (w >> 1) : ((w >> 1) + 1);
+          mbits = (mw[mwi] >> ((w & 1) * 16)) & 0xFFFFu;
+        }
+        uint32_t hm = 0;
+#pragma unroll
+        for (int k = 15; k >= 0; k--) {
+          uint32_t idx = ((word >> (2 * k)) & 3u) | (((mbits >> k) & 1u) << 2);
+          myers_step(eqB[idx], pv, mv, score);
+          hm = (hm << 1) | (uint32_t)(score <= E);
+        }
+        if (w < WPC && hm != 0) {
+          uint32_t slot = atomicAdd(a.rec_count, 1u);
+          if (slot < a.rec_capacity) {
+            ScanRecord r;
+            r.gword = gword0 + (uint32_t)w;
+            r.info = hm | (1u << 16) | ((uint32_t)gi << 17);
+            a.recs[slot] = r;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// align_kernel
+// ------------------------------------------------------------------------------------------------------------------
+
+constexpr int TR_UP = 0, TR_LEFT = 1, TR_DIAG = 2;   // ordered so that max() of (score*4 + code) breaks ties Diag > Left > Up
+constexpr int NEG = -(1 << 20);                      // "minus infinity" that survives a few hundred additions
+constexpr int JOBS_PER_BLOCK = 8;                    // one job per 32-lane half wave
+constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
+
+__device__ __forceinline__ int shift_up_lane(int v) {
+  // value of lane-1 (DPP wave shift right by one); lane 0 keeps its own value, which callers ignore
+  return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int comp_mask4(int m) {  // IUPAC set of the complementary base(s)
+  return ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3);
+}
+
+// target_mask() of the base at contig offset pos (dir 0) or of its complement (dir 1)
+__device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
+  uint32_t code = (a.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u;
+  uint32_t exc = (a.mask[gpos >> 5] >> (gpos & 31)) & 1u;
+  int m;
+  if (!exc) {
+    m = 1 << code;
+  } else {
+    int64_t r = run_floor(a.runs, a.n_runs, gpos);
+    uint8_t ch = 0;
+    if (r >= 0 && gpos < a.runs[r].start + a.runs[r].len) ch = a.runs[r].ch;
+    m = target_mask(ch);
+  }
+  if (dir) m = (m & 16) | comp_mask4(m & 15);
+  return m;
+}
+
+__global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
+  __shared__ uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][STRIP_MAX_COLS + 1];
+  __shared__ uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
+  __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
+
+  const int job = threadIdx.x >> 5;
+  const int r = threadIdx.x & 31;           // lane within the job = query row r+1
+  uint8_t (*tr)[STRIP_MAX_COLS + 1] = s_tr[job];
+  uint8_t* tb = s_tb[job];
+  int* fin = s_fin[job];
+
+  uint32_t n_recs = *a.rec_count;
+  if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
+  const uint32_t total_jobs = gridDim.x * JOBS_PER_BLOCK;
+  const SearchDev& sp = a.sp;
+  const int W = sp.window_size, step = sp.step;
+
+  for (uint32_t ri = blockIdx.x * JOBS_PER_BLOCK + job; ri < n_recs; ri += total_jobs) {
+    const ScanRecord rec = a.recs[ri];
+    const uint32_t cmask = rec.info & 0xFFFFu;
+    const int dir = (rec.info >> 16) & 1;
+    const int gi = (rec.info >> 17) & 0x7F;
+    const GuideDev& g = a.guides[gi];
+    const int L = g.L, span = g.span;
+    const uint32_t tile = rec.gword / a.tile_words;
+    const uint32_t contig = a.tiles[tile].contig;
+    const uint64_t gbase = a.contigs[contig].gbase, clen = a.contigs[contig].len;
+    const int64_t p0 = (int64_t)((uint64_t)rec.gword * 16 - gbase);   // contig offset of bit 0
+    const int first = __ffs(cmask) - 1, last = 31 - __clz(cmask);
+    const int64_t plo = p0 + first, phi = p0 + last;
+    if ((uint64_t)plo >= clen) continue;  // only padding columns: they belong to no window
+    int64_t klo = (plo - W + 1 + step - 1) / step;  // ceil((plo - W + 1) / step) for positive numerator
+    if (plo - W + 1 <= 0) klo = 0;
+    int64_t khi = phi / step;
+    const int qm = (r < L) ? g.qmask[r] : 0;
+
+    for (int64_t k = klo; k <= khi; k++) {
+      int64_t wa, wb;
+      if (!window_bounds(a.runs, a.n_runs, gbase, clen, W, step, (uint64_t)k, wa, wb)) continue;
+      const int n = (int)(wb - wa);
+      if (n < g.cli_length) continue;                         // SearchReference.scala:536
+      // candidate columns of this word that fall inside the window, as strand-space columns
+      uint32_t sel = 0;
+      for (int b = first; b <= last; b++) if ((cmask >> b) & 1u) { int64_t p = p0 + b; if (p >= wa && p < wb) sel |= 1u << b; }
+      if (!sel) continue;
+      const int sfirst = __ffs(sel) - 1, slast = 31 - __clz(sel);
+      int jmin, jmax;
+      if (dir == 0) { jmin = (int)(p0 + sfirst - wa) + 1; jmax = (int)(p0 + slast - wa) + 1; }
+      else          { jmin = (int)(wb - (p0 + slast));    jmax = (int)(wb - (p0 + sfirst)); }
+      int c0 = jmin - span - 1;
+      if (c0 < 0) c0 = 0;
+      const bool true_border = (c0 == 0);
+      const int ncols = jmax - c0;                            // <= 16 + span + 1 <= STRIP_MAX_COLS (host-checked)
+      int look = jmax + sp.max_gaps + MAX_PAM_LEN;            // PAM look-ahead, clipped to the window
+      if (look > n) look = n;
+      const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
+
+      // ---- stage target masks ----
+      for (int x = r; x < ntb; x += 32) {
+        int col = c0 + 1 + x;                                 // 1-based strand-space column
+        int64_t pos = dir ? (wb - col) : (wa + col - 1);
+        tb[x] = (uint8_t)fetch_tmask(a, gbase + (uint64_t)pos, dir);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // ---- fill: antidiagonal wavefront, lane r = row r+1 ----
+      const int i_row = r + 1;
+      int curD = NEG, curL = NEG, curU = true_border ? i_row * sp.target_gap : NEG;
+      int curP = max(max(curD * 4 + TR_DIAG, curL * 4 + TR_LEFT), curU * 4 + TR_UP);
+      int inP = shift_up_lane(curP), inPprev;
+      const int nsteps = ncols + L - 1;
+      for (int t = 1; t <= nsteps; t++) {
+        inPprev = inP;
+        inP = shift_up_lane(curP);
+        int inD = shift_up_lane(curD);
+        int inU = shift_up_lane(curU);
+        if (r == 0) { inPprev = TR_DIAG; inD = 0; inU = 0; }  // row 0: score 0 in all three matrices, ties -> Diag
+        const int c = t - r;                                  // strip column 1..ncols
+        if (c >= 1 && c <= ncols && r < L) {
+          const int tm = tb[c - 1];
+          const bool match = ((qm & tm & 15) != 0) && !(tm & 16);
+          const int add = match ? sp.match : sp.mismatch;
+          const int newD = (inPprev >> 2) + add;
+          const int dtr = inPprev & 3;
+          const int newU = max(inD, inU) + sp.target_gap;
+          const int utr = (inD >= inU) ? 0 : 1;
+          const int newL = max(curD, curL) + sp.query_gap;
+          const int ltr = (curD >= curL) ? 0 : 1;
+          tr[r][c] = (uint8_t)(dtr | (utr << 2) | (ltr << 3));
+          curD = newD; curL = newL; curU = newU;
+          curP = max(max(newD * 4 + TR_DIAG, newL * 4 + TR_LEFT), newU * 4 + TR_UP);
+          if (r == L - 1) fin[c] = curP;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // ---- one lane per candidate column: threshold, traceback, PAM extension, emit ----
+      // lane x takes the x-th selected bit in ascending strand-space column order
+      int myb = -1;
+      {
+        int cnt = 0;
+        if (dir == 0) { for (int b = sfirst; b <= slast; b++) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
+        else          { for (int b = slast; b >= sfirst; b--) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
+      }
+      if (myb >= 0) {
+        const int j = dir ? (int)(wb - (p0 + myb)) : (int)(p0 + myb - wa) + 1;   // strand-space end column
+        const int P = fin[j - c0];
+        const int gscore = P >> 2;
+        if (gscore >= g.min_guide_score) {
+          int m = P & 3, i = L, c = j - c0;
+          uint32_t ops[RAW_MAX_OPS / 16] = {0, 0, 0};
+          int nops = 0, diffs = 0;
+          bool ok = true;
+          while (i > 0) {
+            if (nops >= RAW_MAX_OPS) { ok = false; break; }
+            int op;
+            if (c == 0) {
+              // true left border: only the Up matrix is finite there (leading insertions)
+              if (!true_border || m != TR_UP) { ok = false; break; }
+              op = 2; i--;                                   // 'I'; Up(i,0) traces to Up, Up(1,0) to Diag(0,0)
+            } else {
+              const int t8 = tr[i - 1][c];
+              if (m == TR_DIAG) {
+                const int tm = tb[c - 1], q = g.qmask[i - 1];
+                const bool compat = (q & tm & 15) != 0;
+                const bool eq = sp.eqx_by_score ? (compat && !(tm & 16)) : compat;
+                op = eq ? 0 : 1;
+                m = t8 & 3; i--; c--;
+              } else if (m == TR_UP) {
+                op = 2; m = ((t8 >> 2) & 1) ? TR_UP : TR_DIAG; i--;
+              } else {
+                op = 3; m = ((t8 >> 3) & 1) ? TR_LEFT : TR_DIAG; c--;
+              }
+            }
+            if (op != 0) diffs++;
+            ops[nops >> 4] |= (uint32_t)op << ((nops & 15) * 2);
+            nops++;
+          }
+          if (!ok) {
+            atomicAdd(a.anomalies, 1u);
+          } else if (diffs <= sp.max_guide_diffs) {
+            const int t_start = c0 + c + 1;
+            RawAln o;
+            o.contig = contig; o.window_k = (uint32_t)k; o.t_start = (uint16_t)t_start; o.t_end_guide = (uint16_t)j;
+            o.dir = (uint8_t)dir; o.guide = (uint8_t)gi; o.n_ops = (uint8_t)nops; o.pad = 0;
+            o.ops[0] = 0;
+            uint32_t* ow = reinterpret_cast<uint32_t*>(o.ops);
+            ow[0] = ops[0]; ow[1] = ops[1]; ow[2] = ops[2];
+            if (g.n_pams == 0) {
+              o.score = gscore; o.pam = -1; o.offset = 0; o.pam_x = 0;
+              uint32_t slot = atomicAdd(a.out_count, 1u);
+              if (slot < a.out_capacity) a.out[slot] = o;
+            } else {
+              // terminal indel run = first ops of the traceback
+              int term = 0;
+              {
+                int op0 = ops[0] & 3;
+                if (op0 >= 2) { term = 1; while (term < nops && (int)((ops[term >> 4] >> ((term & 15) * 2)) & 3) == op0) term++; }
+              }
+              int max_extra = sp.max_gaps - term;
+              if (sp.max_diffs_filtering - diffs < max_extra) max_extra = sp.max_diffs_filtering - diffs;
+              for (int pi = 0; pi < g.n_pams; pi++) {
+                const int plen = g.pam_len[pi];
+                bool have = false; int best_score = 0, best_off = 0; uint32_t best_x = 0;
+                for (int off = 0; off <= max_extra; off++) {
+                  const int toff = j + off;                   // 0-based strand-space offset of the first PAM base
+                  int limit = sp.max_pam_mismatches;
+                  if (sp.max_diffs_filtering - diffs - off < limit) limit = sp.max_diffs_filtering - diffs - off;
+                  if (toff + plen > n || limit < 0) continue;
+                  int sc = 0, nx = 0; uint32_t xm = 0;
+                  for (int q = 0; q < plen; q++) {
+                    const int tm = tb[toff + q - c0];
+                    const bool match = ((g.pam_mask[pi][q] & tm & 15) != 0) && !(tm & 16);
+                    const int addend = match ? sp.pam_match : sp.pam_mismatch;
+                    sc += addend;
+                    if (!(addend > 0)) { nx++; xm |= 1u << q; }
+                  }
+                  if (nx > limit) continue;
+                  const int total = gscore + sc + off * sp.query_gap;
+                  if (!have || total > best_score) { have = true; best_score = total; best_off = off; best_x = xm; }
+                }
+                if (have) {
+                  o.score = best_score; o.pam = (int8_t)pi; o.offset = (uint8_t)best_off; o.pam_x = (uint16_t)best_x;
+                  uint32_t slot = atomicAdd(a.out_count, 1u);
+                  if (slot < a.out_capacity) a.out[slot] = o;
+                }
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// Self-test of the cross-lane primitive the fill relies on: out[i] = value held by lane i-1.
+__global__ void dpp_selftest_kernel(int* out) {
+  int v = (int)threadIdx.x * 7 + 3;
+  out[threadIdx.x] = shift_up_lane(v);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------
+
+hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream) {
+  dim3 grid(n_tiles), block(LANES_PER_TILE);
+  switch (chunk) {
+    case 64:  hipLaunchKernelGGL(scan_kernel<64>, grid, block, 0, stream, a); break;
+    case 128: hipLaunchKernelGGL(scan_kernel<128>, grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL(scan_kernel<256>, grid, block, 0, stream, a); break;
+    case 512: hipLaunchKernelGGL(scan_kernel<512>, grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(align_kernel, dim3(n_blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_dpp_selftest(int* out, hipStream_t stream) {
+  hipLaunchKernelGGL(dpp_selftest_kernel, dim3(1), dim3(64), 0, stream, out);
+  return hipGetLastError();
+}
+
+}  // namespace calitas

@@ -1,0 +1,45 @@
+// kernels.hpp -- launch interface of kernels.hip (device pointers only).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "common.hpp"
+
+namespace calitas {
+
+struct ScanArgs {
+  const uint32_t* codes;
+  const uint32_t* mask;
+  const TileInfo* tiles;
+  const GuideDev* guides;
+  ScanRecord* recs;
+  uint32_t* rec_count;
+  uint32_t rec_capacity;
+  uint32_t first_tile;
+  int32_t n_guides;
+  int32_t chrom_index;
+};
+
+struct AlignArgs {
+  const uint32_t* codes;
+  const uint32_t* mask;
+  const Run* runs;
+  int64_t n_runs;
+  const ContigInfo* contigs;
+  const TileInfo* tiles;
+  const GuideDev* guides;
+  const ScanRecord* recs;
+  const uint32_t* rec_count;
+  RawAln* out;
+  uint32_t* out_count;
+  uint32_t* anomalies;
+  uint32_t rec_capacity;
+  uint32_t out_capacity;
+  uint32_t tile_words;     // code words per scan tile
+  SearchDev sp;
+};
+
+hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream);
+hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_dpp_selftest(int* out, hipStream_t stream);
+
+}  // namespace calitas

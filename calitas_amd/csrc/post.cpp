@@ -1,0 +1,330 @@
+// post.cpp -- host-side stages of the product path (see post.hpp).  Reference citations: SGA = SequentialGuideAligner.scala,
+// GA = GuideAlignment.scala, RH = ReferenceHit.scala, SR = SearchReference.scala.
+#include "post.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <map>
+
+namespace calitas {
+
+char complement_base(char c) {  // fgbio Sequences.complement: IUPAC aware, case preserving (SGA:532)
+  static const char* from = "ACGTUMKRYVBHDWSN";
+  static const char* to   = "TGCAAKMYRBVDHWSN";
+  char u = (char)std::toupper((unsigned char)c);
+  const char* p = std::strchr(from, u);
+  if (!p || u == 0) return c;
+  char r = to[p - from];
+  return std::islower((unsigned char)c) ? (char)std::tolower((unsigned char)r) : r;
+}
+
+std::string revcomp_str(const std::string& s) {
+  std::string o(s.rbegin(), s.rend());
+  for (auto& c : o) c = complement_base(c);
+  return o;
+}
+
+std::string GuideHost::query_for(int pam_index) const {
+  if (pam_index < 0 || pams.empty()) return protospacer;
+  return pam5 ? pams[pam_index] + protospacer : protospacer + pams[pam_index];
+}
+
+std::string make_guide_host(const calitas_guide_t& g, GuideHost& out) {
+  if (!g.protospacer || !*g.protospacer) return "guide has no protospacer";
+  out = GuideHost();
+  out.protospacer = g.protospacer;
+  for (auto& c : out.protospacer) c = (char)std::toupper((unsigned char)c);  // SGA:64
+  if ((int)out.protospacer.size() > CALITAS_MAX_PROTOSPACER) return "protospacer longer than 32 nt is not supported by the scan kernel";
+  for (char c : out.protospacer) if (iupac_mask((unsigned char)c) == 0) return std::string("protospacer has a non-IUPAC character: ") + c;
+  if (g.n_pams < 0 || g.n_pams > CALITAS_MAX_PAMS) return "too many PAMs";
+  for (int i = 0; i < g.n_pams; i++) {
+    std::string p = g.pams[i] ? g.pams[i] : "";
+    for (auto& c : p) c = (char)std::tolower((unsigned char)c);          // SGA:65-66
+    if (p.size() > CALITAS_MAX_PAM_LEN) return "PAM longer than 16 nt is not supported";
+    for (char c : p) if (iupac_mask((unsigned char)c) == 0) return std::string("PAM has a non-IUPAC character: ") + c;
+    out.pams.push_back(p);
+  }
+  // SGA:446 treats a single empty PAM as "no PAM"
+  if (out.pams.size() == 1 && out.pams[0].empty()) out.pams.clear();
+  for (auto& p : out.pams) if (p.empty()) return "empty PAM among several PAMs is not supported";
+  out.pam5 = g.pam_is_5prime != 0 && !out.pams.empty();
+  out.cli_length = g.cli_length > 0 ? g.cli_length : (int)(out.protospacer.size() + (out.pams.empty() ? 0 : out.pams[0].size()));
+  out.q = out.pam5 ? revcomp_str(out.protospacer) : out.protospacer;
+  for (auto& p : out.pams) out.pams_q.push_back(out.pam5 ? revcomp_str(p) : p);
+  return "";
+}
+
+static inline bool consumes_target(uint8_t op) { return op == '=' || op == 'X' || op == 'D'; }
+static inline bool consumes_query(uint8_t op) { return op == '=' || op == 'X' || op == 'I'; }
+
+void raw_to_aln(const RawAln& r, const GuideHost& g, int64_t win_a, int64_t win_b, calitas_aln_t& out) {
+  static const char OPC[4] = {'=', 'X', 'I', 'D'};
+  // aligner-space ops: guide part (stored in traceback order), then the gap to the PAM, then the PAM (SGA:472-476)
+  uint8_t ops[CALITAS_MAX_OPS];
+  int n = 0;
+  for (int i = r.n_ops - 1; i >= 0; i--) ops[n++] = (uint8_t)OPC[(r.ops[i >> 2] >> ((i & 3) * 2)) & 3];
+  const int n_guide_ops = n;
+  int pam_len = 0;
+  if (r.pam >= 0) {
+    pam_len = (int)g.pams_q[r.pam].size();
+    for (int i = 0; i < r.offset; i++) ops[n++] = 'D';
+    for (int i = 0; i < pam_len; i++) ops[n++] = ((r.pam_x >> i) & 1) ? 'X' : '=';
+  }
+  // GuideAlignment.apply (GA:21-31), always evaluated with the '+' rule in aligner space (SGA:264,281,297,302):
+  // target letters left of the first / right of the last protospacer column.
+  int first_q = -1, last_q = -1;
+  for (int i = 0; i < n_guide_ops; i++) if (consumes_query(ops[i])) { if (first_q < 0) first_q = i; last_q = i; }
+  int left_delta = 0, right_delta = 0;
+  for (int i = 0; i < first_q; i++) if (consumes_target(ops[i])) left_delta++;
+  for (int i = last_q + 1; i < n; i++) if (consumes_target(ops[i])) right_delta++;
+  const int64_t start_s = (int64_t)r.t_start - 1;                        // SGA:515
+  const int64_t end_s = (int64_t)r.t_end_guide + r.offset + pam_len;     // SGA:516 (targetEnd is inclusive)
+  const int64_t gstart_s = start_s + left_delta, gend_s = end_s - right_delta;
+  const int64_t wn = win_b - win_a;
+
+  std::memset(&out, 0, sizeof(out));
+  out.guide_index = r.guide;
+  out.contig_index = (int32_t)r.contig;
+  out.window_start = (int32_t)win_a;
+  out.score = r.score;
+  out.pam_index = (int8_t)r.pam;
+  out.n_ops = (int16_t)n;
+  if (r.dir == 0) {   // target as is: SGA:297 (3' PAM, '+') and SGA:281 (5' PAM, '-')
+    out.start_offset = (int32_t)(win_a + start_s);  out.end_offset = (int32_t)(win_a + end_s);
+    out.guide_start_offset = (int32_t)(win_a + gstart_s);  out.guide_end_offset = (int32_t)(win_a + gend_s);
+  } else {            // reverse-complemented target: SGA:303-309 (3' PAM, '-') and SGA:271-274 (5' PAM, '+')
+    out.start_offset = (int32_t)(win_a + wn - end_s);  out.end_offset = (int32_t)(win_a + wn - start_s);
+    out.guide_start_offset = (int32_t)(win_a + wn - gend_s);  out.guide_end_offset = (int32_t)(win_a + wn - gstart_s);
+  }
+  const bool plus = g.pam5 ? (r.dir == 1) : (r.dir == 0);
+  out.strand = plus ? '+' : '-';
+  if (g.pam5) for (int i = 0; i < n; i++) out.ops[i] = ops[n - 1 - i];   // cigar.reverse / paddedAlignment.reverse SGA:267-269
+  else std::memcpy(out.ops, ops, n);
+}
+
+static inline int aln_edits(const calitas_aln_t& a) { int e = 0; for (int i = 0; i < a.n_ops; i++) if (a.ops[i] != '=') e++; return e; }      // GA:101
+static inline int aln_gap_bases(const calitas_aln_t& a) { int e = 0; for (int i = 0; i < a.n_ops; i++) if (a.ops[i] == 'I' || a.ops[i] == 'D') e++; return e; }  // GA:100
+
+void window_filter(const calitas_aln_t* alns, int n, int max_total_diffs, int max_overlap, std::vector<int>& kept) {
+  kept.clear();
+  // The caller passes the forward-strand list followed by the reverse-strand list (SGA:316); each is sorted on its own.
+  std::vector<int> idx[2];
+  std::vector<int> gaps(n);
+  for (int i = 0; i < n; i++) { gaps[i] = aln_gap_bases(alns[i]); idx[alns[i].strand == '-' ? 1 : 0].push_back(i); }
+  for (int s = 0; s < 2; s++) {
+    std::stable_sort(idx[s].begin(), idx[s].end(), [&](int x, int y) {   // GA:125-129
+      if (alns[x].score != alns[y].score) return alns[x].score > alns[y].score;
+      return gaps[x] < gaps[y];
+    });
+    for (int i : idx[s]) {
+      const calitas_aln_t& a = alns[i];
+      if (aln_edits(a) > max_total_diffs) continue;
+      bool clash = false;
+      for (int k : kept) {
+        const calitas_aln_t& b = alns[k];
+        if (b.strand != a.strand || b.contig_index != a.contig_index) continue;
+        int o = std::min(a.end_offset, b.end_offset) - std::max(a.start_offset, b.start_offset);   // GA:119-122
+        if (o > max_overlap) { clash = true; break; }
+      }
+      if (!clash) kept.push_back(i);
+    }
+  }
+}
+
+// Upper-cased target bases [start, end) in guide orientation: as is for '+', reverse complement for '-'.
+static std::string target_bases(const PackedRef& ref, int contig, int64_t start, int64_t end, bool minus) {
+  std::string s;
+  const ContigInfo& c = ref.contigs[contig];
+  for (int64_t p = start; p < end; p++) s += (p >= 0 && (uint64_t)p < c.len) ? ref.base_upper(c.gbase + (uint64_t)p) : 'N';
+  return minus ? revcomp_str(s) : s;
+}
+
+void padded_strings(const PackedRef& ref, const GuideHost& g, const calitas_aln_t& a, std::string& pg, std::string& pa, std::string& pt) {
+  const std::string q = g.query_for(a.pam_index);
+  const std::string t = target_bases(ref, a.contig_index, a.start_offset, a.end_offset, a.strand == '-');
+  pg.clear(); pa.clear(); pt.clear();
+  size_t qi = 0, ti = 0;
+  for (int i = 0; i < a.n_ops; i++) {
+    switch (a.ops[i]) {
+      case 'I': pg += q[qi++]; pa += '~'; pt += '-'; break;
+      case 'D': pg += '-'; pa += '~'; pt += t[ti++]; break;
+      case '=': pg += q[qi++]; pa += '|'; pt += t[ti++]; break;
+      default:  pg += q[qi++]; pa += '.'; pt += t[ti++]; break;
+    }
+  }
+}
+
+namespace {
+
+// GuideAlignment.count (GA:139-163) on padded strings.
+int ga_count(const std::string& pg, const std::string& pa, bool lower, bool bothSides, bool mms, bool gaps) {
+  auto is_lower = [](char c) { return c >= 'a' && c <= 'z'; };
+  auto is_letter = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+  const int len = (int)pa.size();
+  int n = 0;
+  for (int i = 0; i < len; i++) {
+    if (mms && pa[i] == '.' && is_lower(pg[i]) == lower) { n++; continue; }
+    if (!(gaps && pa[i] == '~')) continue;
+    const char gb = pg[i];
+    bool me = gb != '-' && is_lower(gb) == lower;
+    if (!me) {
+      int pi = i; while (pi > 0 && pg[pi] == '-') pi--;            // previousNonDash GA:168-172
+      int ni = i; while (ni < len - 1 && pg[ni] == '-') ni++;      // nextNonDash GA:177-182
+      const char prev = pg[pi], next = pg[ni];
+      if (bothSides) me = (prev == '-' || is_lower(prev) == lower) && (next == '-' || is_lower(next) == lower);
+      else me = (is_letter(prev) && is_lower(prev) == lower) || (is_letter(next) && is_lower(next) == lower);
+    }
+    if (me) n++;
+  }
+  return n;
+}
+
+std::string cigar_of(const calitas_aln_t& a) {  // Cigar.coalesce + toString
+  std::string s;
+  int i = 0;
+  while (i < a.n_ops) {
+    int j = i;
+    while (j < a.n_ops && a.ops[j] == a.ops[i]) j++;
+    s += std::to_string(j - i);
+    s += (char)a.ops[i];
+    i = j;
+  }
+  return s;
+}
+
+// fetchBases RH:261-266: 1-based inclusive [start, end], N padded, upper case, strand aware
+std::string fetch_flank(const PackedRef& ref, int contig, int64_t start1, int64_t end1, bool minus) {
+  return target_bases(ref, contig, start1 - 1, end1, minus);
+}
+
+struct Lite {          // what removeOverlaps and the sort look at
+  int contig; int start; int end; char strand; int score; uint64_t idx;
+};
+
+std::string core_parameters(const calitas_params_t& p, int max_total) {  // SR:496-508
+  std::vector<std::string> kv = {
+    "max-variants=" + std::to_string(p.max_variants), "window-size=" + std::to_string(p.window_size),
+    "max-guide-diffs=" + std::to_string(p.max_guide_diffs), "max-pam-mismatches=" + std::to_string(p.max_pam_mismatches),
+    "max-gaps-between-guide-and-pam=" + std::to_string(p.max_gaps_between_guide_and_pam),
+    "max-total-diffs=" + std::to_string(max_total), "max-overlap=" + std::to_string(p.max_overlap),
+    "guide-mismatch-net-cost=" + std::to_string(p.guide_mismatch_net_cost),
+    "pam-mismatch-net-cost=" + std::to_string(p.pam_mismatch_net_cost),
+    "genome-gap-net-cost=" + std::to_string(p.genome_gap_net_cost), "guide-gap-net-cost=" + std::to_string(p.guide_gap_net_cost)};
+  std::sort(kv.begin(), kv.end());
+  std::string s;
+  for (size_t i = 0; i < kv.size(); i++) { if (i) s += ';'; s += kv[i]; }
+  return s;
+}
+
+const char* const kColumns[34] = {
+  "guide_id", "unpadded_guide_sequence", "genome_build", "chromosome", "coordinate_start", "coordinate_end", "strand",
+  "unpadded_target_sequence", "ten_bases_5_prime", "ten_bases_3_prime", "pam_used", "variant_id", "variant_description",
+  "variant_vcf", "allele_frequency", "score", "guide_mm", "guide_gaps", "guide_mm_plus_gaps", "pam_mm", "total_mm_plus_gaps",
+  "padded_guide", "padded_alignment", "padded_target", "padded_extra_8_bases_5_prime", "padded_extra_8_bases_3_prime", "cigar",
+  "unpadded_guide_sequence_length", "unpadded_target_sequence_length", "aligner", "aligner_version", "aligner_search_pam",
+  "aligner_other_parameters", "time_stamp"};
+
+}  // namespace
+
+std::string hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
+                     const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
+                     uint64_t* n_rows) {
+  const int max_total = p.max_total_diffs >= 0 ? p.max_total_diffs
+                                               : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;  // SR:493
+  // ---- removeOverlaps (SR:653-675) on (chromosome, strand) groups; contig index doubles as the dictionary index ----
+  std::vector<Lite> all(n);
+  for (uint64_t i = 0; i < n; i++) {
+    const calitas_aln_t& a = alns[i];
+    int tlen = 0;
+    for (int k = 0; k < a.n_ops; k++) if (consumes_target(a.ops[k])) tlen++;
+    all[i] = Lite{a.contig_index, a.guide_start_offset, a.guide_start_offset + tlen - 1, (char)a.strand, a.score, i};  // RH:135-138
+  }
+  auto by_hit_order = [](const Lite& x, const Lite& y) {   // RH:284
+    if (x.contig != y.contig) return x.contig < y.contig;
+    if (x.start != y.start) return x.start < y.start;
+    if (x.strand != y.strand) return x.strand < y.strand;   // '+' (0x2B) sorts before '-' (0x2D)
+    return -x.score < -y.score;
+  };
+  auto overlap = [](const Lite& x, const Lite& y) {        // RH:141-144
+    if (x.contig != y.contig) return 0;
+    return std::max(0, std::min(x.end, y.end) - std::max(x.start, y.start));
+  };
+  std::map<std::pair<int, char>, std::vector<Lite>> groups;
+  for (auto& l : all) groups[{l.contig, l.strand}].push_back(l);
+  std::vector<Lite> keepers;
+  for (auto& kv : groups) {
+    auto& hs = kv.second;
+    std::stable_sort(hs.begin(), hs.end(), by_hit_order);
+    size_t i = 0;
+    while (i < hs.size()) {
+      const Lite hit = hs[i++];
+      while (i < hs.size() && overlap(hs[i], hit) >= p.max_overlap && hs[i].score <= hit.score) i++;
+      if (i >= hs.size() || overlap(hs[i], hit) < p.max_overlap) keepers.push_back(hit);
+    }
+  }
+  std::stable_sort(keepers.begin(), keepers.end(), by_hit_order);   // SR:647
+
+  // ---- rows (RH:210-254) ----
+  std::string search_pam;
+  for (size_t i = 0; i < g.pams.size(); i++) { if (i) search_pam += ','; search_pam += g.pams[i]; }   // RH:207
+  const std::string args = core_parameters(p, max_total);
+  std::string out;
+  for (int i = 0; i < 34; i++) { if (i) out += '\t'; out += kColumns[i]; }
+  out += '\n';
+  std::string pg, pa, pt;
+  for (auto& k : keepers) {
+    const calitas_aln_t& a = alns[k.idx];
+    const bool minus = a.strand == '-';
+    padded_strings(ref, g, a, pg, pa, pt);
+    const std::string query = g.query_for(a.pam_index);
+    // unpaddedTargetWithoutPam GA:111-115
+    int ps = -1, pe = -1;
+    for (int i = 0; i < (int)pg.size(); i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
+    std::string unpadded_target;
+    for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target += pt[i];
+    const int contig = a.contig_index;
+    // RH:213-216 (coordinates are given in genome orientation, content is strand aware)
+    const std::string tenLeft = fetch_flank(ref, contig, a.guide_start_offset + 1 - 10, a.guide_start_offset, minus);
+    const std::string tenRight = fetch_flank(ref, contig, a.guide_end_offset + 1, a.guide_end_offset + 10, minus);
+    const std::string eightLeft = fetch_flank(ref, contig, a.start_offset + 1 - 8, a.start_offset, minus);
+    const std::string eightRight = fetch_flank(ref, contig, a.end_offset + 1, a.end_offset + 8, minus);
+    std::string pam_used;
+    for (char c : query) if (c >= 'a' && c <= 'z') pam_used += c;   // RH:229
+    const int mm = (int)std::count(pa.begin(), pa.end(), '.'), gp = (int)std::count(pa.begin(), pa.end(), '~');
+
+    out += guide_id; out += '\t';
+    out += g.protospacer; out += '\t';
+    out += ref.genome_build; out += '\t';
+    out += ref.names[contig]; out += '\t';
+    out += std::to_string(a.guide_start_offset); out += '\t';
+    out += std::to_string(a.guide_end_offset); out += '\t';
+    out += (char)a.strand; out += '\t';
+    out += unpadded_target; out += '\t';
+    out += minus ? tenRight : tenLeft; out += '\t';      // RH:227
+    out += minus ? tenLeft : tenRight; out += '\t';      // RH:228
+    out += pam_used; out += '\t';
+    out += "\t\t\t\t";                                   // variant_id, variant_description, variant_vcf, allele_frequency: None
+    out += std::to_string(a.score); out += '\t';
+    out += std::to_string(ga_count(pg, pa, false, false, true, false)); out += '\t';   // guide_mm GA:103
+    out += std::to_string(ga_count(pg, pa, false, false, false, true)); out += '\t';   // guide_gaps GA:104
+    out += std::to_string(ga_count(pg, pa, false, false, true, true)); out += '\t';    // guide_mm_plus_gaps GA:105
+    out += std::to_string(ga_count(pg, pa, true, true, true, false)); out += '\t';     // pam_mm GA:106
+    out += std::to_string(mm + gp); out += '\t';                                       // total_mm_plus_gaps = edits GA:101
+    out += pg; out += '\t'; out += pa; out += '\t'; out += pt; out += '\t';
+    out += minus ? eightRight : eightLeft; out += '\t';  // RH:243
+    out += minus ? eightLeft : eightRight; out += '\t';  // RH:244
+    out += cigar_of(a); out += '\t';
+    out += std::to_string(g.protospacer.size()); out += '\t';
+    out += std::to_string(unpadded_target.size()); out += '\t';
+    out += "CALITAS:SearchReference"; out += '\t';       // SR:522
+    out += version; out += '\t';
+    out += search_pam; out += '\t';
+    out += args; out += '\t';
+    out += time_stamp; out += '\n';
+  }
+  if (n_rows) *n_rows = keepers.size();
+  return out;
+}
+
+}  // namespace calitas

@@ -1,0 +1,43 @@
+// post.hpp -- host-side stages above the kernels: raw alignment -> GuideAlignment record, the per-window filter,
+// removeOverlaps / sort / hits.txt rows.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/calitas_hip.h"
+#include "common.hpp"
+#include "refpack.hpp"
+
+namespace calitas {
+
+struct GuideHost {
+  std::string protospacer;            // upper case
+  std::vector<std::string> pams;      // lower case, as given
+  bool pam5 = false;
+  int cli_length = 0;
+  std::string q;                      // aligner-space query: protospacer, or its reverse complement for a 5' PAM
+  std::vector<std::string> pams_q;    // aligner-space PAMs
+  // query string of an alignment in guide orientation (GuideAlignment.guide): protospacer+pam or pam+protospacer
+  std::string query_for(int pam_index) const;
+};
+
+char complement_base(char c);
+std::string revcomp_str(const std::string& s);
+// Validates and converts; returns an empty string on success, else the error text.
+std::string make_guide_host(const calitas_guide_t& g, GuideHost& out);
+
+// Converts one raw kernel record into a GuideAlignment record (SequentialGuideAligner.scala:260-313, GuideAlignment.scala:10-50).
+void raw_to_aln(const RawAln& r, const GuideHost& g, int64_t win_a, int64_t win_b, calitas_aln_t& out);
+
+// SequentialGuideAligner.scala:315-320 on one window's alignments (forward list then reverse list, enumeration order).
+void window_filter(const calitas_aln_t* alns, int n, int max_total_diffs, int max_overlap, std::vector<int>& kept);
+
+// Padded strings in guide orientation.
+void padded_strings(const PackedRef& ref, const GuideHost& g, const calitas_aln_t& a, std::string& pg, std::string& pa, std::string& pt);
+
+// hits.txt text for one guide's alignments.
+std::string hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
+                     const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
+                     uint64_t* n_rows);
+
+}  // namespace calitas

@@ -1,0 +1,167 @@
+/* calitas_hip.h -- C ABI of the MI355X-native CALITAS SearchReference hot path (libcalitas_hip.so).
+ *
+ * The reference (editasmedicine/calitas, Scala/JVM) has no FFI.  The narrowest seam with stable meaning is
+ *   SequentialGuideAligner.align(guide, target, targetName, targetOffset, maxGuideDiffs, maxGapsBetweenGuideAndPam,
+ *                                maxPamDiffs, maxTotalDiffs, maxOverlap): Seq[GuideAlignment]
+ *   (calitas/src/main/scala/com/editasmedicine/aligner/SequentialGuideAligner.scala:228-236), called once per
+ *   reference window from SearchReference.execute (SearchReference.scala:537-561).
+ * One call per 1000-bp window is too fine for a GPU, so this ABI lifts the same contract to
+ * "all windows of a resident reference x a batch of guides": calitas_search returns, window by window and in the
+ * reference's order, exactly the GuideAlignments those align() calls return.  Everything below that seam
+ * (the fgbio glocal DP, PAM extension, per-window overlap filter) runs in hand-written HIP kernels for gfx950;
+ * everything above it (removeOverlaps, ReferenceHit rows, hits.txt) is host code with the reference's semantics.
+ *
+ * Conventions: plain C types only; inputs are borrowed for the duration of the call; outputs are allocated by the
+ * library and released with calitas_free; every function returning int returns 0 on success and a non-zero
+ * CALITAS_E* code on failure, with a message available from calitas_last_error.  Results are never truncated:
+ * a device buffer overflow is detected and the search is re-run with larger buffers.
+ * Threading: calls on one context are serialised by the caller; one context drives one GPU.
+ */
+#ifndef CALITAS_HIP_H
+#define CALITAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CALITAS_OK 0
+#define CALITAS_EINVAL 1   /* bad argument / unsupported configuration */
+#define CALITAS_ENODEV 2   /* no usable HIP device, or context created host-only */
+#define CALITAS_EHIP 3     /* HIP runtime error */
+#define CALITAS_EIO 4      /* file could not be read / written */
+#define CALITAS_ESTATE 5   /* call made in the wrong state (e.g. search before set_reference) */
+
+#define CALITAS_MAX_PROTOSPACER 32   /* rows of the bit-vector scan kernel */
+#define CALITAS_MAX_PAMS 8
+#define CALITAS_MAX_PAM_LEN 16
+#define CALITAS_MAX_OPS 96           /* padded alignment columns per record */
+#define CALITAS_MAX_GUIDES 64        /* guides per calitas_search batch */
+
+typedef struct calitas_ctx calitas_ctx;
+
+/* Guide = SequentialGuideAligner.Guide (SequentialGuideAligner.scala:32-52): protospacer in upper case, zero or more
+ * PAMs in lower case, all on the same side. */
+typedef struct {
+  const char* protospacer;
+  int32_t n_pams;
+  const char* const* pams;
+  int32_t pam_is_5prime;
+  int32_t cli_length;        /* length of the `-i` string (protospacer + primary PAM), SearchReference.scala:528,536 */
+} calitas_guide_t;
+
+/* Flags of SearchReference (SearchReference.scala:452-470) that reach the aligner. */
+typedef struct {
+  int32_t window_size;                     /* -w  default 1000 */
+  int32_t max_guide_diffs;                 /* -d  default 5 */
+  int32_t max_pam_mismatches;              /* -p  default 1 */
+  int32_t max_gaps_between_guide_and_pam;  /* -g  default 3 */
+  int32_t max_total_diffs;                 /* -D  <0 => d+g+p (SearchReference.scala:493) */
+  int32_t max_overlap;                     /* -O  default 10 */
+  int32_t guide_mismatch_net_cost;         /* -m  default -120 */
+  int32_t pam_mismatch_net_cost;           /* -M  default -260 */
+  int32_t genome_gap_net_cost;             /* -b  default -122 */
+  int32_t guide_gap_net_cost;              /* -B  default -121 */
+  int32_t chrom_index;                     /* -c  contig index, <0 => all */
+  int32_t eqx_by_score;                    /* 0: '='/'X' by IUPAC compatibility (default); 1: by pairing score > 0 */
+  int32_t max_variants;                    /* -V  only echoed into aligner_other_parameters */
+} calitas_params_t;
+
+/* One GuideAlignment (GuideAlignment.scala:72-88).  Coordinates are 0-based half-open on the contig.  ops holds
+ * one byte per padded column in the orientation of the guide as given on the command line:
+ * '=' match, 'X' mismatch, 'I' base only in the guide (gap in genome), 'D' base only in the genome.
+ * The padded strings are a pure function of (query, ops, strand, start_offset) and the reference bases. */
+typedef struct {
+  int32_t guide_index;
+  int32_t contig_index;
+  int32_t window_start;        /* 0-based offset of the (N-trimmed) window the alignment was found in */
+  int32_t start_offset, end_offset;
+  int32_t guide_start_offset, guide_end_offset;
+  int32_t score;
+  int8_t strand;               /* '+' or '-' */
+  int8_t pam_index;            /* index into the guide's pams, -1 for a PAM-less guide */
+  int16_t n_ops;
+  uint8_t ops[CALITAS_MAX_OPS];
+} calitas_aln_t;
+
+/* Timing and volume of the last calitas_search on this context; kernel times are HIP-event measurements on the
+ * stream the kernels were launched on. */
+typedef struct {
+  double scan_kernel_ms;       /* bit-vector scan over the packed reference (both strands, all guides of the batch) */
+  double align_kernel_ms;      /* banded glocal DP + traceback + PAM extension on the scan's candidates */
+  double gpu_total_ms;         /* first launch to last copy-back */
+  double host_post_ms;         /* per-window filter on the host */
+  uint64_t bases_scanned;      /* reference bases covered by the scan (one count per base, not per strand) */
+  uint64_t packed_bytes;       /* 2-bit bytes the scan reads from HBM per pass */
+  uint64_t scan_records;       /* 16-base groups with at least one candidate end column */
+  uint64_t candidate_columns;  /* candidate end columns (guide x strand x position) handed to the aligner kernel */
+  uint64_t raw_alignments;     /* alignments surviving PAM extension, before the per-window filter */
+  uint64_t accepted_alignments;
+  uint32_t retries;            /* re-runs caused by device buffer overflow */
+} calitas_timing_t;
+
+/* Context ------------------------------------------------------------------------------------------------------- */
+
+/* device_id >= 0: bind to that HIP device (fails with CALITAS_ENODEV when there is none -- there is no CPU fallback).
+ * device_id == -1: host-only context for reference packing, window tables and hits formatting; calitas_search fails. */
+int calitas_create(int device_id, calitas_ctx** out);
+void calitas_destroy(calitas_ctx* ctx);
+const char* calitas_last_error(const calitas_ctx* ctx);   /* ctx may be NULL: last error of calitas_create */
+void calitas_free(void* p);
+
+/* Reference ----------------------------------------------------------------------------------------------------- */
+
+/* Replaces ReferenceSequenceIterator + windowIterator's byte[] contigs (SearchReference.scala:39-49): ASCII bases of
+ * every contig, in sequence-dictionary order.  Packs to 2 bit/base + an exception-run table (N runs, IUPAC codes) and
+ * uploads to HBM.  genome_build = first AS tag of the .dict or "unknown" (ReferenceHit.scala:208). */
+int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const* names, const uint64_t* lengths,
+                          const uint8_t* const* bases, const char* genome_build);
+/* Convenience: read FASTA (+ .dict next to it when present) and call calitas_set_reference. */
+int calitas_set_reference_fasta(calitas_ctx* ctx, const char* fasta_path);
+int calitas_reference_info(const calitas_ctx* ctx, int32_t* n_contigs, uint64_t* total_bases, uint64_t* packed_bytes);
+int calitas_contig_name(const calitas_ctx* ctx, int32_t contig_index, const char** name, uint64_t* length);
+/* Upper-cased bases [start, start+len) of a contig re-derived from the packed form (what fetchBases sees after
+ * toUpperCase, ReferenceHit.scala:261-266); out must hold len bytes. */
+int calitas_fetch_bases(const calitas_ctx* ctx, int32_t contig_index, uint64_t start, uint32_t len, char* out);
+
+/* Window table of windowIterator (SearchReference.scala:39-71) after the length filter (SearchReference.scala:536):
+ * rows of (contig_index, start0, end0) with N-trimmed 0-based half-open bounds.  Caller frees *out. */
+int calitas_window_table(const calitas_ctx* ctx, int32_t window_size, int32_t step, int32_t min_length, int32_t chrom_index,
+                         int32_t** out, uint64_t* n_windows);
+
+/* Search -------------------------------------------------------------------------------------------------------- */
+
+/* SearchReference.execute's alignment phase (SearchReference.scala:527-561) for n_guides guides in one pass over the
+ * resident reference.  *out receives, guide by guide and window by window in windowIterator order, the alignments
+ * SequentialGuideAligner.align returns for each window (after its per-window overlap filter). */
+int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                   calitas_aln_t** out, uint64_t* n_out);
+int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
+
+/* Host-side stages, usable on a host-only context ------------------------------------------------------------------ */
+
+/* The per-window greedy filter of SequentialGuideAligner.align (SequentialGuideAligner.scala:315-320) on the
+ * alignments of ONE window given in enumeration order (forward-strand list then reverse-strand list): stable sort by
+ * (score desc, gap bases asc), keep if edits <= max_total_diffs and no kept same-strand alignment overlaps by more
+ * than max_overlap.  keep[i] is set to 1 for survivors; order[] receives the indices of survivors in output order. */
+int calitas_window_filter(const calitas_aln_t* alns, int32_t n, int32_t max_total_diffs, int32_t max_overlap,
+                          int32_t* order, int32_t* n_kept);
+
+/* removeOverlaps + ReferenceHit.sort + the 34-column rows (SearchReference.scala:641-648, ReferenceHit.scala:99-287)
+ * for the alignments of one guide.  Returns the full hits.txt text (header + rows) in *tsv. */
+int calitas_hits_tsv(const calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                     const calitas_aln_t* alns, uint64_t n_alns, const char* aligner_version, const char* time_stamp,
+                     char** tsv, uint64_t* n_rows);
+
+/* Padded strings of one alignment (Alignment.paddedString as used at SequentialGuideAligner.scala:511, plus the
+ * reverse-complement handling of 5' PAM guides): each buffer must hold CALITAS_MAX_OPS+1 bytes. */
+int calitas_padded_strings(const calitas_ctx* ctx, const calitas_guide_t* guide, const calitas_aln_t* aln, char* padded_guide,
+                           char* padded_alignment, char* padded_target);
+
+const char* calitas_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,221 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs -- identical hits.txt rows
+(every column except the run-dependent aligner_version / time_stamp), bit-exact.
+
+Run on the GPU box with:  python -m pytest tests -m gpu
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fasta_util import expand, write_fasta
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SKIP_COLS = {"aligner_version", "time_stamp"}
+
+
+@pytest.fixture(scope="module")
+def C():
+    import calitas_amd
+    return calitas_amd
+
+
+def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
+    pk = dict(window_size=kw.get("window_size", 1000), max_guide_diffs=kw.get("d", 5), max_pam_mismatches=kw.get("p", 1),
+              max_gaps_between_guide_and_pam=kw.get("g", 3), max_total_diffs=kw.get("D"), max_overlap=kw.get("O", 10),
+              eqx_by_score=1 if kw.get("switches", 0) & 2 else 0)
+    for k in ("guide_mismatch_net_cost", "pam_mismatch_net_cost", "genome_gap_net_cost", "guide_gap_net_cost"):
+        if k in kw:
+            pk[k] = kw[k]
+    sr = C.SearchReference(guide=guide, guide_id="a", ref=fasta, auxiliary_pams=aux, chrom=chrom, **pk)
+    text, n = sr.run()
+    rows = C.read_hits(text)
+    assert len(rows) == n
+    return rows
+
+
+def oracle_rows(fasta, guide, aux=(), chrom=None, **kw):
+    ok = dict(window_size=kw.get("window_size", 1000), d=kw.get("d", 5), p=kw.get("p", 1), g=kw.get("g", 3),
+              D=-1 if kw.get("D") is None else kw["D"], O=kw.get("O", 10), switches=kw.get("switches", 0), threads=4)
+    if "guide_mismatch_net_cost" in kw: ok["m"] = kw["guide_mismatch_net_cost"]
+    if "pam_mismatch_net_cost" in kw: ok["M"] = kw["pam_mismatch_net_cost"]
+    if "genome_gap_net_cost" in kw: ok["b"] = kw["genome_gap_net_cost"]
+    if "guide_gap_net_cost" in kw: ok["B"] = kw["guide_gap_net_cost"]
+    _, rows, _ = O.search_reference(fasta, guide, "a", aux=aux, chrom=chrom or "", **ok)
+    return rows
+
+
+def assert_same(prod, orac, tag=""):
+    def strip(rows):
+        return [{k: v for k, v in r.items() if k not in SKIP_COLS} for r in rows]
+    p, o = strip(prod), strip(orac)
+    if p != o:
+        ps = {json.dumps(r, sort_keys=True) for r in p}
+        os_ = {json.dumps(r, sort_keys=True) for r in o}
+        only_p = [json.loads(x) for x in sorted(ps - os_)][:3]
+        only_o = [json.loads(x) for x in sorted(os_ - ps)][:3]
+        raise AssertionError("%s: product %d rows, oracle %d rows\nonly product: %s\nonly oracle: %s" % (tag, len(p), len(o), only_p, only_o))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's own end-to-end vectors (SearchReferenceTest.scala:51-92), now through the GPU path
+# ---------------------------------------------------------------------------------------------------------------------
+SR = json.load(open(os.path.join(GOLD, "kat_sr.json")))
+
+
+@pytest.mark.parametrize("case", SR["cases"], ids=lambda c: c["id"])
+def test_reference_end_to_end_vectors(C, case, tmp_path):
+    contigs = [(name, expand(spec)) for name, spec in SR[case["fasta"]]["contigs"]]
+    fa = write_fasta(str(tmp_path / "kat.fa"), contigs)
+    out = str(tmp_path / "hits.txt")
+    C.SearchReference(guide=case["guide"], guide_id="a", ref=fa, output=out, threads=1).execute()
+    hits = C.read_hits(out)
+    e = case["expect"]
+    assert len(hits) == e["n"]
+    for k in ("chromosome", "padded_alignment"):
+        if k in e:
+            assert [h[k] for h in hits] == e[k]
+    for k in ("coordinate_start", "total_mm_plus_gaps"):
+        if k in e:
+            assert [int(h[k]) for h in hits] == e[k]
+    assert_same(hits, oracle_rows(fa, case["guide"]), case["id"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# seeded synthetic genomes: planted sites, N runs, soft-masking, tandem repeats, IUPAC codes, short contigs
+# ---------------------------------------------------------------------------------------------------------------------
+def synth_fasta(tmp_path, seed, guides, lengths=(60000, 35000, 1500, 700, 26, 12), extra=None, **kw):
+    from calitas_amd import synth
+    spec = [("ctg%d" % i, l) for i, l in enumerate(lengths)]
+    glist = []
+    for g in guides:
+        G = __import__("calitas_amd").Guide(g)
+        pam = G.pams[0] if G.pams else ""
+        glist.append((G.guide, pam, G.pam_is_five_prime))
+    names, seqs = synth.make_genome(spec, seed, guides=glist, sites_per_guide=60, softmask=0.4, tandem_frac=0.03,
+                                    n_run_ends=kw.get("n_run_ends", 300), n_block=kw.get("n_block", 2500), step_hint=kw.get("step_hint", 971))
+    contigs = [(n, s.tobytes().decode()) for n, s in zip(names, seqs)]
+    if extra:
+        contigs += extra
+    return write_fasta(str(tmp_path / ("synth%d.fa" % seed)), contigs)
+
+
+CONFIGS = [
+    # (id, guide, aux, params)
+    ("nrg-d5-g2", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=2)),                     # BASELINE config 3 limits
+    ("nrg-d3", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=3, p=1, g=3)),                        # BASELINE config 2 limits
+    ("pamless-d5", "GTGACTTGAAGTCTCAGTATA", (), dict(d=5)),
+    ("5prime-tttv", "tttvAACCAACCAACCGGTTACGT", (), dict(d=4, p=1, g=2)),
+    ("aux-pams", "ACGTACATGCTCGATACGACGnngrrn", ("nngrrt", "nnagaaw"), dict(d=4, p=1, g=3)),
+    ("iupac-protospacer", "GAGAATTGNTTGAACCCRGG", (), dict(d=3)),
+    ("d0", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=0, p=0, g=0)),
+    ("wide-overlap", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=3, O=100)),
+    ("zero-overlap", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=1, O=0)),
+    ("tight-D", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=3, D=4)),
+    ("small-window", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=2, window_size=120)),
+    ("eqx-by-score", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=2, switches=2)),
+    ("costs", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=2, guide_mismatch_net_cost=-100, pam_mismatch_net_cost=-200,
+                                                  genome_gap_net_cost=-104, guide_gap_net_cost=-102)),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: c[0])
+def test_synthetic_genome_parity(C, cfg, tmp_path):
+    cid, guide, aux, params = cfg
+    W = params.get("window_size", 1000)
+    step = W - (len(guide) + params.get("d", 5) + params.get("g", 3) - 1)
+    extra = [("iupac", "ACGTRYKMSWBDHVN" * 40 + "CTTGCCCCACAGGGCAGTAATGG" + "acgtn" * 30 + "CTTGCCCCACNGGGCAGTAAAGG" + "TTRACGGT" * 20),
+             ("rna", "ACGUACGUUUGGCAUCG" * 30 + "CUUGCCCCACAGGGCAGUAAUGG" + "ACGU" * 20)]
+    fa = synth_fasta(tmp_path, 7 + len(cid), [guide], extra=extra, step_hint=step)
+    prod = product_rows(C, fa, guide, aux, **params)
+    orac = oracle_rows(fa, guide, aux, **params)
+    assert len(orac) > 0
+    assert_same(prod, orac, cid)
+
+
+def test_chrom_filter_and_reuse(C, tmp_path):
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    fa = synth_fasta(tmp_path, 99, [guide])
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    for chrom in ("ctg1", "ctg0", None):
+        sr = C.SearchReference(guide=guide, guide_id="a", context=ctx, chrom=chrom, max_gaps_between_guide_and_pam=2)
+        text, _ = sr.run()
+        assert_same(C.read_hits(text), oracle_rows(fa, guide, chrom=chrom, g=2), "chrom=%s" % chrom)
+    ctx.close()
+
+
+def test_guide_batch_matches_single_guide_runs(C, tmp_path):
+    """A multi-guide pass (BASELINE config 4 shape) returns, guide by guide, what single-guide passes return."""
+    from calitas_amd import synth
+    guides = ["CTTGCCCCACAGGGCAGTAAnrg"] + synth.random_guides(0xC4, 5)
+    fa = synth_fasta(tmp_path, 5, guides, lengths=(50000, 20000))
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    params = C.make_params(max_gaps_between_guide_and_pam=2)
+    G = [C.Guide(g) for g in guides]
+    alns = ctx.search(G, params)
+    for gi, g in enumerate(G):
+        mine = [a for a in alns if a.guide_index == gi]
+        text, _ = ctx.hits_tsv(g, "a", params, mine)
+        assert_same(C.read_hits(text), oracle_rows(fa, guides[gi], g=2), "guide %d" % gi)
+    ctx.close()
+
+
+def test_no_silent_truncation_on_dense_output(C, tmp_path):
+    """PAM-less d=8 on a short tandem-repeat contig floods the candidate buffers; the retry path must deliver everything."""
+    unit = "ACGTTGCA"
+    seq = (unit * 4000) + "GTGACTTGAAGTCTCAGTATA" + (unit[::-1] * 3000)
+    fa = write_fasta(str(tmp_path / "dense.fa"), [("rep", seq)])
+    guide = "ACGTTGCAACGTTGCAACGT"
+    prod = product_rows(C, fa, guide, d=8, O=100)
+    orac = oracle_rows(fa, guide, d=8, O=100)
+    assert_same(prod, orac, "dense")
+
+
+def test_full_size_properties_ecoli_like(C):
+    """BASELINE config 2 size (4.6 Mb): size-independent properties instead of a full oracle run --
+    (1) every planted perfect site is found with 0 edits, (2) searching the reverse-complemented genome with the same
+    guide flips strands and mirrors coordinates, (3) hits are sorted and non-redundant."""
+    from calitas_amd import synth
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    rng = np.random.default_rng(0xC2)
+    seq = synth.random_bases(rng, synth.ECOLI_LENGTH, gc=0.508)
+    planted = []
+    for k in range(50):
+        pos = int(rng.integers(100, len(seq) - 100))
+        minus = bool(k % 2)
+        synth.plant_site(rng, seq, pos, "CTTGCCCCACAGGGCAGTAA", "nrg", False, 0, minus)
+        planted.append((pos, minus))
+    ctx = C.Context(0)
+    ctx.set_reference(["ecoli_like"], [seq])
+    params = C.make_params(max_guide_diffs=3)
+    G = C.Guide(guide)
+    alns = ctx.search([G], params)
+    text, n = ctx.hits_tsv(G, "a", params, alns)
+    hits = C.read_hits(text)
+    perfect = {(int(h["coordinate_start"]), h["strand"]) for h in hits if h["total_mm_plus_gaps"] == "0"}
+    for pos, minus in planted:
+        start = pos + 3 if minus else pos
+        assert (start, "-" if minus else "+") in perfect, (pos, minus)
+    keys = [(int(h["coordinate_start"]), h["strand"], -int(h["score"])) for h in hits]
+    assert keys == sorted(keys)
+    # mirror property
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    rc = comp[seq[::-1]].copy()
+    ctx.set_reference(["ecoli_like"], [rc])
+    alns2 = ctx.search([G], params)
+    text2, _ = ctx.hits_tsv(G, "a", params, alns2)
+    hits2 = C.read_hits(text2)
+    n_len = len(seq)
+    best1 = {(int(h["coordinate_start"]), int(h["coordinate_end"]), h["strand"]) for h in hits if int(h["total_mm_plus_gaps"]) <= 1}
+    best2 = {(n_len - int(h["coordinate_end"]), n_len - int(h["coordinate_start"]), "+" if h["strand"] == "-" else "-")
+             for h in hits2 if int(h["total_mm_plus_gaps"]) <= 1}
+    assert best1 == best2
+    ctx.close()
