@@ -31,7 +31,7 @@ int pick_chunk(uint64_t total_bases) {
   // Aim for >= 2048 tiles so 256 CUs see several waves of workgroups; a lane re-scans 32 warm-up bases per direction,
   // so larger chunks waste less (32/chunk) but give fewer workgroups.
   int chunk = 512;
-  while (chunk > 32 && total_bases / ((uint64_t)chunk * LANES_PER_TILE) < 2048) chunk >>= 1;
+  while (chunk > 64 && total_bases / ((uint64_t)chunk * LANES_PER_TILE) < 2048) chunk >>= 1;
   return chunk;
 }
 
