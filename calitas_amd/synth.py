@@ -53,7 +53,7 @@ def mutate(rng, proto, n_edits, allow_gaps=True):
 
 def plant_site(rng, seq, pos, protospacer, pam, pam5, n_edits, minus, gap_to_pam=0):
     """Writes a near-match of the guide into seq (uint8 array) at pos; returns the number of bases written."""
-    site = mutate(rng, protospacer, n_edits)
+    site = mutate(rng, realise(rng, protospacer), n_edits)
     p = realise(rng, pam) if pam else ""
     filler = "".join(rng.choice(list("ACGT")) for _ in range(gap_to_pam))
     full = (p + filler + site) if pam5 else (site + filler + p)
