@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- SearchReference full-scan throughput on MI355X (BASELINE.json metric).
+
+Workload (N=1): BASELINE config 3 -- one 20-nt guide + NRG PAM against a synthetic hg38-sized genome (25 contigs,
+3 088 286 401 bp, N runs, soft-masking, tandem repeats, planted sites), max-guide-diffs 5, max-pam-mismatches 1,
+max-gaps-between-guide-and-pam 2.  A "step" is one complete SearchReference pass for one guide over the resident
+reference: scan kernel + aligner kernel + copy-back + per-window filter + removeOverlaps/sort/hit rows (everything
+except writing hits.txt to disk).  The packed reference is resident in HBM before the timed region.
+
+N>1: one process per GPU (torch.distributed, RCCL for the barrier).  Default partition = guides (each rank holds the
+genome and runs its own guide of the 96-guide set per step; BASELINE config 4) -> weak scaling, no data-path
+collective.  --shard contigs partitions the contigs of ONE guide's pass instead (strong scaling, host-side gather).
+
+value = candidate loci examined per second = 2 strands x reference bases x guide-passes / wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GUIDE0 = "CTTGCCCCACAGGGCAGTAAnrg"   # README.md:74 of the reference
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def gen_contig(length, seed, device, n_ends, n_block, softmask=0.5, tandem_frac=0.01, gc=0.41):
+    """One synthetic contig as a numpy uint8 array of ASCII bases, generated on the GPU with torch (plumbing only)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    u = torch.randint(0, 256, (length,), dtype=torch.uint8, device=device, generator=g)
+    at = (1.0 - gc) / 2
+    t0, t1, t2 = int(at * 256), int((at + gc / 2) * 256), int((at + gc) * 256)
+    idx = (u >= t0).to(torch.uint8) + (u >= t1).to(torch.uint8) + (u >= t2).to(torch.uint8)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    seq = lut[idx.long()]
+    del u, idx
+    cg = torch.Generator(device="cpu")
+    cg.manual_seed(seed + 1)
+    if tandem_frac > 0 and length > 1000:
+        n_tr = max(1, int(length * tandem_frac / 150))
+        starts = torch.randint(0, max(1, length - 400), (n_tr,), generator=cg).tolist()
+        units = torch.randint(2, 8, (n_tr,), generator=cg).tolist()
+        tracts = torch.randint(30, 300, (n_tr,), generator=cg).tolist()
+        if n_tr > 20000:   # keep the python loop bounded on the big contigs
+            starts, units, tracts = starts[:20000], units[:20000], tracts[:20000]
+        for s, unit, tract in zip(starts, units, tracts):
+            e = min(length, s + tract)
+            seq[s:e] = seq[s:s + unit].repeat(tract // unit + 1)[:e - s]
+    if softmask > 0 and length > 2000:
+        n_runs = int(length * softmask / 2650)
+        starts = torch.randint(0, length, (n_runs,), device=device, generator=g)
+        lens = torch.randint(300, 5000, (n_runs,), device=device, generator=g)
+        delta = torch.zeros(length + 1, dtype=torch.int32, device=device)
+        delta.index_add_(0, starts, torch.ones(n_runs, dtype=torch.int32, device=device))
+        delta.index_add_(0, torch.clamp(starts + lens, max=length), -torch.ones(n_runs, dtype=torch.int32, device=device))
+        low = torch.cumsum(delta[:-1], 0) > 0
+        seq = torch.where(low, seq | 0x20, seq)
+        del delta, low
+    if n_ends > 0:
+        seq[:min(n_ends, length)] = ord("N")
+        seq[max(0, length - n_ends):] = ord("N")
+    if n_block > 0 and length > 3 * n_block:
+        s = int(torch.randint(length // 3, 2 * length // 3 - n_block, (1,), generator=cg))
+        seq[s:s + n_block] = ord("N")
+    out = seq.cpu().numpy()
+    del seq
+    return out
+
+
+def build_genome(scale, device, contig_indices=None, guides=(), log=None):
+    """hg38-sized synthetic genome (seed 0xC3). Returns (names, arrays) for the requested contigs."""
+    import numpy as np
+    from calitas_amd import synth
+    spec = synth.hg38_like_spec(scale)
+    names, seqs = [], []
+    for ci, (name, length) in enumerate(spec):
+        if contig_indices is not None and ci not in contig_indices:
+            continue
+        big = length > 2_000_000
+        rng = np.random.default_rng([0xC3, ci])
+        n_block = int(rng.integers(1_000_000, 3_000_000) * min(1.0, scale * 4)) if big else 0
+        seq = gen_contig(length, 0xC300 + ci, device, n_ends=10_000 if big else 0, n_block=n_block)
+        # planted sites for each guide: 0-6 edits, both strands, some straddling window starts (k*971)
+        n_sites = max(2, int(40 * length / 3.1e9))
+        for gi, gstr in enumerate(guides):
+            proto, pam = gstr[:20], gstr[20:]
+            for k in range(n_sites):
+                lo = 10_000 if big else 0
+                pos = int(rng.integers(lo + 100, max(lo + 200, length - lo - 100)))
+                if k % 3 == 0:
+                    pos = (pos // 971) * 971 - int(rng.integers(0, 30))
+                synth.plant_site(rng, seq, pos, proto, pam, False, int(rng.integers(0, 6)), bool(rng.integers(0, 2)))
+        names.append(name)
+        seqs.append(seq)
+        if log:
+            log("generated %s (%d bp)" % (name, length))
+    return names, seqs
+
+
+def host_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(names, seqs, params_kw, budget_bases):
+    """Times the CPU oracle (the restatement of the reference algorithm, oracle/) on a bounded sample of the same
+    genome with one worker per host core -- the reference's own threading model (SearchReference.scala:459)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = host_cores()
+    # sample: the first non-N stretch of the largest contig
+    big = max(range(len(seqs)), key=lambda i: len(seqs[i]))
+    budget_bases = min(budget_bases, len(seqs[big]))
+    start = 20_000 if len(seqs[big]) > 40_000 + budget_bases else 0
+    sample = bytes(seqs[big][start:start + budget_bases])
+    t0 = time.perf_counter()
+    _, rows, nwin = O.search_memory([names[big]], [sample], GUIDE0, "cpu", d=params_kw["max_guide_diffs"],
+                                    p=params_kw["max_pam_mismatches"], g=params_kw["max_gaps_between_guide_and_pam"], threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": 2 * len(sample) / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": "%d bp of %s (%d windows, %d hits) in %.1f s; oracle/ C++ restatement of the reference algorithm, %d threads"
+                      % (len(sample), names[big], nwin, len(rows), dt, cores),
+            "bases_per_s": len(sample) / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="genome size relative to hg38 (1.0 = 3.09 Gb)")
+    ap.add_argument("--shard", choices=["guides", "contigs"], default="guides")
+    ap.add_argument("--cpu-sample-mb", type=float, default=-1, help="CPU baseline sample in Mb (<0: auto, 0: skip)")
+    ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    gloo = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        gloo = dist.new_group(backend="gloo")
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    import calitas_amd as C
+    from calitas_amd import shard, synth
+
+    params_kw = dict(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+    params = C.make_params(**params_kw)
+    all_guides = [GUIDE0] + synth.random_guides(0xC4, 95)
+    spec = synth.hg38_like_spec(args.scale)
+    lengths = [l for _, l in spec]
+
+    if world > 1 and args.shard == "contigs":
+        mine = shard.lpt_partition(lengths, world)[rank]
+        my_guides = [GUIDE0]
+        guide_passes_per_step = 1          # the ranks share ONE guide pass
+        bases_per_step_total = sum(lengths)
+    else:
+        mine = None
+        my_guides = [all_guides[rank % len(all_guides)]]
+        guide_passes_per_step = world      # every rank runs its own guide over the whole genome
+        bases_per_step_total = sum(lengths) * world
+
+    t_gen = time.perf_counter()
+    names, seqs = build_genome(args.scale, device, contig_indices=mine, guides=[GUIDE0], log=None)
+    log("genome: %d contigs, %d bp on this rank, generated in %.1f s" % (len(names), sum(len(s) for s in seqs), time.perf_counter() - t_gen))
+    ctx = C.Context(local_rank)
+    t_set = time.perf_counter()
+    ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized")
+    info = ctx.reference_info()
+    log("set_reference: %.2f s (pack + upload), %d packed bytes" % (time.perf_counter() - t_set, info["packed_bytes"]))
+
+    G = [C.Guide(g) for g in my_guides]
+
+    def step():
+        out, n = ctx.search_raw(G, params)
+        try:
+            tm = ctx.timing()
+            rows = 0
+            if not args.no_hits:
+                text, rows = ctx.hits_tsv_raw(G[0], "bench", params, out, n, "bench", "bench")
+                if world > 1 and args.shard == "contigs":
+                    import torch.distributed as dist
+                    header, blocks = shard.split_rows_by_contig(text, ctx.contig_names)
+                    gathered = [None] * world if rank == 0 else None
+                    dist.gather_object(blocks, gathered, dst=0, group=gloo)
+                    if rank == 0:
+                        # contig indices are local to each rank's shard; rows carry names, so merge by name order
+                        rows = sum(len(r) for b in gathered for r in b.values())
+        finally:
+            C._lib.lib.calitas_free(out)
+        return tm, n, rows
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    scan_ms = align_ms = post_ms = gpu_ms = 0.0
+    last = None
+    for _ in range(args.steps):
+        tm, n_alns, rows = step()
+        scan_ms += tm["scan_kernel_ms"]; align_ms += tm["align_kernel_ms"]; post_ms += tm["host_post_ms"]; gpu_ms += tm["gpu_total_ms"]
+        last = (tm, n_alns, rows)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        tm, n_alns, rows = last
+        K = args.steps
+        bases_rank = tm["bases_scanned"]
+        value = 2.0 * bases_per_step_total * K / dt
+        scan_avg_ms = scan_ms / K
+        achieved = tm["packed_bytes"] / (scan_avg_ms * 1e-3) / 1e9    # GB/s, algorithmic bytes of one launch / its duration
+        result = {
+            "metric": "off-target candidates/sec (hg38 full scan), 20nt guide+NRG PAM",
+            "value": value, "unit": "candidates/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "strong" if (world > 1 and args.shard == "contigs") else "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "SearchReference: 20 nt guide + NRG PAM vs synthetic hg38-sized genome (25 contigs, %d bp), "
+                                   "max-guide-diffs=5 max-pam-mismatches=1 max-gaps-between-guide-and-pam=2" % sum(lengths),
+                       "guide": my_guides[0], "guide_passes_per_step": guide_passes_per_step, "partition": args.shard if world > 1 else "none",
+                       "genome_scale": args.scale, "step_includes": "scan+align kernels, copy-back, per-window filter"
+                                                                      + ("" if args.no_hits else ", removeOverlaps+sort+hit rows")},
+            "bases_per_s": bases_per_step_total * K / dt,
+            "hits_per_pass": rows, "accepted_alignments_per_pass": n_alns, "raw_alignments_per_pass": tm["raw_alignments"],
+            "scan_records_per_pass": tm["scan_records"],
+            "kernel_ms": {"scan": scan_avg_ms, "align": align_ms / K, "gpu_total": gpu_ms / K, "host_window_filter": post_ms / K},
+            "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": tm["packed_bytes"], "avg_launch_ms": scan_avg_ms,
+                         "note": "integer-VALU bound by construction (bit-vector edit-distance filter, ~40 int ops per base for "
+                                 "two strands); see DESIGN.md for the VALU-side roofline"},
+        }
+        mb = args.cpu_sample_mb
+        if mb < 0:
+            mb = 12.0 * min(host_cores(), 32)   # the oracle runs ~1.2 Mb/s per core: ~10-20 s of CPU work
+        if mb > 0 and world == 1:
+            try:
+                result["cpu_baseline"] = cpu_baseline(names, seqs, params_kw, int(mb * 1e6))
+            except Exception as e:  # the baseline is reporting only; never fail the bench line because of it
+                result["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
