@@ -195,8 +195,9 @@ def main():
             tm = ctx.timing()
             rows = 0
             if not args.no_hits:
-                text, rows = ctx.hits_tsv_raw(G[0], "bench", params, out, n, "bench", "bench")
-                if world > 1 and args.shard == "contigs":
+                contig_mode = world > 1 and args.shard == "contigs"
+                text, rows = ctx.hits_tsv_raw(G[0], "bench", params, out, n, "bench", "bench", decode=contig_mode)
+                if contig_mode:
                     import torch.distributed as dist
                     header, blocks = shard.split_rows_by_contig(text, ctx.contig_names)
                     gathered = [None] * world if rank == 0 else None

@@ -239,13 +239,15 @@ class Context:
         _lib.check(self._h, lib.calitas_get_timing(self._h, ctypes.byref(t)))
         return {f: getattr(t, f) for f, _ in TimingT._fields_}
 
-    def hits_tsv_raw(self, guide, guide_id, params, alns_ptr, n, version=None, time_stamp=None):
+    def hits_tsv_raw(self, guide, guide_id, params, alns_ptr, n, version=None, time_stamp=None, decode=True):
+        """calitas_hits_tsv on a C array of alignments. decode=False returns (None, n_rows) without copying the text
+        into a Python str (the rows are still built)."""
         g = guide.to_c()
         tsv, rows = ctypes.c_void_p(), ctypes.c_uint64()
         _lib.check(self._h, lib.calitas_hits_tsv(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params), alns_ptr, n,
                                                  version.encode() if version else None, time_stamp.encode() if time_stamp else None,
                                                  ctypes.byref(tsv), ctypes.byref(rows)))
-        text = ctypes.string_at(tsv).decode()
+        text = ctypes.string_at(tsv).decode() if decode else None
         lib.calitas_free(tsv)
         return text, rows.value
 

@@ -29,35 +29,84 @@ namespace calitas {
 
 // One column of Myers' bit-vector algorithm (search variant: free start in the text, so no carry into row 1).
 // Guide rows occupy the top L bits; the padding bits below keep Pv=1, Mv=0 as long as eq has them clear.
-__device__ __forceinline__ void myers_step(uint32_t eq, uint32_t& pv, uint32_t& mv, int& score) {
-  uint32_t xv = eq | mv;
-  uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-  uint32_t ph = mv | ~(xh | pv);
-  uint32_t mh = pv & xh;
-  score += (int)(ph >> 31);
-  score -= (int)(mh >> 31);
-  ph <<= 1;
-  mh <<= 1;
-  pv = mh | ~(xv | ph);
-  mv = ph & xv;
+// The horizontal deltas of row L sit in bit 31, so the two shifts are written as x+x and their carry-outs update
+// the running bottom-row score (v_add_co / v_addc on gfx950).
+__device__ __forceinline__ void myers_step(uint32_t eq, uint32_t& pv, uint32_t& mv, int& score, int& smin) {
+  // Hand-scheduled: 13 VALU instructions per column (hipcc's own selection of the same expression needs 17).
+  //   t  = (eq & pv) + pv
+  //   mh = pv & ((t ^ pv) | eq)            bitop3(pv, t, eq)  = 0xb0
+  //   xh = (t ^ pv) | eq                   bitop3(t, pv, eq)  = 0xbe
+  //   ph = mv | ~(xh | pv)                 bitop3(mv, xh, pv) = 0xf1
+  //   xv = eq | mv
+  //   ph <<= 1, score += carry;  mh <<= 1, score -= carry
+  //   pv = mh | ~(xv | ph)                 bitop3(mh, xv, ph) = 0xf1
+  //   mv = ph & xv
+  //   smin = min(smin, score)
+  uint32_t t, xh, ph, mh, xv;
+  asm("v_and_b32 %5, %9, %0\n\t"
+      "v_add_u32 %5, %5, %0\n\t"
+      "v_bitop3_b32 %7, %0, %5, %9 bitop3:0xb0\n\t"
+      "v_bitop3_b32 %6, %5, %0, %9 bitop3:0xbe\n\t"
+      "v_or_b32 %8, %9, %1\n\t"
+      "v_bitop3_b32 %4, %1, %6, %0 bitop3:0xf1\n\t"
+      "v_add_co_u32 %7, vcc, %7, %7\n\t"
+      "v_subb_co_u32 %2, vcc, %2, 0, vcc\n\t"
+      "v_add_co_u32 %4, vcc, %4, %4\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "v_bitop3_b32 %0, %7, %8, %4 bitop3:0xf1\n\t"
+      "v_and_b32 %1, %4, %8\n\t"
+      "v_min_i32 %3, %3, %2"
+      : "+v"(pv), "+v"(mv), "+v"(score), "+v"(smin), "=&v"(ph), "=&v"(t), "=&v"(xh), "=&v"(mh), "=&v"(xv)
+      : "v"(eq)
+      : "vcc");
 }
 
-template <int CHUNK>
+// Pair index of bases 2j and 2j+1 of a code word (+ their exception bits for masked tiles):
+// bits 0-1 code of base 2j, bits 2-3 code of base 2j+1, bit 4 / bit 5 their exception bits.
+template <bool MASKED>
+__device__ __forceinline__ uint32_t pair_index(uint32_t word, uint32_t mbits, int j) {
+  uint32_t idx = (word >> (4 * j)) & 15u;
+  if (MASKED) idx |= ((mbits >> (2 * j)) & 3u) << 4;
+  return idx;
+}
+
+// Replays one 16-base word with a per-column threshold test (taken only when the word's minimum score is <= E).
+template <bool MASKED, bool FORWARD>
+__device__ __noinline__ uint32_t replay_word(const uint2* tab, uint32_t word, uint32_t mbits, uint32_t pv, uint32_t mv, int score, int E) {
+  uint32_t hm = 0;
+  for (int s = 0; s < 16; s++) {
+    const int k = FORWARD ? s : 15 - s;
+    const uint2 e = tab[pair_index<MASKED>(word, mbits, k >> 1)];
+    int unused = 0;
+    myers_step((k & 1) ? e.y : e.x, pv, mv, score, unused);
+    hm |= (uint32_t)(score <= E) << k;
+  }
+  return hm;
+}
+
+template <int CHUNK, bool MASKED>
 __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
   constexpr int WPC = CHUNK / 16;           // code words per lane chunk
   constexpr int MPC = CHUNK / 32;           // mask words per lane chunk
   constexpr int CSTR = WPC + 1;             // padded strides: lane l reads word l*CSTR + k -> conflict-free banks
   constexpr int MSTR = MPC + 1;
   constexpr int NV = LANES_PER_TILE + 2;    // virtual chunks: left halo, 256 lanes, right halo
+  constexpr int TAB = MASKED ? 64 : 16;     // entries of one pair table
   __shared__ uint32_t s_codes[NV * CSTR];
-  __shared__ uint32_t s_mask[NV * MSTR];
-  __shared__ uint32_t s_eq[MAX_GUIDES * 16];
+  __shared__ uint32_t s_mask[MASKED ? NV * MSTR : 1];
+  __shared__ uint2 s_tab[2 * TAB];          // [direction][pair index] -> (Eq of base 2j, Eq of base 2j+1)
 
-  const uint32_t tile = a.first_tile + blockIdx.x;
-  const TileInfo ti = a.tiles[tile];
-  if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
-  if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;
-  const bool masked = ti.flag != 0u;
+  uint32_t tile;
+  if (MASKED) {
+    tile = a.tile_list[blockIdx.x];
+  } else {
+    tile = blockIdx.x;
+    const TileInfo ti = a.tiles[tile];
+    if (ti.flag != 0u) return;              // exception tiles go through the MASKED launch, dead tiles nowhere
+  }
+  const uint32_t contig = a.tiles[tile].contig;
+  if (contig == 0xFFFFFFFFu) return;
+  if (a.chrom_index >= 0 && contig != (uint32_t)a.chrom_index) return;
   const int tid = threadIdx.x;
 
   // ---- stream the tile (+ one halo chunk each side) into LDS: 16-byte coalesced loads, padded scatter ----
@@ -66,93 +115,86 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
     const uint4* src = reinterpret_cast<const uint4*>(a.codes + (w0 - WPC));
     constexpr int NQ = NV * WPC / 4;
     for (int q = tid; q < NQ; q += LANES_PER_TILE) {
-      uint4 v = src[q];
-      int i = q * 4;
-      int vc = i / WPC, k = i % WPC;  // WPC is a multiple of 4, so the four words stay in one chunk
+      const uint4 v = src[q];
+      const int i = q * 4;
+      const int vc = i / WPC, k = i % WPC;  // WPC is a multiple of 4, so the four words stay in one chunk
       uint32_t* d = &s_codes[vc * CSTR + k];
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
-  if (masked) {
+  if (MASKED) {
     const uint32_t* src = a.mask + (w0 / 2 - MPC);
     constexpr int NM = NV * MPC;
     for (int i = tid; i < NM; i += LANES_PER_TILE) s_mask[(i / MPC) * MSTR + (i % MPC)] = src[i];
   }
-  for (int i = tid; i < a.n_guides * 16; i += LANES_PER_TILE) {
-    const GuideDev& g = a.guides[i >> 4];
-    s_eq[i] = (i & 8) ? g.peq_b[i & 7] : g.peq_a[i & 7];
-  }
-  __syncthreads();
 
   const int vc = tid + 1;
   const uint32_t* cw = &s_codes[vc * CSTR];
-  const uint32_t* mw = &s_mask[vc * MSTR];
+  const uint32_t* mw = &s_mask[MASKED ? vc * MSTR : 0];
   const uint32_t gword0 = (uint32_t)(w0 + (uint64_t)tid * WPC);
 
   for (int gi = 0; gi < a.n_guides; gi++) {
     const GuideDev& g = a.guides[gi];
+    __syncthreads();                        // previous guide's table no longer in use / tile data visible
+    for (int i = tid; i < 2 * TAB; i += LANES_PER_TILE) {
+      const uint32_t* peq = (i >= TAB) ? g.peq_b : g.peq_a;
+      const int idx = i & (TAB - 1);
+      const int lo = (idx & 3) | ((idx >> 4) & 1) << 2, hi = ((idx >> 2) & 3) | ((idx >> 5) & 1) << 2;
+      s_tab[i] = make_uint2(peq[lo], peq[hi]);
+    }
+    __syncthreads();
     const int L = g.L, E = g.scan_max_edits;
-    const int warm = (L + E + 15) >> 4;  // warm-up words (host guarantees warm <= WPC)
-    const uint32_t* eqA = &s_eq[gi * 16];
-    const uint32_t* eqB = eqA + 8;
+    const int warm = (L + E + 15) >> 4;     // warm-up words (host guarantees warm <= WPC)
+    const uint2* tabA = &s_tab[0];
+    const uint2* tabB = &s_tab[TAB];
 
-    // ---- pass A: left to right, target as is ----
-    {
-      uint32_t pv = 0xFFFFFFFFu, mv = 0u;
-      int score = L;
-      for (int w = -warm; w < WPC; w++) {
-        // w < 0 reads the tail of the left neighbour's chunk: cw[w - 1] skips the pad word
-        const uint32_t word = (w >= 0) ? cw[w] : cw[w - 1];
-        uint32_t mbits = 0;
-        if (masked) {
-          int mwi = (w >= 0) ? (w >> 1) : ((w >> 1) - 1);
-          mbits = (mw[mwi] >> ((w & 1) * 16)) & 0xFFFFu;
-        }
-        uint32_t hm = 0;
+    // Pass A runs left to right over the chunk (target as is); pass B right to left (target complemented = left to
+    // right over the reverse complement).  The two recurrences are independent, so they share one loop for ILP.
+    uint32_t pvA = 0xFFFFFFFFu, mvA = 0u, pvB = 0xFFFFFFFFu, mvB = 0u;
+    int scA = L, scB = L;
+    const int n_it = WPC + warm;
+    for (int it = 0; it < n_it; it++) {
+      const int wa = it - warm;             // < 0: tail of the left neighbour's chunk (cw[wa - 1] skips the pad word)
+      const int wb = WPC - 1 + warm - it;   // >= WPC: head of the right neighbour's chunk (cw[wb + 1])
+      const uint32_t wordA = (wa >= 0) ? cw[wa] : cw[wa - 1];
+      const uint32_t wordB = (wb < WPC) ? cw[wb] : cw[wb + 1];
+      uint32_t mA = 0, mB = 0;
+      if (MASKED) {
+        const int ia = (wa >= 0) ? (wa >> 1) : ((wa >> 1) - 1);
+        const int ib = (wb < WPC) ? (wb >> 1) : ((wb >> 1) + 1);
+        mA = (mw[ia] >> ((wa & 1) * 16)) & 0xFFFFu;
+        mB = (mw[ib] >> ((wb & 1) * 16)) & 0xFFFFu;
+      }
+      const uint32_t pvA0 = pvA, mvA0 = mvA, pvB0 = pvB, mvB0 = mvB;
+      const int scA0 = scA, scB0 = scB;
+      int minA = 0x7FFFFFFF, minB = 0x7FFFFFFF;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-          uint32_t idx = ((word >> (2 * k)) & 3u) | (((mbits >> k) & 1u) << 2);
-          myers_step(eqA[idx], pv, mv, score);
-          hm = (hm << 1) | (uint32_t)(score <= E);
-        }
-        if (w >= 0 && hm != 0) {
-          uint32_t slot = atomicAdd(a.rec_count, 1u);
-          if (slot < a.rec_capacity) {
-            ScanRecord r;
-            r.gword = gword0 + (uint32_t)w;
-            r.info = (__brev(hm) >> 16) | ((uint32_t)gi << 17);
-            a.recs[slot] = r;
-          }
+      for (int j = 0; j < 8; j++) {
+        const uint2 ea = tabA[pair_index<MASKED>(wordA, mA, j)];
+        const uint2 eb = tabB[pair_index<MASKED>(wordB, mB, 7 - j)];
+        myers_step(ea.x, pvA, mvA, scA, minA);
+        myers_step(eb.y, pvB, mvB, scB, minB);
+        myers_step(ea.y, pvA, mvA, scA, minA);
+        myers_step(eb.x, pvB, mvB, scB, minB);
+      }
+      if (wa >= 0 && minA <= E) {
+        const uint32_t hm = replay_word<MASKED, true>(tabA, wordA, mA, pvA0, mvA0, scA0, E);
+        const uint32_t slot = atomicAdd(a.rec_count, 1u);
+        if (slot < a.rec_capacity) {
+          ScanRecord r;
+          r.gword = gword0 + (uint32_t)wa;
+          r.info = hm | ((uint32_t)gi << 17);
+          a.recs[slot] = r;
         }
       }
-    }
-    // ---- pass B: right to left, target complemented (= left to right over the reverse complement) ----
-    {
-      uint32_t pv = 0xFFFFFFFFu, mv = 0u;
-      int score = L;
-      for (int w = WPC - 1 + warm; w >= 0; w--) {
-        // w >= WPC reads the head of the right neighbour's chunk: skip the pad word
-        const uint32_t word = (w < WPC) ? cw[w] : cw[w + 1];
-        uint32_t mbits = 0;
-        if (masked) {
-          int mwi = (w < WPC) ? (w >> 1) : ((w >> 1) + 1);
-          mbits = (mw[mwi] >> ((w & 1) * 16)) & 0xFFFFu;
-        }
-        uint32_t hm = 0;
-#pragma unroll
-        for (int k = 15; k >= 0; k--) {
-          uint32_t idx = ((word >> (2 * k)) & 3u) | (((mbits >> k) & 1u) << 2);
-          myers_step(eqB[idx], pv, mv, score);
-          hm = (hm << 1) | (uint32_t)(score <= E);
-        }
-        if (w < WPC && hm != 0) {
-          uint32_t slot = atomicAdd(a.rec_count, 1u);
-          if (slot < a.rec_capacity) {
-            ScanRecord r;
-            r.gword = gword0 + (uint32_t)w;
-            r.info = hm | (1u << 16) | ((uint32_t)gi << 17);
-            a.recs[slot] = r;
-          }
+      if (wb < WPC && minB <= E) {
+        const uint32_t hm = replay_word<MASKED, false>(tabB, wordB, mB, pvB0, mvB0, scB0, E);
+        const uint32_t slot = atomicAdd(a.rec_count, 1u);
+        if (slot < a.rec_capacity) {
+          ScanRecord r;
+          r.gword = gword0 + (uint32_t)wb;
+          r.info = hm | (1u << 16) | ((uint32_t)gi << 17);
+          a.recs[slot] = r;
         }
       }
     }
@@ -405,16 +447,27 @@ __global__ void dpp_selftest_kernel(int* out) {
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 
-hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream) {
-  dim3 grid(n_tiles), block(LANES_PER_TILE);
+template <bool MASKED>
+static hipError_t launch_scan_t(const ScanArgs& a, int chunk, uint32_t n_blocks, hipStream_t stream) {
+  if (n_blocks == 0) return hipSuccess;
+  dim3 grid(n_blocks), block(LANES_PER_TILE);
   switch (chunk) {
-    case 64:  hipLaunchKernelGGL(scan_kernel<64>, grid, block, 0, stream, a); break;
-    case 128: hipLaunchKernelGGL(scan_kernel<128>, grid, block, 0, stream, a); break;
-    case 256: hipLaunchKernelGGL(scan_kernel<256>, grid, block, 0, stream, a); break;
-    case 512: hipLaunchKernelGGL(scan_kernel<512>, grid, block, 0, stream, a); break;
+    case 64:  hipLaunchKernelGGL((scan_kernel<64, MASKED>), grid, block, 0, stream, a); break;
+    case 128: hipLaunchKernelGGL((scan_kernel<128, MASKED>), grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((scan_kernel<256, MASKED>), grid, block, 0, stream, a); break;
+    case 512: hipLaunchKernelGGL((scan_kernel<512, MASKED>), grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+// Plain tiles: one workgroup per tile of the packed space (exception / dead tiles exit at once).
+hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream) {
+  return launch_scan_t<false>(a, chunk, n_tiles, stream);
+}
+// Exception tiles (N runs, IUPAC codes, contig ends): one workgroup per entry of a.tile_list.
+hipError_t launch_scan_masked(const ScanArgs& a, int chunk, uint32_t n_listed, hipStream_t stream) {
+  return launch_scan_t<true>(a, chunk, n_listed, stream);
 }
 
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {

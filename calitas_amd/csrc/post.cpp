@@ -4,7 +4,11 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 
 namespace calitas {
@@ -227,19 +231,70 @@ const char* const kColumns[34] = {
 
 }  // namespace
 
-std::string hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
-                     const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
-                     uint64_t* n_rows) {
+// One hits.txt row (RH:210-254) for an accepted alignment, appended to `out`.
+static void append_row(std::string& out, const PackedRef& ref, const GuideHost& g, const std::string& guide_id,
+                       const calitas_aln_t& a, const std::string& version, const std::string& search_pam, const std::string& args,
+                       const std::string& time_stamp) {
+  std::string pg, pa, pt;
+  const bool minus = a.strand == '-';
+  padded_strings(ref, g, a, pg, pa, pt);
+  const std::string query = g.query_for(a.pam_index);
+  // unpaddedTargetWithoutPam GA:111-115
+  int ps = -1, pe = -1;
+  for (int i = 0; i < (int)pg.size(); i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
+  std::string unpadded_target;
+  for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target += pt[i];
+  const int contig = a.contig_index;
+  // RH:213-216 (coordinates are given in genome orientation, content is strand aware)
+  const std::string tenLeft = fetch_flank(ref, contig, a.guide_start_offset + 1 - 10, a.guide_start_offset, minus);
+  const std::string tenRight = fetch_flank(ref, contig, a.guide_end_offset + 1, a.guide_end_offset + 10, minus);
+  const std::string eightLeft = fetch_flank(ref, contig, a.start_offset + 1 - 8, a.start_offset, minus);
+  const std::string eightRight = fetch_flank(ref, contig, a.end_offset + 1, a.end_offset + 8, minus);
+  std::string pam_used;
+  for (char c : query) if (c >= 'a' && c <= 'z') pam_used += c;   // RH:229
+  const int mm = (int)std::count(pa.begin(), pa.end(), '.'), gp = (int)std::count(pa.begin(), pa.end(), '~');
+
+  out += guide_id; out += '\t';
+  out += g.protospacer; out += '\t';
+  out += ref.genome_build; out += '\t';
+  out += ref.names[contig]; out += '\t';
+  out += std::to_string(a.guide_start_offset); out += '\t';
+  out += std::to_string(a.guide_end_offset); out += '\t';
+  out += (char)a.strand; out += '\t';
+  out += unpadded_target; out += '\t';
+  out += minus ? tenRight : tenLeft; out += '\t';      // RH:227
+  out += minus ? tenLeft : tenRight; out += '\t';      // RH:228
+  out += pam_used; out += '\t';
+  out += "\t\t\t\t";                                   // variant_id, variant_description, variant_vcf, allele_frequency: None
+  out += std::to_string(a.score); out += '\t';
+  out += std::to_string(ga_count(pg, pa, false, false, true, false)); out += '\t';   // guide_mm GA:103
+  out += std::to_string(ga_count(pg, pa, false, false, false, true)); out += '\t';   // guide_gaps GA:104
+  out += std::to_string(ga_count(pg, pa, false, false, true, true)); out += '\t';    // guide_mm_plus_gaps GA:105
+  out += std::to_string(ga_count(pg, pa, true, true, true, false)); out += '\t';     // pam_mm GA:106
+  out += std::to_string(mm + gp); out += '\t';                                       // total_mm_plus_gaps = edits GA:101
+  out += pg; out += '\t'; out += pa; out += '\t'; out += pt; out += '\t';
+  out += minus ? eightRight : eightLeft; out += '\t';  // RH:243
+  out += minus ? eightLeft : eightRight; out += '\t';  // RH:244
+  out += cigar_of(a); out += '\t';
+  out += std::to_string(g.protospacer.size()); out += '\t';
+  out += std::to_string(unpadded_target.size()); out += '\t';
+  out += "CALITAS:SearchReference"; out += '\t';       // SR:522
+  out += version; out += '\t';
+  out += search_pam; out += '\t';
+  out += args; out += '\t';
+  out += time_stamp; out += '\n';
+}
+
+char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
+               const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
+               uint64_t* n_rows, WorkerPool* pool) {
+  WorkerPool serial(1);
+  if (!pool) pool = &serial;
+  const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_start = tnow();
   const int max_total = p.max_total_diffs >= 0 ? p.max_total_diffs
                                                : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;  // SR:493
-  // ---- removeOverlaps (SR:653-675) on (chromosome, strand) groups; contig index doubles as the dictionary index ----
-  std::vector<Lite> all(n);
-  for (uint64_t i = 0; i < n; i++) {
-    const calitas_aln_t& a = alns[i];
-    int tlen = 0;
-    for (int k = 0; k < a.n_ops; k++) if (consumes_target(a.ops[k])) tlen++;
-    all[i] = Lite{a.contig_index, a.guide_start_offset, a.guide_start_offset + tlen - 1, (char)a.strand, a.score, i};  // RH:135-138
-  }
   auto by_hit_order = [](const Lite& x, const Lite& y) {   // RH:284
     if (x.contig != y.contig) return x.contig < y.contig;
     if (x.start != y.start) return x.start < y.start;
@@ -250,80 +305,102 @@ std::string hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string
     if (x.contig != y.contig) return 0;
     return std::max(0, std::min(x.end, y.end) - std::max(x.start, y.start));
   };
-  std::map<std::pair<int, char>, std::vector<Lite>> groups;
-  for (auto& l : all) groups[{l.contig, l.strand}].push_back(l);
-  std::vector<Lite> keepers;
-  for (auto& kv : groups) {
-    auto& hs = kv.second;
-    std::stable_sort(hs.begin(), hs.end(), by_hit_order);
-    size_t i = 0;
-    while (i < hs.size()) {
-      const Lite hit = hs[i++];
-      while (i < hs.size() && overlap(hs[i], hit) >= p.max_overlap && hs[i].score <= hit.score) i++;
-      if (i >= hs.size() || overlap(hs[i], hit) < p.max_overlap) keepers.push_back(hit);
-    }
+  // ---- removeOverlaps (SR:653-675): groups are (chromosome, strand); the contig index doubles as the dictionary
+  // index.  Groups are independent, so they are processed in parallel; arrival order inside a group is preserved.
+  const int n_contigs = (int)ref.contigs.size();
+  std::vector<std::vector<Lite>> groups((size_t)n_contigs * 2);
+  for (uint64_t i = 0; i < n; i++) {
+    const calitas_aln_t& a = alns[i];
+    int tlen = 0;
+    for (int k = 0; k < a.n_ops; k++) if (consumes_target(a.ops[k])) tlen++;
+    groups[(size_t)a.contig_index * 2 + (a.strand == '-' ? 1 : 0)].push_back(
+        Lite{a.contig_index, a.guide_start_offset, a.guide_start_offset + tlen - 1, (char)a.strand, a.score, i});  // RH:135-138
   }
-  std::stable_sort(keepers.begin(), keepers.end(), by_hit_order);   // SR:647
+  std::vector<std::vector<Lite>> kept_by_contig(n_contigs);
+  {
+    std::atomic<size_t> next(0);
+    std::vector<std::vector<Lite>> kept_group(groups.size());
+    pool->run([&](int) {
+      for (;;) {
+        size_t gi = next.fetch_add(1);
+        if (gi >= groups.size()) break;
+        auto& hs = groups[gi];
+        if (hs.empty()) continue;
+        std::stable_sort(hs.begin(), hs.end(), by_hit_order);
+        auto& keep = kept_group[gi];
+        size_t i = 0;
+        while (i < hs.size()) {
+          const Lite hit = hs[i++];
+          while (i < hs.size() && overlap(hs[i], hit) >= p.max_overlap && hs[i].score <= hit.score) i++;
+          if (i >= hs.size() || overlap(hs[i], hit) < p.max_overlap) keep.push_back(hit);
+        }
+      }
+    });
+    // final ReferenceHit.sort (SR:647): per contig, the two strand groups are merged; equal keys cannot cross groups
+    std::atomic<size_t> nextc(0);
+    pool->run([&](int) {
+      for (;;) {
+        size_t c = nextc.fetch_add(1);
+        if (c >= (size_t)n_contigs) break;
+        auto& out = kept_by_contig[c];
+        out.resize(kept_group[2 * c].size() + kept_group[2 * c + 1].size());
+        std::merge(kept_group[2 * c].begin(), kept_group[2 * c].end(), kept_group[2 * c + 1].begin(), kept_group[2 * c + 1].end(),
+                   out.begin(), by_hit_order);
+      }
+    });
+  }
+  std::vector<Lite> keepers;
+  for (auto& v : kept_by_contig) keepers.insert(keepers.end(), v.begin(), v.end());
+  auto t_dedup = tnow();
 
-  // ---- rows (RH:210-254) ----
+  // ---- rows (RH:210-254), built in parallel blocks and concatenated in order ----
   std::string search_pam;
   for (size_t i = 0; i < g.pams.size(); i++) { if (i) search_pam += ','; search_pam += g.pams[i]; }   // RH:207
   const std::string args = core_parameters(p, max_total);
-  std::string out;
-  for (int i = 0; i < 34; i++) { if (i) out += '\t'; out += kColumns[i]; }
-  out += '\n';
-  std::string pg, pa, pt;
-  for (auto& k : keepers) {
-    const calitas_aln_t& a = alns[k.idx];
-    const bool minus = a.strand == '-';
-    padded_strings(ref, g, a, pg, pa, pt);
-    const std::string query = g.query_for(a.pam_index);
-    // unpaddedTargetWithoutPam GA:111-115
-    int ps = -1, pe = -1;
-    for (int i = 0; i < (int)pg.size(); i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
-    std::string unpadded_target;
-    for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target += pt[i];
-    const int contig = a.contig_index;
-    // RH:213-216 (coordinates are given in genome orientation, content is strand aware)
-    const std::string tenLeft = fetch_flank(ref, contig, a.guide_start_offset + 1 - 10, a.guide_start_offset, minus);
-    const std::string tenRight = fetch_flank(ref, contig, a.guide_end_offset + 1, a.guide_end_offset + 10, minus);
-    const std::string eightLeft = fetch_flank(ref, contig, a.start_offset + 1 - 8, a.start_offset, minus);
-    const std::string eightRight = fetch_flank(ref, contig, a.end_offset + 1, a.end_offset + 8, minus);
-    std::string pam_used;
-    for (char c : query) if (c >= 'a' && c <= 'z') pam_used += c;   // RH:229
-    const int mm = (int)std::count(pa.begin(), pa.end(), '.'), gp = (int)std::count(pa.begin(), pa.end(), '~');
-
-    out += guide_id; out += '\t';
-    out += g.protospacer; out += '\t';
-    out += ref.genome_build; out += '\t';
-    out += ref.names[contig]; out += '\t';
-    out += std::to_string(a.guide_start_offset); out += '\t';
-    out += std::to_string(a.guide_end_offset); out += '\t';
-    out += (char)a.strand; out += '\t';
-    out += unpadded_target; out += '\t';
-    out += minus ? tenRight : tenLeft; out += '\t';      // RH:227
-    out += minus ? tenLeft : tenRight; out += '\t';      // RH:228
-    out += pam_used; out += '\t';
-    out += "\t\t\t\t";                                   // variant_id, variant_description, variant_vcf, allele_frequency: None
-    out += std::to_string(a.score); out += '\t';
-    out += std::to_string(ga_count(pg, pa, false, false, true, false)); out += '\t';   // guide_mm GA:103
-    out += std::to_string(ga_count(pg, pa, false, false, false, true)); out += '\t';   // guide_gaps GA:104
-    out += std::to_string(ga_count(pg, pa, false, false, true, true)); out += '\t';    // guide_mm_plus_gaps GA:105
-    out += std::to_string(ga_count(pg, pa, true, true, true, false)); out += '\t';     // pam_mm GA:106
-    out += std::to_string(mm + gp); out += '\t';                                       // total_mm_plus_gaps = edits GA:101
-    out += pg; out += '\t'; out += pa; out += '\t'; out += pt; out += '\t';
-    out += minus ? eightRight : eightLeft; out += '\t';  // RH:243
-    out += minus ? eightLeft : eightRight; out += '\t';  // RH:244
-    out += cigar_of(a); out += '\t';
-    out += std::to_string(g.protospacer.size()); out += '\t';
-    out += std::to_string(unpadded_target.size()); out += '\t';
-    out += "CALITAS:SearchReference"; out += '\t';       // SR:522
-    out += version; out += '\t';
-    out += search_pam; out += '\t';
-    out += args; out += '\t';
-    out += time_stamp; out += '\n';
+  std::string header;
+  for (int i = 0; i < 34; i++) { if (i) header += '\t'; header += kColumns[i]; }
+  header += '\n';
+  const size_t BLOCK = 512;
+  const size_t n_blocks = (keepers.size() + BLOCK - 1) / BLOCK;
+  std::vector<std::string> parts(n_blocks);
+  {
+    std::atomic<size_t> next(0);
+    pool->run([&](int) {
+      for (;;) {
+        size_t b = next.fetch_add(1);
+        if (b >= n_blocks) break;
+        std::string& s = parts[b];
+        s.reserve(BLOCK * 420);
+        size_t e = std::min(keepers.size(), (b + 1) * BLOCK);
+        for (size_t i = b * BLOCK; i < e; i++) append_row(s, ref, g, guide_id, alns[keepers[i].idx], version, search_pam, args, time_stamp);
+      }
+    });
+  }
+  size_t total = header.size();
+  std::vector<size_t> offs(n_blocks);
+  for (size_t b = 0; b < n_blocks; b++) { offs[b] = total; total += parts[b].size(); }
+  auto t_rows = tnow();
+  char* out = (char*)std::malloc(total + 1);
+  if (!out) return nullptr;
+  out[total] = 0;
+  std::memcpy(out, header.data(), header.size());
+  {
+    std::atomic<size_t> next(0);
+    pool->run([&](int) {
+      for (;;) {
+        size_t b = next.fetch_add(1);
+        if (b >= n_blocks) break;
+        std::memcpy(out + offs[b], parts[b].data(), parts[b].size());
+        std::string().swap(parts[b]);
+      }
+    });
   }
   if (n_rows) *n_rows = keepers.size();
+  if (trace) {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[calitas] hits_tsv: removeOverlaps+sort %.2f ms, rows %.2f ms, concat %.2f ms (%zu rows, %zu bytes)\n",
+                 ms(t_start, t_dedup), ms(t_dedup, t_rows), ms(t_rows, tnow()), keepers.size(), total);
+  }
   return out;
 }
 

@@ -6,6 +6,7 @@
 
 #include "../../include/calitas_hip.h"
 #include "common.hpp"
+#include "parallel.hpp"
 #include "refpack.hpp"
 
 namespace calitas {
@@ -35,9 +36,9 @@ void window_filter(const calitas_aln_t* alns, int n, int max_total_diffs, int ma
 // Padded strings in guide orientation.
 void padded_strings(const PackedRef& ref, const GuideHost& g, const calitas_aln_t& a, std::string& pg, std::string& pa, std::string& pt);
 
-// hits.txt text for one guide's alignments.
-std::string hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
-                     const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
-                     uint64_t* n_rows);
+// hits.txt text for one guide's alignments: malloc'd, NUL-terminated (nullptr when out of memory).
+char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
+               const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
+               uint64_t* n_rows, WorkerPool* pool = nullptr);
 
 }  // namespace calitas

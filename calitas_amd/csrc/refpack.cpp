@@ -181,6 +181,7 @@ void pack_reference(PackedRef& out, int n_contigs, const char* const* names, con
     bool anyExc, allDead;
     classify(hlo, hhi, anyExc, allDead);
     out.tiles[t].flag = allDead ? 2u : (anyExc ? 1u : 0u);
+    if (out.tiles[t].flag == 1u && out.tiles[t].contig != 0xFFFFFFFFu) out.masked_tiles.push_back((uint32_t)t);
   }
 }
 

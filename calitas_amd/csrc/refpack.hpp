@@ -15,6 +15,7 @@ struct PackedRef {
   std::vector<uint32_t> mask;         // total_packed / 32
   std::vector<Run> runs;              // sorted by start
   std::vector<TileInfo> tiles;        // total_packed / tile
+  std::vector<uint32_t> masked_tiles; // indices of tiles with flag 1 (scanned by the exception-aware kernel variant)
   std::string genome_build = "unknown";
 
   // Upper-cased base at a packed position (what the reference sees after StringUtil.toUpperCase, SearchReference.scala:67).
