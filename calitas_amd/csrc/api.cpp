@@ -330,7 +330,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
     ScanArgs sa{};
     sa.codes = ctx->d_codes; sa.mask = ctx->d_mask; sa.tiles = ctx->d_tiles; sa.guides = ctx->d_guides;
-    sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap; sa.tile_list = ctx->d_tile_list;
+    sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
     sa.n_guides = n_guides; sa.chrom_index = p.chrom_index;
     AlignArgs aa{};
     aa.codes = ctx->d_codes; aa.mask = ctx->d_mask; aa.runs = ctx->d_runs; aa.n_runs = (int64_t)ref.runs.size();
@@ -346,7 +346,6 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     HIP_TRY(ctx, launch_scan(sa, ref.chunk, n_tiles, ctx->stream));
-    HIP_TRY(ctx, launch_scan_masked(sa, ref.chunk, (uint32_t)ref.masked_tiles.size(), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));

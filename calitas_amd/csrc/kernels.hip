@@ -33,6 +33,7 @@ namespace calitas {
 // the running bottom-row score (v_add_co / v_addc on gfx950).
 __device__ __forceinline__ void myers_step(uint32_t eq, uint32_t& pv, uint32_t& mv, int& score, int& smin) {
   // Hand-scheduled: 13 VALU instructions per column (hipcc's own selection of the same expression needs 17).
+  // v_min_i32 issues at ~0.6x the rate of v_or_b32 on gfx950 (tools/valu_bench2.hip), hence the sign-bit accumulator.
   //   t  = (eq & pv) + pv
   //   mh = pv & ((t ^ pv) | eq)            bitop3(pv, t, eq)  = 0xb0
   //   xh = (t ^ pv) | eq                   bitop3(t, pv, eq)  = 0xbe
@@ -41,7 +42,7 @@ __device__ __forceinline__ void myers_step(uint32_t eq, uint32_t& pv, uint32_t& 
   //   ph <<= 1, score += carry;  mh <<= 1, score -= carry
   //   pv = mh | ~(xv | ph)                 bitop3(mh, xv, ph) = 0xf1
   //   mv = ph & xv
-  //   smin = min(smin, score)
+  //   sacc |= score          (the caller keeps score biased by -(E+1): the sign bit of sacc = "some column <= E")
   uint32_t t, xh, ph, mh, xv;
   asm("v_and_b32 %5, %9, %0\n\t"
       "v_add_u32 %5, %5, %0\n\t"
@@ -55,9 +56,48 @@ __device__ __forceinline__ void myers_step(uint32_t eq, uint32_t& pv, uint32_t& 
       "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
       "v_bitop3_b32 %0, %7, %8, %4 bitop3:0xf1\n\t"
       "v_and_b32 %1, %4, %8\n\t"
-      "v_min_i32 %3, %3, %2"
+      "v_or_b32 %3, %3, %2"
       : "+v"(pv), "+v"(mv), "+v"(score), "+v"(smin), "=&v"(ph), "=&v"(t), "=&v"(xh), "=&v"(mh), "=&v"(xv)
       : "v"(eq)
+      : "vcc");
+}
+
+// Two independent columns (pass A and pass B) interleaved instruction by instruction so that dependent VALU
+// instructions of one recurrence are never adjacent; pass B carries through an SGPR pair instead of VCC.
+__device__ __forceinline__ void myers_step2(uint32_t eqa, uint32_t& pva, uint32_t& mva, int& sca, int& mina,
+                                            uint32_t eqb, uint32_t& pvb, uint32_t& mvb, int& scb, int& minb) {
+  uint32_t ta, xha, pha, mha, xva, tb, xhb, phb, mhb, xvb;
+  unsigned long long cb;
+  asm("v_and_b32 %9, %19, %0\n\t"
+      "v_and_b32 %14, %20, %4\n\t"
+      "v_add_u32 %9, %9, %0\n\t"
+      "v_add_u32 %14, %14, %4\n\t"
+      "v_bitop3_b32 %11, %0, %9, %19 bitop3:0xb0\n\t"
+      "v_bitop3_b32 %16, %4, %14, %20 bitop3:0xb0\n\t"
+      "v_bitop3_b32 %10, %9, %0, %19 bitop3:0xbe\n\t"
+      "v_bitop3_b32 %15, %14, %4, %20 bitop3:0xbe\n\t"
+      "v_or_b32 %12, %19, %1\n\t"
+      "v_or_b32 %17, %20, %5\n\t"
+      "v_bitop3_b32 %8, %1, %10, %0 bitop3:0xf1\n\t"
+      "v_bitop3_b32 %13, %5, %15, %4 bitop3:0xf1\n\t"
+      "v_add_co_u32 %11, vcc, %11, %11\n\t"
+      "v_add_co_u32 %16, %18, %16, %16\n\t"
+      "v_subb_co_u32 %2, vcc, %2, 0, vcc\n\t"
+      "v_subb_co_u32 %6, %18, %6, 0, %18\n\t"
+      "v_add_co_u32 %8, vcc, %8, %8\n\t"
+      "v_add_co_u32 %13, %18, %13, %13\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32 %6, %18, 0, %6, %18\n\t"
+      "v_bitop3_b32 %0, %11, %12, %8 bitop3:0xf1\n\t"
+      "v_bitop3_b32 %4, %16, %17, %13 bitop3:0xf1\n\t"
+      "v_and_b32 %1, %8, %12\n\t"
+      "v_and_b32 %5, %13, %17\n\t"
+      "v_or_b32 %3, %3, %2\n\t"
+      "v_or_b32 %7, %7, %6"
+      : "+v"(pva), "+v"(mva), "+v"(sca), "+v"(mina), "+v"(pvb), "+v"(mvb), "+v"(scb), "+v"(minb),
+        "=&v"(pha), "=&v"(ta), "=&v"(xha), "=&v"(mha), "=&v"(xva),
+        "=&v"(phb), "=&v"(tb), "=&v"(xhb), "=&v"(mhb), "=&v"(xvb), "=&s"(cb)
+      : "v"(eqa), "v"(eqb)
       : "vcc");
 }
 
@@ -72,41 +112,25 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t word, uint32_t mbits, in
 
 // Replays one 16-base word with a per-column threshold test (taken only when the word's minimum score is <= E).
 template <bool MASKED, bool FORWARD>
-__device__ __noinline__ uint32_t replay_word(const uint2* tab, uint32_t word, uint32_t mbits, uint32_t pv, uint32_t mv, int score, int E) {
-  uint32_t hm = 0;
+__device__ __noinline__ uint32_t replay_word(const uint2* tab, uint32_t word, uint32_t mbits, uint32_t pv, uint32_t mv, int score) {
+  uint32_t hm = 0;   // score is biased by -(E+1): negative = candidate column
   for (int s = 0; s < 16; s++) {
     const int k = FORWARD ? s : 15 - s;
     const uint2 e = tab[pair_index<MASKED>(word, mbits, k >> 1)];
     int unused = 0;
     myers_step((k & 1) ? e.y : e.x, pv, mv, score, unused);
-    hm |= (uint32_t)(score <= E) << k;
+    hm |= (uint32_t)(score < 0) << k;
   }
   return hm;
 }
 
 template <int CHUNK, bool MASKED>
-__global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
+__device__ __forceinline__ void scan_tile(const ScanArgs& a, uint32_t tile, uint32_t* s_codes, uint2* s_tab) {
   constexpr int WPC = CHUNK / 16;           // code words per lane chunk
   constexpr int MPC = CHUNK / 32;           // mask words per lane chunk
-  constexpr int CSTR = WPC + 1;             // padded strides: lane l reads word l*CSTR + k -> conflict-free banks
-  constexpr int MSTR = MPC + 1;
+  constexpr int CSTR = WPC + 1;             // padded stride: lane l reads word l*CSTR + k -> conflict-free banks
   constexpr int NV = LANES_PER_TILE + 2;    // virtual chunks: left halo, 256 lanes, right halo
   constexpr int TAB = MASKED ? 64 : 16;     // entries of one pair table
-  __shared__ uint32_t s_codes[NV * CSTR];
-  __shared__ uint32_t s_mask[MASKED ? NV * MSTR : 1];
-  __shared__ uint2 s_tab[2 * TAB];          // [direction][pair index] -> (Eq of base 2j, Eq of base 2j+1)
-
-  uint32_t tile;
-  if (MASKED) {
-    tile = a.tile_list[blockIdx.x];
-  } else {
-    tile = blockIdx.x;
-    const TileInfo ti = a.tiles[tile];
-    if (ti.flag != 0u) return;              // exception tiles go through the MASKED launch, dead tiles nowhere
-  }
-  const uint32_t contig = a.tiles[tile].contig;
-  if (contig == 0xFFFFFFFFu) return;
-  if (a.chrom_index >= 0 && contig != (uint32_t)a.chrom_index) return;
   const int tid = threadIdx.x;
 
   // ---- stream the tile (+ one halo chunk each side) into LDS: 16-byte coalesced loads, padded scatter ----
@@ -122,15 +146,10 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
-  if (MASKED) {
-    const uint32_t* src = a.mask + (w0 / 2 - MPC);
-    constexpr int NM = NV * MPC;
-    for (int i = tid; i < NM; i += LANES_PER_TILE) s_mask[(i / MPC) * MSTR + (i % MPC)] = src[i];
-  }
-
-  const int vc = tid + 1;
-  const uint32_t* cw = &s_codes[vc * CSTR];
-  const uint32_t* mw = &s_mask[MASKED ? vc * MSTR : 0];
+  const uint32_t* cw = &s_codes[(tid + 1) * CSTR];
+  // exception bits are rare (N-run edges, contig ends, IUPAC codes): the few tiles that have them read the 1-bit
+  // mask straight from global memory, one word per 32 bases, instead of spending LDS on it
+  const uint32_t* gm = a.mask + (w0 / 2 + (uint64_t)tid * MPC);
   const uint32_t gword0 = (uint32_t)(w0 + (uint64_t)tid * WPC);
 
   for (int gi = 0; gi < a.n_guides; gi++) {
@@ -150,8 +169,9 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
 
     // Pass A runs left to right over the chunk (target as is); pass B right to left (target complemented = left to
     // right over the reverse complement).  The two recurrences are independent, so they share one loop for ILP.
+    // Scores are kept biased by -(E+1): "score <= E" is the sign bit.
     uint32_t pvA = 0xFFFFFFFFu, mvA = 0u, pvB = 0xFFFFFFFFu, mvB = 0u;
-    int scA = L, scB = L;
+    int scA = L - E - 1, scB = L - E - 1;
     const int n_it = WPC + warm;
     for (int it = 0; it < n_it; it++) {
       const int wa = it - warm;             // < 0: tail of the left neighbour's chunk (cw[wa - 1] skips the pad word)
@@ -160,25 +180,21 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
       const uint32_t wordB = (wb < WPC) ? cw[wb] : cw[wb + 1];
       uint32_t mA = 0, mB = 0;
       if (MASKED) {
-        const int ia = (wa >= 0) ? (wa >> 1) : ((wa >> 1) - 1);
-        const int ib = (wb < WPC) ? (wb >> 1) : ((wb >> 1) + 1);
-        mA = (mw[ia] >> ((wa & 1) * 16)) & 0xFFFFu;
-        mB = (mw[ib] >> ((wb & 1) * 16)) & 0xFFFFu;
+        mA = (gm[wa >> 1] >> ((wa & 1) * 16)) & 0xFFFFu;
+        mB = (gm[wb >> 1] >> ((wb & 1) * 16)) & 0xFFFFu;
       }
       const uint32_t pvA0 = pvA, mvA0 = mvA, pvB0 = pvB, mvB0 = mvB;
       const int scA0 = scA, scB0 = scB;
-      int minA = 0x7FFFFFFF, minB = 0x7FFFFFFF;
+      int accA = 0, accB = 0;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const uint2 ea = tabA[pair_index<MASKED>(wordA, mA, j)];
         const uint2 eb = tabB[pair_index<MASKED>(wordB, mB, 7 - j)];
-        myers_step(ea.x, pvA, mvA, scA, minA);
-        myers_step(eb.y, pvB, mvB, scB, minB);
-        myers_step(ea.y, pvA, mvA, scA, minA);
-        myers_step(eb.x, pvB, mvB, scB, minB);
+        myers_step2(ea.x, pvA, mvA, scA, accA, eb.y, pvB, mvB, scB, accB);
+        myers_step2(ea.y, pvA, mvA, scA, accA, eb.x, pvB, mvB, scB, accB);
       }
-      if (wa >= 0 && minA <= E) {
-        const uint32_t hm = replay_word<MASKED, true>(tabA, wordA, mA, pvA0, mvA0, scA0, E);
+      if (wa >= 0 && accA < 0) {
+        const uint32_t hm = replay_word<MASKED, true>(tabA, wordA, mA, pvA0, mvA0, scA0);
         const uint32_t slot = atomicAdd(a.rec_count, 1u);
         if (slot < a.rec_capacity) {
           ScanRecord r;
@@ -187,8 +203,8 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
           a.recs[slot] = r;
         }
       }
-      if (wb < WPC && minB <= E) {
-        const uint32_t hm = replay_word<MASKED, false>(tabB, wordB, mB, pvB0, mvB0, scB0, E);
+      if (wb < WPC && accB < 0) {
+        const uint32_t hm = replay_word<MASKED, false>(tabB, wordB, mB, pvB0, mvB0, scB0);
         const uint32_t slot = atomicAdd(a.rec_count, 1u);
         if (slot < a.rec_capacity) {
           ScanRecord r;
@@ -199,6 +215,20 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
       }
     }
   }
+}
+
+// One workgroup per tile of the packed space.  Dead tiles (nothing but upper-case N / padding, which every window
+// trims away) exit at once; tiles with exception bases take the MASKED instantiation (block-uniform branch).
+template <int CHUNK>
+__global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
+  __shared__ uint32_t s_codes[(LANES_PER_TILE + 2) * (CHUNK / 16 + 1)];
+  __shared__ uint2 s_tab[2 * 64];           // [direction][pair index] -> (Eq of base 2j, Eq of base 2j+1)
+  const uint32_t tile = blockIdx.x;
+  const TileInfo ti = a.tiles[tile];
+  if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
+  if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;
+  if (ti.flag != 0u) scan_tile<CHUNK, true>(a, tile, s_codes, s_tab);
+  else scan_tile<CHUNK, false>(a, tile, s_codes, s_tab);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -447,27 +477,17 @@ __global__ void dpp_selftest_kernel(int* out) {
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 
-template <bool MASKED>
-static hipError_t launch_scan_t(const ScanArgs& a, int chunk, uint32_t n_blocks, hipStream_t stream) {
-  if (n_blocks == 0) return hipSuccess;
-  dim3 grid(n_blocks), block(LANES_PER_TILE);
+hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream) {
+  if (n_tiles == 0) return hipSuccess;
+  dim3 grid(n_tiles), block(LANES_PER_TILE);
   switch (chunk) {
-    case 64:  hipLaunchKernelGGL((scan_kernel<64, MASKED>), grid, block, 0, stream, a); break;
-    case 128: hipLaunchKernelGGL((scan_kernel<128, MASKED>), grid, block, 0, stream, a); break;
-    case 256: hipLaunchKernelGGL((scan_kernel<256, MASKED>), grid, block, 0, stream, a); break;
-    case 512: hipLaunchKernelGGL((scan_kernel<512, MASKED>), grid, block, 0, stream, a); break;
+    case 64:  hipLaunchKernelGGL(scan_kernel<64>, grid, block, 0, stream, a); break;
+    case 128: hipLaunchKernelGGL(scan_kernel<128>, grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL(scan_kernel<256>, grid, block, 0, stream, a); break;
+    case 512: hipLaunchKernelGGL(scan_kernel<512>, grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
-}
-
-// Plain tiles: one workgroup per tile of the packed space (exception / dead tiles exit at once).
-hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream) {
-  return launch_scan_t<false>(a, chunk, n_tiles, stream);
-}
-// Exception tiles (N runs, IUPAC codes, contig ends): one workgroup per entry of a.tile_list.
-hipError_t launch_scan_masked(const ScanArgs& a, int chunk, uint32_t n_listed, hipStream_t stream) {
-  return launch_scan_t<true>(a, chunk, n_listed, stream);
 }
 
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {

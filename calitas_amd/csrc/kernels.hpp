@@ -10,7 +10,6 @@ struct ScanArgs {
   const uint32_t* codes;
   const uint32_t* mask;
   const TileInfo* tiles;
-  const uint32_t* tile_list;   // tiles with exception bases (flag 1), for the masked launch
   const GuideDev* guides;
   ScanRecord* recs;
   uint32_t* rec_count;
@@ -39,7 +38,6 @@ struct AlignArgs {
 };
 
 hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream);
-hipError_t launch_scan_masked(const ScanArgs& a, int chunk, uint32_t n_listed, hipStream_t stream);
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_dpp_selftest(int* out, hipStream_t stream);
 

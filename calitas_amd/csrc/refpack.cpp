@@ -2,6 +2,7 @@
 #include "refpack.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <thread>
@@ -31,6 +32,7 @@ int pick_chunk(uint64_t total_bases) {
   // Aim for >= 2048 tiles so 256 CUs see several waves of workgroups; a lane re-scans 32 warm-up bases per direction,
   // so larger chunks waste less (32/chunk) but give fewer workgroups.
   int chunk = 512;
+  if (const char* e = std::getenv("CALITAS_CHUNK")) { int v = std::atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) return v; }
   while (chunk > 64 && total_bases / ((uint64_t)chunk * LANES_PER_TILE) < 2048) chunk >>= 1;
   return chunk;
 }
