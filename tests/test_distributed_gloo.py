@@ -1,0 +1,87 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU partition logic in calitas_amd/shard.py: contigs are LPT-packed over
+ranks, every rank produces the rows of its own contigs, rank 0 gathers the per-contig blocks over gloo and concatenates
+them in dictionary order.  The compute on each rank is the CPU oracle here (this is a test; on the GPU box the same
+shard/gather code wraps the HIP path in bench.py)."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GUIDE = "CTTGCCCCACAGGGCAGTAAnrg"
+
+
+def _genome():
+    sys.path.insert(0, ROOT)
+    from calitas_amd import synth
+    spec = [("chr1", 26000), ("chr2", 9000), ("chr3", 15000), ("chr4", 4000), ("chr5", 6000)]
+    names, seqs = synth.make_genome(spec, seed=21, guides=[("CTTGCCCCACAGGGCAGTAA", "nrg", False)], sites_per_guide=30,
+                                    n_run_ends=120, n_block=900)
+    return names, [s.tobytes() for s in seqs]
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from calitas_amd import shard
+    names, seqs = _genome()
+    mine = shard.lpt_partition([len(s) for s in seqs], world)[rank]
+    _, rows, _ = O.search_memory([names[i] for i in mine], [seqs[i] for i in mine], GUIDE, "a", d=4, p=1, g=2)
+    if rows:
+        text = "\n".join(["\t".join(rows[0].keys())] + ["\t".join(r.values()) for r in rows]) + "\n"
+    else:
+        text = "chromosome\n"
+    hdr, blocks = shard.split_rows_by_contig(text, names)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((hdr, blocks), gathered, dst=0)
+    if rank == 0:
+        hdr0 = next(h for h, b in gathered if b)
+        merged = shard.merge_contig_rows(hdr0, [b for _, b in gathered])
+        with open(os.path.join(outdir, "merged.txt"), "w") as f:
+            f.write(merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_contig_partition_gather_equals_single_process():
+    sys.path.insert(0, HERE)
+    import oracle_lib as O
+    from calitas_amd import shard
+    names, seqs = _genome()
+    parts = shard.lpt_partition([len(s) for s in seqs], 2)
+    assert sorted(parts[0] + parts[1]) == list(range(len(seqs)))
+    loads = [sum(len(seqs[i]) for i in p) for p in parts]
+    assert max(loads) <= 0.6 * sum(loads)
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + os.getpid() % 2000
+        mp.start_processes(_worker, args=(2, port, d), nprocs=2, join=True, start_method="spawn")
+        merged = open(os.path.join(d, "merged.txt")).read()
+    _, want, _ = O.search_memory(names, seqs, GUIDE, "a", d=4, p=1, g=2)
+    lines = merged.splitlines()
+    got = [dict(zip(lines[0].split("\t"), ln.split("\t"))) for ln in lines[1:]]
+    assert len(want) > 5 and got == want
+
+
+def test_guide_partition_is_a_partition():
+    from calitas_amd import shard
+    for world in (1, 2, 4, 8):
+        seen = sorted(g for r in range(world) for g in shard.guides_for_rank(96, r, world))
+        assert seen == list(range(96))
+        sizes = [len(shard.guides_for_rank(96, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_lpt_partition_hg38_balance():
+    from calitas_amd import shard, synth
+    for n in (2, 4, 8):
+        parts = shard.lpt_partition(synth.HG38_LENGTHS, n)
+        loads = [sum(synth.HG38_LENGTHS[i] for i in p) for p in parts]
+        assert max(loads) / (sum(loads) / n) < 1.06

@@ -1,0 +1,202 @@
+"""CPU tests of the product's host side (no GPU): the C ABI loads and exports every declared symbol, the packed
+reference round-trips, the window table equals windowIterator, and the two host stages above the kernels
+(per-window filter, removeOverlaps/sort/rows) reproduce the oracle when fed the oracle's own alignments.
+The oracle is used here only as the checker / input generator."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fasta_util import write_fasta
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SKIP_COLS = {"aligner_version", "time_stamp"}
+
+
+@pytest.fixture(scope="module")
+def C():
+    import calitas_amd
+    return calitas_amd
+
+
+def test_abi_exports_every_declared_symbol(C):
+    header = open(os.path.join(ROOT, "include", "calitas_hip.h")).read()
+    declared = set(re.findall(r"\b(calitas_[a-z_]+)\s*\(", header))
+    declared -= {"calitas_ctx"}
+    assert declared == set(C._lib.SYMBOLS), declared ^ set(C._lib.SYMBOLS)
+    for s in declared:
+        assert getattr(C._lib.lib, s) is not None
+    assert b"gfx950" in C._lib.lib.calitas_version()
+
+
+def test_no_device_fails_loudly(C):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(C.CalitasError) as e:
+        C.Context(0)
+    assert e.value.code == C._lib.ENODEV
+    ctx = C.Context(-1)
+    ctx.set_reference(["c"], [b"ACGT" * 100])
+    with pytest.raises(C.CalitasError) as e:
+        ctx.search([C.Guide("ACGTACGTACGTACGTACGTnrg")], C.make_params())
+    assert e.value.code == C._lib.ENODEV and "no CPU fallback" in str(e.value)
+
+
+def test_guide_parsing_matches_reference_rules(C):
+    g = C.Guide("AACCAACCAACCnrg")
+    assert (g.guide, g.pams, g.pam_is_five_prime) == ("AACCAACCAACC", ["nrg"], False)
+    g = C.Guide("tttvAACCAACCAACC")
+    assert (g.guide, g.pams, g.pam_is_five_prime) == ("AACCAACCAACC", ["tttv"], True)
+    g = C.Guide("AACCGGTTACGTnnn", ["nnnn", "nn"])
+    assert g.pams == ["nnn", "nnnn", "nn"] and g.pam_length == 4 and g.length == 16
+    assert C.Guide("GTGACTTGAAGTCTCAGTATA").pams == []
+    for bad, aux in (("acgt", ()), ("ACGTacgtACGT", ()), ("ACGT", ("nrg",)), ("ACGTnrg", ("NGG",))):
+        with pytest.raises(ValueError):
+            C.Guide(bad, aux)
+
+
+def test_packed_reference_roundtrip_and_runs(C):
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"ACGTacgtNnRYKMSWBDHVUu*", dtype=np.uint8)
+    probs = np.array([20, 20, 20, 20, 5, 5, 5, 5, 4, 1] + [0.3] * 12 + [0.2])
+    probs = probs / probs.sum()
+    seqs = []
+    for n in (5000, 333, 1, 70000):
+        s = alphabet[rng.choice(len(alphabet), size=n, p=probs)]
+        if n > 1000:
+            s[100:400] = ord("N")
+            s[-50:] = ord("N")
+        seqs.append(s)
+    ctx = C.Context(-1)
+    ctx.set_reference(["a", "b", "c", "d"], seqs)
+    assert ctx.contig_lengths == [5000, 333, 1, 70000]
+    for i, s in enumerate(seqs):
+        want = s.tobytes().decode().upper()
+        got = "".join(ctx.fetch_bases(i, st, min(997, len(s) - st)) for st in range(0, len(s), 997))
+        assert got == want
+
+
+@pytest.mark.parametrize("window,step", [(1000, 971), (451, 426), (120, 91), (50, 7)])
+def test_window_table_equals_window_iterator(C, window, step, tmp_path):
+    rng = np.random.default_rng(window)
+    contigs = []
+    for i, n in enumerate((4321, 999, 1000, 1001, 972, 30, 2, 1, 2600)):
+        s = np.frombuffer(b"ACGTacgtn", dtype=np.uint8)[rng.integers(0, 9, size=n)].copy()
+        if n > 500:
+            s[:137] = ord("N")
+            s[n // 2: n // 2 + 300] = ord("N")
+            s[-61:] = ord("N")
+        if i == 8:
+            s[1000:2100] = ord("N")       # windows that are entirely N
+        contigs.append(("c%d" % i, s.tobytes().decode()))
+    fa = write_fasta(str(tmp_path / "w.fa"), contigs)
+    ctx = C.Context(-1)
+    ctx.set_reference_fasta(fa)
+    min_len = 23
+    want = [(n, s - 1, e) for (n, s, e, ln) in O.windows(fa, window, step) if ln >= min_len]
+    got = [(ctx.contig_names[c], a, b) for (c, a, b) in ctx.window_table(window, step, min_len)]
+    assert got == want
+
+
+def _oracle_alignments(C, guide, contig_name, contig_index, seq, params_kw, window_size=1000):
+    """Per-window SequentialGuideAligner.align results of the ORACLE, converted to product Alignment records."""
+    G = C.Guide(guide)
+    step = window_size - (G.cli_length + params_kw["d"] + params_kw["g"] - 1)
+    out = []
+    n = len(seq)
+    for start in range(0, n - 1, step):
+        end = min(n, start + window_size)
+        a, b = start, end
+        while a < b and seq[a] == "N":
+            a += 1
+        while a < b and seq[b - 1] == "N":
+            b -= 1
+        if b - a < G.cli_length:
+            continue
+        rows = O.align(guide, seq[a:b].upper(), params_kw["d"], params_kw["g"], params_kw["p"], params_kw["D"], O=params_kw["O"],
+                       off=a, name=contig_name)
+        for r in rows:
+            al = C.Alignment.__new__(C.Alignment)
+            al.guide_index, al.contig_index, al.window_start = 0, contig_index, a
+            al.start_offset, al.end_offset = r["start"], r["end"]
+            al.guide_start_offset, al.guide_end_offset = r["gstart"], r["gend"]
+            al.score, al.strand = r["score"], r["strand"]
+            al.pam_index = 0 if G.pams else -1
+            ops = ""
+            for q, m in zip(r["padded_guide"], r["padded_alignment"]):
+                ops += "=" if m == "|" else "X" if m == "." else ("D" if q == "-" else "I")
+            al.ops = ops
+            out.append(al)
+    return out
+
+
+@pytest.mark.parametrize("guide", ["CTTGCCCCACAGGGCAGTAAnrg", "tttvCTTGCCCCACAGGGCAGTAA", "CTTGCCCCACAGGGCAGTAA"])
+def test_hits_tsv_stage_matches_oracle(C, guide, tmp_path):
+    """removeOverlaps + sort + the 34-column rows (product host code) on the oracle's per-window alignments must give
+    the oracle's hits.txt."""
+    from calitas_amd import synth
+    G = C.Guide(guide)
+    pam = G.pams[0] if G.pams else ""
+    names, seqs = synth.make_genome([("chrA", 30000), ("chrB", 12000)], seed=5, guides=[(G.guide, pam, G.pam_is_five_prime)],
+                                    sites_per_guide=40, n_run_ends=150, n_block=1200, tandem_frac=0.05)
+    contigs = [(n, s.tobytes().decode()) for n, s in zip(names, seqs)]
+    fa = write_fasta(str(tmp_path / "h.fa"), contigs)
+    kw = dict(d=4, p=1, g=2, D=7, O=10)
+    alns = []
+    for ci, (n, s) in enumerate(contigs):
+        alns += _oracle_alignments(C, guide, n, ci, s, kw)
+    ctx = C.Context(-1)
+    ctx.set_reference_fasta(fa)
+    params = C.make_params(max_guide_diffs=4, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2, max_total_diffs=7)
+    text, n_rows = ctx.hits_tsv(G, "a", params, alns)
+    got = C.read_hits(text)
+    _, want, _ = O.search_reference(fa, guide, "a", d=4, p=1, g=2, D=7)
+    strip = lambda rows: [{k: v for k, v in r.items() if k not in SKIP_COLS} for r in rows]
+    assert len(want) > 5
+    assert strip(got) == strip(want)
+    # padded strings through the dedicated entry point
+    pg, pa, pt = ctx.padded_strings(G, alns[0])
+    assert len(pg) == len(pa) == len(pt) == len(alns[0].ops)
+
+
+def test_window_filter_stage_matches_oracle(C):
+    """The per-window greedy filter (SGA:315-320) of the product, fed every extended alignment of a window (the oracle
+    run with limits that filter nothing), must keep what the oracle keeps with the real limits."""
+    from calitas_amd import synth
+    rng = np.random.default_rng(17)
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    unit = "CTTGCCCCACAGGGCAGTAATGG"
+    # a window full of overlapping near-matches: tandem copies with mutations
+    seq = "".join(synth.mutate(rng, unit, int(rng.integers(0, 4))) + "ACG"[: int(rng.integers(0, 3))] for _ in range(30))
+    seq = (seq + synth.revcomp(seq))[:1000]
+    for D, Ov in ((8, 10), (4, 10), (8, 0), (8, 100), (3, 5)):
+        everything = O.align(guide, seq, 5, 3, 1, 10 ** 6, O=10 ** 6, off=500, name="w")
+        want = O.align(guide, seq, 5, 3, 1, D, O=Ov, off=500, name="w")
+        recs = []
+        for r in everything:
+            al = C.Alignment.__new__(C.Alignment)
+            al.guide_index, al.contig_index, al.window_start = 0, 0, 500
+            al.start_offset, al.end_offset, al.guide_start_offset, al.guide_end_offset = r["start"], r["end"], r["gstart"], r["gend"]
+            al.score, al.strand, al.pam_index = r["score"], r["strand"], 0
+            al.ops = "".join("=" if m == "|" else "X" if m == "." else ("D" if q == "-" else "I")
+                             for q, m in zip(r["padded_guide"], r["padded_alignment"]))
+            recs.append(al)
+        kept = C.window_filter(recs, D, Ov)
+        assert len(everything) > 20
+        assert [(k.strand, k.start_offset, k.end_offset, k.score, k.ops) for k in kept] == \
+               [(w["strand"], w["start"], w["end"], w["score"],
+                 "".join("=" if m == "|" else "X" if m == "." else ("D" if q == "-" else "I")
+                         for q, m in zip(w["padded_guide"], w["padded_alignment"]))) for w in want]
+
+
+def test_cli_binary_exists_and_reports_usage():
+    import subprocess
+    exe = os.path.join(ROOT, "calitas_amd", "calitas")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "SearchReference" in r.stderr
