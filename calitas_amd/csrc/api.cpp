@@ -9,6 +9,7 @@
 #include <cstring>
 #include <ctime>
 #include <numeric>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,18 +38,62 @@ struct calitas_ctx {
   ContigInfo* d_contigs = nullptr;
   TileInfo* d_tiles = nullptr;
   uint32_t* d_tile_list = nullptr;
+  uint64_t* d_win_base = nullptr;   // window table for (win_W, win_step)
+  int2* d_win = nullptr;
+  uint64_t win_cap = 0;
+  int win_W = 0, win_step = 0;
   GuideDev* d_guides = nullptr;
   ScanRecord* d_recs = nullptr;
   RawAln* d_raw = nullptr;
   uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies
   uint32_t* h_counters = nullptr;   // pinned
   uint32_t rec_cap = 0, raw_cap = 0;
+  RawAln* h_raw = nullptr;          // pinned staging for the copy-back
+  uint32_t h_raw_cap = 0;
   calitas_timing_t timing{};
   WorkerPool* pool = nullptr;
   ~calitas_ctx() { delete pool; }
 };
 
 static std::string g_create_error;
+
+// Output buffers (alignment arrays, hits.txt text) are tens of MB per pass; handing each one back to the OS and faulting
+// a fresh one in costs milliseconds, so calitas_free parks the most recent blocks and out_alloc reuses them.
+namespace {
+struct BlockHeader { uint64_t magic; uint64_t capacity; };
+constexpr uint64_t kMagic = 0xCA117A5B10C0FFEEull;
+std::mutex g_pool_mutex;
+std::vector<BlockHeader*> g_pool;   // at most 4 parked blocks
+
+void* out_alloc(size_t size) {
+  if (size < 1) size = 1;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); i++)
+      if (g_pool[i]->capacity >= size && g_pool[i]->capacity <= 2 * size + (1u << 20) &&
+          (best < 0 || g_pool[i]->capacity < g_pool[best]->capacity)) best = (int)i;
+    if (best >= 0) { BlockHeader* h = g_pool[best]; g_pool.erase(g_pool.begin() + best); return h + 1; }
+  }
+  size_t cap = size + size / 8;
+  BlockHeader* h = (BlockHeader*)std::malloc(sizeof(BlockHeader) + cap);
+  if (!h) return nullptr;
+  h->magic = kMagic; h->capacity = cap;
+  return h + 1;
+}
+
+void out_free(void* p) {
+  if (!p) return;
+  BlockHeader* h = (BlockHeader*)p - 1;
+  if (h->magic != kMagic) return;     // not ours: refuse rather than corrupt the heap
+  if (h->capacity >= (1u << 20)) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (g_pool.size() < 4) { g_pool.push_back(h); return; }
+  }
+  h->magic = 0;
+  std::free(h);
+}
+}  // namespace
 
 static int fail(calitas_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg; else g_create_error = msg;
@@ -63,7 +108,8 @@ static int fail(calitas_ctx* ctx, int code, const std::string& msg) {
 
 static void free_reference_device(calitas_ctx* c) {
   if (c->device < 0) return;
-  (void)hipFree(c->d_codes); (void)hipFree(c->d_mask); (void)hipFree(c->d_runs); (void)hipFree(c->d_contigs); (void)hipFree(c->d_tiles); (void)hipFree(c->d_tile_list);
+  (void)hipFree(c->d_codes); (void)hipFree(c->d_mask); (void)hipFree(c->d_runs); (void)hipFree(c->d_contigs); (void)hipFree(c->d_tiles); (void)hipFree(c->d_tile_list); (void)hipFree(c->d_win_base); (void)hipFree(c->d_win);
+  c->d_win_base = nullptr; c->d_win = nullptr; c->win_cap = 0; c->win_W = c->win_step = 0;
   c->d_codes = c->d_mask = nullptr; c->d_runs = nullptr; c->d_contigs = nullptr; c->d_tiles = nullptr; c->d_tile_list = nullptr;
 }
 
@@ -73,7 +119,7 @@ const char* calitas_version(void) { return "calitas-hip 0.1 (gfx950)"; }
 
 const char* calitas_last_error(const calitas_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-void calitas_free(void* p) { std::free(p); }
+void calitas_free(void* p) { out_free(p); }
 
 int calitas_create(int device_id, calitas_ctx** out) {
   if (!out) return fail(nullptr, CALITAS_EINVAL, "out is NULL");
@@ -125,6 +171,7 @@ void calitas_destroy(calitas_ctx* c) {
     free_reference_device(c);
     (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_raw) (void)hipHostFree(c->h_raw);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
   }
@@ -221,7 +268,7 @@ int calitas_window_table(const calitas_ctx* ctx, int32_t window_size, int32_t st
     }
   }
   *n_windows = rows.size() / 3;
-  *out = (int32_t*)std::malloc(std::max<size_t>(1, rows.size()) * sizeof(int32_t));
+  *out = (int32_t*)out_alloc(std::max<size_t>(1, rows.size()) * sizeof(int32_t));
   if (!rows.empty()) std::memcpy(*out, rows.data(), rows.size() * sizeof(int32_t));
   return CALITAS_OK;
 }
@@ -284,6 +331,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
                    calitas_aln_t** out, uint64_t* n_out) {
   if (!ctx) return CALITAS_EINVAL;
   if (!out || !n_out || !guides || !params) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  const auto t_call = std::chrono::steady_clock::now();
   *out = nullptr; *n_out = 0;
   if (ctx->device < 0) return fail(ctx, CALITAS_ENODEV, "host-only context: calitas_search needs a GPU (there is no CPU fallback)");
   if (!ctx->has_ref) return fail(ctx, CALITAS_ESTATE, "calitas_set_reference has not been called");
@@ -320,6 +368,21 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     if (rc) return rc;
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, gd.data(), sizeof(GuideDev) * n_guides, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->win_W != p.window_size || ctx->win_step != step) {   // (re)build the device window table for this tiling
+    std::vector<uint64_t> wb(ref.contigs.size() + 1, 0);
+    for (size_t c = 0; c < ref.contigs.size(); c++) wb[c + 1] = wb[c] + window_count(ref.contigs[c].len, step);
+    const uint64_t nw = wb.back();
+    if (!ctx->d_win_base) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_win_base, wb.size() * sizeof(uint64_t)));
+    if (nw > ctx->win_cap) {
+      (void)hipFree(ctx->d_win); ctx->d_win = nullptr; ctx->win_cap = 0;
+      HIP_TRY(ctx, hipMalloc((void**)&ctx->d_win, std::max<uint64_t>(1, nw) * sizeof(int2)));
+      ctx->win_cap = nw;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_win_base, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, launch_window_table(ctx->d_runs, (int64_t)ref.runs.size(), ctx->d_contigs, ctx->d_win_base, (int)ref.contigs.size(), nw,
+                                     p.window_size, step, ctx->d_win, ctx->stream));
+    ctx->win_W = p.window_size; ctx->win_step = step;
+  }
 
   calitas_timing_t tm{};
   tm.bases_scanned = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
@@ -334,7 +397,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     sa.n_guides = n_guides; sa.chrom_index = p.chrom_index;
     AlignArgs aa{};
     aa.codes = ctx->d_codes; aa.mask = ctx->d_mask; aa.runs = ctx->d_runs; aa.n_runs = (int64_t)ref.runs.size();
-    aa.contigs = ctx->d_contigs; aa.tiles = ctx->d_tiles; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
+    aa.contigs = ctx->d_contigs; aa.tiles = ctx->d_tiles; aa.win_base = ctx->d_win_base; aa.win = ctx->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
     aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
     aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap; aa.tile_words = (uint32_t)(ref.tile / 16);
     aa.sp.window_size = p.window_size; aa.sp.step = step; aa.sp.n_guides = n_guides;
@@ -365,8 +428,14 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     }
     break;
   }
-  std::vector<RawAln> raw(n_raw);
-  if (n_raw) HIP_TRY(ctx, hipMemcpyAsync(raw.data(), ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  if (n_raw > ctx->h_raw_cap) {
+    if (ctx->h_raw) (void)hipHostFree(ctx->h_raw);
+    ctx->h_raw = nullptr; ctx->h_raw_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_raw, (size_t)ctx->raw_cap * sizeof(RawAln), hipHostMallocDefault));
+    ctx->h_raw_cap = ctx->raw_cap;
+  }
+  const RawAln* raw = ctx->h_raw;
+  if (n_raw) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
@@ -438,7 +507,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   std::vector<size_t> out_off(n_buckets + 1, 0);
   for (size_t b = 0; b < n_buckets; b++) out_off[b + 1] = out_off[b] + bucket_out[b].size();
   const size_t n_result = out_off[n_buckets];
-  calitas_aln_t* result = (calitas_aln_t*)std::malloc(std::max<size_t>(1, n_result) * sizeof(calitas_aln_t));
+  calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_result) * sizeof(calitas_aln_t));
   if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
   {
     std::atomic<size_t> next(0);
@@ -452,8 +521,9 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   }
   tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (std::getenv("CALITAS_TRACE"))
-    std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms, host filter %.3f ms (%u records, %u raw, %zu accepted)\n",
-                 tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms, n_rec, n_raw, n_result);
+    std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms, host filter %.3f ms, call %.3f ms (%u records, %u raw, %zu accepted)\n",
+                 tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_result);
   tm.accepted_alignments = n_result;
   {  // candidate columns = set bits of the scan records; counted from the raw stream would miss rejected ones, so
      // report what the aligner was asked to evaluate: unavailable on the host without copying the records back; leave
@@ -516,7 +586,7 @@ int calitas_hits_tsv(const calitas_ctx* ctx, const calitas_guide_t* guide, const
     char b[64]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
     std::strftime(b, sizeof b, "%a %b %d %H:%M:%S UTC %Y", &tmv); stamp = b;
   }
-  *tsv = hits_tsv(ctx->ref, gh, guide_id ? guide_id : "", *params, alns, n_alns, version, stamp, n_rows, ctx->pool);
+  *tsv = hits_tsv(ctx->ref, gh, guide_id ? guide_id : "", *params, alns, n_alns, version, stamp, n_rows, ctx->pool, out_alloc);
   if (!*tsv) return fail(c, CALITAS_EINVAL, "out of memory");
   return CALITAS_OK;
 }

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
     const uint32_t tile = rec.gword / a.tile_words;
     const uint32_t contig = a.tiles[tile].contig;
     const uint64_t gbase = a.contigs[contig].gbase, clen = a.contigs[contig].len;
+    const uint64_t win_lo = a.win_base[contig], win_cnt = a.win_base[contig + 1] - win_lo;
     const int64_t p0 = (int64_t)((uint64_t)rec.gword * 16 - gbase);   // contig offset of bit 0
     const int first = __ffs(cmask) - 1, last = 31 - __clz(cmask);
     const int64_t plo = p0 + first, phi = p0 + last;
@@ -303,8 +304,9 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
     const int qm = (r < L) ? g.qmask[r] : 0;
 
     for (int64_t k = klo; k <= khi; k++) {
-      int64_t wa, wb;
-      if (!window_bounds(a.runs, a.n_runs, gbase, clen, W, step, (uint64_t)k, wa, wb)) continue;
+      if ((uint64_t)k >= win_cnt) continue;            // no such window on this contig (Range(0, len-1, step), SR:52)
+      const int2 wab = a.win[win_lo + (uint64_t)k];     // N-trimmed bounds, precomputed by window_table_kernel
+      const int64_t wa = wab.x, wb = wab.y;
       const int n = (int)(wb - wa);
       if (n < g.cli_length) continue;                         // SearchReference.scala:536
       // candidate columns of this word that fall inside the window, as strand-space columns
@@ -467,6 +469,19 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
   }
 }
 
+// Window table of windowIterator (SearchReference.scala:39-71) for one (window size, step): out[win_base[c] + k] = N-trimmed
+// 0-based half-open bounds of window k of contig c.  Rebuilt only when the tiling changes.
+__global__ void window_table_kernel(const Run* runs, int64_t n_runs, const ContigInfo* contigs, const uint64_t* win_base,
+                                    int n_contigs, int W, int step, int2* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= win_base[n_contigs]) return;
+  int lo = 0, hi = n_contigs;              // last contig with win_base[c] <= i
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win_base[mid] <= i) lo = mid; else hi = mid; }
+  int64_t a = 0, b = 0;
+  window_bounds(runs, n_runs, contigs[lo].gbase, contigs[lo].len, W, step, i - win_base[lo], a, b);
+  out[i] = make_int2((int)a, (int)b);
+}
+
 // Self-test of the cross-lane primitive the fill relies on: out[i] = value held by lane i-1.
 __global__ void dpp_selftest_kernel(int* out) {
   int v = (int)threadIdx.x * 7 + 3;
@@ -492,6 +507,14 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
 
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
   hipLaunchKernelGGL(align_kernel, dim3(n_blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_table(const Run* runs, int64_t n_runs, const ContigInfo* contigs, const uint64_t* win_base, int n_contigs,
+                               uint64_t n_windows, int W, int step, int2* out, hipStream_t stream) {
+  if (n_windows == 0) return hipSuccess;
+  hipLaunchKernelGGL(window_table_kernel, dim3((unsigned)((n_windows + 255) / 256)), dim3(256), 0, stream, runs, n_runs, contigs,
+                     win_base, n_contigs, W, step, out);
   return hipGetLastError();
 }
 

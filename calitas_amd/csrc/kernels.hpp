@@ -1,6 +1,7 @@
 // kernels.hpp -- launch interface of kernels.hip (device pointers only).
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 
 #include "common.hpp"
 
@@ -25,6 +26,8 @@ struct AlignArgs {
   int64_t n_runs;
   const ContigInfo* contigs;
   const TileInfo* tiles;
+  const uint64_t* win_base;  // per contig: index of its window 0 in win[] (n_contigs + 1 entries)
+  const int2* win;           // N-trimmed window bounds for the current (window size, step)
   const GuideDev* guides;
   const ScanRecord* recs;
   const uint32_t* rec_count;
@@ -39,6 +42,8 @@ struct AlignArgs {
 
 hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_window_table(const Run* runs, int64_t n_runs, const ContigInfo* contigs, const uint64_t* win_base, int n_contigs,
+                               uint64_t n_windows, int W, int step, int2* out, hipStream_t stream);
 hipError_t launch_dpp_selftest(int* out, hipStream_t stream);
 
 }  // namespace calitas

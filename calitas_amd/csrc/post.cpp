@@ -161,47 +161,6 @@ void padded_strings(const PackedRef& ref, const GuideHost& g, const calitas_aln_
 
 namespace {
 
-// GuideAlignment.count (GA:139-163) on padded strings.
-int ga_count(const std::string& pg, const std::string& pa, bool lower, bool bothSides, bool mms, bool gaps) {
-  auto is_lower = [](char c) { return c >= 'a' && c <= 'z'; };
-  auto is_letter = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
-  const int len = (int)pa.size();
-  int n = 0;
-  for (int i = 0; i < len; i++) {
-    if (mms && pa[i] == '.' && is_lower(pg[i]) == lower) { n++; continue; }
-    if (!(gaps && pa[i] == '~')) continue;
-    const char gb = pg[i];
-    bool me = gb != '-' && is_lower(gb) == lower;
-    if (!me) {
-      int pi = i; while (pi > 0 && pg[pi] == '-') pi--;            // previousNonDash GA:168-172
-      int ni = i; while (ni < len - 1 && pg[ni] == '-') ni++;      // nextNonDash GA:177-182
-      const char prev = pg[pi], next = pg[ni];
-      if (bothSides) me = (prev == '-' || is_lower(prev) == lower) && (next == '-' || is_lower(next) == lower);
-      else me = (is_letter(prev) && is_lower(prev) == lower) || (is_letter(next) && is_lower(next) == lower);
-    }
-    if (me) n++;
-  }
-  return n;
-}
-
-std::string cigar_of(const calitas_aln_t& a) {  // Cigar.coalesce + toString
-  std::string s;
-  int i = 0;
-  while (i < a.n_ops) {
-    int j = i;
-    while (j < a.n_ops && a.ops[j] == a.ops[i]) j++;
-    s += std::to_string(j - i);
-    s += (char)a.ops[i];
-    i = j;
-  }
-  return s;
-}
-
-// fetchBases RH:261-266: 1-based inclusive [start, end], N padded, upper case, strand aware
-std::string fetch_flank(const PackedRef& ref, int contig, int64_t start1, int64_t end1, bool minus) {
-  return target_bases(ref, contig, start1 - 1, end1, minus);
-}
-
 struct Lite {          // what removeOverlaps and the sort look at
   int contig; int start; int end; char strand; int score; uint64_t idx;
 };
@@ -231,63 +190,126 @@ const char* const kColumns[34] = {
 
 }  // namespace
 
-// One hits.txt row (RH:210-254) for an accepted alignment, appended to `out`.
-static void append_row(std::string& out, const PackedRef& ref, const GuideHost& g, const std::string& guide_id,
-                       const calitas_aln_t& a, const std::string& version, const std::string& search_pam, const std::string& args,
-                       const std::string& time_stamp) {
-  std::string pg, pa, pt;
+// Upper-cased bases [start, end) of a contig into out (N beyond the contig ends, RH:262-264); reverse complement when minus.
+// Fast path: 2-bit decode; any exception bit in the covered mask words sends the span through base_upper().
+static int fetch_span(const PackedRef& ref, int contig, int64_t start, int64_t end, bool minus, char* out) {
+  const ContigInfo& c = ref.contigs[contig];
+  const int n = (int)(end - start);
+  bool plain = start >= 0 && (uint64_t)end <= c.len;
+  if (plain) {
+    const uint64_t g0 = c.gbase + (uint64_t)start, g1 = c.gbase + (uint64_t)end;
+    for (uint64_t w = g0 >> 5; w <= (g1 - 1) >> 5 && n > 0; w++) if (ref.mask[w]) { plain = false; break; }
+    if (plain) {
+      for (int i = 0; i < n; i++) { const uint64_t g = g0 + i; out[i] = "ACGT"[(ref.codes[g >> 4] >> ((g & 15) * 2)) & 3]; }
+    }
+  }
+  if (!plain)
+    for (int i = 0; i < n; i++) { const int64_t p = start + i; out[i] = (p >= 0 && (uint64_t)p < c.len) ? ref.base_upper(c.gbase + (uint64_t)p) : 'N'; }
+  if (minus) {
+    for (int i = 0, j = n - 1; i < j; i++, j--) { char t = out[i]; out[i] = out[j]; out[j] = t; }
+    for (int i = 0; i < n; i++) out[i] = complement_base(out[i]);
+  }
+  return n;
+}
+
+static inline void put_int(std::string& out, long v) {
+  char b[24]; int n = 0; bool neg = v < 0; unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
+  do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (neg) b[n++] = '-';
+  while (n) out += b[--n];
+}
+
+// GuideAlignment.count (GA:139-163) on padded char arrays of length len.
+static int ga_count_raw(const char* pg, const char* pa, int len, bool lower, bool bothSides, bool mms, bool gaps) {
+  auto is_lower = [](char c) { return c >= 'a' && c <= 'z'; };
+  auto is_letter = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+  int n = 0;
+  for (int i = 0; i < len; i++) {
+    if (mms && pa[i] == '.' && is_lower(pg[i]) == lower) { n++; continue; }
+    if (!(gaps && pa[i] == '~')) continue;
+    const char gb = pg[i];
+    bool me = gb != '-' && is_lower(gb) == lower;
+    if (!me) {
+      int pi = i; while (pi > 0 && pg[pi] == '-') pi--;            // previousNonDash GA:168-172
+      int ni = i; while (ni < len - 1 && pg[ni] == '-') ni++;      // nextNonDash GA:177-182
+      const char prev = pg[pi], next = pg[ni];
+      if (bothSides) me = (prev == '-' || is_lower(prev) == lower) && (next == '-' || is_lower(next) == lower);
+      else me = (is_letter(prev) && is_lower(prev) == lower) || (is_letter(next) && is_lower(next) == lower);
+    }
+    if (me) n++;
+  }
+  return n;
+}
+
+// Per-guide strings shared by all rows.
+struct RowConst {
+  std::string head;        // guide_id \t protospacer \t genome_build \t
+  std::string tail;        // aligner \t version \t search_pam \t args \t time_stamp \n
+  std::vector<std::string> query;     // per PAM index (+1): query in guide orientation
+  std::vector<std::string> pam_used;  // lower-case part of the query (RH:229)
+  std::string proto_len;
+};
+
+// One hits.txt row (RH:210-254) for an accepted alignment, appended to `out`.  No heap allocation per row.
+static void append_row(std::string& out, const PackedRef& ref, const RowConst& rc, const calitas_aln_t& a) {
   const bool minus = a.strand == '-';
-  padded_strings(ref, g, a, pg, pa, pt);
-  const std::string query = g.query_for(a.pam_index);
+  const std::string& q = rc.query[a.pam_index + 1];
+  char t[CALITAS_MAX_OPS + 8], pg[CALITAS_MAX_OPS + 1], pa[CALITAS_MAX_OPS + 1], pt[CALITAS_MAX_OPS + 1];
+  fetch_span(ref, a.contig_index, a.start_offset, a.end_offset, minus, t);
+  const int n = a.n_ops;
+  int qi = 0, ti = 0, mm = 0, gp = 0;
+  for (int i = 0; i < n; i++) {   // Alignment.paddedString (SGA:511)
+    switch (a.ops[i]) {
+      case 'I': pg[i] = q[qi++]; pa[i] = '~'; pt[i] = '-'; gp++; break;
+      case 'D': pg[i] = '-'; pa[i] = '~'; pt[i] = t[ti++]; gp++; break;
+      case '=': pg[i] = q[qi++]; pa[i] = '|'; pt[i] = t[ti++]; break;
+      default:  pg[i] = q[qi++]; pa[i] = '.'; pt[i] = t[ti++]; mm++; break;
+    }
+  }
   // unpaddedTargetWithoutPam GA:111-115
   int ps = -1, pe = -1;
-  for (int i = 0; i < (int)pg.size(); i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
-  std::string unpadded_target;
-  for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target += pt[i];
-  const int contig = a.contig_index;
-  // RH:213-216 (coordinates are given in genome orientation, content is strand aware)
-  const std::string tenLeft = fetch_flank(ref, contig, a.guide_start_offset + 1 - 10, a.guide_start_offset, minus);
-  const std::string tenRight = fetch_flank(ref, contig, a.guide_end_offset + 1, a.guide_end_offset + 10, minus);
-  const std::string eightLeft = fetch_flank(ref, contig, a.start_offset + 1 - 8, a.start_offset, minus);
-  const std::string eightRight = fetch_flank(ref, contig, a.end_offset + 1, a.end_offset + 8, minus);
-  std::string pam_used;
-  for (char c : query) if (c >= 'a' && c <= 'z') pam_used += c;   // RH:229
-  const int mm = (int)std::count(pa.begin(), pa.end(), '.'), gp = (int)std::count(pa.begin(), pa.end(), '~');
+  for (int i = 0; i < n; i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
+  char ut[CALITAS_MAX_OPS + 1]; int utn = 0;
+  for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') ut[utn++] = pt[i];
+  // RH:213-216 (coordinates in genome orientation, content strand aware)
+  char tenL[10], tenR[10], eightL[8], eightR[8];
+  fetch_span(ref, a.contig_index, (int64_t)a.guide_start_offset - 10, a.guide_start_offset, minus, tenL);
+  fetch_span(ref, a.contig_index, a.guide_end_offset, (int64_t)a.guide_end_offset + 10, minus, tenR);
+  fetch_span(ref, a.contig_index, (int64_t)a.start_offset - 8, a.start_offset, minus, eightL);
+  fetch_span(ref, a.contig_index, a.end_offset, (int64_t)a.end_offset + 8, minus, eightR);
 
-  out += guide_id; out += '\t';
-  out += g.protospacer; out += '\t';
-  out += ref.genome_build; out += '\t';
-  out += ref.names[contig]; out += '\t';
-  out += std::to_string(a.guide_start_offset); out += '\t';
-  out += std::to_string(a.guide_end_offset); out += '\t';
+  out += rc.head;
+  out += ref.names[a.contig_index]; out += '\t';
+  put_int(out, a.guide_start_offset); out += '\t';
+  put_int(out, a.guide_end_offset); out += '\t';
   out += (char)a.strand; out += '\t';
-  out += unpadded_target; out += '\t';
-  out += minus ? tenRight : tenLeft; out += '\t';      // RH:227
-  out += minus ? tenLeft : tenRight; out += '\t';      // RH:228
-  out += pam_used; out += '\t';
-  out += "\t\t\t\t";                                   // variant_id, variant_description, variant_vcf, allele_frequency: None
-  out += std::to_string(a.score); out += '\t';
-  out += std::to_string(ga_count(pg, pa, false, false, true, false)); out += '\t';   // guide_mm GA:103
-  out += std::to_string(ga_count(pg, pa, false, false, false, true)); out += '\t';   // guide_gaps GA:104
-  out += std::to_string(ga_count(pg, pa, false, false, true, true)); out += '\t';    // guide_mm_plus_gaps GA:105
-  out += std::to_string(ga_count(pg, pa, true, true, true, false)); out += '\t';     // pam_mm GA:106
-  out += std::to_string(mm + gp); out += '\t';                                       // total_mm_plus_gaps = edits GA:101
-  out += pg; out += '\t'; out += pa; out += '\t'; out += pt; out += '\t';
-  out += minus ? eightRight : eightLeft; out += '\t';  // RH:243
-  out += minus ? eightLeft : eightRight; out += '\t';  // RH:244
-  out += cigar_of(a); out += '\t';
-  out += std::to_string(g.protospacer.size()); out += '\t';
-  out += std::to_string(unpadded_target.size()); out += '\t';
-  out += "CALITAS:SearchReference"; out += '\t';       // SR:522
-  out += version; out += '\t';
-  out += search_pam; out += '\t';
-  out += args; out += '\t';
-  out += time_stamp; out += '\n';
+  out.append(ut, utn); out += '\t';
+  out.append(minus ? tenR : tenL, 10); out += '\t';      // RH:227
+  out.append(minus ? tenL : tenR, 10); out += '\t';      // RH:228
+  out += rc.pam_used[a.pam_index + 1]; out += '\t';
+  out += "\t\t\t\t";                                     // variant_id, variant_description, variant_vcf, allele_frequency: None
+  put_int(out, a.score); out += '\t';
+  put_int(out, ga_count_raw(pg, pa, n, false, false, true, false)); out += '\t';   // guide_mm GA:103
+  put_int(out, ga_count_raw(pg, pa, n, false, false, false, true)); out += '\t';   // guide_gaps GA:104
+  put_int(out, ga_count_raw(pg, pa, n, false, false, true, true)); out += '\t';    // guide_mm_plus_gaps GA:105
+  put_int(out, ga_count_raw(pg, pa, n, true, true, true, false)); out += '\t';     // pam_mm GA:106
+  put_int(out, mm + gp); out += '\t';                                              // total_mm_plus_gaps = edits GA:101
+  out.append(pg, n); out += '\t'; out.append(pa, n); out += '\t'; out.append(pt, n); out += '\t';
+  out.append(minus ? eightR : eightL, 8); out += '\t';   // RH:243
+  out.append(minus ? eightL : eightR, 8); out += '\t';   // RH:244
+  for (int i = 0; i < n;) {                              // Cigar.coalesce + toString
+    int j = i; while (j < n && a.ops[j] == a.ops[i]) j++;
+    put_int(out, j - i); out += (char)a.ops[i]; i = j;
+  }
+  out += '\t';
+  out += rc.proto_len; out += '\t';
+  put_int(out, utn); out += '\t';
+  out += rc.tail;
 }
 
 char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
-               uint64_t* n_rows, WorkerPool* pool) {
+               uint64_t* n_rows, WorkerPool* pool, void* (*alloc)(size_t)) {
   WorkerPool serial(1);
   if (!pool) pool = &serial;
   const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
@@ -356,7 +378,16 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
   // ---- rows (RH:210-254), built in parallel blocks and concatenated in order ----
   std::string search_pam;
   for (size_t i = 0; i < g.pams.size(); i++) { if (i) search_pam += ','; search_pam += g.pams[i]; }   // RH:207
-  const std::string args = core_parameters(p, max_total);
+  RowConst rc;
+  rc.head = guide_id + "\t" + g.protospacer + "\t" + ref.genome_build + "\t";
+  rc.tail = std::string("CALITAS:SearchReference") + "\t" + version + "\t" + search_pam + "\t" + core_parameters(p, max_total) + "\t" +
+            time_stamp + "\n";                                                                       // SR:522
+  rc.proto_len = std::to_string(g.protospacer.size());
+  for (int pi = -1; pi < (int)g.pams.size(); pi++) {
+    std::string q = g.query_for(pi), used;
+    for (char c : q) if (c >= 'a' && c <= 'z') used += c;
+    rc.query.push_back(q); rc.pam_used.push_back(used);
+  }
   std::string header;
   for (int i = 0; i < 34; i++) { if (i) header += '\t'; header += kColumns[i]; }
   header += '\n';
@@ -370,9 +401,9 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
         size_t b = next.fetch_add(1);
         if (b >= n_blocks) break;
         std::string& s = parts[b];
-        s.reserve(BLOCK * 420);
+        s.reserve(BLOCK * 600);
         size_t e = std::min(keepers.size(), (b + 1) * BLOCK);
-        for (size_t i = b * BLOCK; i < e; i++) append_row(s, ref, g, guide_id, alns[keepers[i].idx], version, search_pam, args, time_stamp);
+        for (size_t i = b * BLOCK; i < e; i++) append_row(s, ref, rc, alns[keepers[i].idx]);
       }
     });
   }
@@ -380,7 +411,7 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
   std::vector<size_t> offs(n_blocks);
   for (size_t b = 0; b < n_blocks; b++) { offs[b] = total; total += parts[b].size(); }
   auto t_rows = tnow();
-  char* out = (char*)std::malloc(total + 1);
+  char* out = (char*)(alloc ? alloc(total + 1) : std::malloc(total + 1));
   if (!out) return nullptr;
   out[total] = 0;
   std::memcpy(out, header.data(), header.size());
