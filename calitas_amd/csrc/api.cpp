@@ -45,7 +45,9 @@ struct calitas_ctx {
   GuideDev* d_guides = nullptr;
   ScanRecord* d_recs = nullptr;
   RawAln* d_raw = nullptr;
-  uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies
+  uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies, [3] slab units, [4] candidates
+  uint8_t* d_slab = nullptr;        // strips handed from align_kernel to trace_kernel
+  uint64_t slab_cap = 0;            // bytes
   uint32_t* h_counters = nullptr;   // pinned
   uint32_t rec_cap = 0, raw_cap = 0;
   RawAln* h_raw = nullptr;          // pinned staging for the copy-back
@@ -141,8 +143,8 @@ int calitas_create(int device_id, calitas_ctx** out) {
       return fail(nullptr, CALITAS_EHIP, "device init failed: " + m);
     }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
-    (void)hipMalloc((void**)&c->d_counters, 4 * sizeof(uint32_t));
-    (void)hipHostMalloc((void**)&c->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault);
+    (void)hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t));
+    (void)hipHostMalloc((void**)&c->h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault);
     (void)hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES);
     // The aligner kernel's wavefront relies on the DPP wave shift; verify it on this device once.
     int* d = nullptr;
@@ -170,6 +172,7 @@ void calitas_destroy(calitas_ctx* c) {
     (void)hipSetDevice(c->device);
     free_reference_device(c);
     (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_slab);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -313,7 +316,13 @@ static std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& 
   return "";
 }
 
-static int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap) {
+static int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec) {
+  rec_cap = std::max(rec_cap, ctx->rec_cap);
+  if ((uint64_t)rec_cap * slab_per_rec > ctx->slab_cap) {
+    (void)hipFree(ctx->d_slab); ctx->d_slab = nullptr; ctx->slab_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slab, (size_t)rec_cap * slab_per_rec));
+    ctx->slab_cap = (uint64_t)rec_cap * slab_per_rec;
+  }
   if (rec_cap > ctx->rec_cap) {
     (void)hipFree(ctx->d_recs); ctx->d_recs = nullptr; ctx->rec_cap = 0;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_recs, (size_t)rec_cap * sizeof(ScanRecord)));
@@ -362,9 +371,20 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   }
 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // Strip slabs (align_kernel -> trace_kernel): fixed size and fixed address per (record, window slot).
+  const uint32_t slots_per_rec = (uint32_t)((p.window_size + 14) / step + 1);   // windows a 16-base word can fall into
+  if (slots_per_rec > 8) return fail(ctx, CALITAS_EINVAL, "window step is too small relative to the window size (more than 8 windows per position)");
+  uint32_t slab_bytes = 0;
+  for (int i = 0; i < n_guides; i++) {
+    const uint32_t ncols_max = 16 + gd[i].span + 1;
+    const uint32_t stride_max = (ncols_max + 4) & ~3u;
+    const uint32_t ntb_max = (ncols_max + p.max_gaps_between_guide_and_pam + MAX_PAM_LEN + 3) & ~3u;
+    slab_bytes = std::max<uint32_t>(slab_bytes, (uint32_t)((sizeof(SlabHeader) + ntb_max + gd[i].L * stride_max + 15) & ~15u));
+  }
+  const uint64_t slab_per_rec = (uint64_t)slab_bytes * slots_per_rec;
   {
     uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, ref.total_bases / 8 + 1024));
-    int rc = ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want));
+    int rc = ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), slab_per_rec);
     if (rc) return rc;
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, gd.data(), sizeof(GuideDev) * n_guides, hipMemcpyHostToDevice, ctx->stream));
@@ -390,7 +410,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   const uint32_t n_tiles = (uint32_t)ref.tiles.size();
   uint32_t n_rec = 0, n_raw = 0;
   for (;;) {
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
     ScanArgs sa{};
     sa.codes = ctx->d_codes; sa.mask = ctx->d_mask; sa.tiles = ctx->d_tiles; sa.guides = ctx->d_guides;
     sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
@@ -399,7 +419,9 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     aa.codes = ctx->d_codes; aa.mask = ctx->d_mask; aa.runs = ctx->d_runs; aa.n_runs = (int64_t)ref.runs.size();
     aa.contigs = ctx->d_contigs; aa.tiles = ctx->d_tiles; aa.win_base = ctx->d_win_base; aa.win = ctx->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
     aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
-    aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap; aa.tile_words = (uint32_t)(ref.tile / 16);
+    aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
+    aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = slab_bytes; aa.slots_per_rec = slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
+    aa.debug_skip = std::getenv("CALITAS_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SKIP")) : 0u;
     aa.sp.window_size = p.window_size; aa.sp.step = step; aa.sp.n_guides = n_guides;
     aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
     aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
@@ -411,8 +433,9 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     HIP_TRY(ctx, launch_scan(sa, ref.chunk, n_tiles, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
+    HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
     if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
@@ -420,9 +443,10 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
       tm.retries++;
       uint64_t nr = n_rec > ctx->rec_cap ? (uint64_t)n_rec + n_rec / 4 : ctx->rec_cap;
       uint64_t nw = n_raw > ctx->raw_cap ? (uint64_t)n_raw * 2 : ctx->raw_cap;
-      if (n_rec > ctx->rec_cap) nw = std::max<uint64_t>(nw, nr);   // the raw count was cut short as well
+      if (n_rec > ctx->rec_cap)   // the raw count was cut short as well: scale it with the record count
+        nw = std::max<uint64_t>(nw, (uint64_t)((double)n_raw * nr / std::max<uint32_t>(1, ctx->rec_cap)) + 1024);
       if (nr > 0xFFFFFFF0ull || nw > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
-      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw);
+      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw, slab_per_rec);
       if (rc) return rc;
       continue;
     }
@@ -525,16 +549,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
                  tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_result);
   tm.accepted_alignments = n_result;
-  {  // candidate columns = set bits of the scan records; counted from the raw stream would miss rejected ones, so
-     // report what the aligner was asked to evaluate: unavailable on the host without copying the records back; leave
-     // the record count and let bench.py request the detailed number via CALITAS_COUNT_CANDIDATES when it wants it.
-    tm.candidate_columns = 0;
-    if (std::getenv("CALITAS_COUNT_CANDIDATES") && n_rec) {
-      std::vector<ScanRecord> recs(n_rec);
-      if (hipMemcpy(recs.data(), ctx->d_recs, (size_t)n_rec * sizeof(ScanRecord), hipMemcpyDeviceToHost) == hipSuccess)
-        for (auto& r : recs) tm.candidate_columns += (uint64_t)__builtin_popcount(r.info & 0xFFFFu);
-    }
-  }
+  tm.candidate_columns = ctx->h_counters[4];   // end columns whose best bottom-row score reached minGuideScore inside a window
   ctx->timing = tm;
 
   *n_out = n_result;

@@ -137,4 +137,21 @@ struct RawAln {
   uint8_t ops[RAW_MAX_OPS / 4];  // 2 bits per op in traceback (reverse) order: 0 '=', 1 'X', 2 'I', 3 'D'
 };
 
+// A filled strip handed from align_kernel to trace_kernel.  Slabs have a fixed size per search and a fixed address
+// (record index x slots-per-record + window slot), so the hand-over needs no atomics: header, target masks tb[ntb],
+// trace bytes tr[L][stride].
+struct SlabHeader {
+  uint32_t pass_mask;     // bit x: the x-th candidate column of this (record, window) reached min_guide_score
+  uint32_t contig;
+  uint32_t window_k;
+  int32_t n;              // window length
+  int32_t c0;             // strip boundary column (strip columns are c0+1 .. c0+ncols)
+  uint16_t ncols, ntb;
+  uint8_t dir, guide, true_border, L;
+  uint16_t stride, pad;
+  uint16_t j[16];         // strand-space end column (1-based) of candidate x
+  int32_t best[16];       // score*4 + matrix code of the best of the three bottom-row cells of candidate x
+};
+static_assert(sizeof(SlabHeader) == 128, "slab header layout");
+
 }  // namespace calitas

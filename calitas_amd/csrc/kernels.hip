@@ -124,8 +124,22 @@ __device__ __noinline__ uint32_t replay_word(const uint2* tab, uint32_t word, ui
   return hm;
 }
 
+// Records are staged in LDS and flushed once per tile: a returning atomic on ONE global word completes at only
+// ~90 per microsecond chip-wide (MI355X_MICROARCH.md, row "dequeue"), which a per-record append would approach.
+constexpr int SCAN_STAGE = 192;
+
+__device__ __forceinline__ void stage_record(const ScanArgs& a, ScanRecord* s_recs, uint32_t* s_nrec, uint32_t gword, uint32_t info) {
+  ScanRecord r;
+  r.gword = gword; r.info = info;
+  const uint32_t slot = atomicAdd(s_nrec, 1u);          // LDS atomic
+  if (slot < (uint32_t)SCAN_STAGE) { s_recs[slot] = r; return; }
+  const uint32_t g = atomicAdd(a.rec_count, 1u);        // stage full (dense tile): append directly
+  if (g < a.rec_capacity) a.recs[g] = r;
+}
+
 template <int CHUNK, bool MASKED>
-__device__ __forceinline__ void scan_tile(const ScanArgs& a, uint32_t tile, uint32_t* s_codes, uint2* s_tab) {
+__device__ __forceinline__ void scan_tile(const ScanArgs& a, uint32_t tile, uint32_t* s_codes, uint2* s_tab, ScanRecord* s_recs,
+                                          uint32_t* s_nrec) {
   constexpr int WPC = CHUNK / 16;           // code words per lane chunk
   constexpr int MPC = CHUNK / 32;           // mask words per lane chunk
   constexpr int CSTR = WPC + 1;             // padded stride: lane l reads word l*CSTR + k -> conflict-free banks
@@ -195,23 +209,11 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, uint32_t tile, uint
       }
       if (wa >= 0 && accA < 0) {
         const uint32_t hm = replay_word<MASKED, true>(tabA, wordA, mA, pvA0, mvA0, scA0);
-        const uint32_t slot = atomicAdd(a.rec_count, 1u);
-        if (slot < a.rec_capacity) {
-          ScanRecord r;
-          r.gword = gword0 + (uint32_t)wa;
-          r.info = hm | ((uint32_t)gi << 17);
-          a.recs[slot] = r;
-        }
+        stage_record(a, s_recs, s_nrec, gword0 + (uint32_t)wa, hm | ((uint32_t)gi << 17));
       }
       if (wb < WPC && accB < 0) {
         const uint32_t hm = replay_word<MASKED, false>(tabB, wordB, mB, pvB0, mvB0, scB0);
-        const uint32_t slot = atomicAdd(a.rec_count, 1u);
-        if (slot < a.rec_capacity) {
-          ScanRecord r;
-          r.gword = gword0 + (uint32_t)wb;
-          r.info = hm | (1u << 16) | ((uint32_t)gi << 17);
-          a.recs[slot] = r;
-        }
+        stage_record(a, s_recs, s_nrec, gword0 + (uint32_t)wb, hm | (1u << 16) | ((uint32_t)gi << 17));
       }
     }
   }
@@ -223,12 +225,25 @@ template <int CHUNK>
 __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
   __shared__ uint32_t s_codes[(LANES_PER_TILE + 2) * (CHUNK / 16 + 1)];
   __shared__ uint2 s_tab[2 * 64];           // [direction][pair index] -> (Eq of base 2j, Eq of base 2j+1)
+  __shared__ ScanRecord s_recs[SCAN_STAGE];
+  __shared__ uint32_t s_nrec, s_base;
   const uint32_t tile = blockIdx.x;
   const TileInfo ti = a.tiles[tile];
   if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
   if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;
-  if (ti.flag != 0u) scan_tile<CHUNK, true>(a, tile, s_codes, s_tab);
-  else scan_tile<CHUNK, false>(a, tile, s_codes, s_tab);
+  if (threadIdx.x == 0) s_nrec = 0;         // made visible by the first barrier inside scan_tile
+  if (ti.flag != 0u) scan_tile<CHUNK, true>(a, tile, s_codes, s_tab, s_recs, &s_nrec);
+  else scan_tile<CHUNK, false>(a, tile, s_codes, s_tab, s_recs, &s_nrec);
+  // ---- flush the tile's records with one global atomic ----
+  __syncthreads();
+  const uint32_t n = min(s_nrec, (uint32_t)SCAN_STAGE);
+  if (n == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(a.rec_count, n);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += LANES_PER_TILE) {
+    const uint32_t g = s_base + i;
+    if (g < a.rec_capacity) a.recs[g] = s_recs[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -239,6 +254,8 @@ constexpr int TR_UP = 0, TR_LEFT = 1, TR_DIAG = 2;   // ordered so that max() of
 constexpr int NEG = -(1 << 20);                      // "minus infinity" that survives a few hundred additions
 constexpr int JOBS_PER_BLOCK = 8;                    // one job per 32-lane half wave
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
+constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
+constexpr int TR_STRIDE = 72;                        // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; 71 lanes apart in time -> few bank conflicts)
 
 __device__ __forceinline__ int shift_up_lane(int v) {
   // value of lane-1 (DPP wave shift right by one); lane 0 keeps its own value, which callers ignore
@@ -267,13 +284,13 @@ __device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
 }
 
 __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
-  __shared__ uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][STRIP_MAX_COLS + 1];
-  __shared__ uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
+  // trace rows are 72 bytes apart: lane r writes byte 71r + t at step t, which spreads the 32 lanes over the banks
+  __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
   __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
-
   const int job = threadIdx.x >> 5;
   const int r = threadIdx.x & 31;           // lane within the job = query row r+1
-  uint8_t (*tr)[STRIP_MAX_COLS + 1] = s_tr[job];
+  uint8_t (*tr)[TR_STRIDE] = s_tr[job];
   uint8_t* tb = s_tb[job];
   int* fin = s_fin[job];
 
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
     const int dir = (rec.info >> 16) & 1;
     const int gi = (rec.info >> 17) & 0x7F;
     const GuideDev& g = a.guides[gi];
-    const int L = g.L, span = g.span;
+    const int L = g.L, span = g.span, g_min_score = g.min_guide_score, g_cli = g.cli_length;
     const uint32_t tile = rec.gword / a.tile_words;
     const uint32_t contig = a.tiles[tile].contig;
     const uint64_t gbase = a.contigs[contig].gbase, clen = a.contigs[contig].len;
@@ -297,18 +314,22 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
     const int64_t p0 = (int64_t)((uint64_t)rec.gword * 16 - gbase);   // contig offset of bit 0
     const int first = __ffs(cmask) - 1, last = 31 - __clz(cmask);
     const int64_t plo = p0 + first, phi = p0 + last;
-    if ((uint64_t)plo >= clen) continue;  // only padding columns: they belong to no window
     int64_t klo = (plo - W + 1 + step - 1) / step;  // ceil((plo - W + 1) / step) for positive numerator
     if (plo - W + 1 <= 0) klo = 0;
     int64_t khi = phi / step;
     const int qm = (r < L) ? g.qmask[r] : 0;
+    // every slot of this record starts empty; a window that yields candidates overwrites its slot's header below
+    if (r < (int)a.slots_per_rec)
+      reinterpret_cast<SlabHeader*>(a.slab + ((uint64_t)ri * a.slots_per_rec + (uint64_t)r) * a.slab_bytes)->pass_mask = 0u;
 
+    if ((uint64_t)plo >= clen) continue;  // only padding columns: they belong to no window
     for (int64_t k = klo; k <= khi; k++) {
+      if (k - klo >= (int64_t)a.slots_per_rec) break;   // cannot happen: the host sizes slots_per_rec from the tiling
       if ((uint64_t)k >= win_cnt) continue;            // no such window on this contig (Range(0, len-1, step), SR:52)
       const int2 wab = a.win[win_lo + (uint64_t)k];     // N-trimmed bounds, precomputed by window_table_kernel
       const int64_t wa = wab.x, wb = wab.y;
       const int n = (int)(wb - wa);
-      if (n < g.cli_length) continue;                         // SearchReference.scala:536
+      if (n < g_cli) continue;                         // SearchReference.scala:536
       // candidate columns of this word that fall inside the window, as strand-space columns
       uint32_t sel = 0;
       for (int b = first; b <= last; b++) if ((cmask >> b) & 1u) { int64_t p = p0 + b; if (p >= wa && p < wb) sel |= 1u << b; }
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
       const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
 
       // ---- stage target masks ----
-      for (int x = r; x < ntb; x += 32) {
+      for (int x = r; x < ((a.debug_skip & 4u) ? 0 : ntb); x += 32) {
         int col = c0 + 1 + x;                                 // 1-based strand-space column
         int64_t pos = dir ? (wb - col) : (wa + col - 1);
         tb[x] = (uint8_t)fetch_tmask(a, gbase + (uint64_t)pos, dir);
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
       int curD = NEG, curL = NEG, curU = true_border ? i_row * sp.target_gap : NEG;
       int curP = max(max(curD * 4 + TR_DIAG, curL * 4 + TR_LEFT), curU * 4 + TR_UP);
       int inP = shift_up_lane(curP), inPprev;
-      const int nsteps = ncols + L - 1;
+      const int nsteps = (a.debug_skip & 1u) ? 0 : ncols + L - 1;
       for (int t = 1; t <= nsteps; t++) {
         inPprev = inP;
         inP = shift_up_lane(curP);
@@ -368,7 +389,8 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      // ---- one lane per candidate column: threshold, traceback, PAM extension, emit ----
+      // ---- hand the strip over to trace_kernel: one candidate descriptor per passing end column, plus the strip's
+      //      trace matrix and target masks copied from LDS into a slab in HBM (one slab per record x window) ----
       // lane x takes the x-th selected bit in ascending strand-space column order
       int myb = -1;
       {
@@ -376,97 +398,199 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
         if (dir == 0) { for (int b = sfirst; b <= slast; b++) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
         else          { for (int b = slast; b >= sfirst; b--) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
       }
-      if (myb >= 0) {
-        const int j = dir ? (int)(wb - (p0 + myb)) : (int)(p0 + myb - wa) + 1;   // strand-space end column
-        const int P = fin[j - c0];
-        const int gscore = P >> 2;
-        if (gscore >= g.min_guide_score) {
-          int m = P & 3, i = L, c = j - c0;
-          uint32_t ops[RAW_MAX_OPS / 16] = {0, 0, 0};
-          int nops = 0, diffs = 0;
-          bool ok = true;
-          while (i > 0) {
-            if (nops >= RAW_MAX_OPS) { ok = false; break; }
-            int op;
-            if (c == 0) {
-              // true left border: only the Up matrix is finite there (leading insertions)
-              if (!true_border || m != TR_UP) { ok = false; break; }
-              op = 2; i--;                                   // 'I'; Up(i,0) traces to Up, Up(1,0) to Diag(0,0)
-            } else {
-              const int t8 = tr[i - 1][c];
-              if (m == TR_DIAG) {
-                const int tm = tb[c - 1], q = g.qmask[i - 1];
-                const bool compat = (q & tm & 15) != 0;
-                const bool eq = sp.eqx_by_score ? (compat && !(tm & 16)) : compat;
-                op = eq ? 0 : 1;
-                m = t8 & 3; i--; c--;
-              } else if (m == TR_UP) {
-                op = 2; m = ((t8 >> 2) & 1) ? TR_UP : TR_DIAG; i--;
-              } else {
-                op = 3; m = ((t8 >> 3) & 1) ? TR_LEFT : TR_DIAG; c--;
-              }
-            }
-            if (op != 0) diffs++;
-            ops[nops >> 4] |= (uint32_t)op << ((nops & 15) * 2);
-            nops++;
-          }
-          if (!ok) {
-            atomicAdd(a.anomalies, 1u);
-          } else if (diffs <= sp.max_guide_diffs) {
-            const int t_start = c0 + c + 1;
-            RawAln o;
-            o.contig = contig; o.window_k = (uint32_t)k; o.t_start = (uint16_t)t_start; o.t_end_guide = (uint16_t)j;
-            o.dir = (uint8_t)dir; o.guide = (uint8_t)gi; o.n_ops = (uint8_t)nops; o.pad = 0;
-            o.ops[0] = 0;
-            uint32_t* ow = reinterpret_cast<uint32_t*>(o.ops);
-            ow[0] = ops[0]; ow[1] = ops[1]; ow[2] = ops[2];
-            if (g.n_pams == 0) {
-              o.score = gscore; o.pam = -1; o.offset = 0; o.pam_x = 0;
-              uint32_t slot = atomicAdd(a.out_count, 1u);
-              if (slot < a.out_capacity) a.out[slot] = o;
-            } else {
-              // terminal indel run = first ops of the traceback
-              int term = 0;
-              {
-                int op0 = ops[0] & 3;
-                if (op0 >= 2) { term = 1; while (term < nops && (int)((ops[term >> 4] >> ((term & 15) * 2)) & 3) == op0) term++; }
-              }
-              int max_extra = sp.max_gaps - term;
-              if (sp.max_diffs_filtering - diffs < max_extra) max_extra = sp.max_diffs_filtering - diffs;
-              for (int pi = 0; pi < g.n_pams; pi++) {
-                const int plen = g.pam_len[pi];
-                bool have = false; int best_score = 0, best_off = 0; uint32_t best_x = 0;
-                for (int off = 0; off <= max_extra; off++) {
-                  const int toff = j + off;                   // 0-based strand-space offset of the first PAM base
-                  int limit = sp.max_pam_mismatches;
-                  if (sp.max_diffs_filtering - diffs - off < limit) limit = sp.max_diffs_filtering - diffs - off;
-                  if (toff + plen > n || limit < 0) continue;
-                  int sc = 0, nx = 0; uint32_t xm = 0;
-                  for (int q = 0; q < plen; q++) {
-                    const int tm = tb[toff + q - c0];
-                    const bool match = ((g.pam_mask[pi][q] & tm & 15) != 0) && !(tm & 16);
-                    const int addend = match ? sp.pam_match : sp.pam_mismatch;
-                    sc += addend;
-                    if (!(addend > 0)) { nx++; xm |= 1u << q; }
-                  }
-                  if (nx > limit) continue;
-                  const int total = gscore + sc + off * sp.query_gap;
-                  if (!have || total > best_score) { have = true; best_score = total; best_off = off; best_x = xm; }
-                }
-                if (have) {
-                  o.score = best_score; o.pam = (int8_t)pi; o.offset = (uint8_t)best_off; o.pam_x = (uint16_t)best_x;
-                  uint32_t slot = atomicAdd(a.out_count, 1u);
-                  if (slot < a.out_capacity) a.out[slot] = o;
-                }
-              }
-            }
-          }
+      int j = 0, P = 0;
+      bool pass = false;
+      if (myb >= 0 && !(a.debug_skip & 2u)) {
+        j = dir ? (int)(wb - (p0 + myb)) : (int)(p0 + myb - wa) + 1;   // strand-space end column
+        P = fin[j - c0];
+        pass = (P >> 2) >= g_min_score;                                // fgbio: best of the three matrices >= minScore
+      }
+      const unsigned long long bal = __ballot(pass);
+      const uint32_t mine = (uint32_t)(bal >> (threadIdx.x & 32));     // this job's 32 lanes (only lanes 0..15 can pass)
+      if (mine != 0u && !(a.debug_skip & 32u)) {
+        uint8_t* slab = a.slab + ((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) * a.slab_bytes;
+        SlabHeader* hd = reinterpret_cast<SlabHeader*>(slab);
+        const int stride = (ncols + 4) & ~3;                           // bytes per trace row in the slab (columns 0..ncols)
+        const uint32_t tb_bytes = (uint32_t)((ntb + 3) & ~3);
+        if (r == 0 && !(a.debug_skip & 64u)) {
+          hd->contig = contig; hd->window_k = (uint32_t)k; hd->n = n; hd->c0 = c0; hd->ncols = (uint16_t)ncols; hd->ntb = (uint16_t)ntb;
+          hd->dir = (uint8_t)dir; hd->guide = (uint8_t)gi; hd->true_border = true_border ? 1 : 0; hd->L = (uint8_t)L;
+          hd->stride = (uint16_t)stride; hd->pad = 0;
+          hd->pass_mask = mine;
+        }
+        if (pass && !(a.debug_skip & 128u)) { hd->j[r] = (uint16_t)j; hd->best[r] = P; }
+        uint32_t* dtb = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader));
+        const uint32_t* stb = reinterpret_cast<const uint32_t*>(tb);
+        for (uint32_t x = r; x < tb_bytes / 4; x += 32) dtb[x] = stb[x];
+        if (r < L) {
+          uint32_t* drow = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader) + tb_bytes + (uint32_t)(r * stride));
+          const uint32_t* srow = reinterpret_cast<const uint32_t*>(&tr[r][0]);
+          for (int x = 0; x < stride / 4; x++) drow[x] = srow[x];
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
+}
+
+// Traceback + PAM extension of one candidate end column (item = (record, window slot, candidate index)).
+template <typename Emit>
+__device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& sp, uint64_t it, const uint8_t (*s_qmask)[MAX_L],
+                                          const uint8_t (*s_pam)[MAX_PAMS][MAX_PAM_LEN], const uint8_t (*s_pamlen)[MAX_PAMS],
+                                          const int (*s_gint)[2], uint32_t* s_ncand, Emit& emit) {
+  {
+    const int x = (int)(it & 15);
+    const uint8_t* slab = a.slab + (it >> 4) * a.slab_bytes;
+    const SlabHeader* hd = reinterpret_cast<const SlabHeader*>(slab);
+    if (!((hd->pass_mask >> x) & 1u)) return;
+    const uint8_t* tb = slab + sizeof(SlabHeader);
+    const uint8_t* tr = tb + ((hd->ntb + 3) & ~3);
+    const int L = hd->L, c0 = hd->c0, n = hd->n, gi = hd->guide, stride = hd->stride;
+    const bool true_border = hd->true_border != 0;
+    const int j = hd->j[x], best = hd->best[x], gscore = best >> 2;
+    const int g_npams = s_gint[gi][0];
+    atomicAdd(s_ncand, 1u);
+
+    int m = best & 3, i = L, c = j - c0;
+    uint32_t ops[RAW_MAX_OPS / 16] = {0, 0, 0};
+    int nops = 0, diffs = 0;
+    bool ok = true;
+    while (i > 0) {
+      if (nops >= RAW_MAX_OPS) { ok = false; break; }
+      int op;
+      if (c == 0) {
+        // true left border: only the Up matrix is finite there (leading insertions)
+        if (!true_border || m != TR_UP) { ok = false; break; }
+        op = 2; i--;                                   // 'I'; Up(i,0) traces to Up, Up(1,0) to Diag(0,0)
+      } else {
+        const int t8 = tr[(i - 1) * stride + c];
+        if (m == TR_DIAG) {
+          const int tm = tb[c - 1], q = s_qmask[gi][i - 1];
+          const bool compat = (q & tm & 15) != 0;
+          const bool eq = sp.eqx_by_score ? (compat && !(tm & 16)) : compat;
+          op = eq ? 0 : 1;
+          m = t8 & 3; i--; c--;
+        } else if (m == TR_UP) {
+          op = 2; m = ((t8 >> 2) & 1) ? TR_UP : TR_DIAG; i--;
+        } else {
+          op = 3; m = ((t8 >> 3) & 1) ? TR_LEFT : TR_DIAG; c--;
+        }
+      }
+      if (op != 0) diffs++;
+      ops[nops >> 4] |= (uint32_t)op << ((nops & 15) * 2);
+      nops++;
+    }
+    if (!ok) { atomicAdd(a.anomalies, 1u); return; }
+    if (diffs > sp.max_guide_diffs) return;
+    RawAln o;
+    o.contig = hd->contig; o.window_k = hd->window_k; o.t_start = (uint16_t)(c0 + c + 1); o.t_end_guide = (uint16_t)j;
+    o.dir = hd->dir; o.guide = hd->guide; o.n_ops = (uint8_t)nops; o.pad = 0;
+    uint32_t* ow = reinterpret_cast<uint32_t*>(o.ops);
+    ow[0] = ops[0]; ow[1] = ops[1]; ow[2] = ops[2];
+    if (g_npams == 0) {
+      o.score = gscore; o.pam = -1; o.offset = 0; o.pam_x = 0;
+      emit(o);
+      return;
+    }
+    // terminal indel run = first ops of the traceback
+    int term = 0;
+    {
+      const int op0 = ops[0] & 3;
+      if (op0 >= 2) { term = 1; while (term < nops && (int)((ops[term >> 4] >> ((term & 15) * 2)) & 3) == op0) term++; }
+    }
+    int max_extra = sp.max_gaps - term;
+    if (sp.max_diffs_filtering - diffs < max_extra) max_extra = sp.max_diffs_filtering - diffs;
+    for (int pi = 0; pi < g_npams; pi++) {
+      const int plen = s_pamlen[gi][pi];
+      bool have = false; int best_score = 0, best_off = 0; uint32_t best_x = 0;
+      for (int off = 0; off <= max_extra; off++) {
+        const int toff = j + off;                   // 0-based strand-space offset of the first PAM base
+        int limit = sp.max_pam_mismatches;
+        if (sp.max_diffs_filtering - diffs - off < limit) limit = sp.max_diffs_filtering - diffs - off;
+        if (toff + plen > n || limit < 0) continue;
+        int sc = 0, nx = 0; uint32_t xm = 0;
+        for (int q = 0; q < plen; q++) {
+          const int tm = tb[toff + q - c0];
+          const bool match = ((s_pam[gi][pi][q] & tm & 15) != 0) && !(tm & 16);
+          const int addend = match ? sp.pam_match : sp.pam_mismatch;
+          sc += addend;
+          if (!(addend > 0)) { nx++; xm |= 1u << q; }
+        }
+        if (nx > limit) continue;
+        const int total = gscore + sc + off * sp.query_gap;
+        if (!have || total > best_score) { have = true; best_score = total; best_off = off; best_x = xm; }
+      }
+      if (have) {
+        o.score = best_score; o.pam = (int8_t)pi; o.offset = (uint8_t)best_off; o.pam_x = (uint16_t)best_x;
+        emit(o);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// trace_kernel: one lane per candidate end column -- traceback through the strip's trace matrix (slab in HBM),
+// '='/'X' ops, extendAndFilterRight (SequentialGuideAligner.scala:433-492), one RawAln per (candidate, PAM).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
+  __shared__ uint8_t s_qmask[MAX_GUIDES][MAX_L];
+  __shared__ uint8_t s_pam[MAX_GUIDES][MAX_PAMS][MAX_PAM_LEN];
+  __shared__ uint8_t s_pamlen[MAX_GUIDES][MAX_PAMS];
+  __shared__ int s_gint[MAX_GUIDES][2];     // n_pams, min_guide_score
+  for (int i = threadIdx.x; i < a.sp.n_guides * MAX_L; i += blockDim.x) s_qmask[i / MAX_L][i % MAX_L] = a.guides[i / MAX_L].qmask[i % MAX_L];
+  for (int i = threadIdx.x; i < a.sp.n_guides * MAX_PAMS * MAX_PAM_LEN; i += blockDim.x) {
+    const int gi = i / (MAX_PAMS * MAX_PAM_LEN), rem = i % (MAX_PAMS * MAX_PAM_LEN);
+    s_pam[gi][rem / MAX_PAM_LEN][rem % MAX_PAM_LEN] = a.guides[gi].pam_mask[rem / MAX_PAM_LEN][rem % MAX_PAM_LEN];
+  }
+  for (int i = threadIdx.x; i < a.sp.n_guides * MAX_PAMS; i += blockDim.x) s_pamlen[i / MAX_PAMS][i % MAX_PAMS] = a.guides[i / MAX_PAMS].pam_len[i % MAX_PAMS];
+  for (int i = threadIdx.x; i < a.sp.n_guides; i += blockDim.x) { s_gint[i][0] = a.guides[i].n_pams; s_gint[i][1] = a.guides[i].min_guide_score; }
+  __syncthreads();
+
+  __shared__ RawAln s_out[TRACE_STAGE];
+  __shared__ uint32_t s_nout, s_obase, s_ncand;
+  if (threadIdx.x == 0) { s_nout = 0; s_ncand = 0; }
+  __syncthreads();
+
+  uint32_t n_recs = *a.rec_count;
+  if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
+  const uint64_t n_items = (uint64_t)n_recs * a.slots_per_rec * 16;   // (record, window slot, candidate index)
+  const SearchDev& sp = a.sp;
+  // Results are staged in LDS and flushed with one global atomic per flush (see stage_record above for why).
+  auto emit = [&](const RawAln& o) {
+    const uint32_t slot = atomicAdd(&s_nout, 1u);                     // LDS atomic
+    if (slot < (uint32_t)TRACE_STAGE) { s_out[slot] = o; return; }
+    const uint32_t g = atomicAdd(a.out_count, 1u);                    // stage full: append directly
+    if (g < a.out_capacity) a.out[g] = o;
+  };
+  auto flush = [&]() {                                                // block-uniform call sites only
+    __syncthreads();
+    const uint32_t n = min(s_nout, (uint32_t)TRACE_STAGE);
+    if (n != 0) {
+      if (threadIdx.x == 0) s_obase = atomicAdd(a.out_count, n);
+      __syncthreads();
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(s_out);
+      constexpr uint32_t WPR = sizeof(RawAln) / 4;
+      for (uint32_t w = threadIdx.x; w < n * WPR; w += blockDim.x) {
+        const uint32_t g = s_obase + w / WPR;
+        if (g < a.out_capacity) reinterpret_cast<uint32_t*>(a.out + g)[w % WPR] = src[w];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_nout = 0;
+      __syncthreads();
+    }
+  };
+
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n_items; base += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t it = base + threadIdx.x;
+    if (it < n_items) trace_one(a, sp, it, s_qmask, s_pam, s_pamlen, s_gint, &s_ncand, emit);
+    __syncthreads();
+    const uint32_t staged = s_nout;     // same value in every thread: nobody appends between the two barriers
+    __syncthreads();
+    if (staged > (uint32_t)(TRACE_STAGE / 2)) flush();
+  }
+  flush();
+  if (threadIdx.x == 0 && s_ncand) atomicAdd(a.cand_count, s_ncand);
 }
 
 // Window table of windowIterator (SearchReference.scala:39-71) for one (window size, step): out[win_base[c] + k] = N-trimmed
@@ -507,6 +631,11 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
 
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
   hipLaunchKernelGGL(align_kernel, dim3(n_blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(trace_kernel, dim3(n_blocks), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

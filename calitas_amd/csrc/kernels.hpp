@@ -34,14 +34,20 @@ struct AlignArgs {
   RawAln* out;
   uint32_t* out_count;
   uint32_t* anomalies;
+  uint8_t* slab;            // strips handed from align_kernel to trace_kernel: rec_capacity x slots_per_rec slabs
+  uint32_t* cand_count;     // statistics only
+  uint32_t slab_bytes;      // size of one slab
+  uint32_t slots_per_rec;   // windows a 16-base record can fall into
   uint32_t rec_capacity;
   uint32_t out_capacity;
   uint32_t tile_words;     // code words per scan tile
+  uint32_t debug_skip;     // ablation switches for profiling (0 in production): 1 = no fill, 2 = no traceback/emit, 4 = no staging
   SearchDev sp;
 };
 
 hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_window_table(const Run* runs, int64_t n_runs, const ContigInfo* contigs, const uint64_t* win_base, int n_contigs,
                                uint64_t n_windows, int W, int step, int2* out, hipStream_t stream);
 hipError_t launch_dpp_selftest(int* out, hipStream_t stream);

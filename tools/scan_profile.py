@@ -28,9 +28,14 @@ ctx = C.Context(0)
 ctx.set_reference(names, seqs)
 G = [C.Guide("CTTGCCCCACAGGGCAGTAAnrg")]
 params = C.make_params(max_gaps_between_guide_and_pam=2)
+ts = []
 for i in range(steps):
     out, n = ctx.search_raw(G, params)
     C._lib.lib.calitas_free(out)
     t = ctx.timing()
+    ts.append(t)
     print("step %d: scan %.3f ms align %.3f ms, %d alignments, packed bytes %d" % (i, t["scan_kernel_ms"], t["align_kernel_ms"], n, t["packed_bytes"]), flush=True)
+print("min over %d steps: scan %.3f ms, align %.3f ms, gpu_total %.3f ms, host filter %.3f ms" % (
+    steps, min(t["scan_kernel_ms"] for t in ts), min(t["align_kernel_ms"] for t in ts), min(t["gpu_total_ms"] for t in ts),
+    min(t["host_post_ms"] for t in ts)), flush=True)
 ctx.close()
