@@ -415,6 +415,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     sa.codes = ctx->d_codes; sa.mask = ctx->d_mask; sa.tiles = ctx->d_tiles; sa.guides = ctx->d_guides;
     sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
     sa.n_guides = n_guides; sa.chrom_index = p.chrom_index;
+    sa.debug_skip = std::getenv("CALITAS_DEBUG_SCAN") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SCAN")) : 0u;
     AlignArgs aa{};
     aa.codes = ctx->d_codes; aa.mask = ctx->d_mask; aa.runs = ctx->d_runs; aa.n_runs = (int64_t)ref.runs.size();
     aa.contigs = ctx->d_contigs; aa.tiles = ctx->d_tiles; aa.win_base = ctx->d_win_base; aa.win = ctx->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;

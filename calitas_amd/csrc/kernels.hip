@@ -207,11 +207,11 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, uint32_t tile, uint
         myers_step2(ea.x, pvA, mvA, scA, accA, eb.y, pvB, mvB, scB, accB);
         myers_step2(ea.y, pvA, mvA, scA, accA, eb.x, pvB, mvB, scB, accB);
       }
-      if (wa >= 0 && accA < 0) {
+      if (wa >= 0 && accA < 0 && !(a.debug_skip & 1u)) {
         const uint32_t hm = replay_word<MASKED, true>(tabA, wordA, mA, pvA0, mvA0, scA0);
         stage_record(a, s_recs, s_nrec, gword0 + (uint32_t)wa, hm | ((uint32_t)gi << 17));
       }
-      if (wb < WPC && accB < 0) {
+      if (wb < WPC && accB < 0 && !(a.debug_skip & 1u)) {
         const uint32_t hm = replay_word<MASKED, false>(tabB, wordB, mB, pvB0, mvB0, scB0);
         stage_record(a, s_recs, s_nrec, gword0 + (uint32_t)wb, hm | (1u << 16) | ((uint32_t)gi << 17));
       }
