@@ -1,3 +1,4 @@
 """calitas_amd -- MI355X-native CALITAS SearchReference hot path (HIP kernels behind a C ABI)."""
 from .aligner import (Alignment, CalitasError, Context, Defaults, Guide, SearchReference, make_params, read_hits,  # noqa: F401
                       window_filter)
+from .tools import GuideAlignment, SequentialGuideAligner, pairwise_align_sequences  # noqa: F401,E402

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcalitas_hip.so")
 
-MAX_OPS = 96
+MAX_OPS = 128
 OK, EINVAL, ENODEV, EHIP, EIO, ESTATE = 0, 1, 2, 3, 4, 5
 
 
@@ -50,7 +50,7 @@ class TimingT(ctypes.Structure):
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
            "calitas_set_reference_fasta", "calitas_reference_info", "calitas_contig_name", "calitas_fetch_bases",
            "calitas_window_table", "calitas_search", "calitas_get_timing", "calitas_window_filter", "calitas_hits_tsv",
-           "calitas_padded_strings", "calitas_version"]
+           "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError("%s is missing: build it with `make -C calitas_amd/csrc` (hipcc, gfx950). "
@@ -84,6 +84,14 @@ lib.calitas_hits_tsv.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes
                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_padded_strings.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.POINTER(AlnT), ctypes.c_char_p,
                                        ctypes.c_char_p, ctypes.c_char_p]
+
+
+lib.calitas_align_windows.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(GuideT), ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ParamsT),
+                                      ctypes.POINTER(ctypes.POINTER(AlnT)), ctypes.POINTER(ctypes.c_uint64),
+                                      ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
+lib.calitas_padded_strings_target.argtypes = [ctypes.POINTER(GuideT), ctypes.POINTER(AlnT), ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int32,
+                                              ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
 
 
 def check(ctx, rc):

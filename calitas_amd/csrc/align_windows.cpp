@@ -1,0 +1,256 @@
+// align_windows.cpp -- calitas_align_windows: SequentialGuideAligner.align / alignBest on explicit (guide, target) pairs
+// through the same GPU kernels as SearchReference.  This is the seam PairwiseAlignSequences (PairwiseAlignSequences.scala:64)
+// and AlignToReference (AlignToReference.scala:114-135 via SequentialGuideAligner.scala:359-418) call per task.
+//
+// Every task becomes one contig of a temporary packed reference with a single window [0, len) (no N trimming, no
+// upper-casing requirement: SGA.align works on the bytes it is given and scoring is case-insensitive).  The scan kernel is
+// skipped: with alignBest's limits (d = protospacer length) practically every column reaches minGuideScore, so all
+// columns of both strands go to align_kernel, whose threshold test is the exact enumeration rule anyway.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+struct TempDevice {
+  uint32_t* codes = nullptr; uint32_t* mask = nullptr; Run* runs = nullptr; ContigInfo* contigs = nullptr; TileInfo* tiles = nullptr;
+  uint64_t* win_base = nullptr; int2* win = nullptr; GuideDev* guides = nullptr;
+  ~TempDevice() {
+    (void)hipFree(codes); (void)hipFree(mask); (void)hipFree(runs); (void)hipFree(contigs); (void)hipFree(tiles);
+    (void)hipFree(win_base); (void)hipFree(win); (void)hipFree(guides);
+  }
+};
+
+}  // namespace
+
+extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const calitas_guide_t* guides, const uint8_t* const* targets,
+                                     const uint32_t* target_lengths, const int32_t* target_offsets, const calitas_params_t* params,
+                                     calitas_aln_t** out, uint64_t* n_out, uint32_t** counts) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!guides || !targets || !target_lengths || !params || !out || !n_out || n_tasks < 0) return calitas_fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *out = nullptr; *n_out = 0;
+  if (counts) *counts = nullptr;
+  if (ctx->device < 0) return calitas_fail(ctx, CALITAS_ENODEV, "host-only context: calitas_align_windows needs a GPU (there is no CPU fallback)");
+  const calitas_params_t& p = *params;
+  if (p.max_gaps_between_guide_and_pam < 0 || p.max_gaps_between_guide_and_pam > 16) return calitas_fail(ctx, CALITAS_EINVAL, "max-gaps-between-guide-and-pam must be 0..16");
+  const bool best_mode = p.max_guide_diffs < 0;   // alignBest / alignToRefBest: limits derived from each guide (SGA:339-342, 412-416)
+  const Scores sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  std::vector<calitas_aln_t> result;
+  std::vector<uint32_t> per_task((size_t)std::max(n_tasks, 0), 0u);
+  std::vector<GuideHost> gh((size_t)n_tasks);
+  std::vector<int> task_d(n_tasks), task_p(n_tasks), task_D(n_tasks), task_O(n_tasks);
+  for (int t = 0; t < n_tasks; t++) {
+    std::string e = make_guide_host(guides[t], gh[t]);
+    if (!e.empty()) return calitas_fail(ctx, CALITAS_EINVAL, "task " + std::to_string(t) + ": " + e);
+    if (target_lengths[t] > 60000) return calitas_fail(ctx, CALITAS_EINVAL, "targets longer than 60000 bases are not supported here");
+    const int L = (int)gh[t].protospacer.size();
+    int pamlen = 0;
+    for (auto& pm : gh[t].pams) pamlen = std::max<int>(pamlen, (int)pm.size());
+    if (best_mode) { task_d[t] = L; task_p[t] = pamlen; task_D[t] = L + p.max_gaps_between_guide_and_pam + pamlen; task_O[t] = 0; }
+    else {
+      task_d[t] = p.max_guide_diffs; task_p[t] = p.max_pam_mismatches; task_O[t] = p.max_overlap;
+      task_D[t] = p.max_total_diffs >= 0 ? p.max_total_diffs : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;
+    }
+  }
+
+  // ---- process the tasks in chunks of at most MAX_GUIDES distinct (guide, limits) configurations and 8192 tasks ----
+  int t0 = 0;
+  while (t0 < n_tasks) {
+    std::map<std::string, int> slot_of;
+    std::vector<int> slot_task;              // representative task of each slot
+    std::vector<int> task_slot;
+    int t1 = t0;
+    while (t1 < n_tasks && t1 - t0 < 8192) {
+      std::string key = gh[t1].q + "|" + std::to_string(gh[t1].pam5) + "|" + std::to_string(task_d[t1]) + "|" + std::to_string(task_p[t1]);
+      for (auto& pm : gh[t1].pams_q) key += "|" + pm;
+      auto it = slot_of.find(key);
+      if (it == slot_of.end()) {
+        if ((int)slot_task.size() == MAX_GUIDES) break;
+        it = slot_of.emplace(key, (int)slot_task.size()).first;
+        slot_task.push_back(t1);
+      }
+      task_slot.push_back(it->second);
+      t1++;
+    }
+    const int nt = t1 - t0, ns = (int)slot_task.size();
+
+    std::vector<GuideDev> gd(ns);
+    uint32_t slab_bytes = 0;
+    for (int s = 0; s < ns; s++) {
+      const int t = slot_task[s];
+      std::string e = build_guide_dev(gh[t], p, sc, task_d[t], task_p[t], gd[s]);
+      if (!e.empty()) return calitas_fail(ctx, CALITAS_EINVAL, "task " + std::to_string(t) + ": " + e);
+      gd[s].cli_length = 0;     // SGA.align itself has no length filter (that is SearchReference.scala:536)
+      const uint32_t ncols_max = 16 + gd[s].span + 1, stride_max = (ncols_max + 4) & ~3u;
+      const uint32_t ntb_max = (ncols_max + p.max_gaps_between_guide_and_pam + MAX_PAM_LEN + 3) & ~3u;
+      slab_bytes = std::max<uint32_t>(slab_bytes, (uint32_t)((sizeof(SlabHeader) + ntb_max + gd[s].L * stride_max + 15) & ~15u));
+    }
+
+    // temporary packed reference: one contig per task
+    std::vector<std::string> names(nt);
+    std::vector<const char*> name_ptrs(nt);
+    std::vector<uint64_t> lens(nt);
+    std::vector<const uint8_t*> bases(nt);
+    uint32_t W = 16;
+    for (int i = 0; i < nt; i++) {
+      names[i] = "t" + std::to_string(t0 + i); name_ptrs[i] = names[i].c_str();
+      lens[i] = target_lengths[t0 + i]; bases[i] = targets[t0 + i];
+      W = std::max<uint32_t>(W, target_lengths[t0 + i]);
+    }
+    PackedRef ref;
+    try { pack_reference(ref, nt, name_ptrs.data(), lens.data(), bases.data(), "windows", 1); }
+    catch (std::exception& e) { return calitas_fail(ctx, CALITAS_EINVAL, e.what()); }
+
+    // every column of every task, both directions
+    std::vector<ScanRecord> recs;
+    for (int i = 0; i < nt; i++) {
+      const uint32_t g0 = (uint32_t)(ref.contigs[i].gbase / 16);
+      for (uint32_t w = 0; w * 16 < lens[i]; w++) {
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(16, lens[i] - (uint64_t)w * 16);
+        const uint32_t m = nb == 16 ? 0xFFFFu : ((1u << nb) - 1u);
+        recs.push_back(ScanRecord{g0 + w, m | ((uint32_t)task_slot[i] << 17)});
+        recs.push_back(ScanRecord{g0 + w, m | (1u << 16) | ((uint32_t)task_slot[i] << 17)});
+      }
+    }
+    const uint32_t n_rec = (uint32_t)recs.size();
+    const uint32_t slots_per_rec = (W + 14) / W + 1;
+    const uint64_t slab_per_rec = (uint64_t)slab_bytes * slots_per_rec;
+    {
+      int rc = ensure_buffers(ctx, std::max<uint32_t>(n_rec, 1u << 12), std::max<uint32_t>(ctx->raw_cap, std::max<uint32_t>(n_rec * 4, 1u << 16)), slab_per_rec);
+      if (rc) return rc;
+    }
+
+    TempDevice td;
+    const size_t nruns = std::max<size_t>(1, ref.runs.size());
+    std::vector<uint64_t> wbase(nt + 1);
+    std::iota(wbase.begin(), wbase.end(), 0ull);
+    std::vector<int2> wins(nt);
+    for (int i = 0; i < nt; i++) wins[i] = make_int2(0, (int)lens[i]);
+    HIP_TRY(ctx, hipMalloc((void**)&td.codes, ref.codes.size() * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&td.mask, ref.mask.size() * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&td.runs, nruns * sizeof(Run)));
+    HIP_TRY(ctx, hipMalloc((void**)&td.contigs, ref.contigs.size() * sizeof(ContigInfo)));
+    HIP_TRY(ctx, hipMalloc((void**)&td.tiles, ref.tiles.size() * sizeof(TileInfo)));
+    HIP_TRY(ctx, hipMalloc((void**)&td.win_base, wbase.size() * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&td.win, std::max<size_t>(1, wins.size()) * sizeof(int2)));
+    HIP_TRY(ctx, hipMalloc((void**)&td.guides, sizeof(GuideDev) * ns));
+    HIP_TRY(ctx, hipMemcpyAsync(td.codes, ref.codes.data(), ref.codes.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(td.mask, ref.mask.data(), ref.mask.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!ref.runs.empty()) HIP_TRY(ctx, hipMemcpyAsync(td.runs, ref.runs.data(), ref.runs.size() * sizeof(Run), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(td.contigs, ref.contigs.data(), ref.contigs.size() * sizeof(ContigInfo), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(td.tiles, ref.tiles.data(), ref.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(td.win_base, wbase.data(), wbase.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (!wins.empty()) HIP_TRY(ctx, hipMemcpyAsync(td.win, wins.data(), wins.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(td.guides, gd.data(), sizeof(GuideDev) * ns, hipMemcpyHostToDevice, ctx->stream));
+    if (n_rec) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_recs, recs.data(), (size_t)n_rec * sizeof(ScanRecord), hipMemcpyHostToDevice, ctx->stream));
+
+    uint32_t n_raw = 0;
+    for (;;) {
+      uint32_t zero[8] = {n_rec, 0, 0, 0, 0, 0, 0, 0};
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_counters, zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
+      AlignArgs aa{};
+      aa.codes = td.codes; aa.mask = td.mask; aa.runs = td.runs; aa.n_runs = (int64_t)ref.runs.size();
+      aa.contigs = td.contigs; aa.tiles = td.tiles; aa.win_base = td.win_base; aa.win = td.win; aa.guides = td.guides; aa.recs = ctx->d_recs;
+      aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
+      aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap; aa.tile_words = (uint32_t)(ref.tile / 16);
+      aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = slab_bytes; aa.slots_per_rec = slots_per_rec;
+      aa.debug_skip = 0;
+      aa.sp.window_size = (int)W; aa.sp.step = (int)W; aa.sp.n_guides = ns;
+      aa.sp.max_guide_diffs = 0; aa.sp.max_pam_mismatches = 0; aa.sp.max_diffs_filtering = 0;   // per-guide values live in GuideDev
+      aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
+      aa.sp.match = sc.match; aa.sp.mismatch = sc.mismatch; aa.sp.pam_match = sc.pam_match; aa.sp.pam_mismatch = sc.pam_mismatch;
+      aa.sp.query_gap = sc.query_gap; aa.sp.target_gap = sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score; aa.sp.chrom_index = -1;
+      HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
+      HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->h_counters[2] != 0) return calitas_fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
+      n_raw = ctx->h_counters[1];
+      if (n_raw > ctx->raw_cap) {
+        int rc = ensure_buffers(ctx, ctx->rec_cap, n_raw + n_raw / 8, slab_per_rec);
+        if (rc) return rc;
+        continue;
+      }
+      break;
+    }
+    std::vector<RawAln> raw(n_raw);
+    if (n_raw) HIP_TRY(ctx, hipMemcpy(raw.data(), ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost));
+
+    // ---- host: enumeration order per task, conversion, SGA:315-320 ----
+    std::vector<uint32_t> order(n_raw);
+    std::iota(order.begin(), order.end(), 0u);
+    auto list_of = [&](const RawAln& r) { const bool pam5 = gh[t0 + (int)r.contig].pam5; return pam5 ? (r.dir == 1 ? 0 : 1) : (r.dir == 0 ? 0 : 1); };
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+      const RawAln &a = raw[x], &b = raw[y];
+      if (a.contig != b.contig) return a.contig < b.contig;
+      const int la = list_of(a), lb = list_of(b);
+      if (la != lb) return la < lb;
+      if (a.t_end_guide != b.t_end_guide) return a.t_end_guide < b.t_end_guide;
+      return a.pam < b.pam;
+    });
+    std::vector<calitas_aln_t> win;
+    std::vector<int> kept;
+    size_t i = 0;
+    while (i < order.size()) {
+      const uint32_t c = raw[order[i]].contig;
+      size_t j = i;
+      while (j < order.size() && raw[order[j]].contig == c) j++;
+      const int t = t0 + (int)c;
+      const int64_t off = target_offsets ? target_offsets[t] : 0;
+      win.resize(j - i);
+      for (size_t k = i; k < j; k++) {
+        raw_to_aln(raw[order[k]], gh[t], off, off + (int64_t)lens[c], win[k - i]);
+        win[k - i].contig_index = t;       // task index
+        win[k - i].guide_index = t;
+      }
+      window_filter(win.data(), (int)win.size(), task_D[t], task_O[t], kept);
+      for (int k : kept) result.push_back(win[k]);
+      per_task[t] = (uint32_t)kept.size();
+      i = j;
+    }
+    t0 = t1;
+  }
+
+  *n_out = result.size();
+  *out = (calitas_aln_t*)calitas_out_alloc(std::max<size_t>(1, result.size()) * sizeof(calitas_aln_t));
+  if (!*out) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
+  if (!result.empty()) std::memcpy(*out, result.data(), result.size() * sizeof(calitas_aln_t));
+  if (counts) {
+    *counts = (uint32_t*)calitas_out_alloc(std::max<size_t>(1, per_task.size()) * sizeof(uint32_t));
+    if (!*counts) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
+    if (!per_task.empty()) std::memcpy(*counts, per_task.data(), per_task.size() * sizeof(uint32_t));
+  }
+  return CALITAS_OK;
+}
+
+// Padded strings of an alignment returned by calitas_align_windows, built from the caller's own target bytes (case kept,
+// as Alignment.paddedString does at SequentialGuideAligner.scala:511; '-' strand: Sequences.revcomp of the window).
+extern "C" int calitas_padded_strings_target(const calitas_guide_t* guide, const calitas_aln_t* aln, const uint8_t* target, uint32_t target_length,
+                                             int32_t target_offset, char* padded_guide, char* padded_alignment, char* padded_target) {
+  if (!guide || !aln || !target || !padded_guide || !padded_alignment || !padded_target) return CALITAS_EINVAL;
+  GuideHost gh;
+  if (!make_guide_host(*guide, gh).empty()) return CALITAS_EINVAL;
+  const int64_t s = (int64_t)aln->start_offset - target_offset, e = (int64_t)aln->end_offset - target_offset;
+  if (s < 0 || e > (int64_t)target_length || s > e) return CALITAS_EINVAL;
+  std::string t(reinterpret_cast<const char*>(target) + s, (size_t)(e - s));
+  if (aln->strand == '-') t = revcomp_str(t);
+  const std::string q = gh.query_for(aln->pam_index);
+  size_t qi = 0, ti = 0;
+  int n = aln->n_ops;
+  for (int i = 0; i < n; i++) {
+    switch (aln->ops[i]) {
+      case 'I': padded_guide[i] = q[qi++]; padded_alignment[i] = '~'; padded_target[i] = '-'; break;
+      case 'D': padded_guide[i] = '-'; padded_alignment[i] = '~'; padded_target[i] = t[ti++]; break;
+      case '=': padded_guide[i] = q[qi++]; padded_alignment[i] = '|'; padded_target[i] = t[ti++]; break;
+      default:  padded_guide[i] = q[qi++]; padded_alignment[i] = '.'; padded_target[i] = t[ti++]; break;
+    }
+  }
+  padded_guide[n] = padded_alignment[n] = padded_target[n] = 0;
+  return CALITAS_OK;
+}

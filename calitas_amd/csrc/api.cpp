@@ -21,41 +21,7 @@
 #include "parallel.hpp"
 #include "post.hpp"
 #include "refpack.hpp"
-
-using namespace calitas;
-
-struct calitas_ctx {
-  int device = -1;
-  std::string err;
-  PackedRef ref;
-  bool has_ref = false;
-  // device state
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  uint32_t* d_codes = nullptr;
-  uint32_t* d_mask = nullptr;
-  Run* d_runs = nullptr;
-  ContigInfo* d_contigs = nullptr;
-  TileInfo* d_tiles = nullptr;
-  uint32_t* d_tile_list = nullptr;
-  uint64_t* d_win_base = nullptr;   // window table for (win_W, win_step)
-  int2* d_win = nullptr;
-  uint64_t win_cap = 0;
-  int win_W = 0, win_step = 0;
-  GuideDev* d_guides = nullptr;
-  ScanRecord* d_recs = nullptr;
-  RawAln* d_raw = nullptr;
-  uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies, [3] slab units, [4] candidates
-  uint8_t* d_slab = nullptr;        // strips handed from align_kernel to trace_kernel
-  uint64_t slab_cap = 0;            // bytes
-  uint32_t* h_counters = nullptr;   // pinned
-  uint32_t rec_cap = 0, raw_cap = 0;
-  RawAln* h_raw = nullptr;          // pinned staging for the copy-back
-  uint32_t h_raw_cap = 0;
-  calitas_timing_t timing{};
-  WorkerPool* pool = nullptr;
-  ~calitas_ctx() { delete pool; }
-};
+#include "ctx.hpp"
 
 static std::string g_create_error;
 
@@ -67,7 +33,7 @@ constexpr uint64_t kMagic = 0xCA117A5B10C0FFEEull;
 std::mutex g_pool_mutex;
 std::vector<BlockHeader*> g_pool;   // at most 4 parked blocks
 
-void* out_alloc(size_t size) {
+void* out_alloc_impl(size_t size) {
   if (size < 1) size = 1;
   {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
@@ -96,17 +62,14 @@ void out_free(void* p) {
   std::free(h);
 }
 }  // namespace
+void* calitas_out_alloc(size_t size) { return out_alloc_impl(size); }
+static void* out_alloc(size_t size) { return out_alloc_impl(size); }
 
-static int fail(calitas_ctx* ctx, int code, const std::string& msg) {
+int calitas_fail(calitas_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg; else g_create_error = msg;
   return code;
 }
-
-#define HIP_TRY(ctx, call)                                                                         \
-  do {                                                                                             \
-    hipError_t e_ = (call);                                                                        \
-    if (e_ != hipSuccess) return fail(ctx, CALITAS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-  } while (0)
+static int fail(calitas_ctx* ctx, int code, const std::string& msg) { return calitas_fail(ctx, code, msg); }
 
 static void free_reference_device(calitas_ctx* c) {
   if (c->device < 0) return;
@@ -276,17 +239,23 @@ int calitas_window_table(const calitas_ctx* ctx, int32_t window_size, int32_t st
   return CALITAS_OK;
 }
 
+}  // extern "C"
+
 // -------------------------------------------------------------------------------------------------------------------
 // search
 // -------------------------------------------------------------------------------------------------------------------
 
-static std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, GuideDev& gd) {
+std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, int max_guide_diffs, int max_pam_mismatches,
+                            GuideDev& gd) {
   std::memset(&gd, 0, sizeof(gd));
   const int L = (int)gh.q.size();
   gd.L = L;
   gd.n_pams = (int)gh.pams_q.size();
   gd.cli_length = gh.cli_length;
-  gd.min_guide_score = sc.match * L + sc.worst_guide_diff * p.max_guide_diffs;       // SGA:239-243
+  gd.min_guide_score = sc.match * L + sc.worst_guide_diff * max_guide_diffs;         // SGA:239-243
+  gd.max_guide_diffs = max_guide_diffs;
+  gd.max_pam_mismatches = max_pam_mismatches;
+  gd.max_diffs_filtering = max_guide_diffs + p.max_gaps_between_guide_and_pam + max_pam_mismatches;   // SGA:249
   const int budget = sc.match * L - gd.min_guide_score;                              // = |worst| * d
   // score(all matches) - score(path) = sum of per-edit costs: mismatch |m|, guide-only base |b|, genome-only base |B|
   const int c_mm = iabs(p.guide_mismatch_net_cost), c_ins = iabs(p.genome_gap_net_cost), c_del = iabs(p.guide_gap_net_cost);
@@ -316,7 +285,7 @@ static std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& 
   return "";
 }
 
-static int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec) {
+int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec) {
   rec_cap = std::max(rec_cap, ctx->rec_cap);
   if ((uint64_t)rec_cap * slab_per_rec > ctx->slab_cap) {
     (void)hipFree(ctx->d_slab); ctx->d_slab = nullptr; ctx->slab_cap = 0;
@@ -335,6 +304,8 @@ static int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, 
   }
   return CALITAS_OK;
 }
+
+extern "C" {
 
 int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                    calitas_aln_t** out, uint64_t* n_out) {
@@ -359,7 +330,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   int step = 0;
   for (int i = 0; i < n_guides; i++) {
     std::string e = make_guide_host(guides[i], gh[i]);
-    if (e.empty()) e = build_guide_dev(gh[i], p, sc, gd[i]);
+    if (e.empty()) e = build_guide_dev(gh[i], p, sc, p.max_guide_diffs, p.max_pam_mismatches, gd[i]);
     if (!e.empty()) return fail(ctx, CALITAS_EINVAL, "guide " + std::to_string(i) + ": " + e);
     // SR:529-530: the window step depends on the CLI guide length; one pass shares one tiling
     int overlap = gh[i].cli_length + p.max_guide_diffs + p.max_gaps_between_guide_and_pam - 1;

@@ -31,8 +31,8 @@ constexpr int MAX_L = 32;            // protospacer rows of the scan bit-vector
 constexpr int MAX_PAMS = 8;
 constexpr int MAX_PAM_LEN = 16;
 constexpr int MAX_GUIDES = 64;
-constexpr int STRIP_MAX_COLS = 64;   // columns of one aligner-kernel strip (16 candidate columns + span + 1)
-constexpr int RAW_MAX_OPS = 48;      // guide-part ops of one raw alignment (L + max extra genome bases)
+constexpr int STRIP_MAX_COLS = 96;   // columns of one aligner-kernel strip (16 candidate columns + span + 1; span <= 2 * MAX_L)
+constexpr int RAW_MAX_OPS = 80;      // guide-part ops of one raw alignment (L + max extra genome bases)
 
 struct Run {             // exception run in packed space
   uint64_t start;        // packed position of the first base
@@ -104,6 +104,9 @@ struct GuideDev {
   int32_t min_guide_score;
   int32_t span;           // L + max genome-only bases of any alignment scoring >= min_guide_score
   int32_t cli_length;
+  int32_t max_guide_diffs;      // -d for this guide
+  int32_t max_pam_mismatches;   // -p
+  int32_t max_diffs_filtering;  // d + g + p (SequentialGuideAligner.scala:249)
 };
 
 struct SearchDev {        // scalar parameters of one search

@@ -1,0 +1,61 @@
+// ctx.hpp -- private: the context object behind the C ABI and helpers shared by api.cpp / align_windows.cpp.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+
+#include "../../include/calitas_hip.h"
+#include "common.hpp"
+#include "kernels.hpp"
+#include "parallel.hpp"
+#include "post.hpp"
+#include "refpack.hpp"
+
+using namespace calitas;
+
+struct calitas_ctx {
+  int device = -1;
+  std::string err;
+  PackedRef ref;
+  bool has_ref = false;
+  // device state
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* d_codes = nullptr;
+  uint32_t* d_mask = nullptr;
+  Run* d_runs = nullptr;
+  ContigInfo* d_contigs = nullptr;
+  TileInfo* d_tiles = nullptr;
+  uint32_t* d_tile_list = nullptr;
+  uint64_t* d_win_base = nullptr;   // window table for (win_W, win_step)
+  int2* d_win = nullptr;
+  uint64_t win_cap = 0;
+  int win_W = 0, win_step = 0;
+  GuideDev* d_guides = nullptr;
+  ScanRecord* d_recs = nullptr;
+  RawAln* d_raw = nullptr;
+  uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies, [3] slab units, [4] candidates
+  uint8_t* d_slab = nullptr;        // strips handed from align_kernel to trace_kernel
+  uint64_t slab_cap = 0;            // bytes
+  uint32_t* h_counters = nullptr;   // pinned
+  uint32_t rec_cap = 0, raw_cap = 0;
+  RawAln* h_raw = nullptr;          // pinned staging for the copy-back
+  uint32_t h_raw_cap = 0;
+  calitas_timing_t timing{};
+  WorkerPool* pool = nullptr;
+  ~calitas_ctx() { delete pool; }
+};
+
+
+int calitas_fail(calitas_ctx* ctx, int code, const std::string& msg);
+void* calitas_out_alloc(size_t size);
+// Per-guide device constants for limits (d, p) and costs; returns an error text or "".
+std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, int max_guide_diffs, int max_pam_mismatches,
+                            GuideDev& gd);
+int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec);
+
+#define HIP_TRY(ctx, call)                                                                         \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) return calitas_fail(ctx, CALITAS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)

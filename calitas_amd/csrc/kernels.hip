@@ -255,7 +255,7 @@ constexpr int NEG = -(1 << 20);                      // "minus infinity" that su
 constexpr int JOBS_PER_BLOCK = 8;                    // one job per 32-lane half wave
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
 constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
-constexpr int TR_STRIDE = 72;                        // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; 71 lanes apart in time -> few bank conflicts)
+constexpr int TR_STRIDE = 100;                       // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; lane r writes byte 99r + t)
 
 __device__ __forceinline__ int shift_up_lane(int v) {
   // value of lane-1 (DPP wave shift right by one); lane 0 keeps its own value, which callers ignore
@@ -284,7 +284,7 @@ __device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
 }
 
 __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
-  // trace rows are 72 bytes apart: lane r writes byte 71r + t at step t, which spreads the 32 lanes over the banks
+  // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the 32 lanes over the banks
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
   __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
 template <typename Emit>
 __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& sp, uint64_t it, const uint8_t (*s_qmask)[MAX_L],
                                           const uint8_t (*s_pam)[MAX_PAMS][MAX_PAM_LEN], const uint8_t (*s_pamlen)[MAX_PAMS],
-                                          const int (*s_gint)[2], uint32_t* s_ncand, Emit& emit) {
+                                          const int (*s_gint)[4], uint32_t* s_ncand, Emit& emit) {
   {
     const int x = (int)(it & 15);
     const uint8_t* slab = a.slab + (it >> 4) * a.slab_bytes;
@@ -449,11 +449,11 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
     const int L = hd->L, c0 = hd->c0, n = hd->n, gi = hd->guide, stride = hd->stride;
     const bool true_border = hd->true_border != 0;
     const int j = hd->j[x], best = hd->best[x], gscore = best >> 2;
-    const int g_npams = s_gint[gi][0];
+    const int g_npams = s_gint[gi][0], g_maxd = s_gint[gi][1], g_maxp = s_gint[gi][2], g_maxf = s_gint[gi][3];
     atomicAdd(s_ncand, 1u);
 
     int m = best & 3, i = L, c = j - c0;
-    uint32_t ops[RAW_MAX_OPS / 16] = {0, 0, 0};
+    uint32_t ops[RAW_MAX_OPS / 16] = {0, 0, 0, 0, 0};
     int nops = 0, diffs = 0;
     bool ok = true;
     while (i > 0) {
@@ -482,12 +482,13 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
       nops++;
     }
     if (!ok) { atomicAdd(a.anomalies, 1u); return; }
-    if (diffs > sp.max_guide_diffs) return;
+    if (diffs > g_maxd) return;
     RawAln o;
     o.contig = hd->contig; o.window_k = hd->window_k; o.t_start = (uint16_t)(c0 + c + 1); o.t_end_guide = (uint16_t)j;
     o.dir = hd->dir; o.guide = hd->guide; o.n_ops = (uint8_t)nops; o.pad = 0;
     uint32_t* ow = reinterpret_cast<uint32_t*>(o.ops);
-    ow[0] = ops[0]; ow[1] = ops[1]; ow[2] = ops[2];
+#pragma unroll
+    for (int w = 0; w < RAW_MAX_OPS / 16; w++) ow[w] = ops[w];
     if (g_npams == 0) {
       o.score = gscore; o.pam = -1; o.offset = 0; o.pam_x = 0;
       emit(o);
@@ -500,14 +501,14 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
       if (op0 >= 2) { term = 1; while (term < nops && (int)((ops[term >> 4] >> ((term & 15) * 2)) & 3) == op0) term++; }
     }
     int max_extra = sp.max_gaps - term;
-    if (sp.max_diffs_filtering - diffs < max_extra) max_extra = sp.max_diffs_filtering - diffs;
+    if (g_maxf - diffs < max_extra) max_extra = g_maxf - diffs;
     for (int pi = 0; pi < g_npams; pi++) {
       const int plen = s_pamlen[gi][pi];
       bool have = false; int best_score = 0, best_off = 0; uint32_t best_x = 0;
       for (int off = 0; off <= max_extra; off++) {
         const int toff = j + off;                   // 0-based strand-space offset of the first PAM base
-        int limit = sp.max_pam_mismatches;
-        if (sp.max_diffs_filtering - diffs - off < limit) limit = sp.max_diffs_filtering - diffs - off;
+        int limit = g_maxp;
+        if (g_maxf - diffs - off < limit) limit = g_maxf - diffs - off;
         if (toff + plen > n || limit < 0) continue;
         int sc = 0, nx = 0; uint32_t xm = 0;
         for (int q = 0; q < plen; q++) {
@@ -537,14 +538,17 @@ __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
   __shared__ uint8_t s_qmask[MAX_GUIDES][MAX_L];
   __shared__ uint8_t s_pam[MAX_GUIDES][MAX_PAMS][MAX_PAM_LEN];
   __shared__ uint8_t s_pamlen[MAX_GUIDES][MAX_PAMS];
-  __shared__ int s_gint[MAX_GUIDES][2];     // n_pams, min_guide_score
+  __shared__ int s_gint[MAX_GUIDES][4];     // n_pams, max_guide_diffs, max_pam_mismatches, max_diffs_filtering
   for (int i = threadIdx.x; i < a.sp.n_guides * MAX_L; i += blockDim.x) s_qmask[i / MAX_L][i % MAX_L] = a.guides[i / MAX_L].qmask[i % MAX_L];
   for (int i = threadIdx.x; i < a.sp.n_guides * MAX_PAMS * MAX_PAM_LEN; i += blockDim.x) {
     const int gi = i / (MAX_PAMS * MAX_PAM_LEN), rem = i % (MAX_PAMS * MAX_PAM_LEN);
     s_pam[gi][rem / MAX_PAM_LEN][rem % MAX_PAM_LEN] = a.guides[gi].pam_mask[rem / MAX_PAM_LEN][rem % MAX_PAM_LEN];
   }
   for (int i = threadIdx.x; i < a.sp.n_guides * MAX_PAMS; i += blockDim.x) s_pamlen[i / MAX_PAMS][i % MAX_PAMS] = a.guides[i / MAX_PAMS].pam_len[i % MAX_PAMS];
-  for (int i = threadIdx.x; i < a.sp.n_guides; i += blockDim.x) { s_gint[i][0] = a.guides[i].n_pams; s_gint[i][1] = a.guides[i].min_guide_score; }
+  for (int i = threadIdx.x; i < a.sp.n_guides; i += blockDim.x) {
+    s_gint[i][0] = a.guides[i].n_pams; s_gint[i][1] = a.guides[i].max_guide_diffs;
+    s_gint[i][2] = a.guides[i].max_pam_mismatches; s_gint[i][3] = a.guides[i].max_diffs_filtering;
+  }
   __syncthreads();
 
   __shared__ RawAln s_out[TRACE_STAGE];

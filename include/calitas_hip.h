@@ -36,7 +36,7 @@ extern "C" {
 #define CALITAS_MAX_PROTOSPACER 32   /* rows of the bit-vector scan kernel */
 #define CALITAS_MAX_PAMS 8
 #define CALITAS_MAX_PAM_LEN 16
-#define CALITAS_MAX_OPS 96           /* padded alignment columns per record */
+#define CALITAS_MAX_OPS 128          /* padded alignment columns per record */
 #define CALITAS_MAX_GUIDES 64        /* guides per calitas_search batch */
 
 typedef struct calitas_ctx calitas_ctx;
@@ -138,6 +138,21 @@ int calitas_window_table(const calitas_ctx* ctx, int32_t window_size, int32_t st
 int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                    calitas_aln_t** out, uint64_t* n_out);
 int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
+
+/* SequentialGuideAligner.align on explicit (guide, target) pairs -- the per-task call of PairwiseAlignSequences
+ * (PairwiseAlignSequences.scala:64 -> alignBest, SequentialGuideAligner.scala:333-345) and AlignToReference
+ * (AlignToReference.scala:114-135 -> alignToRef / alignToRefBest, SequentialGuideAligner.scala:359-418).  Task t aligns
+ * guides[t] to targets[t] (target_lengths[t] bytes, used as given: no N trimming, case-insensitive scoring) with
+ * targetOffset = target_offsets[t] (NULL = 0).  params->max_guide_diffs < 0 selects alignBest's limits per task
+ * (d = protospacer length, p = longest PAM, D = d + g + p, maxOverlap = 0); otherwise the limits in params apply to every
+ * task.  *out receives, task by task, what align() returns (forward-strand list then reverse-strand list after the
+ * overlap filter); contig_index / guide_index of each record hold the task index; counts[t] = alignments of task t. */
+int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const calitas_guide_t* guides, const uint8_t* const* targets,
+                          const uint32_t* target_lengths, const int32_t* target_offsets, const calitas_params_t* params,
+                          calitas_aln_t** out, uint64_t* n_out, uint32_t** counts);
+/* Padded strings of a record returned by calitas_align_windows, from the caller's own target bytes (case preserved). */
+int calitas_padded_strings_target(const calitas_guide_t* guide, const calitas_aln_t* aln, const uint8_t* target, uint32_t target_length,
+                                  int32_t target_offset, char* padded_guide, char* padded_alignment, char* padded_target);
 
 /* Host-side stages, usable on a host-only context ------------------------------------------------------------------ */
 
