@@ -48,7 +48,7 @@ class TimingT(ctypes.Structure):
 
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
-           "calitas_set_reference_fasta", "calitas_reference_info", "calitas_contig_name", "calitas_fetch_bases",
+           "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_fetch_bases",
            "calitas_window_table", "calitas_search", "calitas_get_timing", "calitas_window_filter", "calitas_hits_tsv",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
@@ -68,6 +68,8 @@ lib.calitas_free.restype = None
 lib.calitas_set_reference.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint64),
                                       ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p]
 lib.calitas_set_reference_fasta.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+lib.calitas_save_index.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+lib.calitas_load_index.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
 lib.calitas_reference_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64),
                                        ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_contig_name.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint64)]

@@ -200,6 +200,13 @@ class Context:
         _lib.check(self._h, lib.calitas_set_reference_fasta(self._h, str(path).encode()))
         self._load_contig_table()
 
+    def save_index(self, path):
+        _lib.check(self._h, lib.calitas_save_index(self._h, str(path).encode()))
+
+    def load_index(self, path):
+        _lib.check(self._h, lib.calitas_load_index(self._h, str(path).encode()))
+        self._load_contig_table()
+
     def reference_info(self):
         n, tb, pb = ctypes.c_int32(), ctypes.c_uint64(), ctypes.c_uint64()
         _lib.check(self._h, lib.calitas_reference_info(self._h, ctypes.byref(n), ctypes.byref(tb), ctypes.byref(pb)))

@@ -144,19 +144,7 @@ void calitas_destroy(calitas_ctx* c) {
   delete c;
 }
 
-int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const* names, const uint64_t* lengths,
-                          const uint8_t* const* bases, const char* genome_build) {
-  if (!ctx) return CALITAS_EINVAL;
-  if (n_contigs <= 0 || !names || !lengths || !bases) return fail(ctx, CALITAS_EINVAL, "bad contig arguments");
-  for (int i = 0; i < n_contigs; i++)
-    if (lengths[i] > 0x7FFFFFFFull) return fail(ctx, CALITAS_EINVAL, "contigs longer than 2^31-1 bases are not supported (the reference uses Int coordinates)");
-  try {
-    pack_reference(ctx->ref, n_contigs, names, lengths, bases, genome_build, 0);
-  } catch (std::exception& e) {
-    ctx->has_ref = false;
-    return fail(ctx, CALITAS_EINVAL, e.what());
-  }
-  ctx->has_ref = true;
+static int upload_reference(calitas_ctx* ctx) {
   if (ctx->device >= 0) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     free_reference_device(ctx);
@@ -179,6 +167,22 @@ int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const
   return CALITAS_OK;
 }
 
+int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const* names, const uint64_t* lengths,
+                          const uint8_t* const* bases, const char* genome_build) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (n_contigs <= 0 || !names || !lengths || !bases) return fail(ctx, CALITAS_EINVAL, "bad contig arguments");
+  for (int i = 0; i < n_contigs; i++)
+    if (lengths[i] > 0x7FFFFFFFull) return fail(ctx, CALITAS_EINVAL, "contigs longer than 2^31-1 bases are not supported (the reference uses Int coordinates)");
+  try {
+    pack_reference(ctx->ref, n_contigs, names, lengths, bases, genome_build, 0);
+  } catch (std::exception& e) {
+    ctx->has_ref = false;
+    return fail(ctx, CALITAS_EINVAL, e.what());
+  }
+  ctx->has_ref = true;
+  return upload_reference(ctx);
+}
+
 int calitas_set_reference_fasta(calitas_ctx* ctx, const char* fasta_path) {
   if (!ctx || !fasta_path) return CALITAS_EINVAL;
   FastaData fd;
@@ -193,6 +197,72 @@ int calitas_set_reference_fasta(calitas_ctx* ctx, const char* fasta_path) {
     bases.push_back(reinterpret_cast<const uint8_t*>(fd.seqs[i].data()));
   }
   return calitas_set_reference(ctx, (int32_t)names.size(), names.data(), lens.data(), bases.data(), fd.genome_build.c_str());
+}
+
+
+// ---- persistent packed index: skips re-packing 3 GB of ASCII on repeated runs ----
+}  // extern "C"
+namespace {
+struct IndexHeader {
+  char magic[8];            // "CALIDX01"
+  uint32_t chunk, n_contigs;
+  uint64_t tile, total_packed, total_bases, n_runs, n_tiles, n_masked, build_len, names_len;
+};
+template <typename T> bool wr(FILE* f, const T* p, size_t n) { return n == 0 || std::fwrite(p, sizeof(T), n, f) == n; }
+template <typename T> bool rd(FILE* f, T* p, size_t n) { return n == 0 || std::fread(p, sizeof(T), n, f) == n; }
+}  // namespace
+extern "C" {
+
+int calitas_save_index(const calitas_ctx* ctx, const char* path) {
+  if (!ctx || !path) return CALITAS_EINVAL;
+  calitas_ctx* c = const_cast<calitas_ctx*>(ctx);
+  if (!ctx->has_ref) return fail(c, CALITAS_ESTATE, "calitas_set_reference has not been called");
+  const PackedRef& r = ctx->ref;
+  std::string names;
+  for (auto& n : r.names) { names += n; names += '\n'; }
+  IndexHeader h{};
+  std::memcpy(h.magic, "CALIDX01", 8);
+  h.chunk = (uint32_t)r.chunk; h.n_contigs = (uint32_t)r.contigs.size(); h.tile = r.tile; h.total_packed = r.total_packed;
+  h.total_bases = r.total_bases; h.n_runs = r.runs.size(); h.n_tiles = r.tiles.size(); h.n_masked = r.masked_tiles.size();
+  h.build_len = r.genome_build.size(); h.names_len = names.size();
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return fail(c, CALITAS_EIO, std::string("cannot write ") + path);
+  bool ok = wr(f, &h, 1) && wr(f, r.genome_build.data(), r.genome_build.size()) && wr(f, names.data(), names.size()) &&
+            wr(f, r.contigs.data(), r.contigs.size()) && wr(f, r.codes.data(), r.codes.size()) && wr(f, r.mask.data(), r.mask.size()) &&
+            wr(f, r.runs.data(), r.runs.size()) && wr(f, r.tiles.data(), r.tiles.size()) && wr(f, r.masked_tiles.data(), r.masked_tiles.size());
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? CALITAS_OK : fail(c, CALITAS_EIO, std::string("short write to ") + path);
+}
+
+int calitas_load_index(calitas_ctx* ctx, const char* path) {
+  if (!ctx || !path) return CALITAS_EINVAL;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(ctx, CALITAS_EIO, std::string("cannot read ") + path);
+  IndexHeader h{};
+  PackedRef r;
+  std::string names;
+  bool ok = rd(f, &h, 1) && std::memcmp(h.magic, "CALIDX01", 8) == 0 && h.tile == (uint64_t)h.chunk * LANES_PER_TILE &&
+            h.total_packed % std::max<uint64_t>(1, h.tile) == 0 && h.n_tiles == h.total_packed / std::max<uint64_t>(1, h.tile) &&
+            h.build_len < (1u << 16) && h.names_len < (1ull << 32);
+  if (ok) {
+    r.chunk = (int)h.chunk; r.tile = h.tile; r.total_packed = h.total_packed; r.total_bases = h.total_bases;
+    r.genome_build.resize(h.build_len); names.resize(h.names_len);
+    r.contigs.resize(h.n_contigs); r.codes.resize(h.total_packed / 16); r.mask.resize(h.total_packed / 32);
+    r.runs.resize(h.n_runs); r.tiles.resize(h.n_tiles); r.masked_tiles.resize(h.n_masked);
+    ok = rd(f, &r.genome_build[0], h.build_len) && rd(f, &names[0], h.names_len) && rd(f, r.contigs.data(), r.contigs.size()) &&
+         rd(f, r.codes.data(), r.codes.size()) && rd(f, r.mask.data(), r.mask.size()) && rd(f, r.runs.data(), r.runs.size()) &&
+         rd(f, r.tiles.data(), r.tiles.size()) && rd(f, r.masked_tiles.data(), r.masked_tiles.size());
+  }
+  std::fclose(f);
+  if (ok) {
+    size_t a = 0;
+    while (a < names.size()) { size_t b = names.find('\n', a); if (b == std::string::npos) break; r.names.push_back(names.substr(a, b - a)); a = b + 1; }
+    ok = r.names.size() == r.contigs.size();
+  }
+  if (!ok) return fail(ctx, CALITAS_EIO, std::string("not a calitas index (or truncated): ") + path);
+  ctx->ref = std::move(r);
+  ctx->has_ref = true;
+  return upload_reference(ctx);
 }
 
 int calitas_reference_info(const calitas_ctx* ctx, int32_t* n_contigs, uint64_t* total_bases, uint64_t* packed_bytes) {

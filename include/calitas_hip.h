@@ -119,6 +119,10 @@ int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const
                           const uint8_t* const* bases, const char* genome_build);
 /* Convenience: read FASTA (+ .dict next to it when present) and call calitas_set_reference. */
 int calitas_set_reference_fasta(calitas_ctx* ctx, const char* fasta_path);
+/* Persistent packed index: the 2-bit codes, exception mask, run table and tile table of the resident reference, so a later
+ * run can skip FASTA parsing and packing (replaces the per-run ReferenceSequenceFile scan of SearchReference.scala:34-49). */
+int calitas_save_index(const calitas_ctx* ctx, const char* path);
+int calitas_load_index(calitas_ctx* ctx, const char* path);
 int calitas_reference_info(const calitas_ctx* ctx, int32_t* n_contigs, uint64_t* total_bases, uint64_t* packed_bytes);
 int calitas_contig_name(const calitas_ctx* ctx, int32_t contig_index, const char** name, uint64_t* length);
 /* Upper-cased bases [start, start+len) of a contig re-derived from the packed form (what fetchBases sees after

@@ -200,3 +200,24 @@ def test_cli_binary_exists_and_reports_usage():
         pytest.skip("CLI not built")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "SearchReference" in r.stderr
+
+
+def test_persistent_index_roundtrip(C, tmp_path):
+    """calitas_save_index / calitas_load_index reproduce the packed reference bit for bit (window table, bases)."""
+    from calitas_amd import synth
+    names, seqs = synth.make_genome([("chrA", 70000), ("chrB", 5000), ("tiny", 9)], seed=3, n_run_ends=500, n_block=3000)
+    seqs[1][100:110] = np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8)
+    a = C.Context(-1)
+    a.set_reference(names, seqs, genome_build="hgTest")
+    idx = str(tmp_path / "ref.calidx")
+    a.save_index(idx)
+    b = C.Context(-1)
+    b.load_index(idx)
+    assert (b.contig_names, b.contig_lengths, b.reference_info()) == (a.contig_names, a.contig_lengths, a.reference_info())
+    for ci, s in enumerate(seqs):
+        assert b.fetch_bases(ci, 0, len(s)) == s.tobytes().decode().upper()
+    assert b.window_table(1000, 971, 23) == a.window_table(1000, 971, 23)
+    with open(idx, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(C.CalitasError):
+        C.Context(-1).load_index(idx)
