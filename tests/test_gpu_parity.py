@@ -219,3 +219,23 @@ def test_full_size_properties_ecoli_like(C):
              for h in hits2 if int(h["total_mm_plus_gaps"]) <= 1}
     assert best1 == best2
     ctx.close()
+
+
+def test_parity_at_scale_60mb(C):
+    """60 Mb of the bench genome's recipe (two contigs, chunk-512 tiles, N blocks, soft-masking, tandem repeats, planted
+    sites straddling window starts) -- every row against the oracle (BASELINE config 3 limits)."""
+    from calitas_amd import synth
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    names, seqs = synth.make_genome([("chrA", 38_000_000), ("chrB", 22_000_000)], seed=0xC3, guides=[("CTTGCCCCACAGGGCAGTAA", "nrg", False)],
+                                    sites_per_guide=400, n_run_ends=10_000, n_block=1_500_000, softmask=0.5, tandem_frac=0.01)
+    ctx = C.Context(0)
+    ctx.set_reference(names, seqs)
+    G = C.Guide(guide)
+    params = C.make_params(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+    alns = ctx.search([G], params)
+    text, n = ctx.hits_tsv(G, "a", params, alns)
+    prod = C.read_hits(text)
+    _, orac, nwin = O.search_memory(names, [s.tobytes() for s in seqs], guide, "a", d=5, p=1, g=2, threads=16)
+    assert nwin > 55000 and len(orac) > 1500
+    assert_same(prod, orac, "60mb")
+    ctx.close()
