@@ -2,3 +2,4 @@
 from .aligner import (Alignment, CalitasError, Context, Defaults, Guide, SearchReference, make_params, read_hits,  # noqa: F401
                       window_filter)
 from .tools import GuideAlignment, SequentialGuideAligner, pairwise_align_sequences  # noqa: F401,E402
+from .variants import prepare_vcf, read_vcf  # noqa: F401,E402

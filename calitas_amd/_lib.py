@@ -39,6 +39,11 @@ class AlnT(ctypes.Structure):
                 ("pam_index", ctypes.c_int8), ("n_ops", ctypes.c_int16), ("ops", ctypes.c_uint8 * MAX_OPS)]
 
 
+class ExtHitT(ctypes.Structure):
+    _fields_ = [("contig_index", ctypes.c_int32), ("coordinate_start", ctypes.c_int32), ("end", ctypes.c_int32), ("score", ctypes.c_int32),
+                ("strand", ctypes.c_int8), ("variant_description", ctypes.c_char_p), ("row", ctypes.c_char_p)]
+
+
 class TimingT(ctypes.Structure):
     _fields_ = [("scan_kernel_ms", ctypes.c_double), ("align_kernel_ms", ctypes.c_double), ("gpu_total_ms", ctypes.c_double),
                 ("host_post_ms", ctypes.c_double), ("bases_scanned", ctypes.c_uint64), ("packed_bytes", ctypes.c_uint64),
@@ -48,8 +53,8 @@ class TimingT(ctypes.Structure):
 
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
-           "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_fetch_bases",
-           "calitas_window_table", "calitas_search", "calitas_get_timing", "calitas_window_filter", "calitas_hits_tsv",
+           "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases",
+           "calitas_window_table", "calitas_search", "calitas_get_timing", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -84,6 +89,11 @@ lib.calitas_window_filter.argtypes = [ctypes.POINTER(AlnT), ctypes.c_int32, ctyp
 lib.calitas_hits_tsv.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.c_char_p, ctypes.POINTER(ParamsT),
                                  ctypes.POINTER(AlnT), ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p,
                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+lib.calitas_genome_build.restype = ctypes.c_char_p
+lib.calitas_genome_build.argtypes = [ctypes.c_void_p]
+lib.calitas_hits_tsv_ext.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.c_char_p, ctypes.POINTER(ParamsT), ctypes.POINTER(AlnT),
+                                     ctypes.c_uint64, ctypes.POINTER(ExtHitT), ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p,
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_padded_strings.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.POINTER(AlnT), ctypes.c_char_p,
                                        ctypes.c_char_p, ctypes.c_char_p]
 

@@ -207,6 +207,9 @@ class Context:
         _lib.check(self._h, lib.calitas_load_index(self._h, str(path).encode()))
         self._load_contig_table()
 
+    def genome_build(self):
+        return lib.calitas_genome_build(self._h).decode()
+
     def reference_info(self):
         n, tb, pb = ctypes.c_int32(), ctypes.c_uint64(), ctypes.c_uint64()
         _lib.check(self._h, lib.calitas_reference_info(self._h, ctypes.byref(n), ctypes.byref(tb), ctypes.byref(pb)))
@@ -296,8 +299,7 @@ class SearchReference:
                  pam_mismatch_net_cost=Defaults.PamMismatchNetCost, genome_gap_net_cost=Defaults.GenomeGapNetCost,
                  guide_gap_net_cost=Defaults.GuideGapNetCost, chrom=None, variants=None,
                  max_variants=Defaults.MaxVariantsInCluster, context=None, device=0, eqx_by_score=0):
-        if variants is not None:
-            raise NotImplementedError("--variants (SearchReference.scala:570-630) is outside the MI355X hot path (SURVEY 8f)")
+        self.variants = variants
         self.guide_str, self.guide_id, self.ref, self.output = guide, guide_id, ref, output
         self.query = Guide(guide, auxiliary_pams)  # SearchReference.scala:511: fail early on an invalid guide
         self.chrom = chrom
@@ -324,6 +326,9 @@ class SearchReference:
                 if self.chrom not in ctx.contig_names:
                     raise ValueError("Unknown chromosome: %s" % self.chrom)
                 chrom_index = ctx.contig_names.index(self.chrom)
+            if self.variants is not None:   # SearchReference.scala:570-630
+                from .variants import search_reference_with_variants
+                return search_reference_with_variants(self, ctx, self.variants, version, time_stamp)
             params = make_params(chrom_index=chrom_index, **self._kw)
             t0 = time.perf_counter()
             out, n = ctx.search_raw([self.query], params)

@@ -273,6 +273,8 @@ int calitas_reference_info(const calitas_ctx* ctx, int32_t* n_contigs, uint64_t*
   return CALITAS_OK;
 }
 
+const char* calitas_genome_build(const calitas_ctx* ctx) { return (ctx && ctx->has_ref) ? ctx->ref.genome_build.c_str() : ""; }
+
 int calitas_contig_name(const calitas_ctx* ctx, int32_t i, const char** name, uint64_t* length) {
   if (!ctx || !ctx->has_ref || i < 0 || i >= (int32_t)ctx->ref.contigs.size()) return CALITAS_EINVAL;
   if (name) *name = ctx->ref.names[i].c_str();
@@ -627,6 +629,13 @@ int calitas_window_filter(const calitas_aln_t* alns, int32_t n, int32_t max_tota
 int calitas_hits_tsv(const calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                      const calitas_aln_t* alns, uint64_t n_alns, const char* aligner_version, const char* time_stamp, char** tsv,
                      uint64_t* n_rows) {
+  return calitas_hits_tsv_ext(ctx, guide, guide_id, params, alns, n_alns, nullptr, 0, aligner_version, time_stamp, tsv, n_rows);
+}
+
+int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                         const calitas_aln_t* alns, uint64_t n_alns, const calitas_ext_hit_t* ext, uint64_t n_ext,
+                         const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* n_rows) {
+  if (n_ext && !ext) return CALITAS_EINVAL;
   if (!ctx || !guide || !params || !tsv || (n_alns && !alns)) return CALITAS_EINVAL;
   calitas_ctx* c = const_cast<calitas_ctx*>(ctx);
   if (!ctx->has_ref) return fail(c, CALITAS_ESTATE, "calitas_set_reference has not been called");
@@ -643,7 +652,7 @@ int calitas_hits_tsv(const calitas_ctx* ctx, const calitas_guide_t* guide, const
     char b[64]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
     std::strftime(b, sizeof b, "%a %b %d %H:%M:%S UTC %Y", &tmv); stamp = b;
   }
-  *tsv = hits_tsv(ctx->ref, gh, guide_id ? guide_id : "", *params, alns, n_alns, version, stamp, n_rows, ctx->pool, out_alloc);
+  *tsv = hits_tsv(ctx->ref, gh, guide_id ? guide_id : "", *params, alns, n_alns, version, stamp, n_rows, ctx->pool, out_alloc, ext, n_ext);
   if (!*tsv) return fail(c, CALITAS_EINVAL, "out of memory");
   return CALITAS_OK;
 }

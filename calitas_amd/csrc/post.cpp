@@ -309,7 +309,7 @@ static void append_row(std::string& out, const PackedRef& ref, const RowConst& r
 
 char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
-               uint64_t* n_rows, WorkerPool* pool, void* (*alloc)(size_t)) {
+               uint64_t* n_rows, WorkerPool* pool, void* (*alloc)(size_t), const calitas_ext_hit_t* ext, uint64_t n_ext) {
   WorkerPool serial(1);
   if (!pool) pool = &serial;
   const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
@@ -338,6 +338,20 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
     groups[(size_t)a.contig_index * 2 + (a.strand == '-' ? 1 : 0)].push_back(
         Lite{a.contig_index, a.guide_start_offset, a.guide_start_offset + tlen - 1, (char)a.strand, a.score, i});  // RH:135-138
   }
+  // Hits built by the caller (variant windows, SR:570-630): idx >= n refers to ext[idx - n].  They arrive after the reference
+  // hits (SR:622) and group by (chromosome, strand, variant_description) like every other hit (SR:656).
+  std::map<std::string, size_t> desc_group;
+  for (uint64_t e = 0; e < n_ext; e++) {
+    const calitas_ext_hit_t& x = ext[e];
+    if (x.contig_index < 0 || x.contig_index >= n_contigs) continue;
+    const Lite l{x.contig_index, x.coordinate_start, x.end, (char)x.strand, x.score, n + e};
+    const std::string desc = x.variant_description ? x.variant_description : "";
+    if (desc.empty()) { groups[(size_t)x.contig_index * 2 + (x.strand == '-' ? 1 : 0)].push_back(l); continue; }
+    const std::string key = std::to_string(x.contig_index) + ":" + (char)x.strand + ":" + desc;
+    auto it = desc_group.find(key);
+    if (it == desc_group.end()) { it = desc_group.emplace(key, groups.size()).first; groups.emplace_back(); }
+    groups[it->second].push_back(l);
+  }
   std::vector<std::vector<Lite>> kept_by_contig(n_contigs);
   {
     std::atomic<size_t> next(0);
@@ -358,16 +372,19 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
         }
       }
     });
-    // final ReferenceHit.sort (SR:647): per contig, the two strand groups are merged; equal keys cannot cross groups
+    // final ReferenceHit.sort (SR:647): per contig, the groups' keeper lists are concatenated ('+', '-', then the variant
+    // groups in order of first appearance) and stably sorted.  Equal keys can only meet across groups when one of them is
+    // a variant group; the reference leaves that order to a hash map (SR:656), here it is the concatenation order.
+    std::vector<std::vector<size_t>> groups_of_contig(n_contigs);
+    for (size_t gi = 0; gi < groups.size(); gi++) if (!kept_group[gi].empty()) groups_of_contig[kept_group[gi][0].contig].push_back(gi);
     std::atomic<size_t> nextc(0);
     pool->run([&](int) {
       for (;;) {
         size_t c = nextc.fetch_add(1);
         if (c >= (size_t)n_contigs) break;
         auto& out = kept_by_contig[c];
-        out.resize(kept_group[2 * c].size() + kept_group[2 * c + 1].size());
-        std::merge(kept_group[2 * c].begin(), kept_group[2 * c].end(), kept_group[2 * c + 1].begin(), kept_group[2 * c + 1].end(),
-                   out.begin(), by_hit_order);
+        for (size_t gi : groups_of_contig[c]) out.insert(out.end(), kept_group[gi].begin(), kept_group[gi].end());
+        std::stable_sort(out.begin(), out.end(), by_hit_order);
       }
     });
   }
@@ -403,7 +420,10 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
         std::string& s = parts[b];
         s.reserve(BLOCK * 600);
         size_t e = std::min(keepers.size(), (b + 1) * BLOCK);
-        for (size_t i = b * BLOCK; i < e; i++) append_row(s, ref, rc, alns[keepers[i].idx]);
+        for (size_t i = b * BLOCK; i < e; i++) {
+          if (keepers[i].idx < n) append_row(s, ref, rc, alns[keepers[i].idx]);
+          else { s += ext[keepers[i].idx - n].row; s += '\n'; }
+        }
       }
     });
   }

@@ -39,6 +39,7 @@ void padded_strings(const PackedRef& ref, const GuideHost& g, const calitas_aln_
 // hits.txt text for one guide's alignments: malloc'd, NUL-terminated (nullptr when out of memory).
 char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
-               uint64_t* n_rows, WorkerPool* pool = nullptr, void* (*alloc)(size_t) = nullptr);
+               uint64_t* n_rows, WorkerPool* pool = nullptr, void* (*alloc)(size_t) = nullptr, const calitas_ext_hit_t* ext = nullptr,
+               uint64_t n_ext = 0);
 
 }  // namespace calitas

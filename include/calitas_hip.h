@@ -125,6 +125,8 @@ int calitas_save_index(const calitas_ctx* ctx, const char* path);
 int calitas_load_index(calitas_ctx* ctx, const char* path);
 int calitas_reference_info(const calitas_ctx* ctx, int32_t* n_contigs, uint64_t* total_bases, uint64_t* packed_bytes);
 int calitas_contig_name(const calitas_ctx* ctx, int32_t contig_index, const char** name, uint64_t* length);
+/* genome_build column: first AS tag of the sequence dictionary, or "unknown" (ReferenceHit.scala:208). */
+const char* calitas_genome_build(const calitas_ctx* ctx);
 /* Upper-cased bases [start, start+len) of a contig re-derived from the packed form (what fetchBases sees after
  * toUpperCase, ReferenceHit.scala:261-266); out must hold len bytes. */
 int calitas_fetch_bases(const calitas_ctx* ctx, int32_t contig_index, uint64_t start, uint32_t len, char* out);
@@ -172,6 +174,23 @@ int calitas_window_filter(const calitas_aln_t* alns, int32_t n, int32_t max_tota
 int calitas_hits_tsv(const calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                      const calitas_aln_t* alns, uint64_t n_alns, const char* aligner_version, const char* time_stamp,
                      char** tsv, uint64_t* n_rows);
+
+/* A hit row built by the caller -- the variant branch of SearchReference.execute (SearchReference.scala:570-630) builds its
+ * ReferenceHits from variant windows on the host.  calitas_hits_tsv_ext lets such hits take part in removeOverlaps (grouped by
+ * chromosome, strand and variant_description, SearchReference.scala:656) and in the final sort next to the reference hits;
+ * `row` (34 tab-separated columns, no newline) is emitted verbatim. */
+typedef struct {
+  int32_t contig_index;
+  int32_t coordinate_start;     /* ReferenceHit.coordinate_start */
+  int32_t end;                  /* ReferenceHit.end = coordinate_start + cigar.lengthOnTarget - 1 (ReferenceHit.scala:135-138) */
+  int32_t score;
+  int8_t strand;
+  const char* variant_description;   /* NULL or "" = none */
+  const char* row;
+} calitas_ext_hit_t;
+int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                         const calitas_aln_t* alns, uint64_t n_alns, const calitas_ext_hit_t* ext, uint64_t n_ext,
+                         const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* n_rows);
 
 /* Padded strings of one alignment (Alignment.paddedString as used at SequentialGuideAligner.scala:511, plus the
  * reverse-complement handling of 5' PAM guides): each buffer must hold CALITAS_MAX_OPS+1 bytes. */

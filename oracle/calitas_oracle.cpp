@@ -30,6 +30,7 @@
 #include <atomic>
 #include <cctype>
 #include <climits>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -326,6 +327,9 @@ struct GuideAlignment {
   int score = 0;
   Cigar cigar;
   std::string paddedGuide, paddedAlignment, paddedTarget;
+  // flank overrides set by the variant branch (GA:84-87); has* = Option is defined
+  std::string leftOfGuide10bp, rightOfGuide10bp, leftOfFullAln8bp, rightOfFullAln8bp;
+  bool hasL10 = false, hasR10 = false, hasL8 = false, hasR8 = false;
 
   int count_char(char c) const { return (int)std::count(paddedAlignment.begin(), paddedAlignment.end(), c); }
   int mismatches() const { return count_char('.'); }                       // GA:99
@@ -642,6 +646,7 @@ struct Hit {
   std::string guide_id, unpadded_guide_sequence, genome_build, chromosome;
   int coordinate_start, coordinate_end;
   std::string strand, unpadded_target_sequence, ten_bases_5_prime, ten_bases_3_prime, pam_used;
+  std::string variant_id, variant_description, variant_vcf, allele_frequency;   // empty = None
   int score, guide_mm, guide_gaps, guide_mm_plus_gaps, pam_mm, total_mm_plus_gaps;
   std::string padded_guide, padded_alignment, padded_target, padded_extra_8_bases_5_prime, padded_extra_8_bases_3_prime, cigar;
   int unpadded_guide_sequence_length, unpadded_target_sequence_length;
@@ -677,11 +682,235 @@ static std::string fetch_bases(const std::string& contig, int start, int end, bo
   return b;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant path: SearchReferencesWithVariants (SR:101-400).  The VCF side (fgbio vcf.api) is restated minimally:
+// CHROM POS ID REF ALT ... INFO with AF (one value per ALT) and optional END; Variant.end = END or pos + len(ref) - 1.
+// ---------------------------------------------------------------------------------------------------------------
+struct VcfVariant {
+  std::string chrom, id, ref;          // id empty = missing (".")
+  int pos = 0, end = 0;                // 1-based closed
+  std::vector<std::string> alts;
+  std::vector<float> afs;              // per ALT; missing -> 0 (SR:199)
+};
+
+struct VariantAllele {                 // SR:105-110
+  std::string id, ref, alt;
+  int pos = 0;                         // 1-based
+  float af = 0;
+  std::string displayString() const {  // SR:106-109
+    char b[64];
+    std::snprintf(b, sizeof b, "%.3f", (double)af);
+    return (id.empty() ? std::string(".") : id) + ":" + std::to_string(pos - 1) + ":" + ref + ">" + alt + ":" + b;
+  }
+};
+
+struct VariantSet {                    // SR:166-202
+  std::vector<const VcfVariant*> variants;
+  std::vector<int> alleles;            // index into (ref, alts...), never 0
+  int start() const { return variants.front()->pos; }
+  int end() const { return variants.back()->end; }
+  bool isValid() const {               // SR:182-193
+    if (variants.size() == 1) return true;
+    for (size_t i = 0; i + 1 < variants.size(); i++) {
+      int s1 = variants[i]->pos, e1 = s1 + (int)variants[i]->ref.size() - 1;
+      int s2 = variants[i + 1]->pos, e2 = s2 + (int)variants[i + 1]->ref.size() - 1;
+      if (variants[i]->chrom == variants[i + 1]->chrom && s1 <= e2 && e1 >= s2) return false;   // htsjdk Interval.overlaps
+    }
+    return true;
+  }
+  VariantAllele variantAllele(size_t i) const {   // SR:196-201
+    const VcfVariant& v = *variants[i];
+    int a = alleles[i];
+    VariantAllele va;
+    va.id = v.id; va.pos = v.pos; va.ref = v.ref; va.alt = v.alts[a - 1];
+    va.af = (size_t)(a - 1) < v.afs.size() ? v.afs[a - 1] : 0.0f;
+    return va;
+  }
+};
+
+struct VariantWindow {                 // SR:118-157
+  std::string chrom;
+  int start = 0;                       // 1-based
+  std::vector<VariantAllele> variants;
+  Cigar cigar;                         // ops M / I / D
+  std::string bases;
+  static int lenOnQuery(const CigarElem& e) { return (e.op == 'M' || e.op == 'I') ? e.len : 0; }
+  static int lenOnTarget(const CigarElem& e) { return (e.op == 'M' || e.op == 'D') ? e.len : 0; }
+  int refOffsetAtBaseOffset(int offset, bool preceding) const {   // SR:133-156
+    if (offset == (int)bases.size()) { int t = 0; for (auto& e : cigar) t += lenOnTarget(e); return start - 1 + t; }
+    int refOffset = start - 1, baseOffset = 0;
+    size_t k = 0;
+    while (offset >= baseOffset + lenOnQuery(cigar[k])) { refOffset += lenOnTarget(cigar[k]); baseOffset += lenOnQuery(cigar[k]); k++; }
+    if (cigar[k].op == 'I') return preceding ? refOffset - 1 : refOffset;
+    if (cigar[k].op == 'M') return refOffset + (offset - baseOffset);
+    throw std::runtime_error("Query bases can't be present at operator D.");
+  }
+};
+
+// alleleCombos(alleleCounts) SR:377-399: first variant varies slowest
+static std::vector<std::vector<int>> allele_combos(const std::vector<int>& counts) {
+  size_t total = 1;
+  for (int c : counts) total *= (size_t)c;
+  std::vector<std::vector<int>> results(total, std::vector<int>(counts.size(), 0));
+  size_t denom = 1;
+  for (size_t i = 0; i < counts.size(); i++) {
+    int n = counts[i];
+    denom *= (size_t)n;
+    size_t groupSize = total / denom, j = 0;
+    int allele = 0;
+    while (j < total) {
+      size_t end = j + groupSize;
+      while (j < end) { results[j][i] = allele; j++; }
+      allele = (allele + 1) % n;
+    }
+  }
+  return results;
+}
+
+// alleleCombos(vs, maxVariants) SR:351-369
+static std::vector<VariantSet> allele_combos(const std::vector<const VcfVariant*>& vs, int maxVariants) {
+  std::vector<VariantSet> out;
+  if ((int)vs.size() > maxVariants) {
+    const VcfVariant* v = vs.front();
+    for (size_t a = 0; a < v->alts.size(); a++) { VariantSet s; s.variants = {v}; s.alleles = {(int)a + 1}; out.push_back(s); }
+    return out;
+  }
+  std::vector<int> counts;
+  for (auto* v : vs) counts.push_back(1 + (int)v->alts.size());
+  for (auto& alleles : allele_combos(counts)) {
+    VariantSet s;
+    for (size_t i = 0; i < vs.size(); i++) if (alleles[i] != 0) { s.variants.push_back(vs[i]); s.alleles.push_back(alleles[i]); }
+    if (s.variants.empty() || !s.isValid()) continue;
+    out.push_back(std::move(s));
+  }
+  return out;
+}
+
+// buildVariantWindow SR:263-323 (refBases already upper-cased, SR:225)
+static VariantWindow build_variant_window(const VariantSet& set, const std::string& chrom, const std::string& refBases, int padding) {
+  const int windowStart = std::max(1, set.start() - padding);
+  const int windowEnd = std::min((int)refBases.size(), set.end() + padding);
+  std::string bases = refBases.substr(windowStart - 1, windowEnd - (windowStart - 1));
+  std::vector<VariantAllele> alleles;
+  for (size_t i = 0; i < set.variants.size(); i++) alleles.push_back(set.variantAllele(i));
+  for (auto it = alleles.rbegin(); it != alleles.rend(); ++it) {
+    int startIndex = it->pos - windowStart;
+    if (it->ref.size() == it->alt.size()) for (size_t i = 0; i < it->ref.size(); i++) bases[startIndex + i] = it->alt[i];
+    else bases = bases.substr(0, startIndex) + it->alt + bases.substr(startIndex + it->ref.size());   // patch
+  }
+  Cigar elems;
+  int refPos = windowStart, baseOffset = 0;
+  for (auto& al : alleles) {
+    int precedingMatch = al.pos - refPos;
+    if (precedingMatch > 0) { elems.push_back({'M', precedingMatch}); refPos += precedingMatch; baseOffset += precedingMatch; }
+    const int rl = (int)al.ref.size(), alen = (int)al.alt.size();
+    if (rl == alen) elems.push_back({'M', rl});
+    else if (rl == 1 && alen > 1) { elems.push_back({'M', 1}); elems.push_back({'I', alen - 1}); }
+    else if (rl > 1 && alen == 1) { elems.push_back({'M', 1}); elems.push_back({'D', rl - 1}); }
+    else { elems.push_back({'D', rl}); elems.push_back({'I', alen}); }
+    refPos += rl; baseOffset += alen;
+  }
+  elems.push_back({'M', (int)bases.size() - baseOffset});
+  VariantWindow w;
+  w.chrom = chrom; w.start = windowStart; w.variants = alleles; w.cigar = coalesce(elems); w.bases = bases;
+  int q = 0;
+  for (auto& e : w.cigar) q += VariantWindow::lenOnQuery(e);
+  if (q != (int)bases.size()) throw std::runtime_error("requirement failed: cigar length on query != bases (SR:321)");
+  return w;
+}
+
+// Minimal VCF reader (plain text; the tests write uncompressed VCF).
+static std::vector<VcfVariant> read_vcf(const std::string& path) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("cannot read " + path);
+  std::vector<VcfVariant> out;
+  std::string line;
+  while (std::getline(in, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    std::vector<std::string> f;
+    std::stringstream ss(line);
+    std::string x;
+    while (std::getline(ss, x, '\t')) f.push_back(x);
+    if (f.size() < 5) continue;
+    VcfVariant v;
+    v.chrom = f[0]; v.pos = std::atoi(f[1].c_str()); v.id = (f[2] == ".") ? "" : f[2]; v.ref = f[3];
+    std::stringstream as(f[4]);
+    while (std::getline(as, x, ',')) v.alts.push_back(x);
+    v.end = v.pos + (int)v.ref.size() - 1;
+    if (f.size() > 7) {
+      std::stringstream is(f[7]);
+      while (std::getline(is, x, ';')) {
+        if (x.compare(0, 3, "AF=") == 0) { std::stringstream fs(x.substr(3)); std::string y; while (std::getline(fs, y, ',')) v.afs.push_back(std::strtof(y.c_str(), nullptr)); }
+        if (x.compare(0, 4, "END=") == 0) v.end = std::atoi(x.c_str() + 4);
+      }
+    }
+    out.push_back(std::move(v));
+  }
+  return out;
+}
+
+// variantWindowIterator SR:217-256 (+ nextChunk SR:326-337, reChunk SR:343-347), materialised.
+static std::vector<VariantWindow> variant_windows(const Reference& ref, const std::vector<VcfVariant>& vcf, const std::string& chrom,
+                                                  int padding, int maxVariants) {
+  std::vector<VariantWindow> out;
+  std::vector<const VcfVariant*> vs;
+  for (auto& v : vcf) if (chrom.empty() || v.chrom == chrom) vs.push_back(&v);
+  std::vector<int> chromOrder;   // the contigs the iterator walks through (all, or the one requested)
+  for (size_t c = 0; c < ref.names.size(); c++) if (chrom.empty() || ref.names[c] == chrom) chromOrder.push_back((int)c);
+  size_t ci = 0;
+  std::string upper;
+  int upperFor = -1;
+  size_t i = 0;
+  while (i < vs.size()) {
+    // nextChunk
+    std::vector<const VcfVariant*> chunk{vs[i]};
+    const VcfVariant* last = vs[i++];
+    while (i < vs.size() && vs[i]->chrom == last->chrom && vs[i]->pos <= last->end + padding) { last = vs[i++]; chunk.push_back(last); }
+    // reChunk: every suffix, cut where a variant starts more than `padding` past the end of the suffix head
+    std::vector<std::vector<const VcfVariant*>> chunks;
+    for (size_t s = 0; s < chunk.size(); s++) {
+      std::vector<const VcfVariant*> sub;
+      for (size_t k = s; k < chunk.size() && chunk[k]->pos - chunk[s]->end <= padding; k++) sub.push_back(chunk[k]);
+      chunks.push_back(sub);
+    }
+    while (ci < chromOrder.size() && ref.names[chromOrder[ci]] != chunk.front()->chrom) ci++;   // SR:251
+    if (ci >= chromOrder.size()) throw std::runtime_error("next on empty iterator (VCF contig not in reference order)");
+    if (upperFor != chromOrder[ci]) { upper = ref.seqs[chromOrder[ci]]; for (auto& c : upper) c = (char)std::toupper((unsigned char)c); upperFor = chromOrder[ci]; }
+    for (auto& c : chunks)
+      for (auto& set : allele_combos(c, maxVariants)) out.push_back(build_variant_window(set, ref.names[chromOrder[ci]], upper, padding));
+  }
+  return out;
+}
+
+// fgbio Metric.formatValue for a Double: DecimalFormat("0.######") (HALF_EVEN), scientific below 1e-5 -- recalled from the
+// public fgbio source, not pinned by any reference test (only reached with a VCF that carries AF).
+static std::string format_metric_double(double d) {
+  if (d == 0) return "0";
+  char b[64];
+  if (std::fabs(d) < 0.00001) {   // "0.#####E0"
+    int ex = (int)std::floor(std::log10(std::fabs(d)));
+    double m = d / std::pow(10.0, ex);
+    std::snprintf(b, sizeof b, "%.5f", m);
+    std::string ms = b;
+    while (!ms.empty() && ms.back() == '0') ms.pop_back();
+    if (!ms.empty() && ms.back() == '.') ms.pop_back();
+    return ms + "E" + std::to_string(ex);
+  }
+  std::snprintf(b, sizeof b, "%.6f", d);
+  std::string s = b;
+  while (!s.empty() && s.back() == '0') s.pop_back();
+  if (!s.empty() && s.back() == '.') s.pop_back();
+  return s;
+}
+
 struct HitBuilder {  // RH:198-254
   std::string guideId, alignerId, timestamp, arguments, alignerSearchPam, genomeBuild, version;
   const Guide* guide;
   const Reference* ref;
-  Hit build(const GuideAlignment& aln) const {
+  std::string vcfId;   // "<file name>:<md5>" (RH:175-183)
+  Hit build(const GuideAlignment& aln, const std::vector<VariantAllele>& variants = {}) const {
+    std::vector<const VariantAllele*> vs;   // RH:211
+    for (auto& v : variants) if (v.pos - 1 >= aln.startOffset && v.pos - 1 <= aln.endOffset) vs.push_back(&v);
     const int ci = ref->index_of(aln.chrom);
     const std::string& contig = ref->seqs[ci];
     bool neg = !aln.isPositiveStrand();
@@ -690,15 +919,27 @@ struct HitBuilder {  // RH:198-254
     std::string eightLeft = fetch_bases(contig, aln.startOffset + 1 - 8, aln.startOffset, neg);
     std::string eightRight = fetch_bases(contig, aln.endOffset + 1, aln.endOffset + 8, neg);
     Hit h;
-    h.guide_id = guideId; h.unpadded_guide_sequence = guide->guide; h.genome_build = genomeBuild; h.chromosome = aln.chrom;
+    h.guide_id = guideId; h.unpadded_guide_sequence = guide->guide; h.genome_build = vs.empty() ? genomeBuild : genomeBuild + "+variants"; h.chromosome = aln.chrom;
     h.coordinate_start = aln.guideStartOffset; h.coordinate_end = aln.guideEndOffset; h.strand = std::string(1, aln.strand);
     h.unpadded_target_sequence = aln.unpaddedTargetWithoutPam();
-    h.ten_bases_5_prime = neg ? tenRight : tenLeft; h.ten_bases_3_prime = neg ? tenLeft : tenRight;
+    h.ten_bases_5_prime = aln.hasL10 ? aln.leftOfGuide10bp : (neg ? tenRight : tenLeft);     // RH:227
+    h.ten_bases_3_prime = aln.hasR10 ? aln.rightOfGuide10bp : (neg ? tenLeft : tenRight);    // RH:228
+    if (!vs.empty()) {   // RH:230-233
+      const VariantAllele* mn = vs[0];
+      for (size_t i = 0; i < vs.size(); i++) {
+        if (i) { h.variant_id += ';'; h.variant_description += ';'; }
+        h.variant_id += vs[i]->id; h.variant_description += vs[i]->displayString();
+        if (vs[i]->af < mn->af) mn = vs[i];
+      }
+      h.variant_vcf = vcfId;
+      h.allele_frequency = format_metric_double((double)mn->af);
+    }
     for (char c : aln.guide) if (std::islower((unsigned char)c)) h.pam_used += c;  // RH:229
     h.score = aln.score; h.guide_mm = aln.guideMismatches(); h.guide_gaps = aln.guideGapBases();
     h.guide_mm_plus_gaps = aln.guideMmsPlusGaps(); h.pam_mm = aln.pamMismatches(); h.total_mm_plus_gaps = aln.edits();
     h.padded_guide = aln.paddedGuide; h.padded_alignment = aln.paddedAlignment; h.padded_target = aln.paddedTarget;
-    h.padded_extra_8_bases_5_prime = neg ? eightRight : eightLeft; h.padded_extra_8_bases_3_prime = neg ? eightLeft : eightRight;
+    h.padded_extra_8_bases_5_prime = aln.hasL8 ? aln.leftOfFullAln8bp : (neg ? eightRight : eightLeft);    // RH:243
+    h.padded_extra_8_bases_3_prime = aln.hasR8 ? aln.rightOfFullAln8bp : (neg ? eightLeft : eightRight);  // RH:244
     h.cigar = cigar_string(aln.cigar);
     h.unpadded_guide_sequence_length = (int)guide->guide.size();
     h.unpadded_target_sequence_length = (int)h.unpadded_target_sequence.size();
@@ -721,7 +962,7 @@ static void sort_hits(std::vector<Hit>& hs) {
 // removeOverlaps SR:653-675
 static std::vector<Hit> remove_overlaps(const std::vector<Hit>& hits, int maxOverlap) {
   std::map<std::string, std::vector<Hit>> groups;  // key order is irrelevant: the caller sorts the keepers (SR:647)
-  for (auto& h : hits) groups["{" + h.chromosome + ":" + h.strand + ":"].push_back(h);
+  for (auto& h : hits) groups["{" + h.chromosome + ":" + h.strand + ":" + h.variant_description].push_back(h);
   std::vector<Hit> keepers;
   for (auto& kv : groups) {
     auto& hs = kv.second;
@@ -740,8 +981,8 @@ static std::string hit_row(const Hit& h) {
   std::ostringstream o;
   o << h.guide_id << '\t' << h.unpadded_guide_sequence << '\t' << h.genome_build << '\t' << h.chromosome << '\t'
     << h.coordinate_start << '\t' << h.coordinate_end << '\t' << h.strand << '\t' << h.unpadded_target_sequence << '\t'
-    << h.ten_bases_5_prime << '\t' << h.ten_bases_3_prime << '\t' << h.pam_used << '\t' << "" << '\t' << "" << '\t' << "" << '\t' << ""
-    << '\t' << h.score << '\t' << h.guide_mm << '\t' << h.guide_gaps << '\t' << h.guide_mm_plus_gaps << '\t' << h.pam_mm << '\t'
+    << h.ten_bases_5_prime << '\t' << h.ten_bases_3_prime << '\t' << h.pam_used << '\t' << h.variant_id << '\t' << h.variant_description
+    << '\t' << h.variant_vcf << '\t' << h.allele_frequency << '\t' << h.score << '\t' << h.guide_mm << '\t' << h.guide_gaps << '\t' << h.guide_mm_plus_gaps << '\t' << h.pam_mm << '\t'
     << h.total_mm_plus_gaps << '\t' << h.padded_guide << '\t' << h.padded_alignment << '\t' << h.padded_target << '\t'
     << h.padded_extra_8_bases_5_prime << '\t' << h.padded_extra_8_bases_3_prime << '\t' << h.cigar << '\t'
     << h.unpadded_guide_sequence_length << '\t' << h.unpadded_target_sequence_length << '\t' << h.aligner << '\t'
@@ -774,7 +1015,8 @@ static std::string core_parameters(const SearchParams& p, int maxTotalDiffsActua
 }
 
 static std::string search_reference(const Reference& ref, const std::string& guideStr, const std::string& guideId,
-                                    const std::vector<std::string>& auxPams, const SearchParams& p, long* nWindowsOut) {
+                                    const std::vector<std::string>& auxPams, const SearchParams& p, long* nWindowsOut,
+                                    const std::string& vcfPath = std::string()) {
   Guide query = make_guide(guideStr, auxPams);
   const int maxTotalDiffsActual = p.maxTotalDiffs >= 0 ? p.maxTotalDiffs : p.maxGuideDiffs + p.maxGaps + p.maxPamMismatches;  // SR:493
   const int guideLength = (int)guideStr.size();                                  // SR:528
@@ -820,6 +1062,42 @@ static std::string search_reference(const Reference& ref, const std::string& gui
 
   std::vector<Hit> hits;
   for (auto& v : perWindow) for (auto& h : v) hits.push_back(std::move(h));
+
+  // ---- SR:570-630: the same align() on windows with variant alleles substituted in ----
+  if (!vcfPath.empty()) {
+    size_t slash = vcfPath.find_last_of('/');
+    hb.vcfId = (slash == std::string::npos ? vcfPath : vcfPath.substr(slash + 1)) + ":MD5";   // md5 left to the caller (RH:175-183)
+    std::vector<VcfVariant> vcf = read_vcf(vcfPath);
+    const int padding = query.length() - 1 + p.maxGuideDiffs + p.maxGaps;                      // SR:575
+    std::vector<VariantWindow> vws = variant_windows(ref, vcf, p.chrom, padding, p.maxVariants);
+    Aligner al;
+    al.scorer = Scorer(p.guideMismatchNetCost, p.genomeGapNetCost, p.guideGapNetCost, p.pamMismatchNetCost);
+    al.switches = p.switches;
+    for (auto& w : vws) {
+      auto rel = al.align(query, w.bases, w.chrom, 0, p.maxGuideDiffs, p.maxGaps, p.maxPamMismatches, maxTotalDiffsActual, p.maxOverlap);
+      const int wl = (int)w.bases.size();
+      for (auto& a0 : rel) {
+        GuideAlignment a = a0;
+        // SR:598-613 flanks from the window itself where it is long enough
+        bool hl10 = a.guideStartOffset >= 10, hr10 = wl - a.guideEndOffset >= 10, hl8 = a.startOffset >= 8, hr8 = wl - a.endOffset >= 8;
+        std::string l10 = hl10 ? w.bases.substr(a.guideStartOffset - 10, 10) : "", r10 = hr10 ? w.bases.substr(a.guideEndOffset, 10) : "";
+        std::string l8 = hl8 ? w.bases.substr(a.startOffset - 8, 8) : "", r8 = hr8 ? w.bases.substr(a.endOffset, 8) : "";
+        if (a.isPositiveStrand()) {
+          a.hasL10 = hl10; a.leftOfGuide10bp = l10; a.hasR10 = hr10; a.rightOfGuide10bp = r10;
+          a.hasL8 = hl8; a.leftOfFullAln8bp = l8; a.hasR8 = hr8; a.rightOfFullAln8bp = r8;
+        } else {
+          a.hasL10 = hr10; a.leftOfGuide10bp = revcomp(r10); a.hasR10 = hl10; a.rightOfGuide10bp = revcomp(l10);
+          a.hasL8 = hr8; a.leftOfFullAln8bp = revcomp(r8); a.hasR8 = hl8; a.rightOfFullAln8bp = revcomp(l8);
+        }
+        // SR:615-620 window offsets -> reference offsets
+        a.startOffset = w.refOffsetAtBaseOffset(a0.startOffset, true);
+        a.endOffset = w.refOffsetAtBaseOffset(a0.endOffset, false);
+        a.guideStartOffset = w.refOffsetAtBaseOffset(a0.guideStartOffset, true);
+        a.guideEndOffset = w.refOffsetAtBaseOffset(a0.guideEndOffset, false);
+        hits.push_back(hb.build(a, w.variants));
+      }
+    }
+  }
   std::vector<Hit> keepers = remove_overlaps(hits, p.maxOverlap);  // SR:641
   sort_hits(keepers);                                              // SR:647
   std::string out;
@@ -975,6 +1253,74 @@ char* oracle_search_memory(int n_contigs, const char* const* names, const char* 
     p.genomeGapNetCost = iparams[8]; p.guideGapNetCost = iparams[9]; p.maxVariants = iparams[10]; p.threads = iparams[11];
     p.switches = iparams[12];
     return dup_out(search_reference(r, guide, guide_id, split_csv(aux_pams_csv), p, n_windows));
+  } catch (std::exception& e) { return dup_out(std::string("ERROR\t") + e.what()); }
+}
+
+// SearchReference with --variants: iparams as oracle_search_reference; vcf = path of an uncompressed VCF.
+char* oracle_search_reference_vcf(const char* fasta, const char* guide, const char* guide_id, const char* aux_pams_csv,
+                                  const int* iparams, const char* chrom, const char* vcf, long* n_windows) {
+  try {
+    Reference r = load_reference(fasta);
+    SearchParams p;
+    p.windowSize = iparams[0]; p.maxGuideDiffs = iparams[1]; p.maxPamMismatches = iparams[2]; p.maxGaps = iparams[3];
+    p.maxTotalDiffs = iparams[4]; p.maxOverlap = iparams[5]; p.guideMismatchNetCost = iparams[6]; p.pamMismatchNetCost = iparams[7];
+    p.genomeGapNetCost = iparams[8]; p.guideGapNetCost = iparams[9]; p.maxVariants = iparams[10]; p.threads = iparams[11];
+    p.switches = iparams[12];
+    if (chrom) p.chrom = chrom;
+    return dup_out(search_reference(r, guide, guide_id, split_csv(aux_pams_csv), p, n_windows, vcf ? vcf : ""));
+  } catch (std::exception& e) { return dup_out(std::string("ERROR\t") + e.what()); }
+}
+
+// alleleCombos(Seq[Int]) SR:377-399: one row per combination, comma separated.
+char* oracle_allele_combos(const int* counts, int n) {
+  std::string out;
+  for (auto& row : allele_combos(std::vector<int>(counts, counts + n))) {
+    for (size_t i = 0; i < row.size(); i++) { if (i) out += ','; out += std::to_string(row[i]); }
+    out += '\n';
+  }
+  return dup_out(out);
+}
+
+// alleleCombos(variants, maxVariants) + buildVariantWindow on one contig.  variants_spec: "pos:id:ref:alt1/alt2,..." (sorted).
+// allele_sel: comma separated allele index per variant (0 = leave out) for build; empty = list the VariantSets instead.
+// Output (build): bases \t cigar \t start, then one line per query "offset:preceding" -> reference offset.
+char* oracle_variant_window(const char* chrom, const char* ref_bases, const char* variants_spec, const char* allele_sel, int padding,
+                            int max_variants, const char* queries) {
+  try {
+    std::vector<VcfVariant> vs;
+    for (auto& item : split_csv(variants_spec)) {
+      std::stringstream ss(item);
+      std::string f[4];
+      for (int k = 0; k < 4; k++) std::getline(ss, f[k], ':');
+      VcfVariant v;
+      v.chrom = chrom; v.pos = std::atoi(f[0].c_str()); v.id = f[1] == "." ? "" : f[1]; v.ref = f[2];
+      std::stringstream as(f[3]); std::string x;
+      while (std::getline(as, x, '/')) v.alts.push_back(x);
+      v.end = v.pos + (int)v.ref.size() - 1;
+      vs.push_back(v);
+    }
+    std::vector<const VcfVariant*> ptrs;
+    for (auto& v : vs) ptrs.push_back(&v);
+    std::string out;
+    if (!allele_sel || !*allele_sel) {
+      for (auto& set : allele_combos(ptrs, max_variants)) {
+        for (size_t i = 0; i < set.variants.size(); i++) { if (i) out += ','; out += set.variants[i]->id + "=" + std::to_string(set.alleles[i]); }
+        out += '\n';
+      }
+      return dup_out(out);
+    }
+    VariantSet set;
+    auto sel = split_csv(allele_sel);
+    for (size_t i = 0; i < vs.size(); i++) { int a = std::atoi(sel[i].c_str()); if (a) { set.variants.push_back(&vs[i]); set.alleles.push_back(a); } }
+    std::string upper = ref_bases;
+    for (auto& c : upper) c = (char)std::toupper((unsigned char)c);
+    VariantWindow w = build_variant_window(set, chrom, upper, padding);
+    out = w.bases + "\t" + cigar_string(w.cigar) + "\t" + std::to_string(w.start) + "\n";
+    for (auto& qy : split_csv(queries)) {
+      size_t c = qy.find(':');
+      out += std::to_string(w.refOffsetAtBaseOffset(std::atoi(qy.substr(0, c).c_str()), qy.substr(c + 1) == "1")) + "\n";
+    }
+    return dup_out(out);
   } catch (std::exception& e) { return dup_out(std::string("ERROR\t") + e.what()); }
 }
 

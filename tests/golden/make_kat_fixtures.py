@@ -8,7 +8,7 @@ Run once in the build container (the reference tree is not available on the GPU 
 Only DATA is taken from the reference tests: the sequence literals of the in-memory FASTA that
 SequentialGuideAlignerTest.scala:12-44 builds are pulled out with a regex (so they cannot be mistyped); the
 inputs / expected values of every test case were transcribed by hand, each with the line range it comes from.
-Outputs: kat_sga.json (K1-K26), kat_ga.json (G1-G6), kat_sr.json (E1-E3, E5).
+Outputs: kat_sga.json (K1-K26), kat_ga.json (G1-G6), kat_sr.json (E1-E3, E5), kat_variants.json (V1-V9, E4).
 """
 import json
 import os
@@ -171,7 +171,58 @@ def main():
         "window_iterator": {"id": "E5", "lines": "43-49", "fasta": "fasta_windows", "window": 451, "step": 426},
     }
     json.dump(sr, open(os.path.join(HERE, "kat_sr.json"), "w"), indent=1)
-    print("wrote kat_sga.json kat_ga.json kat_sr.json")
+    ref50 = "CTAGACTGACTGACTAGCACTAGCCGCTTTATATATGCTATGGGACACCG"
+    ref79 = "CTAGACTGACTGACTAGCACTAGCCGCTTTATATATGCTAGGCGCTACTGAATGCTATAGCTCTGAGACTGGGACACCG"
+    e4_lines = [
+        "ACACACACACACACACACACACACACACACACACACACAgcgtcacggtcgagcgattggggAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA",
+        "ACACACACACACACACACACACACACACACACACACACAccccaatcgctcgaccgtgacgcAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA",
+        "ACACACACACACACACACACACACACACACACACACACAcacggtcgagcgattggggAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA",
+        "ACACACACACACACACACACACACACACACACACACACAaatcgctcgaccgtgacgcAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA"]
+    assert all(len(x) == 100 for x in e4_lines)
+    var = {
+        "source": "calitas/src/test/scala/com/editasmedicine/aligner/SearchReferenceTest.scala",
+        "allele_combos_counts": [   # V1-V3, lines 150-181
+            {"lines": "150-153", "counts": [2], "expect": [[0], [1]]},
+            {"lines": "150-153", "counts": [3], "expect": [[0], [1], [2]]},
+            {"lines": "155-158", "counts": [2, 2], "expect": [[0, 0], [0, 1], [1, 0], [1, 1]]},
+            {"lines": "155-158", "counts": [3, 2], "expect": [[0, 0], [0, 1], [1, 0], [1, 1], [2, 0], [2, 1]]},
+            {"lines": "160-181", "counts": [3, 2, 3],
+             "expect": [[a, b, c] for a in range(3) for b in range(2) for c in range(3)]},
+        ],
+        "build_variant_window": [   # V4-V7, lines 183-247; variants as [pos, id, ref, alts]
+            {"id": "V4", "lines": "183-196", "ref": ref50, "variants": [[20, "rs123", "C", ["G"]]], "alleles": [1], "padding": 15,
+             "bases": "ACTGACTGACTAGCAgTAGCCGCTTTATATA".upper(), "cigar": "31M",
+             "offsets": [[0, True, 4], [15, True, 19], [20, True, 24], [31, True, 35]]},
+            {"id": "V5", "lines": "198-215", "ref": ref50, "variants": [[20, "rs123", "C", ["CGT"]]], "alleles": [1], "padding": 15,
+             "bases": "ACTGACTGACTAGCAcgtTAGCCGCTTTATATA".upper(), "cigar": "16M2I15M",
+             "offsets": [[0, True, 4], [14, True, 18], [15, True, 19], [16, True, 19], [17, True, 19], [15, False, 19], [16, False, 20],
+                         [17, False, 20]]},
+            {"id": "V6", "lines": "217-230", "ref": ref50, "variants": [[20, "rs123", "CTA", ["C"]]], "alleles": [1], "padding": 15,
+             "bases": "ACTGACTGACTAGCAcGCCGCTTTATATATG".upper(), "cigar": "16M2D15M",
+             "offsets": [[0, True, 4], [15, True, 19], [16, True, 22]]},
+            {"id": "V7", "lines": "232-247", "ref": ref79,
+             "variants": [[10, "snp", "C", ["T"]], [20, "ins", "C", ["CG"]], [30, "del", "TAT", ["T"]]], "alleles": [1, 1, 1], "padding": 15,
+             "bases": "CTAGACTGAtTGACTAGCAcgTAGCCGCTTtATATGCTAGGCGCTA".upper(), "cigar": "20M1I10M2D15M", "offsets": []},
+        ],
+        "allele_combos_variants": [   # V8-V9, lines 249-295; expected sets as lists of "id=allele" (order of the sets is not asserted)
+            {"lines": "249-255", "variants": [[20, "snp", "A", ["C"]]], "max": 10, "expect": [["snp=1"]]},
+            {"lines": "257-266", "variants": [[20, "snp", "A", ["C", "G", "T"]]], "max": 10, "expect": [["snp=1"], ["snp=2"], ["snp=3"]]},
+            {"lines": "268-284", "variants": [[20, "a", "A", ["C"]], [25, "b", "C", ["T"]], [30, "c", "G", ["A"]]], "max": 10,
+             "expect": [["a=1"], ["b=1"], ["c=1"], ["a=1", "b=1"], ["a=1", "c=1"], ["b=1", "c=1"], ["a=1", "b=1", "c=1"]]},
+            {"lines": "286-295", "variants": [[20, "a", "A", ["C"]], [25, "b", "C", ["T"]], [30, "c", "G", ["A"]]], "max": 2, "expect_size": 1},
+            {"lines": "286-295", "variants": [[20, "a", "A", ["C"]], [25, "b", "C", ["T"]], [30, "c", "G", ["A"]]], "max": 3, "expect_size": 7},
+        ],
+        "e4": {"id": "E4", "lines": "94-147", "guide": "GCGTCACGGTCGAGCGATTGnrg", "chr1": "".join(e4_lines).upper(),
+               "variants": [[239, "insGAGGCGT", "A", ["AGAGGCGT"]], [339, "insTCGCCCC", "A", ["ATCGCCCC"]]],
+               "params": {"g": 0, "d": 0},
+               "expect": {"n": 4, "coordinate_start": [39, 142, 238, 338],
+                          "padded_extra_8_bases_5_prime": ["CACACACA", "TTTTTTTT", "ACACAGAG", "TTTTTTTT"],
+                          "padded_extra_8_bases_3_prime": ["AAAAAAAA", "TGTGTGTG", "AAAAAAAA", "CGATGTGT"],
+                          "ten_bases_5_prime": ["CACACACACA", "TTTTTTTTTT", "ACACACAGAG", "TTTTTTTTTT"],
+                          "ten_bases_3_prime": ["GGGAAAAAAA", "GGGTGTGTGT", "GGGAAAAAAA", "GGGCGATGTG"]}},
+    }
+    json.dump(var, open(os.path.join(HERE, "kat_variants.json"), "w"), indent=1)
+    print("wrote kat_sga.json kat_ga.json kat_sr.json kat_variants.json")
 
 
 if __name__ == "__main__":

@@ -31,7 +31,8 @@ def lib():
         build()
         L = ctypes.CDLL(LIB_PATH)
         for name in ["oracle_align", "oracle_align_best", "oracle_align_to_ref", "oracle_guide_alignment", "oracle_windows",
-                     "oracle_search_reference", "oracle_search_memory"]:
+                     "oracle_search_reference", "oracle_search_memory", "oracle_search_reference_vcf", "oracle_allele_combos",
+                     "oracle_variant_window"]:
             getattr(L, name).restype = ctypes.c_void_p
         L.oracle_free.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -121,3 +122,35 @@ def search_memory(names, seqs, guide, guide_id="a", aux=(), **kw):
     header = lines[0].split("\t")
     rows = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
     return header, rows, nwin.value
+
+
+def search_reference_vcf(fasta, vcf, guide, guide_id="a", aux=(), chrom="", **kw):
+    nwin = ctypes.c_long(0)
+    ptr = lib().oracle_search_reference_vcf(fasta.encode(), guide.encode(), guide_id.encode(), ",".join(aux).encode(), _iparams(**kw),
+                                            chrom.encode(), vcf.encode(), ctypes.byref(nwin))
+    lines = _take(ptr).splitlines()
+    header = lines[0].split("\t")
+    rows = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
+    return header, rows, nwin.value
+
+
+def allele_combos(counts):
+    arr = (ctypes.c_int * len(counts))(*counts)
+    return [[int(x) for x in ln.split(",")] for ln in _take(lib().oracle_allele_combos(arr, len(counts))).splitlines()]
+
+
+def _vspec(variants):
+    return ",".join("%d:%s:%s:%s" % (pos, vid or ".", ref, "/".join(alts)) for pos, vid, ref, alts in variants)
+
+
+def allele_sets(variants, max_variants, chrom="chr1"):
+    out = _take(lib().oracle_variant_window(chrom.encode(), b"", _vspec(variants).encode(), b"", 0, max_variants, b""))
+    return [ln.split(",") for ln in out.splitlines()]
+
+
+def build_variant_window(ref, variants, alleles, padding, queries=(), chrom="chr1"):
+    q = ",".join("%d:%d" % (off, 1 if prec else 0) for off, prec in queries)
+    out = _take(lib().oracle_variant_window(chrom.encode(), ref.encode(), _vspec(variants).encode(), ",".join(map(str, alleles)).encode(),
+                                            padding, 16, q.encode())).splitlines()
+    bases, cigar, start = out[0].split("\t")
+    return bases, cigar, int(start), [int(x) for x in out[1:]]

@@ -1,0 +1,101 @@
+"""GPU parity of the variant branch (SearchReference.scala:570-630, BASELINE config 5 shape at test size): the reference's own
+vector E4 and seeded random VCFs, every row against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fasta_util import write_fasta
+from test_oracle_variants import write_vcf
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+V = json.load(open(os.path.join(GOLD, "kat_variants.json")))
+SKIP = {"aligner_version", "time_stamp"}
+
+
+@pytest.fixture(scope="module")
+def C():
+    import calitas_amd
+    return calitas_amd
+
+
+def _norm(rows):
+    out = []
+    for r in rows:
+        r = {k: v for k, v in r.items() if k not in SKIP}
+        if r.get("variant_vcf"):
+            r["variant_vcf"] = r["variant_vcf"].split(":")[0]     # the oracle leaves the md5 out
+        out.append(r)
+    return out
+
+
+def test_e4_through_gpu(C, tmp_path):
+    e = V["e4"]
+    fa = write_fasta(str(tmp_path / "e4.fa"), [("chr1", e["chr1"])], line_len=100)
+    vcf = write_vcf(str(tmp_path / "e4.vcf"), [("chr1", p, i, r, a) for p, i, r, a in e["variants"]])
+    out = str(tmp_path / "results.txt")
+    C.SearchReference(guide=e["guide"], guide_id="test", ref=fa, variants=vcf, output=out, max_gaps_between_guide_and_pam=0,
+                      max_guide_diffs=0).execute()
+    hits = C.read_hits(out)
+    x = e["expect"]
+    assert len(hits) == x["n"]
+    assert [int(h["coordinate_start"]) for h in hits] == x["coordinate_start"]
+    for k in ("padded_extra_8_bases_5_prime", "padded_extra_8_bases_3_prime", "ten_bases_5_prime", "ten_bases_3_prime"):
+        assert [h[k] for h in hits] == x[k], k
+    _, want, _ = O.search_reference_vcf(fa, vcf, e["guide"], "test", d=0, g=0)
+    assert _norm(hits) == _norm(want)
+
+
+@pytest.mark.parametrize("guide,kw", [("CTTGCCCCACAGGGCAGTAAnrg", dict(d=4, p=1, g=2)), ("GTGACTTGAAGTCTCAGTATA", dict(d=5, p=1, g=3)),
+                                      ("tttvAACCAACCAACCGGTTACGT", dict(d=3, p=1, g=1))])
+def test_random_vcf_parity(C, guide, kw, tmp_path):
+    from calitas_amd import synth
+    G = C.Guide(guide)
+    pam = G.pams[0] if G.pams else ""
+    rng = np.random.default_rng(len(guide))
+    names, seqs = synth.make_genome([("chr1", 40000), ("chr2", 15000)], seed=9, guides=[(G.guide, pam, G.pam_is_five_prime)],
+                                    sites_per_guide=120, n_run_ends=100, n_block=800, softmask=0.3)
+    contigs = [(n, s.tobytes().decode()) for n, s in zip(names, seqs)]
+    fa = write_fasta(str(tmp_path / "v.fa"), contigs)
+    # variants: ~1 per 150 bp, mixed kinds, some clustered, AF values, multi-allelic sites
+    variants, afs = [], []
+    for name, seq in contigs:
+        pos, U = 200, seq.upper()
+        while pos < len(seq) - 300:
+            pos += int(rng.integers(5, 300))
+            rb = U[pos - 1]
+            if rb not in "ACGT":
+                continue
+            kind = int(rng.integers(0, 5))
+            others = [b for b in "ACGT" if b != rb]
+            if kind <= 1:
+                ref, alts = rb, [others[int(rng.integers(0, 3))]]
+            elif kind == 2:
+                ref, alts = rb, [rb + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 6))))]
+            elif kind == 3:
+                ln = int(rng.integers(2, 6))
+                ref = U[pos - 1:pos - 1 + ln]
+                if any(c not in "ACGT" for c in ref):
+                    continue
+                alts = [rb]
+            else:
+                ref, alts = rb, others[:2]
+            variants.append((name, pos, "rs%d" % len(variants) if rng.integers(0, 4) else "", ref, alts))
+            afs.append([round(float(rng.uniform(0.0005, 0.5)), 4) for _ in alts])
+            pos += len(ref)
+    vcf = write_vcf(str(tmp_path / "v.vcf"), variants, afs)
+    sr = C.SearchReference(guide=guide, guide_id="a", ref=fa, variants=vcf, max_guide_diffs=kw["d"], max_pam_mismatches=kw["p"],
+                           max_gaps_between_guide_and_pam=kw["g"])
+    text, n = sr.run()
+    got = C.read_hits(text)
+    _, want, _ = O.search_reference_vcf(fa, vcf, guide, "a", d=kw["d"], p=kw["p"], g=kw["g"])
+    assert any(r["variant_id"] or r["variant_description"] for r in want)
+    g2, w2 = _norm(got), _norm(want)
+    if g2 != w2:
+        gs = {json.dumps(r, sort_keys=True) for r in g2}
+        ws = {json.dumps(r, sort_keys=True) for r in w2}
+        raise AssertionError("product %d rows, oracle %d rows\nonly product: %s\nonly oracle: %s" % (
+            len(g2), len(w2), [json.loads(x) for x in sorted(gs - ws)][:2], [json.loads(x) for x in sorted(ws - gs)][:2]))

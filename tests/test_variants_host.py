@@ -1,0 +1,101 @@
+"""CPU tests of the product's variant-window producers (calitas_amd/variants.py) against the reference's own vectors
+V1-V9 (SearchReferenceTest.scala:150-295) and against the oracle on random variant sets; PrepareVcf (PrepareVcfTest.scala)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_oracle_variants import write_vcf
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+V = json.load(open(os.path.join(GOLD, "kat_variants.json")))
+
+
+@pytest.fixture(scope="module")
+def VA():
+    from calitas_amd import variants
+    return variants
+
+
+@pytest.mark.parametrize("case", V["allele_combos_counts"], ids=lambda c: "x".join(map(str, c["counts"])))
+def test_allele_combos_counts(VA, case):
+    assert VA.allele_combos_counts(case["counts"]) == case["expect"]
+
+
+def _variants(VA, spec, chrom="chr1"):
+    return [VA.Variant(chrom, pos, vid, ref, alts) for pos, vid, ref, alts in spec]
+
+
+@pytest.mark.parametrize("case", V["build_variant_window"], ids=lambda c: c["id"])
+def test_build_variant_window(VA, case):
+    vs = _variants(VA, case["variants"])
+    w = VA.build_variant_window(vs, case["alleles"], "chr1", case["ref"].upper().encode(), case["padding"])
+    assert w.bases.decode() == case["bases"] and w.cigar_string == case["cigar"]
+    for off, prec, want in case["offsets"]:
+        assert w.ref_offset_at_base_offset(off, prec) == want
+
+
+@pytest.mark.parametrize("case", V["allele_combos_variants"], ids=lambda c: "%s-max%d" % (c["lines"], c["max"]))
+def test_allele_combos_variants(VA, case):
+    sets = [["%s=%d" % (v.id, a) for v, a in zip(vs, al)] for vs, al in VA.allele_combos(_variants(VA, case["variants"]), case["max"])]
+    if "expect" in case:
+        assert sorted(map(tuple, sets)) == sorted(map(tuple, case["expect"]))
+    else:
+        assert len(sets) == case["expect_size"]
+
+
+def test_random_variant_windows_match_oracle(VA):
+    """Random clusters of SNVs / insertions / deletions / multi-allelic sites: same windows (bases, cigar, start, lift-back)
+    as the oracle for every allele combination."""
+    rng = np.random.default_rng(5)
+    ref = "".join(rng.choice(list("ACGT"), size=400))
+    for trial in range(40):
+        n = int(rng.integers(1, 5))
+        pos, spec = int(rng.integers(5, 40)), []
+        for k in range(n):
+            pos += int(rng.integers(1, 30))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                r, alts = ref[pos - 1], [rng.choice([b for b in "ACGT" if b != ref[pos - 1]])]
+            elif kind == 1:
+                r, alts = ref[pos - 1], [ref[pos - 1] + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 5))))]
+            elif kind == 2:
+                ln = int(rng.integers(2, 6)); r, alts = ref[pos - 1:pos - 1 + ln], [ref[pos - 1]]
+            else:
+                r, alts = ref[pos - 1], [b for b in "ACGT" if b != ref[pos - 1]][:2]
+            spec.append([pos, "v%d" % k, r, alts])
+            pos += len(r)
+        vs = _variants(VA, spec)
+        padding = int(rng.integers(5, 35))
+        for variants, alleles in VA.allele_combos(vs, 16):
+            sel = [alleles[variants.index(v)] if v in variants else 0 for v in vs]
+            w = VA.build_variant_window(variants, alleles, "chr1", ref.encode(), padding)
+            queries = [(o, p) for o in range(0, len(w.bases) + 1, 7) for p in (True, False)]
+            try:
+                ob, oc, ostart, ooffs = O.build_variant_window(ref, spec, sel, padding, queries)
+            except RuntimeError:
+                continue
+            assert (w.bases.decode(), w.cigar_string, w.start) == (ob, oc, ostart)
+            assert [w.ref_offset_at_base_offset(o, p) for o, p in queries] == ooffs
+
+
+def test_prepare_vcf(VA, tmp_path):
+    """PrepareVcfTest.scala:9-39 shape: 10 PASS variants with AF 0.5 and genotypes -> 10 variants, no samples; plus AF filtering."""
+    src = tmp_path / "in.vcf"
+    with open(src, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"x\">\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"x\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample1\tsample2\n")
+        for i in range(10):
+            f.write("1\t%d\t.\tA\tC\t.\tPASS\tAF=0.5;DP=10\tGT\t0/1\t./.\n" % (1000 * (i + 1)))
+        f.write("1\t20000\t.\tA\tC,G\t.\tPASS\tAF=0.001,0.2\tGT\t0/1\t./.\n")
+        f.write("1\t21000\t.\tA\tC\t.\tq10\tAF=0.5\tGT\t0/1\t./.\n")
+        f.write("1\t22000\t.\tA\tC\t.\tPASS\tAF=0.0001\tGT\t0/1\t./.\n")
+    out = tmp_path / "out.vcf"
+    n = VA.prepare_vcf([str(src)], str(out), min_af=0.01)
+    hdr, vs = VA.read_vcf(str(out))
+    assert n == 11 and len(vs) == 11
+    assert [h for h in hdr if h.startswith("#CHROM")][0].split("\t")[-1] == "INFO"     # no samples
+    assert all(v.chrom == "chr1" for v in vs)
+    assert vs[10].alts == ["G"] and vs[10].afs == [0.2]
