@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--shard", choices=["guides", "contigs"], default="guides")
     ap.add_argument("--cpu-sample-mb", type=float, default=-1, help="CPU baseline sample in Mb (<0: auto, 0: skip)")
     ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and gloo replaces RCCL (not a measurement)")
     args = ap.parse_args()
 
     import torch
@@ -148,13 +150,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     gloo = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
-        gloo = dist.new_group(backend="gloo")
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+            gloo = dist.group.WORLD
+        else:
+            dist.init_process_group("nccl", device_id=device)
+            gloo = dist.new_group(backend="gloo")
 
     def log(msg):
         if rank == 0:
@@ -240,7 +248,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
