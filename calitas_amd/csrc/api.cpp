@@ -534,6 +534,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     std::vector<uint32_t> cur(bucket_off.begin(), bucket_off.end() - 1);
     for (uint32_t i = 0; i < n_raw; i++) perm[cur[bucket_of(raw[i])]++] = i;
   }
+  const auto t_bucketed = std::chrono::steady_clock::now();
   std::vector<std::vector<calitas_aln_t>> bucket_out(n_buckets);
   {
     std::atomic<size_t> next(0);
@@ -563,15 +564,16 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
           int64_t wa = 0, wb = 0;
           window_bounds(ref.runs.data(), (int64_t)ref.runs.size(), ref.contigs[f.contig].gbase, ref.contigs[f.contig].len, p.window_size,
                         step, f.window_k, wa, wb);
-          win.resize(j - i);
+          if (win.size() < j - i) win.resize(j - i);
           for (size_t k = i; k < j; k++) raw_to_aln(raw[keyed[k].second], gh[f.guide], wa, wb, win[k - i]);
-          window_filter(win.data(), (int)win.size(), max_total, p.max_overlap, kept);
+          window_filter(win.data(), (int)(j - i), max_total, p.max_overlap, kept);
           for (int k : kept) outv.push_back(win[k]);
           i = j;
         }
       }
     });
   }
+  const auto t_filtered = std::chrono::steady_clock::now();
   std::vector<size_t> out_off(n_buckets + 1, 0);
   for (size_t b = 0; b < n_buckets; b++) out_off[b + 1] = out_off[b] + bucket_out[b].size();
   const size_t n_result = out_off[n_buckets];
@@ -588,6 +590,11 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     });
   }
   tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (std::getenv("CALITAS_TRACE")) {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[calitas] host filter: bucket %.2f ms, sort+convert+filter %.2f ms, concat %.2f ms (%zu buckets)\n",
+                 ms(t0, t_bucketed), ms(t_bucketed, t_filtered), ms(t_filtered, std::chrono::steady_clock::now()), n_buckets);
+  }
   if (std::getenv("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms, host filter %.3f ms, call %.3f ms (%u records, %u raw, %zu accepted)\n",
                  tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 
 namespace calitas {
 
@@ -107,23 +108,39 @@ void raw_to_aln(const RawAln& r, const GuideHost& g, int64_t win_a, int64_t win_
   else std::memcpy(out.ops, ops, n);
 }
 
-static inline int aln_edits(const calitas_aln_t& a) { int e = 0; for (int i = 0; i < a.n_ops; i++) if (a.ops[i] != '=') e++; return e; }      // GA:101
-static inline int aln_gap_bases(const calitas_aln_t& a) { int e = 0; for (int i = 0; i < a.n_ops; i++) if (a.ops[i] == 'I' || a.ops[i] == 'D') e++; return e; }  // GA:100
 
 void window_filter(const calitas_aln_t* alns, int n, int max_total_diffs, int max_overlap, std::vector<int>& kept) {
   kept.clear();
   // The caller passes the forward-strand list followed by the reverse-strand list (SGA:316); each is sorted on its own.
-  std::vector<int> idx[2];
-  std::vector<int> gaps(n);
-  for (int i = 0; i < n; i++) { gaps[i] = aln_gap_bases(alns[i]); idx[alns[i].strand == '-' ? 1 : 0].push_back(i); }
+  // Scratch is per thread and reused: this runs once per window with candidates (~10^5 times per pass).
+  static thread_local std::vector<int> idx[2], gaps, edits;
+  idx[0].clear(); idx[1].clear();
+  gaps.resize(n); edits.resize(n);
+  for (int i = 0; i < n; i++) {
+    int g = 0, e = 0;
+    for (int k = 0; k < alns[i].n_ops; k++) { const uint8_t op = alns[i].ops[k]; e += op != '='; g += (op == 'I' || op == 'D'); }   // GA:100-101
+    gaps[i] = g; edits[i] = e;
+    idx[alns[i].strand == '-' ? 1 : 0].push_back(i);
+  }
   for (int s = 0; s < 2; s++) {
-    std::stable_sort(idx[s].begin(), idx[s].end(), [&](int x, int y) {   // GA:125-129
+    auto& v = idx[s];
+    auto before = [&](int x, int y) {   // GA:125-129
       if (alns[x].score != alns[y].score) return alns[x].score > alns[y].score;
       return gaps[x] < gaps[y];
-    });
-    for (int i : idx[s]) {
+    };
+    if (v.size() > 32) {
+      std::stable_sort(v.begin(), v.end(), before);
+    } else {                            // insertion sort: stable, and no temporary buffer from the heap
+      for (size_t a = 1; a < v.size(); a++) {
+        const int x = v[a];
+        size_t b = a;
+        while (b > 0 && before(x, v[b - 1])) { v[b] = v[b - 1]; b--; }
+        v[b] = x;
+      }
+    }
+    for (int i : v) {
       const calitas_aln_t& a = alns[i];
-      if (aln_edits(a) > max_total_diffs) continue;
+      if (edits[i] > max_total_diffs) continue;
       bool clash = false;
       for (int k : kept) {
         const calitas_aln_t& b = alns[k];
@@ -212,13 +229,6 @@ static int fetch_span(const PackedRef& ref, int contig, int64_t start, int64_t e
   return n;
 }
 
-static inline void put_int(std::string& out, long v) {
-  char b[24]; int n = 0; bool neg = v < 0; unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
-  do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-  if (neg) b[n++] = '-';
-  while (n) out += b[--n];
-}
-
 // GuideAlignment.count (GA:139-163) on padded char arrays of length len.
 static int ga_count_raw(const char* pg, const char* pa, int len, bool lower, bool bothSides, bool mms, bool gaps) {
   auto is_lower = [](char c) { return c >= 'a' && c <= 'z'; };
@@ -250,12 +260,34 @@ struct RowConst {
   std::string proto_len;
 };
 
-// One hits.txt row (RH:210-254) for an accepted alignment, appended to `out`.  No heap allocation per row.
-static void append_row(std::string& out, const PackedRef& ref, const RowConst& rc, const calitas_aln_t& a) {
+static inline char* put_int_p(char* w, long v) {
+  char b[24]; int n = 0; const bool neg = v < 0; unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
+  do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (neg) *w++ = '-';
+  while (n) *w++ = b[--n];
+  return w;
+}
+static inline char* put_mem(char* w, const char* p, size_t n) { std::memcpy(w, p, n); return w + n; }
+static inline char* put_str(char* w, const std::string& s) { return put_mem(w, s.data(), s.size()); }
+
+// Bases [from, to) of a forward-strand buffer that starts at contig offset lo, in guide orientation.
+static inline char* put_bases(char* w, const char* fwd, int64_t lo, int64_t from, int64_t to, bool minus) {
+  if (!minus) return put_mem(w, fwd + (from - lo), (size_t)(to - from));
+  for (int64_t p = to - 1; p >= from; p--) *w++ = complement_base(fwd[p - lo]);
+  return w;
+}
+
+// One hits.txt row (RH:210-254) written at w; returns the new write position.  The caller provides row_bound() bytes.
+static char* write_row(char* w, const PackedRef& ref, const RowConst& rc, const calitas_aln_t& a) {
   const bool minus = a.strand == '-';
   const std::string& q = rc.query[a.pam_index + 1];
+  // one fetch covers the alignment and all four flanks (RH:213-216: 10 bases around the protospacer, 8 around the alignment)
+  const int64_t lo = std::min<int64_t>((int64_t)a.start_offset - 8, (int64_t)a.guide_start_offset - 10);
+  const int64_t hi = std::max<int64_t>((int64_t)a.end_offset + 8, (int64_t)a.guide_end_offset + 10);
+  char fwd[CALITAS_MAX_OPS + 64];
+  fetch_span(ref, a.contig_index, lo, hi, false, fwd);
   char t[CALITAS_MAX_OPS + 8], pg[CALITAS_MAX_OPS + 1], pa[CALITAS_MAX_OPS + 1], pt[CALITAS_MAX_OPS + 1];
-  fetch_span(ref, a.contig_index, a.start_offset, a.end_offset, minus, t);
+  put_bases(t, fwd, lo, a.start_offset, a.end_offset, minus);
   const int n = a.n_ops;
   int qi = 0, ti = 0, mm = 0, gp = 0;
   for (int i = 0; i < n; i++) {   // Alignment.paddedString (SGA:511)
@@ -266,45 +298,52 @@ static void append_row(std::string& out, const PackedRef& ref, const RowConst& r
       default:  pg[i] = q[qi++]; pa[i] = '.'; pt[i] = t[ti++]; mm++; break;
     }
   }
-  // unpaddedTargetWithoutPam GA:111-115
-  int ps = -1, pe = -1;
+  int ps = -1, pe = -1;           // unpaddedTargetWithoutPam GA:111-115
   for (int i = 0; i < n; i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
-  char ut[CALITAS_MAX_OPS + 1]; int utn = 0;
-  for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') ut[utn++] = pt[i];
-  // RH:213-216 (coordinates in genome orientation, content strand aware)
-  char tenL[10], tenR[10], eightL[8], eightR[8];
-  fetch_span(ref, a.contig_index, (int64_t)a.guide_start_offset - 10, a.guide_start_offset, minus, tenL);
-  fetch_span(ref, a.contig_index, a.guide_end_offset, (int64_t)a.guide_end_offset + 10, minus, tenR);
-  fetch_span(ref, a.contig_index, (int64_t)a.start_offset - 8, a.start_offset, minus, eightL);
-  fetch_span(ref, a.contig_index, a.end_offset, (int64_t)a.end_offset + 8, minus, eightR);
 
-  out += rc.head;
-  out += ref.names[a.contig_index]; out += '\t';
-  put_int(out, a.guide_start_offset); out += '\t';
-  put_int(out, a.guide_end_offset); out += '\t';
-  out += (char)a.strand; out += '\t';
-  out.append(ut, utn); out += '\t';
-  out.append(minus ? tenR : tenL, 10); out += '\t';      // RH:227
-  out.append(minus ? tenL : tenR, 10); out += '\t';      // RH:228
-  out += rc.pam_used[a.pam_index + 1]; out += '\t';
-  out += "\t\t\t\t";                                     // variant_id, variant_description, variant_vcf, allele_frequency: None
-  put_int(out, a.score); out += '\t';
-  put_int(out, ga_count_raw(pg, pa, n, false, false, true, false)); out += '\t';   // guide_mm GA:103
-  put_int(out, ga_count_raw(pg, pa, n, false, false, false, true)); out += '\t';   // guide_gaps GA:104
-  put_int(out, ga_count_raw(pg, pa, n, false, false, true, true)); out += '\t';    // guide_mm_plus_gaps GA:105
-  put_int(out, ga_count_raw(pg, pa, n, true, true, true, false)); out += '\t';     // pam_mm GA:106
-  put_int(out, mm + gp); out += '\t';                                              // total_mm_plus_gaps = edits GA:101
-  out.append(pg, n); out += '\t'; out.append(pa, n); out += '\t'; out.append(pt, n); out += '\t';
-  out.append(minus ? eightR : eightL, 8); out += '\t';   // RH:243
-  out.append(minus ? eightL : eightR, 8); out += '\t';   // RH:244
-  for (int i = 0; i < n;) {                              // Cigar.coalesce + toString
+  w = put_str(w, rc.head);
+  w = put_str(w, ref.names[a.contig_index]); *w++ = '\t';
+  w = put_int_p(w, a.guide_start_offset); *w++ = '\t';
+  w = put_int_p(w, a.guide_end_offset); *w++ = '\t';
+  *w++ = (char)a.strand; *w++ = '\t';
+  int utn = 0;
+  for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') { *w++ = pt[i]; utn++; }
+  *w++ = '\t';
+  // ten_bases_5_prime / 3_prime RH:227-228: left/right of the protospacer in genome orientation, swapped and reverse
+  // complemented on the minus strand
+  const int64_t gs = a.guide_start_offset, ge = a.guide_end_offset, as = a.start_offset, ae = a.end_offset;
+  if (!minus) { w = put_bases(w, fwd, lo, gs - 10, gs, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ge, ge + 10, false); }
+  else        { w = put_bases(w, fwd, lo, ge, ge + 10, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, gs - 10, gs, true); }
+  *w++ = '\t';
+  w = put_str(w, rc.pam_used[a.pam_index + 1]); *w++ = '\t';
+  w = put_mem(w, "\t\t\t\t", 4);                        // variant_id, variant_description, variant_vcf, allele_frequency: None
+  w = put_int_p(w, a.score); *w++ = '\t';
+  const int gmm = ga_count_raw(pg, pa, n, false, false, true, false);    // guide_mm GA:103
+  const int ggp = ga_count_raw(pg, pa, n, false, false, false, true);    // guide_gaps GA:104
+  w = put_int_p(w, gmm); *w++ = '\t';
+  w = put_int_p(w, ggp); *w++ = '\t';
+  w = put_int_p(w, gmm + ggp); *w++ = '\t';             // guide_mm_plus_gaps GA:105 (every column is counted once)
+  w = put_int_p(w, ga_count_raw(pg, pa, n, true, true, true, false)); *w++ = '\t';   // pam_mm GA:106
+  w = put_int_p(w, mm + gp); *w++ = '\t';               // total_mm_plus_gaps = edits GA:101
+  w = put_mem(w, pg, n); *w++ = '\t'; w = put_mem(w, pa, n); *w++ = '\t'; w = put_mem(w, pt, n); *w++ = '\t';
+  if (!minus) { w = put_bases(w, fwd, lo, as - 8, as, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ae, ae + 8, false); }   // RH:243-244
+  else        { w = put_bases(w, fwd, lo, ae, ae + 8, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, as - 8, as, true); }
+  *w++ = '\t';
+  for (int i = 0; i < n;) {                             // Cigar.coalesce + toString
     int j = i; while (j < n && a.ops[j] == a.ops[i]) j++;
-    put_int(out, j - i); out += (char)a.ops[i]; i = j;
+    w = put_int_p(w, j - i); *w++ = (char)a.ops[i]; i = j;
   }
-  out += '\t';
-  out += rc.proto_len; out += '\t';
-  put_int(out, utn); out += '\t';
-  out += rc.tail;
+  *w++ = '\t';
+  w = put_str(w, rc.proto_len); *w++ = '\t';
+  w = put_int_p(w, utn); *w++ = '\t';
+  w = put_str(w, rc.tail);
+  return w;
+}
+
+static size_t row_bound(const PackedRef& ref, const RowConst& rc) {
+  size_t name = 0;
+  for (auto& n : ref.names) name = std::max(name, n.size());
+  return rc.head.size() + rc.tail.size() + name + 5 * (CALITAS_MAX_OPS + 4) + 256;
 }
 
 char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
@@ -410,26 +449,31 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
   header += '\n';
   const size_t BLOCK = 512;
   const size_t n_blocks = (keepers.size() + BLOCK - 1) / BLOCK;
-  std::vector<std::string> parts(n_blocks);
+  const size_t bound = row_bound(ref, rc);
+  struct Part { std::unique_ptr<char[]> buf; size_t len = 0; };
+  std::vector<Part> parts(n_blocks);
   {
     std::atomic<size_t> next(0);
     pool->run([&](int) {
       for (;;) {
         size_t b = next.fetch_add(1);
         if (b >= n_blocks) break;
-        std::string& s = parts[b];
-        s.reserve(BLOCK * 600);
-        size_t e = std::min(keepers.size(), (b + 1) * BLOCK);
+        const size_t e = std::min(keepers.size(), (b + 1) * BLOCK);
+        size_t need = 0;
+        for (size_t i = b * BLOCK; i < e; i++) need += keepers[i].idx < n ? bound : std::strlen(ext[keepers[i].idx - n].row) + 1;
+        parts[b].buf.reset(new char[need]);
+        char* w = parts[b].buf.get();
         for (size_t i = b * BLOCK; i < e; i++) {
-          if (keepers[i].idx < n) append_row(s, ref, rc, alns[keepers[i].idx]);
-          else { s += ext[keepers[i].idx - n].row; s += '\n'; }
+          if (keepers[i].idx < n) w = write_row(w, ref, rc, alns[keepers[i].idx]);
+          else { const char* r = ext[keepers[i].idx - n].row; w = put_mem(w, r, std::strlen(r)); *w++ = '\n'; }
         }
+        parts[b].len = (size_t)(w - parts[b].buf.get());
       }
     });
   }
   size_t total = header.size();
   std::vector<size_t> offs(n_blocks);
-  for (size_t b = 0; b < n_blocks; b++) { offs[b] = total; total += parts[b].size(); }
+  for (size_t b = 0; b < n_blocks; b++) { offs[b] = total; total += parts[b].len; }
   auto t_rows = tnow();
   char* out = (char*)(alloc ? alloc(total + 1) : std::malloc(total + 1));
   if (!out) return nullptr;
@@ -441,8 +485,8 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
       for (;;) {
         size_t b = next.fetch_add(1);
         if (b >= n_blocks) break;
-        std::memcpy(out + offs[b], parts[b].data(), parts[b].size());
-        std::string().swap(parts[b]);
+        std::memcpy(out + offs[b], parts[b].buf.get(), parts[b].len);
+        parts[b].buf.reset();
       }
     });
   }
