@@ -1,0 +1,83 @@
+/* calitas_jni.c -- JNI glue between com.editasmedicine.aligner.NativeAligner (integration/scala/NativeAligner.scala) and the
+ * C ABI of include/calitas_hip.h.  NOT compiled in this repository (no JDK / jni.h in the build image); build on a box
+ * with a JDK:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include calitas_jni.c \
+ *       -L../../calitas_amd -lcalitas_hip -Wl,-rpath,'$ORIGIN' -o libcalitas_jni.so
+ */
+#include <jni.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "calitas_hip.h"
+
+static void throw_state(JNIEnv* env, const char* msg) {
+  (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalStateException"), msg ? msg : "calitas error");
+}
+
+JNIEXPORT jlong JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_create(JNIEnv* env, jobject self, jint device) {
+  calitas_ctx* ctx = NULL;
+  if (calitas_create(device, &ctx) != CALITAS_OK) { throw_state(env, calitas_last_error(NULL)); return 0; }
+  return (jlong)(intptr_t)ctx;
+}
+
+JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_destroy(JNIEnv* env, jobject self, jlong h) {
+  calitas_destroy((calitas_ctx*)(intptr_t)h);
+}
+
+/* names: String[]; bases: byte[][] as read by ReferenceSequenceIterator (SearchReference.scala:41-49). */
+JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_setReference(JNIEnv* env, jobject self, jlong h,
+    jobjectArray names, jobjectArray bases, jstring genomeBuild) {
+  calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
+  const jsize n = (*env)->GetArrayLength(env, names);
+  const char** cnames = calloc((size_t)n, sizeof(char*));
+  uint64_t* lens = calloc((size_t)n, sizeof(uint64_t));
+  const uint8_t** ptrs = calloc((size_t)n, sizeof(uint8_t*));
+  jbyteArray* arrs = calloc((size_t)n, sizeof(jbyteArray));
+  jstring* jn = calloc((size_t)n, sizeof(jstring));
+  const char* build = genomeBuild ? (*env)->GetStringUTFChars(env, genomeBuild, NULL) : "unknown";
+  for (jsize i = 0; i < n; i++) {
+    jn[i] = (jstring)(*env)->GetObjectArrayElement(env, names, i);
+    cnames[i] = (*env)->GetStringUTFChars(env, jn[i], NULL);
+    arrs[i] = (jbyteArray)(*env)->GetObjectArrayElement(env, bases, i);
+    lens[i] = (uint64_t)(*env)->GetArrayLength(env, arrs[i]);
+    /* inputs are borrowed only for the duration of calitas_set_reference, which keeps its own 2-bit copy */
+    ptrs[i] = (const uint8_t*)(*env)->GetByteArrayElements(env, arrs[i], NULL);
+  }
+  const int rc = calitas_set_reference(ctx, (int32_t)n, cnames, lens, ptrs, build);
+  for (jsize i = 0; i < n; i++) {
+    (*env)->ReleaseByteArrayElements(env, arrs[i], (jbyte*)ptrs[i], JNI_ABORT);
+    (*env)->ReleaseStringUTFChars(env, jn[i], cnames[i]);
+  }
+  if (genomeBuild) (*env)->ReleaseStringUTFChars(env, genomeBuild, build);
+  free(cnames); free(lens); free(ptrs); free(arrs); free(jn);
+  if (rc != CALITAS_OK) throw_state(env, calitas_last_error(ctx));
+}
+
+/* params: the 13 int fields of calitas_params_t in declaration order.  Returns a direct ByteBuffer over the
+ * library-owned calitas_aln_t array; NativeAligner hands the address back to `free` when done. */
+JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_search(JNIEnv* env, jobject self, jlong h,
+    jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jintArray params) {
+  calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
+  calitas_guide_t g;
+  calitas_params_t p;
+  const jsize np = (*env)->GetArrayLength(env, pams);
+  const char* cp[CALITAS_MAX_PAMS];
+  jstring jp[CALITAS_MAX_PAMS];
+  if (np > CALITAS_MAX_PAMS) { throw_state(env, "too many PAMs"); return NULL; }
+  g.protospacer = (*env)->GetStringUTFChars(env, protospacer, NULL);
+  for (jsize i = 0; i < np; i++) { jp[i] = (jstring)(*env)->GetObjectArrayElement(env, pams, i); cp[i] = (*env)->GetStringUTFChars(env, jp[i], NULL); }
+  g.n_pams = (int32_t)np; g.pams = cp; g.pam_is_5prime = pam5 ? 1 : 0; g.cli_length = cliLength;
+  (*env)->GetIntArrayRegion(env, params, 0, (jsize)(sizeof(p) / sizeof(int32_t)), (jint*)&p);
+  calitas_aln_t* alns = NULL;
+  uint64_t n = 0;
+  const int rc = calitas_search(ctx, 1, &g, &p, &alns, &n);
+  (*env)->ReleaseStringUTFChars(env, protospacer, g.protospacer);
+  for (jsize i = 0; i < np; i++) (*env)->ReleaseStringUTFChars(env, jp[i], cp[i]);
+  if (rc != CALITAS_OK) { throw_state(env, calitas_last_error(ctx)); return NULL; }
+  return (*env)->NewDirectByteBuffer(env, alns, (jlong)(n * sizeof(calitas_aln_t)));
+}
+
+JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_free(JNIEnv* env, jobject self, jobject buffer) {
+  calitas_free((*env)->GetDirectBufferAddress(env, buffer));
+}

@@ -1,0 +1,73 @@
+package com.editasmedicine.aligner
+
+import java.nio.{ByteBuffer, ByteOrder}
+
+import com.editasmedicine.aligner.SequentialGuideAligner.Guide
+import com.fulcrumgenomics.alignment.Cigar
+
+/** JNI wrapper over libcalitas_hip.so (include/calitas_hip.h): one instance = one MI355X = one calitas_ctx.
+  * NOT compiled in the calitas-mi355x repository (no JDK there); drop into calitas/src/main/scala/com/editasmedicine/aligner/
+  * next to SearchReference.scala and build integration/jni/calitas_jni.c into libcalitas_jni.so. */
+final class NativeAligner(device: Int = 0) extends AutoCloseable {
+  System.loadLibrary("calitas_jni")
+  private val handle: Long = NativeAligner.create(device)
+
+  /** calitas_set_reference: contigs in sequence-dictionary order with the bytes windowIterator sees (SearchReference.scala:41-49). */
+  def setReference(names: Array[String], bases: Array[Array[Byte]], genomeBuild: String): Unit =
+    NativeAligner.setReference(handle, names, bases, genomeBuild)
+
+  /** calitas_search for one guide; returns the GuideAlignments of every window in windowIterator order. */
+  def search(guide: Guide, cliLength: Int, params: Array[Int], contigNames: IndexedSeq[String],
+             fetch: (String, Int, Int) => Array[Byte]): IndexedSeq[GuideAlignment] = {
+    val pams = (guide.pams5Prime ++ guide.pams3Prime).toArray
+    val buf  = NativeAligner.search(handle, guide.guide, pams, guide.pamIsFivePrime, cliLength, params).order(ByteOrder.LITTLE_ENDIAN)
+    try NativeAligner.decode(buf, guide, pams, contigNames, fetch) finally NativeAligner.free(buf)
+  }
+
+  override def close(): Unit = NativeAligner.destroy(handle)
+}
+
+object NativeAligner {
+  private val RecordBytes = 168 // sizeof(calitas_aln_t): 8 x int32, 2 x int8, int16, 128 op bytes
+  private val MaxOps      = 128
+
+  @native private def create(device: Int): Long
+  @native private def destroy(handle: Long): Unit
+  @native private def setReference(handle: Long, names: Array[String], bases: Array[Array[Byte]], genomeBuild: String): Unit
+  @native private def search(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
+                             params: Array[Int]): ByteBuffer
+  @native private def free(buffer: ByteBuffer): Unit
+
+  /** calitas_aln_t -> GuideAlignment (GuideAlignment.scala:72-88).  The padded strings follow Alignment.paddedString as used at
+    * SequentialGuideAligner.scala:511: one op byte per padded column, already in guide orientation. */
+  private def decode(buf: ByteBuffer, guide: Guide, pams: Array[String], contigs: IndexedSeq[String],
+                     fetch: (String, Int, Int) => Array[Byte]): IndexedSeq[GuideAlignment] = {
+    val n = buf.capacity() / RecordBytes
+    Range(0, n).map { i =>
+      val o        = i * RecordBytes
+      val chrom    = contigs(buf.getInt(o + 4))
+      val start    = buf.getInt(o + 12); val end    = buf.getInt(o + 16)
+      val gStart   = buf.getInt(o + 20); val gEnd   = buf.getInt(o + 24)
+      val score    = buf.getInt(o + 28)
+      val strand   = buf.get(o + 32).toChar
+      val pamIndex = buf.get(o + 33).toInt
+      val nOps     = buf.getShort(o + 34).toInt
+      val ops      = Array.tabulate(nOps)(k => buf.get(o + 36 + k).toChar)
+      val pam      = if (pamIndex >= 0) pams(pamIndex) else ""
+      val query    = if (guide.pamIsFivePrime) pam + guide.guide else guide.guide + pam
+      val fwd      = new String(fetch(chrom, start, end)).toUpperCase
+      val target   = if (strand == '-') com.fulcrumgenomics.util.Sequences.revcomp(fwd) else fwd
+      val (pg, pa, pt) = (new StringBuilder, new StringBuilder, new StringBuilder)
+      var (qi, ti) = (0, 0)
+      ops.foreach {
+        case 'I' => pg += query(qi); pa += '~'; pt += '-'; qi += 1
+        case 'D' => pg += '-'; pa += '~'; pt += target(ti); ti += 1
+        case '=' => pg += query(qi); pa += '|'; pt += target(ti); qi += 1; ti += 1
+        case _   => pg += query(qi); pa += '.'; pt += target(ti); qi += 1; ti += 1
+      }
+      val cigar = Cigar(ops.map(_.toString).mkString.replaceAll("(.)", "1$1")).coalesce
+      GuideAlignment(guide = query, chrom = chrom, startOffset = start, endOffset = end, guideStartOffset = gStart, guideEndOffset = gEnd,
+        strand = strand, score = score, cigar = cigar, paddedGuide = pg.result(), paddedAlignment = pa.result(), paddedTarget = pt.result())
+    }
+  }
+}
