@@ -136,6 +136,7 @@ void calitas_destroy(calitas_ctx* c) {
     free_reference_device(c);
     (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
     (void)hipFree(c->d_slab);
+    select_destroy(c->select);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -328,6 +329,7 @@ std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, cons
   gd.max_guide_diffs = max_guide_diffs;
   gd.max_pam_mismatches = max_pam_mismatches;
   gd.max_diffs_filtering = max_guide_diffs + p.max_gaps_between_guide_and_pam + max_pam_mismatches;   // SGA:249
+  gd.pam5 = gh.pam5 ? 1 : 0;
   const int budget = sc.match * L - gd.min_guide_score;                              // = |worst| * d
   // score(all matches) - score(path) = sum of per-edit costs: mismatch |m|, guide-only base |b|, genome-only base |B|
   const int c_mm = iabs(p.guide_mismatch_net_cost), c_ins = iabs(p.genome_gap_net_cost), c_del = iabs(p.guide_gap_net_cost);
@@ -503,7 +505,26 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     ctx->h_raw_cap = ctx->raw_cap;
   }
   const RawAln* raw = ctx->h_raw;
-  if (n_raw) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  // ---- per-window filter (SGA:315-320): on the GPU (select.hip) unless the tiling does not fit its sort key, a window
+  //      exceeds its group limit, or CALITAS_HOST_FILTER asks for the host implementation of the same stage ----
+  uint64_t max_wins = 0;
+  for (auto& c : ref.contigs) max_wins = std::max<uint64_t>(max_wins, window_count(c.len, step));
+  bool gpu_select = n_raw > 0 && !std::getenv("CALITAS_HOST_FILTER") && select_supported(ref.contigs.size(), max_wins, p.window_size, n_guides);
+  uint32_t n_sel = 0;
+  if (gpu_select) {
+    const RawAln* d_final = nullptr;
+    const uint32_t* d_cnt = nullptr;
+    HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, ctx->d_win_base, ctx->d_win, max_total, p.max_overlap,
+                            ctx->stream, &d_final, &d_cnt));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_counters[6] != 0) gpu_select = false;   // a window with more alignments than one lane should chew through
+    else {
+      n_sel = ctx->h_counters[5];
+      if (n_sel) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, d_final, (size_t)n_sel * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  if (!gpu_select && n_raw) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
@@ -512,6 +533,33 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); tm.gpu_total_ms = ms;
   tm.scan_records = n_rec;
   tm.raw_alignments = n_raw;
+
+  if (gpu_select) {
+    // accepted alignments arrive in final order; only the coordinate conversion (GA:21-31, SGA:260-313) is left
+    auto t0 = std::chrono::steady_clock::now();
+    calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_sel) * sizeof(calitas_aln_t));
+    if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
+    ctx->pool->for_blocks(n_sel, [&](size_t b, size_t e, int) {
+      for (size_t i = b; i < e; i++) {
+        const RawAln& r = raw[i];
+        int64_t wa = 0, wb = 0;
+        window_bounds(ref.runs.data(), (int64_t)ref.runs.size(), ref.contigs[r.contig].gbase, ref.contigs[r.contig].len, p.window_size, step,
+                      r.window_k, wa, wb);
+        raw_to_aln(r, gh[r.guide], wa, wb, result[i]);
+      }
+    });
+    tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    tm.accepted_alignments = n_sel;
+    tm.candidate_columns = ctx->h_counters[4];
+    ctx->timing = tm;
+    if (std::getenv("CALITAS_TRACE"))
+      std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms (incl. sort+filter on the GPU), host convert %.3f ms, call %.3f ms (%u records, %u raw, %u accepted)\n",
+                   tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_sel);
+    *n_out = n_sel;
+    *out = result;
+    return CALITAS_OK;
+  }
 
   // ---- host: restore the reference's enumeration order, then the per-window filter (SGA:315-320) ----
   // Raw records arrive in atomic-append order.  They are bucketed by (guide, contig, 4096-window chunk), each bucket is

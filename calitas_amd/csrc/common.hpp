@@ -107,6 +107,7 @@ struct GuideDev {
   int32_t max_guide_diffs;      // -d for this guide
   int32_t max_pam_mismatches;   // -p
   int32_t max_diffs_filtering;  // d + g + p (SequentialGuideAligner.scala:249)
+  int32_t pam5;                 // 1 for a 5' PAM guide (the reverse-complemented pass then yields the forward-strand list)
 };
 
 struct SearchDev {        // scalar parameters of one search

@@ -10,6 +10,7 @@
 #include "parallel.hpp"
 #include "post.hpp"
 #include "refpack.hpp"
+#include "select.hpp"
 
 using namespace calitas;
 
@@ -42,6 +43,7 @@ struct calitas_ctx {
   RawAln* h_raw = nullptr;          // pinned staging for the copy-back
   uint32_t h_raw_cap = 0;
   calitas_timing_t timing{};
+  SelectWork* select = nullptr;     // GPU per-window filter scratch
   WorkerPool* pool = nullptr;
   ~calitas_ctx() { delete pool; }
 };

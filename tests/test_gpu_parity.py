@@ -177,6 +177,31 @@ def test_no_silent_truncation_on_dense_output(C, tmp_path):
     assert_same(prod, orac, "dense")
 
 
+def test_device_filter_equals_host_filter(C, tmp_path, monkeypatch):
+    """The per-window overlap filter (SGA:316-331) runs on the device by default and on the host when a window holds more
+    alignments than one lane handles, or on request; both must return the same records in the same order."""
+    guides = ["CTTGCCCCACAGGGCAGTAAnrg", "tttvAACCAACCAACCGGTTACGT"]
+    fa = synth_fasta(tmp_path, 21, guides, lengths=(80000, 30000))
+    unit = "ACGTTGCA"
+    dense = write_fasta(str(tmp_path / "dense2.fa"), [("rep", unit * 3000 + "CTTGCCCCACAGGGCAGTAATGG" + unit * 500)])
+
+    def run(path, guide, **kw):
+        ctx = C.Context(0)
+        ctx.set_reference_fasta(path)
+        al = ctx.search([C.Guide(guide)], C.make_params(**kw))
+        ctx.close()
+        return [(a.contig_index, a.window_start, a.strand, a.start_offset, a.end_offset, a.score, a.ops, a.pam_index, a.guide_start_offset, a.guide_end_offset) for a in al]
+
+    cases = [(fa, guides[0], dict(max_gaps_between_guide_and_pam=2)), (fa, guides[1], dict(max_guide_diffs=4)),
+             (dense, "ACGTTGCAACGTTGCAACGT", dict(max_guide_diffs=6, max_overlap=3))]   # > 256 alignments per window: host fallback
+    for path, guide, kw in cases:
+        monkeypatch.delenv("CALITAS_HOST_FILTER", raising=False)
+        dev = run(path, guide, **kw)
+        monkeypatch.setenv("CALITAS_HOST_FILTER", "1")
+        host = run(path, guide, **kw)
+        assert len(dev) > 0 and dev == host, guide
+
+
 def test_full_size_properties_ecoli_like(C):
     """BASELINE config 2 size (4.6 Mb): size-independent properties instead of a full oracle run --
     (1) every planted perfect site is found with 0 edits, (2) searching the reverse-complemented genome with the same
