@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--shard", choices=["guides", "contigs"], default="guides")
     ap.add_argument("--cpu-sample-mb", type=float, default=-1, help="CPU baseline sample in Mb (<0: auto, 0: skip)")
     ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
+    ap.add_argument("--two-stage", action="store_true", help="calitas_search + calitas_hits_tsv (host rows) instead of the fused calitas_search_hits")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and gloo replaces RCCL (not a measurement)")
     args = ap.parse_args()
@@ -199,26 +200,40 @@ def main():
 
     G = [C.Guide(g) for g in my_guides]
 
-    phase = {"search": 0.0, "hits": 0.0, "free": 0.0}
+    phase = {"search_hits": 0.0, "gather": 0.0, "search": 0.0, "hits": 0.0, "free": 0.0}
+
+    contig_mode = world > 1 and args.shard == "contigs"
+
+    def gather_rows(text, rows):
+        if not contig_mode:
+            return rows
+        import torch.distributed as dist
+        header, blocks = shard.split_rows_by_contig(text, ctx.contig_names)
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(blocks, gathered, dst=0, group=gloo)
+        if rank == 0:
+            # contig indices are local to each rank's shard; rows carry names, so merge by name order
+            rows = sum(len(r) for b in gathered for r in b.values())
+        return rows
 
     def step():
         tp0 = time.perf_counter()
+        if not (args.no_hits or args.two_stage):
+            # calitas_search_hits: kernels through to the finished hits.txt text, one copy-back
+            text, rows = ctx.search_hits(G[0], "bench", params, "bench", "bench", decode=contig_mode)
+            tp1 = time.perf_counter()
+            tm = ctx.timing()
+            rows = gather_rows(text, rows)
+            phase["search_hits"] += tp1 - tp0; phase["gather"] += time.perf_counter() - tp1
+            return tm, tm["accepted_alignments"], rows
         out, n = ctx.search_raw(G, params)
         tp1 = time.perf_counter()
         try:
             tm = ctx.timing()
             rows = 0
             if not args.no_hits:
-                contig_mode = world > 1 and args.shard == "contigs"
                 text, rows = ctx.hits_tsv_raw(G[0], "bench", params, out, n, "bench", "bench", decode=contig_mode)
-                if contig_mode:
-                    import torch.distributed as dist
-                    header, blocks = shard.split_rows_by_contig(text, ctx.contig_names)
-                    gathered = [None] * world if rank == 0 else None
-                    dist.gather_object(blocks, gathered, dst=0, group=gloo)
-                    if rank == 0:
-                        # contig indices are local to each rank's shard; rows carry names, so merge by name order
-                        rows = sum(len(r) for b in gathered for r in b.values())
+                rows = gather_rows(text, rows)
         finally:
             tp2 = time.perf_counter()
             C._lib.lib.calitas_free(out)
@@ -238,11 +253,12 @@ def main():
         phase[k] = 0.0
     sync()
     t0 = time.perf_counter()
-    scan_ms = align_ms = post_ms = gpu_ms = 0.0
+    scan_ms = align_ms = post_ms = gpu_ms = hitsk_ms = copy_ms = 0.0
     last = None
     for _ in range(args.steps):
         tm, n_alns, rows = step()
         scan_ms += tm["scan_kernel_ms"]; align_ms += tm["align_kernel_ms"]; post_ms += tm["host_post_ms"]; gpu_ms += tm["gpu_total_ms"]
+        hitsk_ms += tm["hits_kernel_ms"]; copy_ms += tm["hits_copy_ms"]
         last = (tm, n_alns, rows)
     sync()
     dt = time.perf_counter() - t0
@@ -268,13 +284,16 @@ def main():
             "config": {"workload": "SearchReference: 20 nt guide + NRG PAM vs synthetic hg38-sized genome (25 contigs, %d bp), "
                                    "max-guide-diffs=5 max-pam-mismatches=1 max-gaps-between-guide-and-pam=2" % sum(lengths),
                        "guide": my_guides[0], "guide_passes_per_step": guide_passes_per_step, "partition": args.shard if world > 1 else "none",
-                       "genome_scale": args.scale, "step_includes": "scan+align kernels, copy-back, per-window filter"
-                                                                      + ("" if args.no_hits else ", removeOverlaps+sort+hit rows")},
+                       "genome_scale": args.scale,
+                       "step_includes": "scan + align kernels, per-window filter" + ("" if args.no_hits else ", removeOverlaps, sort, all hits.txt rows")
+                                        + (", copy-back of alignments, host rows" if (args.two_stage or args.no_hits) else " (all on the device), copy-back of the text")},
             "bases_per_s": bases_per_step_total * K / dt,
             "hits_per_pass": rows, "accepted_alignments_per_pass": n_alns, "raw_alignments_per_pass": tm["raw_alignments"],
             "scan_records_per_pass": tm["scan_records"],
-            "host_phase_ms": {k: v / K * 1e3 for k, v in phase.items()},
-            "kernel_ms": {"scan": scan_avg_ms, "align": align_ms / K, "gpu_total": gpu_ms / K, "host_window_filter": post_ms / K},
+            "hits_bytes_per_pass": tm["hits_bytes"],
+            "host_phase_ms": {k: v / K * 1e3 for k, v in phase.items() if v > 0},
+            "kernel_ms": {"scan": scan_avg_ms, "align": align_ms / K, "search_gpu_total": gpu_ms / K, "hits_kernels": hitsk_ms / K,
+                          "text_copy": copy_ms / K, "host_convert": post_ms / K},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": tm["packed_bytes"], "avg_launch_ms": scan_avg_ms,

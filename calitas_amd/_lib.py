@@ -48,13 +48,15 @@ class TimingT(ctypes.Structure):
     _fields_ = [("scan_kernel_ms", ctypes.c_double), ("align_kernel_ms", ctypes.c_double), ("gpu_total_ms", ctypes.c_double),
                 ("host_post_ms", ctypes.c_double), ("bases_scanned", ctypes.c_uint64), ("packed_bytes", ctypes.c_uint64),
                 ("scan_records", ctypes.c_uint64), ("candidate_columns", ctypes.c_uint64), ("raw_alignments", ctypes.c_uint64),
-                ("accepted_alignments", ctypes.c_uint64), ("retries", ctypes.c_uint32)]
+                ("accepted_alignments", ctypes.c_uint64), ("retries", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("hits_kernel_ms", ctypes.c_double), ("hits_copy_ms", ctypes.c_double), ("hit_rows", ctypes.c_uint64),
+                ("hits_bytes", ctypes.c_uint64)]
 
 
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
            "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases",
-           "calitas_window_table", "calitas_search", "calitas_get_timing", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext",
+           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_get_timing", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -89,6 +91,9 @@ lib.calitas_window_filter.argtypes = [ctypes.POINTER(AlnT), ctypes.c_int32, ctyp
 lib.calitas_hits_tsv.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.c_char_p, ctypes.POINTER(ParamsT),
                                  ctypes.POINTER(AlnT), ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p,
                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+lib.calitas_search_hits.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.c_char_p, ctypes.POINTER(ParamsT), ctypes.c_char_p,
+                                    ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64),
+                                    ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_genome_build.restype = ctypes.c_char_p
 lib.calitas_genome_build.argtypes = [ctypes.c_void_p]
 lib.calitas_hits_tsv_ext.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.c_char_p, ctypes.POINTER(ParamsT), ctypes.POINTER(AlnT),

@@ -244,6 +244,18 @@ class Context:
         finally:
             lib.calitas_free(out)
 
+    def search_hits(self, guide, guide_id, params, version=None, time_stamp=None, decode=True):
+        """calitas_search_hits: one guide against the resident reference, finished hits.txt text back (tsv_text, n_rows);
+        decode=False skips the copy into a Python str and returns (n_bytes, n_rows)."""
+        g = guide.to_c()
+        tsv, nbytes, rows = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._h, lib.calitas_search_hits(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params),
+                                                    version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                                    ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(rows)))
+        text = ctypes.string_at(tsv, nbytes.value).decode() if decode else nbytes.value
+        lib.calitas_free(tsv)
+        return text, rows.value
+
     def timing(self):
         t = TimingT()
         _lib.check(self._h, lib.calitas_get_timing(self._h, ctypes.byref(t)))
@@ -298,8 +310,9 @@ class SearchReference:
                  max_overlap=Defaults.MaxOverlap, guide_mismatch_net_cost=Defaults.MismatchNetCost,
                  pam_mismatch_net_cost=Defaults.PamMismatchNetCost, genome_gap_net_cost=Defaults.GenomeGapNetCost,
                  guide_gap_net_cost=Defaults.GuideGapNetCost, chrom=None, variants=None,
-                 max_variants=Defaults.MaxVariantsInCluster, context=None, device=0, eqx_by_score=0):
+                 max_variants=Defaults.MaxVariantsInCluster, context=None, device=0, eqx_by_score=0, two_stage=False):
         self.variants = variants
+        self.two_stage = two_stage
         self.guide_str, self.guide_id, self.ref, self.output = guide, guide_id, ref, output
         self.query = Guide(guide, auxiliary_pams)  # SearchReference.scala:511: fail early on an invalid guide
         self.chrom = chrom
@@ -331,12 +344,16 @@ class SearchReference:
                 return search_reference_with_variants(self, ctx, self.variants, version, time_stamp)
             params = make_params(chrom_index=chrom_index, **self._kw)
             t0 = time.perf_counter()
-            out, n = ctx.search_raw([self.query], params)
-            try:
+            if self.two_stage:   # calitas_search, then calitas_hits_tsv on the host copy of the alignments
+                out, n = ctx.search_raw([self.query], params)
+                try:
+                    self.timing = ctx.timing()
+                    text, rows = ctx.hits_tsv_raw(self.query, self.guide_id, params, out, n, version, time_stamp)
+                finally:
+                    lib.calitas_free(out)
+            else:
+                text, rows = ctx.search_hits(self.query, self.guide_id, params, version, time_stamp)
                 self.timing = ctx.timing()
-                text, rows = ctx.hits_tsv_raw(self.query, self.guide_id, params, out, n, version, time_stamp)
-            finally:
-                lib.calitas_free(out)
             self.wall_ms = (time.perf_counter() - t0) * 1e3
             return text, rows
         finally:

@@ -137,6 +137,7 @@ void calitas_destroy(calitas_ctx* c) {
     (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
     (void)hipFree(c->d_slab);
     select_destroy(c->select);
+    hits_destroy(c->hits);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -146,6 +147,7 @@ void calitas_destroy(calitas_ctx* c) {
 }
 
 static int upload_reference(calitas_ctx* ctx) {
+  ctx->ref_serial++;
   if (ctx->device >= 0) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     free_reference_device(ctx);
@@ -379,10 +381,43 @@ int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_
   return CALITAS_OK;
 }
 
-extern "C" {
+// Accepted alignments left on the device by search_impl for calitas_search_hits.
+struct DeviceSel {
+  bool valid = false;
+  const RawAln* d_final = nullptr;
+  uint32_t n_sel = 0;
+  int step = 0;
+  std::vector<GuideHost> gh;
+  std::vector<GuideDev> gd;
+  std::chrono::steady_clock::time_point t_call;
+};
 
-int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
-                   calitas_aln_t** out, uint64_t* n_out) {
+// Copies the device-selected alignments back and converts them to GuideAlignment records (GA:21-31, SGA:260-313).
+static int convert_selected(calitas_ctx* ctx, const RawAln* d_final, uint32_t n_sel, const std::vector<GuideHost>& gh,
+                            const calitas_params_t& p, int step, calitas_aln_t** out) {
+  const PackedRef& ref = ctx->ref;
+  if (n_sel) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, d_final, (size_t)n_sel * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const RawAln* raw = ctx->h_raw;
+  calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_sel) * sizeof(calitas_aln_t));
+  if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  ctx->pool->for_blocks(n_sel, [&](size_t b, size_t e, int) {
+    for (size_t i = b; i < e; i++) {
+      const RawAln& r = raw[i];
+      int64_t wa = 0, wb = 0;
+      window_bounds(ref.runs.data(), (int64_t)ref.runs.size(), ref.contigs[r.contig].gbase, ref.contigs[r.contig].len, p.window_size, step,
+                    r.window_k, wa, wb);
+      raw_to_aln(r, gh[r.guide], wa, wb, result[i]);
+    }
+  });
+  *out = result;
+  return CALITAS_OK;
+}
+
+// calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
+// (dev->valid), and *out stays NULL.
+static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                       calitas_aln_t** out, uint64_t* n_out, DeviceSel* dev) {
   if (!ctx) return CALITAS_EINVAL;
   if (!out || !n_out || !guides || !params) return fail(ctx, CALITAS_EINVAL, "NULL argument");
   const auto t_call = std::chrono::steady_clock::now();
@@ -511,6 +546,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   for (auto& c : ref.contigs) max_wins = std::max<uint64_t>(max_wins, window_count(c.len, step));
   bool gpu_select = n_raw > 0 && !std::getenv("CALITAS_HOST_FILTER") && select_supported(ref.contigs.size(), max_wins, p.window_size, n_guides);
   uint32_t n_sel = 0;
+  const RawAln* d_sel = nullptr;
   if (gpu_select) {
     const RawAln* d_final = nullptr;
     const uint32_t* d_cnt = nullptr;
@@ -521,7 +557,7 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
     if (ctx->h_counters[6] != 0) gpu_select = false;   // a window with more alignments than one lane should chew through
     else {
       n_sel = ctx->h_counters[5];
-      if (n_sel) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, d_final, (size_t)n_sel * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+      d_sel = d_final;
     }
   }
   if (!gpu_select && n_raw) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
@@ -535,31 +571,29 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   tm.raw_alignments = n_raw;
 
   if (gpu_select) {
-    // accepted alignments arrive in final order; only the coordinate conversion (GA:21-31, SGA:260-313) is left
-    auto t0 = std::chrono::steady_clock::now();
-    calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_sel) * sizeof(calitas_aln_t));
-    if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
-    ctx->pool->for_blocks(n_sel, [&](size_t b, size_t e, int) {
-      for (size_t i = b; i < e; i++) {
-        const RawAln& r = raw[i];
-        int64_t wa = 0, wb = 0;
-        window_bounds(ref.runs.data(), (int64_t)ref.runs.size(), ref.contigs[r.contig].gbase, ref.contigs[r.contig].len, p.window_size, step,
-                      r.window_k, wa, wb);
-        raw_to_aln(r, gh[r.guide], wa, wb, result[i]);
-      }
-    });
-    tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     tm.accepted_alignments = n_sel;
     tm.candidate_columns = ctx->h_counters[4];
+    if (dev) {   // calitas_search_hits goes on from the device copy
+      dev->valid = true; dev->d_final = d_sel; dev->n_sel = n_sel; dev->step = step; dev->gh = gh; dev->gd = gd; dev->t_call = t_call;
+      ctx->timing = tm;
+      return CALITAS_OK;
+    }
+    // accepted alignments arrive in final order; only the coordinate conversion (GA:21-31, SGA:260-313) is left
+    auto t0 = std::chrono::steady_clock::now();
+    calitas_aln_t* result = nullptr;
+    int rc = convert_selected(ctx, d_sel, n_sel, gh, p, step, &result);
+    if (rc) return rc;
+    tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing = tm;
     if (std::getenv("CALITAS_TRACE"))
-      std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms (incl. sort+filter on the GPU), host convert %.3f ms, call %.3f ms (%u records, %u raw, %u accepted)\n",
+      std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms (incl. sort+filter on the GPU), copy+convert %.3f ms, call %.3f ms (%u records, %u raw, %u accepted)\n",
                    tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_sel);
     *n_out = n_sel;
     *out = result;
     return CALITAS_OK;
   }
+  if (dev) { dev->step = step; dev->gh = gh; dev->gd = gd; dev->t_call = t_call; }
 
   // ---- host: restore the reference's enumeration order, then the per-window filter (SGA:315-320) ----
   // Raw records arrive in atomic-append order.  They are bucketed by (guide, contig, 4096-window chunk), each bucket is
@@ -656,6 +690,111 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
   return CALITAS_OK;
 }
 
+static void default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp) {
+  version = aligner_version ? aligner_version : "";
+  stamp = time_stamp ? time_stamp : "";
+  if (version.empty()) {  // EditasMetric.Version without a jar manifest: unknown-YYYY-MM-DD
+    char b[32]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
+    std::strftime(b, sizeof b, "unknown-%Y-%m-%d", &tmv); version = b;
+  }
+  if (stamp.empty()) {    // RH:169-173 "EEE MMM dd HH:mm:ss z yyyy" in UTC
+    char b[64]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
+    std::strftime(b, sizeof b, "%a %b %d %H:%M:%S UTC %Y", &tmv); stamp = b;
+  }
+}
+
+extern "C" {
+
+int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                   calitas_aln_t** out, uint64_t* n_out) {
+  return search_impl(ctx, n_guides, guides, params, out, n_out, nullptr);
+}
+
+int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                        const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!guide || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *tsv = nullptr;
+  if (tsv_bytes) *tsv_bytes = 0;
+  if (n_rows) *n_rows = 0;
+  DeviceSel dev;
+  calitas_aln_t* alns = nullptr;
+  uint64_t n_alns = 0;
+  int rc = search_impl(ctx, 1, guide, params, &alns, &n_alns, &dev);
+  if (rc) return rc;
+  const calitas_params_t& p = *params;
+  const PackedRef& ref = ctx->ref;
+  const GuideHost& gh = dev.gh[0];
+  std::string version, stamp;
+  default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
+
+  if (dev.valid && !std::getenv("CALITAS_HOST_HITS")) {
+    // removeOverlaps, ReferenceHit.sort and the rows on the device (hits.hip); only text crosses PCIe
+    const Scores sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
+    int max_pam = 0;
+    for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
+    const int score_hi = sc.match * (int)gh.protospacer.size() + sc.pam_match * max_pam;
+    const int worst_gap = std::max(iabs(sc.query_gap), std::max(iabs(sc.target_gap), iabs(sc.mismatch)));
+    const int score_lo = dev.gd[0].min_guide_score - iabs(sc.pam_mismatch) * max_pam - worst_gap * (p.max_gaps_between_guide_and_pam + 1);
+    if (hits_supported(ref.contigs.size(), p.max_overlap, score_lo, score_hi)) {
+      if (ctx->hits_names_serial != ctx->ref_serial) {
+        HIP_TRY(ctx, hits_set_names(&ctx->hits, ref.names));
+        ctx->hits_names_serial = ctx->ref_serial;
+      }
+      const RowStrings rs = make_row_strings(ref, gh, guide_id ? guide_id : "", p, version, stamp);
+      HitsRef hr{ctx->d_codes, ctx->d_mask, ctx->d_runs, (int64_t)ref.runs.size(), ctx->d_contigs, (int)ref.contigs.size()};
+      HitsResult res{};
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+      HIP_TRY(ctx, hits_run(&ctx->hits, hr, dev.d_final, dev.n_sel, ctx->d_guides, ctx->d_win_base, ctx->d_win, rs, p.max_overlap, score_hi,
+                            dev.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, ctx->stream, &res));
+      if (res.flags == 0) {
+        const size_t total = rs.header.size() + (size_t)res.text_bytes;
+        char* text = (char*)out_alloc(total + 1);
+        if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
+        std::memcpy(text, rs.header.data(), rs.header.size());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        if (res.text_bytes)
+          HIP_TRY(ctx, hipMemcpyAsync(text + rs.header.size(), res.d_text, (size_t)res.text_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        text[total] = 0;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->timing.hits_kernel_ms = ms;
+        (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->timing.hits_copy_ms = ms;
+        ctx->timing.hit_rows = res.n_rows;
+        ctx->timing.hits_bytes = total;
+        if (trace)
+          std::fprintf(stderr, "[calitas] search_hits: scan %.3f ms, align %.3f ms, search gpu total %.3f ms, hits kernels %.3f ms, text copy %.3f ms, call %.3f ms (%u accepted, %u rows, %zu bytes)\n",
+                       ctx->timing.scan_kernel_ms, ctx->timing.align_kernel_ms, ctx->timing.gpu_total_ms, ctx->timing.hits_kernel_ms,
+                       ctx->timing.hits_copy_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dev.t_call).count(),
+                       dev.n_sel, res.n_rows, total);
+        *tsv = text;
+        if (tsv_bytes) *tsv_bytes = total;
+        if (n_rows) *n_rows = res.n_rows;
+        return CALITAS_OK;
+      }
+      if (trace) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
+    }
+  }
+  // host tail: the same stages as calitas_hits_tsv
+  if (dev.valid) {
+    rc = convert_selected(ctx, dev.d_final, dev.n_sel, dev.gh, p, dev.step, &alns);
+    if (rc) return rc;
+    n_alns = dev.n_sel;
+  }
+  uint64_t rows = 0;
+  char* text = hits_tsv(ref, gh, guide_id ? guide_id : "", p, alns, n_alns, version, stamp, &rows, ctx->pool, out_alloc, nullptr, 0);
+  calitas_free(alns);
+  if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  ctx->timing.hit_rows = rows;
+  ctx->timing.hits_bytes = std::strlen(text);
+  *tsv = text;
+  if (tsv_bytes) *tsv_bytes = ctx->timing.hits_bytes;
+  if (n_rows) *n_rows = rows;
+  return CALITAS_OK;
+}
+
 int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out) {
   if (!ctx || !out) return CALITAS_EINVAL;
   *out = ctx->timing;
@@ -697,16 +836,8 @@ int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, c
   GuideHost gh;
   std::string e = make_guide_host(*guide, gh);
   if (!e.empty()) return fail(c, CALITAS_EINVAL, e);
-  std::string version = aligner_version ? aligner_version : "";
-  std::string stamp = time_stamp ? time_stamp : "";
-  if (version.empty()) {  // EditasMetric.Version without a jar manifest: unknown-YYYY-MM-DD
-    char b[32]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
-    std::strftime(b, sizeof b, "unknown-%Y-%m-%d", &tmv); version = b;
-  }
-  if (stamp.empty()) {    // RH:169-173 "EEE MMM dd HH:mm:ss z yyyy" in UTC
-    char b[64]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
-    std::strftime(b, sizeof b, "%a %b %d %H:%M:%S UTC %Y", &tmv); stamp = b;
-  }
+  std::string version, stamp;
+  default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   *tsv = hits_tsv(ctx->ref, gh, guide_id ? guide_id : "", *params, alns, n_alns, version, stamp, n_rows, ctx->pool, out_alloc, ext, n_ext);
   if (!*tsv) return fail(c, CALITAS_EINVAL, "out of memory");
   return CALITAS_OK;

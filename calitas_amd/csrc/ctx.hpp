@@ -11,6 +11,7 @@
 #include "post.hpp"
 #include "refpack.hpp"
 #include "select.hpp"
+#include "hits.hpp"
 
 using namespace calitas;
 
@@ -44,6 +45,8 @@ struct calitas_ctx {
   uint32_t h_raw_cap = 0;
   calitas_timing_t timing{};
   SelectWork* select = nullptr;     // GPU per-window filter scratch
+  HitsWork* hits = nullptr;         // GPU removeOverlaps / sort / rows scratch
+  uint64_t ref_serial = 0, hits_names_serial = ~0ull;
   WorkerPool* pool = nullptr;
   ~calitas_ctx() { delete pool; }
 };

@@ -1,0 +1,552 @@
+// hits.hip -- the tail of SearchReference.execute for the reference-genome branch, on the device: removeOverlaps
+// (SearchReference.scala:653-675), ReferenceHit.sort (ReferenceHit.scala:284) and the 34-column hits.txt rows
+// (ReferenceHit.scala:210-254), so that only finished text crosses PCIe.  SGA = SequentialGuideAligner.scala,
+// GA = GuideAlignment.scala, RH = ReferenceHit.scala, SR = SearchReference.scala.
+//
+// Input: the accepted alignments of one guide, in calitas_search order, still on the device (select.hip's output).
+//   1. hit_kernel      GuideAlignment coordinates (GA:21-31, SGA:260-313) and ReferenceHit.end (RH:135-138) per alignment;
+//                      sort key A = (contig, strand, coordinate_start, -score): the order removeOverlaps sorts each
+//                      (chromosome, strand) group in (RH:284 inside one group); arrival order breaks ties (stable sort).
+//   2. rocPRIM radix sort, then a running maximum of `end` per group (inclusive scan with max over (group, end)).
+//   3. cluster_kernel  removeOverlaps walks a group left to right carrying one "current hit".  Wherever a hit starts at or
+//                      beyond (max end so far - maxOverlap + 1) no earlier hit can overlap it by >= maxOverlap, the walk
+//                      keeps its current hit and restarts there with a clean state.  Those restart points cut the group
+//                      into clusters that are independent of each other; one lane walks one cluster (usually 1-3 hits).
+//   4. sort key B = (contig, coordinate_start, strand, -score) for kept hits (RH:284; ties can only meet inside one group,
+//                      where order A already is the reference's order), ~0 for dropped ones; stable radix sort.
+//   5. row_kernel      twice: once counting bytes, once writing at the exclusive-scanned offsets.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/calitas_hip.h"
+#include "common.hpp"
+#include "hits.hpp"
+#include "refpack.hpp"
+
+namespace calitas {
+
+namespace {
+
+constexpr int SCORE_BITS = 14;
+constexpr uint32_t CLUSTER_MAX = 1u << 14;
+constexpr uint64_t DROPPED = ~0ull;
+
+struct HitRec {
+  int32_t contig, start, end, gstart, gend, score, rh_end;
+  uint32_t minus;
+};
+
+struct RowConstDev {
+  uint32_t head_off, head_len, tail_off, tail_len, plen_off, plen_len;
+  uint32_t q_off[MAX_PAMS + 1], q_len[MAX_PAMS + 1], pu_off[MAX_PAMS + 1], pu_len[MAX_PAMS + 1];
+};
+
+__device__ __forceinline__ int raw_op(const RawAln& r, int i) { return (r.ops[i >> 2] >> ((i & 3) * 2)) & 3; }  // 0 = 1 X 2 I 3 D
+
+__global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
+                           int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const RawAln r = fin[i];
+  const GuideDev& g = guides[r.guide];
+  const int ng = r.n_ops;
+  int pam_len = 0, gap = 0;
+  if (r.pam >= 0) { pam_len = g.pam_len[r.pam]; gap = r.offset; }
+  // aligner-order op k is raw_op(ng - 1 - k).  Everything left of the first / right of the last protospacer column is 'D'
+  // (GA:21-31 with the '+' rule in aligner space, SGA:264,281,297,302).
+  int lead = 0, trail = 0, t_guide = 0;
+  for (int k = ng - 1; k >= 0 && raw_op(r, k) == 3; k--) lead++;
+  for (int k = 0; k < ng && raw_op(r, k) == 3; k++) trail++;
+  if (lead == ng) { lead = 0; trail = ng; }            // no protospacer column at all: cannot happen, kept total
+  for (int k = 0; k < ng; k++) t_guide += raw_op(r, k) != 2;
+  const int left_delta = lead, right_delta = trail + gap + pam_len;
+  const int tlen = t_guide + gap + pam_len;
+  const int start_s = (int)r.t_start - 1, end_s = (int)r.t_end_guide + r.offset + pam_len;   // SGA:515-516
+  const int gstart_s = start_s + left_delta, gend_s = end_s - right_delta;
+  const int2 w = win[win_base[r.contig] + r.window_k];
+  HitRec h;
+  h.contig = (int32_t)r.contig; h.score = r.score;
+  if (r.dir == 0) { h.start = w.x + start_s; h.end = w.x + end_s; h.gstart = w.x + gstart_s; h.gend = w.x + gend_s; }   // SGA:297, 281
+  else            { h.start = w.y - end_s; h.end = w.y - start_s; h.gstart = w.y - gend_s; h.gend = w.y - gstart_s; }   // SGA:303-309, 271-274
+  const bool plus = g.pam5 ? (r.dir == 1) : (r.dir == 0);
+  h.minus = plus ? 0u : 1u;
+  h.rh_end = h.gstart + tlen - 1;                      // RH:135-138
+  hits[i] = h;
+  int sb = score_hi - r.score;
+  if (sb < 0 || sb >= (1 << SCORE_BITS) || h.gstart < 0) { atomicOr(flags, HITS_FLAG_SCORE_RANGE); sb = 0; }
+  keys[i] = ((uint64_t)r.contig << 46) | ((uint64_t)h.minus << 45) | ((uint64_t)(uint32_t)h.gstart << 14) | (uint64_t)sb;
+  vals[i] = i;
+}
+
+__global__ void sorted_kernel(const HitRec* hits, const uint64_t* keys, const uint32_t* vals, uint32_t n, int32_t* s_start,
+                              int32_t* s_end, int32_t* s_score, uint64_t* ge) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const HitRec h = hits[vals[i]];
+  s_start[i] = h.gstart; s_end[i] = h.rh_end; s_score[i] = h.score;
+  ge[i] = ((keys[i] >> 45) << 32) | (uint64_t)(uint32_t)h.rh_end;
+}
+
+struct MaxU64 {
+  __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; }
+};
+
+__device__ __forceinline__ bool cluster_head(const uint64_t* keys, const uint64_t* rm, const int32_t* s_start, uint32_t j, int max_overlap) {
+  if (j == 0) return true;
+  const uint64_t prev = rm[j - 1];
+  if ((prev >> 32) != (keys[j] >> 45)) return true;
+  return (int)(uint32_t)prev - s_start[j] < max_overlap;
+}
+
+__global__ void cluster_kernel(const uint64_t* keys, const uint64_t* rm, const int32_t* s_start, const int32_t* s_end,
+                               const int32_t* s_score, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !cluster_head(keys, rm, s_start, i, max_overlap)) return;
+  uint32_t j = i, steps = 0;
+  for (;;) {                                            // SR:661-671
+    const uint32_t hit = j++;
+    const int hs = s_start[hit], he = s_end[hit], hsc = s_score[hit];
+    bool more = false;
+    int ov = 0;
+    for (;;) {
+      more = j < n && !cluster_head(keys, rm, s_start, j, max_overlap);
+      if (!more) break;
+      ov = max(0, min(s_end[j], he) - max(s_start[j], hs));   // RH:141-144
+      if (!(ov >= max_overlap && s_score[j] <= hsc)) break;
+      j++;
+      if (++steps > CLUSTER_MAX) break;
+    }
+    if (steps > CLUSTER_MAX) { atomicOr(flags, HITS_FLAG_CLUSTER); return; }
+    if (!more || ov < max_overlap) keep[hit] = 1;
+    if (!more) return;
+    if (++steps > CLUSTER_MAX) { atomicOr(flags, HITS_FLAG_CLUSTER); return; }
+  }
+}
+
+__global__ void keyb_kernel(const HitRec* hits, const uint64_t* keys_a, const uint32_t* vals_a, const uint8_t* keep, uint32_t n,
+                            uint64_t* keys_b, uint32_t* vals_b, uint32_t* n_kept) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool k = false;
+  if (i < n) {
+    k = keep[i] != 0;
+    const uint32_t v = vals_a[i];
+    const HitRec h = hits[v];
+    const uint64_t sb = keys_a[i] & ((1u << SCORE_BITS) - 1);
+    keys_b[i] = k ? (((uint64_t)(uint32_t)h.contig << 46) | ((uint64_t)(uint32_t)h.gstart << 15) | ((uint64_t)h.minus << 14) | sb) : DROPPED;
+    vals_b[i] = v;
+  }
+  const unsigned long long b = __ballot(k);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_kept, (uint32_t)__popcll(b));
+}
+
+// ---- rows ------------------------------------------------------------------------------------------------------------
+// A row is  head | chromosome \t | middle | tail  where head and tail are the same for every row of the call.
+//   mid_kernel: one lane per row builds the middle part in its own LDS slot (byte writes, slot stride an odd number of
+//               words so the 64 lanes hit 64 banks); the wave then copies the slots to a fixed-stride staging buffer with
+//               coalesced dword stores and records the row length.
+//   out_kernel: after the exclusive scan of the lengths, a wave assembles row after row at its final offset with
+//               coalesced byte stores (head / tail come from LDS).
+// Working arrays (ops, padded strings, the fetched reference span) live in the lane's LDS slot behind the output area,
+// never in private memory.
+
+__device__ __forceinline__ char comp_base(char c) {   // fgbio Sequences.complement on an upper-case base
+  switch (c) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'U': return 'A';
+    case 'M': return 'K'; case 'K': return 'M'; case 'R': return 'Y'; case 'Y': return 'R';
+    case 'V': return 'B'; case 'B': return 'V'; case 'H': return 'D'; case 'D': return 'H';
+    default: return c;
+  }
+}
+
+__device__ char base_upper_dev(const HitsRef& ref, uint64_t gpos) {
+  if ((ref.mask[gpos >> 5] >> (gpos & 31)) & 1u) {
+    const int64_t r = run_floor(ref.runs, ref.n_runs, gpos);
+    uint8_t ch = 0;
+    if (r >= 0 && gpos < ref.runs[r].start + ref.runs[r].len) ch = ref.runs[r].ch;
+    if (ch == 0) return 'N';
+    return (char)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);
+  }
+  return "ACGT"[(ref.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u];
+}
+
+__device__ __forceinline__ uint8_t* put_int(uint8_t* w, int v) {
+  if (v < 0) { *w++ = '-'; v = -v; }
+  unsigned u = (unsigned)v;
+  int nd = 1;
+  for (unsigned t = u; t >= 10; t /= 10) nd++;
+  for (int i = nd - 1; i >= 0; i--) { w[i] = (uint8_t)('0' + u % 10); u /= 10; }
+  return w + nd;
+}
+
+// Bases [from, to) of a forward-strand buffer that starts at contig offset lo, in guide orientation.
+__device__ __forceinline__ uint8_t* put_bases(uint8_t* w, const uint8_t* fwd, int lo, int from, int to, bool minus) {
+  if (!minus) { for (int p = from; p < to; p++) *w++ = fwd[p - lo]; }
+  else        { for (int p = to - 1; p >= from; p--) *w++ = (uint8_t)comp_base((char)fwd[p - lo]); }
+  return w;
+}
+
+__device__ __forceinline__ bool is_lower(char c) { return c >= 'a' && c <= 'z'; }
+__device__ __forceinline__ bool is_letter(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+// GuideAlignment.count (GA:139-163)
+__device__ int ga_count(const uint8_t* pg, const uint8_t* pa, int len, bool lower, bool both_sides, bool mms, bool gaps) {
+  int n = 0;
+  for (int i = 0; i < len; i++) {
+    if (mms && pa[i] == '.' && is_lower((char)pg[i]) == lower) { n++; continue; }
+    if (!(gaps && pa[i] == '~')) continue;
+    const char gb = (char)pg[i];
+    bool me = gb != '-' && is_lower(gb) == lower;
+    if (!me) {
+      int pi = i; while (pi > 0 && pg[pi] == '-') pi--;            // previousNonDash GA:168-172
+      int ni = i; while (ni < len - 1 && pg[ni] == '-') ni++;      // nextNonDash GA:177-182
+      const char prev = (char)pg[pi], next = (char)pg[ni];
+      if (both_sides) me = (prev == '-' || is_lower(prev) == lower) && (next == '-' || is_lower(next) == lower);
+      else me = (is_letter(prev) && is_lower(prev) == lower) || (is_letter(next) && is_lower(next) == lower);
+    }
+    if (me) n++;
+  }
+  return n;
+}
+
+struct MidArgs {
+  HitsRef ref;
+  RowConstDev rc;
+  const char* blob;
+  const uint32_t* name_off;
+  const RawAln* fin;
+  const HitRec* hits;
+  const GuideDev* guides;
+  const uint64_t* keys_b;    // sorted
+  const uint32_t* order;     // sorted values: index into fin / hits
+  uint32_t n;
+  uint32_t slot_bytes;       // LDS bytes per lane: multiple of 4, odd number of words
+  uint32_t mid_bound;        // bytes reserved for the middle part = staging stride
+  uint32_t n_max;            // most padded columns a row of this search can have
+};
+
+// The middle part of one hits.txt row (RH:210-254, columns coordinate_start .. unpadded_target_sequence_length) at `out`;
+// `scratch` holds 4 * n_max + n_max + 24 bytes.  Returns its length, or -1 when the alignment has more columns than n_max.
+__device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, const RawAln& r, const HitRec& h, const GuideDev& g) {
+  uint8_t* ops = scratch;
+  uint8_t* pg = ops + a.n_max;
+  uint8_t* pa = pg + a.n_max;
+  uint8_t* pt = pa + a.n_max;
+  uint8_t* fwd = pt + a.n_max;
+  const int pam_len = r.pam >= 0 ? g.pam_len[r.pam] : 0, gap = r.pam >= 0 ? r.offset : 0;
+  const int ng = r.n_ops, n = ng + gap + pam_len;
+  if (n > (int)a.n_max) return -1;
+  // ops in guide orientation: guide part (stored in traceback order), gap to the PAM, PAM (SGA:472-476); reversed for a
+  // 5' PAM (SGA:267-269)
+  for (int i = 0; i < n; i++) {
+    const int k = g.pam5 ? n - 1 - i : i;
+    char op;
+    if (k < ng) op = "=XID"[raw_op(r, ng - 1 - k)];
+    else if (k < ng + gap) op = 'D';
+    else op = ((r.pam_x >> (k - ng - gap)) & 1) ? 'X' : '=';
+    ops[i] = (uint8_t)op;
+  }
+  const bool minus = h.minus != 0;
+  const char* q = a.blob + a.rc.q_off[r.pam + 1];
+  // one fetch covers the alignment and all four flanks (RH:213-216)
+  const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
+  {
+    const ContigInfo c = a.ref.contigs[h.contig];
+    for (int p = lo; p < hi; p++) fwd[p - lo] = (uint8_t)((p >= 0 && (uint64_t)p < c.len) ? base_upper_dev(a.ref, c.gbase + (uint64_t)p) : 'N');   // RH:262-264
+  }
+  int qi = 0, mm = 0, gp = 0, ps = -1, pe = -1;
+  int tp = minus ? h.end - 1 : h.start;                 // next target base, walking in guide orientation
+  for (int i = 0; i < n; i++) {                         // Alignment.paddedString (SGA:511)
+    const char op = (char)ops[i];
+    char tb = '-', qc = '-';
+    if (op != 'I') { tb = (char)fwd[tp - lo]; if (minus) { tb = comp_base(tb); tp--; } else tp++; }
+    if (op != 'D') qc = q[qi++];
+    pg[i] = (uint8_t)qc; pt[i] = (uint8_t)tb;
+    pa[i] = (uint8_t)(op == '=' ? '|' : op == 'X' ? '.' : '~');
+    mm += op == 'X'; gp += (op == 'I' || op == 'D');
+    if (qc >= 'A' && qc <= 'Z') { if (ps < 0) ps = i; pe = i; }   // unpaddedTargetWithoutPam GA:111-115
+  }
+  uint8_t* w = out;
+  w = put_int(w, h.gstart); *w++ = '\t';
+  w = put_int(w, h.gend); *w++ = '\t';
+  *w++ = minus ? '-' : '+'; *w++ = '\t';
+  int utn = 0;
+  for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') { *w++ = pt[i]; utn++; }
+  *w++ = '\t';
+  const int gs = h.gstart, ge = h.gend, as = h.start, ae = h.end;
+  if (!minus) { w = put_bases(w, fwd, lo, gs - 10, gs, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ge, ge + 10, false); }   // RH:227-228
+  else        { w = put_bases(w, fwd, lo, ge, ge + 10, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, gs - 10, gs, true); }
+  *w++ = '\t';
+  { const char* pu = a.blob + a.rc.pu_off[r.pam + 1]; const int l = (int)a.rc.pu_len[r.pam + 1]; for (int i = 0; i < l; i++) *w++ = (uint8_t)pu[i]; }
+  *w++ = '\t';
+  *w++ = '\t'; *w++ = '\t'; *w++ = '\t'; *w++ = '\t';   // variant_id, variant_description, variant_vcf, allele_frequency: None
+  w = put_int(w, h.score); *w++ = '\t';
+  const int gmm = ga_count(pg, pa, n, false, false, true, false);    // guide_mm GA:103
+  const int ggp = ga_count(pg, pa, n, false, false, false, true);    // guide_gaps GA:104
+  w = put_int(w, gmm); *w++ = '\t';
+  w = put_int(w, ggp); *w++ = '\t';
+  w = put_int(w, gmm + ggp); *w++ = '\t';               // guide_mm_plus_gaps GA:105
+  w = put_int(w, ga_count(pg, pa, n, true, true, true, false)); *w++ = '\t';   // pam_mm GA:106
+  w = put_int(w, mm + gp); *w++ = '\t';                 // total_mm_plus_gaps = edits GA:101
+  for (int i = 0; i < n; i++) *w++ = pg[i];
+  *w++ = '\t';
+  for (int i = 0; i < n; i++) *w++ = pa[i];
+  *w++ = '\t';
+  for (int i = 0; i < n; i++) *w++ = pt[i];
+  *w++ = '\t';
+  if (!minus) { w = put_bases(w, fwd, lo, as - 8, as, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ae, ae + 8, false); }     // RH:243-244
+  else        { w = put_bases(w, fwd, lo, ae, ae + 8, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, as - 8, as, true); }
+  *w++ = '\t';
+  for (int i = 0; i < n;) {                             // Cigar.coalesce + toString
+    int j = i;
+    while (j < n && ops[j] == ops[i]) j++;
+    w = put_int(w, j - i); *w++ = ops[i]; i = j;
+  }
+  *w++ = '\t';
+  w = put_int(w, g.L); *w++ = '\t';                     // unpadded_guide_sequence_length
+  w = put_int(w, utn); *w++ = '\t';
+  return (int)(w - out);
+}
+
+__global__ __launch_bounds__(64) void mid_kernel(MidArgs a, uint8_t* stage, uint32_t* midlen, uint64_t* lens, uint32_t* flags) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64, k = row0 + lane;
+  int len = 0;
+  uint32_t name_len = 0;
+  const bool live = k < a.n && a.keys_b[k] != DROPPED;
+  if (live) {
+    const uint32_t v = a.order[k];
+    const RawAln& r = a.fin[v];
+    const HitRec h = a.hits[v];
+    uint8_t* out = lds + lane * a.slot_bytes;
+    len = format_middle(out, out + a.mid_bound, a, r, h, a.guides[r.guide]);
+    if (len < 0 || len > (int)a.mid_bound) { atomicOr(flags, HITS_FLAG_ROW); len = 0; }
+    name_len = a.name_off[h.contig + 1] - a.name_off[h.contig];
+  }
+  if (k < a.n) {
+    midlen[k] = (uint32_t)len;
+    lens[k] = live ? (uint64_t)(a.rc.head_len + name_len + 1 + (uint32_t)len + a.rc.tail_len) : 0;
+  }
+  __syncthreads();
+  for (int r = 0; r < 64; r++) {
+    const int l = __shfl(len, r);
+    const uint32_t* src = (const uint32_t*)(lds + r * a.slot_bytes);
+    uint32_t* dst = (uint32_t*)(stage + (size_t)(row0 + r) * a.mid_bound);
+    for (int wd = lane; wd < (l + 3) / 4; wd += 64) dst[wd] = src[wd];
+  }
+}
+
+struct OutArgs {
+  RowConstDev rc;
+  const char* blob;
+  const char* names;
+  const uint32_t* name_off;
+  const HitRec* hits;
+  const uint32_t* order;
+  const uint32_t* midlen;
+  const uint64_t* offs;
+  const uint8_t* stage;
+  uint32_t n_rows, mid_bound;
+};
+
+constexpr int OUT_ROWS_PER_WAVE = 8;
+
+__global__ __launch_bounds__(256) void out_kernel(OutArgs a, char* text) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // head | tail
+  for (uint32_t i = threadIdx.x; i < a.rc.head_len; i += 256) lds[i] = (uint8_t)a.blob[a.rc.head_off + i];
+  for (uint32_t i = threadIdx.x; i < a.rc.tail_len; i += 256) lds[a.rc.head_len + i] = (uint8_t)a.blob[a.rc.tail_off + i];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint8_t* head = lds;
+  const uint8_t* tail = lds + a.rc.head_len;
+  for (int rr = 0; rr < OUT_ROWS_PER_WAVE; rr++) {
+    const uint32_t k = wave * OUT_ROWS_PER_WAVE + rr;
+    if (k >= a.n_rows) return;
+    const uint32_t contig = (uint32_t)a.hits[a.order[k]].contig;
+    const uint32_t nb = a.name_off[contig], nl = a.name_off[contig + 1] - nb;
+    const uint32_t s0 = a.rc.head_len, s1 = s0 + nl + 1, s2 = s1 + a.midlen[k], total = s2 + a.rc.tail_len;
+    const uint8_t* mid = a.stage + (size_t)k * a.mid_bound;
+    char* dst = text + a.offs[k];
+    for (uint32_t b = lane; b < total; b += 64) {
+      uint8_t c;
+      if (b < s0) c = head[b];
+      else if (b < s1) c = (b - s0 < nl) ? (uint8_t)a.names[nb + b - s0] : (uint8_t)'\t';
+      else if (b < s2) c = mid[b - s1];
+      else c = tail[b - s2];
+      dst[b] = (char)c;
+    }
+  }
+}
+
+__global__ void total_kernel(const uint64_t* offs, const uint64_t* lens, uint32_t n, uint64_t* total) { *total = offs[n - 1] + lens[n - 1]; }
+
+template <typename T>
+hipError_t grow(T** p, size_t& cap, size_t need) {
+  if (need <= cap) return hipSuccess;
+  (void)hipFree(*p); *p = nullptr; cap = 0;
+  need += need / 4;
+  hipError_t e = hipMalloc((void**)p, need * sizeof(T));
+  if (e == hipSuccess) cap = need;
+  return e;
+}
+
+}  // namespace
+
+struct HitsWork {
+  HitRec* hits = nullptr; size_t hits_cap = 0;
+  uint64_t *keys = nullptr, *keys2 = nullptr, *ge = nullptr, *rm = nullptr, *lens = nullptr, *offs = nullptr;
+  size_t keys_cap = 0, keys2_cap = 0, ge_cap = 0, rm_cap = 0, lens_cap = 0, offs_cap = 0;
+  uint32_t *vals = nullptr, *vals2 = nullptr; size_t vals_cap = 0, vals2_cap = 0;
+  int32_t *s_start = nullptr, *s_end = nullptr, *s_score = nullptr; size_t ss_cap = 0, se_cap = 0, sc_cap = 0;
+  uint8_t* keep = nullptr; size_t keep_cap = 0;
+  void* temp = nullptr; size_t temp_cap = 0;
+  char* text = nullptr; size_t text_cap = 0;
+  uint8_t* stage = nullptr; size_t stage_cap = 0;
+  uint32_t* midlen = nullptr; size_t midlen_cap = 0;
+  char* blob = nullptr; size_t blob_cap = 0;
+  char* names = nullptr; size_t names_cap = 0;
+  uint32_t* name_off = nullptr; size_t name_off_cap = 0;
+  uint64_t* d_counts = nullptr;   // [0] text bytes, [1] low word: kept rows, [2] low word: flags
+  uint64_t* h_counts = nullptr;   // pinned
+};
+
+void hits_destroy(HitsWork* w) {
+  if (!w) return;
+  (void)hipFree(w->hits); (void)hipFree(w->keys); (void)hipFree(w->keys2); (void)hipFree(w->ge); (void)hipFree(w->rm);
+  (void)hipFree(w->lens); (void)hipFree(w->offs); (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_start);
+  (void)hipFree(w->s_end); (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->temp); (void)hipFree(w->text); (void)hipFree(w->stage); (void)hipFree(w->midlen);
+  (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off); (void)hipFree(w->d_counts);
+  if (w->h_counts) (void)hipHostFree(w->h_counts);
+  delete w;
+}
+
+bool hits_supported(uint64_t n_contigs, int max_overlap, int score_lo, int score_hi) {
+  return n_contigs < (1ull << 18) - 1 && max_overlap >= 1 && score_hi >= score_lo && (int64_t)score_hi - score_lo < (1 << SCORE_BITS);
+}
+
+#define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+
+hipError_t hits_set_names(HitsWork** pw, const std::vector<std::string>& names) {
+  if (!*pw) *pw = new HitsWork();
+  HitsWork& w = **pw;
+  hipError_t e;
+  std::string blob;
+  std::vector<uint32_t> off(names.size() + 1, 0);
+  for (size_t i = 0; i < names.size(); i++) { blob += names[i]; off[i + 1] = (uint32_t)blob.size(); }
+  TRY(grow(&w.names, w.names_cap, std::max<size_t>(1, blob.size())));
+  TRY(grow(&w.name_off, w.name_off_cap, off.size()));
+  if (!blob.empty()) TRY(hipMemcpy(w.names, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  TRY(hipMemcpy(w.name_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return hipSuccess;
+}
+
+hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, uint32_t n_in, const GuideDev* d_guides,
+                    const uint64_t* d_win_base, const int2* d_win, const RowStrings& st, int max_overlap, int score_hi,
+                    int max_ops, hipStream_t stream, HitsResult* res) {
+  if (!*pw) *pw = new HitsWork();
+  HitsWork& w = **pw;
+  hipError_t e;
+  *res = HitsResult{};
+  const size_t n = n_in;
+  if (n == 0) return hipSuccess;
+  if (!w.d_counts) TRY(hipMalloc((void**)&w.d_counts, 3 * sizeof(uint64_t)));
+  if (!w.h_counts) TRY(hipHostMalloc((void**)&w.h_counts, 3 * sizeof(uint64_t), hipHostMallocDefault));
+  TRY(hipMemsetAsync(w.d_counts, 0, 3 * sizeof(uint64_t), stream));
+  uint32_t* d_kept = (uint32_t*)(w.d_counts + 1);
+  uint32_t* d_flags = (uint32_t*)(w.d_counts + 2);
+
+  // constant row pieces
+  RowConstDev rc{};
+  std::string blob;
+  auto add = [&](const std::string& s, uint32_t& off, uint32_t& len) { off = (uint32_t)blob.size(); len = (uint32_t)s.size(); blob += s; };
+  add(st.head, rc.head_off, rc.head_len); add(st.tail, rc.tail_off, rc.tail_len); add(st.proto_len, rc.plen_off, rc.plen_len);
+  for (size_t i = 0; i < st.query.size() && i <= (size_t)MAX_PAMS; i++) {
+    add(st.query[i], rc.q_off[i], rc.q_len[i]);
+    add(st.pam_used[i], rc.pu_off[i], rc.pu_len[i]);
+  }
+  TRY(grow(&w.blob, w.blob_cap, blob.size() + 1));
+  TRY(hipMemcpyAsync(w.blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));   // blob outlives the sync below
+
+  TRY(grow(&w.hits, w.hits_cap, n)); TRY(grow(&w.keys, w.keys_cap, n)); TRY(grow(&w.keys2, w.keys2_cap, n));
+  TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n)); TRY(grow(&w.ge, w.ge_cap, n)); TRY(grow(&w.rm, w.rm_cap, n));
+  TRY(grow(&w.lens, w.lens_cap, n)); TRY(grow(&w.offs, w.offs_cap, n)); TRY(grow(&w.s_start, w.ss_cap, n));
+  TRY(grow(&w.s_end, w.se_cap, n)); TRY(grow(&w.s_score, w.sc_cap, n)); TRY(grow(&w.keep, w.keep_cap, n));
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  TRY(rocprim::radix_sort_pairs(nullptr, t1, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
+  TRY(rocprim::inclusive_scan(nullptr, t2, w.ge, w.rm, n, MaxU64(), stream));
+  TRY(rocprim::exclusive_scan(nullptr, t3, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
+  {
+    const size_t need = std::max(t1, std::max(t2, t3));
+    if (need > w.temp_cap) { (void)hipFree(w.temp); w.temp = nullptr; w.temp_cap = 0; TRY(hipMalloc(&w.temp, need)); w.temp_cap = need; }
+  }
+  const dim3 block(256), grid((unsigned)((n + 255) / 256));
+  size_t ts;
+  // 1-2: coordinates, order A, running maximum of `end`
+  hipLaunchKernelGGL(hit_kernel, grid, block, 0, stream, d_final, n_in, d_guides, d_win_base, d_win, score_hi, w.hits, w.keys, w.vals, d_flags);
+  ts = w.temp_cap;
+  TRY(rocprim::radix_sort_pairs(w.temp, ts, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
+  hipLaunchKernelGGL(sorted_kernel, grid, block, 0, stream, (const HitRec*)w.hits, (const uint64_t*)w.keys2, (const uint32_t*)w.vals2, n_in,
+                     w.s_start, w.s_end, w.s_score, w.ge);
+  ts = w.temp_cap;
+  TRY(rocprim::inclusive_scan(w.temp, ts, w.ge, w.rm, n, MaxU64(), stream));
+  // 3: removeOverlaps
+  TRY(hipMemsetAsync(w.keep, 0, n, stream));
+  hipLaunchKernelGGL(cluster_kernel, grid, block, 0, stream, (const uint64_t*)w.keys2, (const uint64_t*)w.rm, (const int32_t*)w.s_start,
+                     (const int32_t*)w.s_end, (const int32_t*)w.s_score, n_in, max_overlap, w.keep, d_flags);
+  // 4: final order (keys / vals are free again)
+  hipLaunchKernelGGL(keyb_kernel, grid, block, 0, stream, (const HitRec*)w.hits, (const uint64_t*)w.keys2, (const uint32_t*)w.vals2,
+                     (const uint8_t*)w.keep, n_in, w.keys, w.vals, d_kept);
+  ts = w.temp_cap;
+  TRY(rocprim::radix_sort_pairs(w.temp, ts, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
+  // 5: rows
+  const uint32_t n_max = (uint32_t)std::min<int>(CALITAS_MAX_OPS, std::max(1, max_ops));
+  const uint32_t mid_bound = (6 * n_max + 128 + 3) & ~3u;
+  uint32_t slot = mid_bound + ((5 * n_max + 24 + 3) & ~3u);
+  if (((slot / 4) & 1) == 0) slot += 4;
+  if (64 * slot > 64 * 1024) {   // beyond the default dynamic LDS limit: ask for more (160 KB per CU on gfx950) or decline
+    if (64 * slot > 160 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * slot)) != hipSuccess) {
+      (void)hipGetLastError();
+      TRY(hipStreamSynchronize(stream));
+      res->flags = HITS_FLAG_ROW;
+      return hipSuccess;
+    }
+  }
+  const size_t n_pad = (n + 63) / 64 * 64;
+  TRY(grow(&w.stage, w.stage_cap, n_pad * mid_bound));
+  TRY(grow(&w.midlen, w.midlen_cap, n_pad));
+  MidArgs ma{};
+  ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
+  ma.keys_b = w.keys2; ma.order = w.vals2; ma.n = n_in; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max;
+  hipLaunchKernelGGL(mid_kernel, dim3((unsigned)(n_pad / 64)), dim3(64), 64 * slot, stream, ma, w.stage, w.midlen, w.lens, d_flags);
+  ts = w.temp_cap;
+  TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
+  hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts);
+  TRY(hipMemcpyAsync(w.h_counts, w.d_counts, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  TRY(hipStreamSynchronize(stream));
+  TRY(hipGetLastError());
+  res->flags = (uint32_t)w.h_counts[2];
+  if (res->flags) return hipSuccess;
+  res->n_rows = (uint32_t)w.h_counts[1];
+  res->text_bytes = w.h_counts[0];
+  TRY(grow(&w.text, w.text_cap, std::max<size_t>(1, (size_t)res->text_bytes)));
+  if (res->n_rows) {
+    OutArgs oa{};
+    oa.rc = rc; oa.blob = w.blob; oa.names = w.names; oa.name_off = w.name_off; oa.hits = w.hits; oa.order = w.vals2; oa.midlen = w.midlen;
+    oa.offs = w.offs; oa.stage = w.stage; oa.n_rows = res->n_rows; oa.mid_bound = mid_bound;
+    const unsigned rows_per_block = 4 * OUT_ROWS_PER_WAVE;
+    hipLaunchKernelGGL(out_kernel, dim3((res->n_rows + rows_per_block - 1) / rows_per_block), dim3(256), rc.head_len + rc.tail_len, stream, oa, w.text);
+  }
+  TRY(hipGetLastError());
+  res->d_text = w.text;
+  return hipSuccess;
+}
+
+#undef TRY
+
+}  // namespace calitas

@@ -1,0 +1,53 @@
+// hits.hpp -- device implementation of SearchReference's tail for the reference-genome branch: removeOverlaps
+// (SearchReference.scala:653-675), ReferenceHit.sort (ReferenceHit.scala:284) and the 34-column rows (ReferenceHit.scala:210-254).
+// See hits.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "post.hpp"
+
+namespace calitas {
+
+struct HitsWork;   // device scratch, grown on demand and reused
+
+struct HitsRef {   // the resident reference
+  const uint32_t* codes;
+  const uint32_t* mask;
+  const Run* runs;
+  int64_t n_runs;
+  const ContigInfo* contigs;
+  int n_contigs;
+};
+
+struct HitsResult {
+  uint32_t flags;        // != 0: the device path declined (see HITS_FLAG_*); nothing else is valid
+  uint32_t n_rows;
+  uint64_t text_bytes;   // bytes of row text at d_text
+  const char* d_text;
+};
+
+constexpr uint32_t HITS_FLAG_SCORE_RANGE = 1;   // a score fell outside the sort key's range
+constexpr uint32_t HITS_FLAG_CLUSTER = 2;       // an overlap cluster is longer than one lane should walk
+
+constexpr uint32_t HITS_FLAG_ROW = 4;           // a row has more padded columns than max_ops allows
+
+// Whether the sort keys can represent this search at all.
+bool hits_supported(uint64_t n_contigs, int max_overlap, int score_lo, int score_hi);
+
+// Contig names for the chromosome column; call again after the reference changes.
+hipError_t hits_set_names(HitsWork** work, const std::vector<std::string>& names);
+
+// d_final[0..n): accepted alignments of ONE guide in calitas_search order (device memory).  Stream-ordered except for one
+// synchronisation to learn the text size.  max_ops bounds the padded columns of any alignment of this search (it sizes the
+// per-row LDS slots).  On success the rows are at res->d_text in final order.
+hipError_t hits_run(HitsWork** work, const HitsRef& ref, const RawAln* d_final, uint32_t n, const GuideDev* d_guides,
+                    const uint64_t* d_win_base, const int2* d_win, const RowStrings& strings, int max_overlap, int score_hi,
+                    int max_ops, hipStream_t stream, HitsResult* res);
+void hits_destroy(HitsWork* work);
+
+}  // namespace calitas

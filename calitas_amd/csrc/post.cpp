@@ -251,14 +251,27 @@ static int ga_count_raw(const char* pg, const char* pa, int len, bool lower, boo
   return n;
 }
 
-// Per-guide strings shared by all rows.
-struct RowConst {
-  std::string head;        // guide_id \t protospacer \t genome_build \t
-  std::string tail;        // aligner \t version \t search_pam \t args \t time_stamp \n
-  std::vector<std::string> query;     // per PAM index (+1): query in guide orientation
-  std::vector<std::string> pam_used;  // lower-case part of the query (RH:229)
-  std::string proto_len;
-};
+
+RowStrings make_row_strings(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
+                            const std::string& version, const std::string& time_stamp) {
+  const int max_total = p.max_total_diffs >= 0 ? p.max_total_diffs
+                                               : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;  // SR:493
+  std::string search_pam;
+  for (size_t i = 0; i < g.pams.size(); i++) { if (i) search_pam += ','; search_pam += g.pams[i]; }   // RH:207
+  RowStrings rc;
+  rc.head = guide_id + "\t" + g.protospacer + "\t" + ref.genome_build + "\t";
+  rc.tail = std::string("CALITAS:SearchReference") + "\t" + version + "\t" + search_pam + "\t" + core_parameters(p, max_total) + "\t" +
+            time_stamp + "\n";                                                                       // SR:522
+  rc.proto_len = std::to_string(g.protospacer.size());
+  for (int pi = -1; pi < (int)g.pams.size(); pi++) {
+    std::string q = g.query_for(pi), used;
+    for (char c : q) if (c >= 'a' && c <= 'z') used += c;
+    rc.query.push_back(q); rc.pam_used.push_back(used);
+  }
+  for (int i = 0; i < 34; i++) { if (i) rc.header += '\t'; rc.header += kColumns[i]; }
+  rc.header += '\n';
+  return rc;
+}
 
 static inline char* put_int_p(char* w, long v) {
   char b[24]; int n = 0; const bool neg = v < 0; unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
@@ -278,7 +291,7 @@ static inline char* put_bases(char* w, const char* fwd, int64_t lo, int64_t from
 }
 
 // One hits.txt row (RH:210-254) written at w; returns the new write position.  The caller provides row_bound() bytes.
-static char* write_row(char* w, const PackedRef& ref, const RowConst& rc, const calitas_aln_t& a) {
+static char* write_row(char* w, const PackedRef& ref, const RowStrings& rc, const calitas_aln_t& a) {
   const bool minus = a.strand == '-';
   const std::string& q = rc.query[a.pam_index + 1];
   // one fetch covers the alignment and all four flanks (RH:213-216: 10 bases around the protospacer, 8 around the alignment)
@@ -340,7 +353,7 @@ static char* write_row(char* w, const PackedRef& ref, const RowConst& rc, const 
   return w;
 }
 
-static size_t row_bound(const PackedRef& ref, const RowConst& rc) {
+static size_t row_bound(const PackedRef& ref, const RowStrings& rc) {
   size_t name = 0;
   for (auto& n : ref.names) name = std::max(name, n.size());
   return rc.head.size() + rc.tail.size() + name + 5 * (CALITAS_MAX_OPS + 4) + 256;
@@ -354,8 +367,6 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
   const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_start = tnow();
-  const int max_total = p.max_total_diffs >= 0 ? p.max_total_diffs
-                                               : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;  // SR:493
   auto by_hit_order = [](const Lite& x, const Lite& y) {   // RH:284
     if (x.contig != y.contig) return x.contig < y.contig;
     if (x.start != y.start) return x.start < y.start;
@@ -432,21 +443,8 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
   auto t_dedup = tnow();
 
   // ---- rows (RH:210-254), built in parallel blocks and concatenated in order ----
-  std::string search_pam;
-  for (size_t i = 0; i < g.pams.size(); i++) { if (i) search_pam += ','; search_pam += g.pams[i]; }   // RH:207
-  RowConst rc;
-  rc.head = guide_id + "\t" + g.protospacer + "\t" + ref.genome_build + "\t";
-  rc.tail = std::string("CALITAS:SearchReference") + "\t" + version + "\t" + search_pam + "\t" + core_parameters(p, max_total) + "\t" +
-            time_stamp + "\n";                                                                       // SR:522
-  rc.proto_len = std::to_string(g.protospacer.size());
-  for (int pi = -1; pi < (int)g.pams.size(); pi++) {
-    std::string q = g.query_for(pi), used;
-    for (char c : q) if (c >= 'a' && c <= 'z') used += c;
-    rc.query.push_back(q); rc.pam_used.push_back(used);
-  }
-  std::string header;
-  for (int i = 0; i < 34; i++) { if (i) header += '\t'; header += kColumns[i]; }
-  header += '\n';
+  const RowStrings rc = make_row_strings(ref, g, guide_id, p, version, time_stamp);
+  const std::string& header = rc.header;
   const size_t BLOCK = 512;
   const size_t n_blocks = (keepers.size() + BLOCK - 1) / BLOCK;
   const size_t bound = row_bound(ref, rc);

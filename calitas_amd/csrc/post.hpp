@@ -36,6 +36,18 @@ void window_filter(const calitas_aln_t* alns, int n, int max_total_diffs, int ma
 // Padded strings in guide orientation.
 void padded_strings(const PackedRef& ref, const GuideHost& g, const calitas_aln_t& a, std::string& pg, std::string& pa, std::string& pt);
 
+// The pieces of a hits.txt row that are the same for every hit of one guide (RH:205-254), and the header line.
+struct RowStrings {
+  std::string header;                   // the 34 column names + newline
+  std::string head;                     // guide_id \t protospacer \t genome_build \t
+  std::string tail;                     // aligner \t version \t search_pam \t parameters \t time_stamp \n
+  std::string proto_len;
+  std::vector<std::string> query;       // per PAM index + 1: the query in guide orientation (GuideAlignment.guide)
+  std::vector<std::string> pam_used;    // per PAM index + 1: its lower-case part (RH:229)
+};
+RowStrings make_row_strings(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
+                            const std::string& version, const std::string& time_stamp);
+
 // hits.txt text for one guide's alignments: malloc'd, NUL-terminated (nullptr when out of memory).
 char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,

@@ -99,6 +99,12 @@ typedef struct {
   uint64_t raw_alignments;     /* alignments surviving PAM extension, before the per-window filter */
   uint64_t accepted_alignments;
   uint32_t retries;            /* re-runs caused by device buffer overflow */
+  uint32_t reserved;
+  /* calitas_search_hits only */
+  double hits_kernel_ms;       /* removeOverlaps + sorts + row text on the device */
+  double hits_copy_ms;         /* the text's copy-back */
+  uint64_t hit_rows;
+  uint64_t hits_bytes;
 } calitas_timing_t;
 
 /* Context ------------------------------------------------------------------------------------------------------- */
@@ -144,6 +150,15 @@ int calitas_window_table(const calitas_ctx* ctx, int32_t window_size, int32_t st
 int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                    calitas_aln_t** out, uint64_t* n_out);
 int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
+
+/* SearchReference.execute for one guide on the reference genome, end to end (SearchReference.scala:527-564 and 641-648):
+ * calitas_search followed by removeOverlaps, ReferenceHit.sort and the 34-column rows, with the alignments never leaving
+ * the device -- the per-window filter, removeOverlaps, both sorts and the row text are produced by kernels and only the
+ * finished hits.txt text (header + rows, NUL-terminated, *tsv_bytes without the NUL) is copied back.  Byte-identical to
+ * calitas_search + calitas_hits_tsv; when a device stage cannot represent a search the host
+ * implementation of that stage finishes the call.  aligner_version / time_stamp as in calitas_hits_tsv. */
+int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                        const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
 
 /* SequentialGuideAligner.align on explicit (guide, target) pairs -- the per-task call of PairwiseAlignSequences
  * (PairwiseAlignSequences.scala:64 -> alignBest, SequentialGuideAligner.scala:333-345) and AlignToReference

@@ -31,8 +31,20 @@ def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
     for k in ("guide_mismatch_net_cost", "pam_mismatch_net_cost", "genome_gap_net_cost", "guide_gap_net_cost"):
         if k in kw:
             pk[k] = kw[k]
-    sr = C.SearchReference(guide=guide, guide_id="a", ref=fasta, auxiliary_pams=aux, chrom=chrom, **pk)
-    text, n = sr.run()
+    # the fused call (calitas_search_hits: filter, removeOverlaps, sorts and rows on the device) and the two-stage call
+    # (calitas_search + calitas_hits_tsv: the same stages on the host) must agree byte for byte
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fasta)
+    try:
+        text, n = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, **pk).run("v0", "stamp")
+        text2, n2 = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, two_stage=True, **pk).run("v0", "stamp")
+    finally:
+        ctx.close()
+    assert n == n2
+    if text != text2:
+        a, b = text.splitlines(), text2.splitlines()
+        diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y][:2]
+        raise AssertionError("fused and two-stage hits.txt differ: %d vs %d lines, first differences: %s" % (len(a), len(b), diff))
     rows = C.read_hits(text)
     assert len(rows) == n
     return rows
