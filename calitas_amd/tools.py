@@ -175,3 +175,137 @@ def pairwise_align_sequences(input_path, output_path, max_gaps_between_guide_and
                 a = max(alns, key=lambda x: x.score)
                 out.write("\t".join(str(x) for x in (q, t, a.score, 1, a.start_offset, a.cigar, a.mismatches, a.gap_bases, a.padded_guide,
                                                      a.padded_alignment, a.padded_target)) + "\n")
+
+
+def read_fasta(path):
+    """Contig name -> bases (bytes, case preserved), in file order."""
+    ref, name, parts = {}, None, []
+    with open(path, "rb") as f:
+        for line in f:
+            line = line.rstrip(b"\r\n")
+            if not line:
+                continue
+            if line.startswith(b">"):
+                if name is not None:
+                    ref[name] = b"".join(parts)
+                name, parts = line[1:].split()[0].decode(), []
+            elif name is not None:
+                parts.append(line)
+    if name is not None:
+        ref[name] = b"".join(parts)
+    return ref
+
+
+_COMP = bytes.maketrans(b"ACGTUMKRYVBHDWSNacgtumkryvbhdwsn", b"TGCAAKMYRBVDHWSNtgcaakmyrbvdhwsn")
+
+HIT_COLUMNS = ["guide_id", "unpadded_guide_sequence", "genome_build", "chromosome", "coordinate_start", "coordinate_end", "strand",
+               "unpadded_target_sequence", "ten_bases_5_prime", "ten_bases_3_prime", "pam_used", "variant_id", "variant_description",
+               "variant_vcf", "allele_frequency", "score", "guide_mm", "guide_gaps", "guide_mm_plus_gaps", "pam_mm", "total_mm_plus_gaps",
+               "padded_guide", "padded_alignment", "padded_target", "padded_extra_8_bases_5_prime", "padded_extra_8_bases_3_prime", "cigar",
+               "unpadded_guide_sequence_length", "unpadded_target_sequence_length", "aligner", "aligner_version", "aligner_search_pam",
+               "aligner_other_parameters", "time_stamp"]
+
+
+def reference_hit_row(aln, guide, guide_id, contig, genome_build, aligner_id, version, arguments, time_stamp):
+    """ReferenceHit.Builder.build without variants (ReferenceHit.scala:210-254) for a tools.GuideAlignment on `contig` (bytes)."""
+    neg = aln.strand == "-"
+
+    def fetch(start, end):                                      # fetchBases ReferenceHit.scala:261-266, 1-based closed
+        a_s, a_e = max(1, start), min(len(contig), end)
+        bases = b"N" * (a_s - start) + contig[a_s - 1:a_e] + b"N" * (end - a_e)
+        if neg:
+            bases = bases.translate(_COMP)[::-1]
+        return bases.decode().upper()
+
+    ten_left, ten_right = fetch(aln.guide_start_offset + 1 - 10, aln.guide_start_offset), fetch(aln.guide_end_offset + 1, aln.guide_end_offset + 10)
+    eight_left, eight_right = fetch(aln.start_offset + 1 - 8, aln.start_offset), fetch(aln.end_offset + 1, aln.end_offset + 8)
+    pg, pt = aln.padded_guide, aln.padded_target
+    ups = [i for i, ch in enumerate(pg) if ch.isupper()]        # unpaddedTargetWithoutPam GuideAlignment.scala:111-115
+    unpadded_target = "".join(ch for ch in pt[ups[0]:ups[-1] + 1] if ch != "-")
+    row = [guide_id, guide.guide, genome_build, aln.chrom, aln.guide_start_offset, aln.guide_end_offset, aln.strand, unpadded_target,
+           ten_right if neg else ten_left, ten_left if neg else ten_right, "".join(ch for ch in aln.guide if ch.islower()), "", "", "", "",
+           aln.score, aln.guide_mismatches, aln.guide_gap_bases, aln.guide_mismatches + aln.guide_gap_bases, aln.pam_mismatches, aln.edits,
+           pg, aln.padded_alignment, pt, eight_right if neg else eight_left, eight_left if neg else eight_right, aln.cigar, len(guide.guide),
+           len(unpadded_target), aligner_id, version, ",".join(guide.pams), arguments, time_stamp]
+    return "\t".join(str(x) for x in row)
+
+
+def align_to_reference(input_path, ref, output_path=None, window_size=None, max_guide_diffs=None, max_pam_mismatches=None,
+                       max_gaps_between_guide_and_pam=Defaults.MaxGapsBetweenGuideAndPam, max_total_diffs=None, max_overlap=None,
+                       guide_mismatch_net_cost=Defaults.MismatchNetCost, pam_mismatch_net_cost=Defaults.PamMismatchNetCost,
+                       genome_gap_net_cost=Defaults.GenomeGapNetCost, guide_gap_net_cost=Defaults.GuideGapNetCost, threads=8, context=None,
+                       device=0, version=None, time_stamp=None, eqx_by_score=0):
+    """AlignToReference.execute (AlignToReference.scala:95-146): a tab-delimited file with a header (id optional, query, chrom,
+    position) -> ReferenceHit rows.  All of -d/-p/-O given: every alignment meeting them (alignToRef); none given: the single best
+    alignment per query (alignToRefBest).  Batches of 10000 tasks go to the GPU in one calitas_align_windows call each and are
+    sorted on their own (AlignToReference.scala:104,140).  `threads` is accepted and ignored.  Returns the TSV text."""
+    import time as _time
+    given = [x is not None for x in (max_guide_diffs, max_pam_mismatches, max_overlap)]
+    if any(given) and not all(given):
+        raise ValueError("Must specify all or none of: --max-guide-diffs, --max-pam-mismatches, --max-overlap")
+    limits = all(given)
+    contigs = read_fasta(ref)
+    ctx = context or Context(device)
+    own = context is None
+    try:
+        if not ctx.contig_names:
+            ctx.set_reference_fasta(ref)
+        genome_build = ctx.genome_build()
+        order = {n: i for i, n in enumerate(ctx.contig_names)}
+        aligner = SequentialGuideAligner(context=ctx, ref=contigs, mismatch_net_cost=guide_mismatch_net_cost,
+                                         genome_gap_net_cost=genome_gap_net_cost, guide_gap_net_cost=guide_gap_net_cost,
+                                         pam_mismatch_net_cost=pam_mismatch_net_cost, eqx_by_score=eqx_by_score)
+        opt = lambda v: "Some(%d)" % v if v is not None else "None"          # Scala prints the Option-typed flags this way
+        arguments = ";".join(sorted("%s=%s" % kv for kv in {
+            "max-guide-diffs": opt(max_guide_diffs), "max-pam-mismatches": opt(max_pam_mismatches),
+            "max-gaps-between-guide-and-pam": max_gaps_between_guide_and_pam, "max-overlap": opt(max_overlap),
+            "guide-mismatch-net-cost": guide_mismatch_net_cost, "pam-mismatch-net-cost": pam_mismatch_net_cost,
+            "genome-gap-net-cost": genome_gap_net_cost, "guide-gap-net-cost": guide_gap_net_cost}.items()))   # AlignToReference.scala:70-79
+        version = version or _time.strftime("unknown-%Y-%m-%d", _time.gmtime())
+        time_stamp = time_stamp or _time.strftime("%a %b %d %H:%M:%S UTC %Y", _time.gmtime())
+
+        tasks = []
+        with open(input_path) as f:
+            header = f.readline().rstrip("\r\n").split("\t")
+            for need in ("query", "chrom", "position"):
+                if need not in header:
+                    raise ValueError("input needs the columns query, chrom and position")
+            for line in f:
+                line = line.rstrip("\r\n")
+                if not line:
+                    continue
+                row = dict(zip(header, line.split("\t")))
+                tasks.append((row.get("id") or row["query"], row["query"], row["chrom"], int(row["position"])))
+
+        lines = ["\t".join(HIT_COLUMNS)]
+        for b0 in range(0, len(tasks), 10000):
+            batch = tasks[b0:b0 + 10000]
+            guides = [Guide(q) for _, q, _, _ in batch]
+            regions = [aligner._region(g, chrom, pos, window_size) for g, (_, _, chrom, pos) in zip(guides, batch)]
+            D = None
+            if limits:
+                D = max_total_diffs if max_total_diffs is not None else max_guide_diffs + max_gaps_between_guide_and_pam + max_pam_mismatches
+            res = aligner.align_many(guides, [t for t, _ in regions], [o for _, o in regions], [c for _, _, c, _ in batch],
+                                     max_guide_diffs if limits else None, max_gaps_between_guide_and_pam,
+                                     max_pam_mismatches if limits else None, D, max_overlap if limits else 0)
+            hits = []
+            for (tid, _, chrom, _), g, alns in zip(batch, guides, res):
+                alns = sorted(alns, key=lambda a: (-a.score, a.gap_bases))    # alignToRef's order, SequentialGuideAligner.scala:386
+                if not limits:
+                    if not alns:
+                        raise ValueError("head of empty list")
+                    alns = alns[:1]
+                for a in alns:
+                    key = (order[chrom], a.guide_start_offset, a.strand, -a.score)               # ReferenceHit.scala:284
+                    hits.append((key, reference_hit_row(a, g, tid, contigs[chrom], genome_build, "CALITAS:AlignToReference", version,
+                                                        arguments, time_stamp)))
+            hits.sort(key=lambda h: h[0])                                     # stable
+            lines += [r for _, r in hits]
+        text = "\n".join(lines) + "\n"
+        if output_path is not None:
+            with open(output_path, "w") as f:
+                f.write(text)
+        return text
+    finally:
+        if own:
+            ctx.close()

@@ -1197,6 +1197,85 @@ char* oracle_align_to_ref(const char* guide, const char* chrom, const char* cont
   } catch (std::exception& e) { return dup_out(std::string("ERROR\t") + e.what()); }
 }
 
+// AlignToReference.execute (A2R = AlignToReference.scala:95-146): tab-delimited tasks with a header (id optional, query,
+// chrom, position) -> ReferenceHit rows.  iparams = {has_limits, d, p, g, D(-1 = default), O, window_size(0 = default),
+// m, M, b, B, switches}.  With has_limits == 0 the single best alignment per query is reported (alignToRefBest).
+// coreParameters (A2R:70-79) prints the Option-typed flags the way Scala's string interpolation does: Some(x) / None.
+char* oracle_align_to_reference(const char* fasta, const char* input_tsv, const int* iparams) {
+  try {
+    Reference ref = load_reference(fasta);
+    const bool limits = iparams[0] != 0;
+    const int d = iparams[1], pm = iparams[2], g = iparams[3], D = iparams[4], O = iparams[5], windowSize = iparams[6];
+    Aligner al;
+    al.scorer = Scorer(iparams[7], iparams[9], iparams[10], iparams[8]);
+    al.switches = iparams[11];
+    auto opt = [&](int v) { return limits ? "Some(" + std::to_string(v) + ")" : std::string("None"); };
+    std::vector<std::string> kv = {
+      "max-guide-diffs=" + opt(d), "max-pam-mismatches=" + opt(pm), "max-gaps-between-guide-and-pam=" + std::to_string(g),
+      "max-overlap=" + opt(O), "guide-mismatch-net-cost=" + std::to_string(iparams[7]), "pam-mismatch-net-cost=" + std::to_string(iparams[8]),
+      "genome-gap-net-cost=" + std::to_string(iparams[9]), "guide-gap-net-cost=" + std::to_string(iparams[10])};
+    std::sort(kv.begin(), kv.end());
+    std::string args;
+    for (size_t i = 0; i < kv.size(); i++) { if (i) args += ';'; args += kv[i]; }
+
+    std::ifstream in(input_tsv);
+    if (!in) throw std::runtime_error(std::string("cannot read ") + input_tsv);
+    std::string line;
+    auto split = [](const std::string& l) { std::vector<std::string> f; std::stringstream ss(l); std::string x; while (std::getline(ss, x, '\t')) f.push_back(x); return f; };
+    if (!std::getline(in, line)) throw std::runtime_error("empty input");
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    const std::vector<std::string> header = split(line);
+    auto col = [&](const char* name) { for (size_t i = 0; i < header.size(); i++) if (header[i] == name) return (int)i; return -1; };
+    const int cId = col("id"), cQuery = col("query"), cChrom = col("chrom"), cPos = col("position");
+    if (cQuery < 0 || cChrom < 0 || cPos < 0) throw std::runtime_error("input needs the columns query, chrom and position");
+    struct Task { std::string id, query, chrom; int pos; };
+    std::vector<Task> tasks;
+    while (std::getline(in, line)) {
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (line.empty()) continue;
+      auto f = split(line);
+      f.resize(header.size());
+      Task t; t.query = f[cQuery]; t.id = cId >= 0 && !f[cId].empty() ? f[cId] : t.query; t.chrom = f[cChrom]; t.pos = std::stoi(f[cPos]);
+      tasks.push_back(t);
+    }
+    std::string out;
+    for (int i = 0; i < 34; i++) { if (i) out += '\t'; out += HIT_COLUMNS[i]; }
+    out += '\n';
+    for (size_t b0 = 0; b0 < tasks.size(); b0 += 10000) {           // A2R:104 batches of 10000, each sorted on its own
+      std::vector<Hit> results;
+      std::vector<Guide> guides;                                     // keep the guides alive: HitBuilder holds a pointer
+      guides.reserve(std::min<size_t>(10000, tasks.size() - b0));
+      for (size_t ti = b0; ti < std::min(tasks.size(), b0 + 10000); ti++) {
+        const Task& t = tasks[ti];
+        guides.push_back(make_guide(t.query, {}));
+        const Guide& guide = guides.back();
+        const int ci = ref.index_of(t.chrom);
+        if (ci < 0) throw std::runtime_error("Unknown chromosome: " + t.chrom);
+        const std::string& contig = ref.seqs[ci];
+        const int padding = windowSize > 0 ? windowSize / 2 : guide.length() * 2;                   // SGA:372
+        const int rs = std::max(t.pos - padding, 1), re = std::min(t.pos + padding, (int)contig.size());
+        const std::string target = re >= rs ? contig.substr(rs - 1, re - rs + 1) : std::string();   // not upper-cased (SGA:374)
+        int md = d, mp = pm, mt = D >= 0 ? D : d + g + pm, mo = O;
+        if (!limits) { md = guide.protospacerLength(); mp = guide.pamLength(); mt = guide.protospacerLength() + g + guide.pamLength(); mo = 0; }
+        auto res = al.align(guide, target, t.chrom, rs - 1, md, g, mp, mt, mo);
+        std::stable_sort(res.begin(), res.end(), [](const GuideAlignment& a, const GuideAlignment& b) {
+          if (a.score != b.score) return a.score > b.score;
+          return a.gapBases() < b.gapBases();
+        });
+        if (!limits) { if (res.empty()) throw std::runtime_error("head of empty list"); res.resize(1); }
+        HitBuilder hb;
+        hb.guideId = t.id; hb.guide = &guide; hb.ref = &ref; hb.alignerId = "CALITAS:AlignToReference"; hb.arguments = args;
+        hb.genomeBuild = ref.assembly; hb.version = "unknown"; hb.timestamp = "n/a";
+        for (size_t i = 0; i < guide.pams.size(); i++) { if (i) hb.alignerSearchPam += ','; hb.alignerSearchPam += guide.pams[i]; }
+        for (auto& a : res) results.push_back(hb.build(a));
+      }
+      sort_hits(results);
+      for (auto& h : results) out += hit_row(h);
+    }
+    return dup_out(out);
+  } catch (std::exception& e) { return dup_out(std::string("ERROR\t") + e.what()); }
+}
+
 // GuideAlignment.apply + counters on literal padded strings (GuideAlignmentTest).
 char* oracle_guide_alignment(const char* padded_guide, const char* padded_aln, const char* padded_target, int start, int end, char strand) {
   try {

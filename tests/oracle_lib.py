@@ -32,7 +32,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         for name in ["oracle_align", "oracle_align_best", "oracle_align_to_ref", "oracle_guide_alignment", "oracle_windows",
                      "oracle_search_reference", "oracle_search_memory", "oracle_search_reference_vcf", "oracle_allele_combos",
-                     "oracle_variant_window"]:
+                     "oracle_variant_window", "oracle_align_to_reference"]:
             getattr(L, name).restype = ctypes.c_void_p
         L.oracle_free.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -132,6 +132,15 @@ def search_reference_vcf(fasta, vcf, guide, guide_id="a", aux=(), chrom="", **kw
     header = lines[0].split("\t")
     rows = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
     return header, rows, nwin.value
+
+
+def align_to_reference(fasta, input_tsv, limits=None, g=3, D=-1, window_size=0, costs=DEFAULT_COSTS, switches=0):
+    """AlignToReference on files; limits = (d, p, O) or None for the best alignment per query. Returns (header, rows)."""
+    d, p, O = limits if limits else (0, 0, 0)
+    ip = (ctypes.c_int * 12)(1 if limits else 0, d, p, g, D, O, window_size, costs[0], costs[1], costs[2], costs[3], switches)
+    lines = _take(lib().oracle_align_to_reference(fasta.encode(), input_tsv.encode(), ip)).splitlines()
+    header = lines[0].split("\t")
+    return header, [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
 
 
 def allele_combos(counts):

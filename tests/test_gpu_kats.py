@@ -161,3 +161,74 @@ def test_pairwise_align_sequences_tool(C, aligner, tmp_path):
         w = O.align_best(q, t.upper())
         assert f == [q, t.upper(), str(w["score"]), "1", str(w["start"]), w["cigar"], str(w["mismatches"]), str(w["gap_bases"]),
                      w["padded_guide"], w["padded_alignment"], w["padded_target"]]
+
+
+def _a2r_inputs(tmp_path, seed):
+    """A small FASTA (mixed case, an N block) with planted sites and a task file around them."""
+    from fasta_util import write_fasta
+    rng = np.random.default_rng(seed)
+    guides = ["CTTGCCCCACAGGGCAGTAAnrg", "tttvAACCAACCAACCGGTTACGT", "GTGACTTGAAGTCTCAGTATA", "GATACGTCTCGTACTGTnrg"]
+    contigs = []
+    tasks = []
+    for ci in range(3):
+        n = int(rng.integers(1500, 4000))
+        seq = np.array(list("ACGT"))[rng.integers(0, 4, n)]
+        lower = rng.random(n) < 0.2
+        seq = np.where(lower, np.char.lower(seq), seq)
+        seq[600:640] = "N"
+        s = "".join(seq)
+        for k, g in enumerate(guides):
+            site = g.upper().replace("N", "A").replace("R", "G").replace("V", "C")
+            if k % 2:
+                site = rc(site)
+            pos = int(rng.integers(50, n - 100))
+            site = list(site)
+            for _ in range(int(rng.integers(0, 3))):
+                site[int(rng.integers(0, len(site)))] = "ACGT"[int(rng.integers(0, 4))]
+            s = s[:pos] + "".join(site) + s[pos + len(site):]
+            tasks.append(("t%d_%d" % (ci, k), g, "c%d" % ci, pos + int(rng.integers(0, 25))))
+        tasks.append(("edge%d" % ci, guides[0], "c%d" % ci, 5))            # window clipped at the contig start
+        tasks.append(("", guides[2], "c%d" % ci, n - 3))                   # no id -> the query is the id; clipped at the end
+        contigs.append(("c%d" % ci, s))
+    fa = write_fasta(str(tmp_path / ("a2r%d.fa" % seed)), contigs)
+    inp = tmp_path / ("a2r%d.tsv" % seed)
+    inp.write_text("id\tquery\tchrom\tposition\n" + "".join("%s\t%s\t%s\t%d\n" % t for t in tasks))
+    return fa, str(inp)
+
+
+@pytest.mark.parametrize("mode", ["best", "limits", "limits-window"])
+def test_align_to_reference_tool(C, tmp_path, mode):
+    """AlignToReference (AlignToReference.scala:95-146) file to file: every ReferenceHit column against the oracle's restatement
+    (no reference test pins the tool itself; its aligner calls are pinned by K23-K26)."""
+    fa, inp = _a2r_inputs(tmp_path, 11)
+    kw, okw = {}, {}
+    if mode != "best":
+        kw = dict(max_guide_diffs=4, max_pam_mismatches=1, max_overlap=5, max_gaps_between_guide_and_pam=2)
+        okw = dict(limits=(4, 1, 5), g=2)
+    if mode == "limits-window":
+        kw["window_size"] = 120; okw["window_size"] = 120
+        kw["max_total_diffs"] = 5; okw["D"] = 5
+    out = tmp_path / "a2r_out.txt"
+    text = C.align_to_reference(inp, fa, str(out), version="unknown", time_stamp="n/a", **kw)
+    assert out.read_text() == text
+    header, want = O.align_to_reference(fa, inp, **okw)
+    lines = text.splitlines()
+    assert lines[0].split("\t") == header
+    got = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
+    assert len(want) > 10
+    assert got == want
+
+
+def test_module_cli_align_to_reference(C, tmp_path):
+    """python -m calitas_amd AlignToReference with the reference's flags (AlignToReference.scala:34-51)."""
+    from calitas_amd.__main__ import main
+    fa, inp = _a2r_inputs(tmp_path, 12)
+    out = tmp_path / "cli_out.txt"
+    assert main(["AlignToReference", "-i", inp, "-r", fa, "-o", str(out), "-d", "3", "-p", "1", "-O", "8", "-g", "1"]) == 0
+    header, want = O.align_to_reference(fa, inp, limits=(3, 1, 8), g=1)
+    lines = out.read_text().splitlines()
+    got = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
+    skip = {"aligner_version", "time_stamp"}
+    assert [{k: v for k, v in r.items() if k not in skip} for r in got] == [{k: v for k, v in r.items() if k not in skip} for r in want]
+    with pytest.raises(ValueError):
+        main(["AlignToReference", "-i", inp, "-r", fa, "-o", str(out), "-d", "3"])   # all or none of -d/-p/-O (A2R:81-85)

@@ -221,3 +221,15 @@ def test_persistent_index_roundtrip(C, tmp_path):
         f.write(b"XXXX")
     with pytest.raises(C.CalitasError):
         C.Context(-1).load_index(idx)
+
+
+def test_module_cli_parses_the_reference_flags():
+    """python -m calitas_amd <Tool>: flag names as in the reference's tools (no GPU needed to parse)."""
+    from calitas_amd.__main__ import main
+    for tool in ("SearchReference", "AlignToReference", "PairwiseAlignSequences", "PrepareVcf"):
+        with pytest.raises(SystemExit) as e:
+            main([tool, "--help"])
+        assert e.value.code == 0
+    with pytest.raises(SystemExit) as e:
+        main(["SearchReference", "-i", "ACGTnrg"])    # -I and -r are required (SearchReference.scala:452-455)
+    assert e.value.code != 0

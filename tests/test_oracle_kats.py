@@ -116,3 +116,29 @@ def test_window_iterator_e5(tmp_path):
     assert len(wins) == 59  # Range(0, 24999, 426)
     assert wins[0] == ("chr1", 1, 451, 451)
     assert wins[-1][2] == 25000
+
+
+def test_align_to_reference_tool_restatement_is_consistent(tmp_path):
+    """The file-level AlignToReference restatement (A2R:95-146; no reference test pins it) must agree with the pinned
+    alignToRefBest restatement (K23-K26) task by task, and print the Option-typed flags like Scala does."""
+    from fasta_util import write_fasta
+    contig = SGA["contigs"]
+    name = sorted(contig)[0]
+    fa = write_fasta(str(tmp_path / "a2r.fa"), [(name, contig[name])])
+    tasks = [("q%d" % i, g, name, pos) for i, (g, pos) in enumerate([("CTTGCCCCACAGGGCAGTAAnrg", 40), ("GATACGTCTCGTACTGTnrg", 100),
+                                                                       ("tttvAACCAACCAACCGGTTACGT", 60)])]
+    inp = tmp_path / "tasks.tsv"
+    inp.write_text("id\tquery\tchrom\tposition\n" + "".join("%s\t%s\t%s\t%d\n" % t for t in tasks))
+    header, rows = O.align_to_reference(fa, str(inp))
+    assert len(rows) == len(tasks) and header[0] == "guide_id" and len(header) == 34
+    by_id = {r["guide_id"]: r for r in rows}
+    for tid, g, chrom, pos in tasks:
+        w = O.align_to_ref_best(g, chrom, contig[name], pos)
+        r = by_id[tid]
+        assert (int(r["score"]), r["cigar"], r["strand"], int(r["coordinate_start"]), int(r["coordinate_end"])) == \
+               (w["score"], w["cigar"], w["strand"], w["gstart"], w["gend"])
+        assert r["aligner"] == "CALITAS:AlignToReference" and "max-guide-diffs=None" in r["aligner_other_parameters"]
+    _, rows = O.align_to_reference(fa, str(inp), limits=(5, 1, 10))
+    assert all("max-guide-diffs=Some(5)" in r["aligner_other_parameters"] and "max-overlap=Some(10)" in r["aligner_other_parameters"] for r in rows)
+    keys = [(int(r["coordinate_start"]), r["strand"], -int(r["score"])) for r in rows]
+    assert keys == sorted(keys)
