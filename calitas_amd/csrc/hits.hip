@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -228,11 +229,30 @@ struct MidArgs {
   uint32_t slot_bytes;       // LDS bytes per lane: multiple of 4, odd number of words
   uint32_t mid_bound;        // bytes reserved for the middle part = staging stride
   uint32_t n_max;            // most padded columns a row of this search can have
+  uint32_t blob_bytes;       // constant strings, copied to LDS by each block
 };
 
+static_assert(offsetof(RawAln, ops) % 4 == 0 && sizeof(RawAln) % 4 == 0, "RawAln::ops must be word aligned");
+
+struct RowIn {             // the fields of one RawAln a row needs, ops as five words (2 bits per op, traceback order)
+  uint32_t w[RAW_MAX_OPS / 16];
+  int n_ops, pam, offset;
+  uint32_t pam_x;
+};
+
+__device__ __forceinline__ int row_op(const RowIn& r, int i) {
+  const int k = i >> 4;
+  uint32_t w = r.w[0];
+#pragma unroll
+  for (int j = 1; j < RAW_MAX_OPS / 16; j++) w = (k == j) ? r.w[j] : w;
+  return (int)((w >> ((i & 15) * 2)) & 3u);
+}
+
 // The middle part of one hits.txt row (RH:210-254, columns coordinate_start .. unpadded_target_sequence_length) at `out`;
-// `scratch` holds 4 * n_max + n_max + 24 bytes.  Returns its length, or -1 when the alignment has more columns than n_max.
-__device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, const RawAln& r, const HitRec& h, const GuideDev& g) {
+// `scratch` holds 4 * n_max + n_max + 24 bytes, `blob` is the LDS copy of the constant strings.  Returns its length, or -1
+// when the alignment has more columns than n_max.
+__device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, const uint8_t* blob, const RowIn& r, const HitRec& h,
+                             const GuideDev& g) {
   uint8_t* ops = scratch;
   uint8_t* pg = ops + a.n_max;
   uint8_t* pa = pg + a.n_max;
@@ -246,18 +266,30 @@ __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, c
   for (int i = 0; i < n; i++) {
     const int k = g.pam5 ? n - 1 - i : i;
     char op;
-    if (k < ng) op = "=XID"[raw_op(r, ng - 1 - k)];
+    if (k < ng) op = "=XID"[row_op(r, ng - 1 - k)];
     else if (k < ng + gap) op = 'D';
     else op = ((r.pam_x >> (k - ng - gap)) & 1) ? 'X' : '=';
     ops[i] = (uint8_t)op;
   }
   const bool minus = h.minus != 0;
-  const char* q = a.blob + a.rc.q_off[r.pam + 1];
+  const uint8_t* q = blob + a.rc.q_off[r.pam + 1];
   // one fetch covers the alignment and all four flanks (RH:213-216)
   const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
   {
+    // one code word per 16 bases and one mask word per 32 are fetched, not two words per base
     const ContigInfo c = a.ref.contigs[h.contig];
-    for (int p = lo; p < hi; p++) fwd[p - lo] = (uint8_t)((p >= 0 && (uint64_t)p < c.len) ? base_upper_dev(a.ref, c.gbase + (uint64_t)p) : 'N');   // RH:262-264
+    uint64_t cw_idx = ~0ull, mw_idx = ~0ull;
+    uint32_t cw = 0, mw = 0;
+    for (int p = lo; p < hi; p++) {
+      char b = 'N';                                                                          // RH:262-264
+      if (p >= 0 && (uint64_t)p < c.len) {
+        const uint64_t gpos = c.gbase + (uint64_t)p;
+        if ((gpos >> 5) != mw_idx) { mw_idx = gpos >> 5; mw = a.ref.mask[mw_idx]; }
+        if ((gpos >> 4) != cw_idx) { cw_idx = gpos >> 4; cw = a.ref.codes[cw_idx]; }
+        b = ((mw >> (gpos & 31)) & 1u) ? base_upper_dev(a.ref, gpos) : "ACGT"[(cw >> ((gpos & 15) * 2)) & 3u];
+      }
+      fwd[p - lo] = (uint8_t)b;
+    }
   }
   int qi = 0, mm = 0, gp = 0, ps = -1, pe = -1;
   int tp = minus ? h.end - 1 : h.start;                 // next target base, walking in guide orientation
@@ -265,7 +297,7 @@ __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, c
     const char op = (char)ops[i];
     char tb = '-', qc = '-';
     if (op != 'I') { tb = (char)fwd[tp - lo]; if (minus) { tb = comp_base(tb); tp--; } else tp++; }
-    if (op != 'D') qc = q[qi++];
+    if (op != 'D') qc = (char)q[qi++];
     pg[i] = (uint8_t)qc; pt[i] = (uint8_t)tb;
     pa[i] = (uint8_t)(op == '=' ? '|' : op == 'X' ? '.' : '~');
     mm += op == 'X'; gp += (op == 'I' || op == 'D');
@@ -282,7 +314,7 @@ __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, c
   if (!minus) { w = put_bases(w, fwd, lo, gs - 10, gs, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ge, ge + 10, false); }   // RH:227-228
   else        { w = put_bases(w, fwd, lo, ge, ge + 10, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, gs - 10, gs, true); }
   *w++ = '\t';
-  { const char* pu = a.blob + a.rc.pu_off[r.pam + 1]; const int l = (int)a.rc.pu_len[r.pam + 1]; for (int i = 0; i < l; i++) *w++ = (uint8_t)pu[i]; }
+  { const uint8_t* pu = blob + a.rc.pu_off[r.pam + 1]; const int l = (int)a.rc.pu_len[r.pam + 1]; for (int i = 0; i < l; i++) *w++ = pu[i]; }
   *w++ = '\t';
   *w++ = '\t'; *w++ = '\t'; *w++ = '\t'; *w++ = '\t';   // variant_id, variant_description, variant_vcf, allele_frequency: None
   w = put_int(w, h.score); *w++ = '\t';
@@ -319,12 +351,22 @@ __global__ __launch_bounds__(64) void mid_kernel(MidArgs a, uint8_t* stage, uint
   int len = 0;
   uint32_t name_len = 0;
   const bool live = k < a.n && a.keys_b[k] != DROPPED;
+  // constant strings (queries, PAMs) into LDS behind the 64 slots
+  uint8_t* blob = lds + 64 * a.slot_bytes;
+  for (uint32_t i = lane; i < a.blob_bytes; i += 64) blob[i] = (uint8_t)a.blob[i];
+  __syncthreads();
   if (live) {
     const uint32_t v = a.order[k];
-    const RawAln& r = a.fin[v];
+    const RawAln* rp = a.fin + v;
+    RowIn r;
+    const uint32_t* ow = reinterpret_cast<const uint32_t*>(rp->ops);   // RawAln::ops sits at a 4-byte aligned offset
+#pragma unroll
+    for (int j = 0; j < RAW_MAX_OPS / 16; j++) r.w[j] = ow[j];
+    r.n_ops = rp->n_ops; r.pam = rp->pam; r.offset = rp->offset; r.pam_x = rp->pam_x;
+    const uint32_t guide = rp->guide;
     const HitRec h = a.hits[v];
     uint8_t* out = lds + lane * a.slot_bytes;
-    len = format_middle(out, out + a.mid_bound, a, r, h, a.guides[r.guide]);
+    len = format_middle(out, out + a.mid_bound, a, blob, r, h, a.guides[guide]);
     if (len < 0 || len > (int)a.mid_bound) { atomicOr(flags, HITS_FLAG_ROW); len = 0; }
     name_len = a.name_off[h.contig + 1] - a.name_off[h.contig];
   }
@@ -508,9 +550,10 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   const uint32_t mid_bound = (6 * n_max + 128 + 3) & ~3u;
   uint32_t slot = mid_bound + ((5 * n_max + 24 + 3) & ~3u);
   if (((slot / 4) & 1) == 0) slot += 4;
-  if (64 * slot > 64 * 1024) {   // beyond the default dynamic LDS limit: ask for more (160 KB per CU on gfx950) or decline
-    if (64 * slot > 160 * 1024 ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * slot)) != hipSuccess) {
+  const uint32_t mid_lds = 64 * slot + (uint32_t)((blob.size() + 15) & ~(size_t)15);
+  if (mid_lds > 64 * 1024) {   // beyond the default dynamic LDS limit: ask for more (160 KB per CU on gfx950) or decline
+    if (mid_lds > 160 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds) != hipSuccess) {
       (void)hipGetLastError();
       TRY(hipStreamSynchronize(stream));
       res->flags = HITS_FLAG_ROW;
@@ -522,8 +565,8 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(grow(&w.midlen, w.midlen_cap, n_pad));
   MidArgs ma{};
   ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
-  ma.keys_b = w.keys2; ma.order = w.vals2; ma.n = n_in; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max;
-  hipLaunchKernelGGL(mid_kernel, dim3((unsigned)(n_pad / 64)), dim3(64), 64 * slot, stream, ma, w.stage, w.midlen, w.lens, d_flags);
+  ma.keys_b = w.keys2; ma.order = w.vals2; ma.n = n_in; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob.size();
+  hipLaunchKernelGGL(mid_kernel, dim3((unsigned)(n_pad / 64)), dim3(64), mid_lds, stream, ma, w.stage, w.midlen, w.lens, d_flags);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts);
