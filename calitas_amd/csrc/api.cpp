@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,25 +29,37 @@ static std::string g_create_error;
 // Output buffers (alignment arrays, hits.txt text) are tens of MB per pass; handing each one back to the OS and faulting
 // a fresh one in costs milliseconds, so calitas_free parks the most recent blocks and out_alloc reuses them.
 namespace {
-struct BlockHeader { uint64_t magic; uint64_t capacity; };
+struct BlockHeader { uint64_t magic; uint64_t capacity; uint64_t pinned; uint64_t pad; };
 constexpr uint64_t kMagic = 0xCA117A5B10C0FFEEull;
 std::mutex g_pool_mutex;
 std::vector<BlockHeader*> g_pool;   // at most 4 parked blocks
 
-void* out_alloc_impl(size_t size) {
+void release_block(BlockHeader* h) {
+  h->magic = 0;
+  if (h->pinned) (void)hipHostFree(h); else std::free(h);
+}
+
+// pinned: page-locked memory (hipHostMalloc) -- the destination of the text copy-back, so that the copy is one DMA at
+// PCIe rate from the first use on instead of the runtime pinning pageable memory piecemeal.
+void* out_alloc_impl(size_t size, bool pinned = false) {
   if (size < 1) size = 1;
   {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     int best = -1;
     for (size_t i = 0; i < g_pool.size(); i++)
-      if (g_pool[i]->capacity >= size && g_pool[i]->capacity <= 2 * size + (1u << 20) &&
+      if ((g_pool[i]->pinned != 0) == pinned && g_pool[i]->capacity >= size && g_pool[i]->capacity <= 2 * size + (1u << 20) &&
           (best < 0 || g_pool[i]->capacity < g_pool[best]->capacity)) best = (int)i;
     if (best >= 0) { BlockHeader* h = g_pool[best]; g_pool.erase(g_pool.begin() + best); return h + 1; }
   }
   size_t cap = size + size / 8;
-  BlockHeader* h = (BlockHeader*)std::malloc(sizeof(BlockHeader) + cap);
+  if (size >= (1u << 20) && std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] out_alloc: fresh %s block of %zu bytes\n", pinned ? "pinned" : "pageable", cap);
+  BlockHeader* h = nullptr;
+  if (pinned) {
+    if (hipHostMalloc((void**)&h, sizeof(BlockHeader) + cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; pinned = false; }
+  }
+  if (!h) h = (BlockHeader*)std::malloc(sizeof(BlockHeader) + cap);
   if (!h) return nullptr;
-  h->magic = kMagic; h->capacity = cap;
+  h->magic = kMagic; h->capacity = cap; h->pinned = pinned ? 1 : 0; h->pad = 0;
   return h + 1;
 }
 
@@ -56,10 +69,14 @@ void out_free(void* p) {
   if (h->magic != kMagic) return;     // not ours: refuse rather than corrupt the heap
   if (h->capacity >= (1u << 20)) {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    if (g_pool.size() < 4) { g_pool.push_back(h); return; }
+    g_pool.push_back(h);
+    if (g_pool.size() <= 4) return;
+    size_t small = 0;                   // full: let the smallest parked block go, the big ones are the expensive ones
+    for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i]->capacity < g_pool[small]->capacity) small = i;
+    h = g_pool[small];
+    g_pool.erase(g_pool.begin() + small);
   }
-  h->magic = 0;
-  std::free(h);
+  release_block(h);
 }
 }  // namespace
 void* calitas_out_alloc(size_t size) { return out_alloc_impl(size); }
@@ -70,6 +87,8 @@ int calitas_fail(calitas_ctx* ctx, int code, const std::string& msg) {
   return code;
 }
 static int fail(calitas_ctx* ctx, int code, const std::string& msg) { return calitas_fail(ctx, code, msg); }
+
+static void destroy_lanes(calitas_ctx* ctx);
 
 static void free_reference_device(calitas_ctx* c) {
   if (c->device < 0) return;
@@ -136,8 +155,11 @@ void calitas_destroy(calitas_ctx* c) {
     free_reference_device(c);
     (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
     (void)hipFree(c->d_slab);
+    destroy_lanes(c);
     select_destroy(c->select);
     hits_destroy(c->hits);
+    if (c->scan_done) (void)hipEventDestroy(c->scan_done);
+    if (c->rows_ready) (void)hipEventDestroy(c->rows_ready);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -381,27 +403,49 @@ int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_
   return CALITAS_OK;
 }
 
+// A lane of a chunked search (see calitas_search_hits) is a child context: its own stream, buffers and scratch, the
+// parent's resident reference and window table.
+static inline const calitas_ctx* ref_owner(const calitas_ctx* ctx) { return ctx->parent ? ctx->parent : ctx; }
+static inline calitas_ctx* ref_owner(calitas_ctx* ctx) { return ctx->parent ? ctx->parent : ctx; }
+
+// Everything about one search that does not depend on the lane running it.
+struct SearchPlan {
+  calitas_params_t p{};
+  int n_guides = 0, step = 0, max_total = 0;
+  Scores sc{};
+  std::vector<GuideHost> gh;
+  std::vector<GuideDev> gd;
+  uint32_t slots_per_rec = 0, slab_bytes = 0;
+  uint64_t slab_per_rec = 0;
+  // the part of the packed reference this job covers
+  uint32_t tile_lo = 0, n_tiles = 0;
+  uint64_t bases = 0;
+};
+
 // Accepted alignments left on the device by search_impl for calitas_search_hits.
 struct DeviceSel {
   bool valid = false;
   const RawAln* d_final = nullptr;
   uint32_t n_sel = 0;
-  int step = 0;
-  std::vector<GuideHost> gh;
-  std::vector<GuideDev> gd;
   std::chrono::steady_clock::time_point t_call;
 };
 
 // Copies the device-selected alignments back and converts them to GuideAlignment records (GA:21-31, SGA:260-313).
 static int convert_selected(calitas_ctx* ctx, const RawAln* d_final, uint32_t n_sel, const std::vector<GuideHost>& gh,
                             const calitas_params_t& p, int step, calitas_aln_t** out) {
-  const PackedRef& ref = ctx->ref;
+  const PackedRef& ref = ref_owner(ctx)->ref;
+  if (n_sel > ctx->h_raw_cap) {
+    if (ctx->h_raw) (void)hipHostFree(ctx->h_raw);
+    ctx->h_raw = nullptr; ctx->h_raw_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_raw, (size_t)ctx->raw_cap * sizeof(RawAln), hipHostMallocDefault));
+    ctx->h_raw_cap = ctx->raw_cap;
+  }
   if (n_sel) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, d_final, (size_t)n_sel * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const RawAln* raw = ctx->h_raw;
   calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_sel) * sizeof(calitas_aln_t));
   if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
-  ctx->pool->for_blocks(n_sel, [&](size_t b, size_t e, int) {
+  ref_owner(ctx)->pool->for_blocks(n_sel, [&](size_t b, size_t e, int) {
     for (size_t i = b; i < e; i++) {
       const RawAln& r = raw[i];
       int64_t wa = 0, wb = 0;
@@ -414,105 +458,144 @@ static int convert_selected(calitas_ctx* ctx, const RawAln* d_final, uint32_t n_
   return CALITAS_OK;
 }
 
-// calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
-// (dev->valid), and *out stays NULL.
-static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
-                       calitas_aln_t** out, uint64_t* n_out, DeviceSel* dev) {
-  if (!ctx) return CALITAS_EINVAL;
-  if (!out || !n_out || !guides || !params) return fail(ctx, CALITAS_EINVAL, "NULL argument");
-  const auto t_call = std::chrono::steady_clock::now();
-  *out = nullptr; *n_out = 0;
+// Validation and the host-side constants of a search.  Covers the whole reference (or the one contig of chrom_index);
+// a chunked search narrows tile_lo / n_tiles / bases per lane afterwards.
+static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params, SearchPlan& pl) {
+  if (!guides || !params) return fail(ctx, CALITAS_EINVAL, "NULL argument");
   if (ctx->device < 0) return fail(ctx, CALITAS_ENODEV, "host-only context: calitas_search needs a GPU (there is no CPU fallback)");
-  if (!ctx->has_ref) return fail(ctx, CALITAS_ESTATE, "calitas_set_reference has not been called");
+  if (!ref_owner(ctx)->has_ref) return fail(ctx, CALITAS_ESTATE, "calitas_set_reference has not been called");
   if (n_guides <= 0 || n_guides > MAX_GUIDES) return fail(ctx, CALITAS_EINVAL, "n_guides must be 1..64");
   const calitas_params_t& p = *params;
   if (p.window_size <= 0 || p.window_size > 60000) return fail(ctx, CALITAS_EINVAL, "window-size must be 1..60000");
   if (p.max_guide_diffs < 0 || p.max_pam_mismatches < 0 || p.max_gaps_between_guide_and_pam < 0 || p.max_gaps_between_guide_and_pam > 16)
     return fail(ctx, CALITAS_EINVAL, "limits out of range (max-gaps-between-guide-and-pam must be 0..16)");
-  const PackedRef& ref = ctx->ref;
+  const PackedRef& ref = ref_owner(ctx)->ref;
   if (p.chrom_index >= (int)ref.contigs.size()) return fail(ctx, CALITAS_EINVAL, "chrom_index out of range");
-  const Scores sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
-  const int max_total = p.max_total_diffs >= 0 ? p.max_total_diffs : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;
-
-  std::vector<GuideHost> gh(n_guides);
-  std::vector<GuideDev> gd(n_guides);
-  int step = 0;
+  pl.p = p; pl.n_guides = n_guides;
+  pl.sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
+  pl.max_total = p.max_total_diffs >= 0 ? p.max_total_diffs : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;
+  pl.gh.assign(n_guides, GuideHost());
+  pl.gd.assign(n_guides, GuideDev());
   for (int i = 0; i < n_guides; i++) {
-    std::string e = make_guide_host(guides[i], gh[i]);
-    if (e.empty()) e = build_guide_dev(gh[i], p, sc, p.max_guide_diffs, p.max_pam_mismatches, gd[i]);
+    std::string e = make_guide_host(guides[i], pl.gh[i]);
+    if (e.empty()) e = build_guide_dev(pl.gh[i], p, pl.sc, p.max_guide_diffs, p.max_pam_mismatches, pl.gd[i]);
     if (!e.empty()) return fail(ctx, CALITAS_EINVAL, "guide " + std::to_string(i) + ": " + e);
     // SR:529-530: the window step depends on the CLI guide length; one pass shares one tiling
-    int overlap = gh[i].cli_length + p.max_guide_diffs + p.max_gaps_between_guide_and_pam - 1;
+    int overlap = pl.gh[i].cli_length + p.max_guide_diffs + p.max_gaps_between_guide_and_pam - 1;
     int s = p.window_size - overlap;
     if (s <= 0) return fail(ctx, CALITAS_EINVAL, "window-size is not larger than guide length + max-guide-diffs + max-gaps - 1");
-    if (i == 0) step = s;
-    else if (s != step) return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
-    if ((gd[i].L + gd[i].scan_max_edits + 15) / 16 > ref.chunk / 16) return fail(ctx, CALITAS_EINVAL, "scan warm-up exceeds the lane chunk");
+    if (i == 0) pl.step = s;
+    else if (s != pl.step) return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
+    if ((pl.gd[i].L + pl.gd[i].scan_max_edits + 15) / 16 > ref.chunk / 16) return fail(ctx, CALITAS_EINVAL, "scan warm-up exceeds the lane chunk");
   }
-
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
   // Strip slabs (align_kernel -> trace_kernel): fixed size and fixed address per (record, window slot).
-  const uint32_t slots_per_rec = (uint32_t)((p.window_size + 14) / step + 1);   // windows a 16-base word can fall into
-  if (slots_per_rec > 8) return fail(ctx, CALITAS_EINVAL, "window step is too small relative to the window size (more than 8 windows per position)");
-  uint32_t slab_bytes = 0;
+  pl.slots_per_rec = (uint32_t)((p.window_size + 14) / pl.step + 1);   // windows a 16-base word can fall into
+  if (pl.slots_per_rec > 8) return fail(ctx, CALITAS_EINVAL, "window step is too small relative to the window size (more than 8 windows per position)");
+  pl.slab_bytes = 0;
   for (int i = 0; i < n_guides; i++) {
-    const uint32_t ncols_max = 16 + gd[i].span + 1;
+    const uint32_t ncols_max = 16 + pl.gd[i].span + 1;
     const uint32_t stride_max = (ncols_max + 4) & ~3u;
     const uint32_t ntb_max = (ncols_max + p.max_gaps_between_guide_and_pam + MAX_PAM_LEN + 3) & ~3u;
-    slab_bytes = std::max<uint32_t>(slab_bytes, (uint32_t)((sizeof(SlabHeader) + ntb_max + gd[i].L * stride_max + 15) & ~15u));
+    pl.slab_bytes = std::max<uint32_t>(pl.slab_bytes, (uint32_t)((sizeof(SlabHeader) + ntb_max + pl.gd[i].L * stride_max + 15) & ~15u));
   }
-  const uint64_t slab_per_rec = (uint64_t)slab_bytes * slots_per_rec;
-  {
-    uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, ref.total_bases / 8 + 1024));
-    int rc = ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), slab_per_rec);
+  pl.slab_per_rec = (uint64_t)pl.slab_bytes * pl.slots_per_rec;
+  pl.tile_lo = 0; pl.n_tiles = (uint32_t)ref.tiles.size();
+  pl.bases = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
+  return CALITAS_OK;
+}
+
+// The device window table for (window size, step) lives with the reference; (re)built on `stream` when the tiling changes.
+static int ensure_window_table(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
+  calitas_ctx* o = ref_owner(ctx);
+  if (o->win_W == pl.p.window_size && o->win_step == pl.step) return CALITAS_OK;
+  const PackedRef& ref = o->ref;
+  std::vector<uint64_t> wb(ref.contigs.size() + 1, 0);
+  for (size_t c = 0; c < ref.contigs.size(); c++) wb[c + 1] = wb[c] + window_count(ref.contigs[c].len, pl.step);
+  const uint64_t nw = wb.back();
+  if (!o->d_win_base) HIP_TRY(ctx, hipMalloc((void**)&o->d_win_base, wb.size() * sizeof(uint64_t)));
+  if (nw > o->win_cap) {
+    (void)hipFree(o->d_win); o->d_win = nullptr; o->win_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&o->d_win, std::max<uint64_t>(1, nw) * sizeof(int2)));
+    o->win_cap = nw;
+  }
+  HIP_TRY(ctx, hipMemcpy(o->d_win_base, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, launch_window_table(o->d_runs, (int64_t)ref.runs.size(), o->d_contigs, o->d_win_base, (int)ref.contigs.size(), nw,
+                                   pl.p.window_size, pl.step, o->d_win, stream));
+  o->win_W = pl.p.window_size; o->win_step = pl.step;
+  return CALITAS_OK;
+}
+
+static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& sa, AlignArgs& aa) {
+  const calitas_ctx* o = ref_owner(ctx);
+  const PackedRef& ref = o->ref;
+  const calitas_params_t& p = pl.p;
+  sa = ScanArgs{};
+  sa.codes = o->d_codes; sa.mask = o->d_mask; sa.tiles = o->d_tiles; sa.guides = ctx->d_guides;
+  sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
+  sa.n_guides = pl.n_guides; sa.chrom_index = p.chrom_index; sa.tile_offset = pl.tile_lo;
+  sa.debug_skip = std::getenv("CALITAS_DEBUG_SCAN") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SCAN")) : 0u;
+  aa = AlignArgs{};
+  aa.codes = o->d_codes; aa.mask = o->d_mask; aa.runs = o->d_runs; aa.n_runs = (int64_t)ref.runs.size();
+  aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
+  aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
+  aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
+  aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
+  aa.debug_skip = std::getenv("CALITAS_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SKIP")) : 0u;
+  aa.sp.window_size = p.window_size; aa.sp.step = pl.step; aa.sp.n_guides = pl.n_guides;
+  aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
+  aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
+  aa.sp.max_diffs_filtering = p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;   // SGA:249
+  aa.sp.match = pl.sc.match; aa.sp.mismatch = pl.sc.mismatch; aa.sp.pam_match = pl.sc.pam_match; aa.sp.pam_mismatch = pl.sc.pam_mismatch;
+  aa.sp.query_gap = pl.sc.query_gap; aa.sp.target_gap = pl.sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score; aa.sp.chrom_index = p.chrom_index;
+}
+
+// Device buffers of one lane for this plan (allocation only).
+static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
+  const uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, pl.bases / 8 + 1024));
+  return ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), pl.slab_per_rec);
+}
+
+// Guides, cleared counters and the scan kernel of this lane, queued on `stream` (the lane's own, or the shared scan
+// stream of a chunked search); ev[0] / ev[1] bracket the kernel.
+static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides, hipMemcpyHostToDevice, stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), stream));
+  ScanArgs sa; AlignArgs aa;
+  fill_kernel_args(ctx, pl, sa, aa);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+  HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+  return CALITAS_OK;
+}
+
+// calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
+// (dev->valid), and *out stays NULL.  prelaunched: the scan stage of this lane was queued by the caller on another stream
+// and ctx->stream already waits for it; an overflow then fails the call instead of retrying.
+static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** out, uint64_t* n_out, DeviceSel* dev, bool prelaunched) {
+  const auto t_call = std::chrono::steady_clock::now();
+  *out = nullptr; *n_out = 0;
+  const calitas_params_t& p = pl.p;
+  const PackedRef& ref = ref_owner(ctx)->ref;
+  const int n_guides = pl.n_guides, step = pl.step, max_total = pl.max_total;
+  const std::vector<GuideHost>& gh = pl.gh;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!prelaunched) {
+    int rc = lane_prepare(ctx, pl);
+    if (rc) return rc;
+    rc = ensure_window_table(ctx, pl, ctx->stream);
     if (rc) return rc;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, gd.data(), sizeof(GuideDev) * n_guides, hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->win_W != p.window_size || ctx->win_step != step) {   // (re)build the device window table for this tiling
-    std::vector<uint64_t> wb(ref.contigs.size() + 1, 0);
-    for (size_t c = 0; c < ref.contigs.size(); c++) wb[c + 1] = wb[c] + window_count(ref.contigs[c].len, step);
-    const uint64_t nw = wb.back();
-    if (!ctx->d_win_base) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_win_base, wb.size() * sizeof(uint64_t)));
-    if (nw > ctx->win_cap) {
-      (void)hipFree(ctx->d_win); ctx->d_win = nullptr; ctx->win_cap = 0;
-      HIP_TRY(ctx, hipMalloc((void**)&ctx->d_win, std::max<uint64_t>(1, nw) * sizeof(int2)));
-      ctx->win_cap = nw;
-    }
-    HIP_TRY(ctx, hipMemcpy(ctx->d_win_base, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, launch_window_table(ctx->d_runs, (int64_t)ref.runs.size(), ctx->d_contigs, ctx->d_win_base, (int)ref.contigs.size(), nw,
-                                     p.window_size, step, ctx->d_win, ctx->stream));
-    ctx->win_W = p.window_size; ctx->win_step = step;
-  }
-
   calitas_timing_t tm{};
-  tm.bases_scanned = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
+  tm.bases_scanned = pl.bases;
   tm.packed_bytes = (tm.bases_scanned + 3) / 4;
-  const uint32_t n_tiles = (uint32_t)ref.tiles.size();
   uint32_t n_rec = 0, n_raw = 0;
   for (;;) {
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
-    ScanArgs sa{};
-    sa.codes = ctx->d_codes; sa.mask = ctx->d_mask; sa.tiles = ctx->d_tiles; sa.guides = ctx->d_guides;
-    sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
-    sa.n_guides = n_guides; sa.chrom_index = p.chrom_index;
-    sa.debug_skip = std::getenv("CALITAS_DEBUG_SCAN") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SCAN")) : 0u;
-    AlignArgs aa{};
-    aa.codes = ctx->d_codes; aa.mask = ctx->d_mask; aa.runs = ctx->d_runs; aa.n_runs = (int64_t)ref.runs.size();
-    aa.contigs = ctx->d_contigs; aa.tiles = ctx->d_tiles; aa.win_base = ctx->d_win_base; aa.win = ctx->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
-    aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
-    aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
-    aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = slab_bytes; aa.slots_per_rec = slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
-    aa.debug_skip = std::getenv("CALITAS_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SKIP")) : 0u;
-    aa.sp.window_size = p.window_size; aa.sp.step = step; aa.sp.n_guides = n_guides;
-    aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
-    aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
-    aa.sp.max_diffs_filtering = p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;   // SGA:249
-    aa.sp.match = sc.match; aa.sp.mismatch = sc.mismatch; aa.sp.pam_match = sc.pam_match; aa.sp.pam_mismatch = sc.pam_mismatch;
-    aa.sp.query_gap = sc.query_gap; aa.sp.target_gap = sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score; aa.sp.chrom_index = p.chrom_index;
-
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(ctx, launch_scan(sa, ref.chunk, n_tiles, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (!prelaunched) {
+      int rc = launch_scan_stage(ctx, pl, ctx->stream);
+      if (rc) return rc;
+    }
+    ScanArgs sa; AlignArgs aa;
+    fill_kernel_args(ctx, pl, sa, aa);
     HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
     HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
@@ -521,25 +604,20 @@ static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
     if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
     if (n_rec > ctx->rec_cap || n_raw > ctx->raw_cap) {
+      if (prelaunched) return fail(ctx, CALITAS_ESTATE, "lane buffers overflowed");   // the caller reruns unchunked
       tm.retries++;
       uint64_t nr = n_rec > ctx->rec_cap ? (uint64_t)n_rec + n_rec / 4 : ctx->rec_cap;
       uint64_t nw = n_raw > ctx->raw_cap ? (uint64_t)n_raw * 2 : ctx->raw_cap;
       if (n_rec > ctx->rec_cap)   // the raw count was cut short as well: scale it with the record count
         nw = std::max<uint64_t>(nw, (uint64_t)((double)n_raw * nr / std::max<uint32_t>(1, ctx->rec_cap)) + 1024);
       if (nr > 0xFFFFFFF0ull || nw > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
-      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw, slab_per_rec);
+      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw, pl.slab_per_rec);
       if (rc) return rc;
       continue;
     }
     break;
   }
-  if (n_raw > ctx->h_raw_cap) {
-    if (ctx->h_raw) (void)hipHostFree(ctx->h_raw);
-    ctx->h_raw = nullptr; ctx->h_raw_cap = 0;
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_raw, (size_t)ctx->raw_cap * sizeof(RawAln), hipHostMallocDefault));
-    ctx->h_raw_cap = ctx->raw_cap;
-  }
-  const RawAln* raw = ctx->h_raw;
+  const calitas_ctx* own = ref_owner(ctx);
   // ---- per-window filter (SGA:315-320): on the GPU (select.hip) unless the tiling does not fit its sort key, a window
   //      exceeds its group limit, or CALITAS_HOST_FILTER asks for the host implementation of the same stage ----
   uint64_t max_wins = 0;
@@ -550,7 +628,7 @@ static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
   if (gpu_select) {
     const RawAln* d_final = nullptr;
     const uint32_t* d_cnt = nullptr;
-    HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, ctx->d_win_base, ctx->d_win, max_total, p.max_overlap,
+    HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, max_total, p.max_overlap,
                             ctx->stream, &d_final, &d_cnt));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -560,7 +638,15 @@ static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
       d_sel = d_final;
     }
   }
-  if (!gpu_select && n_raw) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  if (!gpu_select && n_raw) {
+    if (n_raw > ctx->h_raw_cap) {   // pinned staging for the copy-back
+      if (ctx->h_raw) (void)hipHostFree(ctx->h_raw);
+      ctx->h_raw = nullptr; ctx->h_raw_cap = 0;
+      HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_raw, (size_t)ctx->raw_cap * sizeof(RawAln), hipHostMallocDefault));
+      ctx->h_raw_cap = ctx->raw_cap;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
@@ -574,7 +660,7 @@ static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
     tm.accepted_alignments = n_sel;
     tm.candidate_columns = ctx->h_counters[4];
     if (dev) {   // calitas_search_hits goes on from the device copy
-      dev->valid = true; dev->d_final = d_sel; dev->n_sel = n_sel; dev->step = step; dev->gh = gh; dev->gd = gd; dev->t_call = t_call;
+      dev->valid = true; dev->d_final = d_sel; dev->n_sel = n_sel; dev->t_call = t_call;
       ctx->timing = tm;
       return CALITAS_OK;
     }
@@ -593,9 +679,10 @@ static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
     *out = result;
     return CALITAS_OK;
   }
-  if (dev) { dev->step = step; dev->gh = gh; dev->gd = gd; dev->t_call = t_call; }
+  if (dev) dev->t_call = t_call;
 
   // ---- host: restore the reference's enumeration order, then the per-window filter (SGA:315-320) ----
+  const RawAln* raw = ctx->h_raw;
   // Raw records arrive in atomic-append order.  They are bucketed by (guide, contig, 4096-window chunk), each bucket is
   // sorted by (window, strand list, end column, PAM) = fgbio's enumeration order (ascending end column) followed
   // by the PAM order of extendAndFilterRight (SGA:455), filtered window by window, and the buckets are concatenated.
@@ -690,6 +777,18 @@ static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
   return CALITAS_OK;
 }
 
+static int search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                       calitas_aln_t** out, uint64_t* n_out, DeviceSel* dev, SearchPlan* plan_out) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!out || !n_out) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *out = nullptr; *n_out = 0;
+  SearchPlan local;
+  SearchPlan& pl = plan_out ? *plan_out : local;
+  int rc = plan_search(ctx, n_guides, guides, params, pl);
+  if (rc) return rc;
+  return search_run(ctx, pl, out, n_out, dev, false);
+}
+
 static void default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp) {
   version = aligner_version ? aligner_version : "";
   stamp = time_stamp ? time_stamp : "";
@@ -703,96 +802,336 @@ static void default_version_and_stamp(const char* aligner_version, const char* t
   }
 }
 
+// ---- calitas_search_hits ------------------------------------------------------------------------------------------------
+
+// What one lane contributes to a hits.txt: rows on the device, or rows built by the host stages when a device stage declined.
+struct LaneText {
+  int rc = CALITAS_OK;
+  const char* d_text = nullptr;
+  uint64_t bytes = 0, rows = 0;
+  bool on_host = false;
+  std::string host_rows;
+  calitas_timing_t tm{};
+};
+
+// One lane from the scan stage (queued here, or already queued by the caller) to its finished rows.
+static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, const std::string& guide_id,
+                     const std::string& version, const std::string& stamp, LaneText& lt) {
+  calitas_ctx* own = ref_owner(lane);
+  const PackedRef& ref = own->ref;
+  const calitas_params_t& p = pl.p;
+  const GuideHost& gh = pl.gh[0];
+  DeviceSel dev;
+  calitas_aln_t* alns = nullptr;
+  uint64_t n_alns = 0;
+  int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched);
+  if (rc) return rc;
+  lt.tm = lane->timing;
+  if (dev.valid && !std::getenv("CALITAS_HOST_HITS")) {
+    // removeOverlaps, ReferenceHit.sort and the rows on the device (hits.hip); only text crosses PCIe
+    int max_pam = 0;
+    for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
+    const int score_hi = pl.sc.match * (int)gh.protospacer.size() + pl.sc.pam_match * max_pam;
+    const int worst_gap = std::max(iabs(pl.sc.query_gap), std::max(iabs(pl.sc.target_gap), iabs(pl.sc.mismatch)));
+    const int score_lo = pl.gd[0].min_guide_score - iabs(pl.sc.pam_mismatch) * max_pam - worst_gap * (p.max_gaps_between_guide_and_pam + 1);
+    if (hits_supported(ref.contigs.size(), p.max_overlap, score_lo, score_hi)) {
+      if (lane->hits_names_serial != own->ref_serial) {
+        HIP_TRY(lane, hits_set_names(&lane->hits, ref.names));
+        lane->hits_names_serial = own->ref_serial;
+      }
+      HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
+      HitsResult res{};
+      HIP_TRY(lane, hipEventRecord(lane->ev[0], lane->stream));
+      HIP_TRY(lane, hits_run(&lane->hits, hr, dev.d_final, dev.n_sel, lane->d_guides, own->d_win_base, own->d_win, rs, p.max_overlap, score_hi,
+                             pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, lane->stream, &res));
+      HIP_TRY(lane, hipEventRecord(lane->ev[1], lane->stream));
+      if (res.flags == 0) {
+        lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows;
+        return CALITAS_OK;
+      }
+      if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
+    }
+  }
+  // host tail: the same stages as calitas_hits_tsv
+  if (dev.valid) {
+    rc = convert_selected(lane, dev.d_final, dev.n_sel, pl.gh, p, pl.step, &alns);
+    if (rc) return rc;
+    n_alns = dev.n_sel;
+  }
+  uint64_t rows = 0;
+  char* text = hits_tsv(ref, gh, guide_id, p, alns, n_alns, version, stamp, &rows, own->pool, out_alloc, nullptr, 0);
+  calitas_free(alns);
+  if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
+  lt.on_host = true;
+  lt.host_rows.assign(text + rs.header.size());
+  calitas_free(text);
+  lt.bytes = lt.host_rows.size(); lt.rows = rows;
+  return CALITAS_OK;
+}
+
+static void destroy_lanes(calitas_ctx* ctx);
+
+// Child contexts of a chunked search: own stream (high priority), buffers and scratch; the parent's reference.
+static int ensure_lanes(calitas_ctx* ctx, size_t k) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (!ctx->scan_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, least));
+  if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest));
+  while (ctx->lanes.size() < k) {
+    calitas_ctx* c = new calitas_ctx();
+    c->device = ctx->device; c->parent = ctx;
+    bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) == hipSuccess;
+    for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->scan_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->rows_ready, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES) == hipSuccess;
+    ctx->lanes.push_back(c);
+    if (!ok) { destroy_lanes(ctx); return fail(ctx, CALITAS_EHIP, "could not create a search lane"); }
+  }
+  return CALITAS_OK;
+}
+
+static void destroy_lanes(calitas_ctx* ctx) {
+  for (calitas_ctx* c : ctx->lanes) calitas_destroy(c);
+  ctx->lanes.clear();
+  if (ctx->scan_stream) { (void)hipStreamDestroy(ctx->scan_stream); ctx->scan_stream = nullptr; }
+  if (ctx->copy_stream) { (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
+}
+
+// Contig ranges [first, last) of a chunked search: cut at contig boundaries (removeOverlaps groups and the final sort never
+// cross a contig), sized by `weights`.
+static std::vector<std::pair<int, int>> chunk_ranges(const PackedRef& ref, const std::vector<double>& weights) {
+  const int n = (int)ref.contigs.size();
+  std::vector<std::pair<int, int>> out;
+  double wsum = 0;
+  for (double w : weights) wsum += w;
+  uint64_t total = ref.total_bases, acc = 0;
+  double target = 0;
+  int first = 0;
+  size_t k = 0;
+  for (int c = 0; c < n && k + 1 < weights.size(); c++) {
+    acc += ref.contigs[c].len;
+    const double goal = (target + weights[k]) / wsum * (double)total;
+    const uint64_t next = c + 1 < n ? ref.contigs[c + 1].len : 0;
+    // close the chunk after contig c when that lands nearer to the goal than taking one more contig would
+    if ((double)acc >= goal || (double)acc + (double)next / 2 > goal) {
+      if (c + 1 < n) { out.emplace_back(first, c + 1); first = c + 1; target += weights[k]; k++; }
+    }
+  }
+  out.emplace_back(first, n);
+  return out;
+}
+
+static int search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                            const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+  const auto t_call = std::chrono::steady_clock::now();
+  *tsv = nullptr;
+  if (tsv_bytes) *tsv_bytes = 0;
+  if (n_rows) *n_rows = 0;
+  SearchPlan pl;
+  int rc = plan_search(ctx, 1, guide, params, pl);
+  if (rc) return rc;
+  const PackedRef& ref = ctx->ref;
+  std::string version, stamp;
+  default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+  const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  // ---- how many lanes: one pass over the whole reference, or contig ranges pipelined against each other ----
+  std::vector<double> weights;
+  if (const char* e = std::getenv("CALITAS_CHUNKS")) {
+    // "3" = three equal chunks, "5:3:2" = relative sizes
+    for (const char* q = e; *q;) {
+      char* end = nullptr;
+      double v = std::strtod(q, &end);
+      if (end == q) break;
+      weights.push_back(v);
+      q = *end == ':' ? end + 1 : end;
+    }
+    if (weights.size() == 1) { int k = std::max(1, std::min(16, (int)weights[0])); weights.assign((size_t)k, 1.0); }
+    for (double w : weights) if (!(w > 0)) { weights.clear(); break; }
+  } else if (ref.total_bases >= (512ull << 20)) {
+    weights = {5, 4};      // measured on hg38-sized input: more lanes cost more in per-lane fixed work than they hide
+  }
+  std::vector<std::pair<int, int>> ranges;
+  if (weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);
+  const size_t K = ranges.size() > 1 ? ranges.size() : 1;
+
+  std::vector<LaneText> parts(K);
+  std::vector<calitas_ctx*> lanes(K, ctx);
+  char* text = nullptr;
+  size_t capacity = 0;
+  const size_t hlen = rs.header.size();
+  std::mutex copy_mu;
+  auto alloc_text = [&](size_t body) {
+    capacity = body;
+    text = (char*)out_alloc_impl(hlen + body + 1, true);
+    if (text) std::memcpy(text, rs.header.data(), hlen);
+    return text != nullptr;
+  };
+  // copies lane c's rows to their place (offset = header + rows of the lanes before it)
+  auto place = [&](size_t c, size_t offset) -> int {
+    LaneText& lt = parts[c];
+    if (!lt.bytes) return CALITAS_OK;
+    if (lt.on_host) { std::memcpy(text + hlen + offset, lt.host_rows.data(), lt.bytes); return CALITAS_OK; }
+    calitas_ctx* lane = lanes[c];
+    if (lane->parent) {
+      // all text copies of a chunked call go through one stream: PCIe is one resource, and one stream is one thing to warm up
+      HIP_TRY(lane, hipEventRecord(lane->rows_ready, lane->stream));
+      {
+        std::lock_guard<std::mutex> lk(copy_mu);
+        HIP_TRY(lane, hipStreamWaitEvent(ctx->copy_stream, lane->rows_ready, 0));
+        HIP_TRY(lane, hipEventRecord(lane->ev[2], ctx->copy_stream));
+        HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIP_TRY(lane, hipEventRecord(lane->ev[3], ctx->copy_stream));
+      }
+      HIP_TRY(lane, hipEventSynchronize(lane->ev[3]));
+    } else {
+      HIP_TRY(lane, hipEventRecord(lane->ev[2], lane->stream));
+      HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, lane->stream));
+      HIP_TRY(lane, hipEventRecord(lane->ev[3], lane->stream));
+      HIP_TRY(lane, hipStreamSynchronize(lane->stream));
+    }
+    float ms = 0;
+    if (!lt.on_host) { (void)hipEventElapsedTime(&ms, lane->ev[0], lane->ev[1]); lt.tm.hits_kernel_ms = ms; }
+    (void)hipEventElapsedTime(&ms, lane->ev[2], lane->ev[3]); lt.tm.hits_copy_ms = ms;
+    return CALITAS_OK;
+  };
+
+  bool chunked = K > 1;
+  if (chunked) {
+    rc = ensure_lanes(ctx, K);
+    if (rc) return rc;
+    std::vector<SearchPlan> plans(K, pl);
+    for (size_t c = 0; c < K && !rc; c++) {
+      lanes[c] = ctx->lanes[c];
+      SearchPlan& q = plans[c];
+      q.tile_lo = (uint32_t)(ref.contigs[ranges[c].first].gbase / ref.tile);
+      const uint32_t tile_hi = ranges[c].second < (int)ref.contigs.size() ? (uint32_t)(ref.contigs[ranges[c].second].gbase / ref.tile) : (uint32_t)ref.tiles.size();
+      q.n_tiles = tile_hi - q.tile_lo;
+      q.bases = 0;
+      for (int k = ranges[c].first; k < ranges[c].second; k++) q.bases += ref.contigs[k].len;
+      rc = lane_prepare(lanes[c], q);
+      if (rc) ctx->err = lanes[c]->err;
+    }
+    if (rc) return rc;
+    // all scans go to one low-priority stream in chunk order; each lane's own (high-priority) stream picks its chunk up
+    // when its scan is done, so the tail of chunk c runs while chunk c+1 is still being scanned
+    rc = ensure_window_table(ctx, pl, ctx->scan_stream);
+    if (rc) return rc;
+    for (size_t c = 0; c < K; c++) {
+      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);
+      if (rc) { ctx->err = lanes[c]->err; break; }
+      HIP_TRY(ctx, hipEventRecord(lanes[c]->scan_done, ctx->scan_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0));
+    }
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }
+    auto guess = [](size_t last) { return last + last / 4 + (1u << 20); };   // the next call's text is about as long as the last one's
+    if (!alloc_text(guess(ctx->last_text_bytes))) {
+      (void)hipDeviceSynchronize();
+      return fail(ctx, CALITAS_EINVAL, "out of memory");
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> done(K, 0);
+    std::vector<char> placed(K, 0);
+    std::vector<std::thread> threads;
+    for (size_t c = 0; c < K; c++) {
+      threads.emplace_back([&, c] {
+        (void)hipSetDevice(ctx->device);
+        LaneText& lt = parts[c];
+        lt.rc = lane_rows(lanes[c], plans[c], true, rs, guide_id, version, stamp, lt);
+        size_t offset = 0;
+        bool ok = lt.rc == CALITAS_OK;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          done[c] = 1;
+          cv.notify_all();
+          cv.wait(lk, [&] { for (size_t i = 0; i < c; i++) if (!done[i]) return false; return true; });
+          for (size_t i = 0; i < c; i++) { offset += parts[i].bytes; ok = ok && parts[i].rc == CALITAS_OK; }
+        }
+        if (ok && offset + lt.bytes <= capacity) {
+          int r = place(c, offset);
+          if (r) lt.rc = r; else placed[c] = 1;
+        }
+      });
+    }
+    for (auto& t : threads) t.join();
+    rc = CALITAS_OK;
+    bool overflow = false;
+    for (size_t c = 0; c < K; c++) {
+      if (parts[c].rc == CALITAS_ESTATE) overflow = true;
+      else if (parts[c].rc && !rc) { rc = parts[c].rc; ctx->err = lanes[c]->err; }
+    }
+    if (rc || overflow) {
+      (void)hipDeviceSynchronize();
+      calitas_free(text); text = nullptr;
+      if (rc) return rc;
+      if (trace) std::fprintf(stderr, "[calitas] search_hits: a lane's buffers overflowed, rerunning in one pass\n");
+      chunked = false;
+      parts.assign(1, LaneText()); lanes.assign(1, ctx);
+    } else {
+      size_t total = 0;
+      for (auto& lt : parts) total += lt.bytes;
+      bool all = true;
+      for (size_t c = 0; c < K; c++) all = all && (placed[c] || parts[c].bytes == 0);
+      if (!all) {   // the guess was too small: place everything again in a buffer of the right size
+        calitas_free(text);
+        if (!alloc_text(guess(total))) return fail(ctx, CALITAS_EINVAL, "out of memory");   // big enough for the next call's guess as well
+        size_t off = 0;
+        for (size_t c = 0; c < K; c++) { rc = place(c, off); if (rc) { ctx->err = lanes[c]->err; calitas_free(text); return rc; } off += parts[c].bytes; }
+      }
+    }
+  }
+  if (!chunked) {
+    rc = lane_rows(ctx, pl, false, rs, guide_id, version, stamp, parts[0]);
+    if (rc) return rc;
+    if (!alloc_text((size_t)parts[0].bytes)) return fail(ctx, CALITAS_EINVAL, "out of memory");
+    rc = place(0, 0);
+    if (rc) { calitas_free(text); return rc; }
+  }
+  size_t total = hlen;
+  calitas_timing_t tm{};
+  uint64_t rows = 0;
+  for (auto& lt : parts) {
+    total += lt.bytes; rows += lt.rows;
+    tm.scan_kernel_ms += lt.tm.scan_kernel_ms; tm.align_kernel_ms += lt.tm.align_kernel_ms; tm.gpu_total_ms += lt.tm.gpu_total_ms;
+    tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
+    tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
+    tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries;
+    tm.hits_kernel_ms += lt.tm.hits_kernel_ms; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+  }
+  text[total] = 0;
+  tm.hit_rows = rows; tm.hits_bytes = total; tm.reserved = (uint32_t)parts.size();
+  ctx->timing = tm;
+  ctx->last_text_bytes = total;
+  if (trace)
+    std::fprintf(stderr, "[calitas] search_hits: %zu lane(s), scan %.3f ms, align %.3f ms, hits kernels %.3f ms, text copy %.3f ms (sums over lanes), call %.3f ms (%llu accepted, %llu rows, %zu bytes)\n",
+                 parts.size(), tm.scan_kernel_ms, tm.align_kernel_ms, tm.hits_kernel_ms, tm.hits_copy_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),
+                 (unsigned long long)tm.accepted_alignments, (unsigned long long)rows, total);
+  *tsv = text;
+  if (tsv_bytes) *tsv_bytes = total;
+  if (n_rows) *n_rows = rows;
+  return CALITAS_OK;
+}
+
 extern "C" {
 
 int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                    calitas_aln_t** out, uint64_t* n_out) {
-  return search_impl(ctx, n_guides, guides, params, out, n_out, nullptr);
+  return search_impl(ctx, n_guides, guides, params, out, n_out, nullptr, nullptr);
 }
 
 int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                         const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
   if (!ctx) return CALITAS_EINVAL;
   if (!guide || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "NULL argument");
-  *tsv = nullptr;
-  if (tsv_bytes) *tsv_bytes = 0;
-  if (n_rows) *n_rows = 0;
-  DeviceSel dev;
-  calitas_aln_t* alns = nullptr;
-  uint64_t n_alns = 0;
-  int rc = search_impl(ctx, 1, guide, params, &alns, &n_alns, &dev);
-  if (rc) return rc;
-  const calitas_params_t& p = *params;
-  const PackedRef& ref = ctx->ref;
-  const GuideHost& gh = dev.gh[0];
-  std::string version, stamp;
-  default_version_and_stamp(aligner_version, time_stamp, version, stamp);
-  const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
-
-  if (dev.valid && !std::getenv("CALITAS_HOST_HITS")) {
-    // removeOverlaps, ReferenceHit.sort and the rows on the device (hits.hip); only text crosses PCIe
-    const Scores sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
-    int max_pam = 0;
-    for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
-    const int score_hi = sc.match * (int)gh.protospacer.size() + sc.pam_match * max_pam;
-    const int worst_gap = std::max(iabs(sc.query_gap), std::max(iabs(sc.target_gap), iabs(sc.mismatch)));
-    const int score_lo = dev.gd[0].min_guide_score - iabs(sc.pam_mismatch) * max_pam - worst_gap * (p.max_gaps_between_guide_and_pam + 1);
-    if (hits_supported(ref.contigs.size(), p.max_overlap, score_lo, score_hi)) {
-      if (ctx->hits_names_serial != ctx->ref_serial) {
-        HIP_TRY(ctx, hits_set_names(&ctx->hits, ref.names));
-        ctx->hits_names_serial = ctx->ref_serial;
-      }
-      const RowStrings rs = make_row_strings(ref, gh, guide_id ? guide_id : "", p, version, stamp);
-      HitsRef hr{ctx->d_codes, ctx->d_mask, ctx->d_runs, (int64_t)ref.runs.size(), ctx->d_contigs, (int)ref.contigs.size()};
-      HitsResult res{};
-      HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-      HIP_TRY(ctx, hits_run(&ctx->hits, hr, dev.d_final, dev.n_sel, ctx->d_guides, ctx->d_win_base, ctx->d_win, rs, p.max_overlap, score_hi,
-                            dev.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, ctx->stream, &res));
-      if (res.flags == 0) {
-        const size_t total = rs.header.size() + (size_t)res.text_bytes;
-        char* text = (char*)out_alloc(total + 1);
-        if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
-        std::memcpy(text, rs.header.data(), rs.header.size());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-        if (res.text_bytes)
-          HIP_TRY(ctx, hipMemcpyAsync(text + rs.header.size(), res.d_text, (size_t)res.text_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        text[total] = 0;
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->timing.hits_kernel_ms = ms;
-        (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->timing.hits_copy_ms = ms;
-        ctx->timing.hit_rows = res.n_rows;
-        ctx->timing.hits_bytes = total;
-        if (trace)
-          std::fprintf(stderr, "[calitas] search_hits: scan %.3f ms, align %.3f ms, search gpu total %.3f ms, hits kernels %.3f ms, text copy %.3f ms, call %.3f ms (%u accepted, %u rows, %zu bytes)\n",
-                       ctx->timing.scan_kernel_ms, ctx->timing.align_kernel_ms, ctx->timing.gpu_total_ms, ctx->timing.hits_kernel_ms,
-                       ctx->timing.hits_copy_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dev.t_call).count(),
-                       dev.n_sel, res.n_rows, total);
-        *tsv = text;
-        if (tsv_bytes) *tsv_bytes = total;
-        if (n_rows) *n_rows = res.n_rows;
-        return CALITAS_OK;
-      }
-      if (trace) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
-    }
-  }
-  // host tail: the same stages as calitas_hits_tsv
-  if (dev.valid) {
-    rc = convert_selected(ctx, dev.d_final, dev.n_sel, dev.gh, p, dev.step, &alns);
-    if (rc) return rc;
-    n_alns = dev.n_sel;
-  }
-  uint64_t rows = 0;
-  char* text = hits_tsv(ref, gh, guide_id ? guide_id : "", p, alns, n_alns, version, stamp, &rows, ctx->pool, out_alloc, nullptr, 0);
-  calitas_free(alns);
-  if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
-  ctx->timing.hit_rows = rows;
-  ctx->timing.hits_bytes = std::strlen(text);
-  *tsv = text;
-  if (tsv_bytes) *tsv_bytes = ctx->timing.hits_bytes;
-  if (n_rows) *n_rows = rows;
-  return CALITAS_OK;
+  return search_hits_impl(ctx, guide, guide_id ? guide_id : "", params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
 }
 
 int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out) {

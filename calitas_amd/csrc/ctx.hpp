@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/calitas_hip.h"
 #include "common.hpp"
@@ -47,6 +48,14 @@ struct calitas_ctx {
   SelectWork* select = nullptr;     // GPU per-window filter scratch
   HitsWork* hits = nullptr;         // GPU removeOverlaps / sort / rows scratch
   uint64_t ref_serial = 0, hits_names_serial = ~0ull;
+  // chunked calitas_search_hits: the parent owns the lanes and the stream all scans are queued on
+  calitas_ctx* parent = nullptr;    // set in a lane: the context whose reference and window table it uses
+  std::vector<calitas_ctx*> lanes;
+  hipStream_t scan_stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // parent: the text copies of all lanes
+  hipEvent_t scan_done = nullptr;   // lane: recorded on the parent's scan stream after this lane's scan
+  hipEvent_t rows_ready = nullptr;  // lane: recorded on its stream after its row kernels
+  uint64_t last_text_bytes = 0;
   WorkerPool* pool = nullptr;
   ~calitas_ctx() { delete pool; }
 };

@@ -17,6 +17,7 @@ struct ScanArgs {
   uint32_t rec_capacity;
   int32_t n_guides;
   int32_t chrom_index;
+  uint32_t tile_offset;    // first tile of this launch (a chunked search scans one contig range per launch)
   uint32_t debug_skip;     // profiling ablations (0 in production): 1 = never replay / emit
 };
 

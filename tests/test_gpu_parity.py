@@ -214,6 +214,31 @@ def test_device_filter_equals_host_filter(C, tmp_path, monkeypatch):
         assert len(dev) > 0 and dev == host, guide
 
 
+@pytest.mark.parametrize("chunks", ["2", "3", "4", "5:1", "1:1:6"])
+def test_chunked_search_hits_equals_one_pass(C, tmp_path, monkeypatch, chunks):
+    """calitas_search_hits cuts a large reference into contig ranges that flow through the stages as a pipeline (one lane
+    each); the text must not depend on how the reference is cut.  CALITAS_CHUNKS forces the cut on a small reference."""
+    guides = ["CTTGCCCCACAGGGCAGTAAnrg", "tttvAACCAACCAACCGGTTACGT"]
+    extra = [("tiny", "ACGTTGCA" * 6 + "CTTGCCCCACAGGGCAGTAATGG" + "TTGACA" * 5), ("empty-ish", "N" * 300),
+             ("rna", "ACGUACGUUUGGCAUCG" * 30 + "CUUGCCCCACAGGGCAGUAAUGG" + "ACGU" * 20)]
+    fa = synth_fasta(tmp_path, 31, guides, lengths=(60000, 25000, 90000, 12000), extra=extra)
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        for guide, kw in ((guides[0], dict(max_gaps_between_guide_and_pam=2)), (guides[1], dict(max_guide_diffs=4))):
+            params = C.make_params(**kw)
+            monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
+            one, n1 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            assert ctx.timing()["reserved"] == 1
+            monkeypatch.setenv("CALITAS_CHUNKS", chunks)
+            cut, n2 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            assert ctx.timing()["reserved"] > 1                      # number of lanes the call used
+            again, n3 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            assert n1 > 20 and (n1, one) == (n2, cut) == (n3, again)
+    finally:
+        ctx.close()
+
+
 def test_full_size_properties_ecoli_like(C):
     """BASELINE config 2 size (4.6 Mb): size-independent properties instead of a full oracle run --
     (1) every planted perfect site is found with 0 edits, (2) searching the reverse-complemented genome with the same
