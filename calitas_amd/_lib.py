@@ -48,7 +48,7 @@ class TimingT(ctypes.Structure):
     _fields_ = [("scan_kernel_ms", ctypes.c_double), ("align_kernel_ms", ctypes.c_double), ("gpu_total_ms", ctypes.c_double),
                 ("host_post_ms", ctypes.c_double), ("bases_scanned", ctypes.c_uint64), ("packed_bytes", ctypes.c_uint64),
                 ("scan_records", ctypes.c_uint64), ("candidate_columns", ctypes.c_uint64), ("raw_alignments", ctypes.c_uint64),
-                ("accepted_alignments", ctypes.c_uint64), ("retries", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("accepted_alignments", ctypes.c_uint64), ("retries", ctypes.c_uint32), ("lanes", ctypes.c_uint32),
                 ("hits_kernel_ms", ctypes.c_double), ("hits_copy_ms", ctypes.c_double), ("hit_rows", ctypes.c_uint64),
                 ("hits_bytes", ctypes.c_uint64)]
 

@@ -1106,7 +1106,7 @@ static int search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, cons
     tm.hits_kernel_ms += lt.tm.hits_kernel_ms; tm.hits_copy_ms += lt.tm.hits_copy_ms;
   }
   text[total] = 0;
-  tm.hit_rows = rows; tm.hits_bytes = total; tm.reserved = (uint32_t)parts.size();
+  tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = (uint32_t)parts.size();
   ctx->timing = tm;
   ctx->last_text_bytes = total;
   if (trace)

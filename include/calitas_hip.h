@@ -99,7 +99,7 @@ typedef struct {
   uint64_t raw_alignments;     /* alignments surviving PAM extension, before the per-window filter */
   uint64_t accepted_alignments;
   uint32_t retries;            /* re-runs caused by device buffer overflow */
-  uint32_t reserved;
+  uint32_t lanes;              /* contig ranges the last calitas_search_hits call pipelined (1 = one pass; 0 after calitas_search) */
   /* calitas_search_hits only */
   double hits_kernel_ms;       /* removeOverlaps + sorts + row text on the device */
   double hits_copy_ms;         /* the text's copy-back */

@@ -229,10 +229,10 @@ def test_chunked_search_hits_equals_one_pass(C, tmp_path, monkeypatch, chunks):
             params = C.make_params(**kw)
             monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
             one, n1 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
-            assert ctx.timing()["reserved"] == 1
+            assert ctx.timing()["lanes"] == 1
             monkeypatch.setenv("CALITAS_CHUNKS", chunks)
             cut, n2 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
-            assert ctx.timing()["reserved"] > 1                      # number of lanes the call used
+            assert ctx.timing()["lanes"] > 1                      # number of lanes the call used
             again, n3 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
             assert n1 > 20 and (n1, one) == (n2, cut) == (n3, again)
     finally:
