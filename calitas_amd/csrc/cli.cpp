@@ -108,17 +108,15 @@ int main(int argc, char** argv) {
     for (int32_t i = 0; i < n; i++) { const char* nm; uint64_t len; calitas_contig_name(ctx, i, &nm, &len); if (chrom == nm) p.chrom_index = i; }
     if (p.chrom_index < 0) { std::fprintf(stderr, "Unknown chromosome: %s\n", chrom.c_str()); calitas_destroy(ctx); return 1; }
   }
-  calitas_aln_t* alns = nullptr; uint64_t n_alns = 0;
-  if (calitas_search(ctx, 1, &g, &p, &alns, &n_alns) != CALITAS_OK) die("search");
-  char* tsv = nullptr; uint64_t rows = 0;
-  if (calitas_hits_tsv(ctx, &g, guide_id.c_str(), &p, alns, n_alns, nullptr, nullptr, &tsv, &rows) != CALITAS_OK) die("building hits");
+  char* tsv = nullptr; uint64_t rows = 0, bytes = 0;
+  if (calitas_search_hits(ctx, &g, guide_id.c_str(), &p, nullptr, nullptr, &tsv, &bytes, &rows) != CALITAS_OK) die("search");
   FILE* f = output.empty() ? stdout : std::fopen(output.c_str(), "w");
   if (!f) { std::fprintf(stderr, "cannot write %s\n", output.c_str()); return 1; }
-  std::fputs(tsv, f);
+  std::fwrite(tsv, 1, bytes, f);
   if (f != stdout) std::fclose(f);
   calitas_timing_t tm; calitas_get_timing(ctx, &tm);
-  std::fprintf(stderr, "calitas: %llu hits; scan %.3f ms, align %.3f ms, host filter %.3f ms\n", (unsigned long long)rows,
-               tm.scan_kernel_ms, tm.align_kernel_ms, tm.host_post_ms);
-  calitas_free(tsv); calitas_free(alns); calitas_destroy(ctx);
+  std::fprintf(stderr, "calitas: %llu hits; scan %.3f ms, align %.3f ms, filter + rows %.3f ms, text copy %.3f ms (%u lane%s)\n",
+               (unsigned long long)rows, tm.scan_kernel_ms, tm.align_kernel_ms, tm.hits_kernel_ms, tm.hits_copy_ms, tm.lanes, tm.lanes == 1 ? "" : "s");
+  calitas_free(tsv); calitas_destroy(ctx);
   return 0;
 }

@@ -239,6 +239,21 @@ def test_chunked_search_hits_equals_one_pass(C, tmp_path, monkeypatch, chunks):
         ctx.close()
 
 
+def test_cpp_cli_search_reference(C, tmp_path):
+    """The `calitas SearchReference` binary with the reference's flags (SearchReference.scala:452-470), FASTA in, hits.txt out."""
+    import subprocess
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    fa = synth_fasta(tmp_path, 41, [guide], lengths=(40000, 9000))
+    exe = os.path.join(os.path.dirname(os.path.abspath(C.__file__)), "calitas")
+    out = tmp_path / "cli_hits.txt"
+    r = subprocess.run([exe, "SearchReference", "-i", guide, "-I", "a", "-r", fa, "-o", str(out), "-d", "4", "-p", "1", "-g", "2", "-c", "ctg0"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert_same(C.read_hits(out.read_text()), oracle_rows(fa, guide, chrom="ctg0", d=4, p=1, g=2), "cli")
+    r = subprocess.run([exe, "SearchReference", "-i", guide, "-I", "a", "-r", fa, "-c", "nope"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Unknown chromosome" in r.stderr
+
+
 def test_full_size_properties_ecoli_like(C):
     """BASELINE config 2 size (4.6 Mb): size-independent properties instead of a full oracle run --
     (1) every planted perfect site is found with 0 edits, (2) searching the reverse-complemented genome with the same
