@@ -35,7 +35,7 @@ namespace calitas {
 namespace {
 
 constexpr int SCORE_BITS = 14;
-constexpr uint32_t CLUSTER_MAX = 1u << 14;
+constexpr uint32_t CLUSTER_MAX = 1u << 20;
 constexpr uint64_t DROPPED = ~0ull;
 
 struct HitRec {

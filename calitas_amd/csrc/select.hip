@@ -7,8 +7,9 @@
 //   3. filtered window by window, one lane per window: stable order by (score desc, gap bases asc) (GuideAlignment.scala:
 //      125-129), keep if edits <= maxTotalDiffs and no kept alignment of the same strand overlaps by more than maxOverlap;
 //   4. compacted in window order with an exclusive scan, so the host receives only accepted alignments, already ordered.
-// Windows with more than GROUP_MAX alignments (satellite repeats, PAM-less dense searches) raise a flag and the caller
-// falls back to the host implementation of the same stage for this search.
+// Windows with more than GROUP_MAX alignments (satellite repeats, PAM-less dense searches) go to filter_big_kernel, one wave
+// per window; only beyond 65 536 records or 4 096 kept alignments in one window does a flag send the caller to the host
+// implementation of the same stage for this search.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -66,14 +67,14 @@ __global__ void derive_kernel(const RawAln* raw, const uint32_t* vals, uint32_t 
 // One lane per sorted position; only group heads work.  kept[s] = number of survivors of the group starting at s (0 for
 // non-heads); their sorted positions, in output order, go to out_pos[s .. s + kept[s]).
 __global__ void filter_kernel(const uint64_t* keys, const Derived* der, uint32_t n, int max_total_diffs, int max_overlap,
-                              uint8_t* taken, uint32_t* kept, uint32_t* out_pos, uint32_t* flags) {
+                              uint8_t* taken, uint32_t* kept, uint32_t* out_pos, uint32_t* flags, uint32_t* big) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const uint64_t gid = keys[s] >> GROUP_SHIFT;
   if (s > 0 && (keys[s - 1] >> GROUP_SHIFT) == gid) { kept[s] = 0; return; }
   uint32_t e = s + 1;
   while (e < n && (keys[e] >> GROUP_SHIFT) == gid) e++;
-  if (e - s > (uint32_t)GROUP_MAX) { atomicOr(flags, 1u); kept[s] = 0; return; }
+  if (e - s > (uint32_t)GROUP_MAX) { big[atomicAdd(flags + 1, 1u)] = s; kept[s] = 0; return; }   // left to filter_big_kernel
   uint32_t mid = s;                                   // first member of the reverse-strand list
   while (mid < e && !((keys[mid] >> 17) & 1)) mid++;
   uint32_t nk = 0;
@@ -100,6 +101,85 @@ __global__ void filter_kernel(const uint64_t* keys, const Derived* der, uint32_t
     }
   }
   kept[s] = nk;
+}
+
+// Window groups with more than GROUP_MAX records (dense repeats, permissive limits): one wave per group, same greedy.  The
+// "taken" bits and the kept intervals of the current strand list live in LDS; a group beyond those capacities raises the flag.
+constexpr uint32_t BIG_MAX = 1u << 16;     // records per group
+constexpr uint32_t BIG_KEPT = 4096;        // kept alignments per strand list
+
+__global__ __launch_bounds__(64) void filter_big_kernel(const uint64_t* keys, const Derived* der, uint32_t n, int max_total_diffs, int max_overlap,
+                                                        uint32_t* kept, uint32_t* out_pos, uint32_t* flags, const uint32_t* big) {
+  __shared__ uint32_t s_taken[BIG_MAX / 32];
+  __shared__ int s_ks[BIG_KEPT], s_ke[BIG_KEPT];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t n_big = flags[1];
+  for (uint32_t g = blockIdx.x; g < n_big; g += gridDim.x) {
+    const uint32_t s = big[g];
+    const uint64_t gid = keys[s] >> GROUP_SHIFT;
+    uint32_t e = s + 1;
+    for (;;) {                                           // end of the group, 64 positions per probe
+      const uint32_t q = e + lane;
+      const unsigned long long m = __ballot(q < n && (keys[q] >> GROUP_SHIFT) == gid);
+      if (m == ~0ull) { e += 64; continue; }
+      e += (uint32_t)__ffsll((long long)~m) - 1;
+      break;
+    }
+    uint32_t mid = s;                                    // first member of the reverse-strand list
+    for (;;) {
+      const uint32_t q = mid + lane;
+      const unsigned long long m = __ballot(q < e && !((keys[q] >> 17) & 1));
+      if (m == ~0ull) { mid += 64; continue; }
+      mid += (uint32_t)__ffsll((long long)~m) - 1;
+      break;
+    }
+    if (e - s > BIG_MAX) { if (lane == 0) { atomicOr(flags, 1u); kept[s] = 0; } continue; }
+    for (uint32_t i = lane; i < (e - s + 31) / 32; i += 64) s_taken[i] = 0;
+    __syncthreads();
+    uint32_t nk = 0;
+    bool overflow = false;
+    for (int list = 0; list < 2 && !overflow; list++) {
+      const uint32_t lo = list ? mid : s, hi = list ? e : mid;
+      const uint32_t first_kept = nk;
+      for (;;) {
+        // best remaining record: score desc, gap bases asc, enumeration order (GA:125-129, stable sort)
+        unsigned long long bk = 0;
+        for (uint32_t m = lo + lane; m < hi; m += 64) {
+          const uint32_t rel = m - s;
+          if ((s_taken[rel >> 5] >> (rel & 31)) & 1u) continue;
+          const Derived d = der[m];
+          const unsigned long long k = ((unsigned long long)(uint32_t)(d.score + (1 << 22)) << 40) | ((unsigned long long)(0xFFFFu - d.gaps) << 24) |
+                                       (unsigned long long)(0xFFFFFFu - (m - lo));
+          bk = k > bk ? k : bk;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned long long o = __shfl_xor(bk, off);
+          bk = o > bk ? o : bk;
+        }
+        if (bk == 0) break;
+        const uint32_t best = lo + (0xFFFFFFu - (uint32_t)(bk & 0xFFFFFFu));
+        if (lane == 0) { const uint32_t rel = best - s; s_taken[rel >> 5] |= 1u << (rel & 31); }
+        const Derived b = der[best];
+        bool clash = false;
+        if ((int)b.edits <= max_total_diffs) {
+          bool mine = false;
+          for (uint32_t k = first_kept + lane; k < nk; k += 64) {
+            const int o = min(b.end, s_ke[k - first_kept]) - max(b.start, s_ks[k - first_kept]);   // GA:119-122
+            mine = mine || o > max_overlap;
+          }
+          clash = __ballot(mine) != 0;
+          if (!clash) {
+            if (nk - first_kept >= BIG_KEPT) { overflow = true; break; }
+            if (lane == 0) { out_pos[s + nk] = best; s_ks[nk - first_kept] = b.start; s_ke[nk - first_kept] = b.end; }
+            nk++;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (lane == 0) { if (overflow) { atomicOr(flags, 1u); kept[s] = 0; } else kept[s] = nk; }
+    __syncthreads();
+  }
 }
 
 __global__ void gather_kernel(const RawAln* raw, const uint32_t* vals, const uint32_t* kept, const uint32_t* offs, const uint32_t* out_pos,
@@ -130,14 +210,15 @@ struct SelectWork {
   uint8_t* taken = nullptr; size_t taken_cap = 0;
   RawAln* final_out = nullptr; size_t final_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
-  uint32_t* counts = nullptr;   // [0] survivors, [1] flags
+  uint32_t* big = nullptr; size_t big_cap = 0;
+  uint32_t* counts = nullptr;   // [0] survivors, [1] flags, [2] window groups left to filter_big_kernel
 };
 
 void select_destroy(SelectWork* w) {
   if (!w) return;
   (void)hipFree(w->keys); (void)hipFree(w->keys2); (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->kept);
   (void)hipFree(w->offs); (void)hipFree(w->out_pos); (void)hipFree(w->der); (void)hipFree(w->taken); (void)hipFree(w->final_out);
-  (void)hipFree(w->temp); (void)hipFree(w->counts);
+  (void)hipFree(w->temp); (void)hipFree(w->counts); (void)hipFree(w->big);
   delete w;
 }
 
@@ -153,14 +234,14 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   hipError_t e;
   const size_t n = n_raw;
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-  if (!w.counts) TRY(hipMalloc((void**)&w.counts, 2 * sizeof(uint32_t)));
-  TRY(hipMemsetAsync(w.counts, 0, 2 * sizeof(uint32_t), stream));
+  if (!w.counts) TRY(hipMalloc((void**)&w.counts, 3 * sizeof(uint32_t)));
+  TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream));
   *d_final = nullptr; *d_counts = w.counts;
   if (n == 0) return hipSuccess;
   TRY(grow(&w.keys, w.keys_cap, n)); TRY(grow(&w.keys2, w.keys2_cap, n));
   TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n));
   TRY(grow(&w.kept, w.kept_cap, n)); TRY(grow(&w.offs, w.offs_cap, n)); TRY(grow(&w.out_pos, w.out_pos_cap, n));
-  TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.taken, w.taken_cap, n)); TRY(grow(&w.final_out, w.final_cap, n));
+  TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.taken, w.taken_cap, n)); TRY(grow(&w.big, w.big_cap, n / GROUP_MAX + 1)); TRY(grow(&w.final_out, w.final_cap, n));
   size_t t1 = 0, t2 = 0;
   TRY(rocprim::radix_sort_pairs(nullptr, t1, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
   TRY(rocprim::exclusive_scan(nullptr, t2, w.kept, w.offs, 0u, n, rocprim::plus<uint32_t>(), stream));
@@ -175,7 +256,9 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   hipLaunchKernelGGL(derive_kernel, grid, block, 0, stream, d_raw, (const uint32_t*)w.vals2, n_raw, d_guides, d_win_base, d_win, w.der);
   TRY(hipMemsetAsync(w.taken, 0, n, stream));
   hipLaunchKernelGGL(filter_kernel, grid, block, 0, stream, (const uint64_t*)w.keys2, (const Derived*)w.der, n_raw, max_total_diffs,
-                     max_overlap, w.taken, w.kept, w.out_pos, w.counts + 1);
+                     max_overlap, w.taken, w.kept, w.out_pos, w.counts + 1, w.big);
+  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 8192)), dim3(64), 0, stream, (const uint64_t*)w.keys2,
+                     (const Derived*)w.der, n_raw, max_total_diffs, max_overlap, w.kept, w.out_pos, w.counts + 1, (const uint32_t*)w.big);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.kept, w.offs, 0u, n, rocprim::plus<uint32_t>(), stream));
   hipLaunchKernelGGL(gather_kernel, grid, block, 0, stream, d_raw, (const uint32_t*)w.vals2, (const uint32_t*)w.kept,
