@@ -309,6 +309,14 @@ def main():
             if pm["workload_packed_bytes"] == tm["packed_bytes"] and world == 1:
                 result["roofline"]["traffic"] = pm["traffic_bytes_per_launch"] / lanes   # measured on the one-launch pass
                 result["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json"
+            if "SQ_INSTS_VALU" in pm and pm["workload_packed_bytes"] == tm["packed_bytes"] and world == 1:
+                # the roof that binds this kernel: vector-ALU instruction issue.  Counted instructions per
+                # pass (PMC) / measured scan time of this run, against the measured full-rate issue of all 1024 SIMDs.
+                peak = 1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"]            # wave-instructions per ns
+                ach = pm["SQ_INSTS_VALU"] / (scan_ms / K * 1e6)
+                result["roofline"]["valu"] = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-inst/s",
+                                              "frac": ach / peak, "wave_insts_per_pass": pm["SQ_INSTS_VALU"],
+                                              "lane_ops_per_base": pm["valu_lane_ops_per_base"]}
         except Exception:
             pass
         mb = args.cpu_sample_mb
