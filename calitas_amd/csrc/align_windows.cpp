@@ -122,7 +122,8 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
     const uint32_t slots_per_rec = (W + 14) / W + 1;
     const uint64_t slab_per_rec = (uint64_t)slab_bytes * slots_per_rec;
     {
-      int rc = ensure_buffers(ctx, std::max<uint32_t>(n_rec, 1u << 12), std::max<uint32_t>(ctx->raw_cap, std::max<uint32_t>(n_rec * 4, 1u << 16)), slab_per_rec);
+      int rc = ensure_buffers(ctx, std::max<uint32_t>(n_rec, 1u << 12), std::max<uint32_t>(ctx->raw_cap, std::max<uint32_t>(n_rec * 4, 1u << 16)), slab_per_rec,
+                              std::max<uint32_t>(1u << 12, n_rec * slots_per_rec * 16));   // every column of every task can pass
       if (rc) return rc;
     }
 
@@ -160,6 +161,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
       aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap; aa.tile_words = (uint32_t)(ref.tile / 16);
       aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = slab_bytes; aa.slots_per_rec = slots_per_rec;
+      aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
       aa.debug_skip = 0;
       aa.sp.window_size = (int)W; aa.sp.step = (int)W; aa.sp.n_guides = ns;
       aa.sp.max_guide_diffs = 0; aa.sp.max_pam_mismatches = 0; aa.sp.max_diffs_filtering = 0;   // per-guide values live in GuideDev
@@ -173,7 +175,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       if (ctx->h_counters[2] != 0) return calitas_fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
       n_raw = ctx->h_counters[1];
       if (n_raw > ctx->raw_cap) {
-        int rc = ensure_buffers(ctx, ctx->rec_cap, n_raw + n_raw / 8, slab_per_rec);
+        int rc = ensure_buffers(ctx, ctx->rec_cap, n_raw + n_raw / 8, slab_per_rec, ctx->item_cap);
         if (rc) return rc;
         continue;
       }

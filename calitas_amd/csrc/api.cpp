@@ -154,7 +154,7 @@ void calitas_destroy(calitas_ctx* c) {
     (void)hipSetDevice(c->device);
     free_reference_device(c);
     (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
-    (void)hipFree(c->d_slab);
+    (void)hipFree(c->d_slab); (void)hipFree(c->d_items);
     destroy_lanes(c);
     select_destroy(c->select);
     hits_destroy(c->hits);
@@ -383,8 +383,13 @@ std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, cons
   return "";
 }
 
-int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec) {
+int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec, uint32_t item_cap) {
   rec_cap = std::max(rec_cap, ctx->rec_cap);
+  if (item_cap > ctx->item_cap) {
+    (void)hipFree(ctx->d_items); ctx->d_items = nullptr; ctx->item_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_items, (size_t)item_cap * sizeof(uint64_t)));
+    ctx->item_cap = item_cap;
+  }
   if ((uint64_t)rec_cap * slab_per_rec > ctx->slab_cap) {
     (void)hipFree(ctx->d_slab); ctx->d_slab = nullptr; ctx->slab_cap = 0;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slab, (size_t)rec_cap * slab_per_rec));
@@ -539,7 +544,8 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
   aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
   aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
-  aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
+  aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
+  aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
   aa.debug_skip = std::getenv("CALITAS_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SKIP")) : 0u;
   aa.sp.window_size = p.window_size; aa.sp.step = pl.step; aa.sp.n_guides = pl.n_guides;
   aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
@@ -552,7 +558,8 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
 // Device buffers of one lane for this plan (allocation only).
 static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
   const uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, pl.bases / 8 + 1024));
-  return ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), pl.slab_per_rec);
+  return ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), pl.slab_per_rec,
+                        std::max<uint32_t>(ctx->item_cap, (uint32_t)(2 * want)));
 }
 
 // Guides, cleared counters and the scan kernel of this lane, queued on `stream` (the lane's own, or the shared scan
@@ -602,8 +609,9 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
+    const uint32_t n_items = ctx->h_counters[3];
     if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
-    if (n_rec > ctx->rec_cap || n_raw > ctx->raw_cap) {
+    if (n_rec > ctx->rec_cap || n_raw > ctx->raw_cap || n_items > ctx->item_cap) {
       if (prelaunched) return fail(ctx, CALITAS_ESTATE, "lane buffers overflowed");   // the caller reruns unchunked
       tm.retries++;
       uint64_t nr = n_rec > ctx->rec_cap ? (uint64_t)n_rec + n_rec / 4 : ctx->rec_cap;
@@ -611,7 +619,11 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
       if (n_rec > ctx->rec_cap)   // the raw count was cut short as well: scale it with the record count
         nw = std::max<uint64_t>(nw, (uint64_t)((double)n_raw * nr / std::max<uint32_t>(1, ctx->rec_cap)) + 1024);
       if (nr > 0xFFFFFFF0ull || nw > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
-      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw, pl.slab_per_rec);
+      // passing candidates: as counted, or scaled with the record count when that was cut short
+      uint64_t ni = n_items > ctx->item_cap ? (uint64_t)n_items + n_items / 4 : ctx->item_cap;
+      if (n_rec > ctx->rec_cap) ni = std::max<uint64_t>(ni, (uint64_t)((double)std::max<uint32_t>(n_items, 1024) * nr / std::max<uint32_t>(1, ctx->rec_cap)) * 2);
+      if (ni > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
+      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw, pl.slab_per_rec, (uint32_t)ni);
       if (rc) return rc;
       continue;
     }

@@ -37,9 +37,11 @@ struct calitas_ctx {
   GuideDev* d_guides = nullptr;
   ScanRecord* d_recs = nullptr;
   RawAln* d_raw = nullptr;
-  uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies, [3] slab units, [4] candidates
+  uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies, [3] passing candidates (items), [4] candidates
   uint8_t* d_slab = nullptr;        // strips handed from align_kernel to trace_kernel
   uint64_t slab_cap = 0;            // bytes
+  uint64_t* d_items = nullptr;      // passing candidates (align_kernel -> trace_kernel)
+  uint32_t item_cap = 0;
   uint32_t* h_counters = nullptr;   // pinned
   uint32_t rec_cap = 0, raw_cap = 0;
   RawAln* h_raw = nullptr;          // pinned staging for the copy-back
@@ -66,7 +68,7 @@ void* calitas_out_alloc(size_t size);
 // Per-guide device constants for limits (d, p) and costs; returns an error text or "".
 std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, int max_guide_diffs, int max_pam_mismatches,
                             GuideDev& gd);
-int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec);
+int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec, uint32_t item_cap);
 
 #define HIP_TRY(ctx, call)                                                                         \
   do {                                                                                             \

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
 constexpr int TR_UP = 0, TR_LEFT = 1, TR_DIAG = 2;   // ordered so that max() of (score*4 + code) breaks ties Diag > Left > Up
 constexpr int NEG = -(1 << 20);                      // "minus infinity" that survives a few hundred additions
 constexpr int JOBS_PER_BLOCK = 8;                    // one job per 32-lane half wave
+constexpr int ITEM_STAGE = 64 + 2 * 8 * 16;          // per wave: flush threshold + the most one record iteration can add
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
 constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
 constexpr int TR_STRIDE = 100;                       // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; lane r writes byte 99r + t)
@@ -288,8 +289,38 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
   __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
+  // passing candidates are staged per wave and appended to a.items with one global atomic per flush: trace_kernel then
+  // runs one lane per *passing* candidate instead of one per candidate slot (4 % of the slots pass at d = 5)
+  __shared__ uint64_t s_items[JOBS_PER_BLOCK / 2][ITEM_STAGE];
+  __shared__ uint32_t s_nitems[JOBS_PER_BLOCK / 2];
   const int job = threadIdx.x >> 5;
   const int r = threadIdx.x & 31;           // lane within the job = query row r+1
+  const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63;
+  if (wlane == 0) s_nitems[wave] = 0;
+  __syncthreads();
+  // all lanes of the wave that are still in the record loop call this together
+  auto flush_items = [&](uint32_t threshold) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t n = s_nitems[wave];
+    if (n >= threshold && n != 0) {
+      const unsigned long long act = __ballot(1);
+      const int leader = __ffsll((long long)act) - 1;
+      uint32_t base = 0;
+      if (wlane == leader) base = atomicAdd(a.item_count, n);
+      base = __shfl(base, leader);
+      const int rank = __popcll(act & ((1ull << wlane) - 1ull)), nact = __popcll(act);
+      for (uint32_t i = (uint32_t)rank; i < n; i += (uint32_t)nact)
+        if (base + i < a.item_capacity) a.items[base + i] = s_items[wave][i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (wlane == leader) s_nitems[wave] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  };
   uint8_t (*tr)[TR_STRIDE] = s_tr[job];
   uint8_t* tb = s_tb[job];
   int* fin = s_fin[job];
@@ -301,6 +332,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
   const int W = sp.window_size, step = sp.step;
 
   for (uint32_t ri = blockIdx.x * JOBS_PER_BLOCK + job; ri < n_recs; ri += total_jobs) {
+    flush_items(64);                         // a record adds at most 2 jobs x 8 windows x 16 candidates per wave
     const ScanRecord rec = a.recs[ri];
     const uint32_t cmask = rec.info & 0xFFFFu;
     const int dir = (rec.info >> 16) & 1;
@@ -418,7 +450,11 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
           hd->stride = (uint16_t)stride; hd->pad = 0;
           hd->pass_mask = mine;
         }
-        if (pass && !(a.debug_skip & 128u)) { hd->j[r] = (uint16_t)j; hd->best[r] = P; }
+        if (pass && !(a.debug_skip & 128u)) {
+          hd->j[r] = (uint16_t)j; hd->best[r] = P;
+          const uint32_t slot = atomicAdd(&s_nitems[wave], 1u);
+          if (slot < (uint32_t)ITEM_STAGE) s_items[wave][slot] = (((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) << 4) | (uint64_t)r;
+        }
         uint32_t* dtb = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader));
         const uint32_t* stb = reinterpret_cast<const uint32_t*>(tb);
         for (uint32_t x = r; x < tb_bytes / 4; x += 32) dtb[x] = stb[x];
@@ -432,9 +468,10 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
   }
+  flush_items(1);
 }
 
-// Traceback + PAM extension of one candidate end column (item = (record, window slot, candidate index)).
+// Traceback + PAM extension of one candidate end column (item = (record x window slot) slab index << 4 | candidate slot).
 template <typename Emit>
 __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& sp, uint64_t it, const uint8_t (*s_qmask)[MAX_L],
                                           const uint8_t (*s_pam)[MAX_PAMS][MAX_PAM_LEN], const uint8_t (*s_pamlen)[MAX_PAMS],
@@ -531,7 +568,7 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// trace_kernel: one lane per candidate end column -- traceback through the strip's trace matrix (slab in HBM),
+// trace_kernel: one lane per passing candidate end column -- traceback through the strip's trace matrix (slab in HBM),
 // '='/'X' ops, extendAndFilterRight (SequentialGuideAligner.scala:433-492), one RawAln per (candidate, PAM).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
@@ -556,9 +593,8 @@ __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
   if (threadIdx.x == 0) { s_nout = 0; s_ncand = 0; }
   __syncthreads();
 
-  uint32_t n_recs = *a.rec_count;
-  if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
-  const uint64_t n_items = (uint64_t)n_recs * a.slots_per_rec * 16;   // (record, window slot, candidate index)
+  uint32_t n_items = *a.item_count;                                   // passing candidates appended by align_kernel
+  if (n_items > a.item_capacity) n_items = a.item_capacity;
   const SearchDev& sp = a.sp;
   // Results are staged in LDS and flushed with one global atomic per flush (see stage_record above for why).
   auto emit = [&](const RawAln& o) {
@@ -586,8 +622,8 @@ __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
   };
 
   for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n_items; base += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t it = base + threadIdx.x;
-    if (it < n_items) trace_one(a, sp, it, s_qmask, s_pam, s_pamlen, s_gint, &s_ncand, emit);
+    const uint64_t idx = base + threadIdx.x;
+    if (idx < n_items) trace_one(a, sp, a.items[idx], s_qmask, s_pam, s_pamlen, s_gint, &s_ncand, emit);
     __syncthreads();
     const uint32_t staged = s_nout;     // same value in every thread: nobody appends between the two barriers
     __syncthreads();

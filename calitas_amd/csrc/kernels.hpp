@@ -38,6 +38,9 @@ struct AlignArgs {
   uint32_t* anomalies;
   uint8_t* slab;            // strips handed from align_kernel to trace_kernel: rec_capacity x slots_per_rec slabs
   uint32_t* cand_count;     // statistics only
+  uint64_t* items;          // passing candidates, (slab index << 4 | candidate slot): align_kernel appends, trace_kernel consumes
+  uint32_t* item_count;
+  uint32_t item_capacity;
   uint32_t slab_bytes;      // size of one slab
   uint32_t slots_per_rec;   // windows a 16-base record can fall into
   uint32_t rec_capacity;
