@@ -695,6 +695,8 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
 
   // ---- host: restore the reference's enumeration order, then the per-window filter (SGA:315-320) ----
   const RawAln* raw = ctx->h_raw;
+  WorkerPool* pool = ref_owner(ctx)->pool;                                  // lanes share the owner's pool, one at a time
+  std::lock_guard<std::mutex> host_lock(ref_owner(ctx)->host_mu);
   // Raw records arrive in atomic-append order.  They are bucketed by (guide, contig, 4096-window chunk), each bucket is
   // sorted by (window, strand list, end column, PAM) = fgbio's enumeration order (ascending end column) followed
   // by the PAM order of extendAndFilterRight (SGA:455), filtered window by window, and the buckets are concatenated.
@@ -719,7 +721,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   std::vector<std::vector<calitas_aln_t>> bucket_out(n_buckets);
   {
     std::atomic<size_t> next(0);
-    ctx->pool->run([&](int) {
+    pool->run([&](int) {
       std::vector<std::pair<uint64_t, uint32_t>> keyed;
       std::vector<calitas_aln_t> win;
       std::vector<int> kept;
@@ -762,7 +764,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
   {
     std::atomic<size_t> next(0);
-    ctx->pool->run([&](int) {
+    pool->run([&](int) {
       for (;;) {
         size_t b = next.fetch_add(1);
         if (b >= n_buckets) break;
@@ -864,7 +866,8 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
     }
   }
-  // host tail: the same stages as calitas_hits_tsv
+  // host tail: the same stages as calitas_hits_tsv (one lane at a time: they share the owner's worker pool)
+  std::lock_guard<std::mutex> host_lock(own->host_mu);
   if (dev.valid) {
     rc = convert_selected(lane, dev.d_final, dev.n_sel, pl.gh, p, pl.step, &alns);
     if (rc) return rc;

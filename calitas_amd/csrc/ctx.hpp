@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,7 @@ struct calitas_ctx {
   hipEvent_t scan_done = nullptr;   // lane: recorded on the parent's scan stream after this lane's scan
   hipEvent_t rows_ready = nullptr;  // lane: recorded on its stream after its row kernels
   uint64_t last_text_bytes = 0;
+  std::mutex host_mu;               // host stages of concurrent lanes take turns on the worker pool
   WorkerPool* pool = nullptr;
   ~calitas_ctx() { delete pool; }
 };

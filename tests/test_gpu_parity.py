@@ -239,6 +239,38 @@ def test_chunked_search_hits_equals_one_pass(C, tmp_path, monkeypatch, chunks):
         ctx.close()
 
 
+def test_host_tail_of_search_hits(C, tmp_path, monkeypatch):
+    """When a device stage of calitas_search_hits declines (score range, cluster length, -O 0) the host implementation of that
+    stage finishes the call -- in one pass or lane by lane.  CALITAS_HOST_HITS forces that path; -O 0 takes it by itself."""
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    fa = synth_fasta(tmp_path, 43, [guide], lengths=(50000, 30000, 8000))
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        params = C.make_params(max_gaps_between_guide_and_pam=2)
+        want, n = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+        for chunks in ("1", "3"):
+            monkeypatch.setenv("CALITAS_CHUNKS", chunks)
+            monkeypatch.setenv("CALITAS_HOST_HITS", "1")
+            got, n2 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            monkeypatch.delenv("CALITAS_HOST_HITS")
+            assert n > 20 and (n, want) == (n2, got), chunks
+            monkeypatch.setenv("CALITAS_HOST_FILTER", "1")        # the per-window filter on the host as well, in every lane
+            got, n2 = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            monkeypatch.delenv("CALITAS_HOST_FILTER")
+            assert (n, want) == (n2, got), chunks
+            p0 = C.make_params(max_gaps_between_guide_and_pam=2, max_overlap=0)        # removeOverlaps with -O 0: host stage
+            a, na = ctx.search_hits(C.Guide(guide), "a", p0, "v0", "stamp")
+            out, k = ctx.search_raw([C.Guide(guide)], p0)
+            try:
+                b, nb = ctx.hits_tsv_raw(C.Guide(guide), "a", p0, out, k, "v0", "stamp")
+            finally:
+                C._lib.lib.calitas_free(out)
+            assert (na, a) == (nb, b)
+    finally:
+        ctx.close()
+
+
 def test_cpp_cli_search_reference(C, tmp_path):
     """The `calitas SearchReference` binary with the reference's flags (SearchReference.scala:452-470), FASTA in, hits.txt out."""
     import subprocess
