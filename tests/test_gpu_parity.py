@@ -271,6 +271,34 @@ def test_host_tail_of_search_hits(C, tmp_path, monkeypatch):
         ctx.close()
 
 
+def test_search_without_hits_and_degenerate_references(C, tmp_path, monkeypatch):
+    """No candidate anywhere, contigs shorter than the guide, all-N contigs: the header alone comes back, on every path."""
+    cases = [("nohit", [("c0", "ACGT" * 500), ("c1", "TTTTGGGGCCCCAAAA" * 40)], "GGATCCGAATTCAAGCTTCCnrg", dict(max_guide_diffs=0, max_pam_mismatches=0)),
+             ("short", [("s0", "ACGTACGTAC"), ("s1", "G" * 22)], "CTTGCCCCACAGGGCAGTAAnrg", dict()),
+             ("alln", [("n0", "N" * 5000), ("n1", "n" * 300)], "CTTGCCCCACAGGGCAGTAAnrg", dict())]
+    for tag, contigs, guide, kw in cases:
+        fa = write_fasta(str(tmp_path / (tag + ".fa")), contigs)
+        _, orows, _ = O.search_reference(fa, guide, "a", d=kw.get("max_guide_diffs", 5), p=kw.get("max_pam_mismatches", 1))
+        ctx = C.Context(0)
+        ctx.set_reference_fasta(fa)
+        try:
+            params = C.make_params(**kw)
+            for chunks in (None, "2"):
+                if chunks:
+                    monkeypatch.setenv("CALITAS_CHUNKS", chunks)
+                else:
+                    monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
+                text, n = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+                rows = C.read_hits(text)
+                assert n == len(rows) == len(orows), (tag, chunks)
+                assert text.splitlines()[0].split("\t")[0] == "guide_id" and len(text.splitlines()[0].split("\t")) == 34
+                if orows:
+                    assert_same(rows, orows, tag)
+            assert ctx.search([C.Guide(guide)], params) == [] or orows
+        finally:
+            ctx.close()
+
+
 def test_cpp_cli_search_reference(C, tmp_path):
     """The `calitas SearchReference` binary with the reference's flags (SearchReference.scala:452-470), FASTA in, hits.txt out."""
     import subprocess
