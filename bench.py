@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--shard", choices=["guides", "contigs"], default="guides")
     ap.add_argument("--cpu-sample-mb", type=float, default=-1, help="CPU baseline sample in Mb (<0: auto, 0: skip)")
     ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
+    ap.add_argument("--guides-per-step", type=int, default=1,
+                    help="guides each rank runs per step through calitas_search_hits_batch (BASELINE config 4 shape: 96 guides / 8 GPUs = 12); "
+                         "the default 1 is the BASELINE metric's single-guide pass")
+    ap.add_argument("--same-guide", action="store_true", help="with --guides-per-step: every guide of the batch is guide #0 (isolates the pipelining gain)")
     ap.add_argument("--two-stage", action="store_true", help="calitas_search + calitas_hits_tsv (host rows) instead of the fused calitas_search_hits")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and gloo replaces RCCL (not a measurement)")
@@ -185,9 +189,10 @@ def main():
         bases_per_step_total = sum(lengths)
     else:
         mine = None
-        my_guides = [all_guides[rank % len(all_guides)]]
-        guide_passes_per_step = world      # every rank runs its own guide over the whole genome
-        bases_per_step_total = sum(lengths) * world
+        gps = max(1, args.guides_per_step)
+        my_guides = [GUIDE0 if args.same_guide else all_guides[(rank * gps + i) % len(all_guides)] for i in range(gps)]
+        guide_passes_per_step = world * gps   # every rank runs its own guide(s) over the whole genome
+        bases_per_step_total = sum(lengths) * world * gps
 
     t_gen = time.perf_counter()
     names, seqs = build_genome(args.scale, device, contig_indices=mine, guides=[GUIDE0], log=None)
@@ -218,6 +223,13 @@ def main():
 
     def step():
         tp0 = time.perf_counter()
+        if len(G) > 1 and not (args.no_hits or args.two_stage):
+            # a batch of guides, pipelined through the device stages (calitas_search_hits_batch)
+            res = ctx.search_hits_batch(G, ["bench%d" % i for i in range(len(G))], params, "bench", "bench", decode=False)
+            tp1 = time.perf_counter()
+            tm = ctx.timing()
+            phase["search_hits"] += tp1 - tp0
+            return tm, tm["accepted_alignments"], sum(r for _, r in res)
         if not (args.no_hits or args.two_stage):
             # calitas_search_hits: kernels through to the finished hits.txt text, one copy-back
             text, rows = ctx.search_hits(G[0], "bench", params, "bench", "bench", decode=contig_mode)
@@ -275,6 +287,8 @@ def main():
         value = 2.0 * bases_per_step_total * K / dt
         # a pass is scanned in `lanes` launches (one per contig range); per-launch figures are averages over them
         lanes = max(1, int(tm.get("lanes", 1)))
+        if len(G) > 1:
+            lanes = len(G)      # a batch scans the whole reference once per guide: one launch each
         scan_avg_ms = scan_ms / K / lanes
         bytes_per_launch = tm["packed_bytes"] / lanes
         achieved = bytes_per_launch / (scan_avg_ms * 1e-3) / 1e9    # GB/s, algorithmic bytes of one launch / its duration
@@ -306,10 +320,10 @@ def main():
         # measured HBM traffic of the dominant kernel for this exact workload, from the committed PMC passes
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["scan_kernel"]
-            if pm["workload_packed_bytes"] == tm["packed_bytes"] and world == 1:
-                result["roofline"]["traffic"] = pm["traffic_bytes_per_launch"] / lanes   # measured on the one-launch pass
+            if pm["workload_packed_bytes"] * len(G) == tm["packed_bytes"] and world == 1:
+                result["roofline"]["traffic"] = pm["traffic_bytes_per_launch"] / (1 if len(G) > 1 else lanes)   # measured on the one-launch pass
                 result["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json"
-            if "SQ_INSTS_VALU" in pm and pm["workload_packed_bytes"] == tm["packed_bytes"] and world == 1:
+            if "SQ_INSTS_VALU" in pm and pm["workload_packed_bytes"] == tm["packed_bytes"] and world == 1 and len(G) == 1:
                 # the roof that binds this kernel: vector-ALU instruction issue.  Counted instructions per
                 # pass (PMC) / measured scan time of this run, against the measured full-rate issue of all 1024 SIMDs.
                 peak = 1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"]            # wave-instructions per ns

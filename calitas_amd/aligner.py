@@ -256,6 +256,23 @@ class Context:
         lib.calitas_free(tsv)
         return text, rows.value
 
+    def search_hits_batch(self, guides, guide_ids, params, version=None, time_stamp=None, decode=True):
+        """calitas_search_hits_batch: a list of (tsv_text or n_bytes, n_rows), one per guide, pipelined on the device."""
+        n = len(guides)
+        keep = [g.to_c() for g in guides]
+        garr = (GuideT * n)(*keep)
+        ids = (ctypes.c_char_p * n)(*[i.encode() for i in guide_ids])
+        tsv = (ctypes.c_void_p * n)()
+        nbytes, rows = (ctypes.c_uint64 * n)(), (ctypes.c_uint64 * n)()
+        _lib.check(self._h, lib.calitas_search_hits_batch(self._h, n, garr, ids, ctypes.byref(params),
+                                                          version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                                          tsv, nbytes, rows))
+        out = []
+        for i in range(n):
+            out.append((ctypes.string_at(tsv[i], nbytes[i]).decode() if decode else nbytes[i], rows[i]))
+            lib.calitas_free(tsv[i])
+        return out
+
     def timing(self):
         t = TimingT()
         _lib.check(self._h, lib.calitas_get_timing(self._h, ctypes.byref(t)))

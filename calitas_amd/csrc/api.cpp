@@ -32,7 +32,9 @@ namespace {
 struct BlockHeader { uint64_t magic; uint64_t capacity; uint64_t pinned; uint64_t pad; };
 constexpr uint64_t kMagic = 0xCA117A5B10C0FFEEull;
 std::mutex g_pool_mutex;
-std::vector<BlockHeader*> g_pool;   // at most 4 parked blocks
+std::vector<BlockHeader*> g_pool;   // parked blocks
+constexpr size_t kPoolBlocks = 32;     // a batch call hands out one text buffer per guide
+constexpr uint64_t kPoolBytes = 8ull << 30;
 
 void release_block(BlockHeader* h) {
   h->magic = 0;
@@ -70,7 +72,9 @@ void out_free(void* p) {
   if (h->capacity >= (1u << 20)) {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     g_pool.push_back(h);
-    if (g_pool.size() <= 4) return;
+    uint64_t parked = 0;
+    for (auto* b : g_pool) parked += b->capacity;
+    if (g_pool.size() <= kPoolBlocks && parked <= kPoolBytes) return;
     size_t small = 0;                   // full: let the smallest parked block go, the big ones are the expensive ones
     for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i]->capacity < g_pool[small]->capacity) small = i;
     h = g_pool[small];
@@ -1135,6 +1139,129 @@ static int search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, cons
   return CALITAS_OK;
 }
 
+// ---- calitas_search_hits_batch ----------------------------------------------------------------------------------------
+// Guides flow through the lanes as a pipeline: every lane thread queues the scan of its next guide on the shared low-priority
+// scan stream and then runs that guide's tail (align ... rows, copy) on its own stream, so guide g+1 is being scanned while
+// guide g's tail runs.  Each guide's text goes to its own pinned buffer.
+static int search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
+                                  const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
+                                  uint64_t* tsv_bytes, uint64_t* n_rows) {
+  const auto t_call = std::chrono::steady_clock::now();
+  for (int i = 0; i < n_guides; i++) { tsv[i] = nullptr; if (tsv_bytes) tsv_bytes[i] = 0; if (n_rows) n_rows[i] = 0; }
+  std::string version, stamp;
+  default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  auto release = [&]() { for (int i = 0; i < n_guides; i++) { calitas_free(tsv[i]); tsv[i] = nullptr; } };
+  int n_lanes = 3;
+  if (const char* e = std::getenv("CALITAS_BATCH_LANES")) n_lanes = std::max(1, std::min(8, std::atoi(e)));
+  n_lanes = std::min(n_lanes, (int)n_guides);
+  if (n_lanes < 2) {   // nothing to pipeline
+    for (int i = 0; i < n_guides; i++) {
+      int rc = search_hits_impl(ctx, &guides[i], guide_ids && guide_ids[i] ? guide_ids[i] : "", params, version.c_str(), stamp.c_str(), &tsv[i],
+                                tsv_bytes ? &tsv_bytes[i] : nullptr, n_rows ? &n_rows[i] : nullptr);
+      if (rc) { release(); return rc; }
+    }
+    return CALITAS_OK;
+  }
+  // plans first: every guide is validated before anything is queued, and all must share one window tiling
+  std::vector<SearchPlan> plans((size_t)n_guides);
+  for (int i = 0; i < n_guides; i++) {
+    int rc = plan_search(ctx, 1, &guides[i], params, plans[i]);
+    if (rc) return rc;
+    if (plans[i].step != plans[0].step)
+      return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_lanes(ctx, (size_t)n_lanes);
+  if (rc) return rc;
+  for (int l = 0; l < n_lanes && !rc; l++) { rc = lane_prepare(ctx->lanes[l], plans[0]); if (rc) ctx->err = ctx->lanes[l]->err; }
+  if (rc) return rc;
+  rc = ensure_window_table(ctx, plans[0], ctx->scan_stream);
+  if (rc) return rc;
+  const PackedRef& ref = ctx->ref;
+  std::mutex scan_mu, copy_mu;
+  std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
+  std::vector<calitas_timing_t> tms((size_t)n_guides);
+  std::vector<std::thread> threads;
+  for (int l = 0; l < n_lanes; l++) {
+    threads.emplace_back([&, l] {
+      (void)hipSetDevice(ctx->device);
+      calitas_ctx* lane = ctx->lanes[l];
+      for (int g = l; g < n_guides; g += n_lanes) {
+        const SearchPlan& pl = plans[g];
+        const std::string gid = guide_ids && guide_ids[g] ? guide_ids[g] : "";
+        const RowStrings rs = make_row_strings(ref, pl.gh[0], gid, pl.p, version, stamp);
+        auto step = [&]() -> int {
+          {
+            // the previous guide of this lane is completely done (its text was copied before the loop went on), so the
+            // lane's buffers are free for this scan
+            std::lock_guard<std::mutex> lk(scan_mu);
+            int r = launch_scan_stage(lane, pl, ctx->scan_stream);
+            if (r) return r;
+            HIP_TRY(lane, hipEventRecord(lane->scan_done, ctx->scan_stream));
+            HIP_TRY(lane, hipStreamWaitEvent(lane->stream, lane->scan_done, 0));
+          }
+          LaneText lt;
+          int r = lane_rows(lane, pl, true, rs, gid, version, stamp, lt);
+          if (r) return r;
+          const size_t hlen = rs.header.size(), total = hlen + (size_t)lt.bytes;
+          char* text = (char*)out_alloc_impl(total + 1, true);
+          if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
+          std::memcpy(text, rs.header.data(), hlen);
+          if (lt.bytes && lt.on_host) std::memcpy(text + hlen, lt.host_rows.data(), (size_t)lt.bytes);
+          else if (lt.bytes) {
+            hipError_t e = hipEventRecord(lane->rows_ready, lane->stream);
+            {
+              std::lock_guard<std::mutex> lk(copy_mu);
+              if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, lane->rows_ready, 0);
+              if (e == hipSuccess) e = hipMemcpyAsync(text + hlen, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream);
+              if (e == hipSuccess) e = hipEventRecord(lane->ev[3], ctx->copy_stream);
+            }
+            if (e == hipSuccess) e = hipEventSynchronize(lane->ev[3]);
+            if (e != hipSuccess) { calitas_free(text); return fail(lane, CALITAS_EHIP, std::string("text copy: ") + hipGetErrorString(e)); }
+          }
+          text[total] = 0;
+          tsv[g] = text;
+          if (tsv_bytes) tsv_bytes[g] = total;
+          if (n_rows) n_rows[g] = lt.rows;
+          tms[g] = lt.tm; tms[g].hit_rows = lt.rows; tms[g].hits_bytes = total;
+          return CALITAS_OK;
+        };
+        rcs[g] = step();
+        if (rcs[g] != CALITAS_OK) (void)hipStreamSynchronize(lane->stream);   // leave the lane quiet before its next guide
+      }
+    });
+  }
+  for (auto& t : threads) t.join();
+  for (int g = 0; g < n_guides; g++) {
+    if (rcs[g] == CALITAS_OK) continue;
+    if (rcs[g] == CALITAS_ESTATE) {   // a lane's buffers overflowed: this guide again, in one pass with the retry logic
+      int r = search_hits_impl(ctx, &guides[g], guide_ids && guide_ids[g] ? guide_ids[g] : "", params, version.c_str(), stamp.c_str(), &tsv[g],
+                               tsv_bytes ? &tsv_bytes[g] : nullptr, n_rows ? &n_rows[g] : nullptr);
+      if (r) { release(); return r; }
+      tms[g] = ctx->timing;
+      continue;
+    }
+    ctx->err = ctx->lanes[g % n_lanes]->err;
+    release();
+    return rcs[g];
+  }
+  calitas_timing_t tm{};
+  for (auto& t : tms) {
+    tm.scan_kernel_ms += t.scan_kernel_ms; tm.align_kernel_ms += t.align_kernel_ms; tm.gpu_total_ms += t.gpu_total_ms;
+    tm.bases_scanned += t.bases_scanned; tm.packed_bytes += t.packed_bytes; tm.scan_records += t.scan_records;
+    tm.candidate_columns += t.candidate_columns; tm.raw_alignments += t.raw_alignments; tm.accepted_alignments += t.accepted_alignments;
+    tm.retries += t.retries; tm.hit_rows += t.hit_rows; tm.hits_bytes += t.hits_bytes;
+  }
+  tm.lanes = (uint32_t)n_lanes;
+  ctx->timing = tm;
+  if (std::getenv("CALITAS_TRACE"))
+    std::fprintf(stderr, "[calitas] search_hits_batch: %d guides on %d lanes, scan %.3f ms, align %.3f ms (sums), call %.3f ms (%llu rows, %llu bytes)\n",
+                 n_guides, n_lanes, tm.scan_kernel_ms, tm.align_kernel_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),
+                 (unsigned long long)tm.hit_rows, (unsigned long long)tm.hits_bytes);
+  return CALITAS_OK;
+}
+
 extern "C" {
 
 int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
@@ -1147,6 +1274,14 @@ int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const ch
   if (!ctx) return CALITAS_EINVAL;
   if (!guide || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "NULL argument");
   return search_hits_impl(ctx, guide, guide_id ? guide_id : "", params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
+}
+
+int calitas_search_hits_batch(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
+                              const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
+                              uint64_t* tsv_bytes, uint64_t* n_rows) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (n_guides <= 0 || !guides || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "bad argument");
+  return search_hits_batch_impl(ctx, n_guides, guides, guide_ids, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
 }
 
 int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out) {

@@ -160,6 +160,15 @@ int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
 int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                         const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
 
+/* calitas_search_hits for a batch of guides (BASELINE config 4: 96 guides against one reference) -- the loop a caller would
+ * write around SearchReference, with the guides flowing through the stages as a pipeline: while guide g's alignments are
+ * filtered, de-duplicated, turned into rows and copied back, guide g+1 is already being scanned.  tsv[i] / tsv_bytes[i] /
+ * n_rows[i] receive what calitas_search_hits returns for guides[i] (byte-identical); each text is freed with calitas_free.
+ * All guides must have the same length (one window tiling).  guide_ids may be NULL. */
+int calitas_search_hits_batch(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
+                              const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
+                              uint64_t* tsv_bytes, uint64_t* n_rows);
+
 /* SequentialGuideAligner.align on explicit (guide, target) pairs -- the per-task call of PairwiseAlignSequences
  * (PairwiseAlignSequences.scala:64 -> alignBest, SequentialGuideAligner.scala:333-345) and AlignToReference
  * (AlignToReference.scala:114-135 -> alignToRef / alignToRefBest, SequentialGuideAligner.scala:359-418).  Task t aligns

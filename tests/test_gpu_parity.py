@@ -299,6 +299,28 @@ def test_search_without_hits_and_degenerate_references(C, tmp_path, monkeypatch)
             ctx.close()
 
 
+def test_search_hits_batch_equals_single_calls(C, tmp_path, monkeypatch):
+    """calitas_search_hits_batch pipelines guides through lanes; every guide's text must be what calitas_search_hits returns."""
+    from calitas_amd import synth
+    guides = ["CTTGCCCCACAGGGCAGTAAnrg"] + synth.random_guides(0xC4, 6)
+    fa = synth_fasta(tmp_path, 47, guides, lengths=(50000, 20000, 9000))
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        params = C.make_params(max_gaps_between_guide_and_pam=2)
+        G = [C.Guide(g) for g in guides]
+        ids = ["g%d" % i for i in range(len(G))]
+        single = [ctx.search_hits(g, i, params, "v0", "stamp") for g, i in zip(G, ids)]
+        assert sum(n for _, n in single) > 100
+        for lanes in ("3", "2", "1", "8"):
+            monkeypatch.setenv("CALITAS_BATCH_LANES", lanes)
+            assert ctx.search_hits_batch(G, ids, params, "v0", "stamp") == single, lanes
+        with pytest.raises(Exception):
+            ctx.search_hits_batch(G + [C.Guide("ACGTACGTACGTACGTACGTAAAAnrg")], ids + ["x"], params, "v0", "stamp")   # another length
+    finally:
+        ctx.close()
+
+
 def test_cpp_cli_search_reference(C, tmp_path):
     """The `calitas SearchReference` binary with the reference's flags (SearchReference.scala:452-470), FASTA in, hits.txt out."""
     import subprocess
