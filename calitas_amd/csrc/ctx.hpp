@@ -67,6 +67,17 @@ struct calitas_ctx {
 
 int calitas_fail(calitas_ctx* ctx, int code, const std::string& msg);
 void* calitas_out_alloc(size_t size);
+void* calitas_out_alloc_pinned(size_t size);   // page-locked: the destination of the text copy-back
+// search.cpp
+int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                        calitas_aln_t** out, uint64_t* n_out);
+int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                             const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
+int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
+                                   const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
+                                   uint64_t* tsv_bytes, uint64_t* n_rows);
+void calitas_destroy_lanes(calitas_ctx* ctx);
+void calitas_default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp);
 // Per-guide device constants for limits (d, p) and costs; returns an error text or "".
 std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, int max_guide_diffs, int max_pam_mismatches,
                             GuideDev& gd);

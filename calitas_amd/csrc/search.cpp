@@ -1,0 +1,938 @@
+// search.cpp -- the search pipeline behind calitas_search / calitas_search_hits / calitas_search_hits_batch: planning, lane
+// (stream + buffers) management, the scan -> align -> trace -> filter -> rows chain, and the lanes that pipeline contig ranges
+// or guides against each other.  The C entry points themselves are in api.cpp.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ctx.hpp"
+
+static int fail(calitas_ctx* ctx, int code, const std::string& msg) { return calitas_fail(ctx, code, msg); }
+static void* out_alloc(size_t size) { return calitas_out_alloc(size); }
+
+std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, int max_guide_diffs, int max_pam_mismatches,
+                            GuideDev& gd) {
+  std::memset(&gd, 0, sizeof(gd));
+  const int L = (int)gh.q.size();
+  gd.L = L;
+  gd.n_pams = (int)gh.pams_q.size();
+  gd.cli_length = gh.cli_length;
+  gd.min_guide_score = sc.match * L + sc.worst_guide_diff * max_guide_diffs;         // SGA:239-243
+  gd.max_guide_diffs = max_guide_diffs;
+  gd.max_pam_mismatches = max_pam_mismatches;
+  gd.max_diffs_filtering = max_guide_diffs + p.max_gaps_between_guide_and_pam + max_pam_mismatches;   // SGA:249
+  gd.pam5 = gh.pam5 ? 1 : 0;
+  const int budget = sc.match * L - gd.min_guide_score;                              // = |worst| * d
+  // score(all matches) - score(path) = sum of per-edit costs: mismatch |m|, guide-only base |b|, genome-only base |B|
+  const int c_mm = iabs(p.guide_mismatch_net_cost), c_ins = iabs(p.genome_gap_net_cost), c_del = iabs(p.guide_gap_net_cost);
+  const int c_min = std::min(c_mm, std::min(c_ins, c_del));
+  if (c_min <= 0 || c_del <= 0) return "net costs of 0 are not supported (the candidate filter needs every edit to cost something)";
+  gd.scan_max_edits = budget / c_min;
+  const int max_del = budget / c_del;
+  gd.span = L + max_del;
+  if (gd.span + 1 + 16 > STRIP_MAX_COLS || gd.span + 1 > RAW_MAX_OPS)
+    return "max-guide-diffs too large for this protospacer (strip wider than the aligner kernel supports)";
+  if (L + gd.scan_max_edits > 64) return "max-guide-diffs too large for the scan warm-up";
+  for (int code = 0; code < 4; code++) {
+    uint32_t v = 0;
+    for (int i = 0; i < L; i++) if (iupac_mask((unsigned char)gh.q[i]) & (1 << code)) v |= 1u << (32 - L + i);
+    gd.peq_a[code] = v;
+  }
+  uint32_t all = 0;
+  for (int i = 0; i < L; i++) all |= 1u << (32 - L + i);
+  gd.peq_a[4] = 0; gd.peq_a[5] = all; gd.peq_a[6] = 0; gd.peq_a[7] = 0;
+  for (int code = 0; code < 4; code++) gd.peq_b[code] = gd.peq_a[3 - code];
+  for (int k = 4; k < 8; k++) gd.peq_b[k] = gd.peq_a[k];
+  for (int i = 0; i < L; i++) gd.qmask[i] = (uint8_t)iupac_mask((unsigned char)gh.q[i]);
+  for (int pi = 0; pi < gd.n_pams; pi++) {
+    gd.pam_len[pi] = (uint8_t)gh.pams_q[pi].size();
+    for (size_t k = 0; k < gh.pams_q[pi].size(); k++) gd.pam_mask[pi][k] = (uint8_t)iupac_mask((unsigned char)gh.pams_q[pi][k]);
+  }
+  return "";
+}
+
+int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec, uint32_t item_cap) {
+  rec_cap = std::max(rec_cap, ctx->rec_cap);
+  if (item_cap > ctx->item_cap) {
+    (void)hipFree(ctx->d_items); ctx->d_items = nullptr; ctx->item_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_items, (size_t)item_cap * sizeof(uint64_t)));
+    ctx->item_cap = item_cap;
+  }
+  if ((uint64_t)rec_cap * slab_per_rec > ctx->slab_cap) {
+    (void)hipFree(ctx->d_slab); ctx->d_slab = nullptr; ctx->slab_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slab, (size_t)rec_cap * slab_per_rec));
+    ctx->slab_cap = (uint64_t)rec_cap * slab_per_rec;
+  }
+  if (rec_cap > ctx->rec_cap) {
+    (void)hipFree(ctx->d_recs); ctx->d_recs = nullptr; ctx->rec_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_recs, (size_t)rec_cap * sizeof(ScanRecord)));
+    ctx->rec_cap = rec_cap;
+  }
+  if (raw_cap > ctx->raw_cap) {
+    (void)hipFree(ctx->d_raw); ctx->d_raw = nullptr; ctx->raw_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_raw, (size_t)raw_cap * sizeof(RawAln)));
+    ctx->raw_cap = raw_cap;
+  }
+  return CALITAS_OK;
+}
+
+// A lane of a chunked search (see calitas_search_hits) is a child context: its own stream, buffers and scratch, the
+// parent's resident reference and window table.
+static inline calitas_ctx* ref_owner(calitas_ctx* ctx) { return ctx->parent ? ctx->parent : ctx; }
+
+// Everything about one search that does not depend on the lane running it.
+struct SearchPlan {
+  calitas_params_t p{};
+  int n_guides = 0, step = 0, max_total = 0;
+  Scores sc{};
+  std::vector<GuideHost> gh;
+  std::vector<GuideDev> gd;
+  uint32_t slots_per_rec = 0, slab_bytes = 0;
+  uint64_t slab_per_rec = 0;
+  // the part of the packed reference this job covers
+  uint32_t tile_lo = 0, n_tiles = 0;
+  uint64_t bases = 0;
+};
+
+// Accepted alignments left on the device by search_impl for calitas_search_hits.
+struct DeviceSel {
+  bool valid = false;
+  const RawAln* d_final = nullptr;
+  uint32_t n_sel = 0;
+  std::chrono::steady_clock::time_point t_call;
+};
+
+// Copies the device-selected alignments back and converts them to GuideAlignment records (GA:21-31, SGA:260-313).
+static int convert_selected(calitas_ctx* ctx, const RawAln* d_final, uint32_t n_sel, const std::vector<GuideHost>& gh,
+                            const calitas_params_t& p, int step, calitas_aln_t** out) {
+  const PackedRef& ref = ref_owner(ctx)->ref;
+  if (n_sel > ctx->h_raw_cap) {
+    if (ctx->h_raw) (void)hipHostFree(ctx->h_raw);
+    ctx->h_raw = nullptr; ctx->h_raw_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_raw, (size_t)ctx->raw_cap * sizeof(RawAln), hipHostMallocDefault));
+    ctx->h_raw_cap = ctx->raw_cap;
+  }
+  if (n_sel) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, d_final, (size_t)n_sel * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const RawAln* raw = ctx->h_raw;
+  calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_sel) * sizeof(calitas_aln_t));
+  if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  ref_owner(ctx)->pool->for_blocks(n_sel, [&](size_t b, size_t e, int) {
+    for (size_t i = b; i < e; i++) {
+      const RawAln& r = raw[i];
+      int64_t wa = 0, wb = 0;
+      window_bounds(ref.runs.data(), (int64_t)ref.runs.size(), ref.contigs[r.contig].gbase, ref.contigs[r.contig].len, p.window_size, step,
+                    r.window_k, wa, wb);
+      raw_to_aln(r, gh[r.guide], wa, wb, result[i]);
+    }
+  });
+  *out = result;
+  return CALITAS_OK;
+}
+
+// Validation and the host-side constants of a search.  Covers the whole reference (or the one contig of chrom_index);
+// a chunked search narrows tile_lo / n_tiles / bases per lane afterwards.
+static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params, SearchPlan& pl) {
+  if (!guides || !params) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  if (ctx->device < 0) return fail(ctx, CALITAS_ENODEV, "host-only context: calitas_search needs a GPU (there is no CPU fallback)");
+  if (!ref_owner(ctx)->has_ref) return fail(ctx, CALITAS_ESTATE, "calitas_set_reference has not been called");
+  if (n_guides <= 0 || n_guides > MAX_GUIDES) return fail(ctx, CALITAS_EINVAL, "n_guides must be 1..64");
+  const calitas_params_t& p = *params;
+  if (p.window_size <= 0 || p.window_size > 60000) return fail(ctx, CALITAS_EINVAL, "window-size must be 1..60000");
+  if (p.max_guide_diffs < 0 || p.max_pam_mismatches < 0 || p.max_gaps_between_guide_and_pam < 0 || p.max_gaps_between_guide_and_pam > 16)
+    return fail(ctx, CALITAS_EINVAL, "limits out of range (max-gaps-between-guide-and-pam must be 0..16)");
+  const PackedRef& ref = ref_owner(ctx)->ref;
+  if (p.chrom_index >= (int)ref.contigs.size()) return fail(ctx, CALITAS_EINVAL, "chrom_index out of range");
+  pl.p = p; pl.n_guides = n_guides;
+  pl.sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
+  pl.max_total = p.max_total_diffs >= 0 ? p.max_total_diffs : p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;
+  pl.gh.assign(n_guides, GuideHost());
+  pl.gd.assign(n_guides, GuideDev());
+  for (int i = 0; i < n_guides; i++) {
+    std::string e = make_guide_host(guides[i], pl.gh[i]);
+    if (e.empty()) e = build_guide_dev(pl.gh[i], p, pl.sc, p.max_guide_diffs, p.max_pam_mismatches, pl.gd[i]);
+    if (!e.empty()) return fail(ctx, CALITAS_EINVAL, "guide " + std::to_string(i) + ": " + e);
+    // SR:529-530: the window step depends on the CLI guide length; one pass shares one tiling
+    int overlap = pl.gh[i].cli_length + p.max_guide_diffs + p.max_gaps_between_guide_and_pam - 1;
+    int s = p.window_size - overlap;
+    if (s <= 0) return fail(ctx, CALITAS_EINVAL, "window-size is not larger than guide length + max-guide-diffs + max-gaps - 1");
+    if (i == 0) pl.step = s;
+    else if (s != pl.step) return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
+    if ((pl.gd[i].L + pl.gd[i].scan_max_edits + 15) / 16 > ref.chunk / 16) return fail(ctx, CALITAS_EINVAL, "scan warm-up exceeds the lane chunk");
+  }
+  // Strip slabs (align_kernel -> trace_kernel): fixed size and fixed address per (record, window slot).
+  pl.slots_per_rec = (uint32_t)((p.window_size + 14) / pl.step + 1);   // windows a 16-base word can fall into
+  if (pl.slots_per_rec > 8) return fail(ctx, CALITAS_EINVAL, "window step is too small relative to the window size (more than 8 windows per position)");
+  pl.slab_bytes = 0;
+  for (int i = 0; i < n_guides; i++) {
+    const uint32_t ncols_max = 16 + pl.gd[i].span + 1;
+    const uint32_t stride_max = (ncols_max + 4) & ~3u;
+    const uint32_t ntb_max = (ncols_max + p.max_gaps_between_guide_and_pam + MAX_PAM_LEN + 3) & ~3u;
+    pl.slab_bytes = std::max<uint32_t>(pl.slab_bytes, (uint32_t)((sizeof(SlabHeader) + ntb_max + pl.gd[i].L * stride_max + 15) & ~15u));
+  }
+  pl.slab_per_rec = (uint64_t)pl.slab_bytes * pl.slots_per_rec;
+  pl.tile_lo = 0; pl.n_tiles = (uint32_t)ref.tiles.size();
+  pl.bases = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
+  return CALITAS_OK;
+}
+
+// The device window table for (window size, step) lives with the reference; (re)built on `stream` when the tiling changes.
+static int ensure_window_table(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
+  calitas_ctx* o = ref_owner(ctx);
+  if (o->win_W == pl.p.window_size && o->win_step == pl.step) return CALITAS_OK;
+  const PackedRef& ref = o->ref;
+  std::vector<uint64_t> wb(ref.contigs.size() + 1, 0);
+  for (size_t c = 0; c < ref.contigs.size(); c++) wb[c + 1] = wb[c] + window_count(ref.contigs[c].len, pl.step);
+  const uint64_t nw = wb.back();
+  if (!o->d_win_base) HIP_TRY(ctx, hipMalloc((void**)&o->d_win_base, wb.size() * sizeof(uint64_t)));
+  if (nw > o->win_cap) {
+    (void)hipFree(o->d_win); o->d_win = nullptr; o->win_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&o->d_win, std::max<uint64_t>(1, nw) * sizeof(int2)));
+    o->win_cap = nw;
+  }
+  HIP_TRY(ctx, hipMemcpy(o->d_win_base, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, launch_window_table(o->d_runs, (int64_t)ref.runs.size(), o->d_contigs, o->d_win_base, (int)ref.contigs.size(), nw,
+                                   pl.p.window_size, pl.step, o->d_win, stream));
+  o->win_W = pl.p.window_size; o->win_step = pl.step;
+  return CALITAS_OK;
+}
+
+static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& sa, AlignArgs& aa) {
+  const calitas_ctx* o = ref_owner(ctx);
+  const PackedRef& ref = o->ref;
+  const calitas_params_t& p = pl.p;
+  sa = ScanArgs{};
+  sa.codes = o->d_codes; sa.mask = o->d_mask; sa.tiles = o->d_tiles; sa.guides = ctx->d_guides;
+  sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
+  sa.n_guides = pl.n_guides; sa.chrom_index = p.chrom_index; sa.tile_offset = pl.tile_lo;
+  sa.debug_skip = std::getenv("CALITAS_DEBUG_SCAN") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SCAN")) : 0u;
+  aa = AlignArgs{};
+  aa.codes = o->d_codes; aa.mask = o->d_mask; aa.runs = o->d_runs; aa.n_runs = (int64_t)ref.runs.size();
+  aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
+  aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
+  aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
+  aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
+  aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
+  aa.debug_skip = std::getenv("CALITAS_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SKIP")) : 0u;
+  aa.sp.window_size = p.window_size; aa.sp.step = pl.step; aa.sp.n_guides = pl.n_guides;
+  aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
+  aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
+  aa.sp.max_diffs_filtering = p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;   // SGA:249
+  aa.sp.match = pl.sc.match; aa.sp.mismatch = pl.sc.mismatch; aa.sp.pam_match = pl.sc.pam_match; aa.sp.pam_mismatch = pl.sc.pam_mismatch;
+  aa.sp.query_gap = pl.sc.query_gap; aa.sp.target_gap = pl.sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score; aa.sp.chrom_index = p.chrom_index;
+}
+
+// Device buffers of one lane for this plan (allocation only).
+static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
+  const uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, pl.bases / 8 + 1024));
+  return ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), pl.slab_per_rec,
+                        std::max<uint32_t>(ctx->item_cap, (uint32_t)(2 * want)));
+}
+
+// Guides, cleared counters and the scan kernel of this lane, queued on `stream` (the lane's own, or the shared scan
+// stream of a chunked search); ev[0] / ev[1] bracket the kernel.
+static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides, hipMemcpyHostToDevice, stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), stream));
+  ScanArgs sa; AlignArgs aa;
+  fill_kernel_args(ctx, pl, sa, aa);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+  HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+  return CALITAS_OK;
+}
+
+// calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
+// (dev->valid), and *out stays NULL.  prelaunched: the scan stage of this lane was queued by the caller on another stream
+// and ctx->stream already waits for it; an overflow then fails the call instead of retrying.
+static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** out, uint64_t* n_out, DeviceSel* dev, bool prelaunched) {
+  const auto t_call = std::chrono::steady_clock::now();
+  *out = nullptr; *n_out = 0;
+  const calitas_params_t& p = pl.p;
+  const PackedRef& ref = ref_owner(ctx)->ref;
+  const int n_guides = pl.n_guides, step = pl.step, max_total = pl.max_total;
+  const std::vector<GuideHost>& gh = pl.gh;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!prelaunched) {
+    int rc = lane_prepare(ctx, pl);
+    if (rc) return rc;
+    rc = ensure_window_table(ctx, pl, ctx->stream);
+    if (rc) return rc;
+  }
+  calitas_timing_t tm{};
+  tm.bases_scanned = pl.bases;
+  tm.packed_bytes = (tm.bases_scanned + 3) / 4;
+  uint32_t n_rec = 0, n_raw = 0;
+  for (;;) {
+    if (!prelaunched) {
+      int rc = launch_scan_stage(ctx, pl, ctx->stream);
+      if (rc) return rc;
+    }
+    ScanArgs sa; AlignArgs aa;
+    fill_kernel_args(ctx, pl, sa, aa);
+    HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
+    HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
+    const uint32_t n_items = ctx->h_counters[3];
+    if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
+    if (n_rec > ctx->rec_cap || n_raw > ctx->raw_cap || n_items > ctx->item_cap) {
+      if (prelaunched) return fail(ctx, CALITAS_ESTATE, "lane buffers overflowed");   // the caller reruns unchunked
+      tm.retries++;
+      uint64_t nr = n_rec > ctx->rec_cap ? (uint64_t)n_rec + n_rec / 4 : ctx->rec_cap;
+      uint64_t nw = n_raw > ctx->raw_cap ? (uint64_t)n_raw * 2 : ctx->raw_cap;
+      if (n_rec > ctx->rec_cap)   // the raw count was cut short as well: scale it with the record count
+        nw = std::max<uint64_t>(nw, (uint64_t)((double)n_raw * nr / std::max<uint32_t>(1, ctx->rec_cap)) + 1024);
+      if (nr > 0xFFFFFFF0ull || nw > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
+      // passing candidates: as counted, or scaled with the record count when that was cut short
+      uint64_t ni = n_items > ctx->item_cap ? (uint64_t)n_items + n_items / 4 : ctx->item_cap;
+      if (n_rec > ctx->rec_cap) ni = std::max<uint64_t>(ni, (uint64_t)((double)std::max<uint32_t>(n_items, 1024) * nr / std::max<uint32_t>(1, ctx->rec_cap)) * 2);
+      if (ni > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
+      int rc = ensure_buffers(ctx, (uint32_t)nr, (uint32_t)nw, pl.slab_per_rec, (uint32_t)ni);
+      if (rc) return rc;
+      continue;
+    }
+    break;
+  }
+  const calitas_ctx* own = ref_owner(ctx);
+  // ---- per-window filter (SGA:315-320): on the GPU (select.hip) unless the tiling does not fit its sort key, a window
+  //      exceeds its group limit, or CALITAS_HOST_FILTER asks for the host implementation of the same stage ----
+  uint64_t max_wins = 0;
+  for (auto& c : ref.contigs) max_wins = std::max<uint64_t>(max_wins, window_count(c.len, step));
+  bool gpu_select = n_raw > 0 && !std::getenv("CALITAS_HOST_FILTER") && select_supported(ref.contigs.size(), max_wins, p.window_size, n_guides);
+  uint32_t n_sel = 0;
+  const RawAln* d_sel = nullptr;
+  if (gpu_select) {
+    const RawAln* d_final = nullptr;
+    const uint32_t* d_cnt = nullptr;
+    HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, max_total, p.max_overlap,
+                            ctx->stream, &d_final, &d_cnt));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_counters[6] != 0) gpu_select = false;   // a window with more alignments than one lane should chew through
+    else {
+      n_sel = ctx->h_counters[5];
+      d_sel = d_final;
+    }
+  }
+  if (!gpu_select && n_raw) {
+    if (n_raw > ctx->h_raw_cap) {   // pinned staging for the copy-back
+      if (ctx->h_raw) (void)hipHostFree(ctx->h_raw);
+      ctx->h_raw = nullptr; ctx->h_raw_cap = 0;
+      HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_raw, (size_t)ctx->raw_cap * sizeof(RawAln), hipHostMallocDefault));
+      ctx->h_raw_cap = ctx->raw_cap;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); tm.scan_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); tm.align_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); tm.gpu_total_ms = ms;
+  tm.scan_records = n_rec;
+  tm.raw_alignments = n_raw;
+
+  if (gpu_select) {
+    tm.accepted_alignments = n_sel;
+    tm.candidate_columns = ctx->h_counters[4];
+    if (dev) {   // calitas_search_hits goes on from the device copy
+      dev->valid = true; dev->d_final = d_sel; dev->n_sel = n_sel; dev->t_call = t_call;
+      ctx->timing = tm;
+      return CALITAS_OK;
+    }
+    // accepted alignments arrive in final order; only the coordinate conversion (GA:21-31, SGA:260-313) is left
+    auto t0 = std::chrono::steady_clock::now();
+    calitas_aln_t* result = nullptr;
+    int rc = convert_selected(ctx, d_sel, n_sel, gh, p, step, &result);
+    if (rc) return rc;
+    tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->timing = tm;
+    if (std::getenv("CALITAS_TRACE"))
+      std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms (incl. sort+filter on the GPU), copy+convert %.3f ms, call %.3f ms (%u records, %u raw, %u accepted)\n",
+                   tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_sel);
+    *n_out = n_sel;
+    *out = result;
+    return CALITAS_OK;
+  }
+  if (dev) dev->t_call = t_call;
+
+  // ---- host: restore the reference's enumeration order, then the per-window filter (SGA:315-320) ----
+  const RawAln* raw = ctx->h_raw;
+  WorkerPool* pool = ref_owner(ctx)->pool;                                  // lanes share the owner's pool, one at a time
+  std::lock_guard<std::mutex> host_lock(ref_owner(ctx)->host_mu);
+  // Raw records arrive in atomic-append order.  They are bucketed by (guide, contig, 4096-window chunk), each bucket is
+  // sorted by (window, strand list, end column, PAM) = fgbio's enumeration order (ascending end column) followed
+  // by the PAM order of extendAndFilterRight (SGA:455), filtered window by window, and the buckets are concatenated.
+  auto t0 = std::chrono::steady_clock::now();
+  constexpr int WCHUNK_SHIFT = 12;
+  const size_t n_contigs = ref.contigs.size();
+  std::vector<uint64_t> chunk_base(n_contigs + 1, 0);   // bucket index base per contig (within one guide)
+  for (size_t c = 0; c < n_contigs; c++)
+    chunk_base[c + 1] = chunk_base[c] + ((window_count(ref.contigs[c].len, step) >> WCHUNK_SHIFT) + 1);
+  const uint64_t buckets_per_guide = chunk_base[n_contigs];
+  const size_t n_buckets = (size_t)(buckets_per_guide * (uint64_t)n_guides);
+  auto bucket_of = [&](const RawAln& r) { return (size_t)(r.guide * buckets_per_guide + chunk_base[r.contig] + (r.window_k >> WCHUNK_SHIFT)); };
+  std::vector<uint32_t> bucket_off(n_buckets + 1, 0);
+  for (uint32_t i = 0; i < n_raw; i++) bucket_off[bucket_of(raw[i]) + 1]++;
+  for (size_t b = 0; b < n_buckets; b++) bucket_off[b + 1] += bucket_off[b];
+  std::vector<uint32_t> perm(n_raw);
+  {
+    std::vector<uint32_t> cur(bucket_off.begin(), bucket_off.end() - 1);
+    for (uint32_t i = 0; i < n_raw; i++) perm[cur[bucket_of(raw[i])]++] = i;
+  }
+  const auto t_bucketed = std::chrono::steady_clock::now();
+  std::vector<std::vector<calitas_aln_t>> bucket_out(n_buckets);
+  {
+    std::atomic<size_t> next(0);
+    pool->run([&](int) {
+      std::vector<std::pair<uint64_t, uint32_t>> keyed;
+      std::vector<calitas_aln_t> win;
+      std::vector<int> kept;
+      for (;;) {
+        size_t b = next.fetch_add(1);
+        if (b >= n_buckets) break;
+        const uint32_t lo = bucket_off[b], hi = bucket_off[b + 1];
+        if (lo == hi) continue;
+        keyed.clear();
+        for (uint32_t i = lo; i < hi; i++) {
+          const RawAln& r = raw[perm[i]];
+          const uint64_t list = gh[r.guide].pam5 ? (r.dir == 1 ? 0 : 1) : (r.dir == 0 ? 0 : 1);   // 0 = forward-strand list (SGA:316)
+          const uint64_t key = ((uint64_t)r.window_k << 24) | (list << 23) | ((uint64_t)r.t_end_guide << 5) | (uint64_t)(r.pam + 1);
+          keyed.emplace_back(key, perm[i]);
+        }
+        std::sort(keyed.begin(), keyed.end());
+        auto& outv = bucket_out[b];
+        size_t i = 0;
+        while (i < keyed.size()) {
+          const RawAln& f = raw[keyed[i].second];
+          size_t j = i;
+          while (j < keyed.size() && raw[keyed[j].second].window_k == f.window_k) j++;
+          int64_t wa = 0, wb = 0;
+          window_bounds(ref.runs.data(), (int64_t)ref.runs.size(), ref.contigs[f.contig].gbase, ref.contigs[f.contig].len, p.window_size,
+                        step, f.window_k, wa, wb);
+          if (win.size() < j - i) win.resize(j - i);
+          for (size_t k = i; k < j; k++) raw_to_aln(raw[keyed[k].second], gh[f.guide], wa, wb, win[k - i]);
+          window_filter(win.data(), (int)(j - i), max_total, p.max_overlap, kept);
+          for (int k : kept) outv.push_back(win[k]);
+          i = j;
+        }
+      }
+    });
+  }
+  const auto t_filtered = std::chrono::steady_clock::now();
+  std::vector<size_t> out_off(n_buckets + 1, 0);
+  for (size_t b = 0; b < n_buckets; b++) out_off[b + 1] = out_off[b] + bucket_out[b].size();
+  const size_t n_result = out_off[n_buckets];
+  calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_result) * sizeof(calitas_aln_t));
+  if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  {
+    std::atomic<size_t> next(0);
+    pool->run([&](int) {
+      for (;;) {
+        size_t b = next.fetch_add(1);
+        if (b >= n_buckets) break;
+        if (!bucket_out[b].empty()) std::memcpy(result + out_off[b], bucket_out[b].data(), bucket_out[b].size() * sizeof(calitas_aln_t));
+      }
+    });
+  }
+  tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (std::getenv("CALITAS_TRACE")) {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[calitas] host filter: bucket %.2f ms, sort+convert+filter %.2f ms, concat %.2f ms (%zu buckets)\n",
+                 ms(t0, t_bucketed), ms(t_bucketed, t_filtered), ms(t_filtered, std::chrono::steady_clock::now()), n_buckets);
+  }
+  if (std::getenv("CALITAS_TRACE"))
+    std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms, host filter %.3f ms, call %.3f ms (%u records, %u raw, %zu accepted)\n",
+                 tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_result);
+  tm.accepted_alignments = n_result;
+  tm.candidate_columns = ctx->h_counters[4];   // end columns whose best bottom-row score reached minGuideScore inside a window
+  ctx->timing = tm;
+
+  *n_out = n_result;
+  *out = result;
+  return CALITAS_OK;
+}
+
+int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                        calitas_aln_t** out, uint64_t* n_out) {
+  DeviceSel* dev = nullptr;
+  SearchPlan* plan_out = nullptr;
+  if (!ctx) return CALITAS_EINVAL;
+  if (!out || !n_out) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *out = nullptr; *n_out = 0;
+  SearchPlan local;
+  SearchPlan& pl = plan_out ? *plan_out : local;
+  int rc = plan_search(ctx, n_guides, guides, params, pl);
+  if (rc) return rc;
+  return search_run(ctx, pl, out, n_out, dev, false);
+}
+
+void calitas_default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp) {
+  version = aligner_version ? aligner_version : "";
+  stamp = time_stamp ? time_stamp : "";
+  if (version.empty()) {  // EditasMetric.Version without a jar manifest: unknown-YYYY-MM-DD
+    char b[32]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
+    std::strftime(b, sizeof b, "unknown-%Y-%m-%d", &tmv); version = b;
+  }
+  if (stamp.empty()) {    // RH:169-173 "EEE MMM dd HH:mm:ss z yyyy" in UTC
+    char b[64]; std::time_t t = std::time(nullptr); std::tm tmv; gmtime_r(&t, &tmv);
+    std::strftime(b, sizeof b, "%a %b %d %H:%M:%S UTC %Y", &tmv); stamp = b;
+  }
+}
+
+// ---- calitas_search_hits ------------------------------------------------------------------------------------------------
+
+// What one lane contributes to a hits.txt: rows on the device, or rows built by the host stages when a device stage declined.
+struct LaneText {
+  int rc = CALITAS_OK;
+  const char* d_text = nullptr;
+  uint64_t bytes = 0, rows = 0;
+  bool on_host = false;
+  std::string host_rows;
+  calitas_timing_t tm{};
+};
+
+// One lane from the scan stage (queued here, or already queued by the caller) to its finished rows.
+static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, const std::string& guide_id,
+                     const std::string& version, const std::string& stamp, LaneText& lt) {
+  calitas_ctx* own = ref_owner(lane);
+  const PackedRef& ref = own->ref;
+  const calitas_params_t& p = pl.p;
+  const GuideHost& gh = pl.gh[0];
+  DeviceSel dev;
+  calitas_aln_t* alns = nullptr;
+  uint64_t n_alns = 0;
+  int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched);
+  if (rc) return rc;
+  lt.tm = lane->timing;
+  if (dev.valid && !std::getenv("CALITAS_HOST_HITS")) {
+    // removeOverlaps, ReferenceHit.sort and the rows on the device (hits.hip); only text crosses PCIe
+    int max_pam = 0;
+    for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
+    const int score_hi = pl.sc.match * (int)gh.protospacer.size() + pl.sc.pam_match * max_pam;
+    const int worst_gap = std::max(iabs(pl.sc.query_gap), std::max(iabs(pl.sc.target_gap), iabs(pl.sc.mismatch)));
+    const int score_lo = pl.gd[0].min_guide_score - iabs(pl.sc.pam_mismatch) * max_pam - worst_gap * (p.max_gaps_between_guide_and_pam + 1);
+    if (hits_supported(ref.contigs.size(), p.max_overlap, score_lo, score_hi)) {
+      if (lane->hits_names_serial != own->ref_serial) {
+        HIP_TRY(lane, hits_set_names(&lane->hits, ref.names));
+        lane->hits_names_serial = own->ref_serial;
+      }
+      HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
+      HitsResult res{};
+      HIP_TRY(lane, hipEventRecord(lane->ev[0], lane->stream));
+      HIP_TRY(lane, hits_run(&lane->hits, hr, dev.d_final, dev.n_sel, lane->d_guides, own->d_win_base, own->d_win, rs, p.max_overlap, score_hi,
+                             pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, lane->stream, &res));
+      HIP_TRY(lane, hipEventRecord(lane->ev[1], lane->stream));
+      if (res.flags == 0) {
+        lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows;
+        return CALITAS_OK;
+      }
+      if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
+    }
+  }
+  // host tail: the same stages as calitas_hits_tsv (one lane at a time: they share the owner's worker pool)
+  std::lock_guard<std::mutex> host_lock(own->host_mu);
+  if (dev.valid) {
+    rc = convert_selected(lane, dev.d_final, dev.n_sel, pl.gh, p, pl.step, &alns);
+    if (rc) return rc;
+    n_alns = dev.n_sel;
+  }
+  uint64_t rows = 0;
+  char* text = hits_tsv(ref, gh, guide_id, p, alns, n_alns, version, stamp, &rows, own->pool, out_alloc, nullptr, 0);
+  calitas_free(alns);
+  if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
+  lt.on_host = true;
+  lt.host_rows.assign(text + rs.header.size());
+  calitas_free(text);
+  lt.bytes = lt.host_rows.size(); lt.rows = rows;
+  return CALITAS_OK;
+}
+
+// Child contexts of a chunked search: own stream (high priority), buffers and scratch; the parent's reference.
+static int ensure_lanes(calitas_ctx* ctx, size_t k) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (!ctx->scan_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, least));
+  if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest));
+  while (ctx->lanes.size() < k) {
+    calitas_ctx* c = new calitas_ctx();
+    c->device = ctx->device; c->parent = ctx;
+    bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) == hipSuccess;
+    for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->scan_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->rows_ready, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES) == hipSuccess;
+    ctx->lanes.push_back(c);
+    if (!ok) { calitas_destroy_lanes(ctx); return fail(ctx, CALITAS_EHIP, "could not create a search lane"); }
+  }
+  return CALITAS_OK;
+}
+
+void calitas_destroy_lanes(calitas_ctx* ctx) {
+  for (calitas_ctx* c : ctx->lanes) calitas_destroy(c);
+  ctx->lanes.clear();
+  if (ctx->scan_stream) { (void)hipStreamDestroy(ctx->scan_stream); ctx->scan_stream = nullptr; }
+  if (ctx->copy_stream) { (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
+}
+
+// Contig ranges [first, last) of a chunked search: cut at contig boundaries (removeOverlaps groups and the final sort never
+// cross a contig), sized by `weights`.
+static std::vector<std::pair<int, int>> chunk_ranges(const PackedRef& ref, const std::vector<double>& weights) {
+  const int n = (int)ref.contigs.size();
+  std::vector<std::pair<int, int>> out;
+  double wsum = 0;
+  for (double w : weights) wsum += w;
+  uint64_t total = ref.total_bases, acc = 0;
+  double target = 0;
+  int first = 0;
+  size_t k = 0;
+  for (int c = 0; c < n && k + 1 < weights.size(); c++) {
+    acc += ref.contigs[c].len;
+    const double goal = (target + weights[k]) / wsum * (double)total;
+    const uint64_t next = c + 1 < n ? ref.contigs[c + 1].len : 0;
+    // close the chunk after contig c when that lands nearer to the goal than taking one more contig would
+    if ((double)acc >= goal || (double)acc + (double)next / 2 > goal) {
+      if (c + 1 < n) { out.emplace_back(first, c + 1); first = c + 1; target += weights[k]; k++; }
+    }
+  }
+  out.emplace_back(first, n);
+  return out;
+}
+
+int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                            const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+  const auto t_call = std::chrono::steady_clock::now();
+  *tsv = nullptr;
+  if (tsv_bytes) *tsv_bytes = 0;
+  if (n_rows) *n_rows = 0;
+  SearchPlan pl;
+  int rc = plan_search(ctx, 1, guide, params, pl);
+  if (rc) return rc;
+  const PackedRef& ref = ctx->ref;
+  std::string version, stamp;
+  calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+  const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  // ---- how many lanes: one pass over the whole reference, or contig ranges pipelined against each other ----
+  std::vector<double> weights;
+  if (const char* e = std::getenv("CALITAS_CHUNKS")) {
+    // "3" = three equal chunks, "5:3:2" = relative sizes
+    for (const char* q = e; *q;) {
+      char* end = nullptr;
+      double v = std::strtod(q, &end);
+      if (end == q) break;
+      weights.push_back(v);
+      q = *end == ':' ? end + 1 : end;
+    }
+    if (weights.size() == 1) { int k = std::max(1, std::min(16, (int)weights[0])); weights.assign((size_t)k, 1.0); }
+    for (double w : weights) if (!(w > 0)) { weights.clear(); break; }
+  } else if (ref.total_bases >= (512ull << 20)) {
+    weights = {5, 4};      // measured on hg38-sized input: more lanes cost more in per-lane fixed work than they hide
+  }
+  std::vector<std::pair<int, int>> ranges;
+  if (weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);
+  const size_t K = ranges.size() > 1 ? ranges.size() : 1;
+
+  std::vector<LaneText> parts(K);
+  std::vector<calitas_ctx*> lanes(K, ctx);
+  char* text = nullptr;
+  size_t capacity = 0;
+  const size_t hlen = rs.header.size();
+  std::mutex copy_mu;
+  auto alloc_text = [&](size_t body) {
+    capacity = body;
+    text = (char*)calitas_out_alloc_pinned(hlen + body + 1);
+    if (text) std::memcpy(text, rs.header.data(), hlen);
+    return text != nullptr;
+  };
+  // copies lane c's rows to their place (offset = header + rows of the lanes before it)
+  auto place = [&](size_t c, size_t offset) -> int {
+    LaneText& lt = parts[c];
+    if (!lt.bytes) return CALITAS_OK;
+    if (lt.on_host) { std::memcpy(text + hlen + offset, lt.host_rows.data(), lt.bytes); return CALITAS_OK; }
+    calitas_ctx* lane = lanes[c];
+    if (lane->parent) {
+      // all text copies of a chunked call go through one stream: PCIe is one resource, and one stream is one thing to warm up
+      HIP_TRY(lane, hipEventRecord(lane->rows_ready, lane->stream));
+      {
+        std::lock_guard<std::mutex> lk(copy_mu);
+        HIP_TRY(lane, hipStreamWaitEvent(ctx->copy_stream, lane->rows_ready, 0));
+        HIP_TRY(lane, hipEventRecord(lane->ev[2], ctx->copy_stream));
+        HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIP_TRY(lane, hipEventRecord(lane->ev[3], ctx->copy_stream));
+      }
+      HIP_TRY(lane, hipEventSynchronize(lane->ev[3]));
+    } else {
+      HIP_TRY(lane, hipEventRecord(lane->ev[2], lane->stream));
+      HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, lane->stream));
+      HIP_TRY(lane, hipEventRecord(lane->ev[3], lane->stream));
+      HIP_TRY(lane, hipStreamSynchronize(lane->stream));
+    }
+    float ms = 0;
+    if (!lt.on_host) { (void)hipEventElapsedTime(&ms, lane->ev[0], lane->ev[1]); lt.tm.hits_kernel_ms = ms; }
+    (void)hipEventElapsedTime(&ms, lane->ev[2], lane->ev[3]); lt.tm.hits_copy_ms = ms;
+    return CALITAS_OK;
+  };
+
+  bool chunked = K > 1;
+  if (chunked) {
+    rc = ensure_lanes(ctx, K);
+    if (rc) return rc;
+    std::vector<SearchPlan> plans(K, pl);
+    for (size_t c = 0; c < K && !rc; c++) {
+      lanes[c] = ctx->lanes[c];
+      SearchPlan& q = plans[c];
+      q.tile_lo = (uint32_t)(ref.contigs[ranges[c].first].gbase / ref.tile);
+      const uint32_t tile_hi = ranges[c].second < (int)ref.contigs.size() ? (uint32_t)(ref.contigs[ranges[c].second].gbase / ref.tile) : (uint32_t)ref.tiles.size();
+      q.n_tiles = tile_hi - q.tile_lo;
+      q.bases = 0;
+      for (int k = ranges[c].first; k < ranges[c].second; k++) q.bases += ref.contigs[k].len;
+      rc = lane_prepare(lanes[c], q);
+      if (rc) ctx->err = lanes[c]->err;
+    }
+    if (rc) return rc;
+    // all scans go to one low-priority stream in chunk order; each lane's own (high-priority) stream picks its chunk up
+    // when its scan is done, so the tail of chunk c runs while chunk c+1 is still being scanned
+    rc = ensure_window_table(ctx, pl, ctx->scan_stream);
+    if (rc) return rc;
+    for (size_t c = 0; c < K; c++) {
+      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);
+      if (rc) { ctx->err = lanes[c]->err; break; }
+      HIP_TRY(ctx, hipEventRecord(lanes[c]->scan_done, ctx->scan_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0));
+    }
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }
+    auto guess = [](size_t last) { return last + last / 4 + (1u << 20); };   // the next call's text is about as long as the last one's
+    if (!alloc_text(guess(ctx->last_text_bytes))) {
+      (void)hipDeviceSynchronize();
+      return fail(ctx, CALITAS_EINVAL, "out of memory");
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> done(K, 0);
+    std::vector<char> placed(K, 0);
+    std::vector<std::thread> threads;
+    for (size_t c = 0; c < K; c++) {
+      threads.emplace_back([&, c] {
+        (void)hipSetDevice(ctx->device);
+        LaneText& lt = parts[c];
+        lt.rc = lane_rows(lanes[c], plans[c], true, rs, guide_id, version, stamp, lt);
+        size_t offset = 0;
+        bool ok = lt.rc == CALITAS_OK;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          done[c] = 1;
+          cv.notify_all();
+          cv.wait(lk, [&] { for (size_t i = 0; i < c; i++) if (!done[i]) return false; return true; });
+          for (size_t i = 0; i < c; i++) { offset += parts[i].bytes; ok = ok && parts[i].rc == CALITAS_OK; }
+        }
+        if (ok && offset + lt.bytes <= capacity) {
+          int r = place(c, offset);
+          if (r) lt.rc = r; else placed[c] = 1;
+        }
+      });
+    }
+    for (auto& t : threads) t.join();
+    rc = CALITAS_OK;
+    bool overflow = false;
+    for (size_t c = 0; c < K; c++) {
+      if (parts[c].rc == CALITAS_ESTATE) overflow = true;
+      else if (parts[c].rc && !rc) { rc = parts[c].rc; ctx->err = lanes[c]->err; }
+    }
+    if (rc || overflow) {
+      (void)hipDeviceSynchronize();
+      calitas_free(text); text = nullptr;
+      if (rc) return rc;
+      if (trace) std::fprintf(stderr, "[calitas] search_hits: a lane's buffers overflowed, rerunning in one pass\n");
+      chunked = false;
+      parts.assign(1, LaneText()); lanes.assign(1, ctx);
+    } else {
+      size_t total = 0;
+      for (auto& lt : parts) total += lt.bytes;
+      bool all = true;
+      for (size_t c = 0; c < K; c++) all = all && (placed[c] || parts[c].bytes == 0);
+      if (!all) {   // the guess was too small: place everything again in a buffer of the right size
+        calitas_free(text);
+        if (!alloc_text(guess(total))) return fail(ctx, CALITAS_EINVAL, "out of memory");   // big enough for the next call's guess as well
+        size_t off = 0;
+        for (size_t c = 0; c < K; c++) { rc = place(c, off); if (rc) { ctx->err = lanes[c]->err; calitas_free(text); return rc; } off += parts[c].bytes; }
+      }
+    }
+  }
+  if (!chunked) {
+    rc = lane_rows(ctx, pl, false, rs, guide_id, version, stamp, parts[0]);
+    if (rc) return rc;
+    if (!alloc_text((size_t)parts[0].bytes)) return fail(ctx, CALITAS_EINVAL, "out of memory");
+    rc = place(0, 0);
+    if (rc) { calitas_free(text); return rc; }
+  }
+  size_t total = hlen;
+  calitas_timing_t tm{};
+  uint64_t rows = 0;
+  for (auto& lt : parts) {
+    total += lt.bytes; rows += lt.rows;
+    tm.scan_kernel_ms += lt.tm.scan_kernel_ms; tm.align_kernel_ms += lt.tm.align_kernel_ms; tm.gpu_total_ms += lt.tm.gpu_total_ms;
+    tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
+    tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
+    tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries;
+    tm.hits_kernel_ms += lt.tm.hits_kernel_ms; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+  }
+  text[total] = 0;
+  tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = (uint32_t)parts.size();
+  ctx->timing = tm;
+  ctx->last_text_bytes = total;
+  if (trace)
+    std::fprintf(stderr, "[calitas] search_hits: %zu lane(s), scan %.3f ms, align %.3f ms, hits kernels %.3f ms, text copy %.3f ms (sums over lanes), call %.3f ms (%llu accepted, %llu rows, %zu bytes)\n",
+                 parts.size(), tm.scan_kernel_ms, tm.align_kernel_ms, tm.hits_kernel_ms, tm.hits_copy_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),
+                 (unsigned long long)tm.accepted_alignments, (unsigned long long)rows, total);
+  *tsv = text;
+  if (tsv_bytes) *tsv_bytes = total;
+  if (n_rows) *n_rows = rows;
+  return CALITAS_OK;
+}
+
+// ---- calitas_search_hits_batch ----------------------------------------------------------------------------------------
+// Guides flow through the lanes as a pipeline: every lane thread queues the scan of its next guide on the shared low-priority
+// scan stream and then runs that guide's tail (align ... rows, copy) on its own stream, so guide g+1 is being scanned while
+// guide g's tail runs.  Each guide's text goes to its own pinned buffer.
+int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
+                                  const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
+                                  uint64_t* tsv_bytes, uint64_t* n_rows) {
+  const auto t_call = std::chrono::steady_clock::now();
+  for (int i = 0; i < n_guides; i++) { tsv[i] = nullptr; if (tsv_bytes) tsv_bytes[i] = 0; if (n_rows) n_rows[i] = 0; }
+  std::string version, stamp;
+  calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  auto release = [&]() { for (int i = 0; i < n_guides; i++) { calitas_free(tsv[i]); tsv[i] = nullptr; } };
+  int n_lanes = 3;
+  if (const char* e = std::getenv("CALITAS_BATCH_LANES")) n_lanes = std::max(1, std::min(8, std::atoi(e)));
+  n_lanes = std::min(n_lanes, (int)n_guides);
+  if (n_lanes < 2) {   // nothing to pipeline
+    for (int i = 0; i < n_guides; i++) {
+      int rc = calitas_search_hits_impl(ctx, &guides[i], guide_ids && guide_ids[i] ? guide_ids[i] : "", params, version.c_str(), stamp.c_str(), &tsv[i],
+                                tsv_bytes ? &tsv_bytes[i] : nullptr, n_rows ? &n_rows[i] : nullptr);
+      if (rc) { release(); return rc; }
+    }
+    return CALITAS_OK;
+  }
+  // plans first: every guide is validated before anything is queued, and all must share one window tiling
+  std::vector<SearchPlan> plans((size_t)n_guides);
+  for (int i = 0; i < n_guides; i++) {
+    int rc = plan_search(ctx, 1, &guides[i], params, plans[i]);
+    if (rc) return rc;
+    if (plans[i].step != plans[0].step)
+      return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_lanes(ctx, (size_t)n_lanes);
+  if (rc) return rc;
+  for (int l = 0; l < n_lanes && !rc; l++) { rc = lane_prepare(ctx->lanes[l], plans[0]); if (rc) ctx->err = ctx->lanes[l]->err; }
+  if (rc) return rc;
+  rc = ensure_window_table(ctx, plans[0], ctx->scan_stream);
+  if (rc) return rc;
+  const PackedRef& ref = ctx->ref;
+  std::mutex scan_mu, copy_mu;
+  std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
+  std::vector<calitas_timing_t> tms((size_t)n_guides);
+  std::vector<std::thread> threads;
+  for (int l = 0; l < n_lanes; l++) {
+    threads.emplace_back([&, l] {
+      (void)hipSetDevice(ctx->device);
+      calitas_ctx* lane = ctx->lanes[l];
+      for (int g = l; g < n_guides; g += n_lanes) {
+        const SearchPlan& pl = plans[g];
+        const std::string gid = guide_ids && guide_ids[g] ? guide_ids[g] : "";
+        const RowStrings rs = make_row_strings(ref, pl.gh[0], gid, pl.p, version, stamp);
+        auto step = [&]() -> int {
+          {
+            // the previous guide of this lane is completely done (its text was copied before the loop went on), so the
+            // lane's buffers are free for this scan
+            std::lock_guard<std::mutex> lk(scan_mu);
+            int r = launch_scan_stage(lane, pl, ctx->scan_stream);
+            if (r) return r;
+            HIP_TRY(lane, hipEventRecord(lane->scan_done, ctx->scan_stream));
+            HIP_TRY(lane, hipStreamWaitEvent(lane->stream, lane->scan_done, 0));
+          }
+          LaneText lt;
+          int r = lane_rows(lane, pl, true, rs, gid, version, stamp, lt);
+          if (r) return r;
+          const size_t hlen = rs.header.size(), total = hlen + (size_t)lt.bytes;
+          char* text = (char*)calitas_out_alloc_pinned(total + 1);
+          if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
+          std::memcpy(text, rs.header.data(), hlen);
+          if (lt.bytes && lt.on_host) std::memcpy(text + hlen, lt.host_rows.data(), (size_t)lt.bytes);
+          else if (lt.bytes) {
+            hipError_t e = hipEventRecord(lane->rows_ready, lane->stream);
+            {
+              std::lock_guard<std::mutex> lk(copy_mu);
+              if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, lane->rows_ready, 0);
+              if (e == hipSuccess) e = hipMemcpyAsync(text + hlen, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream);
+              if (e == hipSuccess) e = hipEventRecord(lane->ev[3], ctx->copy_stream);
+            }
+            if (e == hipSuccess) e = hipEventSynchronize(lane->ev[3]);
+            if (e != hipSuccess) { calitas_free(text); return fail(lane, CALITAS_EHIP, std::string("text copy: ") + hipGetErrorString(e)); }
+          }
+          text[total] = 0;
+          tsv[g] = text;
+          if (tsv_bytes) tsv_bytes[g] = total;
+          if (n_rows) n_rows[g] = lt.rows;
+          tms[g] = lt.tm; tms[g].hit_rows = lt.rows; tms[g].hits_bytes = total;
+          return CALITAS_OK;
+        };
+        rcs[g] = step();
+        if (rcs[g] != CALITAS_OK) (void)hipStreamSynchronize(lane->stream);   // leave the lane quiet before its next guide
+      }
+    });
+  }
+  for (auto& t : threads) t.join();
+  for (int g = 0; g < n_guides; g++) {
+    if (rcs[g] == CALITAS_OK) continue;
+    if (rcs[g] == CALITAS_ESTATE) {   // a lane's buffers overflowed: this guide again, in one pass with the retry logic
+      int r = calitas_search_hits_impl(ctx, &guides[g], guide_ids && guide_ids[g] ? guide_ids[g] : "", params, version.c_str(), stamp.c_str(), &tsv[g],
+                               tsv_bytes ? &tsv_bytes[g] : nullptr, n_rows ? &n_rows[g] : nullptr);
+      if (r) { release(); return r; }
+      tms[g] = ctx->timing;
+      continue;
+    }
+    ctx->err = ctx->lanes[g % n_lanes]->err;
+    release();
+    return rcs[g];
+  }
+  calitas_timing_t tm{};
+  for (auto& t : tms) {
+    tm.scan_kernel_ms += t.scan_kernel_ms; tm.align_kernel_ms += t.align_kernel_ms; tm.gpu_total_ms += t.gpu_total_ms;
+    tm.bases_scanned += t.bases_scanned; tm.packed_bytes += t.packed_bytes; tm.scan_records += t.scan_records;
+    tm.candidate_columns += t.candidate_columns; tm.raw_alignments += t.raw_alignments; tm.accepted_alignments += t.accepted_alignments;
+    tm.retries += t.retries; tm.hit_rows += t.hit_rows; tm.hits_bytes += t.hits_bytes;
+  }
+  tm.lanes = (uint32_t)n_lanes;
+  ctx->timing = tm;
+  if (std::getenv("CALITAS_TRACE"))
+    std::fprintf(stderr, "[calitas] search_hits_batch: %d guides on %d lanes, scan %.3f ms, align %.3f ms (sums), call %.3f ms (%llu rows, %llu bytes)\n",
+                 n_guides, n_lanes, tm.scan_kernel_ms, tm.align_kernel_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),
+                 (unsigned long long)tm.hit_rows, (unsigned long long)tm.hits_bytes);
+  return CALITAS_OK;
+}
+
