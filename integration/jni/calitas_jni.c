@@ -78,6 +78,34 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
   return (*env)->NewDirectByteBuffer(env, alns, (jlong)(n * sizeof(calitas_aln_t)));
 }
 
+/* calitas_search_hits: the finished hits.txt text (header + rows) for one guide as a direct ByteBuffer over the library-owned
+ * (page-locked) text; `free` releases it.  version may be null (then "unknown-<date>" like EditasMetric.Version without a jar). */
+JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_searchHits(JNIEnv* env, jobject self, jlong h,
+    jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jstring guideId, jintArray params, jstring version) {
+  calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
+  calitas_guide_t g;
+  calitas_params_t p;
+  const jsize np = (*env)->GetArrayLength(env, pams);
+  const char* cp[CALITAS_MAX_PAMS];
+  jstring jp[CALITAS_MAX_PAMS];
+  if (np > CALITAS_MAX_PAMS) { throw_state(env, "too many PAMs"); return NULL; }
+  g.protospacer = (*env)->GetStringUTFChars(env, protospacer, NULL);
+  for (jsize i = 0; i < np; i++) { jp[i] = (jstring)(*env)->GetObjectArrayElement(env, pams, i); cp[i] = (*env)->GetStringUTFChars(env, jp[i], NULL); }
+  g.n_pams = (int32_t)np; g.pams = cp; g.pam_is_5prime = pam5 ? 1 : 0; g.cli_length = cliLength;
+  (*env)->GetIntArrayRegion(env, params, 0, (jsize)(sizeof(p) / sizeof(int32_t)), (jint*)&p);
+  const char* gid = (*env)->GetStringUTFChars(env, guideId, NULL);
+  const char* ver = version ? (*env)->GetStringUTFChars(env, version, NULL) : NULL;
+  char* tsv = NULL;
+  uint64_t bytes = 0, rows = 0;
+  const int rc = calitas_search_hits(ctx, &g, gid, &p, ver, NULL, &tsv, &bytes, &rows);
+  (*env)->ReleaseStringUTFChars(env, protospacer, g.protospacer);
+  for (jsize i = 0; i < np; i++) (*env)->ReleaseStringUTFChars(env, jp[i], cp[i]);
+  (*env)->ReleaseStringUTFChars(env, guideId, gid);
+  if (version) (*env)->ReleaseStringUTFChars(env, version, ver);
+  if (rc != CALITAS_OK) { throw_state(env, calitas_last_error(ctx)); return NULL; }
+  return (*env)->NewDirectByteBuffer(env, tsv, (jlong)bytes);
+}
+
 JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_free(JNIEnv* env, jobject self, jobject buffer) {
   calitas_free((*env)->GetDirectBufferAddress(env, buffer));
 }

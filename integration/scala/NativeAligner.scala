@@ -24,6 +24,15 @@ final class NativeAligner(device: Int = 0) extends AutoCloseable {
     try NativeAligner.decode(buf, guide, pams, contigNames, fetch) finally NativeAligner.free(buf)
   }
 
+  /** calitas_search_hits: the whole reference-genome branch of SearchReference.execute (SearchReference.scala:527-564, 641-648)
+    * for one guide -- per-window filter, removeOverlaps, ReferenceHit.sort and the rows are done on the GPU; the bytes returned
+    * are the hits.txt Metric.writer would have written (header + rows). */
+  def searchHits(guide: Guide, cliLength: Int, guideId: String, params: Array[Int], version: String): Array[Byte] = {
+    val pams = (guide.pams5Prime ++ guide.pams3Prime).toArray
+    val buf  = NativeAligner.searchHits(handle, guide.guide, pams, guide.pamIsFivePrime, cliLength, guideId, params, version)
+    try { val out = new Array[Byte](buf.capacity()); buf.get(out); out } finally NativeAligner.free(buf)
+  }
+
   override def close(): Unit = NativeAligner.destroy(handle)
 }
 
@@ -36,6 +45,8 @@ object NativeAligner {
   @native private def setReference(handle: Long, names: Array[String], bases: Array[Array[Byte]], genomeBuild: String): Unit
   @native private def search(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
                              params: Array[Int]): ByteBuffer
+  @native private def searchHits(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
+                                 guideId: String, params: Array[Int], version: String): ByteBuffer
   @native private def free(buffer: ByteBuffer): Unit
 
   /** calitas_aln_t -> GuideAlignment (GuideAlignment.scala:72-88).  The padded strings follow Alignment.paddedString as used at
