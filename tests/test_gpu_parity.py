@@ -380,6 +380,33 @@ def test_full_size_properties_ecoli_like(C):
     ctx.close()
 
 
+def test_config2_ecoli_size_full_parity(C):
+    """BASELINE config 2 at full size (one 4.64 Mb contig, GC 0.508, seed 0xC2, max-guide-diffs 3): every row against the
+    oracle (a few seconds of CPU), through calitas_search_hits and through the two-stage path."""
+    from calitas_amd import synth
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    rng = np.random.default_rng(0xC2)
+    seq = synth.random_bases(rng, synth.ECOLI_LENGTH, gc=0.508)
+    for k in range(60):
+        synth.plant_site(rng, seq, int(rng.integers(100, len(seq) - 100)), "CTTGCCCCACAGGGCAGTAA", "nrg", False, k % 4, bool(k % 2))
+    _, orows, nwin = O.search_memory(["ecoli_like"], [seq.tobytes()], guide, "a", d=3, threads=8)
+    assert nwin > 4700 and len(orows) >= 30
+    ctx = C.Context(0)
+    ctx.set_reference(["ecoli_like"], [seq], genome_build="unknown")
+    try:
+        params = C.make_params(max_guide_diffs=3)
+        text, n = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+        assert_same(C.read_hits(text), orows, "config 2")
+        out, k = ctx.search_raw([C.Guide(guide)], params)
+        try:
+            text2, n2 = ctx.hits_tsv_raw(C.Guide(guide), "a", params, out, k, "v0", "stamp")
+        finally:
+            C._lib.lib.calitas_free(out)
+        assert (n, text) == (n2, text2)
+    finally:
+        ctx.close()
+
+
 def test_parity_at_scale_60mb(C):
     """60 Mb of the bench genome's recipe (two contigs, chunk-512 tiles, N blocks, soft-masking, tandem repeats, planted
     sites straddling window starts) -- every row against the oracle (BASELINE config 3 limits)."""
