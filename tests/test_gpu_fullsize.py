@@ -1,0 +1,82 @@
+"""BASELINE config 3 at its full size (synthetic hg38-sized genome, 25 contigs, 3.09 Gb, seed 0xC3 -- the bench workload):
+what cannot be compared row by row against the CPU oracle in seconds is checked through properties, and four whole
+chromosomes are compared row by row."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SKIP_COLS = {"aligner_version", "time_stamp"}
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import calitas_amd as C
+    names, seqs = bench.build_genome(1.0, torch.device("cuda", 0), contig_indices=None, guides=[bench.GUIDE0], log=None)
+    ctx = C.Context(0)
+    ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized")
+    yield C, ctx, names, seqs, bench.GUIDE0
+    ctx.close()
+
+
+def test_hg38_size_paths_agree_and_rows_are_ordered(world, monkeypatch):
+    C, ctx, names, seqs, guide = world
+    params = C.make_params(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+    G = C.Guide(guide)
+    monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
+    lanes, n = ctx.search_hits(G, "a", params, "v0", "stamp")
+    assert ctx.timing()["lanes"] == 2                              # the default cut of a reference this large
+    monkeypatch.setenv("CALITAS_CHUNKS", "1")
+    one, n1 = ctx.search_hits(G, "a", params, "v0", "stamp")
+    monkeypatch.setenv("CALITAS_CHUNKS", "3:2:2:1")
+    four, n4 = ctx.search_hits(G, "a", params, "v0", "stamp")
+    monkeypatch.delenv("CALITAS_CHUNKS")
+    out, k = ctx.search_raw([G], params)
+    try:
+        two_stage, n2 = ctx.hits_tsv_raw(G, "a", params, out, k, "v0", "stamp")
+    finally:
+        C._lib.lib.calitas_free(out)
+    assert n > 50000 and (n, lanes) == (n1, one) == (n4, four) == (n2, two_stage)
+    batch = ctx.search_hits_batch([G, G], ["a", "a"], params, "v0", "stamp")
+    assert batch == [(lanes, n), (lanes, n)]
+    # ReferenceHit.sort (RH:284) and removeOverlaps (SR:661-671) as properties of the output
+    order = {nm: i for i, nm in enumerate(names)}
+    rows = C.read_hits(lanes)
+    keys = [(order[r["chromosome"]], int(r["coordinate_start"]), r["strand"], -int(r["score"])) for r in rows]
+    assert keys == sorted(keys)
+    last = {}
+    for r in rows:   # consecutive kept hits of one (chromosome, strand) group overlap by less than maxOverlap
+        g = (r["chromosome"], r["strand"])
+        s = int(r["coordinate_start"])
+        e = s + sum(1 for c in r["padded_target"] if c != "-") - 1
+        if g in last:
+            assert min(e, last[g][1]) - max(s, last[g][0]) < 10, r
+        last[g] = (s, e)
+    # planted perfect sites of the bench genome are all reported (exact matches survive every filter)
+    perfect = sum(1 for r in rows if r["total_mm_plus_gaps"] == "0")
+    assert perfect >= 3
+
+
+def test_hg38_size_whole_chromosomes_against_the_oracle(world):
+    """chr19-chr22 and chrM of the full-size run (about 220 Mb), every column, against the oracle run on those contigs alone:
+    windows, removeOverlaps groups and the sort never cross a contig, so the rows must be identical."""
+    C, ctx, names, seqs, guide = world
+    params = C.make_params(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+    text, _ = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+    rows = C.read_hits(text)
+    pick = [i for i, nm in enumerate(names) if nm in ("chr19", "chr20", "chr21", "chr22", "chrM")]
+    _, orows, _ = O.search_memory([names[i] for i in pick], [seqs[i].tobytes() for i in pick], guide, "a", d=5, p=1, g=2, threads=16)
+    want = [{k: v for k, v in r.items() if k not in SKIP_COLS} for r in orows]
+    chosen = {names[i] for i in pick}
+    got = [{k: v for k, v in r.items() if k not in SKIP_COLS} for r in rows if r["chromosome"] in chosen]
+    for r in want:
+        r["genome_build"] = "synthetic-hg38-sized"                 # the oracle has no .dict for in-memory contigs
+    assert len(want) > 3000 and got == want
