@@ -83,6 +83,19 @@ std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, cons
                             GuideDev& gd);
 int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec, uint32_t item_cap);
 
+// Host waits on the critical path poll instead of blocking: a call has four of them per lane and a blocking wait adds tens of
+// microseconds of wake-up latency each.
+inline hipError_t calitas_spin_sync(hipStream_t s) {
+  hipError_t e;
+  while ((e = hipStreamQuery(s)) == hipErrorNotReady) __builtin_ia32_pause();
+  return e;
+}
+inline hipError_t calitas_spin_sync(hipEvent_t ev) {
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) __builtin_ia32_pause();
+  return e;
+}
+
 #define HIP_TRY(ctx, call)                                                                         \
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \

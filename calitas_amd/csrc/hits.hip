@@ -571,7 +571,8 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts);
   TRY(hipMemcpyAsync(w.h_counts, w.d_counts, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  TRY(hipStreamSynchronize(stream));
+  while ((e = hipStreamQuery(stream)) == hipErrorNotReady) __builtin_ia32_pause();   // poll: a blocking wait costs tens of microseconds more
+  TRY(e);
   TRY(hipGetLastError());
   res->flags = (uint32_t)w.h_counts[2];
   if (res->flags) return hipSuccess;

@@ -124,7 +124,7 @@ static int convert_selected(calitas_ctx* ctx, const RawAln* d_final, uint32_t n_
     ctx->h_raw_cap = ctx->raw_cap;
   }
   if (n_sel) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, d_final, (size_t)n_sel * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
   const RawAln* raw = ctx->h_raw;
   calitas_aln_t* result = (calitas_aln_t*)out_alloc(std::max<size_t>(1, n_sel) * sizeof(calitas_aln_t));
   if (!result) return fail(ctx, CALITAS_EINVAL, "out of memory");
@@ -285,7 +285,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
     const uint32_t n_items = ctx->h_counters[3];
     if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
@@ -321,7 +321,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, max_total, p.max_overlap,
                             ctx->stream, &d_final, &d_cnt));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
     if (ctx->h_counters[6] != 0) gpu_select = false;   // a window with more alignments than one lane should chew through
     else {
       n_sel = ctx->h_counters[5];
@@ -338,7 +338,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); tm.scan_kernel_ms = ms;
   (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); tm.align_kernel_ms = ms;
@@ -682,12 +682,12 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
         HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
         HIP_TRY(lane, hipEventRecord(lane->ev[3], ctx->copy_stream));
       }
-      HIP_TRY(lane, hipEventSynchronize(lane->ev[3]));
+      HIP_TRY(lane, calitas_spin_sync(lane->ev[3]));
     } else {
       HIP_TRY(lane, hipEventRecord(lane->ev[2], lane->stream));
       HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, lane->stream));
       HIP_TRY(lane, hipEventRecord(lane->ev[3], lane->stream));
-      HIP_TRY(lane, hipStreamSynchronize(lane->stream));
+      HIP_TRY(lane, calitas_spin_sync(lane->stream));
     }
     float ms = 0;
     if (!lt.on_host) { (void)hipEventElapsedTime(&ms, lane->ev[0], lane->ev[1]); lt.tm.hits_kernel_ms = ms; }
@@ -733,8 +733,8 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
     std::vector<char> done(K, 0);
     std::vector<char> placed(K, 0);
     std::vector<std::thread> threads;
-    for (size_t c = 0; c < K; c++) {
-      threads.emplace_back([&, c] {
+    auto lane_body = [&](size_t c) {
+      {
         (void)hipSetDevice(ctx->device);
         LaneText& lt = parts[c];
         lt.rc = lane_rows(lanes[c], plans[c], true, rs, guide_id, version, stamp, lt);
@@ -751,8 +751,10 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
           int r = place(c, offset);
           if (r) lt.rc = r; else placed[c] = 1;
         }
-      });
-    }
+      }
+    };
+    for (size_t c = 1; c < K; c++) threads.emplace_back(lane_body, c);
+    lane_body(0);                                        // the calling thread drives the first lane itself
     for (auto& t : threads) t.join();
     rc = CALITAS_OK;
     bool overflow = false;
@@ -890,7 +892,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
               if (e == hipSuccess) e = hipMemcpyAsync(text + hlen, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream);
               if (e == hipSuccess) e = hipEventRecord(lane->ev[3], ctx->copy_stream);
             }
-            if (e == hipSuccess) e = hipEventSynchronize(lane->ev[3]);
+            if (e == hipSuccess) e = calitas_spin_sync(lane->ev[3]);
             if (e != hipSuccess) { calitas_free(text); return fail(lane, CALITAS_EHIP, std::string("text copy: ") + hipGetErrorString(e)); }
           }
           text[total] = 0;
