@@ -141,6 +141,42 @@ struct RawAln {
   uint8_t ops[RAW_MAX_OPS / 4];  // 2 bits per op in traceback (reverse) order: 0 '=', 1 'X', 2 'I', 3 'D'
 };
 
+// Counts over the packed ops of a RawAln (2 bits per op, traceback order, unused slots zero), computed on whole words so that
+// no kernel needs a per-op loop with a runtime index into a private array.
+struct OpCounts {
+  int non_eq;    // ops != '='           (X, I, D)
+  int gaps;      // ops >= 'I'           (I, D)
+  int not_ins;   // ops != 'I' among the first n_ops (=, X, D: the ops that consume a target base)
+  int lead_d;    // run of D at the end of the traceback order (= start of the aligner order)
+  int trail_d;   // run of D at the start of the traceback order (= end of the aligner order)
+};
+CAL_HD inline int popc32(uint32_t x) { return __builtin_popcount(x); }
+static_assert(RAW_MAX_OPS / 16 == 5, "OpsWords holds five words");
+struct OpsWords {       // the five ops words of a RawAln held in registers (selected by comparison, never indexed)
+  uint32_t a, b, c, d, e;
+  CAL_HD uint32_t word(int k) const { return k == 0 ? a : k == 1 ? b : k == 2 ? c : k == 3 ? d : e; }
+  CAL_HD int op(int i) const { return (int)((word(i >> 4) >> ((i & 15) * 2)) & 3u); }
+};
+CAL_HD inline OpsWords load_ops_words(const uint8_t* ops) {   // RawAln::ops is 4-byte aligned
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(ops);
+  return OpsWords{w[0], w[1], w[2], w[3], w[4]};
+}
+CAL_HD inline OpCounts count_ops(const OpsWords& w, int n_ops) {
+  OpCounts c{0, 0, 0, 0, 0};
+  int ins = 0;
+  const uint32_t ws[5] = {w.a, w.b, w.c, w.d, w.e};           // constant indices only: stays in registers
+  for (int k = 0; k < 5; k++) {
+    const uint32_t lo = ws[k] & 0x55555555u, hi = (ws[k] >> 1) & 0x55555555u;
+    c.non_eq += popc32(lo | hi);
+    c.gaps += popc32(hi);
+    ins += popc32(hi & ~lo);
+  }
+  c.not_ins = n_ops - ins;
+  for (int i = 0; i < n_ops && w.op(i) == 3; i++) c.trail_d++;
+  for (int i = n_ops - 1; i >= 0 && w.op(i) == 3; i--) c.lead_d++;
+  return c;
+}
+
 // A filled strip handed from align_kernel to trace_kernel.  Slabs have a fixed size per search and a fixed address
 // (record index x slots-per-record + window slot), so the hand-over needs no atomics: header, target masks tb[ntb],
 // trace bytes tr[L][stride].

@@ -54,18 +54,20 @@ __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides
                            int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const RawAln r = fin[i];
+  const RawAln* rp = fin + i;
+  struct { uint32_t contig, window_k; int32_t score; int t_start, t_end_guide, dir, guide, pam, offset, n_ops; } r;
+  r.contig = rp->contig; r.window_k = rp->window_k; r.score = rp->score; r.t_start = rp->t_start; r.t_end_guide = rp->t_end_guide;
+  r.dir = rp->dir; r.guide = rp->guide; r.pam = rp->pam; r.offset = rp->offset; r.n_ops = rp->n_ops;
   const GuideDev& g = guides[r.guide];
   const int ng = r.n_ops;
   int pam_len = 0, gap = 0;
   if (r.pam >= 0) { pam_len = g.pam_len[r.pam]; gap = r.offset; }
-  // aligner-order op k is raw_op(ng - 1 - k).  Everything left of the first / right of the last protospacer column is 'D'
+  // aligner-order op k is traceback op ng - 1 - k.  Everything left of the first / right of the last protospacer column is 'D'
   // (GA:21-31 with the '+' rule in aligner space, SGA:264,281,297,302).
-  int lead = 0, trail = 0, t_guide = 0;
-  for (int k = ng - 1; k >= 0 && raw_op(r, k) == 3; k--) lead++;
-  for (int k = 0; k < ng && raw_op(r, k) == 3; k++) trail++;
+  const OpCounts oc = count_ops(load_ops_words(rp->ops), ng);
+  int lead = oc.lead_d, trail = oc.trail_d;
+  const int t_guide = oc.not_ins;
   if (lead == ng) { lead = 0; trail = ng; }            // no protospacer column at all: cannot happen, kept total
-  for (int k = 0; k < ng; k++) t_guide += raw_op(r, k) != 2;
   const int left_delta = lead, right_delta = trail + gap + pam_len;
   const int tlen = t_guide + gap + pam_len;
   const int start_s = (int)r.t_start - 1, end_s = (int)r.t_end_guide + r.offset + pam_len;   // SGA:515-516

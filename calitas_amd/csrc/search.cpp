@@ -570,7 +570,11 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   if (!ctx->scan_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, least));
-  if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest));
+  // The runtime performs these device-to-host copies with a blit kernel (rocprofv3: __amd_rocclr_copyBuffer) that shares the CUs
+  // with everything else.  On a high-priority stream it held up the other lane's small kernels for the whole copy (rocprofv3
+  // timeline: a 5 us merge pass took 370 us); on the lowest priority the lanes' kernels get their slots first.  A copy kernel of
+  // our own with a small grid reached the same 55 GB/s but slowed the other lane more, so the runtime's copy stays.
+  if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, least));
   while (ctx->lanes.size() < k) {
     calitas_ctx* c = new calitas_ctx();
     c->device = ctx->device; c->parent = ctx;

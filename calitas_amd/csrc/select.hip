@@ -46,13 +46,12 @@ __global__ void derive_kernel(const RawAln* raw, const uint32_t* vals, uint32_t 
                               const int2* win, Derived* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const RawAln r = raw[vals[i]];
-  int diffs = 0, gaps = 0;
-  for (int k = 0; k < r.n_ops; k++) {
-    const int op = (r.ops[k >> 2] >> ((k & 3) * 2)) & 3;
-    diffs += op != 0;
-    gaps += op >= 2;
-  }
+  const RawAln* rp = raw + vals[i];
+  struct { uint32_t contig, window_k; int32_t score; int t_start, t_end_guide, dir, guide, pam, offset, n_ops; uint32_t pam_x; } r;
+  r.contig = rp->contig; r.window_k = rp->window_k; r.score = rp->score; r.t_start = rp->t_start; r.t_end_guide = rp->t_end_guide;
+  r.dir = rp->dir; r.guide = rp->guide; r.pam = rp->pam; r.offset = rp->offset; r.n_ops = rp->n_ops; r.pam_x = rp->pam_x;
+  const OpCounts oc = count_ops(load_ops_words(rp->ops), r.n_ops);     // no per-op loop over a private copy of the record
+  int diffs = oc.non_eq, gaps = oc.gaps;
   int pam_len = 0;
   if (r.pam >= 0) { pam_len = guides[r.guide].pam_len[r.pam]; diffs += r.offset + __popc((unsigned)r.pam_x); gaps += r.offset; }
   const int2 w = win[win_base[r.contig] + r.window_k];

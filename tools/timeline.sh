@@ -1,0 +1,37 @@
+#!/bin/bash
+# Kernel + copy timeline of the last calitas_search_hits call of a short bench run (inside gpurun): bash tools/timeline.sh [bench args]
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$ROOT/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/tl
+timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o run -- python3 "$ROOT/bench.py" --cpu-sample-mb 0 --steps 3 --warmup 1 "$@" > /tmp/tl.log 2>&1 < /dev/null
+python3 - /tmp/tl "$ROOT/gpurun_out/timeline.txt" <<'PY'
+import csv, glob, sys
+d, out = sys.argv[1], sys.argv[2]
+ev = []
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "calitas" not in n and "ROCPRIM_400200" not in n:
+            continue
+        n = n.replace("calitas::", "").replace("(anonymous namespace)::", "").split("(")[0]
+        if "rocprim" in n:
+            n = "rocprim:" + ("merge" if "merge_sort_block_merge" in n else "blocksort" if "block_sort" in n else "scan" if "scan" in n else "other")
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "q" + r.get("Queue_Id", "?"), n[-28:]))
+for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        b = int(r.get("Bytes", r.get("bytes", 0)) or 0)
+        if b < 1 << 20:
+            continue
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy", "%s %.1f MB" % (r.get("Direction", ""), b / 1e6)))
+ev.sort()
+# the last call starts at the last-but-one scan_kernel launch group: find the last two scan kernels
+scans = [e for e in ev if e[3].startswith("void scan_kernel") or "scan_kernel" in e[3]]
+t0 = scans[-2][0] if len(scans) >= 2 else ev[0][0]
+with open(out, "w") as f:
+    for s, e, q, n in ev:
+        if s < t0:
+            continue
+        f.write("%9.1f %9.1f  %7.1f us  %-6s %s\n" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, n))
+print(open(out).read())
+PY
