@@ -14,6 +14,7 @@
 #include "refpack.hpp"
 #include "select.hpp"
 #include "hits.hpp"
+#include "dma.hpp"
 
 using namespace calitas;
 
@@ -60,6 +61,8 @@ struct calitas_ctx {
   hipEvent_t rows_ready = nullptr;  // lane: recorded on its stream after its row kernels
   uint64_t last_text_bytes = 0;
   std::mutex host_mu;               // host stages of concurrent lanes take turns on the worker pool
+  DmaCopier dma;                    // parent: SDMA copies of the finished text (dma.hpp)
+  bool dma_tried = false;
   WorkerPool* pool = nullptr;
   ~calitas_ctx() { delete pool; }
 };

@@ -496,6 +496,46 @@ void calitas_default_version_and_stamp(const char* aligner_version, const char* 
   }
 }
 
+// The finished text of a lane, device -> page-locked host.  Preferred: an SDMA engine through the HSA runtime (dma.hpp), after
+// waiting for the lane's row kernels -- the CUs stay with the search kernels.  Otherwise the runtime's copy (a blit kernel) on the
+// owner's low-priority copy stream (chunked / batch calls: one stream for all lanes) or on the lane's own stream.
+static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const char* src, size_t n, std::mutex* copy_mu, double* ms_out) {
+  if (!owner->dma_tried) {
+    std::lock_guard<std::mutex> lk(owner->host_mu);
+    if (!owner->dma_tried) {
+      const char* e = std::getenv("CALITAS_SDMA");
+      if (!(e && std::atoi(e) == 0)) owner->dma.open(owner->device);
+      owner->dma_tried = true;
+    }
+  }
+  if (owner->dma.usable()) {
+    HIP_TRY(lane, calitas_spin_sync(lane->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (owner->dma.copy_to_host(dst, src, n)) {
+      if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      return CALITAS_OK;
+    }
+  }
+  hipStream_t cs = (lane->parent && owner->copy_stream) ? owner->copy_stream : lane->stream;
+  if (cs != lane->stream) {
+    HIP_TRY(lane, hipEventRecord(lane->rows_ready, lane->stream));
+    std::lock_guard<std::mutex> lk(*copy_mu);
+    HIP_TRY(lane, hipStreamWaitEvent(cs, lane->rows_ready, 0));
+    HIP_TRY(lane, hipEventRecord(lane->ev[2], cs));
+    HIP_TRY(lane, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(lane, hipEventRecord(lane->ev[3], cs));
+  } else {
+    HIP_TRY(lane, hipEventRecord(lane->ev[2], cs));
+    HIP_TRY(lane, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(lane, hipEventRecord(lane->ev[3], cs));
+  }
+  HIP_TRY(lane, calitas_spin_sync(lane->ev[3]));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, lane->ev[2], lane->ev[3]);
+  if (ms_out) *ms_out = ms;
+  return CALITAS_OK;
+}
+
 // ---- calitas_search_hits ------------------------------------------------------------------------------------------------
 
 // What one lane contributes to a hits.txt: rows on the device, or rows built by the host stages when a device stage declined.
@@ -569,6 +609,8 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  // (Reserving CUs for the lanes with hipExtStreamCreateWithCUMask on the scan stream was tried: 8 of 256 CUs masked out cost the
+  // scan 9 %, 32 cost 80 %, and the lanes' small kernels did not get faster.)
   if (!ctx->scan_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, least));
   // The runtime performs these device-to-host copies with a blit kernel (rocprofv3: __amd_rocclr_copyBuffer) that shares the CUs
   // with everything else.  On a high-priority stream it held up the other lane's small kernels for the whole copy (rocprofv3
@@ -676,26 +718,10 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
     if (!lt.bytes) return CALITAS_OK;
     if (lt.on_host) { std::memcpy(text + hlen + offset, lt.host_rows.data(), lt.bytes); return CALITAS_OK; }
     calitas_ctx* lane = lanes[c];
-    if (lane->parent) {
-      // all text copies of a chunked call go through one stream: PCIe is one resource, and one stream is one thing to warm up
-      HIP_TRY(lane, hipEventRecord(lane->rows_ready, lane->stream));
-      {
-        std::lock_guard<std::mutex> lk(copy_mu);
-        HIP_TRY(lane, hipStreamWaitEvent(ctx->copy_stream, lane->rows_ready, 0));
-        HIP_TRY(lane, hipEventRecord(lane->ev[2], ctx->copy_stream));
-        HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIP_TRY(lane, hipEventRecord(lane->ev[3], ctx->copy_stream));
-      }
-      HIP_TRY(lane, calitas_spin_sync(lane->ev[3]));
-    } else {
-      HIP_TRY(lane, hipEventRecord(lane->ev[2], lane->stream));
-      HIP_TRY(lane, hipMemcpyAsync(text + hlen + offset, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, lane->stream));
-      HIP_TRY(lane, hipEventRecord(lane->ev[3], lane->stream));
-      HIP_TRY(lane, calitas_spin_sync(lane->stream));
-    }
+    int r = text_to_host(ctx, lane, text + hlen + offset, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+    if (r) return r;
     float ms = 0;
-    if (!lt.on_host) { (void)hipEventElapsedTime(&ms, lane->ev[0], lane->ev[1]); lt.tm.hits_kernel_ms = ms; }
-    (void)hipEventElapsedTime(&ms, lane->ev[2], lane->ev[3]); lt.tm.hits_copy_ms = ms;
+    (void)hipEventElapsedTime(&ms, lane->ev[0], lane->ev[1]); lt.tm.hits_kernel_ms = ms;   // recorded around hits_run by lane_rows
     return CALITAS_OK;
   };
 
@@ -889,15 +915,8 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
           std::memcpy(text, rs.header.data(), hlen);
           if (lt.bytes && lt.on_host) std::memcpy(text + hlen, lt.host_rows.data(), (size_t)lt.bytes);
           else if (lt.bytes) {
-            hipError_t e = hipEventRecord(lane->rows_ready, lane->stream);
-            {
-              std::lock_guard<std::mutex> lk(copy_mu);
-              if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, lane->rows_ready, 0);
-              if (e == hipSuccess) e = hipMemcpyAsync(text + hlen, lt.d_text, (size_t)lt.bytes, hipMemcpyDeviceToHost, ctx->copy_stream);
-              if (e == hipSuccess) e = hipEventRecord(lane->ev[3], ctx->copy_stream);
-            }
-            if (e == hipSuccess) e = calitas_spin_sync(lane->ev[3]);
-            if (e != hipSuccess) { calitas_free(text); return fail(lane, CALITAS_EHIP, std::string("text copy: ") + hipGetErrorString(e)); }
+            int cr = text_to_host(ctx, lane, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+            if (cr) { calitas_free(text); return cr; }
           }
           text[total] = 0;
           tsv[g] = text;

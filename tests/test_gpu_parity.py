@@ -321,6 +321,28 @@ def test_search_hits_batch_equals_single_calls(C, tmp_path, monkeypatch):
         ctx.close()
 
 
+def test_text_copy_paths_agree(C, tmp_path, monkeypatch):
+    """The finished text comes back over an SDMA engine (HSA runtime, dma.cpp) by default and through hipMemcpyAsync with
+    CALITAS_SDMA=0; same bytes either way, in one pass and in lanes."""
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    fa = synth_fasta(tmp_path, 53, [guide], lengths=(70000, 20000))
+    params = C.make_params(max_gaps_between_guide_and_pam=2)
+    got = {}
+    for sdma in ("1", "0"):
+        monkeypatch.setenv("CALITAS_SDMA", sdma)
+        ctx = C.Context(0)                       # the choice is made once per context
+        ctx.set_reference_fasta(fa)
+        try:
+            for chunks in ("1", "2"):
+                monkeypatch.setenv("CALITAS_CHUNKS", chunks)
+                got[(sdma, chunks)] = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            got[(sdma, "batch")] = ctx.search_hits_batch([C.Guide(guide)] * 3, ["a"] * 3, params, "v0", "stamp")[2]
+        finally:
+            ctx.close()
+    ref = got[("1", "1")]
+    assert ref[1] > 20 and all(v == ref for v in got.values())
+
+
 def test_cpp_cli_search_reference(C, tmp_path):
     """The `calitas SearchReference` binary with the reference's flags (SearchReference.scala:452-470), FASTA in, hits.txt out."""
     import subprocess
