@@ -103,6 +103,7 @@ struct SearchPlan {
   // the part of the packed reference this job covers
   uint32_t tile_lo = 0, n_tiles = 0;
   uint64_t bases = 0;
+  uint64_t win_lo = 0, win_n = 0;     // its entries of the device window table
 };
 
 // Accepted alignments left on the device by search_impl for calitas_search_hits.
@@ -184,6 +185,8 @@ static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
   pl.slab_per_rec = (uint64_t)pl.slab_bytes * pl.slots_per_rec;
   pl.tile_lo = 0; pl.n_tiles = (uint32_t)ref.tiles.size();
   pl.bases = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
+  pl.win_lo = 0; pl.win_n = 0;
+  for (auto& c : ref.contigs) pl.win_n += window_count(c.len, pl.step);
   return CALITAS_OK;
 }
 
@@ -310,19 +313,18 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   const calitas_ctx* own = ref_owner(ctx);
   // ---- per-window filter (SGA:315-320): on the GPU (select.hip) unless the tiling does not fit its sort key, a window
   //      exceeds its group limit, or CALITAS_HOST_FILTER asks for the host implementation of the same stage ----
-  uint64_t max_wins = 0;
-  for (auto& c : ref.contigs) max_wins = std::max<uint64_t>(max_wins, window_count(c.len, step));
-  bool gpu_select = n_raw > 0 && !std::getenv("CALITAS_HOST_FILTER") && select_supported(ref.contigs.size(), max_wins, p.window_size, n_guides);
+  bool gpu_select = n_raw > 0 && !std::getenv("CALITAS_HOST_FILTER") && select_supported(pl.win_n, p.window_size, n_guides);
   uint32_t n_sel = 0;
   const RawAln* d_sel = nullptr;
   if (gpu_select) {
     const RawAln* d_final = nullptr;
     const uint32_t* d_cnt = nullptr;
-    HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, max_total, p.max_overlap,
-                            ctx->stream, &d_final, &d_cnt));
+    HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
+                            p.max_overlap, ctx->stream, &d_final, &d_cnt));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
-    if (ctx->h_counters[6] != 0) gpu_select = false;   // a window with more alignments than one lane should chew through
+    select_done(ctx->select);
+    if (ctx->h_counters[6] != 0) gpu_select = false;   // a window beyond what the device filter handles
     else {
       n_sel = ctx->h_counters[5];
       d_sel = d_final;
@@ -736,8 +738,9 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
       q.tile_lo = (uint32_t)(ref.contigs[ranges[c].first].gbase / ref.tile);
       const uint32_t tile_hi = ranges[c].second < (int)ref.contigs.size() ? (uint32_t)(ref.contigs[ranges[c].second].gbase / ref.tile) : (uint32_t)ref.tiles.size();
       q.n_tiles = tile_hi - q.tile_lo;
-      q.bases = 0;
-      for (int k = ranges[c].first; k < ranges[c].second; k++) q.bases += ref.contigs[k].len;
+      q.bases = 0; q.win_lo = 0; q.win_n = 0;
+      for (int k = 0; k < ranges[c].first; k++) q.win_lo += window_count(ref.contigs[k].len, q.step);
+      for (int k = ranges[c].first; k < ranges[c].second; k++) { q.bases += ref.contigs[k].len; q.win_n += window_count(ref.contigs[k].len, q.step); }
       rc = lane_prepare(lanes[c], q);
       if (rc) ctx->err = lanes[c]->err;
     }

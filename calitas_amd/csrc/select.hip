@@ -1,15 +1,21 @@
 // select.hip -- the per-window stage of SequentialGuideAligner.align (SequentialGuideAligner.scala:315-320) on the GPU.
 //
-// trace_kernel appends extended alignments in arbitrary order.  Here they are
-//   1. keyed by (guide, contig, window | strand list, end column, PAM) and radix-sorted (rocPRIM): inside a window that is
-//      exactly the reference's enumeration order (fgbio emits ascending end columns, extendAndFilterRight keeps PAM order);
-//   2. annotated with what the filter looks at (score, gap bases, edits, contig start/end);
-//   3. filtered window by window, one lane per window: stable order by (score desc, gap bases asc) (GuideAlignment.scala:
-//      125-129), keep if edits <= maxTotalDiffs and no kept alignment of the same strand overlaps by more than maxOverlap;
-//   4. compacted in window order with an exclusive scan, so the host receives only accepted alignments, already ordered.
+// trace_kernel appends extended alignments in arbitrary order.  Every alignment belongs to exactly one window, and windows have a
+// dense global index (guide x all windows of all contigs), so grouping is a counting sort on that index, not a comparison sort:
+//   1. count_kernel    per alignment: what the filter looks at (score, gap bases, edits, contig start / end, GA:100-101,119-122),
+//                      its place in the reference's enumeration order inside the window (strand list, end column, PAM: fgbio
+//                      emits ascending end columns, extendAndFilterRight keeps PAM order), and cnt[window]++;
+//   2. exclusive scan of cnt over all windows (rocPRIM) -> first slot of every window;
+//   3. scatter_kernel  alignment indices into their window's slots (cnt counts back down to zero: it needs no clearing between
+//                      calls);
+//   4. filter_kernel   one lane per window (the lane of the window's first slot): per strand list, repeatedly the best remaining alignment -- score desc, gap bases asc,
+//                      enumeration order on ties = the reference's stable sort (GA:125-129) --, kept if edits <= maxTotalDiffs and
+//                      no kept alignment of the same list overlaps it by more than maxOverlap;
+//   5. exclusive scan of the kept counts, gather_kernel: accepted alignments in (guide, contig, window, output) order.
 // Windows with more than GROUP_MAX alignments (satellite repeats, PAM-less dense searches) go to filter_big_kernel, one wave
 // per window; only beyond 65 536 records or 4 096 kept alignments in one window does a flag send the caller to the host
-// implementation of the same stage for this search.
+// implementation of the same stage for this search.  (A first version radix-sorted 64-bit keys: eight more launches per call,
+// which is what a lane's tail is made of -- DESIGN.md 4.5.)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -26,254 +32,249 @@ namespace calitas {
 
 namespace {
 
-constexpr int GROUP_MAX = 256;
-constexpr unsigned GROUP_SHIFT = 18;   // key bits below the (guide, contig, window) group id
+constexpr uint32_t GROUP_MAX = 256;
 
-struct Derived { int32_t start, end, score; uint16_t gaps, edits; };
+struct Derived {
+  int32_t start, end, score;
+  uint16_t gaps, edits;
+  uint32_t ekey;      // enumeration order inside the window: strand list << 17 | end column << 4 | PAM + 1
+  uint32_t widx;      // global window index
+};
 
-__global__ void key_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, uint64_t* keys, uint32_t* vals) {
+__global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
+                             uint32_t window_lo, uint32_t windows_per_guide, Derived* der, uint32_t* cnt, uint32_t* counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; }      // survivors, flags, big groups: nobody reads them before step 4
   if (i >= n) return;
-  const RawAln r = raw[i];
-  const uint32_t pam5 = guides[r.guide].pam5;
-  const uint64_t list = pam5 ? (r.dir == 1 ? 0 : 1) : (r.dir == 0 ? 0 : 1);   // 0 = forward-strand list (SGA:316)
-  keys[i] = ((uint64_t)r.guide << 58) | ((uint64_t)r.contig << 40) | ((uint64_t)r.window_k << 18) | (list << 17) |
-            ((uint64_t)r.t_end_guide << 4) | (uint64_t)(r.pam + 1);
-  vals[i] = i;
-}
-
-__global__ void derive_kernel(const RawAln* raw, const uint32_t* vals, uint32_t n, const GuideDev* guides, const uint64_t* win_base,
-                              const int2* win, Derived* out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const RawAln* rp = raw + vals[i];
-  struct { uint32_t contig, window_k; int32_t score; int t_start, t_end_guide, dir, guide, pam, offset, n_ops; uint32_t pam_x; } r;
-  r.contig = rp->contig; r.window_k = rp->window_k; r.score = rp->score; r.t_start = rp->t_start; r.t_end_guide = rp->t_end_guide;
-  r.dir = rp->dir; r.guide = rp->guide; r.pam = rp->pam; r.offset = rp->offset; r.n_ops = rp->n_ops; r.pam_x = rp->pam_x;
-  const OpCounts oc = count_ops(load_ops_words(rp->ops), r.n_ops);     // no per-op loop over a private copy of the record
-  int diffs = oc.non_eq, gaps = oc.gaps;
-  int pam_len = 0;
-  if (r.pam >= 0) { pam_len = guides[r.guide].pam_len[r.pam]; diffs += r.offset + __popc((unsigned)r.pam_x); gaps += r.offset; }
-  const int2 w = win[win_base[r.contig] + r.window_k];
-  const int start_s = (int)r.t_start - 1, end_s = (int)r.t_end_guide + r.offset + pam_len;
+  const RawAln* rp = raw + i;
+  const uint32_t contig = rp->contig, window_k = rp->window_k, guide = rp->guide;
+  const int pam = rp->pam, offset = rp->offset, n_ops = rp->n_ops, dir = rp->dir;
+  const OpCounts oc = count_ops(load_ops_words(rp->ops), n_ops);
+  int diffs = oc.non_eq, gaps = oc.gaps, pam_len = 0;
+  if (pam >= 0) { pam_len = guides[guide].pam_len[pam]; diffs += offset + __popc((unsigned)rp->pam_x); gaps += offset; }
+  const uint64_t wi = win_base[contig] + window_k;
+  const int2 w = win[wi];
+  const int start_s = (int)rp->t_start - 1, end_s = (int)rp->t_end_guide + offset + pam_len;
   Derived d;
-  if (r.dir == 0) { d.start = w.x + start_s; d.end = w.x + end_s; }
-  else            { d.start = w.y - end_s;   d.end = w.y - start_s; }
-  d.score = r.score; d.gaps = (uint16_t)gaps; d.edits = (uint16_t)diffs;
-  out[i] = d;
+  if (dir == 0) { d.start = w.x + start_s; d.end = w.x + end_s; }
+  else          { d.start = w.y - end_s;   d.end = w.y - start_s; }
+  d.score = rp->score; d.gaps = (uint16_t)gaps; d.edits = (uint16_t)diffs;
+  const uint32_t pam5 = guides[guide].pam5;
+  const uint32_t list = pam5 ? (dir == 1 ? 0u : 1u) : (dir == 0 ? 0u : 1u);   // 0 = forward-strand list (SGA:316)
+  d.ekey = (list << 17) | ((uint32_t)rp->t_end_guide << 4) | (uint32_t)(pam + 1);
+  d.widx = guide * windows_per_guide + ((uint32_t)wi - window_lo);
+  der[i] = d;
+  atomicAdd(&cnt[d.widx], 1u);
 }
 
-// One lane per sorted position; only group heads work.  kept[s] = number of survivors of the group starting at s (0 for
-// non-heads); their sorted positions, in output order, go to out_pos[s .. s + kept[s]).
-__global__ void filter_kernel(const uint64_t* keys, const Derived* der, uint32_t n, int max_total_diffs, int max_overlap,
-                              uint8_t* taken, uint32_t* kept, uint32_t* out_pos, uint32_t* flags, uint32_t* big) {
+__global__ void scatter_kernel(const Derived* der, uint32_t n, const uint32_t* offs, uint32_t* cnt, uint32_t* slot, uint8_t* taken) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t w = der[i].widx;
+  const uint32_t pos = offs[w] + atomicSub(&cnt[w], 1u) - 1u;
+  slot[pos] = i;
+  taken[i] = 0;
+}
+
+// One lane per slot position; only the first slot of a window works (a lane per window would leave 97 % of the lanes of an
+// hg38-sized table idle).  kept[s] = number of survivors of the window whose slots start at s (0 for the other positions);
+// their alignment indices, in output order, go to out_idx[s .. s + kept[s]).
+__global__ void filter_kernel(const Derived* der, const uint32_t* offs, const uint32_t* slot, uint32_t n, int max_total_diffs,
+                              int max_overlap, uint8_t* taken, uint32_t* kept, uint32_t* out_idx, uint32_t* counts, uint32_t* big) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const uint64_t gid = keys[s] >> GROUP_SHIFT;
-  if (s > 0 && (keys[s - 1] >> GROUP_SHIFT) == gid) { kept[s] = 0; return; }
-  uint32_t e = s + 1;
-  while (e < n && (keys[e] >> GROUP_SHIFT) == gid) e++;
-  if (e - s > (uint32_t)GROUP_MAX) { big[atomicAdd(flags + 1, 1u)] = s; kept[s] = 0; return; }   // left to filter_big_kernel
-  uint32_t mid = s;                                   // first member of the reverse-strand list
-  while (mid < e && !((keys[mid] >> 17) & 1)) mid++;
+  const uint32_t w = der[slot[s]].widx;
+  if (offs[w] != s) { kept[s] = 0; return; }
+  const uint32_t e = offs[w + 1];
+  if (e - s > GROUP_MAX) { big[atomicAdd(counts + 2, 1u)] = s; kept[s] = 0; return; }   // left to filter_big_kernel
   uint32_t nk = 0;
-  for (int list = 0; list < 2; list++) {
-    const uint32_t lo = list ? mid : s, hi = list ? e : mid;
+  for (uint32_t list = 0; list < 2; list++) {
     const uint32_t first_kept = nk;                   // overlaps are only tested against the same strand (SGA:317)
-    for (uint32_t round = lo; round < hi; round++) {
-      int best = -1, best_score = 0, best_gaps = 0;
-      for (uint32_t m = lo; m < hi; m++) {
-        if (taken[m]) continue;
-        const int sc = der[m].score, gp = der[m].gaps;
-        if (best < 0 || sc > best_score || (sc == best_score && gp < best_gaps)) { best = (int)m; best_score = sc; best_gaps = gp; }
+    for (uint32_t round = s; round < e; round++) {
+      // scalars, not a struct copy: the comparison below is what the whole stage hangs on
+      int best = -1, b_score = 0, b_gaps = 0, b_start = 0, b_end = 0, b_edits = 0;
+      uint32_t b_ekey = 0;
+      for (uint32_t m = s; m < e; m++) {
+        const uint32_t id = slot[m];
+        if (taken[id]) continue;
+        const uint32_t ek = der[id].ekey;
+        if ((ek >> 17) != list) continue;
+        const int sc = der[id].score, gp = der[id].gaps;
+        // score desc, gap bases asc (GA:125-129), then the enumeration order (stable sort)
+        const bool first = best < 0;
+        const bool wins = sc > b_score || (sc == b_score && (gp < b_gaps || (gp == b_gaps && ek < b_ekey)));
+        if (first || wins) { best = (int)id; b_score = sc; b_gaps = gp; b_ekey = ek; b_start = der[id].start; b_end = der[id].end; b_edits = der[id].edits; }
       }
       if (best < 0) break;
       taken[best] = 1;
-      if ((int)der[best].edits > max_total_diffs) continue;
+      if (b_edits > max_total_diffs) continue;
       bool clash = false;
       for (uint32_t k = first_kept; k < nk; k++) {
-        const Derived& b = der[out_pos[s + k]];
-        const int o = min(der[best].end, b.end) - max(der[best].start, b.start);   // GA:119-122
+        const uint32_t kid = out_idx[s + k];
+        const int o = min(b_end, der[kid].end) - max(b_start, der[kid].start);   // GA:119-122
         if (o > max_overlap) { clash = true; break; }
       }
-      if (!clash) out_pos[s + nk++] = (uint32_t)best;
+      if (!clash) out_idx[s + nk++] = (uint32_t)best;
     }
   }
   kept[s] = nk;
 }
 
-// Window groups with more than GROUP_MAX records (dense repeats, permissive limits): one wave per group, same greedy.  The
-// "taken" bits and the kept intervals of the current strand list live in LDS; a group beyond those capacities raises the flag.
-constexpr uint32_t BIG_MAX = 1u << 16;     // records per group
+// Windows with more than GROUP_MAX records: one wave per window, same greedy.  The "taken" bits and the kept intervals of the
+// current strand list live in LDS; a window beyond those capacities raises the flag.
+constexpr uint32_t BIG_MAX = 1u << 16;     // records per window
 constexpr uint32_t BIG_KEPT = 4096;        // kept alignments per strand list
 
-__global__ __launch_bounds__(64) void filter_big_kernel(const uint64_t* keys, const Derived* der, uint32_t n, int max_total_diffs, int max_overlap,
-                                                        uint32_t* kept, uint32_t* out_pos, uint32_t* flags, const uint32_t* big) {
+__global__ __launch_bounds__(64) void filter_big_kernel(const Derived* der, const uint32_t* offs, const uint32_t* slot, int max_total_diffs,
+                                                        int max_overlap, uint32_t* kept, uint32_t* out_idx, uint32_t* counts,
+                                                        const uint32_t* big) {
   __shared__ uint32_t s_taken[BIG_MAX / 32];
   __shared__ int s_ks[BIG_KEPT], s_ke[BIG_KEPT];
   const uint32_t lane = threadIdx.x;
-  const uint32_t n_big = flags[1];
+  const uint32_t n_big = counts[2];
   for (uint32_t g = blockIdx.x; g < n_big; g += gridDim.x) {
     const uint32_t s = big[g];
-    const uint64_t gid = keys[s] >> GROUP_SHIFT;
-    uint32_t e = s + 1;
-    for (;;) {                                           // end of the group, 64 positions per probe
-      const uint32_t q = e + lane;
-      const unsigned long long m = __ballot(q < n && (keys[q] >> GROUP_SHIFT) == gid);
-      if (m == ~0ull) { e += 64; continue; }
-      e += (uint32_t)__ffsll((long long)~m) - 1;
-      break;
-    }
-    uint32_t mid = s;                                    // first member of the reverse-strand list
-    for (;;) {
-      const uint32_t q = mid + lane;
-      const unsigned long long m = __ballot(q < e && !((keys[q] >> 17) & 1));
-      if (m == ~0ull) { mid += 64; continue; }
-      mid += (uint32_t)__ffsll((long long)~m) - 1;
-      break;
-    }
-    if (e - s > BIG_MAX) { if (lane == 0) { atomicOr(flags, 1u); kept[s] = 0; } continue; }
+    const uint32_t e = offs[der[slot[s]].widx + 1];
+    if (e - s > BIG_MAX) { if (lane == 0) { atomicOr(counts + 1, 1u); kept[s] = 0; } continue; }
     for (uint32_t i = lane; i < (e - s + 31) / 32; i += 64) s_taken[i] = 0;
     __syncthreads();
     uint32_t nk = 0;
     bool overflow = false;
-    for (int list = 0; list < 2 && !overflow; list++) {
-      const uint32_t lo = list ? mid : s, hi = list ? e : mid;
+    for (uint32_t list = 0; list < 2 && !overflow; list++) {
       const uint32_t first_kept = nk;
       for (;;) {
-        // best remaining record: score desc, gap bases asc, enumeration order (GA:125-129, stable sort)
+        // best remaining record of this list; the order is total (ekey is unique inside a window), so a max-reduction of a
+        // packed key finds it: score | inverted gap bases | inverted enumeration key | (the slot follows separately)
         unsigned long long bk = 0;
-        for (uint32_t m = lo + lane; m < hi; m += 64) {
+        uint32_t bm = 0;
+        for (uint32_t m = s + lane; m < e; m += 64) {
           const uint32_t rel = m - s;
           if ((s_taken[rel >> 5] >> (rel & 31)) & 1u) continue;
-          const Derived d = der[m];
+          const Derived d = der[slot[m]];
+          if ((d.ekey >> 17) != list) continue;
           const unsigned long long k = ((unsigned long long)(uint32_t)(d.score + (1 << 22)) << 40) | ((unsigned long long)(0xFFFFu - d.gaps) << 24) |
-                                       (unsigned long long)(0xFFFFFFu - (m - lo));
-          bk = k > bk ? k : bk;
+                                       (unsigned long long)(0x3FFFFu - (d.ekey & 0x1FFFFu)) << 1 | 1ull;
+          if (k > bk) { bk = k; bm = m; }
         }
         for (int off = 32; off > 0; off >>= 1) {
-          const unsigned long long o = __shfl_xor(bk, off);
-          bk = o > bk ? o : bk;
+          const unsigned long long ok = __shfl_xor(bk, off);
+          const uint32_t om = __shfl_xor(bm, off);
+          if (ok > bk) { bk = ok; bm = om; }
         }
         if (bk == 0) break;
-        const uint32_t best = lo + (0xFFFFFFu - (uint32_t)(bk & 0xFFFFFFu));
-        if (lane == 0) { const uint32_t rel = best - s; s_taken[rel >> 5] |= 1u << (rel & 31); }
+        if (lane == 0) { const uint32_t rel = bm - s; s_taken[rel >> 5] |= 1u << (rel & 31); }
+        const uint32_t best = slot[bm];
         const Derived b = der[best];
-        bool clash = false;
         if ((int)b.edits <= max_total_diffs) {
           bool mine = false;
           for (uint32_t k = first_kept + lane; k < nk; k += 64) {
             const int o = min(b.end, s_ke[k - first_kept]) - max(b.start, s_ks[k - first_kept]);   // GA:119-122
             mine = mine || o > max_overlap;
           }
-          clash = __ballot(mine) != 0;
-          if (!clash) {
+          if (__ballot(mine) == 0) {
             if (nk - first_kept >= BIG_KEPT) { overflow = true; break; }
-            if (lane == 0) { out_pos[s + nk] = best; s_ks[nk - first_kept] = b.start; s_ke[nk - first_kept] = b.end; }
+            if (lane == 0) { out_idx[s + nk] = best; s_ks[nk - first_kept] = b.start; s_ke[nk - first_kept] = b.end; }
             nk++;
           }
         }
         __syncthreads();
       }
     }
-    if (lane == 0) { if (overflow) { atomicOr(flags, 1u); kept[s] = 0; } else kept[s] = nk; }
+    if (lane == 0) { if (overflow) { atomicOr(counts + 1, 1u); kept[s] = 0; } else kept[s] = nk; }
     __syncthreads();
   }
 }
 
-__global__ void gather_kernel(const RawAln* raw, const uint32_t* vals, const uint32_t* kept, const uint32_t* offs, const uint32_t* out_pos,
-                              uint32_t n, RawAln* final_out, uint32_t* counts) {
+__global__ void gather_kernel(const RawAln* raw, const uint32_t* kept, const uint32_t* koffs, const uint32_t* out_idx, uint32_t n,
+                              RawAln* final_out, uint32_t* counts) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const uint32_t nk = kept[s];
-  for (uint32_t r = 0; r < nk; r++) final_out[offs[s] + r] = raw[vals[out_pos[s + r]]];
-  if (s == n - 1) counts[0] = offs[s] + nk;           // total survivors
+  const uint32_t nk = kept[s], d = koffs[s];
+  for (uint32_t r = 0; r < nk; r++) final_out[d + r] = raw[out_idx[s + r]];
+  if (s == n - 1) counts[0] = d + nk;                  // total survivors
 }
 
 template <typename T>
-hipError_t grow(T** p, size_t& cap, size_t need) {
+hipError_t grow(T** p, size_t& cap, size_t need, bool zero = false) {
   if (need <= cap) return hipSuccess;
   (void)hipFree(*p); *p = nullptr; cap = 0;
+  need += need / 8;
   hipError_t e = hipMalloc((void**)p, need * sizeof(T));
-  if (e == hipSuccess) cap = need;
-  return e;
+  if (e != hipSuccess) return e;
+  cap = need;
+  return zero ? hipMemset(*p, 0, need * sizeof(T)) : hipSuccess;
 }
 
 }  // namespace
 
 struct SelectWork {
-  uint64_t *keys = nullptr, *keys2 = nullptr; size_t keys_cap = 0, keys2_cap = 0;
-  uint32_t *vals = nullptr, *vals2 = nullptr, *kept = nullptr, *offs = nullptr, *out_pos = nullptr;
-  size_t vals_cap = 0, vals2_cap = 0, kept_cap = 0, offs_cap = 0, out_pos_cap = 0;
   Derived* der = nullptr; size_t der_cap = 0;
+  uint32_t *slot = nullptr, *out_idx = nullptr, *big = nullptr; size_t slot_cap = 0, out_idx_cap = 0, big_cap = 0;
   uint8_t* taken = nullptr; size_t taken_cap = 0;
+  uint32_t *cnt = nullptr, *offs = nullptr;       // per window (+ 1)
+  uint32_t *kept = nullptr, *koffs = nullptr;     // per slot position
+  size_t cnt_cap = 0, offs_cap = 0, kept_cap = 0, koffs_cap = 0;
+  bool cnt_dirty = false;      // a call was cut short between count_kernel and scatter_kernel: cnt must be cleared
   RawAln* final_out = nullptr; size_t final_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
-  uint32_t* big = nullptr; size_t big_cap = 0;
-  uint32_t* counts = nullptr;   // [0] survivors, [1] flags, [2] window groups left to filter_big_kernel
+  uint32_t* counts = nullptr;   // [0] survivors, [1] flags, [2] windows left to filter_big_kernel
 };
 
 void select_destroy(SelectWork* w) {
   if (!w) return;
-  (void)hipFree(w->keys); (void)hipFree(w->keys2); (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->kept);
-  (void)hipFree(w->offs); (void)hipFree(w->out_pos); (void)hipFree(w->der); (void)hipFree(w->taken); (void)hipFree(w->final_out);
-  (void)hipFree(w->temp); (void)hipFree(w->counts); (void)hipFree(w->big);
+  (void)hipFree(w->der); (void)hipFree(w->slot); (void)hipFree(w->out_idx); (void)hipFree(w->big); (void)hipFree(w->taken);
+  (void)hipFree(w->cnt); (void)hipFree(w->offs); (void)hipFree(w->kept); (void)hipFree(w->koffs); (void)hipFree(w->final_out);
+  (void)hipFree(w->temp); (void)hipFree(w->counts);
   delete w;
 }
 
-bool select_supported(uint64_t n_contigs, uint64_t max_windows_per_contig, int window_size, int n_guides) {
-  return n_contigs < (1ull << 18) && max_windows_per_contig < (1ull << 22) && window_size < (1 << 13) && n_guides <= 64;
+bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides) {
+  return window_size < (1 << 13) &&      // end columns take 13 bits of the enumeration key
+         windows_per_guide > 0 && windows_per_guide * (uint64_t)n_guides < (1ull << 31) && n_guides <= 64;
 }
 
+void select_done(SelectWork* w) { if (w) w->cnt_dirty = false; }
+
 hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
-                      const int2* d_win, int max_total_diffs, int max_overlap, hipStream_t stream, const RawAln** d_final,
-                      const uint32_t** d_counts) {
+                      const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
+                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts) {
   if (!*pw) *pw = new SelectWork();
   SelectWork& w = **pw;
   hipError_t e;
   const size_t n = n_raw;
+  const size_t nw = (size_t)windows_per_guide * (size_t)n_guides;
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-  if (!w.counts) TRY(hipMalloc((void**)&w.counts, 3 * sizeof(uint32_t)));
-  TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream));
+  if (!w.counts) { TRY(hipMalloc((void**)&w.counts, 3 * sizeof(uint32_t))); TRY(hipMemset(w.counts, 0, 3 * sizeof(uint32_t))); }
   *d_final = nullptr; *d_counts = w.counts;
-  if (n == 0) return hipSuccess;
-  TRY(grow(&w.keys, w.keys_cap, n)); TRY(grow(&w.keys2, w.keys2_cap, n));
-  TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n));
-  TRY(grow(&w.kept, w.kept_cap, n)); TRY(grow(&w.offs, w.offs_cap, n)); TRY(grow(&w.out_pos, w.out_pos_cap, n));
-  TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.taken, w.taken_cap, n)); TRY(grow(&w.big, w.big_cap, n / GROUP_MAX + 1)); TRY(grow(&w.final_out, w.final_cap, n));
+  if (n == 0) { TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream)); return hipSuccess; }
+  const size_t cnt_cap_before = w.cnt_cap;
+  TRY(grow(&w.cnt, w.cnt_cap, nw + 1, true));
+  if (w.cnt_dirty && w.cnt_cap == cnt_cap_before) TRY(hipMemsetAsync(w.cnt, 0, w.cnt_cap * sizeof(uint32_t), stream));
+  TRY(grow(&w.offs, w.offs_cap, nw + 1)); TRY(grow(&w.kept, w.kept_cap, n)); TRY(grow(&w.koffs, w.koffs_cap, n));
+  TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.slot, w.slot_cap, n)); TRY(grow(&w.out_idx, w.out_idx_cap, n));
+  TRY(grow(&w.taken, w.taken_cap, n)); TRY(grow(&w.big, w.big_cap, n / GROUP_MAX + 1)); TRY(grow(&w.final_out, w.final_cap, n));
   size_t t1 = 0, t2 = 0;
-  TRY(rocprim::radix_sort_pairs(nullptr, t1, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
-  TRY(rocprim::exclusive_scan(nullptr, t2, w.kept, w.offs, 0u, n, rocprim::plus<uint32_t>(), stream));
-  {
-    size_t need = std::max(t1, t2);
-    if (need > w.temp_cap) { (void)hipFree(w.temp); w.temp = nullptr; w.temp_cap = 0; TRY(hipMalloc(&w.temp, need)); w.temp_cap = need; }
-  }
-  const dim3 block(256), grid((unsigned)((n + 255) / 256));
-  hipLaunchKernelGGL(key_kernel, grid, block, 0, stream, d_raw, n_raw, d_guides, w.keys, w.vals);
+  TRY(rocprim::exclusive_scan(nullptr, t1, w.cnt, w.offs, 0u, nw + 1, rocprim::plus<uint32_t>(), stream));
+  TRY(rocprim::exclusive_scan(nullptr, t2, w.kept, w.koffs, 0u, n, rocprim::plus<uint32_t>(), stream));
+  t1 = std::max(t1, t2);
+  if (t1 > w.temp_cap) { (void)hipFree(w.temp); w.temp = nullptr; w.temp_cap = 0; TRY(hipMalloc(&w.temp, t1)); w.temp_cap = t1; }
+  const dim3 block(256), grid_n((unsigned)((n + 255) / 256));
+  w.cnt_dirty = true;
+  hipLaunchKernelGGL(count_kernel, grid_n, block, 0, stream, d_raw, n_raw, d_guides, d_win_base, d_win, (uint32_t)window_lo, (uint32_t)windows_per_guide, w.der,
+                     w.cnt, w.counts);
   size_t ts = w.temp_cap;
-  TRY(rocprim::radix_sort_pairs(w.temp, ts, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
-  hipLaunchKernelGGL(derive_kernel, grid, block, 0, stream, d_raw, (const uint32_t*)w.vals2, n_raw, d_guides, d_win_base, d_win, w.der);
-  TRY(hipMemsetAsync(w.taken, 0, n, stream));
-  hipLaunchKernelGGL(filter_kernel, grid, block, 0, stream, (const uint64_t*)w.keys2, (const Derived*)w.der, n_raw, max_total_diffs,
-                     max_overlap, w.taken, w.kept, w.out_pos, w.counts + 1, w.big);
-  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 8192)), dim3(64), 0, stream, (const uint64_t*)w.keys2,
-                     (const Derived*)w.der, n_raw, max_total_diffs, max_overlap, w.kept, w.out_pos, w.counts + 1, (const uint32_t*)w.big);
+  TRY(rocprim::exclusive_scan(w.temp, ts, w.cnt, w.offs, 0u, nw + 1, rocprim::plus<uint32_t>(), stream));   // cnt[nw] = 0: offs[nw] = n
+  hipLaunchKernelGGL(scatter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, n_raw, (const uint32_t*)w.offs, w.cnt, w.slot, w.taken);
+  hipLaunchKernelGGL(filter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, (const uint32_t*)w.offs, (const uint32_t*)w.slot,
+                     n_raw, max_total_diffs, max_overlap, w.taken, w.kept, w.out_idx, w.counts, w.big);
+  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 8192)), dim3(64), 0, stream, (const Derived*)w.der,
+                     (const uint32_t*)w.offs, (const uint32_t*)w.slot, max_total_diffs, max_overlap, w.kept, w.out_idx, w.counts,
+                     (const uint32_t*)w.big);
   ts = w.temp_cap;
-  TRY(rocprim::exclusive_scan(w.temp, ts, w.kept, w.offs, 0u, n, rocprim::plus<uint32_t>(), stream));
-  hipLaunchKernelGGL(gather_kernel, grid, block, 0, stream, d_raw, (const uint32_t*)w.vals2, (const uint32_t*)w.kept,
-                     (const uint32_t*)w.offs, (const uint32_t*)w.out_pos, n_raw, w.final_out, w.counts);
+  TRY(rocprim::exclusive_scan(w.temp, ts, w.kept, w.koffs, 0u, n, rocprim::plus<uint32_t>(), stream));
+  hipLaunchKernelGGL(gather_kernel, grid_n, block, 0, stream, d_raw, (const uint32_t*)w.kept, (const uint32_t*)w.koffs,
+                     (const uint32_t*)w.out_idx, n_raw, w.final_out, w.counts);
   TRY(hipGetLastError());
-  if (std::getenv("CALITAS_SELECT_DEBUG")) {
-    TRY(hipStreamSynchronize(stream));
-    std::vector<uint64_t> k(n); std::vector<uint32_t> v(n), kp(n), op(n), of(n); std::vector<Derived> d(n); std::vector<RawAln> r(n);
-    TRY(hipMemcpy(k.data(), w.keys2, n * 8, hipMemcpyDeviceToHost)); TRY(hipMemcpy(v.data(), w.vals2, n * 4, hipMemcpyDeviceToHost));
-    TRY(hipMemcpy(kp.data(), w.kept, n * 4, hipMemcpyDeviceToHost)); TRY(hipMemcpy(op.data(), w.out_pos, n * 4, hipMemcpyDeviceToHost));
-    TRY(hipMemcpy(of.data(), w.offs, n * 4, hipMemcpyDeviceToHost)); TRY(hipMemcpy(d.data(), w.der, n * sizeof(Derived), hipMemcpyDeviceToHost));
-    TRY(hipMemcpy(r.data(), d_raw, n * sizeof(RawAln), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n && i < 60; i++)
-      std::fprintf(stderr, "[select] %zu key=%016llx val=%u raw(score=%d tend=%d pam=%d wk=%u dir=%d) der(score=%d start=%d end=%d gaps=%d edits=%d) kept=%u off=%u outpos=%u\n", i,
-                   (unsigned long long)k[i], v[i], r[v[i]].score, r[v[i]].t_end_guide, r[v[i]].pam, r[v[i]].window_k, r[v[i]].dir, d[i].score, d[i].start, d[i].end, d[i].gaps, d[i].edits, kp[i], of[i], op[i]);
-  }
 #undef TRY
   *d_final = w.final_out;
   return hipSuccess;

@@ -9,15 +9,18 @@ namespace calitas {
 
 struct SelectWork;   // device scratch, grown on demand and reused across searches
 
-// True when the key layout of the sort can represent this search (contigs < 2^18, windows per contig < 2^22, window < 8192).
-bool select_supported(uint64_t n_contigs, uint64_t max_windows_per_contig, int window_size, int n_guides);
+// True when the global window index (guide x windows) fits the counters and an end column fits the enumeration key.
+bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides);
 
-// Sorts, filters and compacts d_raw[0..n_raw).  On return (stream-ordered) *d_final holds the accepted alignments in
-// (guide, contig, window, retval) order and (*d_counts)[0] their number; (*d_counts)[1] != 0 means a window exceeded the
-// kernel's group limit and the result must not be used.
+// Groups, filters and compacts d_raw[0..n_raw).  [window_lo, window_lo + windows_per_guide) = the entries of the device window
+// table the alignments can fall into (all of it, or the contig range of a lane).  On return
+// (stream-ordered) *d_final holds the accepted alignments in (guide, contig, window, retval) order and (*d_counts)[0] their
+// number; (*d_counts)[1] != 0 means a window exceeded the kernels' limits and the result must not be used.  Call select_done
+// once the stream has been synchronised without error (it certifies that the per-window counters are back to zero).
 hipError_t select_run(SelectWork** work, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
-                      const int2* d_win, int max_total_diffs, int max_overlap, hipStream_t stream, const RawAln** d_final,
-                      const uint32_t** d_counts);
+                      const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
+                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts);
+void select_done(SelectWork* work);
 void select_destroy(SelectWork* work);
 
 }  // namespace calitas
