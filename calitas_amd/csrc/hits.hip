@@ -4,17 +4,18 @@
 // GA = GuideAlignment.scala, RH = ReferenceHit.scala, SR = SearchReference.scala.
 //
 // Input: the accepted alignments of one guide, in calitas_search order, still on the device (select.hip's output).
-//   1. hit_kernel      GuideAlignment coordinates (GA:21-31, SGA:260-313) and ReferenceHit.end (RH:135-138) per alignment;
-//                      sort key A = (contig, strand, coordinate_start, -score): the order removeOverlaps sorts each
-//                      (chromosome, strand) group in (RH:284 inside one group); arrival order breaks ties (stable sort).
-//   2. rocPRIM radix sort, then a running maximum of `end` per group (inclusive scan with max over (group, end)).
-//   3. cluster_kernel  removeOverlaps walks a group left to right carrying one "current hit".  Wherever a hit starts at or
-//                      beyond (max end so far - maxOverlap + 1) no earlier hit can overlap it by >= maxOverlap, the walk
-//                      keeps its current hit and restarts there with a clean state.  Those restart points cut the group
-//                      into clusters that are independent of each other; one lane walks one cluster (usually 1-3 hits).
-//   4. sort key B = (contig, coordinate_start, strand, -score) for kept hits (RH:284; ties can only meet inside one group,
-//                      where order A already is the reference's order), ~0 for dropped ones; stable radix sort.
-//   5. row_kernel      twice: once counting bytes, once writing at the exclusive-scanned offsets.
+//   1. hit_kernel      GuideAlignment coordinates (GA:21-31, SGA:260-313) and ReferenceHit.end (RH:135-138) per alignment; sort
+//                      key = (contig, coordinate_start, strand, -score) = ReferenceHit.sort (RH:284); arrival order breaks ties
+//                      (stable rocPRIM radix sort).  The hits of one (chromosome, strand) group -- what removeOverlaps works on,
+//                      SR:656 -- are a subsequence of that order, and inside the group the order is the group's own sort order.
+//   2. prep_kernel     per sorted position: start / end / score / (contig, strand), and whether removeOverlaps' walk restarts
+//                      here.  The walk carries one "current hit" through a group; wherever a hit starts at or beyond (largest end
+//                      so far - maxOverlap + 1) no earlier hit of the group can overlap it by >= maxOverlap, the walk keeps its
+//                      current hit and restarts with a clean state.  Hits are at most CALITAS_MAX_OPS long, so "largest end so
+//                      far" only needs a look back over the hits that start within that distance.
+//   3. cluster_kernel  the restart points cut every group into clusters (usually 1-3 hits) that are independent of each other;
+//                      one lane walks one cluster with the reference's loop (SR:661-671), stepping over the other strand's hits.
+//   4. mid_kernel / out_kernel: rows of the kept hits, already in final order (dropped hits have length 0).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -36,7 +37,6 @@ namespace {
 
 constexpr int SCORE_BITS = 14;
 constexpr uint32_t CLUSTER_MAX = 1u << 20;
-constexpr uint64_t DROPPED = ~0ull;
 
 struct HitRec {
   int32_t contig, start, end, gstart, gend, score, rh_end;
@@ -47,8 +47,6 @@ struct RowConstDev {
   uint32_t head_off, head_len, tail_off, tail_len, plen_off, plen_len;
   uint32_t q_off[MAX_PAMS + 1], q_len[MAX_PAMS + 1], pu_off[MAX_PAMS + 1], pu_len[MAX_PAMS + 1];
 };
-
-__device__ __forceinline__ int raw_op(const RawAln& r, int i) { return (r.ops[i >> 2] >> ((i & 3) * 2)) & 3; }  // 0 = 1 X 2 I 3 D
 
 __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
                            int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* flags) {
@@ -83,46 +81,57 @@ __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides
   hits[i] = h;
   int sb = score_hi - r.score;
   if (sb < 0 || sb >= (1 << SCORE_BITS) || h.gstart < 0) { atomicOr(flags, HITS_FLAG_SCORE_RANGE); sb = 0; }
-  keys[i] = ((uint64_t)r.contig << 46) | ((uint64_t)h.minus << 45) | ((uint64_t)(uint32_t)h.gstart << 14) | (uint64_t)sb;
+  keys[i] = ((uint64_t)r.contig << 46) | ((uint64_t)(uint32_t)h.gstart << 15) | ((uint64_t)h.minus << 14) | (uint64_t)sb;
   vals[i] = i;
 }
 
-__global__ void sorted_kernel(const HitRec* hits, const uint64_t* keys, const uint32_t* vals, uint32_t n, int32_t* s_start,
-                              int32_t* s_end, int32_t* s_score, uint64_t* ge) {
+constexpr int HIT_MAX_LEN = CALITAS_MAX_OPS;   // a hit covers at most this many reference bases (ReferenceHit.end - start + 1)
+
+__global__ void prep_kernel(const HitRec* hits, const uint32_t* order, uint32_t n, int max_overlap, int32_t* s_start, int32_t* s_end,
+                            int32_t* s_score, uint32_t* s_cs, uint8_t* head, uint8_t* keep) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const HitRec h = hits[vals[i]];
-  s_start[i] = h.gstart; s_end[i] = h.rh_end; s_score[i] = h.score;
-  ge[i] = ((keys[i] >> 45) << 32) | (uint64_t)(uint32_t)h.rh_end;
+  const HitRec h = hits[order[i]];
+  const uint32_t cs = ((uint32_t)h.contig << 1) | h.minus;
+  s_start[i] = h.gstart; s_end[i] = h.rh_end; s_score[i] = h.score; s_cs[i] = cs;
+  keep[i] = 0;
+  // restart point?  look back over the hits of this contig that start close enough to reach maxOverlap bases into this one
+  bool is_head = true;
+  for (uint32_t j = i; j-- > 0;) {
+    const HitRec p = hits[order[j]];
+    if (p.contig != h.contig || p.gstart + HIT_MAX_LEN - 1 - h.gstart < max_overlap) break;
+    if (p.minus == h.minus && p.rh_end - h.gstart >= max_overlap) { is_head = false; break; }
+  }
+  head[i] = is_head ? 1 : 0;
 }
 
-struct MaxU64 {
-  __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; }
-};
-
-__device__ __forceinline__ bool cluster_head(const uint64_t* keys, const uint64_t* rm, const int32_t* s_start, uint32_t j, int max_overlap) {
-  if (j == 0) return true;
-  const uint64_t prev = rm[j - 1];
-  if ((prev >> 32) != (keys[j] >> 45)) return true;
-  return (int)(uint32_t)prev - s_start[j] < max_overlap;
-}
-
-__global__ void cluster_kernel(const uint64_t* keys, const uint64_t* rm, const int32_t* s_start, const int32_t* s_end,
-                               const int32_t* s_score, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+__global__ void cluster_kernel(const int32_t* s_start, const int32_t* s_end, const int32_t* s_score, const uint32_t* s_cs,
+                               const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !cluster_head(keys, rm, s_start, i, max_overlap)) return;
+  if (i >= n || !head[i]) return;
+  const uint32_t cs = s_cs[i];
+  // next hit of this (contig, strand) group after position j, or n
+  auto next = [&](uint32_t j) {
+    for (j++; j < n; j++) {
+      const uint32_t c = s_cs[j];
+      if (c == cs) return j;
+      if ((c >> 1) != (cs >> 1)) break;
+    }
+    return n;
+  };
   uint32_t j = i, steps = 0;
   for (;;) {                                            // SR:661-671
-    const uint32_t hit = j++;
+    const uint32_t hit = j;
+    j = next(j);
     const int hs = s_start[hit], he = s_end[hit], hsc = s_score[hit];
     bool more = false;
     int ov = 0;
     for (;;) {
-      more = j < n && !cluster_head(keys, rm, s_start, j, max_overlap);
+      more = j < n && !head[j];
       if (!more) break;
       ov = max(0, min(s_end[j], he) - max(s_start[j], hs));   // RH:141-144
       if (!(ov >= max_overlap && s_score[j] <= hsc)) break;
-      j++;
+      j = next(j);
       if (++steps > CLUSTER_MAX) break;
     }
     if (steps > CLUSTER_MAX) { atomicOr(flags, HITS_FLAG_CLUSTER); return; }
@@ -130,22 +139,6 @@ __global__ void cluster_kernel(const uint64_t* keys, const uint64_t* rm, const i
     if (!more) return;
     if (++steps > CLUSTER_MAX) { atomicOr(flags, HITS_FLAG_CLUSTER); return; }
   }
-}
-
-__global__ void keyb_kernel(const HitRec* hits, const uint64_t* keys_a, const uint32_t* vals_a, const uint8_t* keep, uint32_t n,
-                            uint64_t* keys_b, uint32_t* vals_b, uint32_t* n_kept) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool k = false;
-  if (i < n) {
-    k = keep[i] != 0;
-    const uint32_t v = vals_a[i];
-    const HitRec h = hits[v];
-    const uint64_t sb = keys_a[i] & ((1u << SCORE_BITS) - 1);
-    keys_b[i] = k ? (((uint64_t)(uint32_t)h.contig << 46) | ((uint64_t)(uint32_t)h.gstart << 15) | ((uint64_t)h.minus << 14) | sb) : DROPPED;
-    vals_b[i] = v;
-  }
-  const unsigned long long b = __ballot(k);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_kept, (uint32_t)__popcll(b));
 }
 
 // ---- rows ------------------------------------------------------------------------------------------------------------
@@ -225,13 +218,14 @@ struct MidArgs {
   const RawAln* fin;
   const HitRec* hits;
   const GuideDev* guides;
-  const uint64_t* keys_b;    // sorted
+  const uint8_t* keep;       // per sorted position: survives removeOverlaps
   const uint32_t* order;     // sorted values: index into fin / hits
   uint32_t n;
   uint32_t slot_bytes;       // LDS bytes per lane: multiple of 4, odd number of words
   uint32_t mid_bound;        // bytes reserved for the middle part = staging stride
   uint32_t n_max;            // most padded columns a row of this search can have
   uint32_t blob_bytes;       // constant strings, copied to LDS by each block
+  uint32_t* n_rows;          // out: number of live rows
 };
 
 static_assert(offsetof(RawAln, ops) % 4 == 0 && sizeof(RawAln) % 4 == 0, "RawAln::ops must be word aligned");
@@ -352,7 +346,7 @@ __global__ __launch_bounds__(64) void mid_kernel(MidArgs a, uint8_t* stage, uint
   const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64, k = row0 + lane;
   int len = 0;
   uint32_t name_len = 0;
-  const bool live = k < a.n && a.keys_b[k] != DROPPED;
+  const bool live = k < a.n && a.keep[k] != 0;
   // constant strings (queries, PAMs) into LDS behind the 64 slots
   uint8_t* blob = lds + 64 * a.slot_bytes;
   for (uint32_t i = lane; i < a.blob_bytes; i += 64) blob[i] = (uint8_t)a.blob[i];
@@ -371,6 +365,10 @@ __global__ __launch_bounds__(64) void mid_kernel(MidArgs a, uint8_t* stage, uint
     len = format_middle(out, out + a.mid_bound, a, blob, r, h, a.guides[guide]);
     if (len < 0 || len > (int)a.mid_bound) { atomicOr(flags, HITS_FLAG_ROW); len = 0; }
     name_len = a.name_off[h.contig + 1] - a.name_off[h.contig];
+  }
+  {
+    const unsigned long long lv = __ballot(live);
+    if (lane == 0 && lv) atomicAdd(a.n_rows, (uint32_t)__popcll(lv));
   }
   if (k < a.n) {
     midlen[k] = (uint32_t)len;
@@ -395,7 +393,7 @@ struct OutArgs {
   const uint32_t* midlen;
   const uint64_t* offs;
   const uint8_t* stage;
-  uint32_t n_rows, mid_bound;
+  uint32_t n, mid_bound;       // n sorted positions; dropped hits have midlen 0
 };
 
 constexpr int OUT_ROWS_PER_WAVE = 8;
@@ -410,7 +408,8 @@ __global__ __launch_bounds__(256) void out_kernel(OutArgs a, char* text) {
   const uint8_t* tail = lds + a.rc.head_len;
   for (int rr = 0; rr < OUT_ROWS_PER_WAVE; rr++) {
     const uint32_t k = wave * OUT_ROWS_PER_WAVE + rr;
-    if (k >= a.n_rows) return;
+    if (k >= a.n) return;
+    if (a.midlen[k] == 0) continue;                     // dropped by removeOverlaps
     const uint32_t contig = (uint32_t)a.hits[a.order[k]].contig;
     const uint32_t nb = a.name_off[contig], nl = a.name_off[contig + 1] - nb;
     const uint32_t s0 = a.rc.head_len, s1 = s0 + nl + 1, s2 = s1 + a.midlen[k], total = s2 + a.rc.tail_len;
@@ -443,11 +442,11 @@ hipError_t grow(T** p, size_t& cap, size_t need) {
 
 struct HitsWork {
   HitRec* hits = nullptr; size_t hits_cap = 0;
-  uint64_t *keys = nullptr, *keys2 = nullptr, *ge = nullptr, *rm = nullptr, *lens = nullptr, *offs = nullptr;
-  size_t keys_cap = 0, keys2_cap = 0, ge_cap = 0, rm_cap = 0, lens_cap = 0, offs_cap = 0;
-  uint32_t *vals = nullptr, *vals2 = nullptr; size_t vals_cap = 0, vals2_cap = 0;
+  uint64_t *keys = nullptr, *keys2 = nullptr, *lens = nullptr, *offs = nullptr;
+  size_t keys_cap = 0, keys2_cap = 0, lens_cap = 0, offs_cap = 0;
+  uint32_t *vals = nullptr, *vals2 = nullptr, *s_cs = nullptr; size_t vals_cap = 0, vals2_cap = 0, cs_cap = 0;
   int32_t *s_start = nullptr, *s_end = nullptr, *s_score = nullptr; size_t ss_cap = 0, se_cap = 0, sc_cap = 0;
-  uint8_t* keep = nullptr; size_t keep_cap = 0;
+  uint8_t *keep = nullptr, *head = nullptr; size_t keep_cap = 0, head_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
   char* text = nullptr; size_t text_cap = 0;
   uint8_t* stage = nullptr; size_t stage_cap = 0;
@@ -461,10 +460,11 @@ struct HitsWork {
 
 void hits_destroy(HitsWork* w) {
   if (!w) return;
-  (void)hipFree(w->hits); (void)hipFree(w->keys); (void)hipFree(w->keys2); (void)hipFree(w->ge); (void)hipFree(w->rm);
-  (void)hipFree(w->lens); (void)hipFree(w->offs); (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_start);
-  (void)hipFree(w->s_end); (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->temp); (void)hipFree(w->text); (void)hipFree(w->stage); (void)hipFree(w->midlen);
-  (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off); (void)hipFree(w->d_counts);
+  (void)hipFree(w->hits); (void)hipFree(w->keys); (void)hipFree(w->keys2); (void)hipFree(w->lens); (void)hipFree(w->offs);
+  (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_cs); (void)hipFree(w->s_start); (void)hipFree(w->s_end);
+  (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->head); (void)hipFree(w->temp); (void)hipFree(w->text);
+  (void)hipFree(w->stage); (void)hipFree(w->midlen); (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off);
+  (void)hipFree(w->d_counts);
   if (w->h_counts) (void)hipHostFree(w->h_counts);
   delete w;
 }
@@ -517,37 +517,28 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(hipMemcpyAsync(w.blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));   // blob outlives the sync below
 
   TRY(grow(&w.hits, w.hits_cap, n)); TRY(grow(&w.keys, w.keys_cap, n)); TRY(grow(&w.keys2, w.keys2_cap, n));
-  TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n)); TRY(grow(&w.ge, w.ge_cap, n)); TRY(grow(&w.rm, w.rm_cap, n));
+  TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n)); TRY(grow(&w.s_cs, w.cs_cap, n));
   TRY(grow(&w.lens, w.lens_cap, n)); TRY(grow(&w.offs, w.offs_cap, n)); TRY(grow(&w.s_start, w.ss_cap, n));
-  TRY(grow(&w.s_end, w.se_cap, n)); TRY(grow(&w.s_score, w.sc_cap, n)); TRY(grow(&w.keep, w.keep_cap, n));
-  size_t t1 = 0, t2 = 0, t3 = 0;
+  TRY(grow(&w.s_end, w.se_cap, n)); TRY(grow(&w.s_score, w.sc_cap, n)); TRY(grow(&w.keep, w.keep_cap, n)); TRY(grow(&w.head, w.head_cap, n));
+  size_t t1 = 0, t3 = 0;
   TRY(rocprim::radix_sort_pairs(nullptr, t1, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
-  TRY(rocprim::inclusive_scan(nullptr, t2, w.ge, w.rm, n, MaxU64(), stream));
   TRY(rocprim::exclusive_scan(nullptr, t3, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   {
-    const size_t need = std::max(t1, std::max(t2, t3));
+    const size_t need = std::max(t1, t3);
     if (need > w.temp_cap) { (void)hipFree(w.temp); w.temp = nullptr; w.temp_cap = 0; TRY(hipMalloc(&w.temp, need)); w.temp_cap = need; }
   }
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
   size_t ts;
-  // 1-2: coordinates, order A, running maximum of `end`
+  // 1: coordinates and the final order
   hipLaunchKernelGGL(hit_kernel, grid, block, 0, stream, d_final, n_in, d_guides, d_win_base, d_win, score_hi, w.hits, w.keys, w.vals, d_flags);
   ts = w.temp_cap;
   TRY(rocprim::radix_sort_pairs(w.temp, ts, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
-  hipLaunchKernelGGL(sorted_kernel, grid, block, 0, stream, (const HitRec*)w.hits, (const uint64_t*)w.keys2, (const uint32_t*)w.vals2, n_in,
-                     w.s_start, w.s_end, w.s_score, w.ge);
-  ts = w.temp_cap;
-  TRY(rocprim::inclusive_scan(w.temp, ts, w.ge, w.rm, n, MaxU64(), stream));
-  // 3: removeOverlaps
-  TRY(hipMemsetAsync(w.keep, 0, n, stream));
-  hipLaunchKernelGGL(cluster_kernel, grid, block, 0, stream, (const uint64_t*)w.keys2, (const uint64_t*)w.rm, (const int32_t*)w.s_start,
-                     (const int32_t*)w.s_end, (const int32_t*)w.s_score, n_in, max_overlap, w.keep, d_flags);
-  // 4: final order (keys / vals are free again)
-  hipLaunchKernelGGL(keyb_kernel, grid, block, 0, stream, (const HitRec*)w.hits, (const uint64_t*)w.keys2, (const uint32_t*)w.vals2,
-                     (const uint8_t*)w.keep, n_in, w.keys, w.vals, d_kept);
-  ts = w.temp_cap;
-  TRY(rocprim::radix_sort_pairs(w.temp, ts, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
-  // 5: rows
+  // 2-3: removeOverlaps
+  hipLaunchKernelGGL(prep_kernel, grid, block, 0, stream, (const HitRec*)w.hits, (const uint32_t*)w.vals2, n_in, max_overlap, w.s_start, w.s_end,
+                     w.s_score, w.s_cs, w.head, w.keep);
+  hipLaunchKernelGGL(cluster_kernel, grid, block, 0, stream, (const int32_t*)w.s_start, (const int32_t*)w.s_end, (const int32_t*)w.s_score,
+                     (const uint32_t*)w.s_cs, (const uint8_t*)w.head, n_in, max_overlap, w.keep, d_flags);
+  // 4: rows
   const uint32_t n_max = (uint32_t)std::min<int>(CALITAS_MAX_OPS, std::max(1, max_ops));
   const uint32_t mid_bound = (6 * n_max + 128 + 3) & ~3u;
   uint32_t slot = mid_bound + ((5 * n_max + 24 + 3) & ~3u);
@@ -567,7 +558,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(grow(&w.midlen, w.midlen_cap, n_pad));
   MidArgs ma{};
   ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
-  ma.keys_b = w.keys2; ma.order = w.vals2; ma.n = n_in; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob.size();
+  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob.size();
   hipLaunchKernelGGL(mid_kernel, dim3((unsigned)(n_pad / 64)), dim3(64), mid_lds, stream, ma, w.stage, w.midlen, w.lens, d_flags);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
@@ -584,9 +575,9 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   if (res->n_rows) {
     OutArgs oa{};
     oa.rc = rc; oa.blob = w.blob; oa.names = w.names; oa.name_off = w.name_off; oa.hits = w.hits; oa.order = w.vals2; oa.midlen = w.midlen;
-    oa.offs = w.offs; oa.stage = w.stage; oa.n_rows = res->n_rows; oa.mid_bound = mid_bound;
+    oa.offs = w.offs; oa.stage = w.stage; oa.n = n_in; oa.mid_bound = mid_bound;
     const unsigned rows_per_block = 4 * OUT_ROWS_PER_WAVE;
-    hipLaunchKernelGGL(out_kernel, dim3((res->n_rows + rows_per_block - 1) / rows_per_block), dim3(256), rc.head_len + rc.tail_len, stream, oa, w.text);
+    hipLaunchKernelGGL(out_kernel, dim3((n_in + rows_per_block - 1) / rows_per_block), dim3(256), rc.head_len + rc.tail_len, stream, oa, w.text);
   }
   TRY(hipGetLastError());
   res->d_text = w.text;

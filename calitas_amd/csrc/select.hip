@@ -67,23 +67,26 @@ __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guid
   atomicAdd(&cnt[d.widx], 1u);
 }
 
-__global__ void scatter_kernel(const Derived* der, uint32_t n, const uint32_t* offs, uint32_t* cnt, uint32_t* slot, uint8_t* taken) {
+// ders[] = der[] in slot order: the filter kernels read a window's records as one contiguous run
+__global__ void scatter_kernel(const Derived* der, uint32_t n, const uint32_t* offs, uint32_t* cnt, uint32_t* slot, Derived* ders,
+                               uint8_t* taken) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t w = der[i].widx;
-  const uint32_t pos = offs[w] + atomicSub(&cnt[w], 1u) - 1u;
+  const Derived d = der[i];
+  const uint32_t pos = offs[d.widx] + atomicSub(&cnt[d.widx], 1u) - 1u;
   slot[pos] = i;
-  taken[i] = 0;
+  ders[pos] = d;
+  taken[i] = 0;                                        // indexed by slot position below; any permutation clears all n
 }
 
 // One lane per slot position; only the first slot of a window works (a lane per window would leave 97 % of the lanes of an
 // hg38-sized table idle).  kept[s] = number of survivors of the window whose slots start at s (0 for the other positions);
 // their alignment indices, in output order, go to out_idx[s .. s + kept[s]).
-__global__ void filter_kernel(const Derived* der, const uint32_t* offs, const uint32_t* slot, uint32_t n, int max_total_diffs,
-                              int max_overlap, uint8_t* taken, uint32_t* kept, uint32_t* out_idx, uint32_t* counts, uint32_t* big) {
+__global__ void filter_kernel(const Derived* ders, const uint32_t* offs, uint32_t n, int max_total_diffs, int max_overlap, uint8_t* taken,
+                              uint32_t* kept, uint32_t* out_pos, uint32_t* counts, uint32_t* big) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const uint32_t w = der[slot[s]].widx;
+  const uint32_t w = ders[s].widx;
   if (offs[w] != s) { kept[s] = 0; return; }
   const uint32_t e = offs[w + 1];
   if (e - s > GROUP_MAX) { big[atomicAdd(counts + 2, 1u)] = s; kept[s] = 0; return; }   // left to filter_big_kernel
@@ -95,26 +98,25 @@ __global__ void filter_kernel(const Derived* der, const uint32_t* offs, const ui
       int best = -1, b_score = 0, b_gaps = 0, b_start = 0, b_end = 0, b_edits = 0;
       uint32_t b_ekey = 0;
       for (uint32_t m = s; m < e; m++) {
-        const uint32_t id = slot[m];
-        if (taken[id]) continue;
-        const uint32_t ek = der[id].ekey;
+        if (taken[m]) continue;
+        const uint32_t ek = ders[m].ekey;
         if ((ek >> 17) != list) continue;
-        const int sc = der[id].score, gp = der[id].gaps;
+        const int sc = ders[m].score, gp = ders[m].gaps;
         // score desc, gap bases asc (GA:125-129), then the enumeration order (stable sort)
         const bool first = best < 0;
         const bool wins = sc > b_score || (sc == b_score && (gp < b_gaps || (gp == b_gaps && ek < b_ekey)));
-        if (first || wins) { best = (int)id; b_score = sc; b_gaps = gp; b_ekey = ek; b_start = der[id].start; b_end = der[id].end; b_edits = der[id].edits; }
+        if (first || wins) { best = (int)m; b_score = sc; b_gaps = gp; b_ekey = ek; b_start = ders[m].start; b_end = ders[m].end; b_edits = ders[m].edits; }
       }
       if (best < 0) break;
       taken[best] = 1;
       if (b_edits > max_total_diffs) continue;
       bool clash = false;
       for (uint32_t k = first_kept; k < nk; k++) {
-        const uint32_t kid = out_idx[s + k];
-        const int o = min(b_end, der[kid].end) - max(b_start, der[kid].start);   // GA:119-122
+        const uint32_t kp = out_pos[s + k];
+        const int o = min(b_end, ders[kp].end) - max(b_start, ders[kp].start);   // GA:119-122
         if (o > max_overlap) { clash = true; break; }
       }
-      if (!clash) out_idx[s + nk++] = (uint32_t)best;
+      if (!clash) out_pos[s + nk++] = (uint32_t)best;
     }
   }
   kept[s] = nk;
@@ -125,16 +127,15 @@ __global__ void filter_kernel(const Derived* der, const uint32_t* offs, const ui
 constexpr uint32_t BIG_MAX = 1u << 16;     // records per window
 constexpr uint32_t BIG_KEPT = 4096;        // kept alignments per strand list
 
-__global__ __launch_bounds__(64) void filter_big_kernel(const Derived* der, const uint32_t* offs, const uint32_t* slot, int max_total_diffs,
-                                                        int max_overlap, uint32_t* kept, uint32_t* out_idx, uint32_t* counts,
-                                                        const uint32_t* big) {
+__global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, const uint32_t* offs, int max_total_diffs, int max_overlap,
+                                                        uint32_t* kept, uint32_t* out_pos, uint32_t* counts, const uint32_t* big) {
   __shared__ uint32_t s_taken[BIG_MAX / 32];
   __shared__ int s_ks[BIG_KEPT], s_ke[BIG_KEPT];
   const uint32_t lane = threadIdx.x;
   const uint32_t n_big = counts[2];
   for (uint32_t g = blockIdx.x; g < n_big; g += gridDim.x) {
     const uint32_t s = big[g];
-    const uint32_t e = offs[der[slot[s]].widx + 1];
+    const uint32_t e = offs[ders[s].widx + 1];
     if (e - s > BIG_MAX) { if (lane == 0) { atomicOr(counts + 1, 1u); kept[s] = 0; } continue; }
     for (uint32_t i = lane; i < (e - s + 31) / 32; i += 64) s_taken[i] = 0;
     __syncthreads();
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* der, cons
         for (uint32_t m = s + lane; m < e; m += 64) {
           const uint32_t rel = m - s;
           if ((s_taken[rel >> 5] >> (rel & 31)) & 1u) continue;
-          const Derived d = der[slot[m]];
+          const Derived d = ders[m];
           if ((d.ekey >> 17) != list) continue;
           const unsigned long long k = ((unsigned long long)(uint32_t)(d.score + (1 << 22)) << 40) | ((unsigned long long)(0xFFFFu - d.gaps) << 24) |
                                        (unsigned long long)(0x3FFFFu - (d.ekey & 0x1FFFFu)) << 1 | 1ull;
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* der, cons
         }
         if (bk == 0) break;
         if (lane == 0) { const uint32_t rel = bm - s; s_taken[rel >> 5] |= 1u << (rel & 31); }
-        const uint32_t best = slot[bm];
-        const Derived b = der[best];
+        const uint32_t best = bm;
+        const Derived b = ders[best];
         if ((int)b.edits <= max_total_diffs) {
           bool mine = false;
           for (uint32_t k = first_kept + lane; k < nk; k += 64) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* der, cons
           }
           if (__ballot(mine) == 0) {
             if (nk - first_kept >= BIG_KEPT) { overflow = true; break; }
-            if (lane == 0) { out_idx[s + nk] = best; s_ks[nk - first_kept] = b.start; s_ke[nk - first_kept] = b.end; }
+            if (lane == 0) { out_pos[s + nk] = best; s_ks[nk - first_kept] = b.start; s_ke[nk - first_kept] = b.end; }
             nk++;
           }
         }
@@ -185,12 +186,12 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* der, cons
   }
 }
 
-__global__ void gather_kernel(const RawAln* raw, const uint32_t* kept, const uint32_t* koffs, const uint32_t* out_idx, uint32_t n,
-                              RawAln* final_out, uint32_t* counts) {
+__global__ void gather_kernel(const RawAln* raw, const uint32_t* slot, const uint32_t* kept, const uint32_t* koffs, const uint32_t* out_pos,
+                              uint32_t n, RawAln* final_out, uint32_t* counts) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const uint32_t nk = kept[s], d = koffs[s];
-  for (uint32_t r = 0; r < nk; r++) final_out[d + r] = raw[out_idx[s + r]];
+  for (uint32_t r = 0; r < nk; r++) final_out[d + r] = raw[slot[out_pos[s + r]]];
   if (s == n - 1) counts[0] = d + nk;                  // total survivors
 }
 
@@ -208,7 +209,7 @@ hipError_t grow(T** p, size_t& cap, size_t need, bool zero = false) {
 }  // namespace
 
 struct SelectWork {
-  Derived* der = nullptr; size_t der_cap = 0;
+  Derived *der = nullptr, *ders = nullptr; size_t der_cap = 0, ders_cap = 0;
   uint32_t *slot = nullptr, *out_idx = nullptr, *big = nullptr; size_t slot_cap = 0, out_idx_cap = 0, big_cap = 0;
   uint8_t* taken = nullptr; size_t taken_cap = 0;
   uint32_t *cnt = nullptr, *offs = nullptr;       // per window (+ 1)
@@ -222,7 +223,7 @@ struct SelectWork {
 
 void select_destroy(SelectWork* w) {
   if (!w) return;
-  (void)hipFree(w->der); (void)hipFree(w->slot); (void)hipFree(w->out_idx); (void)hipFree(w->big); (void)hipFree(w->taken);
+  (void)hipFree(w->der); (void)hipFree(w->ders); (void)hipFree(w->slot); (void)hipFree(w->out_idx); (void)hipFree(w->big); (void)hipFree(w->taken);
   (void)hipFree(w->cnt); (void)hipFree(w->offs); (void)hipFree(w->kept); (void)hipFree(w->koffs); (void)hipFree(w->final_out);
   (void)hipFree(w->temp); (void)hipFree(w->counts);
   delete w;
@@ -251,7 +252,7 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   TRY(grow(&w.cnt, w.cnt_cap, nw + 1, true));
   if (w.cnt_dirty && w.cnt_cap == cnt_cap_before) TRY(hipMemsetAsync(w.cnt, 0, w.cnt_cap * sizeof(uint32_t), stream));
   TRY(grow(&w.offs, w.offs_cap, nw + 1)); TRY(grow(&w.kept, w.kept_cap, n)); TRY(grow(&w.koffs, w.koffs_cap, n));
-  TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.slot, w.slot_cap, n)); TRY(grow(&w.out_idx, w.out_idx_cap, n));
+  TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.ders, w.ders_cap, n)); TRY(grow(&w.slot, w.slot_cap, n)); TRY(grow(&w.out_idx, w.out_idx_cap, n));
   TRY(grow(&w.taken, w.taken_cap, n)); TRY(grow(&w.big, w.big_cap, n / GROUP_MAX + 1)); TRY(grow(&w.final_out, w.final_cap, n));
   size_t t1 = 0, t2 = 0;
   TRY(rocprim::exclusive_scan(nullptr, t1, w.cnt, w.offs, 0u, nw + 1, rocprim::plus<uint32_t>(), stream));
@@ -264,15 +265,14 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
                      w.cnt, w.counts);
   size_t ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.cnt, w.offs, 0u, nw + 1, rocprim::plus<uint32_t>(), stream));   // cnt[nw] = 0: offs[nw] = n
-  hipLaunchKernelGGL(scatter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, n_raw, (const uint32_t*)w.offs, w.cnt, w.slot, w.taken);
-  hipLaunchKernelGGL(filter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, (const uint32_t*)w.offs, (const uint32_t*)w.slot,
-                     n_raw, max_total_diffs, max_overlap, w.taken, w.kept, w.out_idx, w.counts, w.big);
-  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 8192)), dim3(64), 0, stream, (const Derived*)w.der,
-                     (const uint32_t*)w.offs, (const uint32_t*)w.slot, max_total_diffs, max_overlap, w.kept, w.out_idx, w.counts,
-                     (const uint32_t*)w.big);
+  hipLaunchKernelGGL(scatter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, n_raw, (const uint32_t*)w.offs, w.cnt, w.slot, w.ders, w.taken);
+  hipLaunchKernelGGL(filter_kernel, grid_n, block, 0, stream, (const Derived*)w.ders, (const uint32_t*)w.offs, n_raw, max_total_diffs,
+                     max_overlap, w.taken, w.kept, w.out_idx, w.counts, w.big);
+  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 8192)), dim3(64), 0, stream, (const Derived*)w.ders,
+                     (const uint32_t*)w.offs, max_total_diffs, max_overlap, w.kept, w.out_idx, w.counts, (const uint32_t*)w.big);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.kept, w.koffs, 0u, n, rocprim::plus<uint32_t>(), stream));
-  hipLaunchKernelGGL(gather_kernel, grid_n, block, 0, stream, d_raw, (const uint32_t*)w.kept, (const uint32_t*)w.koffs,
+  hipLaunchKernelGGL(gather_kernel, grid_n, block, 0, stream, d_raw, (const uint32_t*)w.slot, (const uint32_t*)w.kept, (const uint32_t*)w.koffs,
                      (const uint32_t*)w.out_idx, n_raw, w.final_out, w.counts);
   TRY(hipGetLastError());
 #undef TRY
