@@ -33,7 +33,7 @@ def test_hg38_size_paths_agree_and_rows_are_ordered(world, monkeypatch):
     G = C.Guide(guide)
     monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
     lanes, n = ctx.search_hits(G, "a", params, "v0", "stamp")
-    assert ctx.timing()["lanes"] == 2                              # the default cut of a reference this large
+    assert ctx.timing()["lanes"] == 3                              # the default cut of a reference this large
     monkeypatch.setenv("CALITAS_CHUNKS", "1")
     one, n1 = ctx.search_hits(G, "a", params, "v0", "stamp")
     monkeypatch.setenv("CALITAS_CHUNKS", "3:2:2:1")
