@@ -13,7 +13,7 @@
 //                      no kept alignment of the same list overlaps it by more than maxOverlap;
 //   5. exclusive scan of the kept counts, gather_kernel: accepted alignments in (guide, contig, window, output) order.
 // Windows with more than GROUP_MAX alignments (satellite repeats, PAM-less dense searches) go to filter_big_kernel, one wave
-// per window; only beyond 65 536 records or 4 096 kept alignments in one window does a flag send the caller to the host
+// per window; only beyond 16 384 records or 512 kept alignments per strand in one window does a flag send the caller to the host
 // implementation of the same stage for this search.  (A first version radix-sorted 64-bit keys: eight more launches per call,
 // which is what a lane's tail is made of -- DESIGN.md 4.5.)
 #include <algorithm>
@@ -124,8 +124,10 @@ __global__ void filter_kernel(const Derived* ders, const uint32_t* offs, uint32_
 
 // Windows with more than GROUP_MAX records: one wave per window, same greedy.  The "taken" bits and the kept intervals of the
 // current strand list live in LDS; a window beyond those capacities raises the flag.
-constexpr uint32_t BIG_MAX = 1u << 16;     // records per window
-constexpr uint32_t BIG_KEPT = 4096;        // kept alignments per strand list
+// LDS is what a workgroup of this kernel has to wait for while the scan of the next lane fills the CUs (4 x 37 KB of 160 KB): kept
+// to 6 KB, because the kernel is launched on every call and usually has nothing to do.
+constexpr uint32_t BIG_MAX = 1u << 14;     // records per window
+constexpr uint32_t BIG_KEPT = 512;         // kept alignments per strand list
 
 __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, const uint32_t* offs, int max_total_diffs, int max_overlap,
                                                         uint32_t* kept, uint32_t* out_pos, uint32_t* counts, const uint32_t* big) {
@@ -268,7 +270,7 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   hipLaunchKernelGGL(scatter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, n_raw, (const uint32_t*)w.offs, w.cnt, w.slot, w.ders, w.taken);
   hipLaunchKernelGGL(filter_kernel, grid_n, block, 0, stream, (const Derived*)w.ders, (const uint32_t*)w.offs, n_raw, max_total_diffs,
                      max_overlap, w.taken, w.kept, w.out_idx, w.counts, w.big);
-  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 8192)), dim3(64), 0, stream, (const Derived*)w.ders,
+  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 2048)), dim3(64), 0, stream, (const Derived*)w.ders,
                      (const uint32_t*)w.offs, max_total_diffs, max_overlap, w.kept, w.out_idx, w.counts, (const uint32_t*)w.big);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.kept, w.koffs, 0u, n, rocprim::plus<uint32_t>(), stream));
