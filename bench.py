@@ -183,7 +183,7 @@ def main():
     lengths = [l for _, l in spec]
 
     if world > 1 and args.shard == "contigs":
-        mine = shard.lpt_partition(lengths, world)[rank]
+        mine = shard.contiguous_partition(lengths, world)[rank]   # consecutive ranges: the gather is a concatenation
         my_guides = [GUIDE0]
         guide_passes_per_step = 1          # the ranks share ONE guide pass
         bases_per_step_total = sum(lengths)
@@ -209,17 +209,36 @@ def main():
 
     contig_mode = world > 1 and args.shard == "contigs"
 
+    shm_path = "/dev/shm/calitas_bench_hits_%s.txt" % os.environ.get("MASTER_PORT", "0")
+    shm_fd = os.open(shm_path, os.O_RDWR | os.O_CREAT, 0o600) if contig_mode else -1
+
+    def place_rows(view, rows):
+        """Contig partition, no copies: this rank's piece of the job's hits.txt goes from the library's buffer straight into the
+        shared file at its offset (rank 0 keeps the header line); only the sizes travel between the ranks."""
+        import torch.distributed as dist
+        nl = 0
+        if rank:
+            while view[nl] != 10:
+                nl += 1
+            nl += 1
+        sizes = torch.zeros(world, 2, dtype=torch.int64)
+        dist.all_gather_into_tensor(sizes.view(-1), torch.tensor([len(view) - nl, rows], dtype=torch.int64), group=gloo)
+        os.pwrite(shm_fd, view[nl:], int(sizes[:rank, 0].sum()))
+        return int(sizes[:, 1].sum())
+
     def gather_rows(text, rows):
+        """Contig partition: every rank owns a consecutive contig range, so its rows are a consecutive piece of the job's hits.txt.
+        The ranks share one node: each writes its piece at its offset into one file in shared memory; only the sizes travel."""
         if not contig_mode:
             return rows
         import torch.distributed as dist
-        header, blocks = shard.split_rows_by_contig(text, ctx.contig_names)
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(blocks, gathered, dst=0, group=gloo)
-        if rank == 0:
-            # contig indices are local to each rank's shard; rows carry names, so merge by name order
-            rows = sum(len(r) for b in gathered for r in b.values())
-        return rows
+        nl = text.index(b"\n") + 1
+        body = text[nl:] if rank else text                    # rank 0 keeps the header line
+        sizes = torch.zeros(world, 2, dtype=torch.int64)
+        mine_t = torch.tensor([len(body), rows], dtype=torch.int64)
+        dist.all_gather_into_tensor(sizes.view(-1), mine_t, group=gloo)
+        os.pwrite(shm_fd, body, int(sizes[:rank, 0].sum()))
+        return int(sizes[:, 1].sum())
 
     def step():
         tp0 = time.perf_counter()
@@ -230,9 +249,16 @@ def main():
             tm = ctx.timing()
             phase["search_hits"] += tp1 - tp0
             return tm, tm["accepted_alignments"], sum(r for _, r in res)
+        if contig_mode and not (args.no_hits or args.two_stage):
+            with ctx.search_hits_view(G[0], "bench", params, "bench", "bench") as (view, rows):
+                tp1 = time.perf_counter()
+                tm = ctx.timing()
+                rows = place_rows(view, rows)
+            phase["search_hits"] += tp1 - tp0; phase["gather"] += time.perf_counter() - tp1
+            return tm, tm["accepted_alignments"], rows
         if not (args.no_hits or args.two_stage):
             # calitas_search_hits: kernels through to the finished hits.txt text, one copy-back
-            text, rows = ctx.search_hits(G[0], "bench", params, "bench", "bench", decode=contig_mode)
+            text, rows = ctx.search_hits(G[0], "bench", params, "bench", "bench", decode=False)
             tp1 = time.perf_counter()
             tm = ctx.timing()
             rows = gather_rows(text, rows)
@@ -245,6 +271,8 @@ def main():
             rows = 0
             if not args.no_hits:
                 text, rows = ctx.hits_tsv_raw(G[0], "bench", params, out, n, "bench", "bench", decode=contig_mode)
+                if contig_mode:
+                    text = text.encode()
                 rows = gather_rows(text, rows)
         finally:
             tp2 = time.perf_counter()
@@ -349,6 +377,15 @@ def main():
     ctx.close()
     if world > 1:
         import torch.distributed as dist
+        if contig_mode:
+            dist.barrier(group=gloo)
+            if rank == 0:   # the assembled file of the last step: one header, `rows` rows, contigs in dictionary order
+                size = os.fstat(shm_fd).st_size
+                whole = os.pread(shm_fd, size, 0)
+                n_lines = whole.count(b"\n")
+                log("contig partition: assembled hits.txt in shared memory has %d lines (%d bytes)" % (n_lines, size))
+                os.unlink(shm_path)
+            os.close(shm_fd)
         dist.destroy_process_group()
 
 

@@ -5,6 +5,7 @@ Names, argument meaning and error behaviour follow
   calitas/src/main/scala/com/editasmedicine/aligner/SearchReference.scala (SearchReference flags, execute)
 so the parity tests read like the reference's own tests.  All alignment work happens in libcalitas_hip.so.
 """
+import contextlib
 import ctypes
 import time
 
@@ -246,15 +247,32 @@ class Context:
 
     def search_hits(self, guide, guide_id, params, version=None, time_stamp=None, decode=True):
         """calitas_search_hits: one guide against the resident reference, finished hits.txt text back (tsv_text, n_rows);
-        decode=False skips the copy into a Python str and returns (n_bytes, n_rows)."""
+        decode=False skips the copy into a Python str and returns (n_bytes, n_rows); decode="bytes" returns the raw bytes."""
         g = guide.to_c()
         tsv, nbytes, rows = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
         _lib.check(self._h, lib.calitas_search_hits(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params),
                                                     version.encode() if version else None, time_stamp.encode() if time_stamp else None,
                                                     ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(rows)))
-        text = ctypes.string_at(tsv, nbytes.value).decode() if decode else nbytes.value
+        if decode == "bytes":
+            text = ctypes.string_at(tsv, nbytes.value)
+        else:
+            text = ctypes.string_at(tsv, nbytes.value).decode() if decode else nbytes.value
         lib.calitas_free(tsv)
         return text, rows.value
+
+    @contextlib.contextmanager
+    def search_hits_view(self, guide, guide_id, params, version=None, time_stamp=None):
+        """calitas_search_hits without a copy: yields (memoryview over the library's text buffer, n_rows); the buffer is
+        released when the block ends."""
+        g = guide.to_c()
+        tsv, nbytes, rows = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._h, lib.calitas_search_hits(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params),
+                                                    version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                                    ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(rows)))
+        try:
+            yield memoryview((ctypes.c_char * nbytes.value).from_address(tsv.value)).cast("B"), rows.value
+        finally:
+            lib.calitas_free(tsv)
 
     def search_hits_batch(self, guides, guide_ids, params, version=None, time_stamp=None, decode=True):
         """calitas_search_hits_batch: a list of (tsv_text or n_bytes, n_rows), one per guide, pipelined on the device."""

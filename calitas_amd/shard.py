@@ -3,7 +3,9 @@
 Two natural partitions exist:
   * contigs -- every window x strand is independent (SearchReference.scala:537-561), and removeOverlaps
     (SearchReference.scala:653-675) groups by chromosome, so a rank that owns whole contigs can finish its rows alone;
-    rank 0 only concatenates the per-contig row blocks in sequence-dictionary order (ReferenceHit.scala:284).
+    rank 0 only concatenates the per-contig row blocks in sequence-dictionary order (ReferenceHit.scala:284).  With
+    consecutive ranges (contiguous_partition) that is a plain concatenation of the ranks' texts; LPT packing balances a
+    little better (1.05x of the mean against 1.14x for hg38 on 8 ranks) but needs the blocks re-ordered.
   * guides  -- the reference runs one guide per invocation, so a 96-guide batch is 96 independent outputs.
 """
 
@@ -19,6 +21,43 @@ def lpt_partition(lengths, n_bins):
         bins[b].append(i)
         loads[b] += lengths[i]
     return [sorted(b) for b in bins]
+
+
+def contiguous_partition(lengths, n_bins):
+    """Contigs in dictionary order cut into n_bins consecutive ranges with the smallest possible largest range (linear
+    partition).  Returns a list of n_bins lists of contig indices (some empty when there are fewer contigs than bins).
+    A rank that owns a consecutive range produces a consecutive piece of the final hits.txt: the gather is a concatenation."""
+    n = len(lengths)
+    k = max(1, min(n_bins, n))
+    prefix = [0]
+    for x in lengths:
+        prefix.append(prefix[-1] + x)
+    INF = float("inf")
+    # best[j][i]: smallest largest range when the first i contigs form j ranges
+    best = [[INF] * (n + 1) for _ in range(k + 1)]
+    cut = [[0] * (n + 1) for _ in range(k + 1)]
+    best[0][0] = 0
+    for j in range(1, k + 1):
+        for i in range(j, n + 1):
+            for m in range(j - 1, i):
+                cost = max(best[j - 1][m], prefix[i] - prefix[m])
+                if cost < best[j][i]:
+                    best[j][i], cut[j][i] = cost, m
+    bounds, i = [], n
+    for j in range(k, 0, -1):
+        bounds.append((cut[j][i], i))
+        i = cut[j][i]
+    ranges = [list(range(a, b)) for a, b in reversed(bounds)]
+    return ranges + [[] for _ in range(n_bins - k)]
+
+
+def concat_rank_texts(texts):
+    """hits.txt texts of consecutive contig ranges (bytes or str, each with the header line) -> the whole file."""
+    nl = b"\n" if isinstance(texts[0], bytes) else "\n"
+    out = [texts[0]]
+    for t in texts[1:]:
+        out.append(t[t.index(nl) + 1:])
+    return (b"" if isinstance(texts[0], bytes) else "").join(out)
 
 
 def split_rows_by_contig(tsv_text, contig_names):

@@ -70,6 +70,52 @@ def test_contig_partition_gather_equals_single_process():
     assert len(want) > 5 and got == want
 
 
+def _worker_contiguous(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from calitas_amd import shard
+    names, seqs = _genome()
+    mine = shard.contiguous_partition([len(s) for s in seqs], world)[rank]
+    hdr, rows, _ = O.search_memory([names[i] for i in mine], [seqs[i] for i in mine], GUIDE, "a", d=4, p=1, g=2)
+    text = ("\n".join(["\t".join(hdr)] + ["\t".join(r.values()) for r in rows]) + "\n").encode()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(text, gathered, dst=0)
+    if rank == 0:
+        with open(os.path.join(outdir, "whole.txt"), "wb") as f:
+            f.write(shard.concat_rank_texts(gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_contiguous_partition_gather_is_a_concatenation():
+    """bench.py --shard contigs: every rank owns a consecutive contig range, rank 0 concatenates the ranks' texts."""
+    sys.path.insert(0, HERE)
+    import oracle_lib as O
+    from calitas_amd import shard, synth
+    names, seqs = _genome()
+    parts = shard.contiguous_partition([len(s) for s in seqs], 2)
+    assert parts[0] + parts[1] == list(range(len(seqs))) and parts[0] and parts[1]
+    with tempfile.TemporaryDirectory() as d:
+        port = 31500 + os.getpid() % 2000
+        mp.start_processes(_worker_contiguous, args=(2, port, d), nprocs=2, join=True, start_method="spawn")
+        whole = open(os.path.join(d, "whole.txt")).read()
+    _, want, _ = O.search_memory(names, seqs, GUIDE, "a", d=4, p=1, g=2)
+    lines = whole.splitlines()
+    got = [dict(zip(lines[0].split("\t"), ln.split("\t"))) for ln in lines[1:]]
+    assert len(want) > 5 and got == want
+    # balance on the real thing: 8 consecutive ranges of hg38's chromosomes
+    for n in (2, 4, 8):
+        p = shard.contiguous_partition(synth.HG38_LENGTHS, n)
+        assert [i for r in p for i in r] == list(range(len(synth.HG38_LENGTHS)))
+        loads = [sum(synth.HG38_LENGTHS[i] for i in r) for r in p]
+        assert max(loads) <= 1.2 * sum(loads) / n, (n, loads)
+    assert shard.contiguous_partition([5, 5], 4) == [[0], [1], [], []]
+
+
 def test_guide_partition_is_a_partition():
     from calitas_amd import shard
     for world in (1, 2, 4, 8):
