@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <sched.h>
+
 #include <mutex>
 #include <string>
 #include <vector>
@@ -88,16 +90,17 @@ int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_
 
 // Host waits on the critical path poll instead of blocking: a call has four of them per lane and a blocking wait adds tens of
 // microseconds of wake-up latency each.
-inline hipError_t calitas_spin_sync(hipStream_t s) {
+// (After a few thousand polls the thread yields between polls, so an oversubscribed host is not starved by waiting lanes.)
+template <typename Q>
+inline hipError_t calitas_poll(Q query) {
   hipError_t e;
-  while ((e = hipStreamQuery(s)) == hipErrorNotReady) __builtin_ia32_pause();
+  for (unsigned spins = 0; (e = query()) == hipErrorNotReady; spins++) {
+    if (spins < 4096) __builtin_ia32_pause(); else sched_yield();
+  }
   return e;
 }
-inline hipError_t calitas_spin_sync(hipEvent_t ev) {
-  hipError_t e;
-  while ((e = hipEventQuery(ev)) == hipErrorNotReady) __builtin_ia32_pause();
-  return e;
-}
+inline hipError_t calitas_spin_sync(hipStream_t s) { return calitas_poll([s] { return hipStreamQuery(s); }); }
+inline hipError_t calitas_spin_sync(hipEvent_t ev) { return calitas_poll([ev] { return hipEventQuery(ev); }); }
 
 #define HIP_TRY(ctx, call)                                                                         \
   do {                                                                                             \

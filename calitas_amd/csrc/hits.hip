@@ -17,6 +17,7 @@
 //                      one lane walks one cluster with the reference's loop (SR:661-671), stepping over the other strand's hits.
 //   4. mid_kernel / out_kernel: rows of the kept hits, already in final order (dropped hits have length 0).
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cstddef>
@@ -564,7 +565,9 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts);
   TRY(hipMemcpyAsync(w.h_counts, w.d_counts, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  while ((e = hipStreamQuery(stream)) == hipErrorNotReady) __builtin_ia32_pause();   // poll: a blocking wait costs tens of microseconds more
+  for (unsigned spins = 0; (e = hipStreamQuery(stream)) == hipErrorNotReady; spins++) {   // poll: a blocking wait costs tens of microseconds more
+    if (spins < 4096) __builtin_ia32_pause(); else sched_yield();
+  }
   TRY(e);
   TRY(hipGetLastError());
   res->flags = (uint32_t)w.h_counts[2];
