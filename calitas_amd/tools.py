@@ -87,7 +87,8 @@ class SequentialGuideAligner:
         n = len(guides)
         tb = [t if isinstance(t, bytes) else t.encode() for t in targets]
         offsets = list(offsets) if offsets is not None else [0] * n
-        keep = [g.to_c() for g in guides]
+        cache = {}                                          # the variant branch passes one Guide object thousands of times
+        keep = [cache[id(g)] if id(g) in cache else cache.setdefault(id(g), g.to_c()) for g in guides]
         garr = (GuideT * max(1, n))(*keep)
         tptr = (ctypes.c_void_p * max(1, n))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in tb])
         tlen = (ctypes.c_uint32 * max(1, n))(*[len(b) for b in tb])

@@ -1,11 +1,11 @@
 #!/bin/bash
-# One rocprofv3 counter pass over tools/scan_profile.py (inside gpurun): bash tools/pmc_pass.sh NAME "COUNTER [COUNTER...]" [scale] [steps]
+# One rocprofv3 counter pass over tools/scan_profile.py (inside gpurun): bash tools/pmc_pass.sh NAME "COUNTER [COUNTER...]" [scale] [steps] [hits]
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-NAME=$1; COUNTERS=$2; SCALE=${3:-1.0}; STEPS=${4:-3}
+NAME=$1; COUNTERS=$2; SCALE=${3:-1.0}; STEPS=${4:-3}; HITS=${5:-}
 mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$NAME
-timeout -k 10 500 rocprofv3 --pmc $COUNTERS --output-format csv -d /tmp/pmc_$NAME -o run -- python3 "$ROOT/tools/scan_profile.py" $SCALE $STEPS > /tmp/pmc_$NAME.log 2>&1 < /dev/null
+timeout -k 10 500 rocprofv3 --pmc $COUNTERS --output-format csv -d /tmp/pmc_$NAME -o run -- python3 "$ROOT/tools/scan_profile.py" $SCALE $STEPS $HITS > /tmp/pmc_$NAME.log 2>&1 < /dev/null
 echo "exit $?"; tail -2 /tmp/pmc_$NAME.log
 f=$(find /tmp/pmc_$NAME -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ]; then

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Torch-free driver for rocprofv3 counter passes: builds an hg38-like synthetic genome with numpy and runs K
-SearchReference passes through the C ABI.  Usage: python3 tools/scan_profile.py [scale] [steps]"""
+SearchReference passes through the C ABI.  Usage: python3 tools/scan_profile.py [scale] [steps] [hits]
+(with a third argument the passes go through calitas_search_hits, so the filter / hits / row kernels run as well)."""
 import os
 import sys
 import time
@@ -29,9 +30,13 @@ ctx.set_reference(names, seqs)
 G = [C.Guide("CTTGCCCCACAGGGCAGTAAnrg")]
 params = C.make_params(max_gaps_between_guide_and_pam=2)
 ts = []
+fused = len(sys.argv) > 3
 for i in range(steps):
-    out, n = ctx.search_raw(G, params)
-    C._lib.lib.calitas_free(out)
+    if fused:
+        _, n = ctx.search_hits(G[0], "p", params, "v", "t", decode=False)
+    else:
+        out, n = ctx.search_raw(G, params)
+        C._lib.lib.calitas_free(out)
     t = ctx.timing()
     ts.append(t)
     print("step %d: scan %.3f ms align %.3f ms, %d alignments, packed bytes %d" % (i, t["scan_kernel_ms"], t["align_kernel_ms"], n, t["packed_bytes"]), flush=True)
