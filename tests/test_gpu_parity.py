@@ -132,6 +132,10 @@ CONFIGS = [
     ("eqx-by-score", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=2, switches=2)),
     ("costs", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=2, guide_mismatch_net_cost=-100, pam_mismatch_net_cost=-200,
                                                   genome_gap_net_cost=-104, guide_gap_net_cost=-102)),
+    ("short-guide-12", "GCAGTAACCTGAnrg", (), dict(d=2, p=1, g=1)),
+    ("long-guide-32", "CTTGCCCCACAGGGCAGTAACGGTTCAATGCA", (), dict(d=6)),               # the scan's 32 rows, PAM-less
+    ("long-pam-8", "CTTGCCCCACAGGGCAGTAAnnagaawn", (), dict(d=4, p=2, g=2)),
+    ("three-strands-of-limits", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=6, p=3, g=4, D=7, O=1)),
 ]
 
 
