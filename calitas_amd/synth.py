@@ -94,7 +94,7 @@ def make_contig(rng, length, gc=0.41, softmask=0.5, n_run_ends=0, n_block=0, tan
     if n_run_ends > 0:
         seq[:min(n_run_ends, length)] = ord("N")
         seq[max(0, length - n_run_ends):] = ord("N")
-    if n_block > 0 and length > 3 * n_block:
+    if n_block > 0 and 2 * length // 3 - n_block > length // 3:
         s = int(rng.integers(length // 3, 2 * length // 3 - n_block))
         seq[s:s + n_block] = ord("N")
     return seq
