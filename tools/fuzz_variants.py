@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Randomised parity of the variant branch (SearchReference --variants): random genomes, VCFs (SNVs, insertions, deletions,
+multi-allelic sites, clusters, AFs), guides and limits; product against the oracle, every column.
+Usage: python3 tools/fuzz_variants.py [iterations] [seed]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import calitas_amd as C
+from calitas_amd import synth
+import oracle_lib as O
+from fasta_util import write_fasta
+from test_oracle_variants import write_vcf
+
+SKIP = {"aligner_version", "time_stamp"}
+
+
+def norm(rows):
+    out = []
+    for r in rows:
+        r = {k: v for k, v in r.items() if k not in SKIP}
+        if r.get("variant_vcf"):
+            r["variant_vcf"] = r["variant_vcf"].split(":")[0]
+        out.append(r)
+    return out
+
+
+def run(iters, seed):
+    rng = np.random.default_rng(seed)
+    tmp = "/tmp/calitas_fuzz_v"
+    os.makedirs(tmp, exist_ok=True)
+    bad = ties = 0
+    t0 = time.time()
+    guides = ["CTTGCCCCACAGGGCAGTAAnrg", "GTGACTTGAAGTCTCAGTATA", "tttvAACCAACCAACCGGTTACGT", "GATACGTCTCGTACTGTnrg"]
+    for it in range(iters):
+        guide = guides[int(rng.integers(0, len(guides)))]
+        G = C.Guide(guide)
+        d, p, g = int(rng.integers(1, 6)), int(rng.integers(0, 2)), int(rng.integers(0, 4))
+        mv = int(rng.choice([2, 4, 16]))
+        spec = [("chr%d" % (i + 1), int(rng.integers(3000, 25000))) for i in range(int(rng.integers(1, 3)))]
+        names, seqs = synth.make_genome(spec, int(rng.integers(0, 1 << 30)), guides=[(G.guide, G.pams[0] if G.pams else "", G.pam_is_five_prime)],
+                                        sites_per_guide=int(rng.integers(20, 120)), n_run_ends=int(rng.integers(0, 150)),
+                                        n_block=int(rng.integers(0, 900)), softmask=float(rng.random() * 0.4))
+        contigs = [(n, s.tobytes().decode()) for n, s in zip(names, seqs)]
+        fa = write_fasta(os.path.join(tmp, "v.fa"), contigs)
+        gap = int(rng.choice([20, 80, 300]))
+        variants, afs = [], []
+        for name, seq in contigs:
+            pos, U = 50, seq.upper()
+            while pos < len(seq) - 100:
+                pos += int(rng.integers(2, gap))
+                if pos >= len(seq) - 50:
+                    break
+                rb = U[pos - 1]
+                if rb not in "ACGT":
+                    continue
+                kind = int(rng.integers(0, 6))
+                others = [b for b in "ACGT" if b != rb]
+                if kind <= 1:
+                    ref, alts = rb, [others[int(rng.integers(0, 3))]]
+                elif kind == 2:
+                    ref, alts = rb, [rb + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 6))))]
+                elif kind == 3:
+                    ln = int(rng.integers(2, 6))
+                    ref = U[pos - 1:pos - 1 + ln]
+                    if any(c not in "ACGT" for c in ref):
+                        continue
+                    alts = [rb]
+                elif kind == 4:
+                    ref, alts = rb, others[:int(rng.integers(2, 4))]
+                else:                                  # MNP / complex
+                    ln = int(rng.integers(2, 4))
+                    ref = U[pos - 1:pos - 1 + ln]
+                    if any(c not in "ACGT" for c in ref):
+                        continue
+                    alts = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(2, 5))))]
+                    if alts[0] == ref:
+                        continue
+                variants.append((name, pos, "rs%d" % len(variants) if rng.integers(0, 4) else "", ref, alts))
+                afs.append([round(float(rng.uniform(0.0005, 0.5)), 4) for _ in alts])
+                pos += len(ref)
+        if not variants:
+            continue
+        vcf = write_vcf(os.path.join(tmp, "v.vcf"), variants, afs)
+        try:
+            _, want, _ = O.search_reference_vcf(fa, vcf, guide, "a", d=d, p=p, g=g, max_variants=mv)
+        except RuntimeError as e:
+            print("iter %d: oracle declined (%s)" % (it, str(e)[:80])); continue
+        try:
+            sr = C.SearchReference(guide=guide, guide_id="a", ref=fa, variants=vcf, max_guide_diffs=d, max_pam_mismatches=p,
+                                   max_gaps_between_guide_and_pam=g, max_variants=mv)
+            text, n = sr.run()
+        except Exception as e:
+            bad += 1
+            print("PRODUCT ERROR iter %d %s d%d p%d g%d V%d: %s" % (it, guide, d, p, g, mv, str(e)[:200]), flush=True); continue
+        g2, w2 = norm(C.read_hits(text)), norm(want)
+        if g2 != w2:
+            # Rows whose sort keys tie across a variant group and the reference group come out in the order of a hash map in the
+            # reference (SearchReference.scala:656, SURVEY unpinned): accept the same multiset in key order on both sides.
+            key = lambda r: (names.index(r["chromosome"]), int(r["coordinate_start"]), r["strand"], -int(r["score"]))
+            same = sorted(json.dumps(r, sort_keys=True) for r in g2) == sorted(json.dumps(r, sort_keys=True) for r in w2)
+            if same and [key(r) for r in g2] == sorted(key(r) for r in g2) and [key(r) for r in w2] == sorted(key(r) for r in w2):
+                ties += 1
+                continue
+            bad += 1
+            gs = {json.dumps(r, sort_keys=True) for r in g2}
+            ws = {json.dumps(r, sort_keys=True) for r in w2}
+            print("MISMATCH iter %d %s d%d p%d g%d V%d gap%d: product %d oracle %d; only product %s; only oracle %s" % (
+                it, guide, d, p, g, mv, gap, len(g2), len(w2), [json.loads(x) for x in sorted(gs - ws)][:1], [json.loads(x) for x in sorted(ws - gs)][:1]), flush=True)
+    print("fuzz_variants: %d iterations, %d mismatches, %d with tied rows in another order, %.1f s" % (iters, bad, ties, time.time() - t0))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
