@@ -457,6 +457,10 @@ struct HitsWork {
   uint32_t* name_off = nullptr; size_t name_off_cap = 0;
   uint64_t* d_counts = nullptr;   // [0] text bytes, [1] low word: kept rows, [2] low word: flags
   uint64_t* h_counts = nullptr;   // pinned
+  RowConstDev rc{};               // set by hits_prepare
+  size_t blob_bytes = 0;
+  std::string blob_host;
+  bool prepared = false;
 };
 
 void hits_destroy(HitsWork* w) {
@@ -490,6 +494,30 @@ hipError_t hits_set_names(HitsWork** pw, const std::vector<std::string>& names) 
   return hipSuccess;
 }
 
+// The per-call constants (row pieces, cleared counters), queued on `stream` ahead of everything else of the call so that nothing of
+// it sits between the filter stage and hit_kernel.  The host copy of the strings lives in the work until the next call.
+hipError_t hits_prepare(HitsWork** pw, const RowStrings& st, hipStream_t stream) {
+  if (!*pw) *pw = new HitsWork();
+  HitsWork& w = **pw;
+  hipError_t e;
+  if (!w.d_counts) TRY(hipMalloc((void**)&w.d_counts, 3 * sizeof(uint64_t)));
+  if (!w.h_counts) TRY(hipHostMalloc((void**)&w.h_counts, 3 * sizeof(uint64_t), hipHostMallocDefault));
+  TRY(hipMemsetAsync(w.d_counts, 0, 3 * sizeof(uint64_t), stream));
+  RowConstDev rc{};
+  std::string& blob = w.blob_host;
+  blob.clear();
+  auto add = [&](const std::string& s, uint32_t& off, uint32_t& len) { off = (uint32_t)blob.size(); len = (uint32_t)s.size(); blob += s; };
+  add(st.head, rc.head_off, rc.head_len); add(st.tail, rc.tail_off, rc.tail_len); add(st.proto_len, rc.plen_off, rc.plen_len);
+  for (size_t i = 0; i < st.query.size() && i <= (size_t)MAX_PAMS; i++) {
+    add(st.query[i], rc.q_off[i], rc.q_len[i]);
+    add(st.pam_used[i], rc.pu_off[i], rc.pu_len[i]);
+  }
+  TRY(grow(&w.blob, w.blob_cap, blob.size() + 1));
+  TRY(hipMemcpyAsync(w.blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+  w.rc = rc; w.blob_bytes = blob.size(); w.prepared = true;
+  return hipSuccess;
+}
+
 hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, uint32_t n_in, const GuideDev* d_guides,
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& st, int max_overlap, int score_hi,
                     int max_ops, hipStream_t stream, HitsResult* res) {
@@ -499,23 +527,12 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   *res = HitsResult{};
   const size_t n = n_in;
   if (n == 0) return hipSuccess;
-  if (!w.d_counts) TRY(hipMalloc((void**)&w.d_counts, 3 * sizeof(uint64_t)));
-  if (!w.h_counts) TRY(hipHostMalloc((void**)&w.h_counts, 3 * sizeof(uint64_t), hipHostMallocDefault));
-  TRY(hipMemsetAsync(w.d_counts, 0, 3 * sizeof(uint64_t), stream));
+  if (!w.prepared) TRY(hits_prepare(pw, st, stream));  // normally done at the start of the call
+  w.prepared = false;
+  const RowConstDev rc = w.rc;
+  const size_t blob_bytes = w.blob_bytes;
   uint32_t* d_kept = (uint32_t*)(w.d_counts + 1);
   uint32_t* d_flags = (uint32_t*)(w.d_counts + 2);
-
-  // constant row pieces
-  RowConstDev rc{};
-  std::string blob;
-  auto add = [&](const std::string& s, uint32_t& off, uint32_t& len) { off = (uint32_t)blob.size(); len = (uint32_t)s.size(); blob += s; };
-  add(st.head, rc.head_off, rc.head_len); add(st.tail, rc.tail_off, rc.tail_len); add(st.proto_len, rc.plen_off, rc.plen_len);
-  for (size_t i = 0; i < st.query.size() && i <= (size_t)MAX_PAMS; i++) {
-    add(st.query[i], rc.q_off[i], rc.q_len[i]);
-    add(st.pam_used[i], rc.pu_off[i], rc.pu_len[i]);
-  }
-  TRY(grow(&w.blob, w.blob_cap, blob.size() + 1));
-  TRY(hipMemcpyAsync(w.blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));   // blob outlives the sync below
 
   TRY(grow(&w.hits, w.hits_cap, n)); TRY(grow(&w.keys, w.keys_cap, n)); TRY(grow(&w.keys2, w.keys2_cap, n));
   TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n)); TRY(grow(&w.s_cs, w.cs_cap, n));
@@ -544,7 +561,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   const uint32_t mid_bound = (6 * n_max + 128 + 3) & ~3u;
   uint32_t slot = mid_bound + ((5 * n_max + 24 + 3) & ~3u);
   if (((slot / 4) & 1) == 0) slot += 4;
-  const uint32_t mid_lds = 64 * slot + (uint32_t)((blob.size() + 15) & ~(size_t)15);
+  const uint32_t mid_lds = 64 * slot + (uint32_t)((blob_bytes + 15) & ~(size_t)15);
   if (mid_lds > 64 * 1024) {   // beyond the default dynamic LDS limit: ask for more (160 KB per CU on gfx950) or decline
     if (mid_lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds) != hipSuccess) {
@@ -559,7 +576,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(grow(&w.midlen, w.midlen_cap, n_pad));
   MidArgs ma{};
   ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
-  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob.size();
+  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
   hipLaunchKernelGGL(mid_kernel, dim3((unsigned)(n_pad / 64)), dim3(64), mid_lds, stream, ma, w.stage, w.midlen, w.lens, d_flags);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));

@@ -42,6 +42,10 @@ bool hits_supported(uint64_t n_contigs, int max_overlap, int score_lo, int score
 // Contig names for the chromosome column; call again after the reference changes.
 hipError_t hits_set_names(HitsWork** work, const std::vector<std::string>& names);
 
+// The call's constant row pieces and cleared counters, queued on `stream`: call it at the start of a search_hits call, ahead of the
+// search kernels; hits_run does it itself otherwise.
+hipError_t hits_prepare(HitsWork** work, const RowStrings& strings, hipStream_t stream);
+
 // d_final[0..n): accepted alignments of ONE guide in calitas_search order (device memory).  Stream-ordered except for one
 // synchronisation to learn the text size.  max_ops bounds the padded columns of any alignment of this search (it sizes the
 // per-row LDS slots).  On success the rows are at res->d_text in final order.

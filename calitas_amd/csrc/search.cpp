@@ -560,6 +560,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   DeviceSel dev;
   calitas_aln_t* alns = nullptr;
   uint64_t n_alns = 0;
+  if (!std::getenv("CALITAS_HOST_HITS")) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // ahead of the lane's kernels, off the critical path
   int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched);
   if (rc) return rc;
   lt.tm = lane->timing;
