@@ -84,7 +84,7 @@ def make_params(window_size=1000, max_guide_diffs=Defaults.MaxGuideDiffs, max_pa
                 max_gaps_between_guide_and_pam=Defaults.MaxGapsBetweenGuideAndPam, max_total_diffs=None,
                 max_overlap=Defaults.MaxOverlap, guide_mismatch_net_cost=Defaults.MismatchNetCost,
                 pam_mismatch_net_cost=Defaults.PamMismatchNetCost, genome_gap_net_cost=Defaults.GenomeGapNetCost,
-                guide_gap_net_cost=Defaults.GuideGapNetCost, chrom_index=-1, eqx_by_score=0,
+                guide_gap_net_cost=Defaults.GuideGapNetCost, chrom_index=-1, eqx_by_score=0, per_matrix=0,
                 max_variants=Defaults.MaxVariantsInCluster):
     p = ParamsT()
     p.window_size = window_size
@@ -98,7 +98,7 @@ def make_params(window_size=1000, max_guide_diffs=Defaults.MaxGuideDiffs, max_pa
     p.genome_gap_net_cost = genome_gap_net_cost
     p.guide_gap_net_cost = guide_gap_net_cost
     p.chrom_index = chrom_index
-    p.eqx_by_score = eqx_by_score
+    p.eqx_by_score = (eqx_by_score & 3) | (2 if per_matrix else 0)   # bit flags, see calitas_hip.h
     p.max_variants = max_variants
     return p
 

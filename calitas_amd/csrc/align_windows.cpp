@@ -167,7 +167,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       aa.sp.max_guide_diffs = 0; aa.sp.max_pam_mismatches = 0; aa.sp.max_diffs_filtering = 0;   // per-guide values live in GuideDev
       aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
       aa.sp.match = sc.match; aa.sp.mismatch = sc.mismatch; aa.sp.pam_match = sc.pam_match; aa.sp.pam_mismatch = sc.pam_mismatch;
-      aa.sp.query_gap = sc.query_gap; aa.sp.target_gap = sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score; aa.sp.chrom_index = -1;
+      aa.sp.query_gap = sc.query_gap; aa.sp.target_gap = sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score & 1; aa.sp.per_matrix = (p.eqx_by_score >> 1) & 1; aa.sp.chrom_index = -1;
       HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
       HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream));
       HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -194,6 +194,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       const int la = list_of(a), lb = list_of(b);
       if (la != lb) return la < lb;
       if (a.t_end_guide != b.t_end_guide) return a.t_end_guide < b.t_end_guide;
+      if (a.pad != b.pad) return a.pad < b.pad;               // per-matrix enumeration: Diag, Left, Up
       return a.pam < b.pam;
     });
     std::vector<calitas_aln_t> win;

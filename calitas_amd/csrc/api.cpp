@@ -133,12 +133,14 @@ int calitas_create(int device_id, calitas_ctx** out) {
     (void)hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES);
     // The aligner kernel's wavefront relies on the DPP wave shift; verify it on this device once.
     int* d = nullptr;
-    int h[64];
-    bool ok = hipMalloc((void**)&d, sizeof(h)) == hipSuccess && launch_dpp_selftest(d, c->stream) == hipSuccess &&
-              hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+    int* h = nullptr;                       // page-locked: no copy of this library lands in pageable memory
+    bool ok = hipMalloc((void**)&d, 64 * sizeof(int)) == hipSuccess && hipHostMalloc((void**)&h, 64 * sizeof(int), hipHostMallocDefault) == hipSuccess &&
+              launch_dpp_selftest(d, c->stream) == hipSuccess &&
+              hipMemcpyAsync(h, d, 64 * sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
               hipStreamSynchronize(c->stream) == hipSuccess;
     (void)hipFree(d);
     for (int i = 1; ok && i < 64; i++) ok = h[i] == (i - 1) * 7 + 3;
+    if (h) (void)hipHostFree(h);
     if (!ok || !c->d_counters || !c->h_counters || !c->d_guides) {
       calitas_destroy(c);
       return fail(nullptr, CALITAS_EHIP, "device self-test failed (DPP wave_shr / allocation)");
@@ -191,6 +193,7 @@ static int upload_reference(calitas_ctx* ctx) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_list, std::max<size_t>(1, r.masked_tiles.size()) * sizeof(uint32_t)));
     if (!r.masked_tiles.empty())
       HIP_TRY(ctx, hipMemcpy(ctx->d_tile_list, r.masked_tiles.data(), r.masked_tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipDeviceSynchronize());   // the searches run on non-blocking streams, which nothing orders against these copies
   }
   return CALITAS_OK;
 }

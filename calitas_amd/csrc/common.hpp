@@ -114,7 +114,8 @@ struct SearchDev {        // scalar parameters of one search
   int32_t window_size, step, n_guides;
   int32_t max_guide_diffs, max_pam_mismatches, max_gaps, max_diffs_filtering;
   int32_t match, mismatch, pam_match, pam_mismatch, query_gap, target_gap;
-  int32_t eqx_by_score;
+  int32_t eqx_by_score;   // '=' / 'X' by pairing score instead of compatibility
+  int32_t per_matrix;     // one alignment per bottom-row matrix cell >= minScore instead of per end column
   int32_t chrom_index;
 };
 
@@ -136,7 +137,7 @@ struct RawAln {
   int8_t pam;             // PAM index or -1
   uint8_t offset;         // genome bases skipped between guide and PAM
   uint8_t n_ops;          // guide-part ops
-  uint8_t pad;
+  uint8_t pad;            // per-matrix enumeration: which matrix the traceback started in (0 Diag, 1 Left, 2 Up); else 0
   uint16_t pam_x;         // bit i set = PAM position i is 'X'
   uint8_t ops[RAW_MAX_OPS / 4];  // 2 bits per op in traceback (reverse) order: 0 '=', 1 'X', 2 'I', 3 'D'
 };
@@ -195,3 +196,7 @@ struct SlabHeader {
 static_assert(sizeof(SlabHeader) == 128, "slab header layout");
 
 }  // namespace calitas
+
+#ifdef CALITAS_ALLOC_DEBUG
+#include "dbg_alloc.hpp"   // make DBG_ALLOC=1: allocation registry dumped on abort
+#endif

@@ -15,15 +15,32 @@ bool DmaCopier::open(int /*device*/) {
   return ok_;
 }
 
+thread_local const char* g_dma_reason = "";
+const char* DmaCopier::last_reason() { return g_dma_reason; }
+
 bool DmaCopier::copy_to_host(void* dst_host, const void* src_dev, size_t n) const {
+  g_dma_reason = "";
   if (!ok_) return false;
   if (n == 0) return true;
   hsa_amd_pointer_info_t si{}, di{};
   si.size = sizeof(si); di.size = sizeof(di);
   if (hsa_amd_pointer_info(const_cast<void*>(src_dev), &si, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS ||
       hsa_amd_pointer_info(dst_host, &di, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS)
+    { g_dma_reason = "pointer info unavailable"; return false; }
+  // both ends must be allocations of the runtime itself (hipMalloc / hipHostMalloc).  A host range that is merely *locked* -- which
+  // is what the runtime's own pageable copies leave behind, possibly mapped read-only -- is left to hipMemcpyAsync.
+  if (si.type != HSA_EXT_POINTER_TYPE_HSA || di.type != HSA_EXT_POINTER_TYPE_HSA) {
+    g_dma_reason = di.type == HSA_EXT_POINTER_TYPE_LOCKED ? "destination is a locked pageable range" : "an end is not a runtime allocation";
     return false;
-  if (si.type != HSA_EXT_POINTER_TYPE_HSA || (di.type != HSA_EXT_POINTER_TYPE_HSA && di.type != HSA_EXT_POINTER_TYPE_LOCKED)) return false;
+  }
+  {
+    const char* base = (const char*)(di.hostBaseAddress ? di.hostBaseAddress : di.agentBaseAddress);
+    if ((const char*)dst_host < base || (const char*)dst_host + n > base + di.sizeInBytes) { g_dma_reason = "destination range leaves its allocation"; return false; }
+  }
+  if ((const char*)src_dev < (const char*)si.agentBaseAddress || (const char*)src_dev + n > (const char*)si.agentBaseAddress + si.sizeInBytes) {
+    g_dma_reason = "source range leaves its allocation";
+    return false;
+  }
   hsa_device_type_t st, dt;
   if (hsa_agent_get_info(si.agentOwner, HSA_AGENT_INFO_DEVICE, &st) != HSA_STATUS_SUCCESS || st != HSA_DEVICE_TYPE_GPU) return false;
   if (hsa_agent_get_info(di.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS || dt != HSA_DEVICE_TYPE_CPU) return false;

@@ -18,6 +18,7 @@ class DmaCopier {
   // Blocking copy of n bytes from device memory to page-locked host memory; the source must be complete (the caller waited for the
   // producing kernels).  Thread-safe: every call uses its own completion signal.  Returns false on failure.
   bool copy_to_host(void* dst_host, const void* src_dev, size_t n) const;
+  static const char* last_reason();   // why the last copy_to_host of this thread declined ("" otherwise)
 
  private:
   bool ok_ = false;

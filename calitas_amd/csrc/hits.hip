@@ -480,7 +480,7 @@ bool hits_supported(uint64_t n_contigs, int max_overlap, int score_lo, int score
 
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
 
-hipError_t hits_set_names(HitsWork** pw, const std::vector<std::string>& names) {
+hipError_t hits_set_names(HitsWork** pw, const std::vector<std::string>& names, hipStream_t stream) {
   if (!*pw) *pw = new HitsWork();
   HitsWork& w = **pw;
   hipError_t e;
@@ -489,9 +489,10 @@ hipError_t hits_set_names(HitsWork** pw, const std::vector<std::string>& names) 
   for (size_t i = 0; i < names.size(); i++) { blob += names[i]; off[i + 1] = (uint32_t)blob.size(); }
   TRY(grow(&w.names, w.names_cap, std::max<size_t>(1, blob.size())));
   TRY(grow(&w.name_off, w.name_off_cap, off.size()));
-  if (!blob.empty()) TRY(hipMemcpy(w.names, blob.data(), blob.size(), hipMemcpyHostToDevice));
-  TRY(hipMemcpy(w.name_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  return hipSuccess;
+  // on the stream of the kernels that read them (a lane's stream is non-blocking: nothing orders it against the null stream)
+  if (!blob.empty()) TRY(hipMemcpyAsync(w.names, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(w.name_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  return hipStreamSynchronize(stream);     // blob / off are locals
 }
 
 // The per-call constants (row pieces, cleared counters), queued on `stream` ahead of everything else of the call so that nothing of

@@ -40,7 +40,7 @@ constexpr uint32_t HITS_FLAG_ROW = 4;           // a row has more padded columns
 bool hits_supported(uint64_t n_contigs, int max_overlap, int score_lo, int score_hi);
 
 // Contig names for the chromosome column; call again after the reference changes.
-hipError_t hits_set_names(HitsWork** work, const std::vector<std::string>& names);
+hipError_t hits_set_names(HitsWork** work, const std::vector<std::string>& names, hipStream_t stream);
 
 // The call's constant row pieces and cleared counters, queued on `stream`: call it at the start of a search_hits call, ahead of the
 // search kernels; hits_run does it itself otherwise.

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
 constexpr int TR_UP = 0, TR_LEFT = 1, TR_DIAG = 2;   // ordered so that max() of (score*4 + code) breaks ties Diag > Left > Up
 constexpr int NEG = -(1 << 20);                      // "minus infinity" that survives a few hundred additions
 constexpr int JOBS_PER_BLOCK = 8;                    // one job per 32-lane half wave
-constexpr int ITEM_STAGE = 64 + 2 * 8 * 16;          // per wave: flush threshold + the most one record iteration can add
+constexpr int ITEM_STAGE = 64 + 3 * 2 * 8 * 16;      // per wave: flush threshold + the most one record iteration can add (x3: per matrix)
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
 constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
 constexpr int TR_STRIDE = 100;                       // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; lane r writes byte 99r + t)
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
   __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
+  __shared__ int s_fin3[JOBS_PER_BLOCK][3][STRIP_MAX_COLS + 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
   // passing candidates are staged per wave and appended to a.items with one global atomic per flush: trace_kernel then
   // runs one lane per *passing* candidate instead of one per candidate slot (4 % of the slots pass at d = 5)
   __shared__ uint64_t s_items[JOBS_PER_BLOCK / 2][ITEM_STAGE];
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
   uint8_t (*tr)[TR_STRIDE] = s_tr[job];
   uint8_t* tb = s_tb[job];
   int* fin = s_fin[job];
+  int (*fin3)[STRIP_MAX_COLS + 1] = s_fin3[job];
 
   uint32_t n_recs = *a.rec_count;
   if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
@@ -414,7 +416,10 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
           tr[r][c] = (uint8_t)(dtr | (utr << 2) | (ltr << 3));
           curD = newD; curL = newL; curU = newU;
           curP = max(max(newD * 4 + TR_DIAG, newL * 4 + TR_LEFT), newU * 4 + TR_UP);
-          if (r == L - 1) fin[c] = curP;
+          if (r == L - 1) {
+            fin[c] = curP;
+            if (sp.per_matrix) { fin3[0][c] = newD; fin3[1][c] = newL; fin3[2][c] = newU; }
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -431,11 +436,19 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
         else          { for (int b = slast; b >= sfirst; b--) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
       }
       int j = 0, P = 0;
+      int pm_score[3] = {0, 0, 0};
+      uint32_t pm_pass = 0;                                            // per-matrix enumeration: bit k = matrix k (Diag, Left, Up) passes
       bool pass = false;
       if (myb >= 0 && !(a.debug_skip & 2u)) {
         j = dir ? (int)(wb - (p0 + myb)) : (int)(p0 + myb - wa) + 1;   // strand-space end column
         P = fin[j - c0];
-        pass = (P >> 2) >= g_min_score;                                // fgbio: best of the three matrices >= minScore
+        if (sp.per_matrix) {                                           // every bottom-row cell >= minScore is an alignment of its own
+#pragma unroll
+          for (int k3 = 0; k3 < 3; k3++) { pm_score[k3] = fin3[k3][j - c0]; if (pm_score[k3] >= g_min_score) pm_pass |= 1u << k3; }
+          pass = pm_pass != 0;
+        } else {
+          pass = (P >> 2) >= g_min_score;                              // best of the three matrices >= minScore
+        }
       }
       const unsigned long long bal = __ballot(pass);
       const uint32_t mine = (uint32_t)(bal >> (threadIdx.x & 32));     // this job's 32 lanes (only lanes 0..15 can pass)
@@ -452,8 +465,20 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
         }
         if (pass && !(a.debug_skip & 128u)) {
           hd->j[r] = (uint16_t)j; hd->best[r] = P;
-          const uint32_t slot = atomicAdd(&s_nitems[wave], 1u);
-          if (slot < (uint32_t)ITEM_STAGE) s_items[wave][slot] = (((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) << 4) | (uint64_t)r;
+          // item = candidate slot | slab index << 4 | start matrix << 40 | (score + 2^21) << 42
+          const uint64_t where = ((((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) & 0xFFFFFFFFFull) << 4) | (uint64_t)r;
+          if (sp.per_matrix) {
+            constexpr int code[3] = {TR_DIAG, TR_LEFT, TR_UP};         // fgbio's order of directions
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) if ((pm_pass >> k3) & 1u) {
+              const uint32_t slot = atomicAdd(&s_nitems[wave], 1u);
+              if (slot < (uint32_t)ITEM_STAGE)
+                s_items[wave][slot] = where | ((uint64_t)code[k3] << 40) | ((uint64_t)(uint32_t)(pm_score[k3] + (1 << 21)) << 42);
+            }
+          } else {
+            const uint32_t slot = atomicAdd(&s_nitems[wave], 1u);
+            if (slot < (uint32_t)ITEM_STAGE) s_items[wave][slot] = where | ((uint64_t)(P & 3) << 40) | ((uint64_t)(uint32_t)((P >> 2) + (1 << 21)) << 42);
+          }
         }
         uint32_t* dtb = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader));
         const uint32_t* stb = reinterpret_cast<const uint32_t*>(tb);
@@ -478,18 +503,19 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
                                           const int (*s_gint)[4], uint32_t* s_ncand, Emit& emit) {
   {
     const int x = (int)(it & 15);
-    const uint8_t* slab = a.slab + (it >> 4) * a.slab_bytes;
+    const uint8_t* slab = a.slab + ((it >> 4) & 0xFFFFFFFFFull) * a.slab_bytes;
     const SlabHeader* hd = reinterpret_cast<const SlabHeader*>(slab);
     if (!((hd->pass_mask >> x) & 1u)) return;
     const uint8_t* tb = slab + sizeof(SlabHeader);
     const uint8_t* tr = tb + ((hd->ntb + 3) & ~3);
     const int L = hd->L, c0 = hd->c0, n = hd->n, gi = hd->guide, stride = hd->stride;
     const bool true_border = hd->true_border != 0;
-    const int j = hd->j[x], best = hd->best[x], gscore = best >> 2;
+    const int j = hd->j[x], gscore = (int)(uint32_t)(it >> 42) - (1 << 21);   // score and start matrix travel in the item
     const int g_npams = s_gint[gi][0], g_maxd = s_gint[gi][1], g_maxp = s_gint[gi][2], g_maxf = s_gint[gi][3];
     atomicAdd(s_ncand, 1u);
 
-    int m = best & 3, i = L, c = j - c0;
+    int m = (int)((it >> 40) & 3u), i = L, c = j - c0;
+    const int m_start = m;
     uint32_t ops[RAW_MAX_OPS / 16] = {0, 0, 0, 0, 0};
     int nops = 0, diffs = 0;
     bool ok = true;
@@ -522,7 +548,8 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
     if (diffs > g_maxd) return;
     RawAln o;
     o.contig = hd->contig; o.window_k = hd->window_k; o.t_start = (uint16_t)(c0 + c + 1); o.t_end_guide = (uint16_t)j;
-    o.dir = hd->dir; o.guide = hd->guide; o.n_ops = (uint8_t)nops; o.pad = 0;
+    o.dir = hd->dir; o.guide = hd->guide; o.n_ops = (uint8_t)nops;
+    o.pad = sp.per_matrix ? (uint8_t)(m_start == TR_DIAG ? 0 : m_start == TR_LEFT ? 1 : 2) : (uint8_t)0;
     uint32_t* ow = reinterpret_cast<uint32_t*>(o.ops);
 #pragma unroll
     for (int w = 0; w < RAW_MAX_OPS / 16; w++) ow[w] = ops[w];

@@ -204,7 +204,8 @@ static int ensure_window_table(calitas_ctx* ctx, const SearchPlan& pl, hipStream
     HIP_TRY(ctx, hipMalloc((void**)&o->d_win, std::max<uint64_t>(1, nw) * sizeof(int2)));
     o->win_cap = nw;
   }
-  HIP_TRY(ctx, hipMemcpy(o->d_win_base, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpyAsync(o->d_win_base, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));   // ordered before the kernel below
+  HIP_TRY(ctx, hipStreamSynchronize(stream));                                                                              // wb is a local
   HIP_TRY(ctx, launch_window_table(o->d_runs, (int64_t)ref.runs.size(), o->d_contigs, o->d_win_base, (int)ref.contigs.size(), nw,
                                    pl.p.window_size, pl.step, o->d_win, stream));
   o->win_W = pl.p.window_size; o->win_step = pl.step;
@@ -233,7 +234,7 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
   aa.sp.max_diffs_filtering = p.max_guide_diffs + p.max_gaps_between_guide_and_pam + p.max_pam_mismatches;   // SGA:249
   aa.sp.match = pl.sc.match; aa.sp.mismatch = pl.sc.mismatch; aa.sp.pam_match = pl.sc.pam_match; aa.sp.pam_mismatch = pl.sc.pam_mismatch;
-  aa.sp.query_gap = pl.sc.query_gap; aa.sp.target_gap = pl.sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score; aa.sp.chrom_index = p.chrom_index;
+  aa.sp.query_gap = pl.sc.query_gap; aa.sp.target_gap = pl.sc.target_gap; aa.sp.eqx_by_score = p.eqx_by_score & 1; aa.sp.per_matrix = (p.eqx_by_score >> 1) & 1; aa.sp.chrom_index = p.chrom_index;
 }
 
 // Device buffers of one lane for this plan (allocation only).
@@ -414,7 +415,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
         for (uint32_t i = lo; i < hi; i++) {
           const RawAln& r = raw[perm[i]];
           const uint64_t list = gh[r.guide].pam5 ? (r.dir == 1 ? 0 : 1) : (r.dir == 0 ? 0 : 1);   // 0 = forward-strand list (SGA:316)
-          const uint64_t key = ((uint64_t)r.window_k << 24) | (list << 23) | ((uint64_t)r.t_end_guide << 5) | (uint64_t)(r.pam + 1);
+          const uint64_t key = ((uint64_t)r.window_k << 24) | (list << 23) | ((uint64_t)r.t_end_guide << 7) | ((uint64_t)r.pad << 5) | (uint64_t)(r.pam + 1);
           keyed.emplace_back(key, perm[i]);
         }
         std::sort(keyed.begin(), keyed.end());
@@ -517,6 +518,7 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
       if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       return CALITAS_OK;
     }
+    if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using hipMemcpyAsync\n", DmaCopier::last_reason());
   }
   hipStream_t cs = (lane->parent && owner->copy_stream) ? owner->copy_stream : lane->stream;
   if (cs != lane->stream) {
@@ -573,7 +575,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
     const int score_lo = pl.gd[0].min_guide_score - iabs(pl.sc.pam_mismatch) * max_pam - worst_gap * (p.max_gaps_between_guide_and_pam + 1);
     if (hits_supported(ref.contigs.size(), p.max_overlap, score_lo, score_hi)) {
       if (lane->hits_names_serial != own->ref_serial) {
-        HIP_TRY(lane, hits_set_names(&lane->hits, ref.names));
+        HIP_TRY(lane, hits_set_names(&lane->hits, ref.names, lane->stream));
         lane->hits_names_serial = own->ref_serial;
       }
       HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};

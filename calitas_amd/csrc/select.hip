@@ -37,7 +37,7 @@ constexpr uint32_t GROUP_MAX = 256;
 struct Derived {
   int32_t start, end, score;
   uint16_t gaps, edits;
-  uint32_t ekey;      // enumeration order inside the window: strand list << 17 | end column << 4 | PAM + 1
+  uint32_t ekey;      // enumeration order inside the window: strand list << 19 | end column << 6 | start matrix << 4 | PAM + 1
   uint32_t widx;      // global window index
 };
 
@@ -61,7 +61,7 @@ __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guid
   d.score = rp->score; d.gaps = (uint16_t)gaps; d.edits = (uint16_t)diffs;
   const uint32_t pam5 = guides[guide].pam5;
   const uint32_t list = pam5 ? (dir == 1 ? 0u : 1u) : (dir == 0 ? 0u : 1u);   // 0 = forward-strand list (SGA:316)
-  d.ekey = (list << 17) | ((uint32_t)rp->t_end_guide << 4) | (uint32_t)(pam + 1);
+  d.ekey = (list << 19) | ((uint32_t)rp->t_end_guide << 6) | ((uint32_t)rp->pad << 4) | (uint32_t)(pam + 1);
   d.widx = guide * windows_per_guide + ((uint32_t)wi - window_lo);
   der[i] = d;
   atomicAdd(&cnt[d.widx], 1u);
@@ -100,7 +100,7 @@ __global__ void filter_kernel(const Derived* ders, const uint32_t* offs, uint32_
       for (uint32_t m = s; m < e; m++) {
         if (taken[m]) continue;
         const uint32_t ek = ders[m].ekey;
-        if ((ek >> 17) != list) continue;
+        if ((ek >> 19) != list) continue;
         const int sc = ders[m].score, gp = ders[m].gaps;
         // score desc, gap bases asc (GA:125-129), then the enumeration order (stable sort)
         const bool first = best < 0;
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, con
           const uint32_t rel = m - s;
           if ((s_taken[rel >> 5] >> (rel & 31)) & 1u) continue;
           const Derived d = ders[m];
-          if ((d.ekey >> 17) != list) continue;
+          if ((d.ekey >> 19) != list) continue;
           const unsigned long long k = ((unsigned long long)(uint32_t)(d.score + (1 << 22)) << 40) | ((unsigned long long)(0xFFFFu - d.gaps) << 24) |
-                                       (unsigned long long)(0x3FFFFu - (d.ekey & 0x1FFFFu)) << 1 | 1ull;
+                                       (unsigned long long)(0xFFFFFu - (d.ekey & 0x7FFFFu)) << 1 | 1ull;
           if (k > bk) { bk = k; bm = m; }
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -197,15 +197,18 @@ __global__ void gather_kernel(const RawAln* raw, const uint32_t* slot, const uin
   if (s == n - 1) counts[0] = d + nk;                  // total survivors
 }
 
+// zero_on: clear the new buffer, ordered on the stream that will use it.  (hipMemset on the null stream is asynchronous to the
+// host and is not ordered against a non-blocking stream: a lane's count_kernel ran ahead of it and scatter_kernel then
+// indexed with negative slots -- DESIGN.md 4.7.)
 template <typename T>
-hipError_t grow(T** p, size_t& cap, size_t need, bool zero = false) {
+hipError_t grow(T** p, size_t& cap, size_t need, hipStream_t zero_on = nullptr, bool zero = false) {
   if (need <= cap) return hipSuccess;
   (void)hipFree(*p); *p = nullptr; cap = 0;
   need += need / 8;
   hipError_t e = hipMalloc((void**)p, need * sizeof(T));
   if (e != hipSuccess) return e;
   cap = need;
-  return zero ? hipMemset(*p, 0, need * sizeof(T)) : hipSuccess;
+  return zero ? hipMemsetAsync(*p, 0, need * sizeof(T), zero_on) : hipSuccess;
 }
 
 }  // namespace
@@ -247,11 +250,11 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   const size_t n = n_raw;
   const size_t nw = (size_t)windows_per_guide * (size_t)n_guides;
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-  if (!w.counts) { TRY(hipMalloc((void**)&w.counts, 3 * sizeof(uint32_t))); TRY(hipMemset(w.counts, 0, 3 * sizeof(uint32_t))); }
+  if (!w.counts) { TRY(hipMalloc((void**)&w.counts, 3 * sizeof(uint32_t))); TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream)); }
   *d_final = nullptr; *d_counts = w.counts;
   if (n == 0) { TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream)); return hipSuccess; }
   const size_t cnt_cap_before = w.cnt_cap;
-  TRY(grow(&w.cnt, w.cnt_cap, nw + 1, true));
+  TRY(grow(&w.cnt, w.cnt_cap, nw + 1, stream, true));
   if (w.cnt_dirty && w.cnt_cap == cnt_cap_before) TRY(hipMemsetAsync(w.cnt, 0, w.cnt_cap * sizeof(uint32_t), stream));
   TRY(grow(&w.offs, w.offs_cap, nw + 1)); TRY(grow(&w.kept, w.kept_cap, n)); TRY(grow(&w.koffs, w.koffs_cap, n));
   TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.ders, w.ders_cap, n)); TRY(grow(&w.slot, w.slot_cap, n)); TRY(grow(&w.out_idx, w.out_idx_cap, n));

@@ -64,7 +64,11 @@ typedef struct {
   int32_t genome_gap_net_cost;             /* -b  default -122 */
   int32_t guide_gap_net_cost;              /* -B  default -121 */
   int32_t chrom_index;                     /* -c  contig index, <0 => all */
-  int32_t eqx_by_score;                    /* 0: '='/'X' by IUPAC compatibility (default); 1: by pairing score > 0 */
+  int32_t eqx_by_score;                    /* bit flags for the two readings of fgbio 2.0.0 that the reference's own tests do not
+                                            * pin; 0 = the defaults.
+                                            * bit 0 (1): '=' / 'X' by pairing score > 0 instead of IUPAC compatibility (U2; differs for a target N)
+                                            * bit 1 (2): one alignment per bottom-row matrix cell (Diag, Left, Up) that reaches minScore
+                                            *            instead of one per end column from the best of the three (U1) */
   int32_t max_variants;                    /* -V  only echoed into aligner_other_parameters */
 } calitas_params_t;
 

@@ -27,7 +27,7 @@ def C():
 def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
     pk = dict(window_size=kw.get("window_size", 1000), max_guide_diffs=kw.get("d", 5), max_pam_mismatches=kw.get("p", 1),
               max_gaps_between_guide_and_pam=kw.get("g", 3), max_total_diffs=kw.get("D"), max_overlap=kw.get("O", 10),
-              eqx_by_score=1 if kw.get("switches", 0) & 2 else 0)
+              eqx_by_score=(1 if kw.get("switches", 0) & 2 else 0) | (2 if kw.get("switches", 0) & 1 else 0))   # oracle bits -> ABI bits
     for k in ("guide_mismatch_net_cost", "pam_mismatch_net_cost", "genome_gap_net_cost", "guide_gap_net_cost"):
         if k in kw:
             pk[k] = kw[k]
@@ -132,6 +132,10 @@ CONFIGS = [
     ("eqx-by-score", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=2, switches=2)),
     ("costs", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=2, guide_mismatch_net_cost=-100, pam_mismatch_net_cost=-200,
                                                   genome_gap_net_cost=-104, guide_gap_net_cost=-102)),
+    ("per-matrix", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=2, switches=1)),
+    ("per-matrix-wide-overlap", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=3, O=100, switches=1)),
+    ("per-matrix-eqx-pamless", "GTGACTTGAAGTCTCAGTATA", (), dict(d=5, O=40, switches=3)),
+    ("per-matrix-5prime", "tttvAACCAACCAACCGGTTACGT", (), dict(d=4, p=1, g=2, O=60, switches=1)),
     ("short-guide-12", "GCAGTAACCTGAnrg", (), dict(d=2, p=1, g=1)),
     ("long-guide-32", "CTTGCCCCACAGGGCAGTAACGGTTCAATGCA", (), dict(d=6)),               # the scan's 32 rows, PAM-less
     ("long-pam-8", "CTTGCCCCACAGGGCAGTAAnnagaawn", (), dict(d=4, p=2, g=2)),
@@ -241,6 +245,29 @@ def test_chunked_search_hits_equals_one_pass(C, tmp_path, monkeypatch, chunks):
             assert n1 > 20 and (n1, one) == (n2, cut) == (n3, again)
     finally:
         ctx.close()
+
+
+def test_first_call_of_fresh_lanes(C, tmp_path, monkeypatch):
+    """The first chunked call of a fresh context is the one that creates and clears every lane's scratch.  That clearing has to
+    be ordered on the lane's own (non-blocking) stream: a null-stream hipMemset once let count_kernel run ahead of it, which
+    regrouped records at random and could index out of bounds.  PAM-less, d = 6 on a 14-mer: every window is crowded."""
+    guide = "ACATTCGTCAGTCG"
+    fa = synth_fasta(tmp_path, 71, [guide + "nrg"], lengths=(24000, 20000))
+    params = C.make_params(window_size=1000, max_guide_diffs=6, max_pam_mismatches=2, max_gaps_between_guide_and_pam=4, max_overlap=29)
+    want = None
+    for _ in range(12):
+        ctx = C.Context(0)
+        ctx.set_reference_fasta(fa)
+        try:
+            monkeypatch.setenv("CALITAS_CHUNKS", "2")
+            got = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            if want is None:
+                monkeypatch.setenv("CALITAS_CHUNKS", "1")
+                want = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+                assert want[1] > 1000
+            assert got == want
+        finally:
+            ctx.close()
 
 
 def test_host_tail_of_search_hits(C, tmp_path, monkeypatch):

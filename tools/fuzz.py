@@ -47,9 +47,17 @@ def run(iters, seed):
                                         sites_per_guide=int(rng.integers(5, 60)), softmask=float(rng.random() * 0.5), tandem_frac=float(rng.random() * (0.4 if rng.random() < 0.2 else 0.05)),
                                         n_run_ends=int(rng.integers(0, 200)), n_block=int(rng.integers(0, 1500)), step_hint=W - (len(guide) + d + g - 1))
         fa = write_fasta(os.path.join(tmp, "f.fa"), [(n, s.tobytes().decode()) for n, s in zip(names, seqs)])
-        okw = dict(window_size=W, d=d, p=p, g=g, D=-1 if D is None else D, O=Ov, threads=8)
+        sw = int(rng.choice([0, 0, 0, 1, 2, 3]))         # the two unpinned readings of fgbio (oracle bits: 1 = per matrix, 2 = '='/'X' by score)
+        okw = dict(window_size=W, d=d, p=p, g=g, D=-1 if D is None else D, O=Ov, threads=8, switches=sw)
         for k, o in (("guide_mismatch_net_cost", "m"), ("pam_mismatch_net_cost", "M"), ("genome_gap_net_cost", "b"), ("guide_gap_net_cost", "B")):
             if k in costs: okw[o] = costs[k]
+        if os.environ.get("CALITAS_FUZZ_ONLY") and it != int(os.environ["CALITAS_FUZZ_ONLY"]):
+            continue                                      # reproduce one iteration of a seed
+        if os.environ.get("CALITAS_FUZZ_SW"):
+            sw = int(os.environ["CALITAS_FUZZ_SW"]); okw["switches"] = sw
+        if os.environ.get("CALITAS_FUZZ_LOG"):
+            with open(os.environ["CALITAS_FUZZ_LOG"], "a") as lf:
+                lf.write("iter %d guide %s aux %s d%d p%d g%d O%d W%d D%s sw%d costs %s spec %s\n" % (it, guide, aux, d, p, g, Ov, W, D, sw, costs, spec))
         try:
             _, want, _ = O.search_reference(fa, guide, "a", aux=aux, **okw)
         except RuntimeError as e:
@@ -58,7 +66,7 @@ def run(iters, seed):
         ctx.set_reference_fasta(fa)
         try:
             params = C.make_params(window_size=W, max_guide_diffs=d, max_pam_mismatches=p, max_gaps_between_guide_and_pam=g, max_total_diffs=D,
-                                   max_overlap=Ov, **costs)
+                                   max_overlap=Ov, eqx_by_score=(1 if sw & 2 else 0) | (2 if sw & 1 else 0), **costs)
             res = {}
             for chunks in ("1", "2"):
                 os.environ["CALITAS_CHUNKS"] = chunks
@@ -74,8 +82,8 @@ def run(iters, seed):
         declined = [v for v in res.values() if isinstance(v, str)]
         if not ok:
             bad += 1
-            print("MISMATCH iter %d guide %s aux %s d%d p%d g%d O%d W%d D%s costs %s: oracle %d rows, product %s" % (
-                it, guide, aux, d, p, g, Ov, W, D, costs, len(w), {k: (len(v) if not isinstance(v, str) else v) for k, v in res.items()}), flush=True)
+            print("MISMATCH iter %d guide %s aux %s d%d p%d g%d O%d W%d D%s sw%d costs %s: oracle %d rows, product %s" % (
+                it, guide, aux, d, p, g, Ov, W, D, sw, costs, len(w), {k: (len(v) if not isinstance(v, str) else v) for k, v in res.items()}), flush=True)
         elif declined and it < 400:
             print("iter %d guide %s d%d: %s" % (it, guide, d, declined[0][:100]), flush=True)
     print("fuzz: %d iterations, %d mismatches, %.1f s" % (iters, bad, time.time() - t0))
