@@ -253,7 +253,9 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
 constexpr int TR_UP = 0, TR_LEFT = 1, TR_DIAG = 2;   // ordered so that max() of (score*4 + code) breaks ties Diag > Left > Up
 constexpr int NEG = -(1 << 20);                      // "minus infinity" that survives a few hundred additions
 constexpr int JOBS_PER_BLOCK = 8;                    // one job per 32-lane half wave
-constexpr int ITEM_STAGE = 64 + 3 * 2 * 8 * 16;      // per wave: flush threshold + the most one record iteration can add (x3: per matrix)
+// per wave: flush threshold + the most one record iteration can add (2 jobs x 8 windows x 16 candidates; x 3 when every matrix
+// of a cell is an alignment of its own)
+template <bool PM> constexpr int ITEM_STAGE = 64 + (PM ? 3 : 1) * 2 * 8 * 16;
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
 constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
 constexpr int TR_STRIDE = 100;                       // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; lane r writes byte 99r + t)
@@ -284,15 +286,19 @@ __device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
   return m;
 }
 
+// PM: the per-matrix reading of fgbio's enumeration.  A template parameter, not a run-time branch: its LDS
+// (s_fin3, the larger item stage) would cost the default reading a workgroup per CU (43 -> 66 KB: 153 -> 243 us per launch).
+template <bool PM>
 __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
+  constexpr int STAGE = ITEM_STAGE<PM>;
   // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the 32 lanes over the banks
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
   __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
-  __shared__ int s_fin3[JOBS_PER_BLOCK][3][STRIP_MAX_COLS + 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
+  __shared__ int s_fin3[PM ? JOBS_PER_BLOCK : 1][3][STRIP_MAX_COLS + 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
   // passing candidates are staged per wave and appended to a.items with one global atomic per flush: trace_kernel then
   // runs one lane per *passing* candidate instead of one per candidate slot (4 % of the slots pass at d = 5)
-  __shared__ uint64_t s_items[JOBS_PER_BLOCK / 2][ITEM_STAGE];
+  __shared__ uint64_t s_items[JOBS_PER_BLOCK / 2][STAGE];
   __shared__ uint32_t s_nitems[JOBS_PER_BLOCK / 2];
   const int job = threadIdx.x >> 5;
   const int r = threadIdx.x & 31;           // lane within the job = query row r+1
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
   uint8_t (*tr)[TR_STRIDE] = s_tr[job];
   uint8_t* tb = s_tb[job];
   int* fin = s_fin[job];
-  int (*fin3)[STRIP_MAX_COLS + 1] = s_fin3[job];
+  int (*fin3)[STRIP_MAX_COLS + 1] = s_fin3[PM ? job : 0];
 
   uint32_t n_recs = *a.rec_count;
   if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
           curP = max(max(newD * 4 + TR_DIAG, newL * 4 + TR_LEFT), newU * 4 + TR_UP);
           if (r == L - 1) {
             fin[c] = curP;
-            if (sp.per_matrix) { fin3[0][c] = newD; fin3[1][c] = newL; fin3[2][c] = newU; }
+            if (PM) { fin3[0][c] = newD; fin3[1][c] = newL; fin3[2][c] = newU; }
           }
         }
       }
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
       if (myb >= 0 && !(a.debug_skip & 2u)) {
         j = dir ? (int)(wb - (p0 + myb)) : (int)(p0 + myb - wa) + 1;   // strand-space end column
         P = fin[j - c0];
-        if (sp.per_matrix) {                                           // every bottom-row cell >= minScore is an alignment of its own
+        if (PM) {                                                      // every bottom-row cell >= minScore is an alignment of its own
 #pragma unroll
           for (int k3 = 0; k3 < 3; k3++) { pm_score[k3] = fin3[k3][j - c0]; if (pm_score[k3] >= g_min_score) pm_pass |= 1u << k3; }
           pass = pm_pass != 0;
@@ -467,17 +473,17 @@ __global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
           hd->j[r] = (uint16_t)j; hd->best[r] = P;
           // item = candidate slot | slab index << 4 | start matrix << 40 | (score + 2^21) << 42
           const uint64_t where = ((((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) & 0xFFFFFFFFFull) << 4) | (uint64_t)r;
-          if (sp.per_matrix) {
+          if (PM) {
             constexpr int code[3] = {TR_DIAG, TR_LEFT, TR_UP};         // fgbio's order of directions
 #pragma unroll
             for (int k3 = 0; k3 < 3; k3++) if ((pm_pass >> k3) & 1u) {
               const uint32_t slot = atomicAdd(&s_nitems[wave], 1u);
-              if (slot < (uint32_t)ITEM_STAGE)
+              if (slot < (uint32_t)STAGE)
                 s_items[wave][slot] = where | ((uint64_t)code[k3] << 40) | ((uint64_t)(uint32_t)(pm_score[k3] + (1 << 21)) << 42);
             }
           } else {
             const uint32_t slot = atomicAdd(&s_nitems[wave], 1u);
-            if (slot < (uint32_t)ITEM_STAGE) s_items[wave][slot] = where | ((uint64_t)(P & 3) << 40) | ((uint64_t)(uint32_t)((P >> 2) + (1 << 21)) << 42);
+            if (slot < (uint32_t)STAGE) s_items[wave][slot] = where | ((uint64_t)(P & 3) << 40) | ((uint64_t)(uint32_t)((P >> 2) + (1 << 21)) << 42);
           }
         }
         uint32_t* dtb = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader));
@@ -697,7 +703,8 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
 }
 
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(align_kernel, dim3(n_blocks), dim3(256), 0, stream, a);
+  if (a.sp.per_matrix) hipLaunchKernelGGL(align_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(align_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
