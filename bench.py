@@ -8,7 +8,8 @@ reference: scan kernel + aligner kernel + copy-back + per-window filter + remove
 except writing hits.txt to disk).  The packed reference is resident in HBM before the timed region.
 
 N>1: one process per GPU (torch.distributed, RCCL for the barrier).  Default partition = guides (each rank holds the
-genome and runs its own guide of the 96-guide set per step; BASELINE config 4) -> weak scaling, no data-path
+genome and runs one guide pass per step -- guide #0 on every rank, so the work per GPU is that of the N=1 line;
+--distinct-guides draws rank r's guide from the 96-guide set of BASELINE config 4) -> weak scaling, no data-path
 collective.  --shard contigs partitions the contigs of ONE guide's pass instead (strong scaling, host-side gather).
 
 value = candidate loci examined per second = 2 strands x reference bases x guide-passes / wall time.
@@ -144,6 +145,7 @@ def main():
                     help="guides each rank runs per step through calitas_search_hits_batch (BASELINE config 4 shape: 96 guides / 8 GPUs = 12); "
                          "the default 1 is the BASELINE metric's single-guide pass")
     ap.add_argument("--same-guide", action="store_true", help="with --guides-per-step: every guide of the batch is guide #0 (isolates the pipelining gain)")
+    ap.add_argument("--distinct-guides", action="store_true", help="N>1: rank r runs guide #r of the 96-guide set instead of guide #0 on every rank")
     ap.add_argument("--two-stage", action="store_true", help="calitas_search + calitas_hits_tsv (host rows) instead of the fused calitas_search_hits")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and gloo replaces RCCL (not a measurement)")
@@ -190,7 +192,11 @@ def main():
     else:
         mine = None
         gps = max(1, args.guides_per_step)
-        my_guides = [GUIDE0 if args.same_guide else all_guides[(rank * gps + i) % len(all_guides)] for i in range(gps)]
+        # weak scaling keeps the work per GPU fixed: every rank runs the pass of the N=1 line (guide #0).  The 96-guide set of
+        # BASELINE config 4 (its random 20-mers yield ~3x the rows of guide #0 on this genome, so a rank's step is copy-back
+        # bound and takes longer) is drawn with --distinct-guides, or by a batch (--guides-per-step > 1) without --same-guide.
+        distinct = args.distinct_guides or (gps > 1 and not args.same_guide)
+        my_guides = [all_guides[(rank * gps + i) % len(all_guides)] if distinct else GUIDE0 for i in range(gps)]
         guide_passes_per_step = world * gps   # every rank runs its own guide(s) over the whole genome
         bases_per_step_total = sum(lengths) * world * gps
 
