@@ -27,7 +27,7 @@ struct calitas_ctx {
   bool has_ref = false;
   // device state
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[8] = {};            // [0..3] scan start / scan end / align+trace end / filter end, [4..5] row kernels, [6..7] text copy
   uint32_t* d_codes = nullptr;
   uint32_t* d_mask = nullptr;
   Run* d_runs = nullptr;

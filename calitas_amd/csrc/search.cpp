@@ -257,6 +257,14 @@ static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t
   return CALITAS_OK;
 }
 
+// Kernel durations of the last search on this context, from its events (all of them complete).
+static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); tm.scan_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); tm.align_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); tm.gpu_total_ms = ms;
+}
+
 // calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
 // (dev->valid), and *out stays NULL.  prelaunched: the scan stage of this lane was queued by the caller on another stream
 // and ctx->stream already waits for it; an overflow then fails the call instead of retrying.
@@ -322,6 +330,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     const uint32_t* d_cnt = nullptr;
     HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
                             p.max_overlap, ctx->stream, &d_final, &d_cnt));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
     select_done(ctx->select);
@@ -340,12 +349,11 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_raw, ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost, ctx->stream));
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); tm.scan_kernel_ms = ms;
-  (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); tm.align_kernel_ms = ms;
-  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); tm.gpu_total_ms = ms;
+  if (!gpu_select) {              // (the device filter recorded ev[3] and waited above)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
+  }
+  if (!(gpu_select && dev)) kernel_times(ctx, tm);   // calitas_search_hits asks later, while its row kernels run
   tm.scan_records = n_rec;
   tm.raw_alignments = n_raw;
 
@@ -525,17 +533,17 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
     HIP_TRY(lane, hipEventRecord(lane->rows_ready, lane->stream));
     std::lock_guard<std::mutex> lk(*copy_mu);
     HIP_TRY(lane, hipStreamWaitEvent(cs, lane->rows_ready, 0));
-    HIP_TRY(lane, hipEventRecord(lane->ev[2], cs));
+    HIP_TRY(lane, hipEventRecord(lane->ev[6], cs));
     HIP_TRY(lane, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cs));
-    HIP_TRY(lane, hipEventRecord(lane->ev[3], cs));
+    HIP_TRY(lane, hipEventRecord(lane->ev[7], cs));
   } else {
-    HIP_TRY(lane, hipEventRecord(lane->ev[2], cs));
+    HIP_TRY(lane, hipEventRecord(lane->ev[6], cs));
     HIP_TRY(lane, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cs));
-    HIP_TRY(lane, hipEventRecord(lane->ev[3], cs));
+    HIP_TRY(lane, hipEventRecord(lane->ev[7], cs));
   }
-  HIP_TRY(lane, calitas_spin_sync(lane->ev[3]));
+  HIP_TRY(lane, calitas_spin_sync(lane->ev[7]));
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, lane->ev[2], lane->ev[3]);
+  (void)hipEventElapsedTime(&ms, lane->ev[6], lane->ev[7]);
   if (ms_out) *ms_out = ms;
   return CALITAS_OK;
 }
@@ -553,8 +561,10 @@ struct LaneText {
 };
 
 // One lane from the scan stage (queued here, or already queued by the caller) to its finished rows.
+// hits_prepared: the caller queued hits_prepare on the lane's stream already -- *before* the stream's wait for the scan, so that
+// the constants are in place while the scan runs instead of sitting between the end of the scan and align_kernel.
 static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, const std::string& guide_id,
-                     const std::string& version, const std::string& stamp, LaneText& lt) {
+                     const std::string& version, const std::string& stamp, LaneText& lt, bool hits_prepared = false) {
   calitas_ctx* own = ref_owner(lane);
   const PackedRef& ref = own->ref;
   const calitas_params_t& p = pl.p;
@@ -562,7 +572,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   DeviceSel dev;
   calitas_aln_t* alns = nullptr;
   uint64_t n_alns = 0;
-  if (!std::getenv("CALITAS_HOST_HITS")) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // ahead of the lane's kernels, off the critical path
+  if (!hits_prepared && !std::getenv("CALITAS_HOST_HITS")) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // ahead of the lane's kernels
   int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched);
   if (rc) return rc;
   lt.tm = lane->timing;
@@ -580,10 +590,11 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       }
       HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
       HitsResult res{};
-      HIP_TRY(lane, hipEventRecord(lane->ev[0], lane->stream));
+      HIP_TRY(lane, hipEventRecord(lane->ev[4], lane->stream));
       HIP_TRY(lane, hits_run(&lane->hits, hr, dev.d_final, dev.n_sel, lane->d_guides, own->d_win_base, own->d_win, rs, p.max_overlap, score_hi,
                              pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, lane->stream, &res));
-      HIP_TRY(lane, hipEventRecord(lane->ev[1], lane->stream));
+      HIP_TRY(lane, hipEventRecord(lane->ev[5], lane->stream));
+      kernel_times(lane, lt.tm);          // while out_kernel runs
       if (res.flags == 0) {
         lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows;
         return CALITAS_OK;
@@ -594,6 +605,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   // host tail: the same stages as calitas_hits_tsv (one lane at a time: they share the owner's worker pool)
   std::lock_guard<std::mutex> host_lock(own->host_mu);
   if (dev.valid) {
+    kernel_times(lane, lt.tm);
     rc = convert_selected(lane, dev.d_final, dev.n_sel, pl.gh, p, pl.step, &alns);
     if (rc) return rc;
     n_alns = dev.n_sel;
@@ -726,7 +738,7 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
     int r = text_to_host(ctx, lane, text + hlen + offset, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
     if (r) return r;
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, lane->ev[0], lane->ev[1]); lt.tm.hits_kernel_ms = ms;   // recorded around hits_run by lane_rows
+    (void)hipEventElapsedTime(&ms, lane->ev[4], lane->ev[5]); lt.tm.hits_kernel_ms = ms;   // recorded around hits_run by lane_rows
     return CALITAS_OK;
   };
 
@@ -752,7 +764,9 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
     // when its scan is done, so the tail of chunk c runs while chunk c+1 is still being scanned
     rc = ensure_window_table(ctx, pl, ctx->scan_stream);
     if (rc) return rc;
+    const bool device_rows = !std::getenv("CALITAS_HOST_HITS");
     for (size_t c = 0; c < K; c++) {
+      if (device_rows) HIP_TRY(ctx, hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream));   // before the wait below is queued
       rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);
       if (rc) { ctx->err = lanes[c]->err; break; }
       HIP_TRY(ctx, hipEventRecord(lanes[c]->scan_done, ctx->scan_stream));
@@ -773,7 +787,7 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
       {
         (void)hipSetDevice(ctx->device);
         LaneText& lt = parts[c];
-        lt.rc = lane_rows(lanes[c], plans[c], true, rs, guide_id, version, stamp, lt);
+        lt.rc = lane_rows(lanes[c], plans[c], true, rs, guide_id, version, stamp, lt, device_rows);
         size_t offset = 0;
         bool ok = lt.rc == CALITAS_OK;
         {
@@ -891,6 +905,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   if (rc) return rc;
   const PackedRef& ref = ctx->ref;
   std::mutex scan_mu, copy_mu;
+  const bool device_rows = !std::getenv("CALITAS_HOST_HITS");
   std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
   std::vector<calitas_timing_t> tms((size_t)n_guides);
   std::vector<std::thread> threads;
@@ -906,6 +921,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
           {
             // the previous guide of this lane is completely done (its text was copied before the loop went on), so the
             // lane's buffers are free for this scan
+            if (device_rows) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // before the wait below is queued
             std::lock_guard<std::mutex> lk(scan_mu);
             int r = launch_scan_stage(lane, pl, ctx->scan_stream);
             if (r) return r;
@@ -913,7 +929,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
             HIP_TRY(lane, hipStreamWaitEvent(lane->stream, lane->scan_done, 0));
           }
           LaneText lt;
-          int r = lane_rows(lane, pl, true, rs, gid, version, stamp, lt);
+          int r = lane_rows(lane, pl, true, rs, gid, version, stamp, lt, device_rows);
           if (r) return r;
           const size_t hlen = rs.header.size(), total = hlen + (size_t)lt.bytes;
           char* text = (char*)calitas_out_alloc_pinned(total + 1);
