@@ -127,10 +127,13 @@ int calitas_create(int device_id, calitas_ctx** out) {
       delete c;
       return fail(nullptr, CALITAS_EHIP, "device init failed: " + m);
     }
-    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    // [0..5] sit between kernels of one device: a device-scope release is enough (the default, release to system, made whatever
+    // waited for the end of a scan wait ~90 us longer); [6..7] bracket the text copy the host waits for
+    for (int i = 0; i < 8; i++) (void)hipEventCreateWithFlags(&c->ev[i], i < 6 ? hipEventReleaseToDevice : hipEventDefault);
     (void)hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t));
     (void)hipHostMalloc((void**)&c->h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault);
     (void)hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES);
+    (void)hipHostMalloc((void**)&c->h_guides, sizeof(GuideDev) * MAX_GUIDES, hipHostMallocDefault);
     // The aligner kernel's wavefront relies on the DPP wave shift; verify it on this device once.
     int* d = nullptr;
     int* h = nullptr;                       // page-locked: no copy of this library lands in pageable memory
@@ -141,7 +144,7 @@ int calitas_create(int device_id, calitas_ctx** out) {
     (void)hipFree(d);
     for (int i = 1; ok && i < 64; i++) ok = h[i] == (i - 1) * 7 + 3;
     if (h) (void)hipHostFree(h);
-    if (!ok || !c->d_counters || !c->h_counters || !c->d_guides) {
+    if (!ok || !c->d_counters || !c->h_counters || !c->d_guides || !c->h_guides) {
       calitas_destroy(c);
       return fail(nullptr, CALITAS_EHIP, "device self-test failed (DPP wave_shr / allocation)");
     }
@@ -166,6 +169,7 @@ void calitas_destroy(calitas_ctx* c) {
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);
     if (c->rows_ready) (void)hipEventDestroy(c->rows_ready);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_guides) (void)hipHostFree(c->h_guides);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);

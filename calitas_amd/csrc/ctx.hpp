@@ -39,6 +39,7 @@ struct calitas_ctx {
   uint64_t win_cap = 0;
   int win_W = 0, win_step = 0;
   GuideDev* d_guides = nullptr;
+  GuideDev* h_guides = nullptr;     // pinned: the source of the upload (an async copy from pageable memory waits for the stream to drain)
   ScanRecord* d_recs = nullptr;
   RawAln* d_raw = nullptr;
   uint32_t* d_counters = nullptr;   // [0] scan records, [1] raw alignments, [2] anomalies, [3] passing candidates (items), [4] candidates
@@ -60,6 +61,7 @@ struct calitas_ctx {
   hipStream_t scan_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // parent: the text copies of all lanes
   hipEvent_t scan_done = nullptr;   // lane: recorded on the parent's scan stream after this lane's scan
+  hipEvent_t t_scan0 = nullptr, t_scan1 = nullptr;   // the two events that bracket the last scan kernel (ev[0] / ev[1], or scan_done events)
   hipEvent_t rows_ready = nullptr;  // lane: recorded on its stream after its row kernels
   uint64_t last_text_bytes = 0;
   std::mutex host_mu;               // host stages of concurrent lanes take turns on the worker pool

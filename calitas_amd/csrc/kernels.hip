@@ -16,6 +16,8 @@
 //                Only columns [j - span - 1, j] are filled: by the locality argument in DESIGN.md this reproduces
 //                the value and the trace of every cell on the optimal path of a candidate (L, j) bit for bit.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "refpack.hpp"
@@ -252,7 +254,9 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
 
 constexpr int TR_UP = 0, TR_LEFT = 1, TR_DIAG = 2;   // ordered so that max() of (score*4 + code) breaks ties Diag > Left > Up
 constexpr int NEG = -(1 << 20);                      // "minus infinity" that survives a few hundred additions
-constexpr int JOBS_PER_BLOCK = 8;                    // one job per 32-lane half wave
+// one job per 32-lane half wave; one wave per workgroup: 10 KB of LDS, which fits on a CU next to four scan workgroups (37 KB each
+// of 160 KB) -- a 256-thread workgroup (40 KB) had to wait until the scan of the next range let go of a CU
+constexpr int JOBS_PER_BLOCK = 2;
 // per wave: flush threshold + the most one record iteration can add (2 jobs x 8 windows x 16 candidates; x 3 when every matrix
 // of a cell is an alignment of its own)
 template <bool PM> constexpr int ITEM_STAGE = 64 + (PM ? 3 : 1) * 2 * 8 * 16;
@@ -289,7 +293,7 @@ __device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
 // PM: the per-matrix reading of fgbio's enumeration.  A template parameter, not a run-time branch: its LDS
 // (s_fin3, the larger item stage) would cost the default reading a workgroup per CU (43 -> 66 KB: 153 -> 243 us per launch).
 template <bool PM>
-__global__ __launch_bounds__(256) void align_kernel(AlignArgs a) {
+__global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a) {
   constexpr int STAGE = ITEM_STAGE<PM>;
   // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the 32 lanes over the banks
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
@@ -689,27 +693,34 @@ __global__ void dpp_selftest_kernel(int* out) {
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 
-hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream) {
-  if (n_tiles == 0) return hipSuccess;
+// start / stop (optional): events attached to the dispatch itself -- no marker packets before and after the kernel on the stream.
+hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  if (n_tiles == 0) {
+    if (start) { hipError_t e = hipEventRecord(start, stream); if (e != hipSuccess) return e; }
+    return stop ? hipEventRecord(stop, stream) : hipSuccess;
+  }
   dim3 grid(n_tiles), block(LANES_PER_TILE);
+  constexpr unsigned pad = 0;
   switch (chunk) {
-    case 64:  hipLaunchKernelGGL(scan_kernel<64>, grid, block, 0, stream, a); break;
-    case 128: hipLaunchKernelGGL(scan_kernel<128>, grid, block, 0, stream, a); break;
-    case 256: hipLaunchKernelGGL(scan_kernel<256>, grid, block, 0, stream, a); break;
-    case 512: hipLaunchKernelGGL(scan_kernel<512>, grid, block, 0, stream, a); break;
+    case 64:  hipExtLaunchKernelGGL(scan_kernel<64>, grid, block, pad, stream, start, stop, 0, a); break;
+    case 128: hipExtLaunchKernelGGL(scan_kernel<128>, grid, block, pad, stream, start, stop, 0, a); break;
+    case 256: hipExtLaunchKernelGGL(scan_kernel<256>, grid, block, pad, stream, start, stop, 0, a); break;
+    case 512: hipExtLaunchKernelGGL(scan_kernel<512>, grid, block, pad, stream, start, stop, 0, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
-  if (a.sp.per_matrix) hipLaunchKernelGGL(align_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(align_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, a);
+  // n_blocks counts 256-lane units (8 jobs)
+  const dim3 grid(n_blocks * (8 / JOBS_PER_BLOCK)), block(32 * JOBS_PER_BLOCK);
+  if (a.sp.per_matrix) hipLaunchKernelGGL(align_kernel<true>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(align_kernel<false>, grid, block, 0, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(trace_kernel, dim3(n_blocks), dim3(256), 0, stream, a);
+hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop) {
+  hipExtLaunchKernelGGL(trace_kernel, dim3(n_blocks), dim3(256), 0, stream, nullptr, stop, 0, a);
   return hipGetLastError();
 }
 

@@ -50,9 +50,9 @@ struct AlignArgs {
   SearchDev sp;
 };
 
-hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream);
+hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
-hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop = nullptr);
 hipError_t launch_window_table(const Run* runs, int64_t n_runs, const ContigInfo* contigs, const uint64_t* win_base, int n_contigs,
                                uint64_t n_windows, int W, int step, int2* out, hipStream_t stream);
 hipError_t launch_dpp_selftest(int* out, hipStream_t stream);

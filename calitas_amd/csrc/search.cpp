@@ -244,25 +244,31 @@ static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
                         std::max<uint32_t>(ctx->item_cap, (uint32_t)(2 * want)));
 }
 
-// Guides, cleared counters and the scan kernel of this lane, queued on `stream` (the lane's own, or the shared scan
-// stream of a chunked search); ev[0] / ev[1] bracket the kernel.
+// Guides, cleared counters and the scan kernel of this lane, queued on `stream` (the lane's own, or the shared scan stream of a
+// chunked search).  t_scan0 / t_scan1 bracket the kernel: ev[0], and the lane's scan_done (the event its stream waits for) or ev[1].
+// Both ride on the dispatch itself (hipExtLaunchKernel): as marker packets of their own on the lowest-priority stream they delayed
+// whatever waited for the end of the scan by 60-90 us.
+// (Queuing the inputs of all ranges first and their scans back to back was tried as well: no gain, the pause between two scans is
+// where the previous range's tail gets onto the CUs.)
 static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides, hipMemcpyHostToDevice, stream));
+  // from the context's pinned copy (an async copy from pageable memory may wait for the stream to drain)
+  std::memcpy(ctx->h_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, ctx->h_guides, sizeof(GuideDev) * pl.n_guides, hipMemcpyHostToDevice, stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), stream));
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(ctx, pl, sa, aa);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-  HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+  ctx->t_scan0 = ctx->ev[0];
+  ctx->t_scan1 = ctx->scan_done ? ctx->scan_done : ctx->ev[1];
+  HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream, ctx->t_scan0, ctx->t_scan1));   // the events ride on the dispatch
   return CALITAS_OK;
 }
 
 // Kernel durations of the last search on this context, from its events (all of them complete).
 static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); tm.scan_kernel_ms = ms;
-  (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); tm.align_kernel_ms = ms;
-  (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); tm.gpu_total_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->t_scan0, ctx->t_scan1); tm.scan_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->t_scan1, ctx->ev[2]); tm.align_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, ctx->t_scan0, ctx->ev[3]); tm.gpu_total_ms = ms;
 }
 
 // calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
@@ -294,8 +300,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     ScanArgs sa; AlignArgs aa;
     fill_kernel_args(ctx, pl, sa, aa);
     HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
-    HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream, ctx->ev[2]));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
@@ -638,12 +643,13 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
     calitas_ctx* c = new calitas_ctx();
     c->device = ctx->device; c->parent = ctx;
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) == hipSuccess;
-    for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->scan_done, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->rows_ready, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 8; i++) ok = ok && hipEventCreateWithFlags(&c->ev[i], i < 6 ? hipEventReleaseToDevice : hipEventDefault) == hipSuccess;   // as in calitas_create
+    ok = ok && hipEventCreateWithFlags(&c->scan_done, hipEventReleaseToDevice) == hipSuccess;   // timed: it also brackets the scan
+    ok = ok && hipEventCreateWithFlags(&c->rows_ready, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_guides, sizeof(GuideDev) * MAX_GUIDES, hipHostMallocDefault) == hipSuccess;
     ctx->lanes.push_back(c);
     if (!ok) { calitas_destroy_lanes(ctx); return fail(ctx, CALITAS_EHIP, "could not create a search lane"); }
   }
@@ -765,11 +771,10 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
     rc = ensure_window_table(ctx, pl, ctx->scan_stream);
     if (rc) return rc;
     const bool device_rows = !std::getenv("CALITAS_HOST_HITS");
-    for (size_t c = 0; c < K; c++) {
+    for (size_t c = 0; c < K && !rc; c++) {
       if (device_rows) HIP_TRY(ctx, hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream));   // before the wait below is queued
-      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);
+      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);                         // records lanes[c]->scan_done
       if (rc) { ctx->err = lanes[c]->err; break; }
-      HIP_TRY(ctx, hipEventRecord(lanes[c]->scan_done, ctx->scan_stream));
       HIP_TRY(ctx, hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0));
     }
     if (rc) { (void)hipDeviceSynchronize(); return rc; }
@@ -923,9 +928,8 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
             // lane's buffers are free for this scan
             if (device_rows) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // before the wait below is queued
             std::lock_guard<std::mutex> lk(scan_mu);
-            int r = launch_scan_stage(lane, pl, ctx->scan_stream);
+            int r = launch_scan_stage(lane, pl, ctx->scan_stream);   // records lane->scan_done
             if (r) return r;
-            HIP_TRY(lane, hipEventRecord(lane->scan_done, ctx->scan_stream));
             HIP_TRY(lane, hipStreamWaitEvent(lane->stream, lane->scan_done, 0));
           }
           LaneText lt;

@@ -8,11 +8,13 @@ timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format c
 python3 - /tmp/tl "$ROOT/gpurun_out/timeline.txt" <<'PY'
 import csv, glob, sys
 d, out = sys.argv[1], sys.argv[2]
+import os
+MIN_COPY = int(os.environ.get("TIMELINE_MIN_COPY", str(1 << 20)))   # bytes; 0 lists every copy
 ev = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "calitas" not in n and "ROCPRIM_400200" not in n:
+        if "calitas" not in n and "ROCPRIM_400200" not in n and "__amd_rocclr" not in n:
             continue
         n = n.replace("calitas::", "").replace("(anonymous namespace)::", "").split("(")[0]
         if "rocprim" in n:
@@ -21,7 +23,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
 for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         b = int(r.get("Bytes", r.get("bytes", 0)) or 0)
-        if b < 1 << 20:
+        if b < MIN_COPY:
             continue
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy", "%s %.1f MB" % (r.get("Direction", ""), b / 1e6)))
 ev.sort()
