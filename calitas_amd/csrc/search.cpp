@@ -633,7 +633,7 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   // (Reserving CUs for the lanes with hipExtStreamCreateWithCUMask on the scan stream was tried: 8 of 256 CUs masked out cost the
   // scan 9 %, 32 cost 80 %, and the lanes' small kernels did not get faster.)
-  if (!ctx->scan_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, least));
+  if (!ctx->scan_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, least));   // (two levels on this device: 0 and -1)
   // The runtime performs these device-to-host copies with a blit kernel (rocprofv3: __amd_rocclr_copyBuffer) that shares the CUs
   // with everything else.  On a high-priority stream it held up the other lane's small kernels for the whole copy (rocprofv3
   // timeline: a 5 us merge pass took 370 us); on the lowest priority the lanes' kernels get their slots first.  A copy kernel of
