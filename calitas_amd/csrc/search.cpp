@@ -487,16 +487,13 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
 
 int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                         calitas_aln_t** out, uint64_t* n_out) {
-  DeviceSel* dev = nullptr;
-  SearchPlan* plan_out = nullptr;
   if (!ctx) return CALITAS_EINVAL;
   if (!out || !n_out) return fail(ctx, CALITAS_EINVAL, "NULL argument");
   *out = nullptr; *n_out = 0;
-  SearchPlan local;
-  SearchPlan& pl = plan_out ? *plan_out : local;
+  SearchPlan pl;
   int rc = plan_search(ctx, n_guides, guides, params, pl);
   if (rc) return rc;
-  return search_run(ctx, pl, out, n_out, dev, false);
+  return search_run(ctx, pl, out, n_out, nullptr, false);
 }
 
 void calitas_default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp) {
