@@ -7,6 +7,9 @@
 // skipped: with alignBest's limits (d = protospacer length) practically every column reaches minGuideScore, so all
 // columns of both strands go to align_kernel, whose threshold test is the exact enumeration rule anyway.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -41,13 +44,28 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
   const Scores sc = derive_scores(p.guide_mismatch_net_cost, p.pam_mismatch_net_cost, p.genome_gap_net_cost, p.guide_gap_net_cost);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+  double ms_prep = 0, ms_pack = 0, ms_recs = 0, ms_upload = 0, ms_gpu = 0, ms_post = 0;
+  auto t_sec = clk::now();
   std::vector<calitas_aln_t> result;
   std::vector<uint32_t> per_task((size_t)std::max(n_tasks, 0), 0u);
-  std::vector<GuideHost> gh((size_t)n_tasks);
+  // guides: consecutive tasks that pass the same guide (the variant branch: one guide, a million windows) share one GuideHost
+  std::vector<GuideHost> uniq;
+  std::vector<int> gh_of((size_t)n_tasks);
+  struct GhView { const std::vector<GuideHost>& u; const std::vector<int>& of; const GuideHost& operator[](int t) const { return u[(size_t)of[(size_t)t]]; } };
+  const GhView gh{uniq, gh_of};
   std::vector<int> task_d(n_tasks), task_p(n_tasks), task_D(n_tasks), task_O(n_tasks);
   for (int t = 0; t < n_tasks; t++) {
-    std::string e = make_guide_host(guides[t], gh[t]);
-    if (!e.empty()) return calitas_fail(ctx, CALITAS_EINVAL, "task " + std::to_string(t) + ": " + e);
+    const bool same = t > 0 && guides[t].protospacer == guides[t - 1].protospacer && guides[t].pams == guides[t - 1].pams &&
+                      guides[t].n_pams == guides[t - 1].n_pams && guides[t].pam_is_5prime == guides[t - 1].pam_is_5prime &&
+                      guides[t].cli_length == guides[t - 1].cli_length;
+    if (!same) {
+      uniq.emplace_back();
+      std::string e = make_guide_host(guides[t], uniq.back());
+      if (!e.empty()) return calitas_fail(ctx, CALITAS_EINVAL, "task " + std::to_string(t) + ": " + e);
+    }
+    gh_of[(size_t)t] = (int)uniq.size() - 1;
     if (target_lengths[t] > 60000) return calitas_fail(ctx, CALITAS_EINVAL, "targets longer than 60000 bases are not supported here");
     const int L = (int)gh[t].protospacer.size();
     int pamlen = 0;
@@ -59,14 +77,21 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
     }
   }
 
+  ms_prep += ms_since(t_sec);
   // ---- process the tasks in chunks of at most MAX_GUIDES distinct (guide, limits) configurations and 8192 tasks ----
   int t0 = 0;
   while (t0 < n_tasks) {
+    t_sec = clk::now();
     std::map<std::string, int> slot_of;
     std::vector<int> slot_task;              // representative task of each slot
     std::vector<int> task_slot;
     int t1 = t0;
-    while (t1 < n_tasks && t1 - t0 < 8192) {
+    while (t1 < n_tasks && t1 - t0 < 32768) {
+      if (t1 > t0 && gh_of[(size_t)t1] == gh_of[(size_t)t1 - 1] && task_d[t1] == task_d[t1 - 1] && task_p[t1] == task_p[t1 - 1]) {
+        task_slot.push_back(task_slot.back());     // same guide and limits as the task before: same slot
+        t1++;
+        continue;
+      }
       std::string key = gh[t1].q + "|" + std::to_string(gh[t1].pam5) + "|" + std::to_string(task_d[t1]) + "|" + std::to_string(task_p[t1]);
       for (auto& pm : gh[t1].pams_q) key += "|" + pm;
       auto it = slot_of.find(key);
@@ -92,21 +117,20 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       slab_bytes = std::max<uint32_t>(slab_bytes, (uint32_t)((sizeof(SlabHeader) + ntb_max + gd[s].L * stride_max + 15) & ~15u));
     }
 
-    // temporary packed reference: one contig per task
-    std::vector<std::string> names(nt);
-    std::vector<const char*> name_ptrs(nt);
+    ms_prep += ms_since(t_sec); t_sec = clk::now();
+    // temporary packed reference: one contig per task, back to back (no scan here, so no tile padding or halos)
     std::vector<uint64_t> lens(nt);
     std::vector<const uint8_t*> bases(nt);
     uint32_t W = 16;
     for (int i = 0; i < nt; i++) {
-      names[i] = "t" + std::to_string(t0 + i); name_ptrs[i] = names[i].c_str();
       lens[i] = target_lengths[t0 + i]; bases[i] = targets[t0 + i];
       W = std::max<uint32_t>(W, target_lengths[t0 + i]);
     }
     PackedRef ref;
-    try { pack_reference(ref, nt, name_ptrs.data(), lens.data(), bases.data(), "windows", 1); }
+    try { pack_targets_dense(ref, nt, lens.data(), bases.data()); }
     catch (std::exception& e) { return calitas_fail(ctx, CALITAS_EINVAL, e.what()); }
 
+    ms_pack += ms_since(t_sec); t_sec = clk::now();
     // every column of every task, both directions
     std::vector<ScanRecord> recs;
     for (int i = 0; i < nt; i++) {
@@ -127,6 +151,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       if (rc) return rc;
     }
 
+    ms_recs += ms_since(t_sec); t_sec = clk::now();
     TempDevice td;
     const size_t nruns = std::max<size_t>(1, ref.runs.size());
     std::vector<uint64_t> wbase(nt + 1);
@@ -151,6 +176,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
     HIP_TRY(ctx, hipMemcpyAsync(td.guides, gd.data(), sizeof(GuideDev) * ns, hipMemcpyHostToDevice, ctx->stream));
     if (n_rec) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_recs, recs.data(), (size_t)n_rec * sizeof(ScanRecord), hipMemcpyHostToDevice, ctx->stream));
 
+    ms_upload += ms_since(t_sec); t_sec = clk::now();
     uint32_t n_raw = 0;
     for (;;) {
       uint32_t zero[8] = {n_rec, 0, 0, 0, 0, 0, 0, 0};
@@ -184,6 +210,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
     std::vector<RawAln> raw(n_raw);
     if (n_raw) HIP_TRY(ctx, hipMemcpy(raw.data(), ctx->d_raw, (size_t)n_raw * sizeof(RawAln), hipMemcpyDeviceToHost));
 
+    ms_gpu += ms_since(t_sec); t_sec = clk::now();
     // ---- host: enumeration order per task, conversion, SGA:315-320 ----
     std::vector<uint32_t> order(n_raw);
     std::iota(order.begin(), order.end(), 0u);
@@ -218,7 +245,11 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       i = j;
     }
     t0 = t1;
+    ms_post += ms_since(t_sec);
   }
+  if (std::getenv("CALITAS_TRACE") && n_tasks >= 1024)
+    std::fprintf(stderr, "[calitas] align_windows: %d tasks: guides %.1f ms, pack %.1f ms, records %.1f ms, alloc+upload %.1f ms, kernels+copy %.1f ms, filter %.1f ms\n",
+                 n_tasks, ms_prep, ms_pack, ms_recs, ms_upload, ms_gpu, ms_post);
 
   *n_out = result.size();
   *out = (calitas_aln_t*)calitas_out_alloc(std::max<size_t>(1, result.size()) * sizeof(calitas_aln_t));

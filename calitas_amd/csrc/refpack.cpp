@@ -54,6 +54,60 @@ char PackedRef::base_upper(uint64_t gpos) const {
   return "ACGT"[(codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3];
 }
 
+// n bases at src -> code words cw / mask words mw of packed position g0 (a multiple of 32) and the exception runs among them.
+static void pack_span(const uint8_t* src, uint64_t n, uint64_t g0, uint32_t* cw, uint32_t* mw, std::vector<Run>& runs) {
+  int runCh = -1; uint64_t runStart = 0;
+  for (uint64_t w = 0; w * 32 < n; w++) {
+    uint32_t m = 0, c0 = 0, c1 = 0;
+    uint64_t lim = std::min<uint64_t>(32, n - w * 32);
+    for (uint64_t k = 0; k < lim; k++) {
+      uint8_t b = src[w * 32 + k];
+      uint32_t code = kClass.code[b];
+      uint32_t e = kClass.exc[b];
+      m |= e << k;
+      if (k < 16) c0 |= code << (2 * k); else c1 |= code << (2 * (k - 16));
+      if (e) {
+        if (runCh != (int)b) {
+          if (runCh >= 0) runs.push_back(Run{g0 + runStart, (uint32_t)(w * 32 + k - runStart), (uint8_t)runCh, {0, 0, 0}});
+          runCh = b; runStart = w * 32 + k;
+        }
+      } else if (runCh >= 0) {
+        runs.push_back(Run{g0 + runStart, (uint32_t)(w * 32 + k - runStart), (uint8_t)runCh, {0, 0, 0}});
+        runCh = -1;
+      }
+    }
+    if (lim < 32) m |= 0xFFFFFFFFu << lim;  // beyond the contig end: padding
+    mw[w] = m; cw[2 * w] = c0; cw[2 * w + 1] = c1;
+  }
+  if (runCh >= 0) runs.push_back(Run{g0 + runStart, (uint32_t)(n - runStart), (uint8_t)runCh, {0, 0, 0}});
+}
+
+// Explicit targets (calitas_align_windows) packed back to back, each starting on a 32-base boundary: the align / trace kernels read
+// inside a target only, so none of the tile padding and halos the scan kernel needs.  "Tiles" are 32 bases (tile -> target lookup).
+void pack_targets_dense(PackedRef& out, int n, const uint64_t* lengths, const uint8_t* const* bases) {
+  out = PackedRef();
+  out.genome_build = "windows";
+  out.chunk = 32; out.tile = 32;
+  uint64_t g = 0, total = 0;
+  out.contigs.resize((size_t)n);
+  for (int i = 0; i < n; i++) {
+    out.contigs[i].gbase = g; out.contigs[i].len = lengths[i];
+    g += (lengths[i] + 31) / 32 * 32;
+    total += lengths[i];
+  }
+  if (g == 0) g = 32;
+  if (g / 16 > 0xFFFFFFFFull) throw std::invalid_argument("targets too large for 32-bit packed word indices");
+  out.total_bases = total; out.total_packed = g;
+  out.codes.assign(g / 16, 0u);
+  out.mask.assign(g / 32, 0xFFFFFFFFu);
+  out.tiles.assign(g / 32, TileInfo{0xFFFFFFFFu, 1u});
+  for (int i = 0; i < n; i++) {
+    const uint64_t g0 = out.contigs[i].gbase;
+    pack_span(bases[i], lengths[i], g0, out.codes.data() + g0 / 16, out.mask.data() + g0 / 32, out.runs);
+    for (uint64_t t = g0 / 32; t < (g0 + lengths[i] + 31) / 32; t++) out.tiles[t].contig = (uint32_t)i;
+  }
+}
+
 void pack_reference(PackedRef& out, int n_contigs, const char* const* names, const uint64_t* lengths,
                     const uint8_t* const* bases, const char* genome_build, int threads) {
   out = PackedRef();
@@ -97,35 +151,8 @@ void pack_reference(PackedRef& out, int n_contigs, const char* const* names, con
   auto work = [&](int tid) {
     for (size_t si = tid; si < segs.size(); si += nt) {
       Seg& s = segs[si];
-      const uint8_t* src = bases[s.contig] + s.off;
       const uint64_t g0 = out.contigs[s.contig].gbase + s.off;  // multiple of 32 (gbase multiple of tile, off of 2^22)
-      uint32_t* cw = out.codes.data() + g0 / 16;
-      uint32_t* mw = out.mask.data() + g0 / 32;
-      uint64_t n = s.len;
-      int runCh = -1; uint64_t runStart = 0;
-      for (uint64_t w = 0; w * 32 < n; w++) {
-        uint32_t m = 0, c0 = 0, c1 = 0;
-        uint64_t lim = std::min<uint64_t>(32, n - w * 32);
-        for (uint64_t k = 0; k < lim; k++) {
-          uint8_t b = src[w * 32 + k];
-          uint32_t code = kClass.code[b];
-          uint32_t e = kClass.exc[b];
-          m |= e << k;
-          if (k < 16) c0 |= code << (2 * k); else c1 |= code << (2 * (k - 16));
-          if (e) {
-            if (runCh != (int)b) {
-              if (runCh >= 0) s.runs.push_back(Run{g0 + runStart, (uint32_t)(w * 32 + k - runStart), (uint8_t)runCh, {0, 0, 0}});
-              runCh = b; runStart = w * 32 + k;
-            }
-          } else if (runCh >= 0) {
-            s.runs.push_back(Run{g0 + runStart, (uint32_t)(w * 32 + k - runStart), (uint8_t)runCh, {0, 0, 0}});
-            runCh = -1;
-          }
-        }
-        if (lim < 32) m |= 0xFFFFFFFFu << lim;  // beyond the contig end: padding
-        mw[w] = m; cw[2 * w] = c0; cw[2 * w + 1] = c1;
-      }
-      if (runCh >= 0) s.runs.push_back(Run{g0 + runStart, (uint32_t)(n - runStart), (uint8_t)runCh, {0, 0, 0}});
+      pack_span(bases[s.contig] + s.off, s.len, g0, out.codes.data() + g0 / 16, out.mask.data() + g0 / 32, s.runs);
     }
   };
   std::vector<std::thread> pool;

@@ -25,6 +25,7 @@ struct PackedRef {
 };
 
 // Packs ASCII contigs.  `threads` <= 0 picks the hardware concurrency.
+void pack_targets_dense(PackedRef& out, int n, const uint64_t* lengths, const uint8_t* const* bases);
 void pack_reference(PackedRef& out, int n_contigs, const char* const* names, const uint64_t* lengths,
                     const uint8_t* const* bases, const char* genome_build, int threads);
 

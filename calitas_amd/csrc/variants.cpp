@@ -1,0 +1,524 @@
+// variants.cpp -- the variant branch of SearchReference.execute (SearchReference.scala:101-400, 570-630) behind one C entry point.
+//
+// calitas_search_variants = the reference hits of calitas_search + the hits of every variant window, merged by removeOverlaps /
+// ReferenceHit.sort (calitas_hits_tsv_ext).  Variant windows are produced on the host exactly as variantWindowIterator does
+// (nextChunk / reChunk SR:326-347, alleleCombos SR:351-399, buildVariantWindow SR:263-323), aligned on the GPU through the
+// calitas_align_windows path in batches, lifted back with refOffsetAtBaseOffset (SR:133-156) and turned into rows with window-local
+// flanks (SR:598-613) and the variant columns (RH:211-233).  calitas_amd/variants.py holds the same logic in Python (the parity
+// tests run both); this file exists because BASELINE config 5 has three million variants.
+//
+// VCF support is the subset the reference's path needs (fgbio vcf.api): CHROM POS ID REF ALT FILTER INFO(AF, END); plain or gzip.
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+struct Var {
+  std::string chrom, id, ref;
+  int pos = 0, end = 0;                    // 1-based; fgbio Variant.end
+  std::vector<std::string> alts;
+  std::vector<float> afs;
+};
+
+struct Allele {                            // VariantAllele SR:105-110
+  const Var* v;
+  int alt;                                 // index into v->alts
+  float af;
+};
+
+struct CigarEl { char op; int n; };
+
+struct Window {                            // VariantWindow SR:118-157
+  int contig = 0, start = 0;               // start: 1-based reference position of the first base
+  std::vector<Allele> variants;
+  std::vector<CigarEl> cigar;
+  std::string bases;
+};
+
+std::vector<std::string> split(const std::string& s, char sep) {
+  std::vector<std::string> out;
+  size_t b = 0;
+  for (;;) {
+    size_t e = s.find(sep, b);
+    if (e == std::string::npos) { out.emplace_back(s, b); break; }
+    out.emplace_back(s, b, e - b);
+    b = e + 1;
+  }
+  return out;
+}
+
+// read_vcf of variants.py
+std::string read_vcf(const char* path, const char* chrom, std::vector<Var>& out) {
+  // gzip goes through zlib; plain text through stdio (gzgets costs 2-3x as much per line)
+  FILE* pf = std::fopen(path, "rb");
+  if (!pf) return std::string("cannot read ") + path;
+  unsigned char magic[2] = {0, 0};
+  const bool gz = std::fread(magic, 1, 2, pf) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  gzFile f = nullptr;
+  if (gz) {
+    std::fclose(pf); pf = nullptr;
+    f = gzopen(path, "rb");
+    if (!f) return std::string("cannot read ") + path;
+    gzbuffer(f, 1 << 20);
+  } else {
+    std::rewind(pf);
+    std::setvbuf(pf, nullptr, _IOFBF, 1 << 20);
+  }
+  std::string line;
+  std::vector<char> buf(1 << 16);
+  bool eof = false;
+  while (!eof) {
+    line.clear();
+    for (;;) {                             // one line of any length
+      if (!(gz ? gzgets(f, buf.data(), (int)buf.size()) : std::fgets(buf.data(), (int)buf.size(), pf))) { eof = true; break; }
+      line += buf.data();
+      if (!line.empty() && line.back() == '\n') break;
+    }
+    if (line.empty()) continue;
+    while (!line.empty() && (line.back() == '\n')) line.pop_back();
+    if (line.empty() || line[0] == '#') continue;
+    // fields 0-4 and 7 (CHROM POS ID REF ALT . . INFO), located in place
+    const char* f0[9]; size_t fl[9]; int nf = 0;
+    {
+      const char* b = line.data(); const char* const e = b + line.size();
+      while (nf < 9) {
+        const char* t = (const char*)std::memchr(b, '\t', (size_t)(e - b));
+        f0[nf] = b; fl[nf] = (size_t)((t ? t : e) - b); nf++;
+        if (!t) break;
+        b = t + 1;
+      }
+    }
+    if (nf < 5 || (chrom && (fl[0] != std::strlen(chrom) || std::memcmp(f0[0], chrom, fl[0]) != 0))) continue;
+    Var v;
+    v.chrom.assign(f0[0], fl[0]);
+    v.pos = std::atoi(std::string(f0[1], fl[1]).c_str());
+    if (!(fl[2] == 1 && f0[2][0] == '.')) v.id.assign(f0[2], fl[2]);
+    v.ref.assign(f0[3], fl[3]);
+    v.alts = split(std::string(f0[4], fl[4]), ',');
+    bool have_end = false;
+    if (nf > 7) {
+      const std::string info(f0[7], fl[7]);
+      if (info.find("AF=") != std::string::npos || info.find("END=") != std::string::npos) {
+        for (const std::string& kv : split(info, ';')) {
+          if (kv.compare(0, 3, "AF=") == 0) {
+            v.afs.clear();
+            for (const std::string& x : split(kv.substr(3), ',')) if (x != "." && !x.empty()) v.afs.push_back((float)std::strtod(x.c_str(), nullptr));
+          } else if (kv.compare(0, 4, "END=") == 0) {
+            v.end = std::atoi(kv.c_str() + 4); have_end = true;
+          }
+        }
+      }
+    }
+    if (!have_end) v.end = v.pos + (int)v.ref.size() - 1;
+    out.push_back(std::move(v));
+  }
+  if (f) gzclose(f);
+  if (pf) std::fclose(pf);
+  return "";
+}
+
+// alleleCombos(counts) SR:377-399: every combination of allele indices, the first variant varying slowest
+std::vector<std::vector<int>> allele_combos_counts(const std::vector<int>& counts) {
+  size_t total = 1;
+  for (int c : counts) total *= (size_t)c;
+  std::vector<std::vector<int>> results(total, std::vector<int>(counts.size(), 0));
+  size_t denom = 1;
+  for (size_t i = 0; i < counts.size(); i++) {
+    denom *= (size_t)counts[i];
+    const size_t group = total / denom;
+    size_t j = 0;
+    int allele = 0;
+    while (j < total) {
+      for (size_t k = 0; k < group; k++) results[j++][i] = allele;
+      allele = (allele + 1) % counts[i];
+    }
+  }
+  return results;
+}
+
+bool is_valid(const std::vector<const Var*>& vs) {   // VariantSet.isValid SR:182-193
+  for (size_t i = 0; i + 1 < vs.size(); i++) {
+    const Var &a = *vs[i], &b = *vs[i + 1];
+    const int s1 = a.pos, e1 = a.pos + (int)a.ref.size() - 1, s2 = b.pos, e2 = b.pos + (int)b.ref.size() - 1;
+    if (a.chrom == b.chrom && s1 <= e2 && e1 >= s2) return false;
+  }
+  return true;
+}
+
+// Upper-cased bases [s, e) of a contig (what the reference reads after toUpperCase): 2-bit decode, exceptions through base_upper.
+void upper_span(const PackedRef& ref, int contig, long s, long e, std::string& out) {
+  const ContigInfo& c = ref.contigs[contig];
+  out.resize((size_t)std::max(0L, e - s));
+  for (long q = s; q < e; q++) {
+    const uint64_t gpos = c.gbase + (uint64_t)q;
+    out[(size_t)(q - s)] = ((ref.mask[gpos >> 5] >> (gpos & 31)) & 1u) ? ref.base_upper(gpos) : "ACGT"[(ref.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u];
+  }
+}
+
+// buildVariantWindow SR:263-323
+std::string build_window(const std::vector<const Var*>& variants, const std::vector<int>& alleles, int contig, const PackedRef& ref,
+                         int padding, Window& w) {
+  const int window_start = std::max(1, variants.front()->pos - padding);
+  const int window_end = std::min((int)ref.contigs[contig].len, variants.back()->end + padding);
+  w.contig = contig; w.start = window_start;
+  upper_span(ref, contig, window_start - 1, std::max(window_start - 1, window_end), w.bases);
+  w.variants.clear(); w.cigar.clear();
+  for (size_t i = 0; i < variants.size(); i++) {
+    const Var* v = variants[i];
+    const int a = alleles[i] - 1;
+    w.variants.push_back(Allele{v, a, (size_t)a < v->afs.size() ? v->afs[a] : 0.0f});
+  }
+  for (size_t k = w.variants.size(); k-- > 0;) {     // right to left, so earlier offsets stay valid
+    const Allele& al = w.variants[k];
+    const int i = al.v->pos - window_start;
+    if (i < 0 || (size_t)i > w.bases.size()) return "variant outside its window";
+    w.bases.replace((size_t)i, std::min(al.v->ref.size(), w.bases.size() - (size_t)i), al.v->alts[al.alt]);
+  }
+  std::vector<CigarEl> cigar;
+  int ref_pos = window_start, base_off = 0;
+  for (const Allele& al : w.variants) {
+    const int pm = al.v->pos - ref_pos;
+    if (pm > 0) { cigar.push_back({'M', pm}); ref_pos += pm; base_off += pm; }
+    const int rl = (int)al.v->ref.size(), alen = (int)al.v->alts[al.alt].size();
+    if (rl == alen) cigar.push_back({'M', rl});
+    else if (rl == 1 && alen > 1) { cigar.push_back({'M', 1}); cigar.push_back({'I', alen - 1}); }
+    else if (rl > 1 && alen == 1) { cigar.push_back({'M', 1}); cigar.push_back({'D', rl - 1}); }
+    else { cigar.push_back({'D', rl}); cigar.push_back({'I', alen}); }
+    ref_pos += rl; base_off += alen;
+  }
+  cigar.push_back({'M', (int)w.bases.size() - base_off});
+  for (const CigarEl& e : cigar) {                    // Cigar.coalesce
+    if (!w.cigar.empty() && w.cigar.back().op == e.op) w.cigar.back().n += e.n; else w.cigar.push_back(e);
+  }
+  long on_query = 0;
+  for (const CigarEl& e : w.cigar) if (e.op == 'M' || e.op == 'I') on_query += e.n;
+  if (on_query != (long)w.bases.size()) return "requirement failed: cigar length on query != bases";
+  return "";
+}
+
+// refOffsetAtBaseOffset SR:133-156
+bool ref_offset_at(const Window& w, int offset, bool preceding, int& out) {
+  auto on_q = [](const CigarEl& e) { return (e.op == 'M' || e.op == 'I') ? e.n : 0; };
+  auto on_t = [](const CigarEl& e) { return (e.op == 'M' || e.op == 'D') ? e.n : 0; };
+  if (offset == (int)w.bases.size()) {
+    int t = 0;
+    for (const CigarEl& e : w.cigar) t += on_t(e);
+    out = w.start - 1 + t;
+    return true;
+  }
+  int ref_off = w.start - 1, base_off = 0;
+  size_t k = 0;
+  while (k < w.cigar.size() && offset >= base_off + on_q(w.cigar[k])) { ref_off += on_t(w.cigar[k]); base_off += on_q(w.cigar[k]); k++; }
+  if (k >= w.cigar.size()) return false;
+  const char op = w.cigar[k].op;
+  if (op == 'I') { out = preceding ? ref_off - 1 : ref_off; return true; }
+  if (op == 'M') { out = ref_off + (offset - base_off); return true; }
+  return false;                                       // "Query bases can't be present at operator D."
+}
+
+std::string format_metric_double(double d) {          // fgbio Metric.formatValue(Double), as variants.py states it
+  char b[64];
+  auto strip = [](std::string s) {
+    while (!s.empty() && s.back() == '0') s.pop_back();
+    if (!s.empty() && s.back() == '.') s.pop_back();
+    return s;
+  };
+  if (d == 0) return "0";
+  if (std::fabs(d) < 0.00001) {
+    const int ex = (int)std::floor(std::log10(std::fabs(d)));
+    std::snprintf(b, sizeof b, "%.5f", d / std::pow(10.0, ex));
+    return strip(b) + "E" + std::to_string(ex);
+  }
+  std::snprintf(b, sizeof b, "%.6f", d);
+  return strip(b);
+}
+
+std::string display_string(const Allele& a) {         // VariantAllele.displayString SR:108
+  char b[64];
+  std::snprintf(b, sizeof b, ":%d:", a.v->pos - 1);
+  std::string s = (a.v->id.empty() ? std::string(".") : a.v->id) + b + a.v->ref + ">" + a.v->alts[a.alt];
+  std::snprintf(b, sizeof b, ":%.3f", (double)a.af);
+  return s + b;
+}
+
+std::string revcomp(const std::string& s) { return calitas::revcomp_str(s); }
+
+int ga_count(const char* pg, const char* pa, int len, bool lower, bool both_sides, bool mms, bool gaps) {   // GA:139-163
+  auto is_lower = [](char c) { return c >= 'a' && c <= 'z'; };
+  auto is_letter = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+  int n = 0;
+  for (int i = 0; i < len; i++) {
+    if (mms && pa[i] == '.' && is_lower(pg[i]) == lower) { n++; continue; }
+    if (!(gaps && pa[i] == '~')) continue;
+    const char gb = pg[i];
+    bool me = gb != '-' && is_lower(gb) == lower;
+    if (!me) {
+      int pi = i; while (pi > 0 && pg[pi] == '-') pi--;
+      int ni = i; while (ni < len - 1 && pg[ni] == '-') ni++;
+      const char prev = pg[pi], next = pg[ni];
+      if (both_sides) me = (prev == '-' || is_lower(prev) == lower) && (next == '-' || is_lower(next) == lower);
+      else me = (is_letter(prev) && is_lower(prev) == lower) || (is_letter(next) && is_lower(next) == lower);
+    }
+    if (me) n++;
+  }
+  return n;
+}
+
+struct ExtRow { int contig, start, end, score; char strand; std::string desc, row; };
+
+}  // namespace
+
+extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                                       const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
+                                       const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows, uint64_t* n_windows) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!guide || !params || !vcf_path || !tsv) return calitas_fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *tsv = nullptr;
+  if (tsv_bytes) *tsv_bytes = 0;
+  if (n_rows) *n_rows = 0;
+  if (n_windows) *n_windows = 0;
+  if (!ctx->has_ref) return calitas_fail(ctx, CALITAS_ESTATE, "calitas_set_reference has not been called");
+  const PackedRef& ref = ctx->ref;
+  const calitas_params_t& p = *params;
+  GuideHost gh;
+  {
+    std::string e = make_guide_host(*guide, gh);
+    if (!e.empty()) return calitas_fail(ctx, CALITAS_EINVAL, e);
+  }
+  const std::string gid = guide_id ? guide_id : "", vid = vcf_id ? vcf_id : "";
+  std::string version, stamp;
+  calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  const int d = p.max_guide_diffs, g = p.max_gaps_between_guide_and_pam;
+  const int max_pam = [&] { size_t m = 0; for (auto& q : gh.pams) m = std::max(m, q.size()); return (int)m; }();
+  const int padding = (int)gh.protospacer.size() + max_pam - 1 + d + g;                          // SR:575 (query.length - 1 + d + g)
+
+  const auto t_call = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+  double ms_ref = 0, ms_parse = 0, ms_align = 0, ms_rows = 0, ms_merge = 0;
+
+  // reference windows on the GPU (SR:527-561)
+  calitas_aln_t* ref_alns = nullptr;
+  uint64_t n_ref = 0;
+  int rc = calitas_search_impl(ctx, 1, guide, params, &ref_alns, &n_ref);
+  if (rc) return rc;
+  ms_ref = ms_since(t_call);
+
+  std::vector<Var> vcf;
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string e = read_vcf(vcf_path, chrom, vcf);
+    ms_parse = ms_since(t0);
+    if (!e.empty()) { calitas_free(ref_alns); return calitas_fail(ctx, CALITAS_EIO, e); }
+  }
+  std::vector<std::string> order;                                                                 // contigs the iterator walks
+  for (auto& n : ref.names) if (!chrom || n == chrom) order.push_back(n);
+
+  // the pieces of a row that do not depend on the hit
+  const RowStrings rs = make_row_strings(ref, gh, gid, p, version, stamp);
+  calitas_params_t ap = p;                                                                         // the explicit-target pass
+  ap.chrom_index = -1;
+
+  std::deque<ExtRow> rows;
+  const size_t kBatch = 16384;
+  std::vector<Window> batch(kBatch + 1);                                                             // reused: their vectors keep their capacity
+  size_t nb = 0;
+  uint64_t windows_total = 0;
+  std::string err;
+
+  auto fetch_ref = [&](int ci, long s1, long e1, bool minus) {                                     // fetchBases RH:261-266, 1-based closed
+    const long clen = (long)ref.contigs[ci].len;
+    const long as = std::max(1L, s1), ae = std::min(clen, e1);
+    std::string b((size_t)std::max(0L, as - s1), 'N');
+    for (long q = as; q <= ae; q++) b += ref.base_upper(ref.contigs[ci].gbase + (uint64_t)(q - 1));
+    b.append((size_t)std::max(0L, e1 - ae), 'N');
+    return minus ? revcomp(b) : b;
+  };
+
+  auto flush = [&]() -> int {
+    if (nb == 0) return CALITAS_OK;
+    const size_t n = nb;
+    std::vector<calitas_guide_t> guides(n, *guide);
+    std::vector<const uint8_t*> targets(n);
+    std::vector<uint32_t> lens(n);
+    std::vector<int32_t> offs(n, 0);
+    for (size_t i = 0; i < n; i++) { targets[i] = reinterpret_cast<const uint8_t*>(batch[i].bases.data()); lens[i] = (uint32_t)batch[i].bases.size(); }
+    calitas_aln_t* out = nullptr;
+    uint64_t n_out = 0;
+    uint32_t* counts = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    int r = calitas_align_windows(ctx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &out, &n_out, &counts);
+    if (r) return r;
+    ms_align += ms_since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    size_t k = 0;
+    for (size_t t = 0; t < n && err.empty(); t++) {
+      const Window& w = batch[t];
+      const int wl = (int)w.bases.size();
+      for (uint32_t c = 0; c < counts[t] && err.empty(); c++, k++) {
+        const calitas_aln_t& a = out[k];
+        const bool minus = a.strand == '-';
+        const int gs = a.guide_start_offset, ge = a.guide_end_offset, as = a.start_offset, ae = a.end_offset;   // window-local
+        int start = 0, end = 0, gstart = 0, gend = 0;                                              // lifted back (SR:615-620)
+        if (!ref_offset_at(w, as, true, start) || !ref_offset_at(w, ae, false, end) || !ref_offset_at(w, gs, true, gstart) ||
+            !ref_offset_at(w, ge, false, gend)) { err = "Query bases can't be present at operator D."; break; }
+        // flanks from the window where it reaches far enough, from the reference otherwise (SR:598-613)
+        auto flank = [&](int from, int to, bool have) { return have ? w.bases.substr((size_t)from, (size_t)(to - from)) : std::string(); };
+        const bool h_l10 = gs >= 10, h_r10 = wl - ge >= 10, h_l8 = as >= 8, h_r8 = wl - ae >= 8;
+        std::string l10 = flank(gs - 10, gs, h_l10), r10 = flank(ge, ge + 10, h_r10), l8 = flank(as - 8, as, h_l8), r8 = flank(ae, ae + 8, h_r8);
+        bool v_l10 = h_l10, v_r10 = h_r10, v_l8 = h_l8, v_r8 = h_r8;
+        if (minus) {
+          std::string t10 = l10, t8 = l8;
+          l10 = h_r10 ? revcomp(r10) : std::string(); r10 = h_l10 ? revcomp(t10) : std::string();
+          l8 = h_r8 ? revcomp(r8) : std::string();   r8 = h_l8 ? revcomp(t8) : std::string();
+          v_l10 = h_r10; v_r10 = h_l10; v_l8 = h_r8; v_r8 = h_l8;
+        }
+        auto ten_left = [&] { return fetch_ref(w.contig, gstart + 1 - 10, gstart, minus); };
+        auto ten_right = [&] { return fetch_ref(w.contig, gend + 1, gend + 10, minus); };
+        auto eight_left = [&] { return fetch_ref(w.contig, start + 1 - 8, start, minus); };
+        auto eight_right = [&] { return fetch_ref(w.contig, end + 1, end + 8, minus); };
+        const std::string c5_10 = v_l10 ? l10 : (!minus ? ten_left() : ten_right());
+        const std::string c3_10 = v_r10 ? r10 : (!minus ? ten_right() : ten_left());
+        const std::string c5_8 = v_l8 ? l8 : (!minus ? eight_left() : eight_right());
+        const std::string c3_8 = v_r8 ? r8 : (!minus ? eight_right() : eight_left());
+        // padded strings from the window's own bases (SGA:511; '-' strand: revcomp of the window span)
+        const std::string& q = rs.query[a.pam_index + 1];
+        std::string t = w.bases.substr((size_t)as, (size_t)(ae - as));
+        if (minus) t = revcomp(t);
+        const int n_ops = a.n_ops;
+        char pg[CALITAS_MAX_OPS + 1], pa[CALITAS_MAX_OPS + 1], pt[CALITAS_MAX_OPS + 1];
+        size_t qi = 0, ti = 0;
+        int mm = 0, gp = 0, tlen = 0;
+        for (int i = 0; i < n_ops; i++) {
+          switch (a.ops[i]) {
+            case 'I': pg[i] = q[qi++]; pa[i] = '~'; pt[i] = '-'; gp++; break;
+            case 'D': pg[i] = '-'; pa[i] = '~'; pt[i] = t[ti++]; gp++; tlen++; break;
+            case '=': pg[i] = q[qi++]; pa[i] = '|'; pt[i] = t[ti++]; tlen++; break;
+            default:  pg[i] = q[qi++]; pa[i] = '.'; pt[i] = t[ti++]; mm++; tlen++; break;
+          }
+        }
+        int ps = -1, pe = -1;                                                                       // GA:111-115
+        for (int i = 0; i < n_ops; i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
+        std::string unpadded_target;
+        for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target += pt[i];
+        // variants under the hit (RH:211) and their columns (RH:211-233)
+        std::vector<const Allele*> vs;
+        for (const Allele& al : w.variants) if (start <= al.v->pos - 1 && al.v->pos - 1 <= end) vs.push_back(&al);
+        std::string ids, descs, af;
+        if (!vs.empty()) {
+          const Allele* mn = vs[0];
+          for (const Allele* al : vs) if (al->af < mn->af) mn = al;                                 // minBy keeps the first minimum
+          af = format_metric_double((double)mn->af);
+          for (size_t i = 0; i < vs.size(); i++) { if (i) { ids += ';'; descs += ';'; } ids += vs[i]->v->id; descs += display_string(*vs[i]); }
+        }
+        const int gmm = ga_count(pg, pa, n_ops, false, false, true, false), ggp = ga_count(pg, pa, n_ops, false, false, false, true);
+        std::string cigar;
+        for (int i = 0; i < n_ops;) { int j = i; while (j < n_ops && a.ops[j] == a.ops[i]) j++; cigar += std::to_string(j - i); cigar += (char)a.ops[i]; i = j; }
+        std::string row;
+        row.reserve(640);
+        auto add = [&](const std::string& s) { row += s; row += '\t'; };
+        add(gid); add(gh.protospacer); add(ref.genome_build + (vs.empty() ? "" : "+variants")); add(ref.names[w.contig]);
+        add(std::to_string(gstart)); add(std::to_string(gend)); add(std::string(1, (char)a.strand)); add(unpadded_target);
+        add(c5_10); add(c3_10); add(rs.pam_used[a.pam_index + 1]); add(ids); add(descs); add(vs.empty() ? std::string() : vid); add(af);
+        add(std::to_string(a.score)); add(std::to_string(gmm)); add(std::to_string(ggp)); add(std::to_string(gmm + ggp));
+        add(std::to_string(ga_count(pg, pa, n_ops, true, true, true, false))); add(std::to_string(mm + gp));
+        add(std::string(pg, (size_t)n_ops)); add(std::string(pa, (size_t)n_ops)); add(std::string(pt, (size_t)n_ops));
+        add(c5_8); add(c3_8); add(cigar); add(rs.proto_len); add(std::to_string(unpadded_target.size()));
+        row += rs.tail;                                                                             // aligner .. time_stamp + '\n'
+        if (!row.empty() && row.back() == '\n') row.pop_back();
+        rows.push_back(ExtRow{w.contig, gstart, gstart + tlen - 1, a.score, (char)a.strand, descs, std::move(row)});
+      }
+    }
+    calitas_free(out);
+    calitas_free(counts);
+    nb = 0;
+    ms_rows += ms_since(t1);
+    return CALITAS_OK;
+  };
+
+  // variantWindowIterator SR:217-256 with nextChunk / reChunk SR:326-347
+  const int max_variants = p.max_variants;
+  size_t ci = 0, i = 0;
+  while (i < vcf.size() && err.empty() && rc == CALITAS_OK) {
+    std::vector<const Var*> chunk{&vcf[i]};
+    const Var* last = &vcf[i];
+    i++;
+    while (i < vcf.size() && vcf[i].chrom == last->chrom && vcf[i].pos <= last->end + padding) { last = &vcf[i]; chunk.push_back(last); i++; }
+    while (ci < order.size() && order[ci] != chunk[0]->chrom) ci++;
+    if (ci >= order.size()) { err = "next on empty iterator (VCF contig " + chunk[0]->chrom + " not in reference order)"; break; }
+    int contig = -1;
+    for (size_t k = 0; k < ref.names.size(); k++) if (ref.names[k] == order[ci]) { contig = (int)k; break; }
+    for (size_t s = 0; s < chunk.size() && err.empty(); s++) {
+      std::vector<const Var*> sub;
+      for (size_t k = s; k < chunk.size(); k++) { if (chunk[k]->pos - chunk[s]->end > padding) break; sub.push_back(chunk[k]); }
+      // alleleCombos SR:351-369
+      if ((int)sub.size() > max_variants) {
+        const Var* v = sub[0];
+        for (size_t a = 0; a < v->alts.size() && err.empty(); a++) {
+          err = build_window({v}, {(int)a + 1}, contig, ref, padding, batch[nb++]);
+          windows_total++;
+          if (nb >= kBatch) { rc = flush(); if (rc) break; }
+        }
+      } else if (sub.size() == 1) {                                                                // the common case, without the tables
+        const Var* v = sub[0];
+        for (size_t a = 0; a < v->alts.size() && err.empty(); a++) {
+          err = build_window({v}, {(int)a + 1}, contig, ref, padding, batch[nb++]);
+          windows_total++;
+          if (nb >= kBatch) { rc = flush(); if (rc) break; }
+        }
+      } else {
+        std::vector<int> counts;
+        for (const Var* v : sub) counts.push_back(1 + (int)v->alts.size());
+        for (const std::vector<int>& alleles : allele_combos_counts(counts)) {
+          std::vector<const Var*> sv; std::vector<int> sa;
+          for (size_t k = 0; k < sub.size(); k++) if (alleles[k] != 0) { sv.push_back(sub[k]); sa.push_back(alleles[k]); }
+          if (sv.empty() || !is_valid(sv)) continue;
+          err = build_window(sv, sa, contig, ref, padding, batch[nb++]);
+          windows_total++;
+          if (!err.empty()) break;
+          if (nb >= kBatch) { rc = flush(); if (rc) break; }
+        }
+      }
+      if (rc) break;
+    }
+  }
+  if (rc == CALITAS_OK && err.empty()) rc = flush();
+  if (rc != CALITAS_OK || !err.empty()) {
+    calitas_free(ref_alns);
+    return rc != CALITAS_OK ? rc : calitas_fail(ctx, CALITAS_EINVAL, err);
+  }
+
+  // merge: removeOverlaps + sort over everything (SR:641-648)
+  std::vector<calitas_ext_hit_t> ext(rows.size());
+  {
+    size_t k = 0;
+    for (const ExtRow& r : rows) {
+      ext[k].contig_index = r.contig; ext[k].coordinate_start = r.start; ext[k].end = r.end; ext[k].score = r.score; ext[k].strand = (int8_t)r.strand;
+      ext[k].variant_description = r.desc.c_str(); ext[k].row = r.row.c_str();
+      k++;
+    }
+  }
+  uint64_t nr = 0;
+  const auto t_merge = std::chrono::steady_clock::now();
+  rc = calitas_hits_tsv_ext(ctx, guide, gid.c_str(), params, ref_alns, n_ref, ext.data(), (uint64_t)ext.size(), version.c_str(), stamp.c_str(), tsv, &nr);
+  calitas_free(ref_alns);
+  if (rc) return rc;
+  if (tsv_bytes) *tsv_bytes = std::strlen(*tsv);
+  if (n_rows) *n_rows = nr;
+  if (n_windows) *n_windows = windows_total;
+  ms_merge = ms_since(t_merge);
+  if (std::getenv("CALITAS_TRACE"))
+    std::fprintf(stderr, "[calitas] search_variants: reference search %.1f ms, VCF %.1f ms (%zu records), %llu windows: align %.1f ms, rows %.1f ms, merge %.1f ms, call %.1f ms\n",
+                 ms_ref, ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_merge, ms_since(t_call));
+  return CALITAS_OK;
+}

@@ -211,6 +211,33 @@ def format_metric_double(d):
     return ("%.6f" % d).rstrip("0").rstrip(".")
 
 
+def vcf_identifier(vcf_path):
+    """ReferenceHit.scala:175-183: file name and md5 of the VCF."""
+    h = hashlib.md5()
+    with open(vcf_path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 22), b""):
+            h.update(block)
+    return "%s:%s" % (os.path.basename(str(vcf_path)), h.hexdigest())
+
+
+def search_variants(sr, ctx, vcf_path, chrom_index=-1, version=None, time_stamp=None):
+    """SearchReference.execute with --variants through calitas_search_variants (window production, lift-back and rows in C++;
+    the windows are aligned on the GPU).  Returns (tsv_text, n_rows); sr.variant_windows = number of variant windows."""
+    params = make_params(chrom_index=chrom_index, **sr._kw)
+    gq = sr.query.to_c()
+    tsv, nbytes, rows, nwin = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(ctx._h, lib.calitas_search_variants(ctx._h, ctypes.byref(gq), sr.guide_id.encode(), ctypes.byref(params), str(vcf_path).encode(),
+                                                   sr.chrom.encode() if sr.chrom is not None else None, vcf_identifier(vcf_path).encode(),
+                                                   version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                                   ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(rows), ctypes.byref(nwin)))
+    try:
+        text = ctypes.string_at(tsv, nbytes.value).decode()
+    finally:
+        lib.calitas_free(tsv)
+    sr.variant_windows = nwin.value
+    return text, rows.value
+
+
 def search_reference_with_variants(sr, ctx, vcf_path, version=None, time_stamp=None):
     """SearchReference.execute with --variants on a resident reference.  `sr` is the SearchReference mirror object."""
     import struct

@@ -220,6 +220,18 @@ int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, c
                          const calitas_aln_t* alns, uint64_t n_alns, const calitas_ext_hit_t* ext, uint64_t n_ext,
                          const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* n_rows);
 
+/* SearchReference.execute with --variants (SearchReference.scala:570-648), end to end: the reference hits of calitas_search plus
+ * the hits of every variant window -- variantWindowIterator / nextChunk / reChunk / alleleCombos / buildVariantWindow
+ * (SearchReference.scala:217-399) on the host, the windows aligned on the GPU in batches (the calitas_align_windows path), coordinates
+ * lifted back with refOffsetAtBaseOffset (SearchReference.scala:133-156), window-local flanks (SearchReference.scala:598-613), the
+ * variant columns of ReferenceHit.Builder.build (ReferenceHit.scala:211-233) -- merged by removeOverlaps / ReferenceHit.sort.
+ * vcf_path: plain or gzip VCF, records in reference order (CHROM POS ID REF ALT FILTER INFO with AF / END); chrom: NULL or the
+ * --chrom filter (params->chrom_index must name the same contig); vcf_id: the "name:md5" string of ReferenceHit.scala:175-183
+ * (the caller computes it); params->max_variants = --max-variants.  *n_windows (optional) receives the number of variant windows. */
+int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                            const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
+                            const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows, uint64_t* n_windows);
+
 /* Padded strings of one alignment (Alignment.paddedString as used at SequentialGuideAligner.scala:511, plus the
  * reverse-complement handling of 5' PAM guides): each buffer must hold CALITAS_MAX_OPS+1 bytes. */
 int calitas_padded_strings(const calitas_ctx* ctx, const calitas_guide_t* guide, const calitas_aln_t* aln, char* padded_guide,

@@ -106,6 +106,41 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
   return (*env)->NewDirectByteBuffer(env, tsv, (jlong)bytes);
 }
 
+/* calitas_search_variants: SearchReference.execute with --variants (SearchReference.scala:570-648); vcfId is the "name:md5" string
+ * of ReferenceHit.scala:175-183, chrom the --chrom filter or null.  Returns the finished hits.txt text like searchHits. */
+JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_searchVariants(JNIEnv* env, jobject self, jlong h,
+    jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jstring guideId, jintArray params, jstring vcfPath,
+    jstring chrom, jstring vcfId, jstring version) {
+  calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
+  calitas_guide_t g;
+  calitas_params_t p;
+  const jsize np = (*env)->GetArrayLength(env, pams);
+  const char* cp[CALITAS_MAX_PAMS];
+  jstring jp[CALITAS_MAX_PAMS];
+  if (np > CALITAS_MAX_PAMS) { throw_state(env, "too many PAMs"); return NULL; }
+  g.protospacer = (*env)->GetStringUTFChars(env, protospacer, NULL);
+  for (jsize i = 0; i < np; i++) { jp[i] = (jstring)(*env)->GetObjectArrayElement(env, pams, i); cp[i] = (*env)->GetStringUTFChars(env, jp[i], NULL); }
+  g.n_pams = (int32_t)np; g.pams = cp; g.pam_is_5prime = pam5 ? 1 : 0; g.cli_length = cliLength;
+  (*env)->GetIntArrayRegion(env, params, 0, (jsize)(sizeof(p) / sizeof(int32_t)), (jint*)&p);
+  const char* gid = (*env)->GetStringUTFChars(env, guideId, NULL);
+  const char* vcf = (*env)->GetStringUTFChars(env, vcfPath, NULL);
+  const char* vid = (*env)->GetStringUTFChars(env, vcfId, NULL);
+  const char* chr = chrom ? (*env)->GetStringUTFChars(env, chrom, NULL) : NULL;
+  const char* ver = version ? (*env)->GetStringUTFChars(env, version, NULL) : NULL;
+  char* tsv = NULL;
+  uint64_t bytes = 0, rows = 0;
+  const int rc = calitas_search_variants(ctx, &g, gid, &p, vcf, chr, vid, ver, NULL, &tsv, &bytes, &rows, NULL);
+  (*env)->ReleaseStringUTFChars(env, protospacer, g.protospacer);
+  for (jsize i = 0; i < np; i++) (*env)->ReleaseStringUTFChars(env, jp[i], cp[i]);
+  (*env)->ReleaseStringUTFChars(env, guideId, gid);
+  (*env)->ReleaseStringUTFChars(env, vcfPath, vcf);
+  (*env)->ReleaseStringUTFChars(env, vcfId, vid);
+  if (chrom) (*env)->ReleaseStringUTFChars(env, chrom, chr);
+  if (version) (*env)->ReleaseStringUTFChars(env, version, ver);
+  if (rc != CALITAS_OK) { throw_state(env, calitas_last_error(ctx)); return NULL; }
+  return (*env)->NewDirectByteBuffer(env, tsv, (jlong)bytes);
+}
+
 JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_free(JNIEnv* env, jobject self, jobject buffer) {
   calitas_free((*env)->GetDirectBufferAddress(env, buffer));
 }

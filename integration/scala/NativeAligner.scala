@@ -33,6 +33,17 @@ final class NativeAligner(device: Int = 0) extends AutoCloseable {
     try { val out = new Array[Byte](buf.capacity()); buf.get(out); out } finally NativeAligner.free(buf)
   }
 
+  /** calitas_search_variants: SearchReference.execute with --variants (SearchReference.scala:570-648) -- variant windows, their
+    * alignment, the lift-back to reference coordinates and the merge with the reference hits.  vcfId = ReferenceHit's
+    * "name:md5" identifier (ReferenceHit.scala:175-183); params carries --max-variants. */
+  def searchVariants(guide: Guide, cliLength: Int, guideId: String, params: Array[Int], vcf: java.nio.file.Path, chrom: Option[String],
+                     vcfId: String, version: String): Array[Byte] = {
+    val pams = (guide.pams5Prime ++ guide.pams3Prime).toArray
+    val buf  = NativeAligner.searchVariants(handle, guide.guide, pams, guide.pamIsFivePrime, cliLength, guideId, params, vcf.toString,
+                                            chrom.orNull, vcfId, version)
+    try { val out = new Array[Byte](buf.capacity()); buf.get(out); out } finally NativeAligner.free(buf)
+  }
+
   override def close(): Unit = NativeAligner.destroy(handle)
 }
 
@@ -47,6 +58,9 @@ object NativeAligner {
                              params: Array[Int]): ByteBuffer
   @native private def searchHits(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
                                  guideId: String, params: Array[Int], version: String): ByteBuffer
+  @native private def searchVariants(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
+                                     guideId: String, params: Array[Int], vcfPath: String, chrom: String, vcfId: String,
+                                     version: String): ByteBuffer
   @native private def free(buffer: ByteBuffer): Unit
 
   /** calitas_aln_t -> GuideAlignment (GuideAlignment.scala:72-88).  The padded strings follow Alignment.paddedString as used at

@@ -89,8 +89,18 @@ def test_random_vcf_parity(C, guide, kw, tmp_path):
     vcf = write_vcf(str(tmp_path / "v.vcf"), variants, afs)
     sr = C.SearchReference(guide=guide, guide_id="a", ref=fa, variants=vcf, max_guide_diffs=kw["d"], max_pam_mismatches=kw["p"],
                            max_gaps_between_guide_and_pam=kw["g"])
-    text, n = sr.run()
+    text, n = sr.run("v0", "stamp")                            # calitas_search_variants (C++ window production and rows)
+    sr.python_variants = True
+    assert sr.run("v0", "stamp") == (text, n)                  # the same branch written in Python (variants.py): same bytes
+    assert sr.variant_windows > 0
     got = C.read_hits(text)
+    import gzip, shutil                                       # the same records gzipped: same rows (the file id differs)
+    with open(vcf, "rb") as fi, gzip.open(str(tmp_path / "v.vcf.gz"), "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    sz = C.SearchReference(guide=guide, guide_id="a", ref=fa, variants=str(tmp_path / "v.vcf.gz"), max_guide_diffs=kw["d"],
+                           max_pam_mismatches=kw["p"], max_gaps_between_guide_and_pam=kw["g"])
+    blank = lambda rows: [dict(r, variant_vcf="") for r in rows]
+    assert blank(C.read_hits(sz.run("v0", "stamp")[0])) == blank(got)
     _, want, _ = O.search_reference_vcf(fa, vcf, guide, "a", d=kw["d"], p=kw["p"], g=kw["g"])
     assert any(r["variant_id"] or r["variant_description"] for r in want)
     g2, w2 = _norm(got), _norm(want)

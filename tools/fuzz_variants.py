@@ -89,7 +89,12 @@ def run(iters, seed):
         try:
             sr = C.SearchReference(guide=guide, guide_id="a", ref=fa, variants=vcf, max_guide_diffs=d, max_pam_mismatches=p,
                                    max_gaps_between_guide_and_pam=g, max_variants=mv)
-            text, n = sr.run()
+            text, n = sr.run("v", "t")
+            sr.python_variants = True                      # the same branch written in Python: byte-identical
+            text_py, n_py = sr.run("v", "t")
+            if (text_py, n_py) != (text, n):
+                bad += 1
+                print("C++ / PYTHON DIFFER iter %d %s d%d p%d g%d V%d: %d vs %d rows" % (it, guide, d, p, g, mv, n, n_py), flush=True); continue
         except Exception as e:
             bad += 1
             print("PRODUCT ERROR iter %d %s d%d p%d g%d V%d: %s" % (it, guide, d, p, g, mv, str(e)[:200]), flush=True); continue
