@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcalitas_hip.so")
 
 MAX_OPS = 128
-OK, EINVAL, ENODEV, EHIP, EIO, ESTATE = 0, 1, 2, 3, 4, 5
+OK, EINVAL, ENODEV, EHIP, EIO, ESTATE, ENOMEM = 0, 1, 2, 3, 4, 5, 6
 
 
 class CalitasError(RuntimeError):

@@ -107,5 +107,6 @@ inline hipError_t calitas_spin_sync(hipEvent_t ev) { return calitas_poll([ev] { 
 #define HIP_TRY(ctx, call)                                                                         \
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \
-    if (e_ != hipSuccess) return calitas_fail(ctx, CALITAS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    if (e_ != hipSuccess) { if (e_ == hipErrorOutOfMemory) (void)hipGetLastError();                    \
+      return calitas_fail(ctx, e_ == hipErrorOutOfMemory ? CALITAS_ENOMEM : CALITAS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } \
   } while (0)

@@ -64,6 +64,12 @@ std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, cons
 
 int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec, uint32_t item_cap) {
   rec_cap = std::max(rec_cap, ctx->rec_cap);
+  if (const char* e = std::getenv("CALITAS_DEVICE_BUDGET_MB")) {   // refuse instead of trying: what a caller sharing the card can set
+    const uint64_t want = (uint64_t)rec_cap * slab_per_rec + (uint64_t)rec_cap * sizeof(ScanRecord) +
+                          (uint64_t)std::max(raw_cap, ctx->raw_cap) * sizeof(RawAln) + (uint64_t)std::max(item_cap, ctx->item_cap) * sizeof(uint64_t);
+    if (want > (uint64_t)std::atoll(e) << 20)
+      return calitas_fail(ctx, CALITAS_ENOMEM, "search buffers of " + std::to_string(want >> 20) + " MB exceed CALITAS_DEVICE_BUDGET_MB");
+  }
   if (item_cap > ctx->item_cap) {
     (void)hipFree(ctx->d_items); ctx->d_items = nullptr; ctx->item_cap = 0;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_items, (size_t)item_cap * sizeof(uint64_t)));
@@ -684,8 +690,121 @@ static std::vector<std::pair<int, int>> chunk_ranges(const PackedRef& ref, const
   return out;
 }
 
+// Frees every scratch buffer of the context and its lanes (not the reference): the state a memory-bounded retry starts from.
+static void release_scratch(calitas_ctx* ctx) {
+  (void)hipDeviceSynchronize();
+  calitas_destroy_lanes(ctx);
+  (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_raw); (void)hipFree(ctx->d_slab); (void)hipFree(ctx->d_items);
+  ctx->d_recs = nullptr; ctx->d_raw = nullptr; ctx->d_slab = nullptr; ctx->d_items = nullptr;
+  ctx->rec_cap = ctx->raw_cap = ctx->item_cap = 0; ctx->slab_cap = 0;
+  if (ctx->h_raw) { (void)hipHostFree(ctx->h_raw); ctx->h_raw = nullptr; ctx->h_raw_cap = 0; }
+  select_destroy(ctx->select); ctx->select = nullptr;
+  hits_destroy(ctx->hits); ctx->hits = nullptr; ctx->hits_names_serial = ~0ull;
+}
+
+// calitas_search_hits when one pass does not fit the device (a PAM-less search at max-guide-diffs 8 on a whole genome keeps 2.4 KB of
+// strip per scan record and yields ~27 rows per kilobase): one pass per contig, one after the other on this context's own stream,
+// every contig's text copied to the host before the next one starts; the texts are concatenated at the end (removeOverlaps groups
+// and the final sort never cross a contig).
+static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                                  const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+  const auto t_call = std::chrono::steady_clock::now();
+  SearchPlan pl;
+  int rc = plan_search(ctx, 1, guide, params, pl);
+  if (rc) return rc;
+  const PackedRef& ref = ctx->ref;
+  std::string version, stamp;
+  calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  struct Piece { char* p; size_t n; };
+  std::vector<Piece> pieces;
+  auto drop = [&] { for (auto& x : pieces) calitas_free(x.p); pieces.clear(); };
+  calitas_timing_t tm{};
+  uint64_t rows = 0;
+  std::mutex copy_mu;
+  const int n_contigs = (int)ref.contigs.size();
+  uint64_t win_lo = 0;
+  for (int c = 0; c < n_contigs; c++) {
+    const uint64_t win_n = window_count(ref.contigs[c].len, pl.step);
+    if (pl.p.chrom_index < 0 || pl.p.chrom_index == c) {
+      SearchPlan q = pl;
+      q.tile_lo = (uint32_t)(ref.contigs[c].gbase / ref.tile);
+      const uint32_t tile_hi = c + 1 < n_contigs ? (uint32_t)(ref.contigs[c + 1].gbase / ref.tile) : (uint32_t)ref.tiles.size();
+      q.n_tiles = tile_hi - q.tile_lo;
+      q.bases = ref.contigs[c].len; q.win_lo = win_lo; q.win_n = win_n;
+      LaneText lt;
+      rc = lane_rows(ctx, q, false, rs, guide_id, version, stamp, lt);
+      if (rc) { drop(); return rc; }
+      if (lt.bytes) {
+        char* piece = (char*)calitas_out_alloc_pinned((size_t)lt.bytes);
+        if (!piece) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
+        pieces.push_back(Piece{piece, (size_t)lt.bytes});
+        if (lt.on_host) std::memcpy(piece, lt.host_rows.data(), (size_t)lt.bytes);
+        else {
+          rc = text_to_host(ctx, ctx, piece, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+          if (rc) { drop(); return rc; }
+        }
+      }
+      rows += lt.rows;
+      tm.scan_kernel_ms += lt.tm.scan_kernel_ms; tm.align_kernel_ms += lt.tm.align_kernel_ms; tm.gpu_total_ms += lt.tm.gpu_total_ms;
+      tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
+      tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
+      tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+    }
+    win_lo += win_n;
+  }
+  const size_t hlen = rs.header.size();
+  size_t total = hlen;
+  for (auto& x : pieces) total += x.n;
+  char* text = (char*)(total < (4ull << 30) ? calitas_out_alloc_pinned(total + 1) : calitas_out_alloc(total + 1));   // pinning tens of GB takes longer than it saves
+  if (!text) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
+  std::memcpy(text, rs.header.data(), hlen);
+  {
+    size_t off = hlen;
+    for (auto& x : pieces) {      // piece by piece, each split over the worker pool; freed as soon as it is in place
+      char* dst = text + off;
+      const char* src = x.p;
+      ctx->pool->for_blocks(x.n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
+      off += x.n;
+      calitas_free(x.p);
+    }
+    pieces.clear();
+  }
+  text[total] = 0;
+  tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1;
+  ctx->timing = tm;
+  ctx->last_text_bytes = total;
+  if (std::getenv("CALITAS_TRACE"))
+    std::fprintf(stderr, "[calitas] search_hits: one pass per contig (%d), scan %.3f ms, align %.3f ms, text copy %.3f ms (sums), call %.3f ms (%llu rows, %zu bytes)\n",
+                 n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, tm.hits_copy_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), (unsigned long long)rows, total);
+  *tsv = text;
+  if (tsv_bytes) *tsv_bytes = total;
+  if (n_rows) *n_rows = rows;
+  return CALITAS_OK;
+}
+
+static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
+
 int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                             const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+  int rc = CALITAS_ENOMEM;
+  if (!std::getenv("CALITAS_SEQUENTIAL")) {      // (the variable forces the per-contig mode: tests)
+    rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
+    if (rc != CALITAS_ENOMEM) return rc;
+    if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
+    release_scratch(ctx);
+  }
+  *tsv = nullptr;
+  rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
+  if (rc == CALITAS_ENOMEM) release_scratch(ctx);   // leave the context usable for smaller searches
+  return rc;
+}
+
+static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
   const auto t_call = std::chrono::steady_clock::now();
   *tsv = nullptr;
   if (tsv_bytes) *tsv_bytes = 0;
@@ -956,7 +1075,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   for (auto& t : threads) t.join();
   for (int g = 0; g < n_guides; g++) {
     if (rcs[g] == CALITAS_OK) continue;
-    if (rcs[g] == CALITAS_ESTATE) {   // a lane's buffers overflowed: this guide again, in one pass with the retry logic
+    if (rcs[g] == CALITAS_ESTATE || rcs[g] == CALITAS_ENOMEM) {   // a lane's buffers overflowed / did not fit: this guide again through calitas_search_hits (retry logic, per-contig passes)
       int r = calitas_search_hits_impl(ctx, &guides[g], guide_ids && guide_ids[g] ? guide_ids[g] : "", params, version.c_str(), stamp.c_str(), &tsv[g],
                                tsv_bytes ? &tsv_bytes[g] : nullptr, n_rows ? &n_rows[g] : nullptr);
       if (r) { release(); return r; }

@@ -32,6 +32,7 @@ extern "C" {
 #define CALITAS_EHIP 3     /* HIP runtime error */
 #define CALITAS_EIO 4      /* file could not be read / written */
 #define CALITAS_ESTATE 5   /* call made in the wrong state (e.g. search before set_reference) */
+#define CALITAS_ENOMEM 6   /* a device allocation failed (calitas_search_hits answers it with one pass per contig before giving up) */
 
 #define CALITAS_MAX_PROTOSPACER 32   /* rows of the bit-vector scan kernel */
 #define CALITAS_MAX_PAMS 8

@@ -478,3 +478,36 @@ def test_parity_at_scale_60mb(C):
     assert nwin > 55000 and len(orac) > 1500
     assert_same(prod, orac, "60mb")
     ctx.close()
+
+
+def test_per_contig_passes_equal_one_pass(C, tmp_path, monkeypatch):
+    """When a search does not fit the device (CALITAS_ENOMEM from an allocation, or the buffers exceed CALITAS_DEVICE_BUDGET_MB)
+    calitas_search_hits runs one pass per contig and concatenates the texts; CALITAS_SEQUENTIAL forces that mode.  Same bytes as
+    the one-pass call, with and without --chrom, and the context stays usable."""
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    extra = [("tiny", "ACGTTGCA" * 6 + "CTTGCCCCACAGGGCAGTAATGG" + "TTGACA" * 5), ("empty-ish", "N" * 300)]
+    fa = synth_fasta(tmp_path, 47, [guide], lengths=(700000, 300000, 200000), extra=extra)
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        for kw in (dict(max_gaps_between_guide_and_pam=2), dict(max_gaps_between_guide_and_pam=2, chrom_index=1)):
+            params = C.make_params(**kw)
+            monkeypatch.setenv("CALITAS_CHUNKS", "1")
+            want = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            assert want[1] > 10
+            monkeypatch.setenv("CALITAS_SEQUENTIAL", "1")
+            assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want
+            monkeypatch.delenv("CALITAS_SEQUENTIAL")
+            monkeypatch.setenv("CALITAS_CHUNKS", "2")
+            monkeypatch.setenv("CALITAS_DEVICE_BUDGET_MB", "1")          # nothing fits, not even a contig: the call fails with ENOMEM
+            with pytest.raises(Exception, match="exceed CALITAS_DEVICE_BUDGET_MB"):
+                ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            # the buffers of a pass over everything (1.2 Mb: 1.5e5 records x 2 KB of strip) do not fit, a contig's do
+            monkeypatch.setenv("CALITAS_CHUNKS", "1")
+            monkeypatch.setenv("CALITAS_DEVICE_BUDGET_MB", "250")
+            got = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
+            assert got == want
+            monkeypatch.delenv("CALITAS_DEVICE_BUDGET_MB")
+            assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want
+    finally:
+        ctx.close()
