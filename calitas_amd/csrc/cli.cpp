@@ -15,7 +15,8 @@ static void usage() {
     "usage: calitas SearchReference -i GUIDEpam -I guide-id -r ref.fa [-o hits.txt] [-x aux-pam ...]\n"
     "         [-w window-size=1000] [-d max-guide-diffs=5] [-p max-pam-mismatches=1] [-g max-gaps-between-guide-and-pam=3]\n"
     "         [-D max-total-diffs] [-O max-overlap=10] [-m guide-mismatch-net-cost=-120] [-M pam-mismatch-net-cost=-260]\n"
-    "         [-b genome-gap-net-cost=-122] [-B guide-gap-net-cost=-121] [-c chrom] [-t threads (ignored)] [-V max-variants=16]\n"
+    "         [-b genome-gap-net-cost=-122] [-B guide-gap-net-cost=-121] [-c chrom] [-t threads (ignored)]\n"
+    "         [-v variants.vcf[.gz]] [-V max-variants=16]\n"
     "         [--device N]\n");
 }
 
@@ -32,7 +33,7 @@ static std::string long_to_short(const std::string& a) {
 
 int main(int argc, char** argv) {
   if (argc < 2 || std::strcmp(argv[1], "SearchReference") != 0) { usage(); return 2; }
-  std::string guide, guide_id, ref, output, chrom;
+  std::string guide, guide_id, ref, output, chrom, variants;
   std::vector<std::string> aux;
   calitas_params_t p;
   p.window_size = 1000; p.max_guide_diffs = 5; p.max_pam_mismatches = 1; p.max_gaps_between_guide_and_pam = 3; p.max_total_diffs = -1;
@@ -68,7 +69,7 @@ int main(int argc, char** argv) {
     else if (a == "-V") p.max_variants = std::atoi(next().c_str());
     else if (a == "-t") (void)next();
     else if (a == "--device") device = std::atoi(next().c_str());
-    else if (a == "-v") { std::fprintf(stderr, "--variants is not supported by the MI355X path yet\n"); return 2; }
+    else if (a == "-v") variants = next();
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
   }
   if (guide.empty() || guide_id.empty() || ref.empty()) { usage(); return 2; }
@@ -109,7 +110,12 @@ int main(int argc, char** argv) {
     if (p.chrom_index < 0) { std::fprintf(stderr, "Unknown chromosome: %s\n", chrom.c_str()); calitas_destroy(ctx); return 1; }
   }
   char* tsv = nullptr; uint64_t rows = 0, bytes = 0;
-  if (calitas_search_hits(ctx, &g, guide_id.c_str(), &p, nullptr, nullptr, &tsv, &bytes, &rows) != CALITAS_OK) die("search");
+  if (!variants.empty()) {   // SearchReference.scala:570-630
+    uint64_t windows = 0;
+    if (calitas_search_variants(ctx, &g, guide_id.c_str(), &p, variants.c_str(), chrom.empty() ? nullptr : chrom.c_str(), nullptr, nullptr, nullptr,
+                                &tsv, &bytes, &rows, &windows) != CALITAS_OK) die("search with variants");
+    std::fprintf(stderr, "calitas: %llu variant windows\n", (unsigned long long)windows);
+  } else if (calitas_search_hits(ctx, &g, guide_id.c_str(), &p, nullptr, nullptr, &tsv, &bytes, &rows) != CALITAS_OK) die("search");
   FILE* f = output.empty() ? stdout : std::fopen(output.c_str(), "w");
   if (!f) { std::fprintf(stderr, "cannot write %s\n", output.c_str()); return 1; }
   std::fwrite(tsv, 1, bytes, f);

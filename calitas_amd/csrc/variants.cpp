@@ -277,6 +277,63 @@ int ga_count(const char* pg, const char* pa, int len, bool lower, bool both_side
 
 struct ExtRow { int contig, start, end, score; char strand; std::string desc, row; };
 
+// MD5 (RFC 1321) of a file, hex: the second half of ReferenceHit's VCF identifier "name:md5" (RH:175-183).
+std::string md5_file(const char* path, std::string& hex) {
+  static const uint32_t K[64] = {
+    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
+    0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
+    0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
+    0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
+    0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
+    0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+  static const int R[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                            4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return std::string("cannot read ") + path;
+  uint32_t h[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+  auto block = [&](const unsigned char* p) {
+    uint32_t m[16];
+    for (int i = 0; i < 16; i++) m[i] = (uint32_t)p[4 * i] | (uint32_t)p[4 * i + 1] << 8 | (uint32_t)p[4 * i + 2] << 16 | (uint32_t)p[4 * i + 3] << 24;
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+    for (int i = 0; i < 64; i++) {
+      uint32_t fn; int g;
+      if (i < 16) { fn = (b & c) | (~b & d); g = i; }
+      else if (i < 32) { fn = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+      else if (i < 48) { fn = b ^ c ^ d; g = (3 * i + 5) & 15; }
+      else { fn = c ^ (b | ~d); g = (7 * i) & 15; }
+      const uint32_t t = a + fn + K[i] + m[g];
+      a = d; d = c; c = b;
+      b = b + ((t << R[i]) | (t >> (32 - R[i])));
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+  };
+  std::vector<unsigned char> buf(1 << 20);
+  uint64_t total = 0;
+  size_t have = 0;                                   // bytes of an incomplete block at the start of buf
+  for (;;) {
+    const size_t got = std::fread(buf.data() + have, 1, buf.size() - have, f);
+    total += got;
+    const size_t n = have + got;
+    size_t off = 0;
+    for (; off + 64 <= n; off += 64) block(buf.data() + off);
+    have = n - off;
+    std::memmove(buf.data(), buf.data() + off, have);
+    if (got == 0) break;
+  }
+  std::fclose(f);
+  unsigned char tail[128] = {0};
+  std::memcpy(tail, buf.data(), have);
+  tail[have] = 0x80;
+  const size_t tl = have < 56 ? 64 : 128;
+  const uint64_t bits = total * 8;
+  for (int i = 0; i < 8; i++) tail[tl - 8 + i] = (unsigned char)(bits >> (8 * i));
+  for (size_t off = 0; off < tl; off += 64) block(tail + off);
+  char out[33];
+  for (int i = 0; i < 16; i++) std::snprintf(out + 2 * i, 3, "%02x", (h[i / 4] >> (8 * (i % 4))) & 0xFFu);
+  hex = out;
+  return "";
+}
+
 }  // namespace
 
 extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
@@ -296,7 +353,14 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     std::string e = make_guide_host(*guide, gh);
     if (!e.empty()) return calitas_fail(ctx, CALITAS_EINVAL, e);
   }
-  const std::string gid = guide_id ? guide_id : "", vid = vcf_id ? vcf_id : "";
+  const std::string gid = guide_id ? guide_id : "";
+  std::string vid = vcf_id ? vcf_id : "";
+  if (!vcf_id) {                                                                                   // ReferenceHit.scala:175-183: file name and md5
+    std::string hex, e = md5_file(vcf_path, hex);
+    if (!e.empty()) return calitas_fail(ctx, CALITAS_EIO, e);
+    const char* slash = std::strrchr(vcf_path, '/');
+    vid = std::string(slash ? slash + 1 : vcf_path) + ":" + hex;
+  }
   std::string version, stamp;
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const int d = p.max_guide_diffs, g = p.max_gaps_between_guide_and_pam;

@@ -227,7 +227,7 @@ def search_variants(sr, ctx, vcf_path, chrom_index=-1, version=None, time_stamp=
     gq = sr.query.to_c()
     tsv, nbytes, rows, nwin = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
     _lib.check(ctx._h, lib.calitas_search_variants(ctx._h, ctypes.byref(gq), sr.guide_id.encode(), ctypes.byref(params), str(vcf_path).encode(),
-                                                   sr.chrom.encode() if sr.chrom is not None else None, vcf_identifier(vcf_path).encode(),
+                                                   sr.chrom.encode() if sr.chrom is not None else None, None,   # NULL: the library computes name:md5
                                                    version.encode() if version else None, time_stamp.encode() if time_stamp else None,
                                                    ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(rows), ctypes.byref(nwin)))
     try:

@@ -227,8 +227,8 @@ int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, c
  * lifted back with refOffsetAtBaseOffset (SearchReference.scala:133-156), window-local flanks (SearchReference.scala:598-613), the
  * variant columns of ReferenceHit.Builder.build (ReferenceHit.scala:211-233) -- merged by removeOverlaps / ReferenceHit.sort.
  * vcf_path: plain or gzip VCF, records in reference order (CHROM POS ID REF ALT FILTER INFO with AF / END); chrom: NULL or the
- * --chrom filter (params->chrom_index must name the same contig); vcf_id: the "name:md5" string of ReferenceHit.scala:175-183
- * (the caller computes it); params->max_variants = --max-variants.  *n_windows (optional) receives the number of variant windows. */
+ * --chrom filter (params->chrom_index must name the same contig); vcf_id: the "name:md5" string of ReferenceHit.scala:175-183,
+ * or NULL to have it computed from the file; params->max_variants = --max-variants.  *n_windows (optional) receives the number of variant windows. */
 int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                             const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
                             const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows, uint64_t* n_windows);

@@ -160,3 +160,25 @@ def test_many_batches_equal_python_twin(C, tmp_path):
     assert sum(1 for r in got if r["variant_id"] or r["variant_description"]) > 10
     key = lambda r: json.dumps(r, sort_keys=True)
     assert sorted(map(key, _norm(got))) == sorted(map(key, _norm(want)))      # ties between groups may come in another order (SR:656)
+
+
+def test_cpp_cli_with_variants(C, tmp_path):
+    """`calitas SearchReference --variants` (the C++ front end; the library computes the VCF's name:md5 identifier itself) writes the
+    rows the Python API returns, whose identifier comes from hashlib."""
+    import subprocess
+    from calitas_amd import variants as VV
+    e = V["e4"]
+    fa = write_fasta(str(tmp_path / "e4.fa"), [("chr1", e["chr1"])], line_len=100)
+    vcf = write_vcf(str(tmp_path / "e4.vcf"), [("chr1", p, i, r, a) for p, i, r, a in e["variants"]])
+    exe = os.path.join(os.path.dirname(os.path.abspath(C.__file__)), "calitas")
+    out = str(tmp_path / "cli.txt")
+    r = subprocess.run([exe, "SearchReference", "-i", e["guide"], "-I", "test", "-r", fa, "-v", vcf, "-o", out, "-g", "0", "-d", "0"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = C.read_hits(out)
+    sr = C.SearchReference(guide=e["guide"], guide_id="test", ref=fa, variants=vcf, max_gaps_between_guide_and_pam=0, max_guide_diffs=0)
+    want = C.read_hits(sr.run()[0])
+    strip = lambda rows: [{k: v for k, v in r.items() if k not in SKIP} for r in rows]
+    assert strip(got) == strip(want) and len(got) == e["expect"]["n"]
+    ids = {r["variant_vcf"] for r in got if r["variant_vcf"]}
+    assert ids == {VV.vcf_identifier(vcf)}                     # "e4.vcf:<md5>" from the library's own MD5 == hashlib's
