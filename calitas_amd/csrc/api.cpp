@@ -69,7 +69,7 @@ void out_free(void* p) {
   if (!p) return;
   BlockHeader* h = (BlockHeader*)p - 1;
   if (h->magic != kMagic) return;     // not ours: refuse rather than corrupt the heap
-  if (h->capacity >= (1u << 20)) {
+  if (h->capacity >= (1u << 20) && h->capacity <= kPoolBytes / 4) {   // (a block of many gigabytes would only crowd the others out)
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     g_pool.push_back(h);
     uint64_t parked = 0;
@@ -83,6 +83,20 @@ void out_free(void* p) {
   release_block(h);
 }
 }  // namespace
+// A pageable block of at least `size` bytes with the first `keep` bytes of p (a pageable block of this allocator, or NULL): realloc,
+// so growing a multi-gigabyte text moves pages instead of copying them.
+void* calitas_out_grow(void* p, size_t keep, size_t size) {
+  if (!p) return out_alloc_impl(size);
+  BlockHeader* h = (BlockHeader*)p - 1;
+  if (h->magic != kMagic || h->pinned) return nullptr;
+  if (h->capacity >= size) return p;
+  (void)keep;
+  const size_t cap = size + size / 4;
+  BlockHeader* n = (BlockHeader*)std::realloc(h, sizeof(BlockHeader) + cap);
+  if (!n) return nullptr;
+  n->capacity = cap;
+  return n + 1;
+}
 void* calitas_out_alloc(size_t size) { return out_alloc_impl(size); }
 void* calitas_out_alloc_pinned(size_t size) { return out_alloc_impl(size, true); }
 static void* out_alloc(size_t size) { return out_alloc_impl(size); }

@@ -75,6 +75,7 @@ struct calitas_ctx {
 int calitas_fail(calitas_ctx* ctx, int code, const std::string& msg);
 void* calitas_out_alloc(size_t size);
 void* calitas_out_alloc_pinned(size_t size);   // page-locked: the destination of the text copy-back
+void* calitas_out_grow(void* p, size_t keep, size_t size);   // pageable block grown in place (realloc); p may be NULL
 // search.cpp
 int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                         calitas_aln_t** out, uint64_t* n_out);

@@ -717,14 +717,22 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  struct Piece { char* p; size_t n; };
-  std::vector<Piece> pieces;
-  auto drop = [&] { for (auto& x : pieces) calitas_free(x.p); pieces.clear(); };
+  // The text grows in one pageable block (realloc: pages move, bytes are not copied); every contig's rows come over PCIe into a
+  // reused page-locked bounce buffer and from there into the block on the worker pool (page-locking 40+ GB of pieces and
+  // concatenating them afterwards took longer than the search).
+  const size_t hlen = rs.header.size();
+  char* text = (char*)calitas_out_grow(nullptr, 0, hlen + (64u << 20));
+  if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  std::memcpy(text, rs.header.data(), hlen);
+  size_t total = hlen;
+  char* bounce = nullptr;
+  size_t bounce_cap = 0;
+  auto drop = [&] { calitas_free(text); calitas_free(bounce); };
   calitas_timing_t tm{};
   uint64_t rows = 0;
   std::mutex copy_mu;
   const int n_contigs = (int)ref.contigs.size();
-  uint64_t win_lo = 0;
+  uint64_t win_lo = 0, bases_done = 0;
   for (int c = 0; c < n_contigs; c++) {
     const uint64_t win_n = window_count(ref.contigs[c].len, pl.step);
     if (pl.p.chrom_index < 0 || pl.p.chrom_index == c) {
@@ -736,15 +744,31 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       LaneText lt;
       rc = lane_rows(ctx, q, false, rs, guide_id, version, stamp, lt);
       if (rc) { drop(); return rc; }
+      bases_done += ref.contigs[c].len;
       if (lt.bytes) {
-        char* piece = (char*)calitas_out_alloc_pinned((size_t)lt.bytes);
-        if (!piece) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
-        pieces.push_back(Piece{piece, (size_t)lt.bytes});
-        if (lt.on_host) std::memcpy(piece, lt.host_rows.data(), (size_t)lt.bytes);
+        // room for this contig, and -- extrapolating from the bases done so far -- for the rest
+        const double per_base = (double)(total - hlen + lt.bytes) / (double)std::max<uint64_t>(1, bases_done);
+        const size_t guess = pl.p.chrom_index >= 0 ? 0 : (size_t)(per_base * 1.05 * (double)(ref.total_bases - bases_done));
+        char* grown = (char*)calitas_out_grow(text, total, total + (size_t)lt.bytes + 1 + guess);
+        if (!grown) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
+        text = grown;
+        if (lt.on_host) std::memcpy(text + total, lt.host_rows.data(), (size_t)lt.bytes);
         else {
-          rc = text_to_host(ctx, ctx, piece, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
-          if (rc) { drop(); return rc; }
+          const size_t kPiece = 1ull << 30;             // bounce buffer: at most 1 GB page-locked
+          for (size_t off = 0; off < (size_t)lt.bytes; off += kPiece) {
+            const size_t n = std::min(kPiece, (size_t)lt.bytes - off);
+            if (n > bounce_cap) { calitas_free(bounce); bounce = (char*)calitas_out_alloc_pinned(n); bounce_cap = bounce ? n : 0; }
+            if (!bounce) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
+            double ms = 0;
+            rc = text_to_host(ctx, ctx, bounce, lt.d_text + off, n, &copy_mu, &ms);
+            if (rc) { drop(); return rc; }
+            lt.tm.hits_copy_ms += ms;
+            char* dst = text + total + off;
+            const char* src = bounce;
+            ctx->pool->for_blocks(n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
+          }
         }
+        total += (size_t)lt.bytes;
       }
       rows += lt.rows;
       tm.scan_kernel_ms += lt.tm.scan_kernel_ms; tm.align_kernel_ms += lt.tm.align_kernel_ms; tm.gpu_total_ms += lt.tm.gpu_total_ms;
@@ -754,22 +778,11 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     }
     win_lo += win_n;
   }
-  const size_t hlen = rs.header.size();
-  size_t total = hlen;
-  for (auto& x : pieces) total += x.n;
-  char* text = (char*)(total < (4ull << 30) ? calitas_out_alloc_pinned(total + 1) : calitas_out_alloc(total + 1));   // pinning tens of GB takes longer than it saves
-  if (!text) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
-  std::memcpy(text, rs.header.data(), hlen);
+  calitas_free(bounce);
   {
-    size_t off = hlen;
-    for (auto& x : pieces) {      // piece by piece, each split over the worker pool; freed as soon as it is in place
-      char* dst = text + off;
-      const char* src = x.p;
-      ctx->pool->for_blocks(x.n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
-      off += x.n;
-      calitas_free(x.p);
-    }
-    pieces.clear();
+    char* grown = (char*)calitas_out_grow(text, total, total + 1);
+    if (!grown) { calitas_free(text); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
+    text = grown;
   }
   text[total] = 0;
   tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1;
@@ -937,6 +950,16 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       (void)hipDeviceSynchronize();
       calitas_free(text); text = nullptr;
       if (rc) return rc;
+      {
+        // the lanes counted their scan records and alignments even where they could not keep them: would one pass over everything fit?
+        uint64_t n_rec = 0, n_raw = 0;
+        for (size_t c = 0; c < K; c++) { n_rec += lanes[c]->h_counters[0]; n_raw += std::max(lanes[c]->h_counters[1], lanes[c]->h_counters[3]); }
+        // strips + records + alignments with the filter's and the row stage's scratch (~110 + ~1100 bytes each, text included)
+        const uint64_t need = n_rec * (pl.slab_per_rec + sizeof(ScanRecord)) * 5 / 4 + n_raw * (sizeof(RawAln) + 110 + 1100);
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && need > (uint64_t)mem_total * 7 / 10)
+          return fail(ctx, CALITAS_ENOMEM, "one pass would need about " + std::to_string(need >> 30) + " GB of scratch on the device");
+      }
       if (trace) std::fprintf(stderr, "[calitas] search_hits: a lane's buffers overflowed, rerunning in one pass\n");
       chunked = false;
       parts.assign(1, LaneText()); lanes.assign(1, ctx);
