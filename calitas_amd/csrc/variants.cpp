@@ -58,73 +58,78 @@ std::vector<std::string> split(const std::string& s, char sep) {
   return out;
 }
 
-// read_vcf of variants.py
-std::string read_vcf(const char* path, const char* chrom, std::vector<Var>& out) {
-  // gzip goes through zlib; plain text through stdio (gzgets costs 2-3x as much per line)
-  FILE* pf = std::fopen(path, "rb");
-  if (!pf) return std::string("cannot read ") + path;
-  unsigned char magic[2] = {0, 0};
-  const bool gz = std::fread(magic, 1, 2, pf) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-  gzFile f = nullptr;
-  if (gz) {
-    std::fclose(pf); pf = nullptr;
-    f = gzopen(path, "rb");
-    if (!f) return std::string("cannot read ") + path;
-    gzbuffer(f, 1 << 20);
-  } else {
-    std::rewind(pf);
-    std::setvbuf(pf, nullptr, _IOFBF, 1 << 20);
+// One VCF record (a line without its newline) -> v; false for headers, short lines and other chromosomes (read_vcf of variants.py).
+bool parse_record(const char* b, const char* e, const char* chrom, size_t chrom_len, Var& v) {
+  if (b >= e || *b == '#') return false;
+  // fields 0-4 and 7 (CHROM POS ID REF ALT . . INFO), located in place
+  const char* f0[9]; size_t fl[9]; int nf = 0;
+  while (nf < 9) {
+    const char* t = (const char*)std::memchr(b, '\t', (size_t)(e - b));
+    f0[nf] = b; fl[nf] = (size_t)((t ? t : e) - b); nf++;
+    if (!t) break;
+    b = t + 1;
   }
-  std::string line;
-  std::vector<char> buf(1 << 16);
-  bool eof = false;
-  while (!eof) {
-    line.clear();
-    for (;;) {                             // one line of any length
-      if (!(gz ? gzgets(f, buf.data(), (int)buf.size()) : std::fgets(buf.data(), (int)buf.size(), pf))) { eof = true; break; }
-      line += buf.data();
-      if (!line.empty() && line.back() == '\n') break;
-    }
-    if (line.empty()) continue;
-    while (!line.empty() && (line.back() == '\n')) line.pop_back();
-    if (line.empty() || line[0] == '#') continue;
-    // fields 0-4 and 7 (CHROM POS ID REF ALT . . INFO), located in place
-    const char* f0[9]; size_t fl[9]; int nf = 0;
-    {
-      const char* b = line.data(); const char* const e = b + line.size();
-      while (nf < 9) {
-        const char* t = (const char*)std::memchr(b, '\t', (size_t)(e - b));
-        f0[nf] = b; fl[nf] = (size_t)((t ? t : e) - b); nf++;
-        if (!t) break;
-        b = t + 1;
-      }
-    }
-    if (nf < 5 || (chrom && (fl[0] != std::strlen(chrom) || std::memcmp(f0[0], chrom, fl[0]) != 0))) continue;
-    Var v;
-    v.chrom.assign(f0[0], fl[0]);
-    v.pos = std::atoi(std::string(f0[1], fl[1]).c_str());
-    if (!(fl[2] == 1 && f0[2][0] == '.')) v.id.assign(f0[2], fl[2]);
-    v.ref.assign(f0[3], fl[3]);
-    v.alts = split(std::string(f0[4], fl[4]), ',');
-    bool have_end = false;
-    if (nf > 7) {
-      const std::string info(f0[7], fl[7]);
-      if (info.find("AF=") != std::string::npos || info.find("END=") != std::string::npos) {
-        for (const std::string& kv : split(info, ';')) {
-          if (kv.compare(0, 3, "AF=") == 0) {
-            v.afs.clear();
-            for (const std::string& x : split(kv.substr(3), ',')) if (x != "." && !x.empty()) v.afs.push_back((float)std::strtod(x.c_str(), nullptr));
-          } else if (kv.compare(0, 4, "END=") == 0) {
-            v.end = std::atoi(kv.c_str() + 4); have_end = true;
-          }
+  if (nf < 5 || (chrom && (fl[0] != chrom_len || std::memcmp(f0[0], chrom, fl[0]) != 0))) return false;
+  v.chrom.assign(f0[0], fl[0]);
+  v.pos = std::atoi(std::string(f0[1], fl[1]).c_str());
+  if (!(fl[2] == 1 && f0[2][0] == '.')) v.id.assign(f0[2], fl[2]);
+  v.ref.assign(f0[3], fl[3]);
+  v.alts = split(std::string(f0[4], fl[4]), ',');
+  bool have_end = false;
+  if (nf > 7) {
+    const std::string info(f0[7], fl[7]);
+    if (info.find("AF=") != std::string::npos || info.find("END=") != std::string::npos) {
+      for (const std::string& kv : split(info, ';')) {
+        if (kv.compare(0, 3, "AF=") == 0) {
+          v.afs.clear();
+          for (const std::string& x : split(kv.substr(3), ',')) if (x != "." && !x.empty()) v.afs.push_back((float)std::strtod(x.c_str(), nullptr));
+        } else if (kv.compare(0, 4, "END=") == 0) {
+          v.end = std::atoi(kv.c_str() + 4); have_end = true;
         }
       }
     }
-    if (!have_end) v.end = v.pos + (int)v.ref.size() - 1;
-    out.push_back(std::move(v));
   }
-  if (f) gzclose(f);
-  if (pf) std::fclose(pf);
+  if (!have_end) v.end = v.pos + (int)v.ref.size() - 1;
+  return true;
+}
+
+// The whole file in memory (gzip through zlib), then the lines parsed on the worker pool: every worker takes the lines that
+// start in its byte range, and the per-worker lists are joined in file order.
+std::string read_vcf(const char* path, const char* chrom, calitas::WorkerPool* pool, std::vector<Var>& out) {
+  std::string data;
+  {
+    gzFile f = gzopen(path, "rb");           // transparent for plain text
+    if (!f) return std::string("cannot read ") + path;
+    gzbuffer(f, 1 << 20);
+    std::vector<char> buf(8u << 20);
+    for (;;) {
+      const int got = gzread(f, buf.data(), (unsigned)buf.size());
+      if (got < 0) { gzclose(f); return std::string("cannot read ") + path; }
+      if (got == 0) break;
+      data.append(buf.data(), (size_t)got);
+    }
+    gzclose(f);
+  }
+  const size_t n = data.size(), chrom_len = chrom ? std::strlen(chrom) : 0;
+  std::vector<std::vector<Var>> parts((size_t)pool->size());
+  pool->for_blocks(n, [&](size_t b, size_t e, int tid) {
+    const char* const base = data.data();
+    const char* const end = base + n;
+    const char* p = base + b;
+    if (b > 0) { const char* nl = (const char*)std::memchr(base + b - 1, '\n', n - (b - 1)); p = nl ? nl + 1 : end; }   // first line start >= b
+    std::vector<Var>& mine = parts[(size_t)tid];
+    while (p < base + e) {
+      const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+      const char* le = nl ? nl : end;
+      Var v;
+      if (parse_record(p, le, chrom, chrom_len, v)) mine.push_back(std::move(v));
+      p = le + 1;
+    }
+  });
+  size_t total = 0;
+  for (auto& v : parts) total += v.size();
+  out.reserve(out.size() + total);
+  for (auto& v : parts) { for (auto& x : v) out.push_back(std::move(x)); std::vector<Var>().swap(v); }
   return "";
 }
 
@@ -167,14 +172,13 @@ void upper_span(const PackedRef& ref, int contig, long s, long e, std::string& o
 }
 
 // buildVariantWindow SR:263-323
-std::string build_window(const std::vector<const Var*>& variants, const std::vector<int>& alleles, int contig, const PackedRef& ref,
-                         int padding, Window& w) {
-  const int window_start = std::max(1, variants.front()->pos - padding);
-  const int window_end = std::min((int)ref.contigs[contig].len, variants.back()->end + padding);
+std::string build_window(const Var* const* variants, const int* alleles, size_t nv, int contig, const PackedRef& ref, int padding, Window& w) {
+  const int window_start = std::max(1, variants[0]->pos - padding);
+  const int window_end = std::min((int)ref.contigs[contig].len, variants[nv - 1]->end + padding);
   w.contig = contig; w.start = window_start;
   upper_span(ref, contig, window_start - 1, std::max(window_start - 1, window_end), w.bases);
   w.variants.clear(); w.cigar.clear();
-  for (size_t i = 0; i < variants.size(); i++) {
+  for (size_t i = 0; i < nv; i++) {
     const Var* v = variants[i];
     const int a = alleles[i] - 1;
     w.variants.push_back(Allele{v, a, (size_t)a < v->afs.size() ? v->afs[a] : 0.0f});
@@ -381,7 +385,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   std::vector<Var> vcf;
   {
     const auto t0 = std::chrono::steady_clock::now();
-    std::string e = read_vcf(vcf_path, chrom, vcf);
+    std::string e = read_vcf(vcf_path, chrom, ctx->pool, vcf);
     ms_parse = ms_since(t0);
     if (!e.empty()) { calitas_free(ref_alns); return calitas_fail(ctx, CALITAS_EIO, e); }
   }
@@ -510,7 +514,33 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     return CALITAS_OK;
   };
 
-  // variantWindowIterator SR:217-256 with nextChunk / reChunk SR:326-347
+  // variantWindowIterator SR:217-256 with nextChunk / reChunk SR:326-347.  The iterator itself only lists what each window is made
+  // of (variants and alleles); a full batch of windows is then built on the worker pool and handed to the GPU.
+  std::vector<uint32_t> spec_off{0};
+  std::vector<const Var*> spec_v;
+  std::vector<int> spec_a, spec_contig;
+  auto build_and_flush = [&]() -> int {
+    nb = spec_contig.size();
+    if (nb == 0) return CALITAS_OK;
+    std::vector<std::string> errs((size_t)ctx->pool->size());
+    ctx->pool->for_blocks(nb, [&](size_t b, size_t e, int tid) {
+      for (size_t k = b; k < e && errs[(size_t)tid].empty(); k++)
+        errs[(size_t)tid] = build_window(spec_v.data() + spec_off[k], spec_a.data() + spec_off[k], spec_off[k + 1] - spec_off[k], spec_contig[k], ref,
+                                         padding, batch[k]);
+    });
+    for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
+    spec_off.assign(1, 0u); spec_v.clear(); spec_a.clear(); spec_contig.clear();
+    if (!err.empty()) { nb = 0; return CALITAS_OK; }
+    return flush();
+  };
+  auto emit = [&](const Var* const* vs, const int* al, size_t nv, int contig) -> int {
+    spec_v.insert(spec_v.end(), vs, vs + nv);
+    spec_a.insert(spec_a.end(), al, al + nv);
+    spec_off.push_back((uint32_t)spec_v.size());
+    spec_contig.push_back(contig);
+    windows_total++;
+    return spec_contig.size() >= kBatch ? build_and_flush() : CALITAS_OK;
+  };
   const int max_variants = p.max_variants;
   size_t ci = 0, i = 0;
   while (i < vcf.size() && err.empty() && rc == CALITAS_OK) {
@@ -522,24 +552,13 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     if (ci >= order.size()) { err = "next on empty iterator (VCF contig " + chunk[0]->chrom + " not in reference order)"; break; }
     int contig = -1;
     for (size_t k = 0; k < ref.names.size(); k++) if (ref.names[k] == order[ci]) { contig = (int)k; break; }
-    for (size_t s = 0; s < chunk.size() && err.empty(); s++) {
+    for (size_t s = 0; s < chunk.size() && err.empty() && rc == CALITAS_OK; s++) {
       std::vector<const Var*> sub;
       for (size_t k = s; k < chunk.size(); k++) { if (chunk[k]->pos - chunk[s]->end > padding) break; sub.push_back(chunk[k]); }
       // alleleCombos SR:351-369
-      if ((int)sub.size() > max_variants) {
+      if ((int)sub.size() > max_variants || sub.size() == 1) {       // (a single variant: the same windows, without the tables)
         const Var* v = sub[0];
-        for (size_t a = 0; a < v->alts.size() && err.empty(); a++) {
-          err = build_window({v}, {(int)a + 1}, contig, ref, padding, batch[nb++]);
-          windows_total++;
-          if (nb >= kBatch) { rc = flush(); if (rc) break; }
-        }
-      } else if (sub.size() == 1) {                                                                // the common case, without the tables
-        const Var* v = sub[0];
-        for (size_t a = 0; a < v->alts.size() && err.empty(); a++) {
-          err = build_window({v}, {(int)a + 1}, contig, ref, padding, batch[nb++]);
-          windows_total++;
-          if (nb >= kBatch) { rc = flush(); if (rc) break; }
-        }
+        for (size_t a = 0; a < v->alts.size() && err.empty() && rc == CALITAS_OK; a++) { const int al = (int)a + 1; rc = emit(&v, &al, 1, contig); }
       } else {
         std::vector<int> counts;
         for (const Var* v : sub) counts.push_back(1 + (int)v->alts.size());
@@ -547,16 +566,13 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
           std::vector<const Var*> sv; std::vector<int> sa;
           for (size_t k = 0; k < sub.size(); k++) if (alleles[k] != 0) { sv.push_back(sub[k]); sa.push_back(alleles[k]); }
           if (sv.empty() || !is_valid(sv)) continue;
-          err = build_window(sv, sa, contig, ref, padding, batch[nb++]);
-          windows_total++;
-          if (!err.empty()) break;
-          if (nb >= kBatch) { rc = flush(); if (rc) break; }
+          rc = emit(sv.data(), sa.data(), sv.size(), contig);
+          if (rc || !err.empty()) break;
         }
       }
-      if (rc) break;
     }
   }
-  if (rc == CALITAS_OK && err.empty()) rc = flush();
+  if (rc == CALITAS_OK && err.empty()) rc = build_and_flush();
   if (rc != CALITAS_OK || !err.empty()) {
     calitas_free(ref_alns);
     return rc != CALITAS_OK ? rc : calitas_fail(ctx, CALITAS_EINVAL, err);
