@@ -161,7 +161,9 @@ int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
  * the device -- the per-window filter, removeOverlaps, both sorts and the row text are produced by kernels and only the
  * finished hits.txt text (header + rows, NUL-terminated, *tsv_bytes without the NUL) is copied back.  Byte-identical to
  * calitas_search + calitas_hits_tsv; when a device stage cannot represent a search the host
- * implementation of that stage finishes the call.  aligner_version / time_stamp as in calitas_hits_tsv. */
+ * implementation of that stage finishes the call, and when the buffers of a pass over the whole reference do not fit the
+ * device (very permissive searches) the call runs one pass per contig instead (CALITAS_ENOMEM only if a single contig does
+ * not fit).  aligner_version / time_stamp as in calitas_hits_tsv. */
 int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                         const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
 
