@@ -1,5 +1,6 @@
 // api.cpp -- C ABI of libcalitas_hip.so (include/calitas_hip.h): context, reference upload, the search pipeline.
 #include <hip/hip_runtime_api.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -95,6 +96,10 @@ void* calitas_out_grow(void* p, size_t keep, size_t size) {
   BlockHeader* n = (BlockHeader*)std::realloc(h, sizeof(BlockHeader) + cap);
   if (!n) return nullptr;
   n->capacity = cap;
+  if (cap >= (1ull << 30)) {   // tens of gigabytes are about to be touched for the first time: ask for huge pages (512x fewer faults)
+    const uintptr_t lo = ((uintptr_t)n + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)n + sizeof(BlockHeader) + cap) & ~(uintptr_t)4095;
+    if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+  }
   return n + 1;
 }
 void* calitas_out_alloc(size_t size) { return out_alloc_impl(size); }
