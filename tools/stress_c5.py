@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config-5 shape without the VCF: PAM-less 20-mer, max-guide-diffs 8, on a synthetic genome of the given scale.
-Usage: python3 tools/stress_c5.py SCALE [d]"""
+Usage: python3 tools/stress_c5.py SCALE [d] [calls]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,7 @@ ctx = C.Context(0)
 ctx.set_reference(names, seqs, genome_build="synthetic")
 g = C.Guide("GTGACTTGAAGTCTCAGTAT")
 p = C.make_params(max_guide_diffs=d, max_pam_mismatches=0, max_gaps_between_guide_and_pam=3)
-for it in range(2):
+for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 2):
     t = time.perf_counter()
     try:
         nbytes, rows = ctx.search_hits(g, "c5", p, "v", "t", decode=False)
