@@ -4,7 +4,12 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl
-timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o run -- python3 "$ROOT/bench.py" --cpu-sample-mb 0 --steps 3 --warmup 1 "$@" > /tmp/tl.log 2>&1 < /dev/null
+# TIMELINE_PROG=tools/c2_speed.py: another driver than bench.py (the timeline then starts at its last scan kernel)
+if [ -n "$TIMELINE_PROG" ]; then
+  timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o run -- python3 "$ROOT/$TIMELINE_PROG" "$@" > /tmp/tl.log 2>&1 < /dev/null
+else
+  timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o run -- python3 "$ROOT/bench.py" --cpu-sample-mb 0 --steps 3 --warmup 1 "$@" > /tmp/tl.log 2>&1 < /dev/null
+fi
 python3 - /tmp/tl "$ROOT/gpurun_out/timeline.txt" <<'PY'
 import csv, glob, sys
 d, out = sys.argv[1], sys.argv[2]
@@ -30,6 +35,8 @@ ev.sort()
 # the last call starts at the last-but-one scan_kernel launch group: find the last two scan kernels
 scans = [e for e in ev if e[3].startswith("void scan_kernel") or "scan_kernel" in e[3]]
 t0 = scans[-2][0] if len(scans) >= 2 else ev[0][0]
+if os.environ.get("TIMELINE_PROG"):
+    t0 = scans[-1][0]
 with open(out, "w") as f:
     for s, e, q, n in ev:
         if s < t0:
