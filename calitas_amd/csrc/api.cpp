@@ -141,7 +141,9 @@ int calitas_create(int device_id, calitas_ctx** out) {
       return fail(nullptr, CALITAS_ENODEV, "no HIP device available (the product path has no CPU fallback)");
     }
     if (device_id >= n) { delete c; return fail(nullptr, CALITAS_ENODEV, "device index out of range"); }
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+    // non-blocking, like the lanes' streams: nothing here relies on the null stream, and an application's own default-stream work
+    // (PyTorch) neither waits for a search nor holds one up
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
       std::string m = hipGetErrorString(e);
       delete c;
       return fail(nullptr, CALITAS_EHIP, "device init failed: " + m);
