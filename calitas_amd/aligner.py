@@ -260,6 +260,30 @@ class Context:
         lib.calitas_free(tsv)
         return text, rows.value
 
+    def search_hits_stream(self, guide, guide_id, params, write, version=None, time_stamp=None):
+        """calitas_search_hits_stream: `write(memoryview)` receives consecutive pieces of hits.txt (one piece when the search fits
+        one call; header, then per-contig pieces when it does not fit the device).  A piece is the library's own buffer, valid only
+        during the call -- file.write() takes it as it is, bytes(piece) keeps a copy.  Returns (n_bytes, n_rows)."""
+        g = guide.to_c()
+        nbytes, rows = ctypes.c_uint64(), ctypes.c_uint64()
+        failure = []
+
+        def sink(piece, n, _user):
+            try:
+                write(memoryview((ctypes.c_char * n).from_address(piece)).cast("B"))
+                return 0
+            except Exception as e:          # an exception must not cross the C frames
+                failure.append(e)
+                return 1
+        cb = _lib.TextSink(sink)
+        rc = lib.calitas_search_hits_stream(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params),
+                                            version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                            cb, None, ctypes.byref(nbytes), ctypes.byref(rows))
+        if failure:
+            raise failure[0]
+        _lib.check(self._h, rc)
+        return nbytes.value, rows.value
+
     @contextlib.contextmanager
     def search_hits_view(self, guide, guide_id, params, version=None, time_stamp=None):
         """calitas_search_hits without a copy: yields (memoryview over the library's text buffer, n_rows); the buffer is

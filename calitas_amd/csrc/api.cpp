@@ -200,6 +200,7 @@ void calitas_destroy(calitas_ctx* c) {
 
 static int upload_reference(calitas_ctx* ctx) {
   ctx->ref_serial++;
+  ctx->seq_pams = -1;               // what did not fit the old reference may fit this one
   if (ctx->device >= 0) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     free_reference_device(ctx);
@@ -381,6 +382,16 @@ int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const ch
   if (!ctx) return CALITAS_EINVAL;
   if (!guide || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "NULL argument");
   return calitas_search_hits_impl(ctx, guide, guide_id ? guide_id : "", params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
+}
+
+int calitas_search_hits_stream(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                               const char* aligner_version, const char* time_stamp, calitas_text_sink_t sink, void* user,
+                               uint64_t* tsv_bytes, uint64_t* n_rows) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!guide || !params || !sink) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  if (tsv_bytes) *tsv_bytes = 0;
+  if (n_rows) *n_rows = 0;
+  return calitas_search_hits_stream_impl(ctx, guide, guide_id ? guide_id : "", params, aligner_version, time_stamp, sink, user, tsv_bytes, n_rows);
 }
 
 int calitas_search_hits_batch(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,

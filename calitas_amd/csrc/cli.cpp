@@ -115,10 +115,13 @@ int main(int argc, char** argv) {
     if (calitas_search_variants(ctx, &g, guide_id.c_str(), &p, variants.c_str(), chrom.empty() ? nullptr : chrom.c_str(), nullptr, nullptr, nullptr,
                                 &tsv, &bytes, &rows, &windows) != CALITAS_OK) die("search with variants");
     std::fprintf(stderr, "calitas: %llu variant windows\n", (unsigned long long)windows);
-  } else if (calitas_search_hits(ctx, &g, guide_id.c_str(), &p, nullptr, nullptr, &tsv, &bytes, &rows) != CALITAS_OK) die("search");
+  }
   FILE* f = output.empty() ? stdout : std::fopen(output.c_str(), "w");
   if (!f) { std::fprintf(stderr, "cannot write %s\n", output.c_str()); return 1; }
-  std::fwrite(tsv, 1, bytes, f);
+  if (variants.empty()) {     // straight to the file: a hits.txt of tens of gigabytes (PAM-less, many diffs) is never held in memory
+    auto to_file = [](const char* piece, uint64_t n, void* user) -> int { return std::fwrite(piece, 1, n, (FILE*)user) == n ? 0 : 1; };
+    if (calitas_search_hits_stream(ctx, &g, guide_id.c_str(), &p, nullptr, nullptr, to_file, f, &bytes, &rows) != CALITAS_OK) die("search");
+  } else std::fwrite(tsv, 1, bytes, f);
   if (f != stdout) std::fclose(f);
   calitas_timing_t tm; calitas_get_timing(ctx, &tm);
   std::fprintf(stderr, "calitas: %llu hits; scan %.3f ms, align %.3f ms, filter + rows %.3f ms, text copy %.3f ms (%u lane%s)\n",

@@ -64,6 +64,9 @@ struct calitas_ctx {
   hipEvent_t t_scan0 = nullptr, t_scan1 = nullptr;   // the two events that bracket the last scan kernel (ev[0] / ev[1], or scan_done events)
   hipEvent_t rows_ready = nullptr;  // lane: recorded on its stream after its row kernels
   uint64_t last_text_bytes = 0;
+  // the last search that had to run one pass per contig: protospacer length, number of PAMs, minGuideScore (a search at least as
+  // permissive goes there directly instead of finding out again)
+  int seq_L = 0, seq_pams = -1, seq_min_score = 0;
   std::mutex host_mu;               // host stages of concurrent lanes take turns on the worker pool
   DmaCopier dma;                    // parent: SDMA copies of the finished text (dma.hpp)
   bool dma_tried = false;
@@ -81,6 +84,9 @@ int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_
                         calitas_aln_t** out, uint64_t* n_out);
 int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                              const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
+int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                                    const char* aligner_version, const char* time_stamp, calitas_text_sink_t sink, void* user,
+                                    uint64_t* tsv_bytes, uint64_t* n_rows);
 int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
                                    const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
                                    uint64_t* tsv_bytes, uint64_t* n_rows);

@@ -706,8 +706,11 @@ static void release_scratch(calitas_ctx* ctx) {
 // strip per scan record and yields ~27 rows per kilobase): one pass per contig, one after the other on this context's own stream,
 // every contig's text copied to the host before the next one starts; the texts are concatenated at the end (removeOverlaps groups
 // and the final sort never cross a contig).
+// With a sink the pieces (header, then every contig's rows in at most 1 GB portions) are handed over as they arrive instead of being
+// collected: no text block at all, *tsv stays NULL.
 static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
-                                  const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+                                  const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
+                                  calitas_text_sink_t sink = nullptr, void* sink_user = nullptr) {
   const auto t_call = std::chrono::steady_clock::now();
   SearchPlan pl;
   int rc = plan_search(ctx, 1, guide, params, pl);
@@ -721,9 +724,10 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   // reused page-locked bounce buffer and from there into the block on the worker pool (page-locking 40+ GB of pieces and
   // concatenating them afterwards took longer than the search).
   const size_t hlen = rs.header.size();
-  char* text = (char*)calitas_out_grow(nullptr, 0, hlen + (64u << 20));
-  if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
-  std::memcpy(text, rs.header.data(), hlen);
+  char* text = sink ? nullptr : (char*)calitas_out_grow(nullptr, 0, hlen + (64u << 20));
+  if (!sink && !text) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  if (text) std::memcpy(text, rs.header.data(), hlen);
+  else if (sink(rs.header.data(), hlen, sink_user) != 0) return fail(ctx, CALITAS_EIO, "the text sink reported an error");
   size_t total = hlen;
   char* bounce = nullptr;
   size_t bounce_cap = 0;
@@ -733,6 +737,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   std::mutex copy_mu;
   const int n_contigs = (int)ref.contigs.size();
   uint64_t win_lo = 0, bases_done = 0;
+  double ms_rows = 0;              // inside lane_rows: kernels, their host round trips and every (re)allocation of scratch
   for (int c = 0; c < n_contigs; c++) {
     const uint64_t win_n = window_count(ref.contigs[c].len, pl.step);
     if (pl.p.chrom_index < 0 || pl.p.chrom_index == c) {
@@ -742,18 +747,24 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       q.n_tiles = tile_hi - q.tile_lo;
       q.bases = ref.contigs[c].len; q.win_lo = win_lo; q.win_n = win_n;
       LaneText lt;
+      const auto t_rows = std::chrono::steady_clock::now();
       rc = lane_rows(ctx, q, false, rs, guide_id, version, stamp, lt);
       if (rc) { drop(); return rc; }
+      ms_rows += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count();
       bases_done += ref.contigs[c].len;
       if (lt.bytes) {
         // room for this contig, and -- extrapolating from the bases done so far -- for the rest
         const double per_base = (double)(total - hlen + lt.bytes) / (double)std::max<uint64_t>(1, bases_done);
         const size_t guess = pl.p.chrom_index >= 0 ? 0 : (size_t)(per_base * 1.05 * (double)(ref.total_bases - bases_done));
-        char* grown = (char*)calitas_out_grow(text, total, total + (size_t)lt.bytes + 1 + guess);
-        if (!grown) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
-        text = grown;
-        if (lt.on_host) std::memcpy(text + total, lt.host_rows.data(), (size_t)lt.bytes);
-        else {
+        if (!sink) {
+          char* grown = (char*)calitas_out_grow(text, total, total + (size_t)lt.bytes + 1 + guess);
+          if (!grown) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
+          text = grown;
+        }
+        if (lt.on_host) {
+          if (!sink) std::memcpy(text + total, lt.host_rows.data(), (size_t)lt.bytes);
+          else if (sink(lt.host_rows.data(), lt.bytes, sink_user) != 0) { drop(); return fail(ctx, CALITAS_EIO, "the text sink reported an error"); }
+        } else {
           const size_t kPiece = 1ull << 30;             // bounce buffer: at most 1 GB page-locked
           for (size_t off = 0; off < (size_t)lt.bytes; off += kPiece) {
             const size_t n = std::min(kPiece, (size_t)lt.bytes - off);
@@ -763,6 +774,10 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
             rc = text_to_host(ctx, ctx, bounce, lt.d_text + off, n, &copy_mu, &ms);
             if (rc) { drop(); return rc; }
             lt.tm.hits_copy_ms += ms;
+            if (sink) {
+              if (sink(bounce, n, sink_user) != 0) { drop(); return fail(ctx, CALITAS_EIO, "the text sink reported an error"); }
+              continue;
+            }
             char* dst = text + total + off;
             const char* src = bounce;
             ctx->pool->for_blocks(n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
@@ -779,18 +794,18 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     win_lo += win_n;
   }
   calitas_free(bounce);
-  {
+  if (!sink) {
     char* grown = (char*)calitas_out_grow(text, total, total + 1);
     if (!grown) { calitas_free(text); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
     text = grown;
+    text[total] = 0;
   }
-  text[total] = 0;
   tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1;
   ctx->timing = tm;
   ctx->last_text_bytes = total;
   if (std::getenv("CALITAS_TRACE"))
-    std::fprintf(stderr, "[calitas] search_hits: one pass per contig (%d), scan %.3f ms, align %.3f ms, text copy %.3f ms (sums), call %.3f ms (%llu rows, %zu bytes)\n",
-                 n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, tm.hits_copy_ms,
+    std::fprintf(stderr, "[calitas] search_hits: one pass per contig (%d), scan %.3f ms, align %.3f ms, all device stages incl. allocation %.3f ms, text copy %.3f ms (sums), call %.3f ms (%llu rows, %zu bytes)\n",
+                 n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, ms_rows, tm.hits_copy_ms,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), (unsigned long long)rows, total);
   *tsv = text;
   if (tsv_bytes) *tsv_bytes = total;
@@ -801,18 +816,58 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
 static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
 
+// Whether this search is known not to fit one pass: forced (CALITAS_SEQUENTIAL, tests), or at least as permissive as the last one on
+// this context that did not.  remember = true records the search as such.
+static bool known_not_to_fit(calitas_ctx* ctx, const calitas_guide_t* guide, const calitas_params_t* params, bool remember) {
+  if (!remember && std::getenv("CALITAS_SEQUENTIAL")) return true;
+  SearchPlan pl;
+  if (!guide || !params || plan_search(ctx, 1, guide, params, pl) != CALITAS_OK) return false;
+  const GuideDev& g = pl.gd[0];
+  if (remember) { ctx->seq_L = g.L; ctx->seq_pams = g.n_pams; ctx->seq_min_score = g.min_guide_score; return true; }
+  return params->chrom_index < 0 && ctx->seq_pams == g.n_pams && ctx->seq_L == g.L && g.min_guide_score <= ctx->seq_min_score;
+}
+
 int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                             const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
   int rc = CALITAS_ENOMEM;
-  if (!std::getenv("CALITAS_SEQUENTIAL")) {      // (the variable forces the per-contig mode: tests)
+  if (!known_not_to_fit(ctx, guide, params, false)) {
     rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
     if (rc != CALITAS_ENOMEM) return rc;
     if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
     release_scratch(ctx);
+    (void)known_not_to_fit(ctx, guide, params, true);
   }
   *tsv = nullptr;
   rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
   if (rc == CALITAS_ENOMEM) release_scratch(ctx);   // leave the context usable for smaller searches
+  return rc;
+}
+
+// calitas_search_hits_stream: the text goes to `sink` -- in one piece when the search fits one call, header and per-contig pieces
+// otherwise (no block of the size of the whole text is ever allocated then).
+int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                                    const char* aligner_version, const char* time_stamp, calitas_text_sink_t sink, void* user,
+                                    uint64_t* tsv_bytes, uint64_t* n_rows) {
+  char* text = nullptr;
+  uint64_t bytes = 0, rows = 0;
+  int rc = CALITAS_ENOMEM;
+  if (!known_not_to_fit(ctx, guide, params, false)) {
+    rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, &bytes, &rows);
+    if (rc == CALITAS_OK) {
+      const int s = sink(text, bytes, user);
+      calitas_free(text);
+      if (s != 0) return fail(ctx, CALITAS_EIO, "the text sink reported an error");
+      if (tsv_bytes) *tsv_bytes = bytes;
+      if (n_rows) *n_rows = rows;
+      return CALITAS_OK;
+    }
+    if (rc != CALITAS_ENOMEM) return rc;
+    if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
+    release_scratch(ctx);
+    (void)known_not_to_fit(ctx, guide, params, true);
+  }
+  rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, tsv_bytes, n_rows, sink, user);
+  if (rc == CALITAS_ENOMEM) release_scratch(ctx);
   return rc;
 }
 

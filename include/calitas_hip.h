@@ -223,6 +223,16 @@ int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, c
                          const calitas_aln_t* alns, uint64_t n_alns, const calitas_ext_hit_t* ext, uint64_t n_ext,
                          const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* n_rows);
 
+/* calitas_search_hits with the text handed to a callback instead of returned in one block (Metric.writer's output stream,
+ * SearchReference.scala:646-648): `sink` receives consecutive pieces of hits.txt -- the whole text in one piece when the search fits
+ * one call, the header and then every contig's rows (in portions of at most 1 GB) when it runs one pass per contig; a piece is
+ * valid only during the call.  A non-zero return of the sink aborts the search with CALITAS_EIO.  For searches whose hits.txt has
+ * tens of gigabytes this avoids holding it in memory. */
+typedef int (*calitas_text_sink_t)(const char* piece, uint64_t bytes, void* user);
+int calitas_search_hits_stream(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                               const char* aligner_version, const char* time_stamp, calitas_text_sink_t sink, void* user,
+                               uint64_t* tsv_bytes, uint64_t* n_rows);
+
 /* SearchReference.execute with --variants (SearchReference.scala:570-648), end to end: the reference hits of calitas_search plus
  * the hits of every variant window -- variantWindowIterator / nextChunk / reChunk / alleleCombos / buildVariantWindow
  * (SearchReference.scala:217-399) on the host, the windows aligned on the GPU in batches (the calitas_align_windows path), coordinates

@@ -511,3 +511,30 @@ def test_per_contig_passes_equal_one_pass(C, tmp_path, monkeypatch):
             assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want
     finally:
         ctx.close()
+
+
+def test_search_hits_stream(C, tmp_path, monkeypatch):
+    """calitas_search_hits_stream hands the text to a callback: one piece when the search fits one call, header + per-contig pieces
+    in the per-contig mode; the pieces concatenate to calitas_search_hits' text either way; a failing sink fails the call."""
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    fa = synth_fasta(tmp_path, 59, [guide], lengths=(60000, 25000, 40000))
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        params = C.make_params(max_gaps_between_guide_and_pam=2)
+        want, n = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp", decode="bytes")
+        for sequential in (False, True):
+            if sequential:
+                monkeypatch.setenv("CALITAS_SEQUENTIAL", "1")
+            pieces = []
+            nbytes, rows = ctx.search_hits_stream(C.Guide(guide), "a", params, lambda mv: pieces.append(bytes(mv)), "v0", "stamp")
+            assert b"".join(pieces) == want and (nbytes, rows) == (len(want), n)
+            assert len(pieces) == (1 if not sequential else 1 + 3)        # header + one piece per contig with hits
+        def broken(_piece):
+            raise IOError("disk full")
+        with pytest.raises(IOError):
+            ctx.search_hits_stream(C.Guide(guide), "a", params, broken, "v0", "stamp")
+        monkeypatch.delenv("CALITAS_SEQUENTIAL")
+        assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp", decode="bytes") == (want, n)
+    finally:
+        ctx.close()

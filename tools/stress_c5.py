@@ -18,7 +18,14 @@ p = C.make_params(max_guide_diffs=d, max_pam_mismatches=0, max_gaps_between_guid
 for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 2):
     t = time.perf_counter()
     try:
-        nbytes, rows = ctx.search_hits(g, "c5", p, "v", "t", decode=False)
+        if os.environ.get("STRESS_STREAM"):          # calitas_search_hits_stream: pieces are counted and dropped
+            got = [0]
+            def take(piece):
+                got[0] += len(piece)
+            nbytes, rows = ctx.search_hits_stream(g, "c5", p, take, "v", "t")
+            assert got[0] == nbytes
+        else:
+            nbytes, rows = ctx.search_hits(g, "c5", p, "v", "t", decode=False)
     except Exception as e:
         print("FAILED after %.1f ms: %s" % ((time.perf_counter() - t) * 1e3, e)); break
     tm = ctx.timing()
