@@ -237,6 +237,40 @@ class Context:
         _lib.check(self._h, lib.calitas_search(self._h, n, arr, ctypes.byref(params), ctypes.byref(out), ctypes.byref(cnt)))
         return out, cnt.value
 
+    def scan_candidates(self, guides, params):
+        """calitas_scan_candidates: the candidate filter alone.  Returns a sorted list of (contig_index, contig_offset, pass, guide):
+        one entry per end column whose seamless glocal bottom-row score reaches minGuideScore (pass 0 = target as is, the column
+        is the alignment's last base; pass 1 = reverse-complemented target, the column is its first base in contig coordinates).
+        Columns in the padding behind a contig are dropped."""
+        import bisect
+        n = len(guides)
+        keep = [g.to_c() for g in guides]
+        arr = (GuideT * n)(*keep)
+        out, cnt = ctypes.POINTER(ctypes.c_uint32)(), ctypes.c_uint64()
+        _lib.check(self._h, lib.calitas_scan_candidates(self._h, n, arr, ctypes.byref(params), ctypes.byref(out), ctypes.byref(cnt)))
+        try:
+            words = out[:2 * cnt.value]
+        finally:
+            lib.calitas_free(out)
+        nc = self.reference_info()["n_contigs"]
+        bases, lens = [], []
+        for i in range(nc):
+            g, nm, ln = ctypes.c_uint64(), ctypes.c_char_p(), ctypes.c_uint64()
+            _lib.check(self._h, lib.calitas_contig_packed_base(self._h, i, ctypes.byref(g)))
+            _lib.check(self._h, lib.calitas_contig_name(self._h, i, ctypes.byref(nm), ctypes.byref(ln)))
+            bases.append(g.value); lens.append(ln.value)
+        res = []
+        for k in range(cnt.value):
+            gword, info = words[2 * k], words[2 * k + 1]
+            c = bisect.bisect_right(bases, gword * 16) - 1
+            for b in range(16):
+                if (info >> b) & 1:
+                    off = gword * 16 + b - bases[c]
+                    if 0 <= off < lens[c]:
+                        res.append((c, off, (info >> 16) & 1, (info >> 17) & 0x7F))
+        res.sort()
+        return res
+
     def search(self, guides, params):
         """Per-window accepted alignments of every guide, in the reference's order (list of Alignment)."""
         out, n = self.search_raw(guides, params)

@@ -188,7 +188,6 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap; aa.tile_words = (uint32_t)(ref.tile / 16);
       aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = slab_bytes; aa.slots_per_rec = slots_per_rec;
       aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
-      aa.debug_skip = 0;
       aa.sp.window_size = (int)W; aa.sp.step = (int)W; aa.sp.n_guides = ns;
       aa.sp.max_guide_diffs = 0; aa.sp.max_pam_mismatches = 0; aa.sp.max_diffs_filtering = 0;   // per-guide values live in GuideDev
       aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;

@@ -114,9 +114,9 @@ static int fail(calitas_ctx* ctx, int code, const std::string& msg) { return cal
 
 static void free_reference_device(calitas_ctx* c) {
   if (c->device < 0) return;
-  (void)hipFree(c->d_codes); (void)hipFree(c->d_mask); (void)hipFree(c->d_runs); (void)hipFree(c->d_contigs); (void)hipFree(c->d_tiles); (void)hipFree(c->d_tile_list); (void)hipFree(c->d_win_base); (void)hipFree(c->d_win);
+  (void)hipFree(c->d_codes); (void)hipFree(c->d_planes); (void)hipFree(c->d_mask); (void)hipFree(c->d_runs); (void)hipFree(c->d_contigs); (void)hipFree(c->d_tiles); (void)hipFree(c->d_tile_list); (void)hipFree(c->d_win_base); (void)hipFree(c->d_win);
   c->d_win_base = nullptr; c->d_win = nullptr; c->win_cap = 0; c->win_W = c->win_step = 0;
-  c->d_codes = c->d_mask = nullptr; c->d_runs = nullptr; c->d_contigs = nullptr; c->d_tiles = nullptr; c->d_tile_list = nullptr;
+  c->d_codes = c->d_mask = nullptr; c->d_planes = nullptr; c->d_runs = nullptr; c->d_contigs = nullptr; c->d_tiles = nullptr; c->d_tile_list = nullptr;
 }
 
 extern "C" {
@@ -198,29 +198,55 @@ void calitas_destroy(calitas_ctx* c) {
   delete c;
 }
 
+static int upload_reference_device(calitas_ctx* ctx) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // searches of the old reference may still be queued on the lanes' streams: nothing of it may be freed under them
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  free_reference_device(ctx);
+  const PackedRef& r = ctx->ref;
+  size_t nruns = std::max<size_t>(1, r.runs.size());
+  if (const char* e = std::getenv("CALITAS_DEVICE_BUDGET_MB")) {   // the budget a caller sharing the card sets covers the reference too
+    const uint64_t want = (uint64_t)r.codes.size() * 8 + (uint64_t)r.mask.size() * 4 + nruns * sizeof(Run) + r.tiles.size() * sizeof(TileInfo);
+    if (want > (uint64_t)std::atoll(e) << 20)
+      return fail(ctx, CALITAS_ENOMEM, "the packed reference (" + std::to_string(want >> 20) + " MB on the device) exceeds CALITAS_DEVICE_BUDGET_MB");
+  }
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_codes, r.codes.size() * 4));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_planes, r.codes.size() * 4));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mask, r.mask.size() * 4));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_runs, nruns * sizeof(Run)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_contigs, r.contigs.size() * sizeof(ContigInfo)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, r.tiles.size() * sizeof(TileInfo)));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_codes, r.codes.data(), r.codes.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_mask, r.mask.data(), r.mask.size() * 4, hipMemcpyHostToDevice));
+  if (!r.runs.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_runs, r.runs.data(), r.runs.size() * sizeof(Run), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_contigs, r.contigs.data(), r.contigs.size() * sizeof(ContigInfo), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_tiles, r.tiles.data(), r.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_list, std::max<size_t>(1, r.masked_tiles.size()) * sizeof(uint32_t)));
+  if (!r.masked_tiles.empty())
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tile_list, r.masked_tiles.data(), r.masked_tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  // the scan streams the codes as two bit-planes per 32 bases (scan_rows.hip); derived on the device, once per reference
+  HIP_TRY(ctx, launch_planes(ctx->d_codes, ctx->d_planes, r.total_packed / 32, ctx->stream));
+  HIP_TRY(ctx, hipDeviceSynchronize());   // the searches run on non-blocking streams, which nothing orders against these copies
+  return CALITAS_OK;
+}
+
+// ctx->ref holds a freshly packed reference.  has_ref becomes true only when the device copy is complete: a failed upload
+// (CALITAS_ENOMEM for a genome that does not fit) leaves a context that answers CALITAS_ESTATE, not one whose next search
+// launches kernels on freed pointers.
 static int upload_reference(calitas_ctx* ctx) {
   ctx->ref_serial++;
   ctx->seq_pams = -1;               // what did not fit the old reference may fit this one
+  ctx->has_ref = false;
   if (ctx->device >= 0) {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    free_reference_device(ctx);
-    const PackedRef& r = ctx->ref;
-    size_t nruns = std::max<size_t>(1, r.runs.size());
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_codes, r.codes.size() * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mask, r.mask.size() * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_runs, nruns * sizeof(Run)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_contigs, r.contigs.size() * sizeof(ContigInfo)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, r.tiles.size() * sizeof(TileInfo)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_codes, r.codes.data(), r.codes.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_mask, r.mask.data(), r.mask.size() * 4, hipMemcpyHostToDevice));
-    if (!r.runs.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_runs, r.runs.data(), r.runs.size() * sizeof(Run), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_contigs, r.contigs.data(), r.contigs.size() * sizeof(ContigInfo), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_tiles, r.tiles.data(), r.tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_list, std::max<size_t>(1, r.masked_tiles.size()) * sizeof(uint32_t)));
-    if (!r.masked_tiles.empty())
-      HIP_TRY(ctx, hipMemcpy(ctx->d_tile_list, r.masked_tiles.data(), r.masked_tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipDeviceSynchronize());   // the searches run on non-blocking streams, which nothing orders against these copies
+    const int rc = upload_reference_device(ctx);
+    if (rc) {
+      (void)hipDeviceSynchronize();
+      free_reference_device(ctx);
+      ctx->ref = PackedRef();
+      return rc;
+    }
   }
+  ctx->has_ref = true;
   return CALITAS_OK;
 }
 
@@ -236,7 +262,6 @@ int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const
     ctx->has_ref = false;
     return fail(ctx, CALITAS_EINVAL, e.what());
   }
-  ctx->has_ref = true;
   return upload_reference(ctx);
 }
 
@@ -261,10 +286,73 @@ int calitas_set_reference_fasta(calitas_ctx* ctx, const char* fasta_path) {
 }  // extern "C"
 namespace {
 struct IndexHeader {
-  char magic[8];            // "CALIDX01"
+  char magic[8];            // "CALIDX02"
   uint32_t chunk, n_contigs;
   uint64_t tile, total_packed, total_bases, n_runs, n_tiles, n_masked, build_len, names_len;
+  uint64_t layout;          // kIndexLayout: a file written by a build with another packed layout is refused, not misread
+  uint64_t checksum;        // index_checksum() over contigs, codes, mask, runs, tiles, masked_tiles
 };
+constexpr uint64_t kIndexLayout = 2 | ((uint64_t)LANES_PER_TILE << 8) | ((uint64_t)sizeof(Run) << 24) | ((uint64_t)sizeof(TileInfo) << 32) | ((uint64_t)sizeof(ContigInfo) << 40);
+
+// 64-bit multiply-xor hash over 8-byte words in four independent lanes (memory-bound; the arrays are 4-byte aligned and a multiple of 4 bytes long)
+uint64_t hash_bytes(const void* p, size_t n, uint64_t seed) {
+  const unsigned char* b = (const unsigned char*)p;
+  uint64_t h[4] = {seed ^ 0x9E3779B97F4A7C15ull, seed ^ 0xC2B2AE3D27D4EB4Full, seed ^ 0x165667B19E3779F9ull, seed ^ 0x27D4EB2F165667C5ull};
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    uint64_t w[4];
+    std::memcpy(w, b + i, 32);
+    for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
+  }
+  uint64_t tail = 0x1234567ull + n;
+  for (; i < n; i++) tail = (tail ^ b[i]) * 0x100000001B3ull;
+  uint64_t r = tail;
+  for (int k = 0; k < 4; k++) { r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull; r ^= r >> 32; }
+  return r;
+}
+uint64_t index_checksum(const PackedRef& r) {
+  uint64_t c = hash_bytes(r.contigs.data(), r.contigs.size() * sizeof(ContigInfo), 1);
+  c = hash_bytes(r.codes.data(), r.codes.size() * 4, c);
+  c = hash_bytes(r.mask.data(), r.mask.size() * 4, c);
+  c = hash_bytes(r.runs.data(), r.runs.size() * sizeof(Run), c);
+  c = hash_bytes(r.tiles.data(), r.tiles.size() * sizeof(TileInfo), c);
+  return hash_bytes(r.masked_tiles.data(), r.masked_tiles.size() * 4, c);
+}
+
+// Everything the kernels index with goes to the device unchecked, so a loaded index is checked here: "" or what is wrong.
+std::string validate_index(const PackedRef& r) {
+  if (!(r.chunk == 64 || r.chunk == 128 || r.chunk == 256 || r.chunk == 512) || r.tile != (uint64_t)r.chunk * LANES_PER_TILE) return "tile geometry";
+  const uint64_t T = r.tile, n_tiles = r.total_packed / T;
+  if (r.contigs.empty() || r.total_packed / 16 > 0xFFFFFFFFull || n_tiles < 3) return "size";
+  if (r.codes.size() != r.total_packed / 16 || r.mask.size() != r.total_packed / 32 || r.tiles.size() != n_tiles) return "array sizes";
+  uint64_t next = T, sum = 0;            // tile 0 is padding
+  std::vector<uint32_t> owner(n_tiles, 0xFFFFFFFFu);
+  for (size_t c = 0; c < r.contigs.size(); c++) {
+    const ContigInfo& ci = r.contigs[c];
+    if (ci.gbase % T != 0 || ci.gbase < next || ci.len > 0x7FFFFFFFull) return "contig placement";
+    uint64_t nt = (ci.len + (uint64_t)r.chunk + T - 1) / T;   // the contig and >= one chunk of padding
+    if (nt == 0) nt = 1;
+    if (ci.gbase / T + nt + 1 > n_tiles) return "contig beyond the packed space";
+    for (uint64_t t = 0; t < nt; t++) owner[ci.gbase / T + t] = (uint32_t)c;
+    next = ci.gbase + nt * T;
+    sum += ci.len;
+  }
+  if (sum != r.total_bases) return "total_bases";
+  for (uint64_t t = 0; t < n_tiles; t++)
+    if (r.tiles[t].contig != owner[t] || r.tiles[t].flag > 2u) return "tile table";
+  uint64_t prev_end = 0;
+  for (const Run& u : r.runs) {
+    if (u.len == 0 || u.start < prev_end || u.start + u.len > r.total_packed) return "run table";
+    prev_end = u.start + u.len;
+  }
+  uint64_t prev_tile = 0;
+  for (size_t i = 0; i < r.masked_tiles.size(); i++) {
+    const uint32_t t = r.masked_tiles[i];
+    if (t >= n_tiles || (i && t <= prev_tile) || r.tiles[t].flag != 1u) return "masked tile list";
+    prev_tile = t;
+  }
+  return "";
+}
 template <typename T> bool wr(FILE* f, const T* p, size_t n) { return n == 0 || std::fwrite(p, sizeof(T), n, f) == n; }
 template <typename T> bool rd(FILE* f, T* p, size_t n) { return n == 0 || std::fread(p, sizeof(T), n, f) == n; }
 }  // namespace
@@ -278,7 +366,8 @@ int calitas_save_index(const calitas_ctx* ctx, const char* path) {
   std::string names;
   for (auto& n : r.names) { names += n; names += '\n'; }
   IndexHeader h{};
-  std::memcpy(h.magic, "CALIDX01", 8);
+  std::memcpy(h.magic, "CALIDX02", 8);
+  h.layout = kIndexLayout; h.checksum = index_checksum(r);
   h.chunk = (uint32_t)r.chunk; h.n_contigs = (uint32_t)r.contigs.size(); h.tile = r.tile; h.total_packed = r.total_packed;
   h.total_bases = r.total_bases; h.n_runs = r.runs.size(); h.n_tiles = r.tiles.size(); h.n_masked = r.masked_tiles.size();
   h.build_len = r.genome_build.size(); h.names_len = names.size();
@@ -298,9 +387,15 @@ int calitas_load_index(calitas_ctx* ctx, const char* path) {
   IndexHeader h{};
   PackedRef r;
   std::string names;
-  bool ok = rd(f, &h, 1) && std::memcmp(h.magic, "CALIDX01", 8) == 0 && h.tile == (uint64_t)h.chunk * LANES_PER_TILE &&
+  bool ok = rd(f, &h, 1) && std::memcmp(h.magic, "CALIDX02", 8) == 0 && h.layout == kIndexLayout && h.tile == (uint64_t)h.chunk * LANES_PER_TILE &&
             h.total_packed % std::max<uint64_t>(1, h.tile) == 0 && h.n_tiles == h.total_packed / std::max<uint64_t>(1, h.tile) &&
             h.build_len < (1u << 16) && h.names_len < (1ull << 32);
+  if (ok) {   // the counts size the allocations below: they must add up to the file's own length
+    const uint64_t want = sizeof(IndexHeader) + h.build_len + h.names_len + (uint64_t)h.n_contigs * sizeof(ContigInfo) + h.total_packed / 16 * 4 +
+                          h.total_packed / 32 * 4 + h.n_runs * sizeof(Run) + h.n_tiles * sizeof(TileInfo) + h.n_masked * 4;
+    ok = h.n_runs < (1ull << 40) && h.n_masked <= h.n_tiles && std::fseek(f, 0, SEEK_END) == 0 && (uint64_t)std::ftell(f) == want &&
+         std::fseek(f, (long)sizeof(IndexHeader), SEEK_SET) == 0;
+  }
   if (ok) {
     r.chunk = (int)h.chunk; r.tile = h.tile; r.total_packed = h.total_packed; r.total_bases = h.total_bases;
     r.genome_build.resize(h.build_len); names.resize(h.names_len);
@@ -316,9 +411,11 @@ int calitas_load_index(calitas_ctx* ctx, const char* path) {
     while (a < names.size()) { size_t b = names.find('\n', a); if (b == std::string::npos) break; r.names.push_back(names.substr(a, b - a)); a = b + 1; }
     ok = r.names.size() == r.contigs.size();
   }
+  if (ok && index_checksum(r) != h.checksum) return fail(ctx, CALITAS_EIO, std::string("calitas index fails its checksum: ") + path);
   if (!ok) return fail(ctx, CALITAS_EIO, std::string("not a calitas index (or truncated): ") + path);
+  const std::string bad = validate_index(r);
+  if (!bad.empty()) return fail(ctx, CALITAS_EIO, std::string("corrupt calitas index (") + bad + "): " + path);
   ctx->ref = std::move(r);
-  ctx->has_ref = true;
   return upload_reference(ctx);
 }
 
@@ -400,6 +497,17 @@ int calitas_search_hits_batch(calitas_ctx* ctx, int32_t n_guides, const calitas_
   if (!ctx) return CALITAS_EINVAL;
   if (n_guides <= 0 || !guides || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "bad argument");
   return calitas_search_hits_batch_impl(ctx, n_guides, guides, guide_ids, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
+}
+
+int calitas_scan_candidates(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                            uint32_t** records, uint64_t* n_records) {
+  return calitas_scan_candidates_impl(ctx, n_guides, guides, params, records, n_records);
+}
+
+int calitas_contig_packed_base(const calitas_ctx* ctx, int32_t i, uint64_t* gbase) {
+  if (!ctx || !ctx->has_ref || i < 0 || i >= (int32_t)ctx->ref.contigs.size() || !gbase) return CALITAS_EINVAL;
+  *gbase = ctx->ref.contigs[i].gbase;
+  return CALITAS_OK;
 }
 
 int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out) {

@@ -95,6 +95,7 @@ inline Scores derive_scores(int mmNet, int pamNet, int genomeGapNet, int guideGa
 struct GuideDev {
   uint32_t peq_a[8];      // scan, left-to-right pass: Eq vector per (exception<<2 | code), guide rows top-aligned in 32 bits
   uint32_t peq_b[8];      // scan, right-to-left pass (target is read complemented)
+  uint64_t row_sets[2];   // scan (row-wise kernel): the same IUPAC sets, 4 bits per protospacer row, rows 0-15 / 16-31
   uint8_t qmask[MAX_L];   // IUPAC set of each row of the aligner-space query (guideFw, or guideRc for a 5' PAM)
   uint8_t pam_mask[MAX_PAMS][MAX_PAM_LEN];  // IUPAC sets of the aligner-space PAMs (pamFw or pamRc)
   uint8_t pam_len[MAX_PAMS];

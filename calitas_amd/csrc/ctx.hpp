@@ -29,6 +29,7 @@ struct calitas_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};            // [0..3] scan start / scan end / align+trace end / filter end, [4..5] row kernels, [6..7] text copy
   uint32_t* d_codes = nullptr;
+  uint2* d_planes = nullptr;        // codes as bit-planes per 32 bases (scan_rows.hip)
   uint32_t* d_mask = nullptr;
   Run* d_runs = nullptr;
   ContigInfo* d_contigs = nullptr;
@@ -90,6 +91,8 @@ int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* gui
 int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
                                    const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
                                    uint64_t* tsv_bytes, uint64_t* n_rows);
+int calitas_scan_candidates_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                                 uint32_t** records, uint64_t* n_records);
 void calitas_destroy_lanes(calitas_ctx* ctx);
 void calitas_default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp);
 // Per-guide device constants for limits (d, p) and costs; returns an error text or "".

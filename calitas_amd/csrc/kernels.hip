@@ -209,11 +209,11 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, uint32_t tile, uint
         myers_step2(ea.x, pvA, mvA, scA, accA, eb.y, pvB, mvB, scB, accB);
         myers_step2(ea.y, pvA, mvA, scA, accA, eb.x, pvB, mvB, scB, accB);
       }
-      if (wa >= 0 && accA < 0 && !(a.debug_skip & 1u)) {
+      if (wa >= 0 && accA < 0) {
         const uint32_t hm = replay_word<MASKED, true>(tabA, wordA, mA, pvA0, mvA0, scA0);
         stage_record(a, s_recs, s_nrec, gword0 + (uint32_t)wa, hm | ((uint32_t)gi << 17));
       }
-      if (wb < WPC && accB < 0 && !(a.debug_skip & 1u)) {
+      if (wb < WPC && accB < 0) {
         const uint32_t hm = replay_word<MASKED, false>(tabB, wordB, mB, pvB0, mvB0, scB0);
         stage_record(a, s_recs, s_nrec, gword0 + (uint32_t)wb, hm | (1u << 16) | ((uint32_t)gi << 17));
       }
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
       const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
 
       // ---- stage target masks ----
-      for (int x = r; x < ((a.debug_skip & 4u) ? 0 : ntb); x += 32) {
+      for (int x = r; x < ntb; x += 32) {
         int col = c0 + 1 + x;                                 // 1-based strand-space column
         int64_t pos = dir ? (wb - col) : (wa + col - 1);
         tb[x] = (uint8_t)fetch_tmask(a, gbase + (uint64_t)pos, dir);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
       int curD = NEG, curL = NEG, curU = true_border ? i_row * sp.target_gap : NEG;
       int curP = max(max(curD * 4 + TR_DIAG, curL * 4 + TR_LEFT), curU * 4 + TR_UP);
       int inP = shift_up_lane(curP), inPprev;
-      const int nsteps = (a.debug_skip & 1u) ? 0 : ncols + L - 1;
+      const int nsteps = ncols + L - 1;
       for (int t = 1; t <= nsteps; t++) {
         inPprev = inP;
         inP = shift_up_lane(curP);
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
       int pm_score[3] = {0, 0, 0};
       uint32_t pm_pass = 0;                                            // per-matrix enumeration: bit k = matrix k (Diag, Left, Up) passes
       bool pass = false;
-      if (myb >= 0 && !(a.debug_skip & 2u)) {
+      if (myb >= 0) {
         j = dir ? (int)(wb - (p0 + myb)) : (int)(p0 + myb - wa) + 1;   // strand-space end column
         P = fin[j - c0];
         if (PM) {                                                      // every bottom-row cell >= minScore is an alignment of its own
@@ -462,18 +462,18 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
       }
       const unsigned long long bal = __ballot(pass);
       const uint32_t mine = (uint32_t)(bal >> (threadIdx.x & 32));     // this job's 32 lanes (only lanes 0..15 can pass)
-      if (mine != 0u && !(a.debug_skip & 32u)) {
+      if (mine != 0u) {
         uint8_t* slab = a.slab + ((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) * a.slab_bytes;
         SlabHeader* hd = reinterpret_cast<SlabHeader*>(slab);
         const int stride = (ncols + 4) & ~3;                           // bytes per trace row in the slab (columns 0..ncols)
         const uint32_t tb_bytes = (uint32_t)((ntb + 3) & ~3);
-        if (r == 0 && !(a.debug_skip & 64u)) {
+        if (r == 0) {
           hd->contig = contig; hd->window_k = (uint32_t)k; hd->n = n; hd->c0 = c0; hd->ncols = (uint16_t)ncols; hd->ntb = (uint16_t)ntb;
           hd->dir = (uint8_t)dir; hd->guide = (uint8_t)gi; hd->true_border = true_border ? 1 : 0; hd->L = (uint8_t)L;
           hd->stride = (uint16_t)stride; hd->pad = 0;
           hd->pass_mask = mine;
         }
-        if (pass && !(a.debug_skip & 128u)) {
+        if (pass) {
           hd->j[r] = (uint16_t)j; hd->best[r] = P;
           // item = candidate slot | slab index << 4 | start matrix << 40 | (score + 2^21) << 42
           const uint64_t where = ((((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) & 0xFFFFFFFFFull) << 4) | (uint64_t)r;

@@ -9,6 +9,7 @@ namespace calitas {
 
 struct ScanArgs {
   const uint32_t* codes;
+  const uint2* planes;     // the same 2-bit codes as two bit-planes per 32 bases (.x = low bits, .y = high bits): what scan_rows_kernel streams
   const uint32_t* mask;
   const TileInfo* tiles;
   const GuideDev* guides;
@@ -18,7 +19,6 @@ struct ScanArgs {
   int32_t n_guides;
   int32_t chrom_index;
   uint32_t tile_offset;    // first tile of this launch (a chunked search scans one contig range per launch)
-  uint32_t debug_skip;     // profiling ablations (0 in production): 1 = never replay / emit
 };
 
 struct AlignArgs {
@@ -46,11 +46,13 @@ struct AlignArgs {
   uint32_t rec_capacity;
   uint32_t out_capacity;
   uint32_t tile_words;     // code words per scan tile
-  uint32_t debug_skip;     // ablation switches for profiling (0 in production): 1 = no fill, 2 = no traceback/emit, 4 = no staging
   SearchDev sp;
 };
 
 hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// scan_rows.hip: the row-wise scan (default) and the one-off conversion codes[] -> planes[] at upload time
+hipError_t launch_scan_rows(const ScanArgs& a, int chunk, int warm_words, uint32_t n_tiles, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+hipError_t launch_planes(const uint32_t* codes, uint2* planes, uint64_t n32, hipStream_t stream);
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop = nullptr);
 hipError_t launch_window_table(const Run* runs, int64_t n_runs, const ContigInfo* contigs, const uint64_t* win_base, int n_contigs,

@@ -1,0 +1,303 @@
+// scan_rows.hip -- the exact candidate filter of the SearchReference hot path, row-wise bit-parallel form (gfx950).
+//
+// What it decides (same rule as fgbio's Aligner.align(query, target, minScore) enumeration, called at
+// SequentialGuideAligner.scala:261,278,295,299): for every reference position and both strands, whether the bottom row of the
+// glocal DP reaches minGuideScore at that end column.  With the reference's linear gap costs that is "semi-global edit distance
+// <= E" (SearchReference.scala:432-441), computed exactly with Myers' bit-vector recurrence.
+//
+// Orientation.  The first version of this kernel (kernels.hip, scan_kernel) kept one DP *column* (the L protospacer rows) in a
+// 32-bit word and walked the text base by base: 13 VALU instructions per base and strand for L = 20 cells, 12 of the 32 bits idle,
+// plus a table lookup per base.  Here the bit-vector runs along the *text*: a lane owns NW consecutive 32-base words of the
+// reference as one long integer (plus NWARM warm-up words from its neighbour), and one step of the recurrence handles one
+// protospacer ROW for all of those positions -- every bit of every instruction is a DP cell.  Per 32-base word and row: one
+// v_and, one v_addc_co (the carry chain runs along the text), four v_bitop3, one v_or and two v_alignbit (the one-position shifts
+// across word boundaries) = 10 instructions for 32 cells.  The Eq vector of a row is simply the bit-plane of its base ("is this
+// position an A"), so there is no table and no per-base index arithmetic: the four planes of a lane's words are built once per
+// tile and strand from the 2-bit reference, which the packed reference keeps as two bit-planes per 32 bases for this kernel.
+// The reverse strand is the same recurrence on the bit-reversed, complemented words (right-to-left in the text).
+//
+// After the last row the lane holds the horizontal deltas of the bottom row; the bottom-row values are L + prefix sums of those
+// deltas.  A byte-granular lower bound from masked popcounts (value at the byte's start minus the number of -1 steps in the byte)
+// rejects 99.5 % of the words; the survivors go to a small LDS queue that the workgroup resolves position by position at the end
+// of the tile (one lane per queued word), and only true candidate columns become ScanRecords -- the same records, bit for bit,
+// as the column-wise kernel produced, so everything downstream is unchanged.
+//
+// Truncation at the left end of a lane's chain (the DP column left of the warm-up words is taken as 0..L) can only raise values,
+// and a cell with true value <= E has its whole optimal path inside L + E - 1 <= 32 * NWARM columns, so every reported cell is exact.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace calitas {
+
+namespace {
+
+constexpr int ROWS_STAGE = 192;   // ScanRecords staged in LDS per tile (flushed with one global atomic)
+constexpr int ROWS_QCAP = 512;    // suspect words queued per tile
+
+struct SuspectWord {
+  uint32_t p, m;      // +1 / -1 horizontal deltas of the bottom row over the word's 32 positions (chain order)
+  int32_t s;          // bottom-row value before the word, biased by -(E+1): a negative running value = candidate column
+  uint32_t id;        // bits 0-15 word index in the tile (text order), bit 16 direction, bits 17-23 guide
+};
+
+// where a tile's records go: an LDS stage flushed once per tile, the global list beyond that
+struct RecordSink {
+  ScanRecord* recs;
+  uint32_t* rec_count;
+  uint32_t rec_capacity;
+  ScanRecord* s_recs;
+  uint32_t* s_nrec;
+};
+
+__device__ __forceinline__ void stage_scan_record(const RecordSink k, uint32_t gword, uint32_t info) {
+  ScanRecord r;
+  r.gword = gword; r.info = info;
+  const uint32_t slot = atomicAdd(k.s_nrec, 1u);        // LDS atomic
+  if (slot < (uint32_t)ROWS_STAGE) { k.s_recs[slot] = r; return; }
+  const uint32_t g = atomicAdd(k.rec_count, 1u);        // stage full (dense tile): append directly
+  if (g < k.rec_capacity) k.recs[g] = r;
+}
+
+// Position-by-position walk over one suspect word: bit k of the result = the bottom-row value after position k is <= E.
+// (everything by value: a reference to the kernel's argument block would force that block into scratch memory)
+__device__ __noinline__ void resolve_suspect(const RecordSink sink, uint32_t w32_base, const SuspectWord q) {
+  uint32_t hm = 0;
+  int s = q.s;
+#pragma unroll 8
+  for (int k = 0; k < 32; k++) {
+    s += (int)((q.p >> k) & 1u);
+    s -= (int)((q.m >> k) & 1u);
+    hm |= (uint32_t)(s < 0) << k;
+  }
+  if (hm == 0u) return;
+  const uint32_t dir = (q.id >> 16) & 1u;
+  if (dir) hm = __builtin_bitreverse32(hm);              // the reverse-strand chain runs right to left
+  const uint32_t gword = (w32_base + (q.id & 0xFFFFu)) * 2u;   // ScanRecords address 16-base words
+  const uint32_t tag = q.id & 0xFFFF0000u;               // direction and guide already sit where ScanRecord::info wants them
+  if (hm & 0xFFFFu) stage_scan_record(sink, gword, (hm & 0xFFFFu) | tag);
+  if (hm >> 16) stage_scan_record(sink, gword + 1u, (hm >> 16) | tag);
+}
+
+// One row of the recurrence over a chain of NC words (word 0 = lowest text position in chain order).
+//   x  = eq & pv;  t = x + pv (carry runs along the chain)
+//   xh = (t ^ pv) | eq;  mh = pv & xh;  ph = mv | ~(xh | pv);  xv = eq | mv
+//   ph, mh shift up one position (a 1 enters ph at the chain's low end: the DP column left of the chain is 0, 1, .., L)
+//   pv = mh | ~(xv | ph);  mv = ph & xv
+template <int NC>
+__device__ __forceinline__ void myers_row(const uint32_t (&eqs)[NC], uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
+  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u;
+#pragma unroll
+  for (int w = 0; w < NC; w++) {
+    const uint32_t eq = eqs[w];
+    const uint32_t x = eq & pv[w];
+    uint32_t cout;
+    const uint32_t t = __builtin_addc(x, pv[w], carry, &cout);   // v_addc_co_u32: the carry chain runs along the text
+    carry = cout;
+    const uint32_t xh = (t ^ pv[w]) | eq;
+    const uint32_t mh = pv[w] & xh;
+    const uint32_t ph = mv[w] | ~(xh | pv[w]);
+    const uint32_t xv = eq | mv[w];
+    const uint32_t phs = __builtin_amdgcn_alignbit(ph, php, 31);
+    const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mhp, 31);
+    php = ph; mhp = mh;
+    pv[w] = mhs | ~(xv | phs);
+    mv[w] = phs & xv;
+  }
+}
+
+template <int NW, int NWARM, bool MASKED>
+__device__ __forceinline__ void scan_tile_rows(const ScanArgs& a, uint32_t tile, const uint2* s_pl, SuspectWord* s_q, uint32_t* s_qn,
+                                               const RecordSink sink) {
+  constexpr int NC = NW + NWARM;            // words of a lane's chain
+  constexpr int CSTR = NW + 1;              // uint2 per staged chunk (padded: lane l reads 8-byte word l * CSTR + k, conflict-free)
+  const int tid = threadIdx.x;
+  const uint32_t w32_base = tile * (uint32_t)(LANES_PER_TILE * NW);   // first 32-base word of the tile
+
+  for (int dir = 0; dir < 2; dir++) {
+    // ---- bit-planes of this lane's chain for this strand ----
+    uint32_t pl[4][NC];
+#pragma unroll
+    for (int v = 0; v < NC; v++) {
+      // text word behind chain word v: dir 0 reads left to right (warm-up = tail of the left neighbour's chunk),
+      // dir 1 right to left (warm-up = head of the right neighbour's chunk)
+      int chunk, k;
+      if (dir == 0) { chunk = (v < NWARM) ? tid : tid + 1; k = (v < NWARM) ? NW - NWARM + v : v - NWARM; }
+      else          { chunk = (v < NWARM) ? tid + 2 : tid + 1; k = (v < NWARM) ? NWARM - 1 - v : NW - 1 - (v - NWARM); }
+      const uint2 x = s_pl[chunk * CSTR + k];
+      uint32_t lo = x.x, hi = x.y, exc = 0u, wild = 0u;
+      if (MASKED) {
+        // exception bases (N, padding, IUPAC codes): code 0 never matches, code 1 matches every row (the aligner decides exactly)
+        exc = a.mask[(uint64_t)w32_base + (uint64_t)((chunk - 1) * NW + k)];
+        wild = exc & ~hi & lo;
+      }
+      if (dir) {                              // reverse strand: complemented text, read right to left
+        lo = ~__builtin_bitreverse32(lo); hi = ~__builtin_bitreverse32(hi);
+        if (MASKED) { exc = __builtin_bitreverse32(exc); wild = __builtin_bitreverse32(wild); }
+      }
+      pl[0][v] = ~hi & ~lo; pl[1][v] = ~hi & lo; pl[2][v] = hi & ~lo; pl[3][v] = hi & lo;
+      if (MASKED) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) pl[c][v] = (pl[c][v] & ~exc) | wild;
+      }
+    }
+
+    for (int gi = 0; gi < a.n_guides; gi++) {
+      const GuideDev& g = a.guides[gi];
+      const int L = __builtin_amdgcn_readfirstlane(g.L), E = __builtin_amdgcn_readfirstlane(g.scan_max_edits);
+      const uint64_t rows_lo = g.row_sets[0], rows_hi = g.row_sets[1];   // 4-bit base set per protospacer row
+      uint32_t pv[NC], mv[NC];
+#pragma unroll
+      for (int v = 0; v < NC; v++) { pv[v] = 0u; mv[v] = 0u; }          // row 0 of the DP is all zeros (free start in the text)
+      for (int i = 0; i < L; i++) {
+        const uint32_t set = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((i < 16 ? rows_lo : rows_hi) >> ((i & 15) * 4)) & 15u));
+        // Eq of this row = the plane of its base, copied once (one v_mov per word).  Four copies of the row body, each reading its
+        // plane in place, cost more: the compiler then moves all 2 x NC state words at the loop's back edge instead.
+        uint32_t eqs[NC];
+        switch (set) {
+          case 1: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[0][w]; break;
+          case 2: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[1][w]; break;
+          case 4: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[2][w]; break;
+          case 8: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[3][w]; break;
+          default: {   // an IUPAC letter in the protospacer: union of the planes in its set (A=1 C=2 G=4 T=8)
+            const uint32_t ka = 0u - (set & 1u), kc = 0u - ((set >> 1) & 1u), kg = 0u - ((set >> 2) & 1u), kt = 0u - ((set >> 3) & 1u);
+            _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = (pl[0][w] & ka) | (pl[1][w] & kc) | (pl[2][w] & kg) | (pl[3][w] & kt);
+          }
+        }
+        myers_row<NC>(eqs, pv, mv);
+      }
+      // ---- bottom row: value before chain word 0 is L; hunt for values <= E ----
+      int s = L - (E + 1);
+#pragma unroll
+      for (int v = 0; v < NWARM; v++) s += __builtin_popcount(pv[v]) - __builtin_popcount(mv[v]);
+#pragma unroll
+      for (int v = NWARM; v < NC; v++) {
+        const uint32_t P = pv[v], M = mv[v];
+        const int u1 = __builtin_popcount(P & 0xFFu) + s, u2 = __builtin_popcount(P & 0xFFFFu) + s, u3 = __builtin_popcount(P & 0xFFFFFFu) + s;
+        const int d1 = __builtin_popcount(M & 0xFFu), d2 = __builtin_popcount(M & 0xFFFFu), d3 = __builtin_popcount(M & 0xFFFFFFu);
+        const int d4 = __builtin_popcount(M);
+        // lower bound of the running value inside each byte: its value at the byte's start minus the -1 steps in the byte
+        const int lb = min(min(s - d1, u1 - d2), min(u2 - d3, u3 - d4));
+        if (lb < 0) {
+          SuspectWord q;
+          q.p = P; q.m = M; q.s = s;
+          const int k = v - NWARM;
+          q.id = (uint32_t)(tid * NW + (dir ? NW - 1 - k : k)) | ((uint32_t)dir << 16) | ((uint32_t)gi << 17);
+          const uint32_t slot = atomicAdd(s_qn, 1u);     // LDS atomic
+          if (slot < (uint32_t)ROWS_QCAP) s_q[slot] = q;
+          else resolve_suspect(sink, w32_base, q);        // queue full (dense repeats): resolve in place
+        }
+        s += __builtin_popcount(P) - d4;
+      }
+    }
+  }
+}
+
+// One workgroup per tile of the packed space.  Dead tiles (nothing but upper-case N / padding, which every window trims away)
+// exit at once; tiles with exception bases take the MASKED instantiation (block-uniform branch).
+template <int NW, int NWARM>
+__global__ __launch_bounds__(LANES_PER_TILE) void scan_rows_kernel(ScanArgs a) {
+  __shared__ uint2 s_pl[(LANES_PER_TILE + 2) * (NW + 1)];
+  __shared__ SuspectWord s_q[ROWS_QCAP];
+  __shared__ ScanRecord s_recs[ROWS_STAGE];
+  __shared__ uint32_t s_nrec, s_qn, s_base;
+  const uint32_t tile = blockIdx.x + a.tile_offset;
+  const TileInfo ti = a.tiles[tile];
+  if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
+  if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_nrec = 0; s_qn = 0; }
+  // ---- stream the tile (+ one halo chunk each side) into LDS: 16-byte coalesced loads, padded scatter ----
+  {
+    constexpr int CSTR = NW + 1;
+    const uint64_t w0 = (uint64_t)tile * (LANES_PER_TILE * NW);
+    const uint4* src = reinterpret_cast<const uint4*>(a.planes + (w0 - NW));
+    constexpr int NQ = (LANES_PER_TILE + 2) * NW / 2;   // 16-byte pieces (two 32-base words each)
+    for (int q = tid; q < NQ; q += LANES_PER_TILE) {
+      const uint4 v = src[q];
+      const int i = q * 2;
+      const int vc = i / NW, k = i % NW;                // NW is even: the pair stays inside one chunk
+      uint2* d = &s_pl[vc * CSTR + k];
+      d[0] = make_uint2(v.x, v.y); d[1] = make_uint2(v.z, v.w);
+    }
+  }
+  __syncthreads();
+  const uint32_t w32_base = tile * (uint32_t)(LANES_PER_TILE * NW);
+  const RecordSink sink{a.recs, a.rec_count, a.rec_capacity, s_recs, &s_nrec};
+  if (ti.flag != 0u) scan_tile_rows<NW, NWARM, true>(a, tile, s_pl, s_q, &s_qn, sink);
+  else scan_tile_rows<NW, NWARM, false>(a, tile, s_pl, s_q, &s_qn, sink);
+  // ---- resolve the queued suspect words, one lane each ----
+  __syncthreads();
+  const uint32_t nq = min(s_qn, (uint32_t)ROWS_QCAP);
+  for (uint32_t i = tid; i < nq; i += LANES_PER_TILE) resolve_suspect(sink, w32_base, s_q[i]);
+  // ---- flush the tile's records with one global atomic ----
+  __syncthreads();
+  const uint32_t n = min(s_nrec, (uint32_t)ROWS_STAGE);
+  if (n == 0) return;
+  if (tid == 0) s_base = atomicAdd(a.rec_count, n);
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += LANES_PER_TILE) {
+    const uint32_t g = s_base + i;
+    if (g < a.rec_capacity) a.recs[g] = s_recs[i];
+  }
+}
+
+// codes[] (2 bits per base, interleaved) -> planes[] (per 32 bases: low bits of the codes, high bits of the codes).
+__device__ __forceinline__ uint32_t even_bits(uint32_t x) {   // bits 0, 2, 4, .. of x gathered into the low 16 bits
+  x &= 0x55555555u;
+  x = (x | (x >> 1)) & 0x33333333u;
+  x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+  x = (x | (x >> 4)) & 0x00FF00FFu;
+  x = (x | (x >> 8)) & 0x0000FFFFu;
+  return x;
+}
+
+__global__ void planes_kernel(const uint32_t* codes, uint2* planes, uint64_t n32) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n32) return;
+  const uint32_t c0 = codes[2 * i], c1 = codes[2 * i + 1];
+  planes[i] = make_uint2(even_bits(c0) | (even_bits(c1) << 16), even_bits(c0 >> 1) | (even_bits(c1 >> 1) << 16));
+}
+
+}  // namespace
+
+hipError_t launch_planes(const uint32_t* codes, uint2* planes, uint64_t n32, hipStream_t stream) {
+  if (n32 == 0) return hipSuccess;
+  hipLaunchKernelGGL(planes_kernel, dim3((unsigned)((n32 + 255) / 256)), dim3(256), 0, stream, codes, planes, n32);
+  return hipGetLastError();
+}
+
+// start / stop (optional): events attached to the dispatch itself -- no marker packets before and after the kernel on the stream.
+hipError_t launch_scan_rows(const ScanArgs& a, int chunk, int warm_words, uint32_t n_tiles, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  if (n_tiles == 0) {
+    if (start) { hipError_t e = hipEventRecord(start, stream); if (e != hipSuccess) return e; }
+    return stop ? hipEventRecord(stop, stream) : hipSuccess;
+  }
+  const dim3 grid(n_tiles), block(LANES_PER_TILE);
+#define CALITAS_LAUNCH_ROWS(NW, NWARM) hipExtLaunchKernelGGL((scan_rows_kernel<NW, NWARM>), grid, block, 0, stream, start, stop, 0, a)
+  if (warm_words == 1) {
+    switch (chunk) {
+      case 64:  CALITAS_LAUNCH_ROWS(2, 1); break;
+      case 128: CALITAS_LAUNCH_ROWS(4, 1); break;
+      case 256: CALITAS_LAUNCH_ROWS(8, 1); break;
+      case 512: CALITAS_LAUNCH_ROWS(16, 1); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else if (warm_words == 2) {
+    switch (chunk) {
+      case 64:  CALITAS_LAUNCH_ROWS(2, 2); break;
+      case 128: CALITAS_LAUNCH_ROWS(4, 2); break;
+      case 256: CALITAS_LAUNCH_ROWS(8, 2); break;
+      case 512: CALITAS_LAUNCH_ROWS(16, 2); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else {
+    return hipErrorInvalidValue;
+  }
+#undef CALITAS_LAUNCH_ROWS
+  return hipGetLastError();
+}
+
+}  // namespace calitas

@@ -55,6 +55,7 @@ std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, cons
   for (int code = 0; code < 4; code++) gd.peq_b[code] = gd.peq_a[3 - code];
   for (int k = 4; k < 8; k++) gd.peq_b[k] = gd.peq_a[k];
   for (int i = 0; i < L; i++) gd.qmask[i] = (uint8_t)iupac_mask((unsigned char)gh.q[i]);
+  for (int i = 0; i < L; i++) gd.row_sets[i >> 4] |= (uint64_t)gd.qmask[i] << ((i & 15) * 4);
   for (int pi = 0; pi < gd.n_pams; pi++) {
     gd.pam_len[pi] = (uint8_t)gh.pams_q[pi].size();
     for (size_t k = 0; k < gh.pams_q[pi].size(); k++) gd.pam_mask[pi][k] = (uint8_t)iupac_mask((unsigned char)gh.pams_q[pi][k]);
@@ -106,6 +107,7 @@ struct SearchPlan {
   std::vector<GuideDev> gd;
   uint32_t slots_per_rec = 0, slab_bytes = 0;
   uint64_t slab_per_rec = 0;
+  int warm_words = 1;                 // 32-base warm-up words of a scan lane: L + E - 1 <= 32 * warm_words
   // the part of the packed reference this job covers
   uint32_t tile_lo = 0, n_tiles = 0;
   uint64_t bases = 0;
@@ -177,6 +179,7 @@ static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
     if (i == 0) pl.step = s;
     else if (s != pl.step) return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
     if ((pl.gd[i].L + pl.gd[i].scan_max_edits + 15) / 16 > ref.chunk / 16) return fail(ctx, CALITAS_EINVAL, "scan warm-up exceeds the lane chunk");
+    pl.warm_words = std::max(pl.warm_words, (pl.gd[i].L + pl.gd[i].scan_max_edits - 1 + 31) / 32);
   }
   // Strip slabs (align_kernel -> trace_kernel): fixed size and fixed address per (record, window slot).
   pl.slots_per_rec = (uint32_t)((p.window_size + 14) / pl.step + 1);   // windows a 16-base word can fall into
@@ -223,10 +226,9 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   const PackedRef& ref = o->ref;
   const calitas_params_t& p = pl.p;
   sa = ScanArgs{};
-  sa.codes = o->d_codes; sa.mask = o->d_mask; sa.tiles = o->d_tiles; sa.guides = ctx->d_guides;
+  sa.codes = o->d_codes; sa.planes = o->d_planes; sa.mask = o->d_mask; sa.tiles = o->d_tiles; sa.guides = ctx->d_guides;
   sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
   sa.n_guides = pl.n_guides; sa.chrom_index = p.chrom_index; sa.tile_offset = pl.tile_lo;
-  sa.debug_skip = std::getenv("CALITAS_DEBUG_SCAN") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SCAN")) : 0u;
   aa = AlignArgs{};
   aa.codes = o->d_codes; aa.mask = o->d_mask; aa.runs = o->d_runs; aa.n_runs = (int64_t)ref.runs.size();
   aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
@@ -234,7 +236,6 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
   aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
   aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
-  aa.debug_skip = std::getenv("CALITAS_DEBUG_SKIP") ? (uint32_t)std::atoi(std::getenv("CALITAS_DEBUG_SKIP")) : 0u;
   aa.sp.window_size = p.window_size; aa.sp.step = pl.step; aa.sp.n_guides = pl.n_guides;
   aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
   aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
@@ -256,6 +257,14 @@ static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
 // whatever waited for the end of the scan by 60-90 us.
 // (Queuing the inputs of all ranges first and their scans back to back was tried as well: no gain, the pause between two scans is
 // where the previous range's tail gets onto the CUs.)
+// CALITAS_SCAN=columns selects the first-generation column-wise scan_kernel (kernels.hip) instead of scan_rows_kernel: the two
+// emit the same ScanRecords (tests/test_gpu_parity.py::test_scan_kernels_emit_the_same_records), so this is an A/B switch for
+// measurements, not a behaviour switch.
+static bool scan_columnwise() {
+  const char* e = std::getenv("CALITAS_SCAN");
+  return e && std::strcmp(e, "columns") == 0;
+}
+
 static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
   // from the context's pinned copy (an async copy from pageable memory may wait for the stream to drain)
   std::memcpy(ctx->h_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides);
@@ -265,7 +274,9 @@ static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t
   fill_kernel_args(ctx, pl, sa, aa);
   ctx->t_scan0 = ctx->ev[0];
   ctx->t_scan1 = ctx->scan_done ? ctx->scan_done : ctx->ev[1];
-  HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream, ctx->t_scan0, ctx->t_scan1));   // the events ride on the dispatch
+  // the events ride on the dispatch
+  if (scan_columnwise()) HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream, ctx->t_scan0, ctx->t_scan1));
+  else HIP_TRY(ctx, launch_scan_rows(sa, ref_owner(ctx)->ref.chunk, pl.warm_words, pl.n_tiles, stream, ctx->t_scan0, ctx->t_scan1));
   return CALITAS_OK;
 }
 
@@ -500,6 +511,47 @@ int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_
   int rc = plan_search(ctx, n_guides, guides, params, pl);
   if (rc) return rc;
   return search_run(ctx, pl, out, n_out, nullptr, false);
+}
+
+// calitas_scan_candidates: plan, scan stage, records back (sorted).  Test and profiling entry; no lanes.
+int calitas_scan_candidates_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                                 uint32_t** records, uint64_t* n_records) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!records || !n_records) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *records = nullptr; *n_records = 0;
+  SearchPlan pl;
+  int rc = plan_search(ctx, n_guides, guides, params, pl);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = lane_prepare(ctx, pl);
+  if (rc) return rc;
+  uint32_t n_rec = 0;
+  for (;;) {
+    rc = launch_scan_stage(ctx, pl, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    n_rec = ctx->h_counters[0];
+    if (n_rec <= ctx->rec_cap) break;
+    rc = ensure_buffers(ctx, n_rec + n_rec / 4, ctx->raw_cap, pl.slab_per_rec, ctx->item_cap);
+    if (rc) return rc;
+  }
+  static_assert(sizeof(ScanRecord) == 8, "two words per record");
+  uint64_t* recs = (uint64_t*)out_alloc(std::max<size_t>(1, n_rec) * sizeof(ScanRecord));
+  if (!recs) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  if (n_rec) HIP_TRY(ctx, hipMemcpy(recs, ctx->d_recs, (size_t)n_rec * sizeof(ScanRecord), hipMemcpyDeviceToHost));
+  // {gword, info} little-endian as one 64-bit key: sort by info then gword would interleave; sort by (gword, info) instead
+  std::sort(recs, recs + n_rec, [](uint64_t a, uint64_t b) {
+    const uint64_t ka = (a << 32) | (a >> 32), kb = (b << 32) | (b >> 32);
+    return ka < kb;
+  });
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->t_scan0, ctx->t_scan1);
+  ctx->timing = calitas_timing_t{};
+  ctx->timing.scan_kernel_ms = ms; ctx->timing.scan_records = n_rec; ctx->timing.bases_scanned = pl.bases; ctx->timing.packed_bytes = (pl.bases + 3) / 4;
+  *records = (uint32_t*)recs;
+  *n_records = n_rec;
+  return CALITAS_OK;
 }
 
 void calitas_default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp) {

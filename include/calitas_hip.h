@@ -156,6 +156,17 @@ int calitas_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* gu
                    calitas_aln_t** out, uint64_t* n_out);
 int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
 
+/* The candidate filter of calitas_search on its own (the stage that decides which end columns the aligner kernel looks at):
+ * every (16-base word of the packed reference, strand, guide) that holds at least one end column whose glocal bottom-row score
+ * reaches minGuideScore for a seamless scan of the contig, i.e. fgbio's enumeration rule (SequentialGuideAligner.scala:261-299)
+ * before windowing.  Out: n records of two uint32 each, sorted: [0] packed position / 16, [1] bits 0-15 column mask,
+ * bit 16 strand pass (0 = target as is, 1 = reverse-complemented), bits 17-23 guide.  Exposed so that the two scan kernels can
+ * be held against each other and against a plain dynamic-programming count in the tests; calitas_free releases *records. */
+int calitas_scan_candidates(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                            uint32_t** records, uint64_t* n_records);
+/* Packed position (the unit of calitas_scan_candidates) of base 0 of contig i. */
+int calitas_contig_packed_base(const calitas_ctx* ctx, int32_t i, uint64_t* gbase);
+
 /* SearchReference.execute for one guide on the reference genome, end to end (SearchReference.scala:527-564 and 641-648):
  * calitas_search followed by removeOverlaps, ReferenceHit.sort and the 34-column rows, with the alignments never leaving
  * the device -- the per-window filter, removeOverlaps, both sorts and the row text are produced by kernels and only the
