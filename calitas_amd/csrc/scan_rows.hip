@@ -10,8 +10,8 @@
 // plus a table lookup per base.  Here the bit-vector runs along the *text*: a lane owns NW consecutive 32-base words of the
 // reference as one long integer (plus NWARM warm-up words from its neighbour), and one step of the recurrence handles one
 // protospacer ROW for all of those positions -- every bit of every instruction is a DP cell.  Per 32-base word and row: one
-// v_and, one v_addc_co (the carry chain runs along the text), four v_bitop3, one v_or and two v_alignbit (the one-position shifts
-// across word boundaries) = 10 instructions for 32 cells.  The Eq vector of a row is simply the bit-plane of its base ("is this
+// v_and, one v_or, one v_addc_co (the carry chain runs along the text), three v_bitop3 and a second v_or, two v_alignbit (the
+// one-position shifts across word boundaries) and a last v_and = 10 instructions for 32 cells.  The Eq vector of a row is simply the bit-plane of its base ("is this
 // position an A"), so there is no table and no per-base index arithmetic: the four planes of a lane's words are built once per
 // tile and strand from the 2-bit reference, which the packed reference keeps as two bit-planes per 32 bases for this kernel.
 // The reverse strand is the same recurrence on the bit-reversed, complemented words (right-to-left in the text).
@@ -35,7 +35,10 @@ namespace calitas {
 namespace {
 
 constexpr int ROWS_STAGE = 192;   // ScanRecords staged in LDS per tile (flushed with one global atomic)
-constexpr int ROWS_QCAP = 512;    // suspect words queued per tile
+constexpr int ROWS_QCAP = 128;    // suspect words queued per wave
+
+// GuideDev in the constant address space: loads through it are scalar (s_load) and may be hoisted
+typedef const __attribute__((address_space(4))) GuideDev GuideConst;
 
 struct SuspectWord {
   uint32_t p, m;      // +1 / -1 horizontal deltas of the bottom row over the word's 32 positions (chain order)
@@ -86,35 +89,55 @@ __device__ __noinline__ void resolve_suspect(const RecordSink sink, uint32_t w32
 //   xh = (t ^ pv) | eq;  mh = pv & xh;  ph = mv | ~(xh | pv);  xv = eq | mv
 //   ph, mh shift up one position (a 1 enters ph at the chain's low end: the DP column left of the chain is 0, 1, .., L)
 //   pv = mh | ~(xv | ph);  mv = ph & xv
-template <int NC>
-__device__ __forceinline__ void myers_row(const uint32_t (&eqs)[NC], uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
-  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u;
+// One row of the recurrence over a chain of NC words (word 0 = lowest text position in chain order), in two parts.
+// Part 1 needs the row's Eq vector (the bit-plane of its base) and is instantiated per base, reading the plane where it lies:
+//   x = eq & pv;   xv = eq | mv
+// Part 2 is common to all rows.  Where mv = 1 (so pv = 0) the textbook's xh = (t ^ pv) | eq is irrelevant to both of its uses
+// (ph = mv | ~(xh | pv) is 1 there, mh = pv & xh is 0), and where mv = 0, eq = xv; so Eq itself is not needed again:
+//   t  = x + pv                         (the carry chain runs along the text: v_addc_co_u32)
+//   mh = pv & ((t ^ pv) | xv);   ph = mv | (~pv & ~t & ~xv)
+//   ph, mh move up one position (a 1 enters ph at the chain's low end: the DP column left of the chain is 0, 1, .., L)
+//   pv = mh | ~(xv | ph);   mv = ph & xv
+// (Inline assembly with the plane's number as an immediate operand: written as plain C++ the four instantiations are identical
+// up to their source registers, and the compiler sinks them into one copy behind the switch -- fed by 17 v_mov per row.)
+template <int NC, int PLANE>
+__device__ __forceinline__ void myers_row_part1(const uint32_t (&plane)[NC], const uint32_t (&pv)[NC], const uint32_t (&mv)[NC],
+                                                uint32_t (&x)[NC], uint32_t (&xv)[NC]) {
 #pragma unroll
   for (int w = 0; w < NC; w++) {
-    const uint32_t eq = eqs[w];
-    const uint32_t x = eq & pv[w];
-    uint32_t cout;
-    const uint32_t t = __builtin_addc(x, pv[w], carry, &cout);   // v_addc_co_u32: the carry chain runs along the text
-    carry = cout;
-    const uint32_t xh = (t ^ pv[w]) | eq;
-    const uint32_t mh = pv[w] & xh;
-    const uint32_t ph = mv[w] | ~(xh | pv[w]);
-    const uint32_t xv = eq | mv[w];
-    const uint32_t phs = __builtin_amdgcn_alignbit(ph, php, 31);
-    const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mhp, 31);
-    php = ph; mhp = mh;
-    pv[w] = mhs | ~(xv | phs);
-    mv[w] = phs & xv;
+    asm("v_and_b32 %0, %2, %3 ; plane %5\n\tv_or_b32 %1, %2, %4"
+        : "=&v"(x[w]), "=v"(xv[w]) : "v"(plane[w]), "v"(pv[w]), "v"(mv[w]), "n"(PLANE));
   }
 }
 
+template <int NC>
+__device__ __forceinline__ void myers_row_part2(const uint32_t (&x)[NC], const uint32_t (&xv)[NC], uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
+  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u;
+#pragma unroll
+  for (int w = 0; w < NC; w++) {
+    uint32_t cout;
+    const uint32_t t = __builtin_addc(x[w], pv[w], carry, &cout);
+    carry = cout;
+    const uint32_t mh = pv[w] & ((t ^ pv[w]) | xv[w]);
+    const uint32_t ph = mv[w] | (~pv[w] & ~t & ~xv[w]);
+    const uint32_t phs = __builtin_amdgcn_alignbit(ph, php, 31);
+    const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mhp, 31);
+    php = ph; mhp = mh;
+    pv[w] = mhs | ~(xv[w] | phs);
+    mv[w] = phs & xv[w];
+  }
+}
+
+// One wave's share of a tile: 64 lanes x NW words, staged (with one halo chunk on each side) in the wave's own LDS region, so the
+// four waves of a workgroup never wait for each other.
 template <int NW, int NWARM, bool MASKED>
-__device__ __forceinline__ void scan_tile_rows(const ScanArgs& a, uint32_t tile, const uint2* s_pl, SuspectWord* s_q, uint32_t* s_qn,
-                                               const RecordSink sink) {
+__device__ __forceinline__ void scan_wave_rows(const ScanArgs& a, uint32_t tile, int wave, int wl, const uint2* s_pl, SuspectWord* s_q,
+                                               uint32_t* s_qn, const RecordSink sink) {
   constexpr int NC = NW + NWARM;            // words of a lane's chain
   constexpr int CSTR = NW + 1;              // uint2 per staged chunk (padded: lane l reads 8-byte word l * CSTR + k, conflict-free)
-  const int tid = threadIdx.x;
+  const int tid = wave * 64 + wl;           // lane of the tile
   const uint32_t w32_base = tile * (uint32_t)(LANES_PER_TILE * NW);   // first 32-base word of the tile
+  const GuideConst* guides = (const GuideConst*)(a.guides);   // constant address space: scalar loads
 
   for (int dir = 0; dir < 2; dir++) {
     // ---- bit-planes of this lane's chain for this strand ----
@@ -124,13 +147,13 @@ __device__ __forceinline__ void scan_tile_rows(const ScanArgs& a, uint32_t tile,
       // text word behind chain word v: dir 0 reads left to right (warm-up = tail of the left neighbour's chunk),
       // dir 1 right to left (warm-up = head of the right neighbour's chunk)
       int chunk, k;
-      if (dir == 0) { chunk = (v < NWARM) ? tid : tid + 1; k = (v < NWARM) ? NW - NWARM + v : v - NWARM; }
-      else          { chunk = (v < NWARM) ? tid + 2 : tid + 1; k = (v < NWARM) ? NWARM - 1 - v : NW - 1 - (v - NWARM); }
+      if (dir == 0) { chunk = (v < NWARM) ? wl : wl + 1; k = (v < NWARM) ? NW - NWARM + v : v - NWARM; }
+      else          { chunk = (v < NWARM) ? wl + 2 : wl + 1; k = (v < NWARM) ? NWARM - 1 - v : NW - 1 - (v - NWARM); }
       const uint2 x = s_pl[chunk * CSTR + k];
       uint32_t lo = x.x, hi = x.y, exc = 0u, wild = 0u;
       if (MASKED) {
         // exception bases (N, padding, IUPAC codes): code 0 never matches, code 1 matches every row (the aligner decides exactly)
-        exc = a.mask[(uint64_t)w32_base + (uint64_t)((chunk - 1) * NW + k)];
+        exc = a.mask[(int64_t)w32_base + (int64_t)((wave * 64 + chunk - 1) * NW + k)];
         wild = exc & ~hi & lo;
       }
       if (dir) {                              // reverse strand: complemented text, read right to left
@@ -145,28 +168,27 @@ __device__ __forceinline__ void scan_tile_rows(const ScanArgs& a, uint32_t tile,
     }
 
     for (int gi = 0; gi < a.n_guides; gi++) {
-      const GuideDev& g = a.guides[gi];
-      const int L = __builtin_amdgcn_readfirstlane(g.L), E = __builtin_amdgcn_readfirstlane(g.scan_max_edits);
-      const uint64_t rows_lo = g.row_sets[0], rows_hi = g.row_sets[1];   // 4-bit base set per protospacer row
+      const int L = guides[gi].L, E = guides[gi].scan_max_edits;
+      const uint64_t rows_lo = guides[gi].row_sets[0], rows_hi = guides[gi].row_sets[1];   // 4-bit base set per protospacer row
       uint32_t pv[NC], mv[NC];
 #pragma unroll
       for (int v = 0; v < NC; v++) { pv[v] = 0u; mv[v] = 0u; }          // row 0 of the DP is all zeros (free start in the text)
       for (int i = 0; i < L; i++) {
-        const uint32_t set = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((i < 16 ? rows_lo : rows_hi) >> ((i & 15) * 4)) & 15u));
-        // Eq of this row = the plane of its base, copied once (one v_mov per word).  Four copies of the row body, each reading its
-        // plane in place, cost more: the compiler then moves all 2 x NC state words at the loop's back edge instead.
-        uint32_t eqs[NC];
+        const uint32_t set = (uint32_t)(((i < 16 ? rows_lo : rows_hi) >> ((i & 15) * 4)) & 15u);
+        uint32_t x[NC], xv[NC];
         switch (set) {
-          case 1: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[0][w]; break;
-          case 2: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[1][w]; break;
-          case 4: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[2][w]; break;
-          case 8: _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = pl[3][w]; break;
+          case 1: myers_row_part1<NC, 0>(pl[0], pv, mv, x, xv); break;
+          case 2: myers_row_part1<NC, 1>(pl[1], pv, mv, x, xv); break;
+          case 4: myers_row_part1<NC, 2>(pl[2], pv, mv, x, xv); break;
+          case 8: myers_row_part1<NC, 3>(pl[3], pv, mv, x, xv); break;
           default: {   // an IUPAC letter in the protospacer: union of the planes in its set (A=1 C=2 G=4 T=8)
             const uint32_t ka = 0u - (set & 1u), kc = 0u - ((set >> 1) & 1u), kg = 0u - ((set >> 2) & 1u), kt = 0u - ((set >> 3) & 1u);
+            uint32_t eqs[NC];
             _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = (pl[0][w] & ka) | (pl[1][w] & kc) | (pl[2][w] & kg) | (pl[3][w] & kt);
+            myers_row_part1<NC, 4>(eqs, pv, mv, x, xv);
           }
         }
-        myers_row<NC>(eqs, pv, mv);
+        myers_row_part2<NC>(x, xv, pv, mv);
       }
       // ---- bottom row: value before chain word 0 is L; hunt for values <= E ----
       int s = L - (E + 1);
@@ -195,51 +217,69 @@ __device__ __forceinline__ void scan_tile_rows(const ScanArgs& a, uint32_t tile,
   }
 }
 
-// One workgroup per tile of the packed space.  Dead tiles (nothing but upper-case N / padding, which every window trims away)
-// exit at once; tiles with exception bases take the MASKED instantiation (block-uniform branch).
+__device__ __forceinline__ void wave_sync_lds() {   // orders this wave's LDS writes before its later LDS reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One workgroup per tile of the packed space, one wave per quarter of it.  Dead tiles (nothing but upper-case N / padding, which
+// every window trims away) exit at once; tiles with exception bases take the MASKED instantiation (block-uniform branch).
+// After the one barrier at the start (the shared counters) the waves run on their own: private staging region, private suspect
+// queue; the wave that finishes last flushes the tile's records.
 template <int NW, int NWARM>
 __global__ __launch_bounds__(LANES_PER_TILE) void scan_rows_kernel(ScanArgs a) {
-  __shared__ uint2 s_pl[(LANES_PER_TILE + 2) * (NW + 1)];
-  __shared__ SuspectWord s_q[ROWS_QCAP];
+  constexpr int CSTR = NW + 1;
+  constexpr int WAVE_PL = (64 + 2) * CSTR;            // staged 8-byte words per wave: its 64 chunks and one halo chunk each side
+  __shared__ uint2 s_pl[4 * WAVE_PL];
+  __shared__ SuspectWord s_q[4][ROWS_QCAP];
   __shared__ ScanRecord s_recs[ROWS_STAGE];
-  __shared__ uint32_t s_nrec, s_qn, s_base;
+  __shared__ uint32_t s_nrec, s_done, s_qn[4];
   const uint32_t tile = blockIdx.x + a.tile_offset;
   const TileInfo ti = a.tiles[tile];
   if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
   if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;
-  const int tid = threadIdx.x;
-  if (tid == 0) { s_nrec = 0; s_qn = 0; }
-  // ---- stream the tile (+ one halo chunk each side) into LDS: 16-byte coalesced loads, padded scatter ----
+  const int tid = threadIdx.x, wave = tid >> 6, wl = tid & 63;
+  if (tid == 0) { s_nrec = 0; s_done = 0; }
+  if (wl == 0) s_qn[wave] = 0;
+  __syncthreads();
+  // ---- stream this wave's quarter of the tile (+ one halo chunk each side) into LDS: 16-byte coalesced loads, padded scatter ----
+  uint2* my_pl = &s_pl[wave * WAVE_PL];
   {
-    constexpr int CSTR = NW + 1;
-    const uint64_t w0 = (uint64_t)tile * (LANES_PER_TILE * NW);
+    const uint64_t w0 = (uint64_t)tile * (LANES_PER_TILE * NW) + (uint64_t)(wave * 64 * NW);
     const uint4* src = reinterpret_cast<const uint4*>(a.planes + (w0 - NW));
-    constexpr int NQ = (LANES_PER_TILE + 2) * NW / 2;   // 16-byte pieces (two 32-base words each)
-    for (int q = tid; q < NQ; q += LANES_PER_TILE) {
+    constexpr int NQ = (64 + 2) * NW / 2;             // 16-byte pieces (two 32-base words each)
+    for (int q = wl; q < NQ; q += 64) {
       const uint4 v = src[q];
       const int i = q * 2;
-      const int vc = i / NW, k = i % NW;                // NW is even: the pair stays inside one chunk
-      uint2* d = &s_pl[vc * CSTR + k];
+      const int vc = i / NW, k = i % NW;              // NW is even: the pair stays inside one chunk
+      uint2* d = &my_pl[vc * CSTR + k];
       d[0] = make_uint2(v.x, v.y); d[1] = make_uint2(v.z, v.w);
     }
   }
-  __syncthreads();
+  wave_sync_lds();
   const uint32_t w32_base = tile * (uint32_t)(LANES_PER_TILE * NW);
   const RecordSink sink{a.recs, a.rec_count, a.rec_capacity, s_recs, &s_nrec};
-  if (ti.flag != 0u) scan_tile_rows<NW, NWARM, true>(a, tile, s_pl, s_q, &s_qn, sink);
-  else scan_tile_rows<NW, NWARM, false>(a, tile, s_pl, s_q, &s_qn, sink);
-  // ---- resolve the queued suspect words, one lane each ----
-  __syncthreads();
-  const uint32_t nq = min(s_qn, (uint32_t)ROWS_QCAP);
-  for (uint32_t i = tid; i < nq; i += LANES_PER_TILE) resolve_suspect(sink, w32_base, s_q[i]);
-  // ---- flush the tile's records with one global atomic ----
-  __syncthreads();
+  if (ti.flag != 0u) scan_wave_rows<NW, NWARM, true>(a, tile, wave, wl, my_pl, s_q[wave], &s_qn[wave], sink);
+  else scan_wave_rows<NW, NWARM, false>(a, tile, wave, wl, my_pl, s_q[wave], &s_qn[wave], sink);
+  // ---- resolve this wave's queued suspect words, one lane each ----
+  wave_sync_lds();
+  const uint32_t nq = min(s_qn[wave], (uint32_t)ROWS_QCAP);
+  for (uint32_t i = wl; i < nq; i += 64) resolve_suspect(sink, w32_base, s_q[wave][i]);
+  // ---- the last wave to get here flushes the tile's records with one global atomic ----
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  uint32_t arrived = 0;
+  if (wl == 0) arrived = atomicAdd(&s_done, 1u);
+  arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+  if (arrived != 3u) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const uint32_t n = min(s_nrec, (uint32_t)ROWS_STAGE);
   if (n == 0) return;
-  if (tid == 0) s_base = atomicAdd(a.rec_count, n);
-  __syncthreads();
-  for (uint32_t i = tid; i < n; i += LANES_PER_TILE) {
-    const uint32_t g = s_base + i;
+  uint32_t base = 0;
+  if (wl == 0) base = atomicAdd(a.rec_count, n);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  for (uint32_t i = wl; i < n; i += 64) {
+    const uint32_t g = base + i;
     if (g < a.rec_capacity) a.recs[g] = s_recs[i];
   }
 }
