@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- SearchReference full-scan throughput on MI355X (BASELINE.json metric).
 
-Workload (N=1): BASELINE config 3 -- one 20-nt guide + NRG PAM against a synthetic hg38-sized genome (25 contigs,
+Default workload (--config 3, N=1): BASELINE config 3 -- one 20-nt guide + NRG PAM against a synthetic hg38-sized genome (25 contigs,
 3 088 286 401 bp, N runs, soft-masking, tandem repeats, planted sites), max-guide-diffs 5, max-pam-mismatches 1,
-max-gaps-between-guide-and-pam 2.  A "step" is one complete SearchReference pass for one guide over the resident
-reference: scan kernel + aligner kernel + copy-back + per-window filter + removeOverlaps/sort/hit rows (everything
-except writing hits.txt to disk).  The packed reference is resident in HBM before the timed region.
+max-gaps-between-guide-and-pam 2.  A "step" is one complete SearchReference pass for one guide over the resident reference:
+scan kernel + aligner kernels + per-window filter + removeOverlaps / sort / all hits.txt rows on the device + copy-back of the text
+(everything except writing hits.txt to disk).  The packed reference is resident in HBM before the timed region.
 
-N>1: one process per GPU (torch.distributed, RCCL for the barrier).  Default partition = guides (each rank holds the
-genome and runs one guide pass per step -- guide #0 on every rank, so the work per GPU is that of the N=1 line;
---distinct-guides draws rank r's guide from the 96-guide set of BASELINE config 4) -> weak scaling, no data-path
-collective.  --shard contigs partitions the contigs of ONE guide's pass instead (strong scaling, host-side gather).
+--gpus N > 1: one process per GPU.  Started by a launcher (torchrun: WORLD_SIZE / RANK / LOCAL_RANK in the environment) the script
+is one rank; started plainly (`python bench.py --gpus 8`) it spawns the N ranks itself -- fresh child processes, decided before
+this process touches a GPU -- and prints rank 0's line.  RCCL carries the barriers around the timed region; there is no data-path
+collective.  The N > 1 headline is BASELINE's partition: the contigs of ONE pass are divided over the ranks (--shard contigs,
+strong scaling; every rank packs only its slice and the ranks' texts are concatenated in one shared-memory file); the same run
+then measures the guide-sharded mode (every rank holds the genome and runs its own guide pass, weak scaling) and reports it in the
+labelled field "guide_sharded".  --shard guides makes that mode the headline instead.
 
-value = candidate loci examined per second = 2 strands x reference bases x guide-passes / wall time.
+--config 4: BASELINE config 4, the 96-guide batch (guide #0 + 95 random 20-mers, seed 0xC4) through calitas_search_hits_batch;
+a step = all 96 guides.  --config 5: BASELINE config 5's shape, PAM-less 20-mer, max-guide-diffs 8, with a synthetic VCF
+(one variant per kilobase, seed 0xC5) through calitas_search_variants; its default --scale is reduced.
+
+value = candidate loci examined per second = 2 strands x reference bases x guide passes / wall time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +34,9 @@ sys.path.insert(0, ROOT)
 
 GUIDE0 = "CTTGCCCCACAGGGCAGTAAnrg"   # README.md:74 of the reference
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# vector-ALU issue roof of the chip: 256 CUs x 4 SIMD-32, a wave64 instruction every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md,
+# "Wave scheduling" and the cycle-constants table), in wave-instructions per nanosecond
+VALU_PEAK_GUIDE = 256 * 4 * 2.4 / 2
 
 
 def gen_contig(length, seed, device, n_ends, n_block, softmask=0.5, tandem_frac=0.01, gc=0.41):
@@ -102,6 +114,46 @@ def build_genome(scale, device, contig_indices=None, guides=(), log=None):
     return names, seqs
 
 
+def synthetic_vcf(path, names, seqs, per_kb=1.0, seed=0xC5):
+    """Biallelic SNVs and short indels at about one per kilobase, AF in [0.01, 0.5] (BASELINE config 5)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n_var = 0
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele frequency\">\n")
+        for nm, s in zip(names, seqs):
+            f.write("##contig=<ID=%s,length=%d>\n" % (nm, len(s)))
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for nm, s in zip(names, seqs):
+            n = int(len(s) * per_kb / 1000)
+            if n == 0:
+                continue
+            pos = np.unique(rng.integers(50, max(51, len(s) - 50), size=n))
+            pos = pos[np.concatenate(([True], np.diff(pos) > 8))]          # keep REF spans apart
+            kinds = rng.integers(0, 4, size=len(pos))
+            afs = rng.uniform(0.01, 0.5, size=len(pos))
+            alt_pick = rng.integers(0, 3, size=len(pos))
+            ins = rng.integers(0, 4, size=(len(pos), 3))
+            lines = []
+            for p, k, af, ap, iv in zip(pos.tolist(), kinds.tolist(), afs.tolist(), alt_pick.tolist(), ins.tolist()):
+                ref = chr(s[p - 1] & 0xDF)
+                if ref not in "ACGT":
+                    continue
+                if k <= 1:
+                    alt = [b for b in "ACGT" if b != ref][ap]
+                elif k == 2:
+                    alt = ref + "".join("ACGT"[x] for x in iv[:1 + ap])
+                else:
+                    span = bytes(s[p - 1:p + 1 + ap]).decode().upper()
+                    if any(c not in "ACGT" for c in span):
+                        continue
+                    ref, alt = span, span[0]
+                lines.append("%s\t%d\trs%d\t%s\t%s\t.\t.\tAF=%.3f\n" % (nm, p, n_var, ref, alt, af))
+                n_var += 1
+            f.write("".join(lines))
+    return n_var
+
+
 def host_cores():
     try:
         return max(1, len(os.sched_getaffinity(0)))
@@ -109,52 +161,118 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(names, seqs, params_kw, budget_bases):
-    """Times the CPU oracle (the restatement of the reference algorithm, oracle/) on a bounded sample of the same
-    genome with one worker per host core -- the reference's own threading model (SearchReference.scala:459)."""
+def cpu_baseline(names, seqs, guides, params_kw, budget_bases):
+    """Times the CPU oracle (the restatement of the reference algorithm, oracle/) on a bounded sample of the same genome with one
+    worker per host core -- the reference's own threading model (SearchReference.scala:459).  Returns (report, {contig: rows}) with
+    the oracle's rows of the whole contigs of the sample (for the parity check of the bench's own output)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cores = min(host_cores(), 16)   # the GPU box gives one GPU a 16-core CPU share
     # sample: whole contigs of the same genome, in order, until the budget is reached (the last one truncated)
-    s_names, s_seqs, total = [], [], 0
+    s_names, s_seqs, total, whole = [], [], 0, []
     for n, s in zip(names, seqs):
         if total >= budget_bases:
             break
         take = min(len(s), budget_bases - total)
         s_names.append(n); s_seqs.append(bytes(s[:take])); total += take
+        if take == len(s):
+            whole.append(n)
     t0 = time.perf_counter()
-    _, rows, nwin = O.search_memory(s_names, s_seqs, GUIDE0, "cpu", d=params_kw["max_guide_diffs"],
-                                    p=params_kw["max_pam_mismatches"], g=params_kw["max_gaps_between_guide_and_pam"], threads=cores)
+    rows_by_guide, nwin = [], 0
+    for g in guides:
+        _, rows, nwin = O.search_memory(s_names, s_seqs, g, "bench", d=params_kw["max_guide_diffs"], p=params_kw["max_pam_mismatches"],
+                                        g=params_kw["max_gaps_between_guide_and_pam"], threads=cores)
+        rows_by_guide.append(rows)
     dt = time.perf_counter() - t0
-    return {"value": 2 * total / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": "%d bp (%s%s; %d windows, %d hits) in %.1f s; oracle/ C++ restatement of the reference algorithm, %d threads"
-                      % (total, ",".join(s_names[:3]), "..." if len(s_names) > 3 else "", nwin, len(rows), dt, cores),
-            "bases_per_s": total / dt}
+    report = {"value": 2 * total * len(guides) / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+              "sample": "%d bp (%s%s; %d windows, %d guide pass(es), %d hits) in %.1f s; oracle/ C++ restatement of the reference algorithm, %d threads"
+                        % (total, ",".join(s_names[:3]), "..." if len(s_names) > 3 else "", nwin, len(guides), sum(len(r) for r in rows_by_guide), dt, cores),
+              "bases_per_s": total * len(guides) / dt}
+    return report, whole, rows_by_guide
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes (this one has not imported torch or touched a GPU),
+    rank 0's JSON line passed through.  A failing rank fails the run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit("bench.py: rank exit codes %s" % codes)
+    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not line:
+        raise SystemExit("bench.py: rank 0 printed no result line")
+    if json.loads(line[-1]).get("n_gpus") != n:
+        raise SystemExit("bench.py: the result line does not report n_gpus = %d" % n)
+    print(line[-1], flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scale", type=float, default=1.0, help="genome size relative to hg38 (1.0 = 3.09 Gb)")
-    ap.add_argument("--shard", choices=["guides", "contigs"], default="guides")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, choices=[3, 4, 5], default=3, help="BASELINE config: 3 one guide (the metric's), 4 the 96-guide batch, 5 PAM-less d=8 + VCF")
+    ap.add_argument("--scale", type=float, default=None, help="genome size relative to hg38 (1.0 = 3.09 Gb; default 1.0, config 5: 0.05)")
+    ap.add_argument("--shard", choices=["contigs", "windows", "guides"], default="contigs",
+                    help="N>1: contigs = consecutive contig ranges of one pass (strong scaling, BASELINE's partition); windows = consecutive "
+                         "window ranges, contigs cut where the balance asks for it; guides = every rank its own guide pass over the whole genome (weak)")
     ap.add_argument("--cpu-sample-mb", type=float, default=-1, help="CPU baseline sample in Mb (<0: auto, 0: skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second measurement (the mode that is not the headline)")
     ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
     ap.add_argument("--guides-per-step", type=int, default=1,
-                    help="guides each rank runs per step through calitas_search_hits_batch (BASELINE config 4 shape: 96 guides / 8 GPUs = 12); "
-                         "the default 1 is the BASELINE metric's single-guide pass")
+                    help="config 3: guides each rank runs per step through calitas_search_hits_batch; the default 1 is the BASELINE metric's single-guide pass")
     ap.add_argument("--same-guide", action="store_true", help="with --guides-per-step: every guide of the batch is guide #0 (isolates the pipelining gain)")
-    ap.add_argument("--distinct-guides", action="store_true", help="N>1: rank r runs guide #r of the 96-guide set instead of guide #0 on every rank")
+    ap.add_argument("--distinct-guides", action="store_true", help="--shard guides: rank r runs guide #r of the 96-guide set instead of guide #0 on every rank")
     ap.add_argument("--two-stage", action="store_true", help="calitas_search + calitas_hits_tsv (host rows) instead of the fused calitas_search_hits")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and gloo replaces RCCL (not a measurement)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="the ranks rendezvous over gloo, reduce one number and rank 0 prints a stub line: exercises the launch path without a GPU")
     args = ap.parse_args()
-
-    import torch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)          # before torch is imported: the children are the first to touch a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or with torchrun --nproc-per-node N and --gpus N)"
+                         % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        import torch
+        import torch.distributed as dist
+        total = rank + 1
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([rank + 1], dtype=torch.int64)
+            dist.all_reduce(t)
+            total = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": total, "local_rank": local_rank}), flush=True)
+        return
+    if args.steps is None:
+        args.steps = {3: 20, 4: 2, 5: 2}[args.config]
+    if args.warmup is None:
+        args.warmup = {3: 3, 4: 1, 5: 1}[args.config]
+    if args.scale is None:
+        args.scale = 0.05 if args.config == 5 else 1.0
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if args.rehearse_on_one_gpu:
@@ -178,114 +296,50 @@ def main():
     import calitas_amd as C
     from calitas_amd import shard, synth
 
-    params_kw = dict(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
-    params = C.make_params(**params_kw)
     all_guides = [GUIDE0] + synth.random_guides(0xC4, 95)
+    if args.config == 5:
+        params_kw = dict(max_guide_diffs=8, max_pam_mismatches=0, max_gaps_between_guide_and_pam=3)
+        all_guides = [GUIDE0[:20]]                                         # PAM-less guide #0
+        workload = "SearchReference --variants: PAM-less 20 nt guide, max-guide-diffs=8, synthetic VCF (1 variant / kb)"
+    else:
+        params_kw = dict(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+        workload = ("SearchReference: 96-guide batch (20 nt + NRG PAM)" if args.config == 4 else "SearchReference: 20 nt guide + NRG PAM")
+    params = C.make_params(**params_kw)
     spec = synth.hg38_like_spec(args.scale)
     lengths = [l for _, l in spec]
+    workload += " vs synthetic hg38-sized genome (25 contigs, %d bp), " % sum(lengths) + " ".join(
+        "%s=%d" % (k.replace("_", "-"), v) for k, v in params_kw.items())
 
-    if world > 1 and args.shard == "contigs":
-        mine = shard.contiguous_partition(lengths, world)[rank]   # consecutive ranges: the gather is a concatenation
-        my_guides = [GUIDE0]
-        guide_passes_per_step = 1          # the ranks share ONE guide pass
-        bases_per_step_total = sum(lengths)
-    else:
-        mine = None
+    # ---- what this rank holds and runs ----
+    def partition_mode(mode):
+        """(contig indices of this rank or None = all, its guides, guide passes per step over the job, bases per step over the job)"""
+        if args.config == 4:
+            gl = all_guides
+        elif args.config == 5:
+            gl = all_guides[:1]
+        else:
+            gl = None
+        if world > 1 and mode == "contigs":
+            mine = shard.contiguous_partition(lengths, world)[rank]        # consecutive ranges: the gather is a concatenation
+            g = gl or [GUIDE0]
+            return mine, g, len(g), sum(lengths) * len(g)                  # the ranks share ONE pass per guide
         gps = max(1, args.guides_per_step)
-        # weak scaling keeps the work per GPU fixed: every rank runs the pass of the N=1 line (guide #0).  The 96-guide set of
-        # BASELINE config 4 (its random 20-mers yield ~3x the rows of guide #0 on this genome, so a rank's step is copy-back
-        # bound and takes longer) is drawn with --distinct-guides, or by a batch (--guides-per-step > 1) without --same-guide.
-        distinct = args.distinct_guides or (gps > 1 and not args.same_guide)
-        my_guides = [all_guides[(rank * gps + i) % len(all_guides)] if distinct else GUIDE0 for i in range(gps)]
-        guide_passes_per_step = world * gps   # every rank runs its own guide(s) over the whole genome
-        bases_per_step_total = sum(lengths) * world * gps
+        if gl is None:
+            # weak scaling keeps the work per GPU fixed: every rank runs the pass of the N=1 line (guide #0); the 96-guide set's random
+            # 20-mers yield ~3x the rows of guide #0 on this genome (copy-back bound) and are drawn with --distinct-guides or a batch
+            distinct = args.distinct_guides or (gps > 1 and not args.same_guide)
+            gl = [all_guides[(rank * gps + i) % len(all_guides)] if distinct else GUIDE0 for i in range(gps)]
+        return None, gl, world * len(gl), sum(lengths) * world * len(gl)
 
-    t_gen = time.perf_counter()
-    names, seqs = build_genome(args.scale, device, contig_indices=mine, guides=[GUIDE0], log=None)
-    log("genome: %d contigs, %d bp on this rank, generated in %.1f s" % (len(names), sum(len(s) for s in seqs), time.perf_counter() - t_gen))
-    ctx = C.Context(local_rank)
-    t_set = time.perf_counter()
-    ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized")
-    info = ctx.reference_info()
-    log("set_reference: %.2f s (pack + upload), %d packed bytes" % (time.perf_counter() - t_set, info["packed_bytes"]))
-
-    G = [C.Guide(g) for g in my_guides]
-
-    phase = {"search_hits": 0.0, "gather": 0.0, "search": 0.0, "hits": 0.0, "free": 0.0}
-
-    contig_mode = world > 1 and args.shard == "contigs"
-
-    shm_path = "/dev/shm/calitas_bench_hits_%s.txt" % os.environ.get("MASTER_PORT", "0")
-    shm_fd = os.open(shm_path, os.O_RDWR | os.O_CREAT, 0o600) if contig_mode else -1
-
-    def place_rows(view, rows):
-        """Contig partition, no copies: this rank's piece of the job's hits.txt goes from the library's buffer straight into the
-        shared file at its offset (rank 0 keeps the header line); only the sizes travel between the ranks."""
-        import torch.distributed as dist
-        nl = 0
-        if rank:
-            while view[nl] != 10:
-                nl += 1
-            nl += 1
-        sizes = torch.zeros(world, 2, dtype=torch.int64)
-        dist.all_gather_into_tensor(sizes.view(-1), torch.tensor([len(view) - nl, rows], dtype=torch.int64), group=gloo)
-        os.pwrite(shm_fd, view[nl:], int(sizes[:rank, 0].sum()))
-        return int(sizes[:, 1].sum())
-
-    def gather_rows(text, rows):
-        """Contig partition: every rank owns a consecutive contig range, so its rows are a consecutive piece of the job's hits.txt.
-        The ranks share one node: each writes its piece at its offset into one file in shared memory; only the sizes travel."""
-        if not contig_mode:
-            return rows
-        import torch.distributed as dist
-        nl = text.index(b"\n") + 1
-        body = text[nl:] if rank else text                    # rank 0 keeps the header line
-        sizes = torch.zeros(world, 2, dtype=torch.int64)
-        mine_t = torch.tensor([len(body), rows], dtype=torch.int64)
-        dist.all_gather_into_tensor(sizes.view(-1), mine_t, group=gloo)
-        os.pwrite(shm_fd, body, int(sizes[:rank, 0].sum()))
-        return int(sizes[:, 1].sum())
-
-    def step():
-        tp0 = time.perf_counter()
-        if len(G) > 1 and not (args.no_hits or args.two_stage):
-            # a batch of guides, pipelined through the device stages (calitas_search_hits_batch)
-            res = ctx.search_hits_batch(G, ["bench%d" % i for i in range(len(G))], params, "bench", "bench", decode=False)
-            tp1 = time.perf_counter()
-            tm = ctx.timing()
-            phase["search_hits"] += tp1 - tp0
-            return tm, tm["accepted_alignments"], sum(r for _, r in res)
-        if contig_mode and not (args.no_hits or args.two_stage):
-            with ctx.search_hits_view(G[0], "bench", params, "bench", "bench") as (view, rows):
-                tp1 = time.perf_counter()
-                tm = ctx.timing()
-                rows = place_rows(view, rows)
-            phase["search_hits"] += tp1 - tp0; phase["gather"] += time.perf_counter() - tp1
-            return tm, tm["accepted_alignments"], rows
-        if not (args.no_hits or args.two_stage):
-            # calitas_search_hits: kernels through to the finished hits.txt text, one copy-back
-            text, rows = ctx.search_hits(G[0], "bench", params, "bench", "bench", decode=False)
-            tp1 = time.perf_counter()
-            tm = ctx.timing()
-            rows = gather_rows(text, rows)
-            phase["search_hits"] += tp1 - tp0; phase["gather"] += time.perf_counter() - tp1
-            return tm, tm["accepted_alignments"], rows
-        out, n = ctx.search_raw(G, params)
-        tp1 = time.perf_counter()
-        try:
-            tm = ctx.timing()
-            rows = 0
-            if not args.no_hits:
-                text, rows = ctx.hits_tsv_raw(G[0], "bench", params, out, n, "bench", "bench", decode=contig_mode)
-                if contig_mode:
-                    text = text.encode()
-                rows = gather_rows(text, rows)
-        finally:
-            tp2 = time.perf_counter()
-            C._lib.lib.calitas_free(out)
-            tp3 = time.perf_counter()
-            phase["search"] += tp1 - tp0; phase["hits"] += tp2 - tp1; phase["free"] += tp3 - tp2
-        return tm, n, rows
+    def make_context(mine):
+        t_gen = time.perf_counter()
+        names, seqs = build_genome(args.scale, device, contig_indices=mine, guides=[GUIDE0], log=None)
+        log("genome: %d contigs, %d bp on this rank, generated in %.1f s" % (len(names), sum(len(s) for s in seqs), time.perf_counter() - t_gen))
+        ctx = C.Context(local_rank)
+        t_set = time.perf_counter()
+        ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized")
+        log("set_reference: %.2f s (pack + upload), %d packed bytes" % (time.perf_counter() - t_set, ctx.reference_info()["packed_bytes"]))
+        return ctx, names, seqs
 
     def sync():
         if world > 1:
@@ -293,105 +347,250 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Prime the context before the contract's warmup: the first calls create the lanes, grow the device buffers and the pinned
-    # text buffer, and the runtime sets up its copy path under load (three calls); none of it is per-step work.
-    for _ in range(3):
-        step()
-    for _ in range(args.warmup):
-        step()
-    for k in phase:
-        phase[k] = 0.0
-    sync()
-    t0 = time.perf_counter()
-    scan_ms = align_ms = post_ms = gpu_ms = hitsk_ms = copy_ms = 0.0
-    last = None
-    for _ in range(args.steps):
-        tm, n_alns, rows = step()
-        scan_ms += tm["scan_kernel_ms"]; align_ms += tm["align_kernel_ms"]; post_ms += tm["host_post_ms"]; gpu_ms += tm["gpu_total_ms"]
-        hitsk_ms += tm["hits_kernel_ms"]; copy_ms += tm["hits_copy_ms"]
-        last = (tm, n_alns, rows)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def measure(mode, keep_text=False):
+        """K timed steps of one partition mode, bracketed by barrier + synchronize; the MAX over ranks is the job's time."""
+        mine, my_guides, passes_per_step, bases_per_step_total = partition_mode(mode)
+        contig_mode = world > 1 and mode == "contigs"
+        ctx, names, seqs = make_context(mine)
+        G = [C.Guide(g) for g in my_guides]
+        ids = ["bench%d" % i for i in range(len(G))]
+        phase = {"search_hits": 0.0, "gather": 0.0, "search": 0.0, "hits": 0.0, "free": 0.0}
+        shm_path = "/dev/shm/calitas_bench_hits_%s.txt" % os.environ.get("MASTER_PORT", "0")
+        shm_fd = os.open(shm_path, os.O_RDWR | os.O_CREAT, 0o600) if (contig_mode and len(G) == 1) else -1
+        vcf_path, n_variants = None, 0
+        if args.config == 5:
+            vcf_path = "/dev/shm/calitas_bench_c5_%d_%d.vcf" % (os.getpid(), rank)
+            t_v = time.perf_counter()
+            n_variants = synthetic_vcf(vcf_path, names, seqs)
+            log("synthetic VCF: %d variants in %.1f s" % (n_variants, time.perf_counter() - t_v))
+
+        def place_rows(view, rows):
+            """Contig partition, no copies: this rank's piece of the job's hits.txt goes from the library's buffer straight into the
+            shared file at its offset (rank 0 keeps the header line); only the sizes travel between the ranks."""
+            import torch.distributed as dist
+            nl = 0
+            if rank:
+                while view[nl] != 10:
+                    nl += 1
+                nl += 1
+            sizes = torch.zeros(world, 2, dtype=torch.int64)
+            dist.all_gather_into_tensor(sizes.view(-1), torch.tensor([len(view) - nl, rows], dtype=torch.int64), group=gloo)
+            os.pwrite(shm_fd, view[nl:], int(sizes[:rank, 0].sum()))
+            return int(sizes[:, 1].sum())
+
+        def total_rows(rows):
+            if not contig_mode:
+                return rows
+            import torch.distributed as dist
+            t = torch.tensor([rows], dtype=torch.int64)
+            dist.all_reduce(t, group=gloo)
+            return int(t.item())
+
+        def step():
+            tp0 = time.perf_counter()
+            if args.config == 5:
+                text, rows, nwin = ctx.search_variants_raw(G[0], "bench", params, vcf_path, "bench", "bench")
+                tp1 = time.perf_counter()
+                tm = ctx.timing()
+                tm["hits_bytes"] = text
+                tm["variant_windows"] = nwin
+                phase["search_hits"] += tp1 - tp0
+                return tm, tm["accepted_alignments"], total_rows(rows)
+            if len(G) > 1 and not (args.no_hits or args.two_stage):
+                # a batch of guides, pipelined through the device stages (calitas_search_hits_batch)
+                res = ctx.search_hits_batch(G, ids, params, "bench", "bench", decode=False)
+                tp1 = time.perf_counter()
+                tm = ctx.timing()
+                phase["search_hits"] += tp1 - tp0
+                return tm, tm["accepted_alignments"], total_rows(sum(r for _, r in res))
+            if contig_mode and not (args.no_hits or args.two_stage):
+                with ctx.search_hits_view(G[0], "bench", params, "bench", "bench") as (view, rows):
+                    tp1 = time.perf_counter()
+                    tm = ctx.timing()
+                    rows = place_rows(view, rows)
+                phase["search_hits"] += tp1 - tp0; phase["gather"] += time.perf_counter() - tp1
+                return tm, tm["accepted_alignments"], rows
+            if not (args.no_hits or args.two_stage):
+                # calitas_search_hits: kernels through to the finished hits.txt text, one copy-back
+                text, rows = ctx.search_hits(G[0], "bench", params, "bench", "bench", decode=False)
+                tp1 = time.perf_counter()
+                tm = ctx.timing()
+                phase["search_hits"] += tp1 - tp0
+                return tm, tm["accepted_alignments"], rows
+            out, n = ctx.search_raw(G, params)
+            tp1 = time.perf_counter()
+            try:
+                tm = ctx.timing()
+                rows = 0
+                if not args.no_hits:
+                    text, rows = ctx.hits_tsv_raw(G[0], "bench", params, out, n, "bench", "bench", decode=False)
+            finally:
+                tp2 = time.perf_counter()
+                C._lib.lib.calitas_free(out)
+                tp3 = time.perf_counter()
+                phase["search"] += tp1 - tp0; phase["hits"] += tp2 - tp1; phase["free"] += tp3 - tp2
+            return tm, n, total_rows(rows)
+
+        # Prime the context before the contract's warmup: the first calls create the lanes, grow the device buffers and the pinned
+        # text buffer (three calls, see DESIGN.md 4.7); none of it is per-step work.
+        for _ in range(3 if args.config == 3 else 1):
+            step()
+        for _ in range(args.warmup):
+            step()
+        for k in phase:
+            phase[k] = 0.0
+        sync()
+        t0 = time.perf_counter()
+        acc = {"scan": 0.0, "align": 0.0, "post": 0.0, "gpu": 0.0, "hitsk": 0.0, "copy": 0.0}
+        last = None
+        for _ in range(args.steps):
+            tm, n_alns, rows = step()
+            acc["scan"] += tm["scan_kernel_ms"]; acc["align"] += tm["align_kernel_ms"]; acc["post"] += tm["host_post_ms"]
+            acc["gpu"] += tm["gpu_total_ms"]; acc["hitsk"] += tm["hits_kernel_ms"]; acc["copy"] += tm["hits_copy_ms"]
+            last = (tm, n_alns, rows)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        text = None
+        if keep_text and rank == 0 and args.config != 5:
+            if len(G) > 1:
+                text = [t for t, _ in ctx.search_hits_batch(G[:2], ids[:2], params, "bench", "bench")]
+            else:
+                text = [ctx.search_hits(G[0], "bench", params, "bench", "bench")[0]]
+        tiles = ctx.tile_census()
+        ctx.close()
+        if shm_fd >= 0:
+            import torch.distributed as dist
+            dist.barrier(group=gloo)
+            if rank == 0:   # the assembled file of the last step: one header, `rows` rows, contigs in dictionary order
+                size = os.fstat(shm_fd).st_size
+                n_lines = os.pread(shm_fd, size, 0).count(b"\n")
+                log("contig partition: assembled hits.txt in shared memory has %d lines (%d bytes)" % (n_lines, size))
+                os.unlink(shm_path)
+            os.close(shm_fd)
+        if vcf_path:
+            os.unlink(vcf_path)
+        return dict(dt=dt, acc=acc, last=last, phase=phase, my_guides=my_guides, passes_per_step=passes_per_step,
+                    bases_per_step_total=bases_per_step_total, names=names, seqs=seqs, text=text, tiles=tiles, n_variants=n_variants,
+                    mine=mine)
+
+    headline_mode = args.shard if world > 1 else "none"
+    if headline_mode == "windows":
+        raise SystemExit("--shard windows: see calitas_amd/shard.py window_partition and tests/test_distributed_gloo.py; not wired into bench.py yet")
+    m = measure(headline_mode, keep_text=(world == 1))
+    second = None
+    if world > 1 and not args.no_secondary and args.config == 3:
+        other = "guides" if headline_mode == "contigs" else "contigs"
+        s = measure(other)
+        second = {"partition": other, "scaling": "weak" if other == "guides" else "strong",
+                  "value": 2.0 * s["bases_per_step_total"] * args.steps / s["dt"], "unit": "candidates/s", "ms_per_step": s["dt"] / args.steps * 1e3,
+                  "guide_passes_per_step": s["passes_per_step"],
+                  "note": ("every rank holds the whole genome and runs its own guide pass (the shape of a guide batch spread over the GPUs)"
+                           if other == "guides" else "consecutive contig ranges of one pass, one range per rank")}
 
     if rank == 0:
-        tm, n_alns, rows = last
         K = args.steps
-        bases_rank = tm["bases_scanned"]
-        value = 2.0 * bases_per_step_total * K / dt
-        # a pass is scanned in `lanes` launches (one per contig range); per-launch figures are averages over them
-        lanes = max(1, int(tm.get("lanes", 1)))
-        if len(G) > 1:
-            lanes = len(G)      # a batch scans the whole reference once per guide: one launch each
-        scan_avg_ms = scan_ms / K / lanes
-        bytes_per_launch = tm["packed_bytes"] / lanes
-        achieved = bytes_per_launch / (scan_avg_ms * 1e-3) / 1e9    # GB/s, algorithmic bytes of one launch / its duration
+        dt, acc = m["dt"], m["acc"]
+        tm, n_alns, rows = m["last"]
+        value = 2.0 * m["bases_per_step_total"] * K / dt
+        # a pass is scanned in `launches` launches (one per contig range / guide, DESIGN.md 4.5); per-launch figures are averages over them
+        n_guides_rank = len(m["my_guides"])
+        launches = max(1, int(tm.get("lanes", 1))) if n_guides_rank == 1 else n_guides_rank
+        if tm.get("contig_passes", 0):
+            launches = int(tm["contig_passes"])
+        scan_avg_ms = acc["scan"] / K / launches
+        packed_rank = tm["packed_bytes"] / max(1, n_guides_rank)            # algorithmic bytes of ONE pass over this rank's slice
+        bytes_per_launch = packed_rank / (launches if n_guides_rank == 1 else 1)
+        achieved = bytes_per_launch / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+        tiles = m["tiles"]
         result = {
             "metric": "off-target candidates/sec (hg38 full scan), 20nt guide+NRG PAM",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and args.shard == "contigs") else "weak",
+            "scaling": "strong" if (world > 1 and headline_mode == "contigs") else "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "SearchReference: 20 nt guide + NRG PAM vs synthetic hg38-sized genome (25 contigs, %d bp), "
-                                   "max-guide-diffs=5 max-pam-mismatches=1 max-gaps-between-guide-and-pam=2" % sum(lengths),
-                       "guide": my_guides[0], "guide_passes_per_step": guide_passes_per_step, "partition": args.shard if world > 1 else "none",
-                       "genome_scale": args.scale,
+            "config": {"workload": workload, "baseline_config": args.config,
+                       "guide": m["my_guides"][0], "guides_per_step_per_rank": n_guides_rank, "guide_passes_per_step": m["passes_per_step"],
+                       "partition": headline_mode, "genome_scale": args.scale,
                        "step_includes": "scan + align kernels, per-window filter" + ("" if args.no_hits else ", removeOverlaps, sort, all hits.txt rows")
-                                        + (", copy-back of alignments, host rows" if (args.two_stage or args.no_hits) else " (all on the device), copy-back of the text")},
-            "bases_per_s": bases_per_step_total * K / dt,
+                                        + (", copy-back of alignments, host rows" if (args.two_stage or args.no_hits or args.config == 5)
+                                           else " (all on the device), copy-back of the text")},
+            "bases_per_s": m["bases_per_step_total"] * K / dt,
+            "dead_tile_fraction": tiles["dead"] / max(1, tiles["tiles"]),
             "hits_per_pass": rows, "accepted_alignments_per_pass": n_alns, "raw_alignments_per_pass": tm["raw_alignments"],
             "scan_records_per_pass": tm["scan_records"],
             "hits_bytes_per_pass": tm["hits_bytes"],
-            "host_phase_ms": {k: v / K * 1e3 for k, v in phase.items() if v > 0},
-            "kernel_ms": {"scan": scan_ms / K, "align": align_ms / K, "search_gpu_total": gpu_ms / K, "hits_kernels": hitsk_ms / K,
-                          "text_copy": copy_ms / K, "host_convert": post_ms / K},
-            "roofline": {"bound": "hbm", "kernel": "scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "host_phase_ms": {k: v / K * 1e3 for k, v in m["phase"].items() if v > 0},
+            "kernel_ms": {"scan": acc["scan"] / K, "align": acc["align"] / K, "search_gpu_total": acc["gpu"] / K, "hits_kernels": acc["hitsk"] / K,
+                          "text_copy": acc["copy"] / K, "host_convert": acc["post"] / K},
+            "roofline": {"bound": "hbm", "kernel": "scan_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_avg_ms, "launches_per_step": lanes,
-                         "note": "integer-VALU bound by construction (bit-vector edit-distance filter, ~31 int lane-ops per base for "
-                                 "two strands); see DESIGN.md 4.1 for the VALU-side roofline"},
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": scan_avg_ms, "launches_per_step": launches,
+                         "note": "integer-VALU bound by construction (row-wise bit-vector edit-distance filter: 10 vector instructions per "
+                                 "32 DP cells, 20 rows, 2 strands); roofline.valu is the roof that binds, see DESIGN.md 4.1"},
         }
-        # measured HBM traffic of the dominant kernel for this exact workload, from the committed PMC passes
+        if args.config == 5:
+            result["config"]["variants"] = m["n_variants"]
+            result["config"]["variant_windows_per_pass"] = tm.get("variant_windows", 0)
+        if args.config == 4:
+            result["roofline"]["g_equivalent"] = {"guides_per_step": n_guides_rank, "achieved": achieved,
+                                                  "note": "every guide of the batch is a scan launch of its own over the whole slice: bytes are counted once per launch, "
+                                                          "nothing is shared between guides"}
+        # instruction count and HBM traffic of the dominant kernel for this exact workload, from the committed counter passes
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["scan_kernel"]
-            if pm["workload_packed_bytes"] * len(G) == tm["packed_bytes"] and world == 1:
-                result["roofline"]["traffic"] = pm["traffic_bytes_per_launch"] / (1 if len(G) > 1 else lanes)   # measured on the one-launch pass
-                result["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json"
-            if "SQ_INSTS_VALU" in pm and pm["workload_packed_bytes"] == tm["packed_bytes"] and world == 1 and len(G) == 1:
-                # the roof that binds this kernel: vector-ALU instruction issue.  Counted instructions per
-                # pass (PMC) / measured scan time of this run, against the measured full-rate issue of all 1024 SIMDs.
-                peak = 1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"]            # wave-instructions per ns
-                ach = pm["SQ_INSTS_VALU"] / (scan_ms / K * 1e6)
-                result["roofline"]["valu"] = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-inst/s",
-                                              "frac": ach / peak, "wave_insts_per_pass": pm["SQ_INSTS_VALU"],
-                                              "lane_ops_per_base": pm["valu_lane_ops_per_base"]}
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))["scan_rows_kernel"]
+            if world == 1 and args.config in (3, 4) and args.scale == 1.0:
+                scale = 1.0 if n_guides_rank > 1 else 1.0 / launches
+                result["roofline"]["traffic"] = pm["traffic_bytes_per_pass"] * scale
+                result["roofline"]["traffic_source"] = "profiles/r02_pmc_summary.json"
+                result["roofline"]["traffic_measured_in_run"] = False
+                insts = pm["SQ_INSTS_VALU"]                                 # wave-instructions of one pass (one guide)
+                ach = insts * max(1, n_guides_rank) / (acc["scan"] / K * 1e6)   # per nanosecond
+                result["roofline"]["valu"] = {
+                    "bound": "valu-issue", "achieved": ach, "unit": "G wave-inst/s", "wave_insts_per_pass": insts,
+                    "lane_ops_per_base": pm["valu_lane_ops_per_base"], "counted_in_run": False, "source": "profiles/r02_pmc_summary.json",
+                    "peak": VALU_PEAK_GUIDE, "frac": ach / VALU_PEAK_GUIDE,
+                    "peak_note": "256 CU x 4 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)",
+                    "peak_measured": 1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"],
+                    "frac_of_measured": ach / (1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"]),
+                    "peak_measured_note": "v_and / v_add streams on all 1024 SIMDs, profiles/r01_valu_rates.txt"}
         except Exception:
             pass
+        if second is not None:
+            result["guide_sharded" if second["partition"] == "guides" else "contig_sharded"] = second
         mb = args.cpu_sample_mb
         if mb < 0:
-            mb = 40.0 * min(host_cores(), 16)   # the oracle runs ~2.7 Mb/s per core on the GPU box: ~15 s of CPU work
+            # the oracle runs ~2.7 Mb/s per core and guide pass on the GPU box: ~15 s of CPU work
+            mb = 40.0 * min(host_cores(), 16) / (2 if args.config == 4 else 4 if args.config == 5 else 1)
         if mb > 0 and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(names, seqs, params_kw, int(mb * 1e6))
+                cg = m["my_guides"][:2] if args.config == 4 else m["my_guides"][:1]
+                report, whole, oracle_rows = cpu_baseline(m["names"], m["seqs"], cg, params_kw, int(mb * 1e6))
+                result["cpu_baseline"] = report
+                if m["text"] is not None and whole:
+                    # the bench checks its own output: the rows of the sample's whole contigs, every column but the run-dependent two
+                    skip = {"aligner_version", "time_stamp", "genome_build"}
+                    n_cmp, same = 0, True
+                    for gi, text in enumerate(m["text"][:len(oracle_rows)]):
+                        got = [{k: v for k, v in r.items() if k not in skip} for r in C.read_hits(text) if r["chromosome"] in whole]
+                        want = [{k: v for k, v in r.items() if k not in skip} for r in oracle_rows[gi] if r["chromosome"] in whole]
+                        n_cmp += len(want)
+                        same = same and got == want
+                    result["parity_sample"] = {"contigs": whole, "guides": len(oracle_rows), "rows": n_cmp, "identical": bool(same)}
+                    if not same:
+                        print(json.dumps(result), flush=True)
+                        raise SystemExit("bench.py: GPU rows differ from the oracle's on %s" % ",".join(whole))
+            except SystemExit:
+                raise
             except Exception as e:  # the baseline is reporting only; never fail the bench line because of it
                 result["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(result), flush=True)
-    ctx.close()
     if world > 1:
         import torch.distributed as dist
-        if contig_mode:
-            dist.barrier(group=gloo)
-            if rank == 0:   # the assembled file of the last step: one header, `rows` rows, contigs in dictionary order
-                size = os.fstat(shm_fd).st_size
-                whole = os.pread(shm_fd, size, 0)
-                n_lines = whole.count(b"\n")
-                log("contig partition: assembled hits.txt in shared memory has %d lines (%d bytes)" % (n_lines, size))
-                os.unlink(shm_path)
-            os.close(shm_fd)
         dist.destroy_process_group()
 
 

@@ -50,13 +50,13 @@ class TimingT(ctypes.Structure):
                 ("scan_records", ctypes.c_uint64), ("candidate_columns", ctypes.c_uint64), ("raw_alignments", ctypes.c_uint64),
                 ("accepted_alignments", ctypes.c_uint64), ("retries", ctypes.c_uint32), ("lanes", ctypes.c_uint32),
                 ("hits_kernel_ms", ctypes.c_double), ("hits_copy_ms", ctypes.c_double), ("hit_rows", ctypes.c_uint64),
-                ("hits_bytes", ctypes.c_uint64)]
+                ("hits_bytes", ctypes.c_uint64), ("contig_passes", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
            "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases",
-           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_contig_packed_base", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
+           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -87,6 +87,7 @@ lib.calitas_search.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(G
                                ctypes.POINTER(ctypes.POINTER(AlnT)), ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_scan_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(GuideT), ctypes.POINTER(ParamsT),
                                         ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32)), ctypes.POINTER(ctypes.c_uint64)]
+lib.calitas_reference_tiles.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint64)] * 4
 lib.calitas_contig_packed_base.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_get_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(TimingT)]
 lib.calitas_window_filter.argtypes = [ctypes.POINTER(AlnT), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

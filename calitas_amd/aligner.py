@@ -237,6 +237,23 @@ class Context:
         _lib.check(self._h, lib.calitas_search(self._h, n, arr, ctypes.byref(params), ctypes.byref(out), ctypes.byref(cnt)))
         return out, cnt.value
 
+    def tile_census(self):
+        """calitas_reference_tiles: {"tiles", "dead", "masked", "tile_bases"} of the resident reference."""
+        v = [ctypes.c_uint64() for _ in range(4)]
+        _lib.check(self._h, lib.calitas_reference_tiles(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("tiles", "dead", "masked", "tile_bases"), [x.value for x in v]))
+
+    def search_variants_raw(self, guide, guide_id, params, vcf_path, version=None, time_stamp=None, chrom=None):
+        """calitas_search_variants without bringing the text into Python: (n_bytes, n_rows, n_variant_windows)."""
+        g = guide.to_c()
+        tsv, nbytes, rows, nwin = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._h, lib.calitas_search_variants(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params), str(vcf_path).encode(),
+                                                        chrom.encode() if chrom is not None else None, None,
+                                                        version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                                        ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(rows), ctypes.byref(nwin)))
+        lib.calitas_free(tsv)
+        return nbytes.value, rows.value, nwin.value
+
     def scan_candidates(self, guides, params):
         """calitas_scan_candidates: the candidate filter alone.  Returns a sorted list of (contig_index, contig_offset, pass, guide):
         one entry per end column whose seamless glocal bottom-row score reaches minGuideScore (pass 0 = target as is, the column

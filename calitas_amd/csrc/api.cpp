@@ -235,7 +235,7 @@ static int upload_reference_device(calitas_ctx* ctx) {
 // launches kernels on freed pointers.
 static int upload_reference(calitas_ctx* ctx) {
   ctx->ref_serial++;
-  ctx->seq_pams = -1;               // what did not fit the old reference may fit this one
+  ctx->seq_pams = -1; ctx->fit_pams = -1;   // what did (not) fit the old reference may (not) fit this one
   ctx->has_ref = false;
   if (ctx->device >= 0) {
     const int rc = upload_reference_device(ctx);
@@ -502,6 +502,21 @@ int calitas_search_hits_batch(calitas_ctx* ctx, int32_t n_guides, const calitas_
 int calitas_scan_candidates(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                             uint32_t** records, uint64_t* n_records) {
   return calitas_scan_candidates_impl(ctx, n_guides, guides, params, records, n_records);
+}
+
+int calitas_reference_tiles(const calitas_ctx* ctx, uint64_t* n_tiles, uint64_t* n_dead, uint64_t* n_masked, uint64_t* tile_bases) {
+  if (!ctx || !ctx->has_ref) return CALITAS_ESTATE;
+  uint64_t n = 0, dead = 0, masked = 0;
+  for (const TileInfo& t : ctx->ref.tiles) {
+    if (t.contig == 0xFFFFFFFFu) continue;
+    n++;
+    if (t.flag == 2u) dead++; else if (t.flag == 1u) masked++;
+  }
+  if (n_tiles) *n_tiles = n;
+  if (n_dead) *n_dead = dead;
+  if (n_masked) *n_masked = masked;
+  if (tile_bases) *tile_bases = ctx->ref.tile;
+  return CALITAS_OK;
 }
 
 int calitas_contig_packed_base(const calitas_ctx* ctx, int32_t i, uint64_t* gbase) {

@@ -68,6 +68,9 @@ struct calitas_ctx {
   // the last search that had to run one pass per contig: protospacer length, number of PAMs, minGuideScore (a search at least as
   // permissive goes there directly instead of finding out again)
   int seq_L = 0, seq_pams = -1, seq_min_score = 0;
+  double seq_recs_per_tile = 0;     // scan records per live tile of that search (estimate_scan_records): sizes the per-contig passes
+  // ... and the last one that fit one pass: a search at most as permissive needs no estimate
+  int fit_L = 0, fit_pams = -1, fit_min_score = 0;
   std::mutex host_mu;               // host stages of concurrent lanes take turns on the worker pool
   DmaCopier dma;                    // parent: SDMA copies of the finished text (dma.hpp)
   bool dma_tried = false;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
   __shared__ uint2 s_tab[2 * 64];           // [direction][pair index] -> (Eq of base 2j, Eq of base 2j+1)
   __shared__ ScanRecord s_recs[SCAN_STAGE];
   __shared__ uint32_t s_nrec, s_base;
-  const uint32_t tile = blockIdx.x + a.tile_offset;
+  const uint32_t tile = blockIdx.x * a.tile_stride + a.tile_offset;
   const TileInfo ti = a.tiles[tile];
   if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
   if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;

@@ -19,6 +19,7 @@ struct ScanArgs {
   int32_t n_guides;
   int32_t chrom_index;
   uint32_t tile_offset;    // first tile of this launch (a chunked search scans one contig range per launch)
+  uint32_t tile_stride;    // 1; > 1 = every tile_stride-th tile only (the record-count estimate of a search that may not fit the device)
 };
 
 struct AlignArgs {

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_rows_kernel(ScanArgs a) {
   __shared__ SuspectWord s_q[4][ROWS_QCAP];
   __shared__ ScanRecord s_recs[ROWS_STAGE];
   __shared__ uint32_t s_nrec, s_done, s_qn[4];
-  const uint32_t tile = blockIdx.x + a.tile_offset;
+  const uint32_t tile = blockIdx.x * a.tile_stride + a.tile_offset;
   const TileInfo ti = a.tiles[tile];
   if (ti.flag == 2u || ti.contig == 0xFFFFFFFFu) return;
   if (a.chrom_index >= 0 && ti.contig != (uint32_t)a.chrom_index) return;

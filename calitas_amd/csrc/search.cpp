@@ -108,6 +108,7 @@ struct SearchPlan {
   uint32_t slots_per_rec = 0, slab_bytes = 0;
   uint64_t slab_per_rec = 0;
   int warm_words = 1;                 // 32-base warm-up words of a scan lane: L + E - 1 <= 32 * warm_words
+  uint64_t rec_hint = 0;              // expected scan records of this job (from estimate_scan_records), 0 = unknown
   // the part of the packed reference this job covers
   uint32_t tile_lo = 0, n_tiles = 0;
   uint64_t bases = 0;
@@ -228,7 +229,7 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   sa = ScanArgs{};
   sa.codes = o->d_codes; sa.planes = o->d_planes; sa.mask = o->d_mask; sa.tiles = o->d_tiles; sa.guides = ctx->d_guides;
   sa.recs = ctx->d_recs; sa.rec_count = ctx->d_counters; sa.rec_capacity = ctx->rec_cap;
-  sa.n_guides = pl.n_guides; sa.chrom_index = p.chrom_index; sa.tile_offset = pl.tile_lo;
+  sa.n_guides = pl.n_guides; sa.chrom_index = p.chrom_index; sa.tile_offset = pl.tile_lo; sa.tile_stride = 1;
   aa = AlignArgs{};
   aa.codes = o->d_codes; aa.mask = o->d_mask; aa.runs = o->d_runs; aa.n_runs = (int64_t)ref.runs.size();
   aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
@@ -246,7 +247,8 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
 
 // Device buffers of one lane for this plan (allocation only).
 static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
-  const uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, pl.bases / 8 + 1024));
+  uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, pl.bases / 8 + 1024));
+  if (pl.rec_hint) want = std::max<uint64_t>(want, std::min<uint64_t>(0xFFFFFFF0ull, pl.rec_hint + pl.rec_hint / 4 + 4096));   // no retry round for a dense search
   return ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), pl.slab_per_rec,
                         std::max<uint32_t>(ctx->item_cap, (uint32_t)(2 * want)));
 }
@@ -356,6 +358,8 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
     select_done(ctx->select);
+    if (ctx->h_counters[6] & SELECT_FLAG_INTERNAL)
+      return fail(ctx, CALITAS_EHIP, "per-window filter: window counters were not clear at the start of the stage (internal error)");
     if (ctx->h_counters[6] != 0) gpu_select = false;   // a window beyond what the device filter handles
     else {
       n_sel = ctx->h_counters[5];
@@ -789,15 +793,20 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   std::mutex copy_mu;
   const int n_contigs = (int)ref.contigs.size();
   uint64_t win_lo = 0, bases_done = 0;
+  uint32_t n_passes = 0;
   double ms_rows = 0;              // inside lane_rows: kernels, their host round trips and every (re)allocation of scratch
   for (int c = 0; c < n_contigs; c++) {
     const uint64_t win_n = window_count(ref.contigs[c].len, pl.step);
     if (pl.p.chrom_index < 0 || pl.p.chrom_index == c) {
+      n_passes++;
       SearchPlan q = pl;
       q.tile_lo = (uint32_t)(ref.contigs[c].gbase / ref.tile);
       const uint32_t tile_hi = c + 1 < n_contigs ? (uint32_t)(ref.contigs[c + 1].gbase / ref.tile) : (uint32_t)ref.tiles.size();
       q.n_tiles = tile_hi - q.tile_lo;
       q.bases = ref.contigs[c].len; q.win_lo = win_lo; q.win_n = win_n;
+      // buffers sized from the estimate that sent this search here: no retry round per contig
+      if (ctx->seq_recs_per_tile > 0 && ctx->seq_pams == pl.gd[0].n_pams && ctx->seq_L == pl.gd[0].L && pl.gd[0].min_guide_score == ctx->seq_min_score)
+        q.rec_hint = (uint64_t)(ctx->seq_recs_per_tile * (double)q.n_tiles) + 1;
       LaneText lt;
       const auto t_rows = std::chrono::steady_clock::now();
       rc = lane_rows(ctx, q, false, rs, guide_id, version, stamp, lt);
@@ -852,7 +861,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     text = grown;
     text[total] = 0;
   }
-  tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1;
+  tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1; tm.contig_passes = n_passes;
   ctx->timing = tm;
   ctx->last_text_bytes = total;
   if (std::getenv("CALITAS_TRACE"))
@@ -875,14 +884,74 @@ static bool known_not_to_fit(calitas_ctx* ctx, const calitas_guide_t* guide, con
   SearchPlan pl;
   if (!guide || !params || plan_search(ctx, 1, guide, params, pl) != CALITAS_OK) return false;
   const GuideDev& g = pl.gd[0];
-  if (remember) { ctx->seq_L = g.L; ctx->seq_pams = g.n_pams; ctx->seq_min_score = g.min_guide_score; return true; }
+  if (remember) { ctx->seq_L = g.L; ctx->seq_pams = g.n_pams; ctx->seq_min_score = g.min_guide_score; ctx->seq_recs_per_tile = 0; return true; }
   return params->chrom_index < 0 && ctx->seq_pams == g.n_pams && ctx->seq_L == g.L && g.min_guide_score <= ctx->seq_min_score;
+}
+
+// Scan records per live tile this search produces, from a scan of every k-th tile with a record capacity of 0 (counted, not kept):
+// a few hundred tiles, tens of microseconds.
+static int estimate_scan_records(calitas_ctx* ctx, const SearchPlan& pl, double* recs_per_tile, uint64_t* live_tiles) {
+  const PackedRef& ref = ctx->ref;
+  const uint32_t stride = std::max<uint32_t>(1, pl.n_tiles / 512);
+  const uint32_t n_sample = (pl.n_tiles + stride - 1) / stride;
+  auto live = [&](uint32_t t) {
+    const TileInfo& ti = ref.tiles[t];
+    return ti.flag != 2u && ti.contig != 0xFFFFFFFFu && (pl.p.chrom_index < 0 || ti.contig == (uint32_t)pl.p.chrom_index);
+  };
+  uint64_t live_all = 0, live_sample = 0;
+  for (uint32_t t = 0; t < pl.n_tiles; t++) if (live(pl.tile_lo + t)) { live_all++; if (t % stride == 0) live_sample++; }
+  *live_tiles = live_all; *recs_per_tile = 0;
+  if (live_sample == 0) return CALITAS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::memcpy(ctx->h_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, ctx->h_guides, sizeof(GuideDev) * pl.n_guides, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
+  ScanArgs sa; AlignArgs aa;
+  fill_kernel_args(ctx, pl, sa, aa);
+  sa.rec_capacity = 0; sa.tile_stride = stride;
+  HIP_TRY(ctx, launch_scan_rows(sa, ref.chunk, pl.warm_words, n_sample, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *recs_per_tile = (double)ctx->h_counters[0] / (double)live_sample;
+  return CALITAS_OK;
+}
+
+// Whether one pass of this search over the whole reference would overrun the device (or CALITAS_DEVICE_BUDGET_MB): decided from the
+// worst case when that is harmless, from the memory of the last search that fit, and otherwise from a sampled record count -- not
+// from a failed allocation of hundreds of gigabytes.  true: the search is remembered as one for per-contig passes.
+static bool predicted_not_to_fit(calitas_ctx* ctx, const calitas_guide_t* guide, const calitas_params_t* params) {
+  SearchPlan pl;
+  if (!guide || !params || plan_search(ctx, 1, guide, params, pl) != CALITAS_OK) return false;   // the attempt reports the error
+  const GuideDev& g = pl.gd[0];
+  if (ctx->fit_pams == g.n_pams && ctx->fit_L == g.L && g.min_guide_score >= ctx->fit_min_score) return false;
+  uint64_t limit = 0;
+  if (const char* e = std::getenv("CALITAS_DEVICE_BUDGET_MB")) limit = (uint64_t)std::atoll(e) << 20;
+  else {
+    size_t mem_free = 0, mem_total = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return false;
+    limit = (uint64_t)mem_total * 7 / 10;
+  }
+  // per scan record: its strips and itself, with the growth margin of the buffers; per raw alignment (about 1.5 per record): the
+  // record, the filter's and the row stage's scratch and its share of the text (~110 + ~1100 bytes)
+  const uint64_t per_rec = (pl.slab_per_rec + sizeof(ScanRecord)) * 5 / 4 + (sizeof(RawAln) + 110 + 1100) * 3 / 2;
+  const uint64_t worst = (pl.bases / 16 + 1) * 2;
+  if (worst <= limit / per_rec) return false;
+  double per_tile = 0;
+  uint64_t live = 0;
+  if (estimate_scan_records(ctx, pl, &per_tile, &live) != CALITAS_OK) return false;
+  const double n_rec = per_tile * (double)live;
+  if (std::getenv("CALITAS_TRACE"))
+    std::fprintf(stderr, "[calitas] search_hits: about %.3g scan records expected (%.1f per tile), %.1f GB of scratch for one pass, limit %.1f GB\n",
+                 n_rec, per_tile, n_rec * (double)per_rec / 1e9, (double)limit / 1e9);
+  if (n_rec * (double)per_rec <= (double)limit) return false;
+  ctx->seq_L = g.L; ctx->seq_pams = g.n_pams; ctx->seq_min_score = g.min_guide_score; ctx->seq_recs_per_tile = per_tile;
+  return true;
 }
 
 int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                             const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
   int rc = CALITAS_ENOMEM;
-  if (!known_not_to_fit(ctx, guide, params, false)) {
+  if (!known_not_to_fit(ctx, guide, params, false) && !predicted_not_to_fit(ctx, guide, params)) {
     rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
     if (rc != CALITAS_ENOMEM) return rc;
     if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
@@ -903,7 +972,7 @@ int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* gui
   char* text = nullptr;
   uint64_t bytes = 0, rows = 0;
   int rc = CALITAS_ENOMEM;
-  if (!known_not_to_fit(ctx, guide, params, false)) {
+  if (!known_not_to_fit(ctx, guide, params, false) && !predicted_not_to_fit(ctx, guide, params)) {
     rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, &bytes, &rows);
     if (rc == CALITAS_OK) {
       const int s = sink(text, bytes, user);
@@ -1007,11 +1076,18 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     rc = ensure_window_table(ctx, pl, ctx->scan_stream);
     if (rc) return rc;
     const bool device_rows = !std::getenv("CALITAS_HOST_HITS");
+    // (no early return inside this loop: the scans of the earlier lanes are already in flight and every exit waits for them)
+    auto hip_rc = [&](hipError_t e, const char* what) {
+      if (e == hipSuccess) return (int)CALITAS_OK;
+      if (e == hipErrorOutOfMemory) (void)hipGetLastError();
+      return fail(ctx, e == hipErrorOutOfMemory ? CALITAS_ENOMEM : CALITAS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
     for (size_t c = 0; c < K && !rc; c++) {
-      if (device_rows) HIP_TRY(ctx, hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream));   // before the wait below is queued
+      if (device_rows) rc = hip_rc(hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream), "hits_prepare");   // before the wait below is queued
+      if (rc) break;
       rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);                         // records lanes[c]->scan_done
       if (rc) { ctx->err = lanes[c]->err; break; }
-      HIP_TRY(ctx, hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0));
+      rc = hip_rc(hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0), "hipStreamWaitEvent");
     }
     if (rc) { (void)hipDeviceSynchronize(); return rc; }
     auto guess = [](size_t last) { return last + last / 4 + (1u << 20); };   // the next call's text is about as long as the last one's
@@ -1110,6 +1186,9 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
                  parts.size(), tm.scan_kernel_ms, tm.align_kernel_ms, tm.hits_kernel_ms, tm.hits_copy_ms,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),
                  (unsigned long long)tm.accepted_alignments, (unsigned long long)rows, total);
+  if (pl.p.chrom_index < 0 && (ctx->fit_pams != pl.gd[0].n_pams || ctx->fit_L != pl.gd[0].L || pl.gd[0].min_guide_score < ctx->fit_min_score)) {
+    ctx->fit_L = pl.gd[0].L; ctx->fit_pams = pl.gd[0].n_pams; ctx->fit_min_score = pl.gd[0].min_guide_score;   // the most permissive search seen to fit
+  }
   *tsv = text;
   if (tsv_bytes) *tsv_bytes = total;
   if (n_rows) *n_rows = rows;
@@ -1158,6 +1237,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   std::mutex scan_mu, copy_mu;
   const bool device_rows = !std::getenv("CALITAS_HOST_HITS");
   std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
+  std::vector<std::string> errs((size_t)n_guides);   // a failed guide's message, kept apart from its lane (a retry below destroys the lanes)
   std::vector<calitas_timing_t> tms((size_t)n_guides);
   std::vector<std::thread> threads;
   for (int l = 0; l < n_lanes; l++) {
@@ -1198,7 +1278,10 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
           return CALITAS_OK;
         };
         rcs[g] = step();
-        if (rcs[g] != CALITAS_OK) (void)hipStreamSynchronize(lane->stream);   // leave the lane quiet before its next guide
+        if (rcs[g] != CALITAS_OK) {
+          errs[g] = lane->err;
+          (void)hipStreamSynchronize(lane->stream);   // leave the lane quiet before its next guide
+        }
       }
     });
   }
@@ -1212,7 +1295,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
       tms[g] = ctx->timing;
       continue;
     }
-    ctx->err = ctx->lanes[g % n_lanes]->err;
+    ctx->err = errs[g];
     release();
     return rcs[g];
   }

@@ -69,11 +69,14 @@ __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guid
 
 // ders[] = der[] in slot order: the filter kernels read a window's records as one contiguous run
 __global__ void scatter_kernel(const Derived* der, uint32_t n, const uint32_t* offs, uint32_t* cnt, uint32_t* slot, Derived* ders,
-                               uint8_t* taken) {
+                               uint8_t* taken, uint32_t* counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Derived d = der[i];
   const uint32_t pos = offs[d.widx] + atomicSub(&cnt[d.widx], 1u) - 1u;
+  // cnt[] must have been all zero when count_kernel started (new buffers are filled with 0xFF and then cleared on the using
+  // stream, see grow()): a clear that is missing or ordered wrongly shows here as a slot outside [0, n) -- reported, not written
+  if (pos >= n) { atomicOr(&counts[1], SELECT_FLAG_INTERNAL); return; }
   slot[pos] = i;
   ders[pos] = d;
   taken[i] = 0;                                        // indexed by slot position below; any permutation clears all n
@@ -208,7 +211,12 @@ hipError_t grow(T** p, size_t& cap, size_t need, hipStream_t zero_on = nullptr, 
   hipError_t e = hipMalloc((void**)p, need * sizeof(T));
   if (e != hipSuccess) return e;
   cap = need;
-  return zero ? hipMemsetAsync(*p, 0, need * sizeof(T), zero_on) : hipSuccess;
+  if (!zero) return hipSuccess;
+  // poison first, then the clear, both on the using stream: if the clear ever gets lost or reordered again, the first call on the
+  // new buffer trips scatter_kernel's range check deterministically instead of depending on what the allocator handed out
+  e = hipMemsetAsync(*p, 0xFF, need * sizeof(T), zero_on);
+  if (e != hipSuccess) return e;
+  return hipMemsetAsync(*p, 0, need * sizeof(T), zero_on);
 }
 
 }  // namespace
@@ -270,7 +278,7 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
                      w.cnt, w.counts);
   size_t ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.cnt, w.offs, 0u, nw + 1, rocprim::plus<uint32_t>(), stream));   // cnt[nw] = 0: offs[nw] = n
-  hipLaunchKernelGGL(scatter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, n_raw, (const uint32_t*)w.offs, w.cnt, w.slot, w.ders, w.taken);
+  hipLaunchKernelGGL(scatter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, n_raw, (const uint32_t*)w.offs, w.cnt, w.slot, w.ders, w.taken, w.counts);
   hipLaunchKernelGGL(filter_kernel, grid_n, block, 0, stream, (const Derived*)w.ders, (const uint32_t*)w.offs, n_raw, max_total_diffs,
                      max_overlap, w.taken, w.kept, w.out_idx, w.counts, w.big);
   hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 2048)), dim3(64), 0, stream, (const Derived*)w.ders,

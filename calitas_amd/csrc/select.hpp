@@ -9,6 +9,10 @@ namespace calitas {
 
 struct SelectWork;   // device scratch, grown on demand and reused across searches
 
+// bit of (*d_counts)[1]: the per-window counters were not zero when the stage started (an internal error, never a property of the
+// input): the caller fails the search instead of falling back to the host filter
+constexpr uint32_t SELECT_FLAG_INTERNAL = 0x80000000u;
+
 // True when the global window index (guide x windows) fits the counters and an end column fits the enumeration key.
 bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides);
 

@@ -110,6 +110,8 @@ typedef struct {
   double hits_copy_ms;         /* the text's copy-back */
   uint64_t hit_rows;
   uint64_t hits_bytes;
+  uint32_t contig_passes;        /* calitas_search_hits in one-pass-per-contig mode: passes run (0 otherwise) */
+  uint32_t reserved;
 } calitas_timing_t;
 
 /* Context ------------------------------------------------------------------------------------------------------- */
@@ -164,6 +166,10 @@ int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
  * be held against each other and against a plain dynamic-programming count in the tests; calitas_free releases *records. */
 int calitas_scan_candidates(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                             uint32_t** records, uint64_t* n_records);
+/* Scan tiles of the resident reference: how many there are (contig tiles, padding excluded), how many of them the scan skips because
+ * they hold nothing but upper-case N (no window can contain any of their bases, SearchReference.scala:58-59), how many carry
+ * exception bases (N-run edges, IUPAC codes, contig ends), and the bases per tile. */
+int calitas_reference_tiles(const calitas_ctx* ctx, uint64_t* n_tiles, uint64_t* n_dead, uint64_t* n_masked, uint64_t* tile_bases);
 /* Packed position (the unit of calitas_scan_candidates) of base 0 of contig i. */
 int calitas_contig_packed_base(const calitas_ctx* ctx, int32_t i, uint64_t* gbase);
 

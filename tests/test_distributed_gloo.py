@@ -131,3 +131,20 @@ def test_lpt_partition_hg38_balance():
         parts = shard.lpt_partition(synth.HG38_LENGTHS, n)
         loads = [sum(synth.HG38_LENGTHS[i] for i in p) for p in parts]
         assert max(loads) / (sum(loads) / n) < 1.06
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the script starts two fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, 127.0.0.1), they rendezvous over gloo (--dry-run: no GPU work), and rank 0's line reports n_gpus = 2.  Under a
+    launcher's WORLD_SIZE that disagrees with --gpus the script refuses to run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line == {"dry_run": True, "n_gpus": 2, "rank_sum": 3, "local_rank": 0}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, timeout=120)
+    assert bad.returncode != 0 and b"WORLD_SIZE=2" in bad.stderr
