@@ -355,28 +355,36 @@ def main():
         G = [C.Guide(g) for g in my_guides]
         ids = ["bench%d" % i for i in range(len(G))]
         phase = {"search_hits": 0.0, "gather": 0.0, "search": 0.0, "hits": 0.0, "free": 0.0}
-        shm_path = "/dev/shm/calitas_bench_hits_%s.txt" % os.environ.get("MASTER_PORT", "0")
-        shm_fd = os.open(shm_path, os.O_RDWR | os.O_CREAT, 0o600) if (contig_mode and len(G) == 1) else -1
+        # Contig partition, host-side gather without a second copy: one file in shared memory holds a size table and a fixed slot per
+        # rank; every rank maps it, page-locks its slot and has the library deliver its piece of hits.txt straight into the slot
+        # (calitas_search_hits_into); hits.txt = rank 0's slot followed by the other slots without their header line.
+        shm = None
+        if contig_mode and len(G) == 1 and args.config == 3:
+            import mmap
+            import ctypes
+            import numpy as np
+            slot_bytes = max(8 << 20, int(160e6 * args.scale / world) * 2)
+            slot_bytes = (slot_bytes + 4095) & ~4095
+            shm_path = "/dev/shm/calitas_bench_hits_%s.bin" % os.environ.get("MASTER_PORT", "0")
+            if rank == 0:
+                with open(shm_path, "wb") as f:
+                    f.truncate(4096 + world * slot_bytes)
+            import torch.distributed as dist
+            dist.barrier(group=gloo)
+            fd = os.open(shm_path, os.O_RDWR)
+            mm = mmap.mmap(fd, 4096 + world * slot_bytes)
+            os.close(fd)
+            table = np.frombuffer(mm, dtype=np.uint64, count=world * 2)      # per rank: bytes, rows of its last step
+            base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+            slot_addr = base + 4096 + rank * slot_bytes
+            ctx.pin_host(slot_addr, slot_bytes)
+            shm = dict(mm=mm, table=table, slot_addr=slot_addr, slot_bytes=slot_bytes, path=shm_path)
         vcf_path, n_variants = None, 0
         if args.config == 5:
             vcf_path = "/dev/shm/calitas_bench_c5_%d_%d.vcf" % (os.getpid(), rank)
             t_v = time.perf_counter()
             n_variants = synthetic_vcf(vcf_path, names, seqs)
             log("synthetic VCF: %d variants in %.1f s" % (n_variants, time.perf_counter() - t_v))
-
-        def place_rows(view, rows):
-            """Contig partition, no copies: this rank's piece of the job's hits.txt goes from the library's buffer straight into the
-            shared file at its offset (rank 0 keeps the header line); only the sizes travel between the ranks."""
-            import torch.distributed as dist
-            nl = 0
-            if rank:
-                while view[nl] != 10:
-                    nl += 1
-                nl += 1
-            sizes = torch.zeros(world, 2, dtype=torch.int64)
-            dist.all_gather_into_tensor(sizes.view(-1), torch.tensor([len(view) - nl, rows], dtype=torch.int64), group=gloo)
-            os.pwrite(shm_fd, view[nl:], int(sizes[:rank, 0].sum()))
-            return int(sizes[:, 1].sum())
 
         def total_rows(rows):
             if not contig_mode:
@@ -403,11 +411,11 @@ def main():
                 tm = ctx.timing()
                 phase["search_hits"] += tp1 - tp0
                 return tm, tm["accepted_alignments"], total_rows(sum(r for _, r in res))
-            if contig_mode and not (args.no_hits or args.two_stage):
-                with ctx.search_hits_view(G[0], "bench", params, "bench", "bench") as (view, rows):
-                    tp1 = time.perf_counter()
-                    tm = ctx.timing()
-                    rows = place_rows(view, rows)
+            if shm is not None and not (args.no_hits or args.two_stage):
+                nbytes, rows = ctx.search_hits_into(G[0], "bench", params, shm["slot_addr"], shm["slot_bytes"], "bench", "bench")
+                tp1 = time.perf_counter()
+                tm = ctx.timing()
+                shm["table"][2 * rank] = nbytes; shm["table"][2 * rank + 1] = rows      # the gather: the text is in place already
                 phase["search_hits"] += tp1 - tp0; phase["gather"] += time.perf_counter() - tp1
                 return tm, tm["accepted_alignments"], rows
             if not (args.no_hits or args.two_stage):
@@ -462,16 +470,29 @@ def main():
             else:
                 text = [ctx.search_hits(G[0], "bench", params, "bench", "bench")[0]]
         tiles = ctx.tile_census()
-        ctx.close()
-        if shm_fd >= 0:
+        if shm is not None:
             import torch.distributed as dist
             dist.barrier(group=gloo)
-            if rank == 0:   # the assembled file of the last step: one header, `rows` rows, contigs in dictionary order
-                size = os.fstat(shm_fd).st_size
-                n_lines = os.pread(shm_fd, size, 0).count(b"\n")
-                log("contig partition: assembled hits.txt in shared memory has %d lines (%d bytes)" % (n_lines, size))
-                os.unlink(shm_path)
-            os.close(shm_fd)
+            total = 0
+            if rank == 0:   # the gathered file of the last step: one header, all rows, contigs in dictionary order
+                mm, tb = shm["mm"], shm["table"]
+                n_lines, n_bytes = 0, 0
+                for r in range(world):
+                    lo = 4096 + r * shm["slot_bytes"]
+                    piece = mm[lo:lo + int(tb[2 * r])]
+                    if r:
+                        piece = piece[piece.index(b"\n") + 1:]
+                    n_lines += piece.count(b"\n"); n_bytes += len(piece)
+                total = int(sum(int(tb[2 * r + 1]) for r in range(world)))
+                assert n_lines == total + 1, (n_lines, total)
+                log("contig partition: hits.txt gathered in shared memory has %d rows (%d bytes) from %d ranks" % (total, n_bytes, world))
+            ctx.unpin_host(shm["slot_addr"])
+            dist.barrier(group=gloo)
+            del shm["table"]
+            if rank == 0:
+                os.unlink(shm["path"])
+                last = (last[0], last[1], total)
+        ctx.close()
         if vcf_path:
             os.unlink(vcf_path)
         return dict(dt=dt, acc=acc, last=last, phase=phase, my_guides=my_guides, passes_per_step=passes_per_step,

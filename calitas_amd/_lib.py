@@ -56,7 +56,7 @@ class TimingT(ctypes.Structure):
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
            "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases",
-           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
+           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_into", "calitas_pin_host", "calitas_unpin_host", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -101,6 +101,10 @@ lib.calitas_search_hits.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), cty
 lib.calitas_search_hits_batch.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(GuideT), ctypes.POINTER(ctypes.c_char_p),
                                           ctypes.POINTER(ParamsT), ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p),
                                           ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+lib.calitas_search_hits_into.argtypes = [ctypes.c_void_p, ctypes.POINTER(GuideT), ctypes.c_char_p, ctypes.POINTER(ParamsT), ctypes.c_char_p,
+                                         ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+lib.calitas_pin_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+lib.calitas_unpin_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.calitas_genome_build.restype = ctypes.c_char_p
 lib.calitas_genome_build.argtypes = [ctypes.c_void_p]
 TextSink = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)

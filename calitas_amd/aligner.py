@@ -311,6 +311,22 @@ class Context:
         lib.calitas_free(tsv)
         return text, rows.value
 
+    def search_hits_into(self, guide, guide_id, params, address, capacity, version=None, time_stamp=None):
+        """calitas_search_hits_into: the text goes to `capacity` bytes at `address` (memory of the caller, ideally pinned with
+        pin_host).  Returns (n_bytes, n_rows)."""
+        g = guide.to_c()
+        nbytes, rows = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._h, lib.calitas_search_hits_into(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params),
+                                                         version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                                         ctypes.c_void_p(address), capacity, ctypes.byref(nbytes), ctypes.byref(rows)))
+        return nbytes.value, rows.value
+
+    def pin_host(self, address, nbytes):
+        _lib.check(self._h, lib.calitas_pin_host(self._h, ctypes.c_void_p(address), nbytes))
+
+    def unpin_host(self, address):
+        _lib.check(self._h, lib.calitas_unpin_host(self._h, ctypes.c_void_p(address)))
+
     def search_hits_stream(self, guide, guide_id, params, write, version=None, time_stamp=None):
         """calitas_search_hits_stream: `write(memoryview)` receives consecutive pieces of hits.txt (one piece when the search fits
         one call; header, then per-contig pieces when it does not fit the device).  A piece is the library's own buffer, valid only

@@ -190,6 +190,7 @@ void calitas_destroy(calitas_ctx* c) {
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);
     if (c->rows_ready) (void)hipEventDestroy(c->rows_ready);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    mailbox_close(c->mbox);
     if (c->h_guides) (void)hipHostFree(c->h_guides);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -479,6 +480,30 @@ int calitas_search_hits(calitas_ctx* ctx, const calitas_guide_t* guide, const ch
   if (!ctx) return CALITAS_EINVAL;
   if (!guide || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "NULL argument");
   return calitas_search_hits_impl(ctx, guide, guide_id ? guide_id : "", params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
+}
+
+int calitas_search_hits_into(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                             const char* aligner_version, const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes,
+                             uint64_t* n_rows) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!guide || !params || !dst) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  if (tsv_bytes) *tsv_bytes = 0;
+  if (n_rows) *n_rows = 0;
+  return calitas_search_hits_into_impl(ctx, guide, guide_id ? guide_id : "", params, aligner_version, time_stamp, dst, dst_capacity, tsv_bytes, n_rows);
+}
+
+int calitas_pin_host(calitas_ctx* ctx, void* p, uint64_t bytes) {
+  if (!ctx || !p || !bytes) return CALITAS_EINVAL;
+  if (ctx->device < 0) return fail(ctx, CALITAS_ENODEV, "host-only context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+  return CALITAS_OK;
+}
+
+int calitas_unpin_host(calitas_ctx* ctx, void* p) {
+  if (!ctx || !p) return CALITAS_EINVAL;
+  HIP_TRY(ctx, hipHostUnregister(p));
+  return CALITAS_OK;
 }
 
 int calitas_search_hits_stream(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,

@@ -17,6 +17,7 @@
 #include "select.hpp"
 #include "hits.hpp"
 #include "dma.hpp"
+#include "mailbox.hpp"
 
 using namespace calitas;
 
@@ -49,6 +50,7 @@ struct calitas_ctx {
   uint64_t* d_items = nullptr;      // passing candidates (align_kernel -> trace_kernel)
   uint32_t item_cap = 0;
   uint32_t* h_counters = nullptr;   // pinned
+  Mailbox mbox;                     // how the counters reach h_counters between two stages of a search (mailbox.hpp)
   uint32_t rec_cap = 0, raw_cap = 0;
   RawAln* h_raw = nullptr;          // pinned staging for the copy-back
   uint32_t h_raw_cap = 0;
@@ -88,6 +90,9 @@ int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_
                         calitas_aln_t** out, uint64_t* n_out);
 int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                              const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
+int calitas_search_hits_into_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                                  const char* aligner_version, const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes,
+                                  uint64_t* n_rows);
 int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                     const char* aligner_version, const char* time_stamp, calitas_text_sink_t sink, void* user,
                                     uint64_t* tsv_bytes, uint64_t* n_rows);

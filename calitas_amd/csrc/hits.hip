@@ -30,6 +30,7 @@
 #include "../../include/calitas_hip.h"
 #include "common.hpp"
 #include "hits.hpp"
+#include "mailbox.hpp"
 #include "refpack.hpp"
 
 namespace calitas {
@@ -50,7 +51,7 @@ struct RowConstDev {
 };
 
 __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
-                           int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* flags) {
+                           int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* wks, uint32_t* flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const RawAln* rp = fin + i;
@@ -84,6 +85,33 @@ __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides
   if (sb < 0 || sb >= (1 << SCORE_BITS) || h.gstart < 0) { atomicOr(flags, HITS_FLAG_SCORE_RANGE); sb = 0; }
   keys[i] = ((uint64_t)r.contig << 46) | ((uint64_t)(uint32_t)h.gstart << 15) | ((uint64_t)h.minus << 14) | (uint64_t)sb;
   vals[i] = i;
+  wks[i] = r.window_k;
+}
+
+// ReferenceHit.sort without a sort.  The accepted alignments arrive in (contig, window, ...) order, and hits of two windows that
+// share no base cannot be out of order relative to each other (a hit starts inside its window): with reach = the number of
+// window steps after which two windows are disjoint, hit i only has to be compared with the hits of the windows less than
+// `reach` steps away.  rank(i) = i - (earlier neighbours with a greater key) + (later neighbours with a smaller key); equal keys
+// keep their arrival order, as a stable sort would.  One launch instead of the seven of a 64-bit radix / merge sort; the caller
+// takes the general sort when a window holds more records than a lane should walk past.
+__global__ void rank_kernel(const uint64_t* keys, const uint32_t* wks, uint32_t n, uint32_t reach, uint32_t* order) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  const uint64_t contig = k >> 46;
+  const uint32_t wk = wks[i];
+  uint32_t rank = i;
+  for (uint32_t j = i; j-- > 0;) {
+    const uint64_t kj = keys[j];
+    if ((kj >> 46) != contig || wk - wks[j] >= reach) break;
+    rank -= kj > k;
+  }
+  for (uint32_t j = i + 1; j < n; j++) {
+    const uint64_t kj = keys[j];
+    if ((kj >> 46) != contig || wks[j] - wk >= reach) break;
+    rank += kj < k;
+  }
+  order[rank] = i;
 }
 
 constexpr int HIT_MAX_LEN = CALITAS_MAX_OPS;   // a hit covers at most this many reference bases (ReferenceHit.end - start + 1)
@@ -445,7 +473,7 @@ struct HitsWork {
   HitRec* hits = nullptr; size_t hits_cap = 0;
   uint64_t *keys = nullptr, *keys2 = nullptr, *lens = nullptr, *offs = nullptr;
   size_t keys_cap = 0, keys2_cap = 0, lens_cap = 0, offs_cap = 0;
-  uint32_t *vals = nullptr, *vals2 = nullptr, *s_cs = nullptr; size_t vals_cap = 0, vals2_cap = 0, cs_cap = 0;
+  uint32_t *vals = nullptr, *vals2 = nullptr, *s_cs = nullptr, *wks = nullptr; size_t vals_cap = 0, vals2_cap = 0, cs_cap = 0, wks_cap = 0;
   int32_t *s_start = nullptr, *s_end = nullptr, *s_score = nullptr; size_t ss_cap = 0, se_cap = 0, sc_cap = 0;
   uint8_t *keep = nullptr, *head = nullptr; size_t keep_cap = 0, head_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
@@ -457,6 +485,7 @@ struct HitsWork {
   uint32_t* name_off = nullptr; size_t name_off_cap = 0;
   uint64_t* d_counts = nullptr;   // [0] text bytes, [1] low word: kept rows, [2] low word: flags
   uint64_t* h_counts = nullptr;   // pinned
+  Mailbox mbox;                   // carries d_counts to the host (mailbox.hpp)
   RowConstDev rc{};               // set by hits_prepare
   size_t blob_bytes = 0;
   std::string blob_host;
@@ -466,11 +495,12 @@ struct HitsWork {
 void hits_destroy(HitsWork* w) {
   if (!w) return;
   (void)hipFree(w->hits); (void)hipFree(w->keys); (void)hipFree(w->keys2); (void)hipFree(w->lens); (void)hipFree(w->offs);
-  (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_cs); (void)hipFree(w->s_start); (void)hipFree(w->s_end);
+  (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_cs); (void)hipFree(w->wks); (void)hipFree(w->s_start); (void)hipFree(w->s_end);
   (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->head); (void)hipFree(w->temp); (void)hipFree(w->text);
   (void)hipFree(w->stage); (void)hipFree(w->midlen); (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off);
   (void)hipFree(w->d_counts);
   if (w->h_counts) (void)hipHostFree(w->h_counts);
+  mailbox_close(w->mbox);
   delete w;
 }
 
@@ -521,7 +551,7 @@ hipError_t hits_prepare(HitsWork** pw, const RowStrings& st, hipStream_t stream)
 
 hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, uint32_t n_in, const GuideDev* d_guides,
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& st, int max_overlap, int score_hi,
-                    int max_ops, hipStream_t stream, HitsResult* res) {
+                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res) {
   if (!*pw) *pw = new HitsWork();
   HitsWork& w = **pw;
   hipError_t e;
@@ -536,11 +566,11 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   uint32_t* d_flags = (uint32_t*)(w.d_counts + 2);
 
   TRY(grow(&w.hits, w.hits_cap, n)); TRY(grow(&w.keys, w.keys_cap, n)); TRY(grow(&w.keys2, w.keys2_cap, n));
-  TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n)); TRY(grow(&w.s_cs, w.cs_cap, n));
+  TRY(grow(&w.vals, w.vals_cap, n)); TRY(grow(&w.vals2, w.vals2_cap, n)); TRY(grow(&w.s_cs, w.cs_cap, n)); TRY(grow(&w.wks, w.wks_cap, n));
   TRY(grow(&w.lens, w.lens_cap, n)); TRY(grow(&w.offs, w.offs_cap, n)); TRY(grow(&w.s_start, w.ss_cap, n));
   TRY(grow(&w.s_end, w.se_cap, n)); TRY(grow(&w.s_score, w.sc_cap, n)); TRY(grow(&w.keep, w.keep_cap, n)); TRY(grow(&w.head, w.head_cap, n));
   size_t t1 = 0, t3 = 0;
-  TRY(rocprim::radix_sort_pairs(nullptr, t1, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
+  if (window_reach == 0) TRY(rocprim::radix_sort_pairs(nullptr, t1, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
   TRY(rocprim::exclusive_scan(nullptr, t3, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   {
     const size_t need = std::max(t1, t3);
@@ -549,9 +579,13 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
   size_t ts;
   // 1: coordinates and the final order
-  hipLaunchKernelGGL(hit_kernel, grid, block, 0, stream, d_final, n_in, d_guides, d_win_base, d_win, score_hi, w.hits, w.keys, w.vals, d_flags);
-  ts = w.temp_cap;
-  TRY(rocprim::radix_sort_pairs(w.temp, ts, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
+  hipLaunchKernelGGL(hit_kernel, grid, block, 0, stream, d_final, n_in, d_guides, d_win_base, d_win, score_hi, w.hits, w.keys, w.vals, w.wks, d_flags);
+  if (window_reach) {   // the order by counting among the neighbouring windows (rank_kernel)
+    hipLaunchKernelGGL(rank_kernel, grid, block, 0, stream, (const uint64_t*)w.keys, (const uint32_t*)w.wks, n_in, window_reach, w.vals2);
+  } else {              // a window is too crowded for that: the general stable sort
+    ts = w.temp_cap;
+    TRY(rocprim::radix_sort_pairs(w.temp, ts, w.keys, w.keys2, w.vals, w.vals2, n, 0, 64, stream));
+  }
   // 2-3: removeOverlaps
   hipLaunchKernelGGL(prep_kernel, grid, block, 0, stream, (const HitRec*)w.hits, (const uint32_t*)w.vals2, n_in, max_overlap, w.s_start, w.s_end,
                      w.s_score, w.s_cs, w.head, w.keep);
@@ -582,11 +616,9 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts);
-  TRY(hipMemcpyAsync(w.h_counts, w.d_counts, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  for (unsigned spins = 0; (e = hipStreamQuery(stream)) == hipErrorNotReady; spins++) {   // poll: a blocking wait costs tens of microseconds more
-    if (spins < 4096) __builtin_ia32_pause(); else sched_yield();
-  }
-  TRY(e);
+  TRY(mailbox_post(w.mbox, reinterpret_cast<const uint32_t*>(w.d_counts), 6, stream));
+  TRY(mailbox_wait(w.mbox, stream));
+  for (int k = 0; k < 3; k++) w.h_counts[k] = (uint64_t)w.mbox.host[1 + 2 * k] | ((uint64_t)w.mbox.host[2 + 2 * k] << 32);
   TRY(hipGetLastError());
   res->flags = (uint32_t)w.h_counts[2];
   if (res->flags) return hipSuccess;

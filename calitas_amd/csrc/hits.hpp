@@ -48,10 +48,12 @@ hipError_t hits_prepare(HitsWork** work, const RowStrings& strings, hipStream_t 
 
 // d_final[0..n): accepted alignments of ONE guide in calitas_search order (device memory).  Stream-ordered except for one
 // synchronisation to learn the text size.  max_ops bounds the padded columns of any alignment of this search (it sizes the
-// per-row LDS slots).  On success the rows are at res->d_text in final order.
+// per-row LDS slots).  window_reach: the number of window steps after which two windows share no base (the final order then comes
+// from a count among neighbouring windows), or 0 for the general sort (crowded windows).  On success the rows are at res->d_text in
+// final order.
 hipError_t hits_run(HitsWork** work, const HitsRef& ref, const RawAln* d_final, uint32_t n, const GuideDev* d_guides,
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& strings, int max_overlap, int score_hi,
-                    int max_ops, hipStream_t stream, HitsResult* res);
+                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res);
 void hits_destroy(HitsWork* work);
 
 }  // namespace calitas

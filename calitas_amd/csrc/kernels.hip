@@ -22,6 +22,7 @@
 #include "common.hpp"
 #include "refpack.hpp"
 #include "kernels.hpp"
+#include "mailbox.hpp"
 
 namespace calitas {
 
@@ -687,6 +688,60 @@ __global__ void window_table_kernel(const Run* runs, int64_t n_runs, const Conti
 __global__ void dpp_selftest_kernel(int* out) {
   int v = (int)threadIdx.x * 7 + 3;
   out[threadIdx.x] = shift_up_lane(v);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// mailbox (mailbox.hpp)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void mailbox_kernel(const uint32_t* src, int n, uint32_t* box, uint32_t seq) {
+  for (int i = 0; i < n; i++) box[1 + i] = src[i];
+  __threadfence_system();
+  __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t mailbox_open(Mailbox& mb) {
+  if (mb.host) return hipSuccess;
+  void* h = nullptr;
+  hipError_t e = hipHostMalloc(&h, (MAILBOX_WORDS + 1) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) return e;
+  void* d = nullptr;
+  e = hipHostGetDevicePointer(&d, h, 0);
+  if (e != hipSuccess) { (void)hipHostFree(h); return e; }
+  mb.host = (volatile uint32_t*)h; mb.dev = (uint32_t*)d; mb.seq = 0;
+  mb.host[0] = 0;
+  return hipSuccess;
+}
+
+void mailbox_close(Mailbox& mb) {
+  if (mb.host) (void)hipHostFree((void*)mb.host);
+  mb.host = nullptr; mb.dev = nullptr;
+}
+
+hipError_t mailbox_post(Mailbox& mb, const uint32_t* src, int n, hipStream_t stream) {
+  hipError_t e = mailbox_open(mb);
+  if (e != hipSuccess) return e;
+  if (n > MAILBOX_WORDS) return hipErrorInvalidValue;
+  mb.seq++;
+  hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, stream, src, n, mb.dev, mb.seq);
+  return hipGetLastError();
+}
+
+hipError_t mailbox_wait(Mailbox& mb, hipStream_t stream) {
+  for (unsigned spins = 0; mb.host[0] != mb.seq; spins++) {
+    if ((spins & 0x3FF) == 0x3FF) {            // now and then: is the stream still alive?
+      const hipError_t e = hipStreamQuery(stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return e;
+      if (e == hipSuccess && mb.host[0] != mb.seq) {      // everything queued has run, yet nothing arrived
+        if (mb.host[0] == mb.seq) break;
+        return hipErrorUnknown;
+      }
+      if (spins > (1u << 16)) sched_yield();
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

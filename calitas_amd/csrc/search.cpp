@@ -120,6 +120,7 @@ struct DeviceSel {
   bool valid = false;
   const RawAln* d_final = nullptr;
   uint32_t n_sel = 0;
+  bool crowded = false;    // some window held more records than one lane filters (select.hip GROUP_MAX)
   std::chrono::steady_clock::time_point t_call;
 };
 
@@ -267,11 +268,17 @@ static bool scan_columnwise() {
   return e && std::strcmp(e, "columns") == 0;
 }
 
-static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
+// The inputs of a lane's scan: guide constants and cleared counters, queued on `stream`.
+static int queue_scan_inputs(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
   // from the context's pinned copy (an async copy from pageable memory may wait for the stream to drain)
   std::memcpy(ctx->h_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, ctx->h_guides, sizeof(GuideDev) * pl.n_guides, hipMemcpyHostToDevice, stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), stream));
+  return CALITAS_OK;
+}
+
+static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream, bool inputs_queued = false) {
+  if (!inputs_queued) { int rc = queue_scan_inputs(ctx, pl, stream); if (rc) return rc; }
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(ctx, pl, sa, aa);
   ctx->t_scan0 = ctx->ev[0];
@@ -320,8 +327,9 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     fill_kernel_args(ctx, pl, sa, aa);
     HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
     HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream, ctx->ev[2]));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
+    HIP_TRY(ctx, mailbox_post(ctx->mbox, ctx->d_counters, 8, ctx->stream));
+    HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
+    for (int k = 0; k < 8; k++) ctx->h_counters[k] = ctx->mbox.host[1 + k];
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
     const uint32_t n_items = ctx->h_counters[3];
     if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
@@ -355,8 +363,9 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
                             p.max_overlap, ctx->stream, &d_final, &d_cnt));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + 5, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
+    HIP_TRY(ctx, mailbox_post(ctx->mbox, d_cnt, 3, ctx->stream));
+    HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
+    ctx->h_counters[5] = ctx->mbox.host[1]; ctx->h_counters[6] = ctx->mbox.host[2]; ctx->h_counters[7] = ctx->mbox.host[3];
     select_done(ctx->select);
     if (ctx->h_counters[6] & SELECT_FLAG_INTERNAL)
       return fail(ctx, CALITAS_EHIP, "per-window filter: window counters were not clear at the start of the stage (internal error)");
@@ -387,7 +396,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     tm.accepted_alignments = n_sel;
     tm.candidate_columns = ctx->h_counters[4];
     if (dev) {   // calitas_search_hits goes on from the device copy
-      dev->valid = true; dev->d_final = d_sel; dev->n_sel = n_sel; dev->t_call = t_call;
+      dev->valid = true; dev->d_final = d_sel; dev->n_sel = n_sel; dev->t_call = t_call; dev->crowded = ctx->h_counters[7] != 0;
       ctx->timing = tm;
       return CALITAS_OK;
     }
@@ -656,7 +665,8 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       HitsResult res{};
       HIP_TRY(lane, hipEventRecord(lane->ev[4], lane->stream));
       HIP_TRY(lane, hits_run(&lane->hits, hr, dev.d_final, dev.n_sel, lane->d_guides, own->d_win_base, own->d_win, rs, p.max_overlap, score_hi,
-                             pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, lane->stream, &res));
+                             pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, dev.crowded ? 0u : (uint32_t)((p.window_size + pl.step - 1) / pl.step),
+                             lane->stream, &res));
       HIP_TRY(lane, hipEventRecord(lane->ev[5], lane->stream));
       kernel_times(lane, lt.tm);          // while out_kernel runs
       if (res.flags == 0) {
@@ -875,7 +885,8 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
 }
 
 static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
-                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows);
+                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
+                               char* user_dst = nullptr, uint64_t user_cap = 0);
 
 // Whether this search is known not to fit one pass: forced (CALITAS_SEQUENTIAL, tests), or at least as permissive as the last one on
 // this context that did not.  remember = true records the search as such.
@@ -964,6 +975,16 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
   return rc;
 }
 
+// calitas_search_hits_into: one pass (with lanes), text straight into the caller's buffer.  No per-contig mode here: a search that
+// does not fit the device answers CALITAS_ENOMEM.
+int calitas_search_hits_into_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                                  const char* aligner_version, const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes,
+                                  uint64_t* n_rows) {
+  if (!dst || dst_capacity < 2) return fail(ctx, CALITAS_EINVAL, "no destination buffer");
+  char* text = nullptr;
+  return search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, tsv_bytes, n_rows, dst, dst_capacity);
+}
+
 // calitas_search_hits_stream: the text goes to `sink` -- in one piece when the search fits one call, header and per-contig pieces
 // otherwise (no block of the size of the whole text is ever allocated then).
 int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
@@ -992,8 +1013,11 @@ int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* gui
   return rc;
 }
 
+// user_dst: the text goes into this caller-owned buffer of user_cap bytes (calitas_search_hits_into) instead of a block of the
+// library; CALITAS_EINVAL when it is too small.
 static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
-                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
+                               char* user_dst, uint64_t user_cap) {
   const auto t_call = std::chrono::steady_clock::now();
   *tsv = nullptr;
   if (tsv_bytes) *tsv_bytes = 0;
@@ -1022,7 +1046,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     if (weights.size() == 1) { int k = std::max(1, std::min(16, (int)weights[0])); weights.assign((size_t)k, 1.0); }
     for (double w : weights) if (!(w > 0)) { weights.clear(); break; }
   } else if (ref.total_bases >= (512ull << 20)) {
-    weights = {4, 3, 2};   // measured on hg38-sized input: the last range small, its tail is what nothing hides
+    weights = {5, 3, 2};   // measured on hg38-sized input: the last range small, its tail is what nothing hides
   }
   std::vector<std::pair<int, int>> ranges;
   if (weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);
@@ -1035,11 +1059,19 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   const size_t hlen = rs.header.size();
   std::mutex copy_mu;
   auto alloc_text = [&](size_t body) {
-    capacity = body;
-    text = (char*)calitas_out_alloc_pinned(hlen + body + 1);
+    if (user_dst) {                                   // the caller's buffer: as much room as it has
+      if (user_cap < hlen + body + 1 && user_cap < hlen + 1) return false;
+      capacity = (size_t)user_cap - hlen - 1;
+      text = user_dst;
+    } else {
+      capacity = body;
+      text = (char*)calitas_out_alloc_pinned(hlen + body + 1);
+    }
     if (text) std::memcpy(text, rs.header.data(), hlen);
     return text != nullptr;
   };
+  auto free_text = [&] { if (!user_dst) calitas_free(text); text = nullptr; };
+  const char* no_room = "the caller's buffer is too small for the text";
   // copies lane c's rows to their place (offset = header + rows of the lanes before it)
   auto place = [&](size_t c, size_t offset) -> int {
     LaneText& lt = parts[c];
@@ -1082,6 +1114,8 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       if (e == hipErrorOutOfMemory) (void)hipGetLastError();
       return fail(ctx, e == hipErrorOutOfMemory ? CALITAS_ENOMEM : CALITAS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
     };
+    // (The inputs of all ranges queued ahead of the first scan, so that the scans run back to back: tried again with the row-wise
+    // scan, 2.71 vs 2.68-2.72 ms per pass -- the scans then take 6 % longer beside the tails and nothing is won.)
     for (size_t c = 0; c < K && !rc; c++) {
       if (device_rows) rc = hip_rc(hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream), "hits_prepare");   // before the wait below is queued
       if (rc) break;
@@ -1131,7 +1165,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     }
     if (rc || overflow) {
       (void)hipDeviceSynchronize();
-      calitas_free(text); text = nullptr;
+      free_text();
       if (rc) return rc;
       {
         // the lanes counted their scan records and alignments even where they could not keep them: would one pass over everything fit?
@@ -1152,19 +1186,20 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       bool all = true;
       for (size_t c = 0; c < K; c++) all = all && (placed[c] || parts[c].bytes == 0);
       if (!all) {   // the guess was too small: place everything again in a buffer of the right size
-        calitas_free(text);
+        if (user_dst) return fail(ctx, CALITAS_EINVAL, no_room);
+        free_text();
         if (!alloc_text(guess(total))) return fail(ctx, CALITAS_EINVAL, "out of memory");   // big enough for the next call's guess as well
         size_t off = 0;
-        for (size_t c = 0; c < K; c++) { rc = place(c, off); if (rc) { ctx->err = lanes[c]->err; calitas_free(text); return rc; } off += parts[c].bytes; }
+        for (size_t c = 0; c < K; c++) { rc = place(c, off); if (rc) { ctx->err = lanes[c]->err; free_text(); return rc; } off += parts[c].bytes; }
       }
     }
   }
   if (!chunked) {
     rc = lane_rows(ctx, pl, false, rs, guide_id, version, stamp, parts[0]);
     if (rc) return rc;
-    if (!alloc_text((size_t)parts[0].bytes)) return fail(ctx, CALITAS_EINVAL, "out of memory");
+    if (!alloc_text((size_t)parts[0].bytes) || parts[0].bytes > capacity) return fail(ctx, CALITAS_EINVAL, user_dst ? no_room : "out of memory");
     rc = place(0, 0);
-    if (rc) { calitas_free(text); return rc; }
+    if (rc) { free_text(); return rc; }
   }
   size_t total = hlen;
   calitas_timing_t tm{};

@@ -240,6 +240,18 @@ int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, c
                          const calitas_aln_t* alns, uint64_t n_alns, const calitas_ext_hit_t* ext, uint64_t n_ext,
                          const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* n_rows);
 
+/* calitas_search_hits with the text delivered into a buffer of the caller (dst_capacity bytes, NUL included) instead of a block of
+ * the library: what a multi-process job uses to have every process's piece of hits.txt land in one shared mapping without a second
+ * copy (bench.py --gpus N).  The buffer should be page-locked -- calitas_pin_host does that -- or the copy from the device falls back
+ * to the runtime's staged path.  One pass only: CALITAS_ENOMEM when the search does not fit the device, CALITAS_EINVAL when the
+ * buffer is too small. */
+int calitas_search_hits_into(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                             const char* aligner_version, const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes,
+                             uint64_t* n_rows);
+/* Page-locks / releases host memory the caller owns (hipHostRegister): destinations of calitas_search_hits_into. */
+int calitas_pin_host(calitas_ctx* ctx, void* p, uint64_t bytes);
+int calitas_unpin_host(calitas_ctx* ctx, void* p);
+
 /* calitas_search_hits with the text handed to a callback instead of returned in one block (Metric.writer's output stream,
  * SearchReference.scala:646-648): `sink` receives consecutive pieces of hits.txt -- the whole text in one piece when the search fits
  * one call, the header and then every contig's rows (in portions of at most 1 GB) when it runs one pass per contig; a piece is

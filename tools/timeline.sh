@@ -33,10 +33,12 @@ for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy", "%s %.1f MB" % (r.get("Direction", ""), b / 1e6)))
 ev.sort()
 # the last call starts at the last-but-one scan_kernel launch group: find the last two scan kernels
-scans = [e for e in ev if e[3].startswith("void scan_kernel") or "scan_kernel" in e[3]]
+scans = [e for e in ev if "scan_kernel" in e[3] or "scan_rows_kernel" in e[3]]
+if not ev:
+    print(open("/tmp/tl.log").read()[-3000:]); sys.exit(1)
 t0 = scans[-2][0] if len(scans) >= 2 else ev[0][0]
 if os.environ.get("TIMELINE_PROG"):
-    t0 = scans[-1][0]
+    t0 = scans[-1][0] if scans else ev[0][0]
 with open(out, "w") as f:
     for s, e, q, n in ev:
         if s < t0:
