@@ -438,7 +438,6 @@ class SearchReference:
                  guide_gap_net_cost=Defaults.GuideGapNetCost, chrom=None, variants=None,
                  max_variants=Defaults.MaxVariantsInCluster, context=None, device=0, eqx_by_score=0, two_stage=False):
         self.variants = variants
-        self.python_variants = False
         self.two_stage = two_stage
         self.guide_str, self.guide_id, self.ref, self.output = guide, guide_id, ref, output
         self.query = Guide(guide, auxiliary_pams)  # SearchReference.scala:511: fail early on an invalid guide
@@ -468,8 +467,6 @@ class SearchReference:
                 chrom_index = ctx.contig_names.index(self.chrom)
             if self.variants is not None:   # SearchReference.scala:570-630
                 from . import variants as V
-                if self.python_variants:     # the same branch written in Python (cross-check of calitas_search_variants)
-                    return V.search_reference_with_variants(self, ctx, self.variants, version, time_stamp)
                 return V.search_variants(self, ctx, self.variants, chrom_index, version, time_stamp)
             params = make_params(chrom_index=chrom_index, **self._kw)
             t0 = time.perf_counter()

@@ -90,8 +90,13 @@ def test_random_vcf_parity(C, guide, kw, tmp_path):
     sr = C.SearchReference(guide=guide, guide_id="a", ref=fa, variants=vcf, max_guide_diffs=kw["d"], max_pam_mismatches=kw["p"],
                            max_gaps_between_guide_and_pam=kw["g"])
     text, n = sr.run("v0", "stamp")                            # calitas_search_variants (C++ window production and rows)
-    sr.python_variants = True
-    assert sr.run("v0", "stamp") == (text, n)                  # the same branch written in Python (variants.py): same bytes
+    import variants_twin                                        # the same branch written in Python: same bytes
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        assert variants_twin.search_reference_with_variants(sr, ctx, vcf, "v0", "stamp") == (text, n)
+    finally:
+        ctx.close()
     assert sr.variant_windows > 0
     got = C.read_hits(text)
     import gzip, shutil                                       # the same records gzipped: same rows (the file id differs)
@@ -153,8 +158,13 @@ def test_many_batches_equal_python_twin(C, tmp_path):
                            max_gaps_between_guide_and_pam=2, max_variants=3)
     text, n = sr.run("v0", "stamp")
     assert sr.variant_windows > 16384                          # more than one batch
-    sr.python_variants = True
-    assert sr.run("v0", "stamp") == (text, n)
+    import variants_twin
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        assert variants_twin.search_reference_with_variants(sr, ctx, vcf, "v0", "stamp") == (text, n)
+    finally:
+        ctx.close()
     _, want, _ = O.search_reference_vcf(fa, vcf, guide, "a", d=4, p=1, g=2, max_variants=3)
     got = C.read_hits(text)
     assert sum(1 for r in got if r["variant_id"] or r["variant_description"]) > 10

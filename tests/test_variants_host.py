@@ -1,4 +1,5 @@
-"""CPU tests of the product's variant-window producers (calitas_amd/variants.py) against the reference's own vectors
+"""CPU tests of the Python cross-check of the variant branch (tests/variants_twin.py, what the GPU tests hold calitas_search_variants
+against) and of the package's VCF helpers against the reference's own vectors
 V1-V9 (SearchReferenceTest.scala:150-295) and against the oracle on random variant sets; PrepareVcf (PrepareVcfTest.scala)."""
 import json
 import os
@@ -7,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+import calitas_amd.variants as PV
 from test_oracle_variants import write_vcf
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -15,8 +17,8 @@ V = json.load(open(os.path.join(GOLD, "kat_variants.json")))
 
 @pytest.fixture(scope="module")
 def VA():
-    from calitas_amd import variants
-    return variants
+    import variants_twin
+    return variants_twin
 
 
 @pytest.mark.parametrize("case", V["allele_combos_counts"], ids=lambda c: "x".join(map(str, c["counts"])))
@@ -93,8 +95,8 @@ def test_prepare_vcf(VA, tmp_path):
         f.write("1\t21000\t.\tA\tC\t.\tq10\tAF=0.5\tGT\t0/1\t./.\n")
         f.write("1\t22000\t.\tA\tC\t.\tPASS\tAF=0.0001\tGT\t0/1\t./.\n")
     out = tmp_path / "out.vcf"
-    n = VA.prepare_vcf([str(src)], str(out), min_af=0.01)
-    hdr, vs = VA.read_vcf(str(out))
+    n = PV.prepare_vcf([str(src)], str(out), min_af=0.01)
+    hdr, vs = PV.read_vcf(str(out))
     assert n == 11 and len(vs) == 11
     assert [h for h in hdr if h.startswith("#CHROM")][0].split("\t")[-1] == "INFO"     # no samples
     assert all(v.chrom == "chr1" for v in vs)

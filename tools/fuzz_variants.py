@@ -9,6 +9,7 @@ import numpy as np
 import calitas_amd as C
 from calitas_amd import synth
 import oracle_lib as O
+import variants_twin
 from fasta_util import write_fasta
 from test_oracle_variants import write_vcf
 
@@ -90,8 +91,12 @@ def run(iters, seed):
             sr = C.SearchReference(guide=guide, guide_id="a", ref=fa, variants=vcf, max_guide_diffs=d, max_pam_mismatches=p,
                                    max_gaps_between_guide_and_pam=g, max_variants=mv)
             text, n = sr.run("v", "t")
-            sr.python_variants = True                      # the same branch written in Python: byte-identical
-            text_py, n_py = sr.run("v", "t")
+            tctx = C.Context(0)                            # the same branch written in Python (tests/variants_twin.py): byte-identical
+            tctx.set_reference_fasta(fa)
+            try:
+                text_py, n_py = variants_twin.search_reference_with_variants(sr, tctx, vcf, "v", "t")
+            finally:
+                tctx.close()
             if (text_py, n_py) != (text, n):
                 bad += 1
                 print("C++ / PYTHON DIFFER iter %d %s d%d p%d g%d V%d: %d vs %d rows" % (it, guide, d, p, g, mv, n, n_py), flush=True); continue
