@@ -499,13 +499,164 @@ def main():
                     bases_per_step_total=bases_per_step_total, names=names, seqs=seqs, text=text, tiles=tiles, n_variants=n_variants,
                     mine=mine)
 
+    def measure_windows():
+        """--shard windows (config 3): consecutive window ranges of equal size (shard.window_partition).  A rank finishes the contigs
+        that lie entirely inside its range with calitas_search_hits (text into its slot of the shared mapping); of a contig that is cut it
+        aligns its windows with calitas_search (first_window / n_windows), the parts' alignment records meet in shared memory at the
+        lowest rank that touches the contig, and that rank runs removeOverlaps / sort / rows on them (calitas_hits_tsv)."""
+        import ctypes
+        import mmap
+        import numpy as np
+        import torch.distributed as dist
+        AlnT = C._lib.AlnT
+        rec_size = ctypes.sizeof(AlnT)
+        step_w = 1000 - (len(GUIDE0) + params_kw["max_guide_diffs"] + params_kw["max_gaps_between_guide_and_pam"] - 1)
+        ranges = shard.window_partition(lengths, world, step_w)
+        parts_all = [shard.range_contigs(lengths, step_w, f, n) for f, n in ranges]
+        owner = shard.contig_owner(parts_all)
+        mine_parts = parts_all[rank]
+        whole_ids = [ci for ci, _, _, w in mine_parts if w]
+        cut = [(ci, k0, n) for ci, k0, n, w in mine_parts if not w]
+        cut_ids = sorted({ci for ci, _, _ in cut})
+        G0 = C.Guide(GUIDE0)
+        ctx_a = ctx_b = None
+        t_gen = time.perf_counter()
+        if whole_ids:
+            na, sa = build_genome(args.scale, device, contig_indices=whole_ids, guides=[GUIDE0], log=None)
+            ctx_a = C.Context(local_rank); ctx_a.set_reference(na, sa, genome_build="synthetic-hg38-sized"); del sa
+        if cut_ids:
+            nb, sb = build_genome(args.scale, device, contig_indices=cut_ids, guides=[GUIDE0], log=None)
+            ctx_b = C.Context(local_rank); ctx_b.set_reference(nb, sb, genome_build="synthetic-hg38-sized"); del sb
+        log("window partition: rank 0 holds %d whole contigs and %d cut ones, set up in %.1f s" % (len(whole_ids), len(cut_ids), time.perf_counter() - t_gen))
+        # window index of a cut contig's first window inside ctx_b's own window table
+        b_base, acc = {}, 0
+        for ci in cut_ids:
+            b_base[ci] = acc
+            acc += shard.window_counts([lengths[ci]], step_w)[0]
+        # shared mapping: table (8 words per rank), text slot and record slot per rank
+        slot_bytes = ((max(8 << 20, int(160e6 * args.scale / world) * 2)) + 4095) & ~4095
+        rec_slot = 8 << 20
+        shm_path = "/dev/shm/calitas_bench_win_%s.bin" % os.environ.get("MASTER_PORT", "0")
+        size = 4096 + world * (slot_bytes + rec_slot)
+        if rank == 0:
+            with open(shm_path, "wb") as f:
+                f.truncate(size)
+        dist.barrier(group=gloo)
+        fd = os.open(shm_path, os.O_RDWR)
+        mm = mmap.mmap(fd, size)
+        os.close(fd)
+        table = np.frombuffer(mm, dtype=np.uint64, count=world * 8).reshape(world, 8)   # text bytes, rows, cut rows, records, rec seq, done seq
+        base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+        text_addr = lambda r: base + 4096 + r * (slot_bytes + rec_slot)
+        rec_addr = lambda r: text_addr(r) + slot_bytes
+        if ctx_a is not None:
+            ctx_a.pin_host(text_addr(rank), slot_bytes)
+        sends = [(ci, k0, n) for ci, k0, n in cut if owner[ci] != rank]            # at most one: the head part of this rank's range
+        owned = [(ci, k0, n) for ci, k0, n in cut if owner[ci] == rank]
+        feeders = {ci: [q for q in range(world) if q != rank and any(c == ci for c, _, _, _ in parts_all[q])] for ci, _, _ in owned}
+        phase = {"search_hits": 0.0, "cut_search": 0.0, "exchange": 0.0, "cut_rows": 0.0}
+
+        def spin(cond):
+            n = 0
+            while not cond():
+                n += 1
+                if n > 200000000:
+                    raise SystemExit("bench.py: a rank stopped answering in the window-partition exchange")
+
+        def step(seq):
+            t0 = time.perf_counter()
+            rows_a = nbytes = 0
+            tm = None
+            if ctx_a is not None:
+                nbytes, rows_a = ctx_a.search_hits_into(G0, "bench", params, text_addr(rank), slot_bytes, "bench", "bench")
+                tm = ctx_a.timing()
+            t1 = time.perf_counter()
+            mine_recs = {}
+            for ci, k0, n in cut:
+                out, cnt = ctx_b.search_raw([G0], C.make_params(first_window=b_base[ci] + k0, n_windows=n, **params_kw))
+                mine_recs[ci] = (out, cnt)
+                if tm is None:
+                    tm = ctx_b.timing()
+            t2 = time.perf_counter()
+            for ci, k0, n in sends:                       # this part's records to the owner, through the record slot
+                out, cnt = mine_recs[ci]
+                o = owner[ci]
+                spin(lambda: int(table[o, 5]) >= seq - 1)         # the owner is done with the previous step's records
+                if cnt * rec_size > rec_slot:
+                    raise SystemExit("bench.py: record slot too small")
+                ctypes.memmove(rec_addr(rank), out, cnt * rec_size)
+                table[rank, 3] = cnt
+                table[rank, 4] = seq
+            rows_c = 0
+            t3 = time.perf_counter()
+            for ci, k0, n in owned:
+                out, cnt = mine_recs[ci]
+                pieces = [(ctypes.addressof(out.contents) if cnt else 0, cnt)]
+                for q in feeders[ci]:
+                    spin(lambda: int(table[q, 4]) >= seq)
+                    pieces.append((rec_addr(q), int(table[q, 3])))
+                total = sum(c for _, c in pieces)
+                arr = (AlnT * max(1, total))()
+                off = 0
+                for addr, c in pieces:
+                    if c:
+                        ctypes.memmove(ctypes.addressof(arr) + off * rec_size, addr, c * rec_size)
+                    off += c
+                if total:                                   # the feeders number the contig differently in their own context
+                    np.frombuffer(arr, dtype=np.int32).reshape(-1, rec_size // 4)[:total, 1] = cut_ids.index(ci)
+                _, r = ctx_b.hits_tsv_raw(G0, "bench", params, arr, total, "bench", "bench", decode=False)
+                rows_c += r
+            table[rank, 0] = nbytes; table[rank, 1] = rows_a; table[rank, 2] = rows_c
+            table[rank, 5] = seq
+            for out, _ in mine_recs.values():
+                C._lib.lib.calitas_free(out)
+            t4 = time.perf_counter()
+            phase["search_hits"] += t1 - t0; phase["cut_search"] += t2 - t1; phase["exchange"] += t3 - t2; phase["cut_rows"] += t4 - t3
+            return tm
+
+        seq = 0
+        for _ in range(3 + args.warmup):
+            seq += 1
+            step(seq)
+        for k in phase:
+            phase[k] = 0.0
+        sync()
+        t0 = time.perf_counter()
+        acc = {"scan": 0.0, "align": 0.0, "post": 0.0, "gpu": 0.0, "hitsk": 0.0, "copy": 0.0}
+        tm = None
+        for _ in range(args.steps):
+            seq += 1
+            tm = step(seq)
+            acc["scan"] += tm["scan_kernel_ms"]; acc["align"] += tm["align_kernel_ms"]; acc["gpu"] += tm["gpu_total_ms"]
+            acc["hitsk"] += tm["hits_kernel_ms"]; acc["copy"] += tm["hits_copy_ms"]
+        sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier(group=gloo)
+        rows = int(table[:, 1].sum() + table[:, 2].sum())
+        loads = [shard.range_bases(lengths, step_w, 1000, f, n) for f, n in ranges]
+        log("window partition: %d rows over %d ranks; bases per rank max / mean = %.4f" % (rows, world, max(loads) / (sum(loads) / world)))
+        tiles = (ctx_a or ctx_b).tile_census()
+        if ctx_a is not None:
+            ctx_a.unpin_host(text_addr(rank)); ctx_a.close()
+        if ctx_b is not None:
+            ctx_b.close()
+        dist.barrier(group=gloo)
+        del table
+        if rank == 0:
+            os.unlink(shm_path)
+        return dict(dt=dt, acc=acc, last=(tm, tm["accepted_alignments"], rows), phase=phase, my_guides=[GUIDE0], passes_per_step=1,
+                    bases_per_step_total=sum(lengths), names=[], seqs=[], text=None, tiles=tiles, n_variants=0, mine=None)
+
     headline_mode = args.shard if world > 1 else "none"
-    if headline_mode == "windows":
-        raise SystemExit("--shard windows: see calitas_amd/shard.py window_partition and tests/test_distributed_gloo.py; not wired into bench.py yet")
-    m = measure(headline_mode, keep_text=(world == 1))
+    if headline_mode == "windows" and args.config != 3:
+        raise SystemExit("--shard windows is implemented for --config 3")
+    m = measure_windows() if headline_mode == "windows" else measure(headline_mode, keep_text=(world == 1))
     second = None
     if world > 1 and not args.no_secondary and args.config == 3:
-        other = "guides" if headline_mode == "contigs" else "contigs"
+        other = "guides" if headline_mode in ("contigs", "windows") else "contigs"
         s = measure(other)
         second = {"partition": other, "scaling": "weak" if other == "guides" else "strong",
                   "value": 2.0 * s["bases_per_step_total"] * args.steps / s["dt"], "unit": "candidates/s", "ms_per_step": s["dt"] / args.steps * 1e3,
@@ -532,7 +683,7 @@ def main():
             "metric": "off-target candidates/sec (hg38 full scan), 20nt guide+NRG PAM",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and headline_mode == "contigs") else "weak",
+            "scaling": "strong" if (world > 1 and headline_mode in ("contigs", "windows")) else "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": args.config,
                        "guide": m["my_guides"][0], "guides_per_step_per_rank": n_guides_rank, "guide_passes_per_step": m["passes_per_step"],

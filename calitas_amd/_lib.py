@@ -29,7 +29,7 @@ class ParamsT(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "window_size", "max_guide_diffs", "max_pam_mismatches", "max_gaps_between_guide_and_pam", "max_total_diffs", "max_overlap",
         "guide_mismatch_net_cost", "pam_mismatch_net_cost", "genome_gap_net_cost", "guide_gap_net_cost", "chrom_index",
-        "eqx_by_score", "max_variants")]
+        "eqx_by_score", "max_variants", "first_window", "n_windows")]
 
 
 class AlnT(ctypes.Structure):

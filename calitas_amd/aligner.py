@@ -85,7 +85,7 @@ def make_params(window_size=1000, max_guide_diffs=Defaults.MaxGuideDiffs, max_pa
                 max_overlap=Defaults.MaxOverlap, guide_mismatch_net_cost=Defaults.MismatchNetCost,
                 pam_mismatch_net_cost=Defaults.PamMismatchNetCost, genome_gap_net_cost=Defaults.GenomeGapNetCost,
                 guide_gap_net_cost=Defaults.GuideGapNetCost, chrom_index=-1, eqx_by_score=0, per_matrix=0,
-                max_variants=Defaults.MaxVariantsInCluster):
+                max_variants=Defaults.MaxVariantsInCluster, first_window=0, n_windows=0):
     p = ParamsT()
     p.window_size = window_size
     p.max_guide_diffs = max_guide_diffs
@@ -100,6 +100,7 @@ def make_params(window_size=1000, max_guide_diffs=Defaults.MaxGuideDiffs, max_pa
     p.chrom_index = chrom_index
     p.eqx_by_score = (eqx_by_score & 3) | (2 if per_matrix else 0)   # bit flags, see calitas_hip.h
     p.max_variants = max_variants
+    p.first_window, p.n_windows = first_window, n_windows   # calitas_search only: a window range of the job (shard.window_partition)
     return p
 
 

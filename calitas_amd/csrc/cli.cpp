@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
   if (argc < 2 || std::strcmp(argv[1], "SearchReference") != 0) { usage(); return 2; }
   std::string guide, guide_id, ref, output, chrom, variants;
   std::vector<std::string> aux;
-  calitas_params_t p;
+  calitas_params_t p{};
   p.window_size = 1000; p.max_guide_diffs = 5; p.max_pam_mismatches = 1; p.max_gaps_between_guide_and_pam = 3; p.max_total_diffs = -1;
   p.max_overlap = 10; p.guide_mismatch_net_cost = -120; p.pam_mismatch_net_cost = -260; p.genome_gap_net_cost = -122;
   p.guide_gap_net_cost = -121; p.chrom_index = -1; p.eqx_by_score = 0; p.max_variants = 16;

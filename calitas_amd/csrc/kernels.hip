@@ -371,6 +371,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
     for (int64_t k = klo; k <= khi; k++) {
       if (k - klo >= (int64_t)a.slots_per_rec) break;   // cannot happen: the host sizes slots_per_rec from the tiling
       if ((uint64_t)k >= win_cnt) continue;            // no such window on this contig (Range(0, len-1, step), SR:52)
+      if (win_lo + (uint64_t)k < a.gw_lo || win_lo + (uint64_t)k >= a.gw_hi) continue;   // outside this call's window range
       const int2 wab = a.win[win_lo + (uint64_t)k];     // N-trimmed bounds, precomputed by window_table_kernel
       const int64_t wa = wab.x, wb = wab.y;
       const int n = (int)(wb - wa);

@@ -46,6 +46,7 @@ struct AlignArgs {
   uint32_t slots_per_rec;   // windows a 16-base record can fall into
   uint32_t rec_capacity;
   uint32_t out_capacity;
+  uint64_t gw_lo, gw_hi;   // global window indices [gw_lo, gw_hi) this call covers (calitas_params_t::first_window / n_windows)
   uint32_t tile_words;     // code words per scan tile
   SearchDev sp;
 };

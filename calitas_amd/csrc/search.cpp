@@ -109,6 +109,7 @@ struct SearchPlan {
   uint64_t slab_per_rec = 0;
   int warm_words = 1;                 // 32-base warm-up words of a scan lane: L + E - 1 <= 32 * warm_words
   uint64_t rec_hint = 0;              // expected scan records of this job (from estimate_scan_records), 0 = unknown
+  uint64_t gw_lo = 0, gw_hi = ~0ull;  // global window range of the call (calitas_params_t::first_window / n_windows); all by default
   // the part of the packed reference this job covers
   uint32_t tile_lo = 0, n_tiles = 0;
   uint64_t bases = 0;
@@ -198,6 +199,30 @@ static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
   pl.bases = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
   pl.win_lo = 0; pl.win_n = 0;
   for (auto& c : ref.contigs) pl.win_n += window_count(c.len, pl.step);
+  if (p.n_windows != 0 || p.first_window != 0) {
+    // a window range of the job: scan the tiles its windows touch, align only inside those windows
+    if (p.first_window < 0 || p.n_windows <= 0 || (uint64_t)p.first_window + (uint64_t)p.n_windows > pl.win_n)
+      return fail(ctx, CALITAS_EINVAL, "first_window / n_windows outside the window table (" + std::to_string(pl.win_n) + " windows)");
+    if (p.chrom_index >= 0) return fail(ctx, CALITAS_EINVAL, "a window range and chrom_index exclude each other");
+    pl.gw_lo = (uint64_t)p.first_window; pl.gw_hi = pl.gw_lo + (uint64_t)p.n_windows;
+    uint64_t base = 0, g_lo = 0, g_hi = 0, bases = 0;
+    bool first = true;
+    for (auto& c : ref.contigs) {
+      const uint64_t nw = window_count(c.len, pl.step);
+      const uint64_t a = std::max(pl.gw_lo, base), b = std::min(pl.gw_hi, base + nw);     // this contig's share of the range
+      if (a < b) {
+        const uint64_t lo = (a - base) * (uint64_t)pl.step, hi = std::min<uint64_t>(c.len, (b - 1 - base) * (uint64_t)pl.step + (uint64_t)p.window_size);
+        if (first) { g_lo = c.gbase + lo; first = false; }
+        g_hi = c.gbase + hi;
+        bases += hi - lo;
+      }
+      base += nw;
+    }
+    pl.tile_lo = (uint32_t)(g_lo / ref.tile);
+    pl.n_tiles = (uint32_t)((g_hi + ref.tile - 1) / ref.tile) - pl.tile_lo;
+    pl.bases = bases;
+    pl.win_lo = pl.gw_lo; pl.win_n = pl.gw_hi - pl.gw_lo;
+  }
   return CALITAS_OK;
 }
 
@@ -238,6 +263,7 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
   aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
   aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
+  aa.gw_lo = pl.gw_lo; aa.gw_hi = pl.gw_hi;
   aa.sp.window_size = p.window_size; aa.sp.step = pl.step; aa.sp.n_guides = pl.n_guides;
   aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
   aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;

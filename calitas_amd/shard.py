@@ -7,6 +7,13 @@ Two natural partitions exist:
     consecutive ranges (contiguous_partition) that is a plain concatenation of the ranks' texts; LPT packing balances a
     little better (1.05x of the mean against 1.14x for hg38 on 8 ranks) but needs the blocks re-ordered.
   * guides  -- the reference runs one guide per invocation, so a 96-guide batch is 96 independent outputs.
+  * windows -- the finest grain: windowIterator's sequence of windows (SearchReference.scala:39-71, contigs in order, starts
+    0, step, 2 step, ...) cut into consecutive ranges of equal size, wherever that falls (window_partition).  A rank runs
+    calitas_search on its range (calitas_params_t first_window / n_windows: every window is aligned exactly as in the whole job,
+    the window's own overlap is its halo); contigs that lie entirely inside a range finish on their rank as before, and for a
+    contig that is cut the alignments of its parts go to one rank -- in range order they are the alignments of the whole contig --
+    which runs removeOverlaps / sort / rows on them (SearchReference.scala:641-675).  Balance: every rank gets the same number of
+    windows, i.e. the same number of new bases to within one window step.
 """
 
 
@@ -90,3 +97,49 @@ def merge_contig_rows(header, per_rank_blocks):
 def guides_for_rank(n_guides, rank, world):
     """Round-robin assignment of guide indices to ranks."""
     return list(range(rank, n_guides, world))
+
+
+def window_counts(lengths, step):
+    """|Range(0, len - 1, step)| per contig: the windows windowIterator makes (SearchReference.scala:52)."""
+    return [0 if n < 2 else (n - 2) // step + 1 for n in lengths]
+
+
+def window_partition(lengths, n_bins, step):
+    """The job's windows (global index: contig-major, as calitas_window_table lists them) cut into n_bins consecutive ranges whose
+    sizes differ by at most one.  Returns a list of (first_window, n_windows)."""
+    total = sum(window_counts(lengths, step))
+    out, first = [], 0
+    for b in range(n_bins):
+        n = total // n_bins + (1 if b < total % n_bins else 0)
+        out.append((first, n))
+        first += n
+    return out
+
+
+def range_contigs(lengths, step, first_window, n_windows):
+    """What a window range covers: a list of (contig index, first window on the contig, number of windows, whole) in contig order,
+    whole = the range holds every window of that contig."""
+    out, base = [], 0
+    for ci, nw in enumerate(window_counts(lengths, step)):
+        a, b = max(first_window, base), min(first_window + n_windows, base + nw)
+        if a < b:
+            out.append((ci, a - base, b - a, b - a == nw))
+        base += nw
+    return out
+
+
+def range_bases(lengths, step, window_size, first_window, n_windows):
+    """Reference bases the windows of a range cover (the scan work of the rank that owns it)."""
+    total = 0
+    for ci, k0, n, _ in range_contigs(lengths, step, first_window, n_windows):
+        total += min(lengths[ci], (k0 + n - 1) * step + window_size) - k0 * step
+    return total
+
+
+def contig_owner(parts_per_rank):
+    """parts_per_rank[r] = range_contigs(...) of rank r.  {contig index: rank that finishes it} -- the lowest rank touching it."""
+    owner = {}
+    for r, parts in enumerate(parts_per_rank):
+        for ci, _, _, _ in parts:
+            owner.setdefault(ci, r)
+    return owner

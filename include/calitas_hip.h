@@ -71,6 +71,13 @@ typedef struct {
                                             * bit 1 (2): one alignment per bottom-row matrix cell (Diag, Left, Up) that reaches minScore
                                             *            instead of one per end column from the best of the three (U1) */
   int32_t max_variants;                    /* -V  only echoed into aligner_other_parameters */
+  /* calitas_search only: restrict the call to windows [first_window, first_window + n_windows) of windowIterator's sequence for this
+   * (window size, step) over the whole reference, contigs in order (the index calitas_window_table lists them in when min_length is 0);
+   * n_windows = 0 means all of them.  The piece of a job one process of a window-range partition runs (calitas_amd/shard.py
+   * window_partition): the alignments of consecutive ranges, concatenated, are the alignments of the whole call.  The calls that
+   * go on to removeOverlaps (calitas_search_hits*) refuse a range: a contig that is cut needs its other part first. */
+  int32_t first_window;
+  int32_t n_windows;
 } calitas_params_t;
 
 /* One GuideAlignment (GuideAlignment.scala:72-88).  Coordinates are 0-based half-open on the contig.  ops holds

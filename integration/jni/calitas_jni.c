@@ -60,7 +60,7 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
     jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jintArray params) {
   calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
   calitas_guide_t g;
-  calitas_params_t p;
+  calitas_params_t p = {0};
   const jsize np = (*env)->GetArrayLength(env, pams);
   const char* cp[CALITAS_MAX_PAMS];
   jstring jp[CALITAS_MAX_PAMS];
@@ -84,7 +84,7 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
     jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jstring guideId, jintArray params, jstring version) {
   calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
   calitas_guide_t g;
-  calitas_params_t p;
+  calitas_params_t p = {0};
   const jsize np = (*env)->GetArrayLength(env, pams);
   const char* cp[CALITAS_MAX_PAMS];
   jstring jp[CALITAS_MAX_PAMS];
@@ -113,7 +113,7 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
     jstring chrom, jstring vcfId, jstring version) {
   calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
   calitas_guide_t g;
-  calitas_params_t p;
+  calitas_params_t p = {0};
   const jsize np = (*env)->GetArrayLength(env, pams);
   const char* cp[CALITAS_MAX_PAMS];
   jstring jp[CALITAS_MAX_PAMS];

@@ -148,3 +148,90 @@ def test_bench_spawns_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, timeout=120)
     assert bad.returncode != 0 and b"WORLD_SIZE=2" in bad.stderr
+
+
+def _worker_windows(rank, world, port, outdir):
+    """Window-range partition: this rank aligns the windows of its range (the oracle's per-window SequentialGuideAligner.align as
+    compute), the alignments of every contig travel to the rank that owns it, and that rank runs the product's removeOverlaps /
+    sort / rows (calitas_hits_tsv on a host-only context)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import calitas_amd as C
+    from calitas_amd import shard
+    from test_host_logic import _oracle_alignments
+    names, seqs = _genome()
+    lengths = [len(s) for s in seqs]
+    kw = dict(d=4, p=1, g=2, D=7, O=10)
+    G = C.Guide(GUIDE)
+    step = 1000 - (G.cli_length + kw["d"] + kw["g"] - 1)
+    ranges = shard.window_partition(lengths, world, step)
+    parts = [shard.range_contigs(lengths, step, f, n) for f, n in ranges]
+    owner = shard.contig_owner(parts)
+    mine = {}
+    for ci, k0, n, whole in parts[rank]:
+        alns = _oracle_alignments(C, GUIDE, names[ci], ci, seqs[ci].decode(), kw, window_range=(k0, k0 + n))
+        mine[ci] = [(a.guide_index, a.contig_index, a.window_start, a.start_offset, a.end_offset, a.guide_start_offset, a.guide_end_offset,
+                     a.score, a.strand, a.pam_index, a.ops) for a in alns]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    rows = {}
+    ctx = C.Context(-1)
+    ctx.set_reference(names, seqs)
+    params = C.make_params(max_guide_diffs=4, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2, max_total_diffs=7)
+    for ci in sorted(c for c, r in owner.items() if r == rank):
+        alns = []
+        for r in range(world):                                   # range order = window order on the contig
+            for t in gathered[r].get(ci, []):
+                a = C.Alignment.__new__(C.Alignment)
+                (a.guide_index, a.contig_index, a.window_start, a.start_offset, a.end_offset, a.guide_start_offset, a.guide_end_offset,
+                 a.score, a.strand, a.pam_index, a.ops) = t
+                alns.append(a)
+        text, _ = ctx.hits_tsv(G, "a", params, alns)
+        rows[ci] = text.splitlines()
+    ctx.close()
+    blocks = [None] * world if rank == 0 else None
+    dist.gather_object(rows, blocks, dst=0)
+    if rank == 0:
+        merged, header = {}, None
+        for b in blocks:
+            for ci, lines in b.items():
+                header = lines[0]
+                merged[ci] = lines[1:]
+        with open(os.path.join(outdir, "windows.txt"), "w") as f:
+            f.write("\n".join([header] + [ln for ci in sorted(merged) for ln in merged[ci]]) + "\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_partition_cuts_a_contig_and_reproduces_the_rows():
+    """bench.py --shard windows: consecutive window ranges of equal size; with two ranks the cut falls inside chr2.  The rows after the
+    cross-rank merge of the cut contig equal the single-process rows, and on hg38 the ranges balance to well under 1.02."""
+    sys.path.insert(0, HERE)
+    import oracle_lib as O
+    import calitas_amd as C
+    from calitas_amd import shard, synth
+    names, seqs = _genome()
+    lengths = [len(s) for s in seqs]
+    step = 1000 - (C.Guide(GUIDE).cli_length + 4 + 2 - 1)
+    ranges = shard.window_partition(lengths, 2, step)
+    parts = [shard.range_contigs(lengths, step, f, n) for f, n in ranges]
+    assert sum(n for _, n in ranges) == sum(shard.window_counts(lengths, step))
+    cut = [ci for ci, _, _, whole in parts[0] if not whole]
+    assert cut and cut == [ci for ci, _, _, whole in parts[1] if not whole][:1]      # one contig is shared by the two ranks
+    with tempfile.TemporaryDirectory() as d:
+        port = 33500 + os.getpid() % 2000
+        mp.start_processes(_worker_windows, args=(2, port, d), nprocs=2, join=True, start_method="spawn")
+        whole = open(os.path.join(d, "windows.txt")).read()
+    _, want, _ = O.search_memory(names, seqs, GUIDE, "a", d=4, p=1, g=2, D=7)
+    lines = whole.splitlines()
+    skip = {"aligner_version", "time_stamp", "genome_build"}
+    got = [{k: v for k, v in zip(lines[0].split("\t"), ln.split("\t")) if k not in skip} for ln in lines[1:]]
+    assert len(want) > 5 and got == [{k: v for k, v in r.items() if k not in skip} for r in want]
+    # balance on hg38: 971-base steps, 1000-base windows
+    for n in (2, 4, 8):
+        loads = [shard.range_bases(synth.HG38_LENGTHS, 971, 1000, f, k) for f, k in shard.window_partition(synth.HG38_LENGTHS, n, 971)]
+        assert max(loads) <= 1.02 * sum(loads) / n, (n, loads)
+        assert max(loads) <= 1.0005 * sum(loads) / n

@@ -214,3 +214,38 @@ def test_failed_reference_upload_leaves_no_half_set_reference(C, tmp_path, monke
         assert ctx.search_hits(C.Guide(GUIDE0), "a", params, "v0", "stamp") == want
     finally:
         ctx.close()
+
+
+def test_window_ranges_of_calitas_search_concatenate_to_the_whole_call(C, tmp_path):
+    """calitas_params_t first_window / n_windows (the piece of a job one rank of a window-range partition runs, shard.window_partition):
+    the alignments of consecutive ranges -- cuts inside contigs, inside an N block, one range a single window -- concatenate to the
+    alignments of the whole call, record for record, and calitas_hits_tsv on them gives calitas_search_hits' bytes.  The calls that
+    run removeOverlaps themselves refuse a range."""
+    import test_gpu_parity as P
+    from calitas_amd import shard
+    fa = P.synth_fasta(tmp_path, 73, [GUIDE0], lengths=(1_400_000, 300_000, 90_000, 700, 26), n_block=40_000)
+    ctx = C.Context(0)
+    try:
+        ctx.set_reference_fasta(fa)
+        G = C.Guide(GUIDE0)
+        kw = dict(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+        params = C.make_params(**kw)
+        step = 1000 - (G.cli_length + 5 + 2 - 1)
+        want_text = ctx.search_hits(G, "a", params, "v0", "stamp")
+        whole = ctx.search([G], params)
+        key = lambda a: (a.contig_index, a.window_start, a.strand, a.start_offset, a.end_offset, a.score, a.pam_index, a.ops)
+        total = sum(shard.window_counts(ctx.contig_lengths, step))
+        for cuts in ([(0, total)], shard.window_partition(ctx.contig_lengths, 3, step), [(0, 700), (700, 1), (701, total - 701)],
+                     shard.window_partition(ctx.contig_lengths, 8, step)):
+            got = []
+            for f, n in cuts:
+                got += ctx.search([G], C.make_params(first_window=f, n_windows=n, **kw))
+            assert [key(a) for a in got] == [key(a) for a in whole], cuts
+        assert len(whole) > 60
+        assert ctx.hits_tsv(G, "a", params, got, "v0", "stamp") == want_text
+        with pytest.raises(C.CalitasError, match="calitas_search only"):
+            ctx.search_hits(G, "a", C.make_params(first_window=0, n_windows=10, **kw))
+        with pytest.raises(C.CalitasError, match="outside the window table"):
+            ctx.search([G], C.make_params(first_window=total - 5, n_windows=10, **kw))
+    finally:
+        ctx.close()

@@ -102,13 +102,16 @@ def test_window_table_equals_window_iterator(C, window, step, tmp_path):
     assert got == want
 
 
-def _oracle_alignments(C, guide, contig_name, contig_index, seq, params_kw, window_size=1000):
-    """Per-window SequentialGuideAligner.align results of the ORACLE, converted to product Alignment records."""
+def _oracle_alignments(C, guide, contig_name, contig_index, seq, params_kw, window_size=1000, window_range=None):
+    """Per-window SequentialGuideAligner.align results of the ORACLE, converted to product Alignment records (all windows of the
+    contig, or windows [window_range[0], window_range[1]) of it)."""
     G = C.Guide(guide)
     step = window_size - (G.cli_length + params_kw["d"] + params_kw["g"] - 1)
     out = []
     n = len(seq)
-    for start in range(0, n - 1, step):
+    for k, start in enumerate(range(0, n - 1, step)):
+        if window_range is not None and not (window_range[0] <= k < window_range[1]):
+            continue
         end = min(n, start + window_size)
         a, b = start, end
         while a < b and seq[a] == "N":
