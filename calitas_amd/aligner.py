@@ -379,7 +379,12 @@ class Context:
                                                           tsv, nbytes, rows))
         out = []
         for i in range(n):
-            out.append((ctypes.string_at(tsv[i], nbytes[i]).decode() if decode else nbytes[i], rows[i]))
+            if decode == "digest":      # a checksum of the text instead of the text (a full-size batch is many gigabytes)
+                import zlib
+                what = (zlib.crc32((ctypes.c_char * nbytes[i]).from_address(tsv[i])), nbytes[i])
+            else:
+                what = ctypes.string_at(tsv[i], nbytes[i]).decode() if decode else nbytes[i]
+            out.append((what, rows[i]))
             lib.calitas_free(tsv[i])
         return out
 

@@ -80,3 +80,21 @@ def test_hg38_size_whole_chromosomes_against_the_oracle(world):
     for r in want:
         r["genome_build"] = "synthetic-hg38-sized"                 # the oracle has no .dict for in-memory contigs
     assert len(want) > 3000 and got == want
+
+
+def test_hg38_size_96_guide_batch_equals_single_calls(world):
+    """BASELINE config 4 at its stated size: guide #0 + 95 random 20-mers (seed 0xC4) against the 3.09 Gb genome in one
+    calitas_search_hits_batch call.  Every guide's text is held by size, row count and CRC; a sample of guides is compared byte for byte
+    with its own calitas_search_hits call, and guide #0's rows are the ones the other full-size tests hold against the oracle."""
+    import zlib
+    from calitas_amd import synth
+    C, ctx, names, seqs, guide = world
+    guides = [guide] + synth.random_guides(0xC4, 95)
+    params = C.make_params(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+    G = [C.Guide(g) for g in guides]
+    ids = ["g%02d" % i for i in range(96)]
+    res = ctx.search_hits_batch(G, ids, params, "v0", "stamp", decode="digest")
+    assert len(res) == 96 and all(rows > 10000 for _, rows in res)
+    for i in (0, 1, 37, 95):
+        text, rows = ctx.search_hits(G[i], ids[i], params, "v0", "stamp", decode="bytes")
+        assert (zlib.crc32(text), len(text)) == res[i][0] and rows == res[i][1], i
