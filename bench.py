@@ -161,7 +161,7 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(names, seqs, guides, params_kw, budget_bases):
+def cpu_baseline(names, seqs, guides, params_kw, budget_bases, guide_ids=None):
     """Times the CPU oracle (the restatement of the reference algorithm, oracle/) on a bounded sample of the same genome with one
     worker per host core -- the reference's own threading model (SearchReference.scala:459).  Returns (report, {contig: rows}) with
     the oracle's rows of the whole contigs of the sample (for the parity check of the bench's own output)."""
@@ -179,8 +179,8 @@ def cpu_baseline(names, seqs, guides, params_kw, budget_bases):
             whole.append(n)
     t0 = time.perf_counter()
     rows_by_guide, nwin = [], 0
-    for g in guides:
-        _, rows, nwin = O.search_memory(s_names, s_seqs, g, "bench", d=params_kw["max_guide_diffs"], p=params_kw["max_pam_mismatches"],
+    for gi, g in enumerate(guides):
+        _, rows, nwin = O.search_memory(s_names, s_seqs, g, guide_ids[gi] if guide_ids else "bench", d=params_kw["max_guide_diffs"], p=params_kw["max_pam_mismatches"],
                                         g=params_kw["max_gaps_between_guide_and_pam"], threads=cores)
         rows_by_guide.append(rows)
     dt = time.perf_counter() - t0
@@ -671,7 +671,7 @@ def main():
         value = 2.0 * m["bases_per_step_total"] * K / dt
         # a pass is scanned in `launches` launches (one per contig range / guide); per-launch figures are averages over them
         n_guides_rank = len(m["my_guides"])
-        launches = max(1, int(tm.get("lanes", 1))) if n_guides_rank == 1 else n_guides_rank
+        launches = max(1, int(tm.get("scan_launches") or tm.get("lanes", 1))) if n_guides_rank == 1 else n_guides_rank
         if tm.get("contig_passes", 0):
             launches = int(tm["contig_passes"])
         scan_avg_ms = acc["scan"] / K / launches
@@ -741,7 +741,8 @@ def main():
         if mb > 0 and world == 1:
             try:
                 cg = m["my_guides"][:2] if args.config == 4 else m["my_guides"][:1]
-                report, whole, oracle_rows = cpu_baseline(m["names"], m["seqs"], cg, params_kw, int(mb * 1e6))
+                report, whole, oracle_rows = cpu_baseline(m["names"], m["seqs"], cg, params_kw, int(mb * 1e6),
+                                                          ["bench%d" % i for i in range(len(cg))] if args.config == 4 else None)
                 result["cpu_baseline"] = report
                 if m["text"] is not None and whole:
                     # the bench checks its own output: the rows of the sample's whole contigs, every column but the run-dependent two

@@ -34,8 +34,8 @@ struct BlockHeader { uint64_t magic; uint64_t capacity; uint64_t pinned; uint64_
 constexpr uint64_t kMagic = 0xCA117A5B10C0FFEEull;
 std::mutex g_pool_mutex;
 std::vector<BlockHeader*> g_pool;   // parked blocks
-constexpr size_t kPoolBlocks = 32;     // a batch call hands out one text buffer per guide
-constexpr uint64_t kPoolBytes = 8ull << 30;
+constexpr size_t kPoolBlocks = 128;    // a batch call hands out one text buffer per guide (BASELINE config 4: 96 guides)
+constexpr uint64_t kPoolBytes = 24ull << 30;   // ... of ~180 MB each at hg38 size; page-locking a fresh one costs tens of milliseconds
 
 void release_block(BlockHeader* h) {
   h->magic = 0;
