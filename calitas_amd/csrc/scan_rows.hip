@@ -60,7 +60,15 @@ __device__ __forceinline__ void stage_scan_record(const RecordSink k, uint32_t g
   r.gword = gword; r.info = info;
   const uint32_t slot = atomicAdd(k.s_nrec, 1u);        // LDS atomic
   if (slot < (uint32_t)ROWS_STAGE) { k.s_recs[slot] = r; return; }
-  const uint32_t g = atomicAdd(k.rec_count, 1u);        // stage full (dense tile): append directly
+  // stage full (dense tile): append directly, one global atomic for all the lanes of the wave that are here together -- a
+  // returning atomic on one global word completes at ~90 per microsecond chip-wide, and a PAM-less search at max-guide-diffs 8
+  // emits 1.8e8 records (one atomic each: 2 s of a pass)
+  const unsigned long long here = __ballot(1);
+  const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)here) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(k.rec_count, (uint32_t)__popcll(here));
+  base = (uint32_t)__shfl((int)base, leader);
+  const uint32_t g = base + (uint32_t)__popcll(here & ((1ull << lane) - 1ull));
   if (g < k.rec_capacity) k.recs[g] = r;
 }
 

@@ -275,9 +275,14 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
 // Device buffers of one lane for this plan (allocation only).
 static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
   uint64_t want = std::max<uint64_t>(1u << 16, std::min<uint64_t>(1u << 20, pl.bases / 8 + 1024));
-  if (pl.rec_hint) want = std::max<uint64_t>(want, std::min<uint64_t>(0xFFFFFFF0ull, pl.rec_hint + pl.rec_hint / 4 + 4096));   // no retry round for a dense search
-  return ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want), pl.slab_per_rec,
-                        std::max<uint32_t>(ctx->item_cap, (uint32_t)(2 * want)));
+  uint64_t want_raw = want, want_items = 2 * want;
+  if (pl.rec_hint) {   // a dense search (estimate_scan_records): no retry round per contig -- such searches yield ~3 alignments and passing candidates per record
+    want = std::max<uint64_t>(want, std::min<uint64_t>(0xFFFFFFF0ull, pl.rec_hint + pl.rec_hint / 4 + 4096));
+    want_raw = std::min<uint64_t>(0xFFFFFFF0ull, want * 7 / 2);
+    want_items = std::min<uint64_t>(0xFFFFFFF0ull, want * 4);
+  }
+  return ensure_buffers(ctx, std::max<uint32_t>(ctx->rec_cap, (uint32_t)want), std::max<uint32_t>(ctx->raw_cap, (uint32_t)want_raw), pl.slab_per_rec,
+                        std::max<uint32_t>(ctx->item_cap, (uint32_t)want_items));
 }
 
 // Guides, cleared counters and the scan kernel of this lane, queued on `stream` (the lane's own, or the shared scan stream of a
