@@ -189,6 +189,11 @@ __device__ __forceinline__ char comp_base(char c) {   // fgbio Sequences.complem
   }
 }
 
+// "ACGT"[code] and "=XID"[op] from a constant in a register: indexing the string literals is a load from constant memory per
+// character, i.e. a dependent round trip per base in loops every lane of the wave runs in lockstep (half of mid_kernel's time).
+__device__ __forceinline__ char base_letter(uint32_t code) { return (char)((0x54474341u >> (8u * code)) & 0xFFu); }   // A C G T
+__device__ __forceinline__ char op_letter(int op) { return (char)((0x4449583Du >> (8 * op)) & 0xFFu); }               // = X I D
+
 __device__ char base_upper_dev(const HitsRef& ref, uint64_t gpos) {
   if ((ref.mask[gpos >> 5] >> (gpos & 31)) & 1u) {
     const int64_t r = run_floor(ref.runs, ref.n_runs, gpos);
@@ -197,7 +202,7 @@ __device__ char base_upper_dev(const HitsRef& ref, uint64_t gpos) {
     if (ch == 0) return 'N';
     return (char)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);
   }
-  return "ACGT"[(ref.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u];
+  return base_letter((ref.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u);
 }
 
 __device__ __forceinline__ uint8_t* put_int(uint8_t* w, int v) {
@@ -209,11 +214,40 @@ __device__ __forceinline__ uint8_t* put_int(uint8_t* w, int v) {
   return w + nd;
 }
 
-// Bases [from, to) of a forward-strand buffer that starts at contig offset lo, in guide orientation.
-__device__ __forceinline__ uint8_t* put_bases(uint8_t* w, const uint8_t* fwd, int lo, int from, int to, bool minus) {
-  if (!minus) { for (int p = from; p < to; p++) *w++ = fwd[p - lo]; }
-  else        { for (int p = to - 1; p >= from; p--) *w++ = (uint8_t)comp_base((char)fwd[p - lo]); }
-  return w;
+// n bytes from one place of the lane's LDS slot to another (they never overlap), eight at a time: the reads of a group are issued
+// together and waited for once.  Byte by byte every read is a round trip to the LDS that the next write waits for (~100 cycles each,
+// and a row copies ~250 bytes): the compiler cannot batch them itself because it must assume the two pointers alias.
+__device__ __forceinline__ uint8_t* copy_bytes(uint8_t* __restrict__ w, const uint8_t* __restrict__ src, int n) {
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint8_t b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) b[k] = src[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[i + k] = b[k];
+  }
+  if (i < n) {
+    uint8_t b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) b[k] = (i + k < n) ? src[i + k] : (uint8_t)0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (i + k < n) w[i + k] = b[k];
+  }
+  return w + n;
+}
+
+// Bases [from, to) of a forward-strand buffer that starts at contig offset lo, in guide orientation (flanks: 8 or 10 bases).
+__device__ __forceinline__ uint8_t* put_bases(uint8_t* __restrict__ w, const uint8_t* __restrict__ fwd, int lo, int from, int to, bool minus) {
+  const int n = to - from;
+  if (!minus) return copy_bytes(w, fwd + (from - lo), n);
+  for (int i = 0; i < n; i += 8) {
+    uint8_t b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) b[k] = (i + k < n) ? fwd[to - 1 - (i + k) - lo] : (uint8_t)0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (i + k < n) w[i + k] = (uint8_t)comp_base((char)b[k]);
+  }
+  return w + n;
 }
 
 __device__ __forceinline__ bool is_lower(char c) { return c >= 'a' && c <= 'z'; }
@@ -238,6 +272,10 @@ __device__ int ga_count(const uint8_t* pg, const uint8_t* pa, int len, bool lowe
   }
   return n;
 }
+
+// words of the packed reference a row's span can touch (alignment + flanks <= CALITAS_MAX_OPS + 20 bases), staged per lane
+constexpr int MID_CODE_WORDS = (CALITAS_MAX_OPS + 20) / 16 + 2, MID_MASK_WORDS = (CALITAS_MAX_OPS + 20) / 32 + 2;
+constexpr int MID_WORDS = MID_CODE_WORDS + MID_MASK_WORDS;
 
 struct MidArgs {
   HitsRef ref;
@@ -274,7 +312,7 @@ __device__ __forceinline__ int row_op(const RowIn& r, int i) {
 }
 
 // The middle part of one hits.txt row (RH:210-254, columns coordinate_start .. unpadded_target_sequence_length) at `out`;
-// `scratch` holds 4 * n_max + n_max + 24 bytes, `blob` is the LDS copy of the constant strings.  Returns its length, or -1
+// `scratch` holds 4 * n_max + n_max + 24 bytes and, word aligned behind them, MID_WORDS words; `blob` is the LDS copy of the constant strings.  Returns its length, or -1
 // when the alignment has more columns than n_max.
 __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, const uint8_t* blob, const RowIn& r, const HitRec& h,
                              const GuideDev& g) {
@@ -291,7 +329,7 @@ __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, c
   for (int i = 0; i < n; i++) {
     const int k = g.pam5 ? n - 1 - i : i;
     char op;
-    if (k < ng) op = "=XID"[row_op(r, ng - 1 - k)];
+    if (k < ng) op = op_letter(row_op(r, ng - 1 - k));
     else if (k < ng + gap) op = 'D';
     else op = ((r.pam_x >> (k - ng - gap)) & 1) ? 'X' : '=';
     ops[i] = (uint8_t)op;
@@ -301,17 +339,27 @@ __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, c
   // one fetch covers the alignment and all four flanks (RH:213-216)
   const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
   {
-    // one code word per 16 bases and one mask word per 32 are fetched, not two words per base
+    // The code words (16 bases each) and mask words (32 bases each) of the span are fetched up front into the lane's scratch -- a
+    // dozen independent loads and one wait.  Fetching them inside the loop as it reached a new word made every iteration of the
+    // wave a dependent round trip to memory (the lanes cross word boundaries at different bases): ~100 of them per wave, half of
+    // the kernel's time.
     const ContigInfo c = a.ref.contigs[h.contig];
-    uint64_t cw_idx = ~0ull, mw_idx = ~0ull;
-    uint32_t cw = 0, mw = 0;
+    uint32_t* wsc = reinterpret_cast<uint32_t*>(scratch + ((5 * a.n_max + 24 + 3) & ~3u));   // MID_WORDS words behind fwd[]
+    const int p0 = max(lo, 0), p1 = (int)min((int64_t)hi, (int64_t)c.len);
+    uint64_t cw0 = 0, mw0 = 0;
+    if (p0 < p1) {
+      const uint64_t g0 = c.gbase + (uint64_t)p0, g1 = c.gbase + (uint64_t)p1 - 1;
+      cw0 = g0 >> 4; mw0 = g0 >> 5;
+      const int ncw = (int)((g1 >> 4) - cw0) + 1, nmw = (int)((g1 >> 5) - mw0) + 1;
+      for (int k = 0; k < ncw && k < MID_CODE_WORDS; k++) wsc[k] = a.ref.codes[cw0 + k];
+      for (int k = 0; k < nmw && k < MID_MASK_WORDS; k++) wsc[MID_CODE_WORDS + k] = a.ref.mask[mw0 + k];
+    }
     for (int p = lo; p < hi; p++) {
       char b = 'N';                                                                          // RH:262-264
-      if (p >= 0 && (uint64_t)p < c.len) {
+      if (p >= p0 && p < p1) {
         const uint64_t gpos = c.gbase + (uint64_t)p;
-        if ((gpos >> 5) != mw_idx) { mw_idx = gpos >> 5; mw = a.ref.mask[mw_idx]; }
-        if ((gpos >> 4) != cw_idx) { cw_idx = gpos >> 4; cw = a.ref.codes[cw_idx]; }
-        b = ((mw >> (gpos & 31)) & 1u) ? base_upper_dev(a.ref, gpos) : "ACGT"[(cw >> ((gpos & 15) * 2)) & 3u];
+        const uint32_t mw = wsc[MID_CODE_WORDS + (int)((gpos >> 5) - mw0)], cw = wsc[(int)((gpos >> 4) - cw0)];
+        b = ((mw >> (gpos & 31)) & 1u) ? base_upper_dev(a.ref, gpos) : base_letter((cw >> ((gpos & 15) * 2)) & 3u);
       }
       fwd[p - lo] = (uint8_t)b;
     }
@@ -339,7 +387,7 @@ __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, c
   if (!minus) { w = put_bases(w, fwd, lo, gs - 10, gs, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ge, ge + 10, false); }   // RH:227-228
   else        { w = put_bases(w, fwd, lo, ge, ge + 10, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, gs - 10, gs, true); }
   *w++ = '\t';
-  { const uint8_t* pu = blob + a.rc.pu_off[r.pam + 1]; const int l = (int)a.rc.pu_len[r.pam + 1]; for (int i = 0; i < l; i++) *w++ = pu[i]; }
+  w = copy_bytes(w, blob + a.rc.pu_off[r.pam + 1], (int)a.rc.pu_len[r.pam + 1]);
   *w++ = '\t';
   *w++ = '\t'; *w++ = '\t'; *w++ = '\t'; *w++ = '\t';   // variant_id, variant_description, variant_vcf, allele_frequency: None
   w = put_int(w, h.score); *w++ = '\t';
@@ -350,11 +398,11 @@ __device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, c
   w = put_int(w, gmm + ggp); *w++ = '\t';               // guide_mm_plus_gaps GA:105
   w = put_int(w, ga_count(pg, pa, n, true, true, true, false)); *w++ = '\t';   // pam_mm GA:106
   w = put_int(w, mm + gp); *w++ = '\t';                 // total_mm_plus_gaps = edits GA:101
-  for (int i = 0; i < n; i++) *w++ = pg[i];
+  w = copy_bytes(w, pg, n);
   *w++ = '\t';
-  for (int i = 0; i < n; i++) *w++ = pa[i];
+  w = copy_bytes(w, pa, n);
   *w++ = '\t';
-  for (int i = 0; i < n; i++) *w++ = pt[i];
+  w = copy_bytes(w, pt, n);
   *w++ = '\t';
   if (!minus) { w = put_bases(w, fwd, lo, as - 8, as, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ae, ae + 8, false); }     // RH:243-244
   else        { w = put_bases(w, fwd, lo, ae, ae + 8, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, as - 8, as, true); }
@@ -594,7 +642,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   // 4: rows
   const uint32_t n_max = (uint32_t)std::min<int>(CALITAS_MAX_OPS, std::max(1, max_ops));
   const uint32_t mid_bound = (6 * n_max + 128 + 3) & ~3u;
-  uint32_t slot = mid_bound + ((5 * n_max + 24 + 3) & ~3u);
+  uint32_t slot = mid_bound + ((5 * n_max + 24 + 3) & ~3u) + 4 * MID_WORDS;   // output | ops, padded strings, fetched bases | staged reference words
   if (((slot / 4) & 1) == 0) slot += 4;
   const uint32_t mid_lds = 64 * slot + (uint32_t)((blob_bytes + 15) & ~(size_t)15);
   if (mid_lds > 64 * 1024) {   // beyond the default dynamic LDS limit: ask for more (160 KB per CU on gfx950) or decline

@@ -85,14 +85,24 @@ __global__ void scatter_kernel(const Derived* der, uint32_t n, const uint32_t* o
 // One lane per slot position; only the first slot of a window works (a lane per window would leave 97 % of the lanes of an
 // hg38-sized table idle).  kept[s] = number of survivors of the window whose slots start at s (0 for the other positions);
 // their alignment indices, in output order, go to out_idx[s .. s + kept[s]).
-__global__ void filter_kernel(const Derived* ders, const uint32_t* offs, uint32_t n, int max_total_diffs, int max_overlap, uint8_t* taken,
-                              uint32_t* kept, uint32_t* out_pos, uint32_t* counts, uint32_t* big) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const uint32_t* offs, uint32_t n, int max_total_diffs, int max_overlap, uint8_t* taken,
+                                                     uint32_t* kept, uint32_t* out_pos, uint32_t* counts, uint32_t* big) {
+  // The block's 256 records (a window's records are consecutive slots) and their "taken" flags are staged in LDS: the greedy below
+  // visits every record of the window once per round, and as loads from global memory those visits were a chain of dependent round
+  // trips (33-60 us for windows of two or three records).  Slots beyond the block (a window that starts here and ends in the next
+  // block) are read from global memory as before; only this window's lane touches them.
+  __shared__ Derived s_d[256];
+  __shared__ uint8_t s_taken[256];
+  const uint32_t base = blockIdx.x * blockDim.x, s = base + threadIdx.x;
+  if (s < n) s_d[threadIdx.x] = ders[s];
+  s_taken[threadIdx.x] = 0;
+  __syncthreads();
   if (s >= n) return;
-  const uint32_t w = ders[s].widx;
+  const uint32_t w = s_d[threadIdx.x].widx;
   if (offs[w] != s) { kept[s] = 0; return; }
   const uint32_t e = offs[w + 1];
   if (e - s > GROUP_MAX) { big[atomicAdd(counts + 2, 1u)] = s; kept[s] = 0; return; }   // left to filter_big_kernel
+  const uint32_t lim = base + 256;                  // slots [base, lim) are in LDS
   uint32_t nk = 0;
   for (uint32_t list = 0; list < 2; list++) {
     const uint32_t first_kept = nk;                   // overlaps are only tested against the same strand (SGA:317)
@@ -101,22 +111,32 @@ __global__ void filter_kernel(const Derived* ders, const uint32_t* offs, uint32_
       int best = -1, b_score = 0, b_gaps = 0, b_start = 0, b_end = 0, b_edits = 0;
       uint32_t b_ekey = 0;
       for (uint32_t m = s; m < e; m++) {
-        if (taken[m]) continue;
-        const uint32_t ek = ders[m].ekey;
+        uint32_t ek;
+        int sc, gp, st, en, ed;
+        if (m < lim) {                                  // two explicit branches: one generic pointer would make every access a flat load
+          if (s_taken[m - base]) continue;
+          const Derived& d = s_d[m - base];
+          ek = d.ekey; sc = d.score; gp = d.gaps; st = d.start; en = d.end; ed = d.edits;
+        } else {
+          if (taken[m]) continue;
+          const Derived& d = ders[m];
+          ek = d.ekey; sc = d.score; gp = d.gaps; st = d.start; en = d.end; ed = d.edits;
+        }
         if ((ek >> 19) != list) continue;
-        const int sc = ders[m].score, gp = ders[m].gaps;
         // score desc, gap bases asc (GA:125-129), then the enumeration order (stable sort)
         const bool first = best < 0;
         const bool wins = sc > b_score || (sc == b_score && (gp < b_gaps || (gp == b_gaps && ek < b_ekey)));
-        if (first || wins) { best = (int)m; b_score = sc; b_gaps = gp; b_ekey = ek; b_start = ders[m].start; b_end = ders[m].end; b_edits = ders[m].edits; }
+        if (first || wins) { best = (int)m; b_score = sc; b_gaps = gp; b_ekey = ek; b_start = st; b_end = en; b_edits = ed; }
       }
       if (best < 0) break;
-      taken[best] = 1;
+      if ((uint32_t)best < lim) s_taken[(uint32_t)best - base] = 1; else taken[best] = 1;
       if (b_edits > max_total_diffs) continue;
       bool clash = false;
       for (uint32_t k = first_kept; k < nk; k++) {
         const uint32_t kp = out_pos[s + k];
-        const int o = min(b_end, ders[kp].end) - max(b_start, ders[kp].start);   // GA:119-122
+        int ks, ke;
+        if (kp < lim) { ks = s_d[kp - base].start; ke = s_d[kp - base].end; } else { ks = ders[kp].start; ke = ders[kp].end; }
+        const int o = min(b_end, ke) - max(b_start, ks);   // GA:119-122
         if (o > max_overlap) { clash = true; break; }
       }
       if (!clash) out_pos[s + nk++] = (uint32_t)best;

@@ -17,7 +17,7 @@ with open(sys.argv[2], "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
 agg = {}
 for r in keep:
-    k = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
+    k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-40:], r["Counter_Name"])
     agg.setdefault(k, []).append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print("%-42s %-22s n=%d mean=%.6g" % (k[0], k[1], len(v), sum(v) / len(v)))
