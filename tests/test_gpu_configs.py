@@ -249,3 +249,57 @@ def test_window_ranges_of_calitas_search_concatenate_to_the_whole_call(C, tmp_pa
             ctx.search([G], C.make_params(first_window=total - 5, n_windows=10, **kw))
     finally:
         ctx.close()
+
+
+def test_search_hits_into_a_caller_buffer(C, tmp_path):
+    """calitas_search_hits_into: the same bytes as calitas_search_hits, delivered into memory of the caller (page-locked with
+    calitas_pin_host, or plain); a buffer that is too small is refused with CALITAS_EINVAL and nothing is written past it."""
+    import ctypes
+    import test_gpu_parity as P
+    fa = P.synth_fasta(tmp_path, 74, [GUIDE0], lengths=(250000, 60000, 700))
+    ctx = C.Context(0)
+    try:
+        ctx.set_reference_fasta(fa)
+        G = C.Guide(GUIDE0)
+        params = C.make_params(max_guide_diffs=5, max_gaps_between_guide_and_pam=2)
+        want, rows = ctx.search_hits(G, "a", params, "v0", "stamp", decode="bytes")
+        assert rows > 50
+        cap = len(want) + 4096
+        for pinned in (True, False):
+            buf = ctypes.create_string_buffer(b"\xAA" * (cap + 64), cap + 64)
+            addr = ctypes.addressof(buf)
+            if pinned:
+                ctx.pin_host(addr, cap)
+            try:
+                for chunks in ("1", "2"):
+                    os.environ["CALITAS_CHUNKS"] = chunks
+                    n, r = ctx.search_hits_into(G, "a", params, addr, cap, "v0", "stamp")
+                    assert (n, r) == (len(want), rows) and buf.raw[:n] == want and buf.raw[n] == 0
+                    assert buf.raw[cap:] == b"\xAA" * 64
+                with pytest.raises(C.CalitasError, match="too small") as e:
+                    ctx.search_hits_into(G, "a", params, addr, len(want) // 2, "v0", "stamp")
+                assert e.value.code == C._lib.EINVAL and buf.raw[cap:] == b"\xAA" * 64
+            finally:
+                os.environ.pop("CALITAS_CHUNKS", None)
+                if pinned:
+                    ctx.unpin_host(addr)
+    finally:
+        ctx.close()
+
+
+def test_record_estimate_with_a_chromosome_filter(C, tmp_path, monkeypatch):
+    """The planner's sampled record estimate honours --chrom: a budget that the whole reference would exceed but the one contig does not
+    lets the filtered search run as one pass, with the rows of that contig alone."""
+    guide, fa, _, _ = c5_genome(tmp_path, (400000, 250000, 90000), seed=12)
+    ctx = C.Context(0)
+    try:
+        ctx.set_reference_fasta(fa)
+        G = C.Guide(guide)
+        kw = dict(max_guide_diffs=8, max_pam_mismatches=0, max_gaps_between_guide_and_pam=3)
+        whole = C.read_hits(ctx.search_hits(G, "c5", C.make_params(**kw), "v", "t")[0])
+        monkeypatch.setenv("CALITAS_DEVICE_BUDGET_MB", "200")
+        text, rows = ctx.search_hits(G, "c5", C.make_params(chrom_index=2, **kw), "v", "t")
+        assert ctx.timing()["contig_passes"] <= 1
+        assert C.read_hits(text) == [r for r in whole if r["chromosome"] == "chr3"] and rows > 500
+    finally:
+        ctx.close()
