@@ -70,7 +70,9 @@ void out_free(void* p) {
   if (!p) return;
   BlockHeader* h = (BlockHeader*)p - 1;
   if (h->magic != kMagic) return;     // not ours: refuse rather than corrupt the heap
-  if (h->capacity >= (1u << 20) && h->capacity <= kPoolBytes / 4) {   // (a block of many gigabytes would only crowd the others out)
+  // (a block of many gigabytes would only crowd the others out; small page-locked blocks are parked too: hipHostFree + hipHostMalloc
+  // of the 11 KB text of an E. coli-sized call cost 0.2 ms per call, more than the search's kernels)
+  if ((h->capacity >= (1u << 20) || h->pinned) && h->capacity <= kPoolBytes / 4) {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     g_pool.push_back(h);
     uint64_t parked = 0;

@@ -18,6 +18,24 @@
 
 #include "ctx.hpp"
 
+// CALITAS_TRACE=2: host-side time line of a call (microseconds since the first mark), one line at the end of calitas_search_hits
+namespace {
+struct HostMarks {
+  bool on = false;
+  std::chrono::steady_clock::time_point t0;
+  std::string line;
+  void start() { const char* e = std::getenv("CALITAS_TRACE"); on = e && std::atoi(e) >= 2; line.clear(); t0 = std::chrono::steady_clock::now(); }
+  void mark(const char* what) {
+    if (!on) return;
+    char b[64];
+    std::snprintf(b, sizeof b, " %s %.0f", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    line += b;
+  }
+  void dump() { if (on) std::fprintf(stderr, "[calitas] host marks (us):%s\n", line.c_str()); }
+};
+thread_local HostMarks g_marks;
+}  // namespace
+
 static int fail(calitas_ctx* ctx, int code, const std::string& msg) { return calitas_fail(ctx, code, msg); }
 static void* out_alloc(size_t size) { return calitas_out_alloc(size); }
 
@@ -359,7 +377,9 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
     HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream, ctx->ev[2]));
     HIP_TRY(ctx, mailbox_post(ctx->mbox, ctx->d_counters, 8, ctx->stream));
+    g_marks.mark("queued-scan-align-trace");
     HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
+    g_marks.mark("counts1");
     for (int k = 0; k < 8; k++) ctx->h_counters[k] = ctx->mbox.host[1 + k];
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
     const uint32_t n_items = ctx->h_counters[3];
@@ -395,7 +415,9 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
                             p.max_overlap, ctx->stream, &d_final, &d_cnt));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIP_TRY(ctx, mailbox_post(ctx->mbox, d_cnt, 3, ctx->stream));
+    g_marks.mark("queued-filter");
     HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
+    g_marks.mark("counts2");
     ctx->h_counters[5] = ctx->mbox.host[1]; ctx->h_counters[6] = ctx->mbox.host[2]; ctx->h_counters[7] = ctx->mbox.host[3];
     select_done(ctx->select);
     if (ctx->h_counters[6] & SELECT_FLAG_INTERNAL)
@@ -699,6 +721,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
                              pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, dev.crowded ? 0u : (uint32_t)((p.window_size + pl.step - 1) / pl.step),
                              lane->stream, &res));
       HIP_TRY(lane, hipEventRecord(lane->ev[5], lane->stream));
+      g_marks.mark("rows-queued");
       kernel_times(lane, lt.tm);          // while out_kernel runs
       if (res.flags == 0) {
         lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows;
@@ -992,6 +1015,8 @@ static bool predicted_not_to_fit(calitas_ctx* ctx, const calitas_guide_t* guide,
 
 int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                             const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows) {
+  g_marks.start();
+  struct Dump { ~Dump() { g_marks.mark("return"); g_marks.dump(); } } dump_at_exit;
   int rc = CALITAS_ENOMEM;
   if (!known_not_to_fit(ctx, guide, params, false) && !predicted_not_to_fit(ctx, guide, params)) {
     rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
@@ -1226,11 +1251,14 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     }
   }
   if (!chunked) {
+    g_marks.mark("planned");
     rc = lane_rows(ctx, pl, false, rs, guide_id, version, stamp, parts[0]);
     if (rc) return rc;
+    g_marks.mark("lane-done");
     if (!alloc_text((size_t)parts[0].bytes) || parts[0].bytes > capacity) return fail(ctx, CALITAS_EINVAL, user_dst ? no_room : "out of memory");
     rc = place(0, 0);
     if (rc) { free_text(); return rc; }
+    g_marks.mark("text-copied");
   }
   size_t total = hlen;
   calitas_timing_t tm{};
