@@ -350,6 +350,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   if (n_rows) *n_rows = 0;
   if (n_windows) *n_windows = 0;
   if (!ctx->has_ref) return calitas_fail(ctx, CALITAS_ESTATE, "calitas_set_reference has not been called");
+  if (params->first_window != 0 || params->n_windows != 0)
+    return calitas_fail(ctx, CALITAS_EINVAL, "a window range (first_window / n_windows) is for calitas_search only: removeOverlaps needs every alignment of a contig");
   const PackedRef& ref = ctx->ref;
   const calitas_params_t& p = *params;
   GuideHost gh;
