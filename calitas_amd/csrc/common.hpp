@@ -198,6 +198,13 @@ static_assert(sizeof(SlabHeader) == 128, "slab header layout");
 
 }  // namespace calitas
 
+// Wave priority of the kernels that follow a scan (align ... rows).  They share SIMDs with the scan of the next contig range, whose
+// waves issue a vector instruction every cycle they can; at the default priority a small kernel's waves got one issue slot in
+// five to nine and took 40-70 us instead of 5-10 (rocprofv3 timeline).  The scan stays at priority 0.
+#if defined(__HIPCC__)
+#define CALITAS_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 #ifdef CALITAS_ALLOC_DEBUG
 #include "dbg_alloc.hpp"   // make DBG_ALLOC=1: allocation registry dumped on abort
 #endif

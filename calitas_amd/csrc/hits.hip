@@ -52,6 +52,7 @@ struct RowConstDev {
 
 __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
                            int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* wks, uint32_t* flags) {
+  CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const RawAln* rp = fin + i;
@@ -95,6 +96,7 @@ __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides
 // keep their arrival order, as a stable sort would.  One launch instead of the seven of a 64-bit radix / merge sort; the caller
 // takes the general sort when a window holds more records than a lane should walk past.
 __global__ void rank_kernel(const uint64_t* keys, const uint32_t* wks, uint32_t n, uint32_t reach, uint32_t* order) {
+  CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = keys[i];
@@ -118,6 +120,7 @@ constexpr int HIT_MAX_LEN = CALITAS_MAX_OPS;   // a hit covers at most this many
 
 __global__ void prep_kernel(const HitRec* hits, const uint32_t* order, uint32_t n, int max_overlap, int32_t* s_start, int32_t* s_end,
                             int32_t* s_score, uint32_t* s_cs, uint8_t* head, uint8_t* keep) {
+  CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const HitRec h = hits[order[i]];
@@ -136,6 +139,7 @@ __global__ void prep_kernel(const HitRec* hits, const uint32_t* order, uint32_t 
 
 __global__ void cluster_kernel(const int32_t* s_start, const int32_t* s_end, const int32_t* s_score, const uint32_t* s_cs,
                                const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+  CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !head[i]) return;
   const uint32_t cs = s_cs[i];
@@ -172,13 +176,14 @@ __global__ void cluster_kernel(const int32_t* s_start, const int32_t* s_end, con
 
 // ---- rows ------------------------------------------------------------------------------------------------------------
 // A row is  head | chromosome \t | middle | tail  where head and tail are the same for every row of the call.
-//   mid_kernel: one lane per row builds the middle part in its own LDS slot (byte writes, slot stride an odd number of
-//               words so the 64 lanes hit 64 banks); the wave then copies the slots to a fixed-stride staging buffer with
-//               coalesced dword stores and records the row length.
+//   mid_kernel: one *wave* per row builds the middle part: lane i owns padded column i of the alignment (op, query, target and
+//               alignment characters; the counts of GuideAlignment are popcounts of wave ballots), lane f owns field f's length and
+//               -- for the numeric fields -- its digits; a prefix sum over the 25 field lengths places every field in the wave's
+//               line buffer, which is copied to a fixed-stride staging buffer with coalesced dword stores.
 //   out_kernel: after the exclusive scan of the lengths, a wave assembles row after row at its final offset with
 //               coalesced byte stores (head / tail come from LDS).
-// Working arrays (ops, padded strings, the fetched reference span) live in the lane's LDS slot behind the output area,
-// never in private memory.
+// (The first version ran one lane per row with its working arrays in a 560-byte LDS slot: 36 KB per single-wave workgroup, each of
+// which kept a four-wave workgroup of the next range's scan off its CU, and a 100 us chain of dependent LDS round trips -- DESIGN.md 4.4.)
 
 __device__ __forceinline__ char comp_base(char c) {   // fgbio Sequences.complement on an upper-case base
   switch (c) {
@@ -189,8 +194,7 @@ __device__ __forceinline__ char comp_base(char c) {   // fgbio Sequences.complem
   }
 }
 
-// "ACGT"[code] and "=XID"[op] from a constant in a register: indexing the string literals is a load from constant memory per
-// character, i.e. a dependent round trip per base in loops every lane of the wave runs in lockstep (half of mid_kernel's time).
+// "ACGT"[code] and "=XID"[op] from a constant in a register (indexing the string literals is a load from constant memory per character)
 __device__ __forceinline__ char base_letter(uint32_t code) { return (char)((0x54474341u >> (8u * code)) & 0xFFu); }   // A C G T
 __device__ __forceinline__ char op_letter(int op) { return (char)((0x4449583Du >> (8 * op)) & 0xFFu); }               // = X I D
 
@@ -205,77 +209,11 @@ __device__ char base_upper_dev(const HitsRef& ref, uint64_t gpos) {
   return base_letter((ref.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u);
 }
 
-__device__ __forceinline__ uint8_t* put_int(uint8_t* w, int v) {
-  if (v < 0) { *w++ = '-'; v = -v; }
-  unsigned u = (unsigned)v;
-  int nd = 1;
-  for (unsigned t = u; t >= 10; t /= 10) nd++;
-  for (int i = nd - 1; i >= 0; i--) { w[i] = (uint8_t)('0' + u % 10); u /= 10; }
-  return w + nd;
-}
-
-// n bytes from one place of the lane's LDS slot to another (they never overlap), eight at a time: the reads of a group are issued
-// together and waited for once.  Byte by byte every read is a round trip to the LDS that the next write waits for (~100 cycles each,
-// and a row copies ~250 bytes): the compiler cannot batch them itself because it must assume the two pointers alias.
-__device__ __forceinline__ uint8_t* copy_bytes(uint8_t* __restrict__ w, const uint8_t* __restrict__ src, int n) {
-  int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    uint8_t b[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) b[k] = src[i + k];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[i + k] = b[k];
-  }
-  if (i < n) {
-    uint8_t b[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) b[k] = (i + k < n) ? src[i + k] : (uint8_t)0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) if (i + k < n) w[i + k] = b[k];
-  }
-  return w + n;
-}
-
-// Bases [from, to) of a forward-strand buffer that starts at contig offset lo, in guide orientation (flanks: 8 or 10 bases).
-__device__ __forceinline__ uint8_t* put_bases(uint8_t* __restrict__ w, const uint8_t* __restrict__ fwd, int lo, int from, int to, bool minus) {
-  const int n = to - from;
-  if (!minus) return copy_bytes(w, fwd + (from - lo), n);
-  for (int i = 0; i < n; i += 8) {
-    uint8_t b[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) b[k] = (i + k < n) ? fwd[to - 1 - (i + k) - lo] : (uint8_t)0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) if (i + k < n) w[i + k] = (uint8_t)comp_base((char)b[k]);
-  }
-  return w + n;
-}
-
-__device__ __forceinline__ bool is_lower(char c) { return c >= 'a' && c <= 'z'; }
-__device__ __forceinline__ bool is_letter(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
-
-// GuideAlignment.count (GA:139-163)
-__device__ int ga_count(const uint8_t* pg, const uint8_t* pa, int len, bool lower, bool both_sides, bool mms, bool gaps) {
-  int n = 0;
-  for (int i = 0; i < len; i++) {
-    if (mms && pa[i] == '.' && is_lower((char)pg[i]) == lower) { n++; continue; }
-    if (!(gaps && pa[i] == '~')) continue;
-    const char gb = (char)pg[i];
-    bool me = gb != '-' && is_lower(gb) == lower;
-    if (!me) {
-      int pi = i; while (pi > 0 && pg[pi] == '-') pi--;            // previousNonDash GA:168-172
-      int ni = i; while (ni < len - 1 && pg[ni] == '-') ni++;      // nextNonDash GA:177-182
-      const char prev = (char)pg[pi], next = (char)pg[ni];
-      if (both_sides) me = (prev == '-' || is_lower(prev) == lower) && (next == '-' || is_lower(next) == lower);
-      else me = (is_letter(prev) && is_lower(prev) == lower) || (is_letter(next) && is_lower(next) == lower);
-    }
-    if (me) n++;
-  }
-  return n;
-}
-
-// words of the packed reference a row's span can touch (alignment + flanks <= CALITAS_MAX_OPS + 20 bases), staged per lane
-constexpr int MID_CODE_WORDS = (CALITAS_MAX_OPS + 20) / 16 + 2, MID_MASK_WORDS = (CALITAS_MAX_OPS + 20) / 32 + 2;
-constexpr int MID_WORDS = MID_CODE_WORDS + MID_MASK_WORDS;
+constexpr int MID_ROWS_PER_WAVE = 4;
+constexpr int MID_COLS = 64;          // padded columns a row may have on this path: one per lane
+constexpr int MID_LINE = 6 * MID_COLS + 128;   // bytes of a wave's line buffer = the largest mid_bound
+constexpr int MID_FWD = 128;          // reference bases staged per row: the alignment and its flanks
+constexpr int MID_FIELDS = 25;
 
 struct MidArgs {
   HitsRef ref;
@@ -288,9 +226,8 @@ struct MidArgs {
   const uint8_t* keep;       // per sorted position: survives removeOverlaps
   const uint32_t* order;     // sorted values: index into fin / hits
   uint32_t n;
-  uint32_t slot_bytes;       // LDS bytes per lane: multiple of 4, odd number of words
-  uint32_t mid_bound;        // bytes reserved for the middle part = staging stride
-  uint32_t n_max;            // most padded columns a row of this search can have
+  uint32_t mid_bound;        // bytes reserved for the middle part = staging stride (<= MID_LINE)
+  uint32_t n_max;            // most padded columns a row of this search can have (<= MID_COLS)
   uint32_t blob_bytes;       // constant strings, copied to LDS by each block
   uint32_t* n_rows;          // out: number of live rows
 };
@@ -298,166 +235,235 @@ struct MidArgs {
 static_assert(offsetof(RawAln, ops) % 4 == 0 && sizeof(RawAln) % 4 == 0, "RawAln::ops must be word aligned");
 
 struct RowIn {             // the fields of one RawAln a row needs, ops as five words (2 bits per op, traceback order)
-  uint32_t w[RAW_MAX_OPS / 16];
+  uint32_t w0, w1, w2, w3, w4;
   int n_ops, pam, offset;
   uint32_t pam_x;
 };
+static_assert(RAW_MAX_OPS / 16 == 5, "RowIn holds five ops words");
+struct RowGuide { int L, pam5, pam_len; };   // what a row needs of its GuideDev (pam_len: of the row's PAM, 0 without one)
 
-__device__ __forceinline__ int row_op(const RowIn& r, int i) {
+// op i of the row: the word is chosen by comparison (the five words are wave-uniform and live in scalar registers; indexing them
+// as an array made the compiler spill them to scratch and load per lane)
+__device__ __forceinline__ int row_op(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t w3, const uint32_t w4, int i) {
   const int k = i >> 4;
-  uint32_t w = r.w[0];
-#pragma unroll
-  for (int j = 1; j < RAW_MAX_OPS / 16; j++) w = (k == j) ? r.w[j] : w;
+  uint32_t w = w0;
+  w = (k == 1) ? w1 : w; w = (k == 2) ? w2 : w; w = (k == 3) ? w3 : w; w = (k == 4) ? w4 : w;
   return (int)((w >> ((i & 15) * 2)) & 3u);
 }
 
-// The middle part of one hits.txt row (RH:210-254, columns coordinate_start .. unpadded_target_sequence_length) at `out`;
-// `scratch` holds 4 * n_max + n_max + 24 bytes and, word aligned behind them, MID_WORDS words; `blob` is the LDS copy of the constant strings.  Returns its length, or -1
-// when the alignment has more columns than n_max.
-__device__ int format_middle(uint8_t* out, uint8_t* scratch, const MidArgs& a, const uint8_t* blob, const RowIn& r, const HitRec& h,
-                             const GuideDev& g) {
-  uint8_t* ops = scratch;
-  uint8_t* pg = ops + a.n_max;
-  uint8_t* pa = pg + a.n_max;
-  uint8_t* pt = pa + a.n_max;
-  uint8_t* fwd = pt + a.n_max;
-  const int pam_len = r.pam >= 0 ? g.pam_len[r.pam] : 0, gap = r.pam >= 0 ? r.offset : 0;
-  const int ng = r.n_ops, n = ng + gap + pam_len;
-  if (n > (int)a.n_max) return -1;
-  // ops in guide orientation: guide part (stored in traceback order), gap to the PAM, PAM (SGA:472-476); reversed for a
-  // 5' PAM (SGA:267-269)
-  for (int i = 0; i < n; i++) {
-    const int k = g.pam5 ? n - 1 - i : i;
-    char op;
-    if (k < ng) op = op_letter(row_op(r, ng - 1 - k));
-    else if (k < ng + gap) op = 'D';
-    else op = ((r.pam_x >> (k - ng - gap)) & 1) ? 'X' : '=';
-    ops[i] = (uint8_t)op;
-  }
-  const bool minus = h.minus != 0;
-  const uint8_t* q = blob + a.rc.q_off[r.pam + 1];
-  // one fetch covers the alignment and all four flanks (RH:213-216)
-  const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
-  {
-    // The code words (16 bases each) and mask words (32 bases each) of the span are fetched up front into the lane's scratch -- a
-    // dozen independent loads and one wait.  Fetching them inside the loop as it reached a new word made every iteration of the
-    // wave a dependent round trip to memory (the lanes cross word boundaries at different bases): ~100 of them per wave, half of
-    // the kernel's time.
-    const ContigInfo c = a.ref.contigs[h.contig];
-    uint32_t* wsc = reinterpret_cast<uint32_t*>(scratch + ((5 * a.n_max + 24 + 3) & ~3u));   // MID_WORDS words behind fwd[]
-    const int p0 = max(lo, 0), p1 = (int)min((int64_t)hi, (int64_t)c.len);
-    uint64_t cw0 = 0, mw0 = 0;
-    if (p0 < p1) {
-      const uint64_t g0 = c.gbase + (uint64_t)p0, g1 = c.gbase + (uint64_t)p1 - 1;
-      cw0 = g0 >> 4; mw0 = g0 >> 5;
-      const int ncw = (int)((g1 >> 4) - cw0) + 1, nmw = (int)((g1 >> 5) - mw0) + 1;
-      for (int k = 0; k < ncw && k < MID_CODE_WORDS; k++) wsc[k] = a.ref.codes[cw0 + k];
-      for (int k = 0; k < nmw && k < MID_MASK_WORDS; k++) wsc[MID_CODE_WORDS + k] = a.ref.mask[mw0 + k];
-    }
-    for (int p = lo; p < hi; p++) {
-      char b = 'N';                                                                          // RH:262-264
-      if (p >= p0 && p < p1) {
-        const uint64_t gpos = c.gbase + (uint64_t)p;
-        const uint32_t mw = wsc[MID_CODE_WORDS + (int)((gpos >> 5) - mw0)], cw = wsc[(int)((gpos >> 4) - cw0)];
-        b = ((mw >> (gpos & 31)) & 1u) ? base_upper_dev(a.ref, gpos) : base_letter((cw >> ((gpos & 15) * 2)) & 3u);
-      }
-      fwd[p - lo] = (uint8_t)b;
-    }
-  }
-  int qi = 0, mm = 0, gp = 0, ps = -1, pe = -1;
-  int tp = minus ? h.end - 1 : h.start;                 // next target base, walking in guide orientation
-  for (int i = 0; i < n; i++) {                         // Alignment.paddedString (SGA:511)
-    const char op = (char)ops[i];
-    char tb = '-', qc = '-';
-    if (op != 'I') { tb = (char)fwd[tp - lo]; if (minus) { tb = comp_base(tb); tp--; } else tp++; }
-    if (op != 'D') qc = (char)q[qi++];
-    pg[i] = (uint8_t)qc; pt[i] = (uint8_t)tb;
-    pa[i] = (uint8_t)(op == '=' ? '|' : op == 'X' ? '.' : '~');
-    mm += op == 'X'; gp += (op == 'I' || op == 'D');
-    if (qc >= 'A' && qc <= 'Z') { if (ps < 0) ps = i; pe = i; }   // unpaddedTargetWithoutPam GA:111-115
-  }
-  uint8_t* w = out;
-  w = put_int(w, h.gstart); *w++ = '\t';
-  w = put_int(w, h.gend); *w++ = '\t';
-  *w++ = minus ? '-' : '+'; *w++ = '\t';
-  int utn = 0;
-  for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') { *w++ = pt[i]; utn++; }
-  *w++ = '\t';
-  const int gs = h.gstart, ge = h.gend, as = h.start, ae = h.end;
-  if (!minus) { w = put_bases(w, fwd, lo, gs - 10, gs, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ge, ge + 10, false); }   // RH:227-228
-  else        { w = put_bases(w, fwd, lo, ge, ge + 10, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, gs - 10, gs, true); }
-  *w++ = '\t';
-  w = copy_bytes(w, blob + a.rc.pu_off[r.pam + 1], (int)a.rc.pu_len[r.pam + 1]);
-  *w++ = '\t';
-  *w++ = '\t'; *w++ = '\t'; *w++ = '\t'; *w++ = '\t';   // variant_id, variant_description, variant_vcf, allele_frequency: None
-  w = put_int(w, h.score); *w++ = '\t';
-  const int gmm = ga_count(pg, pa, n, false, false, true, false);    // guide_mm GA:103
-  const int ggp = ga_count(pg, pa, n, false, false, false, true);    // guide_gaps GA:104
-  w = put_int(w, gmm); *w++ = '\t';
-  w = put_int(w, ggp); *w++ = '\t';
-  w = put_int(w, gmm + ggp); *w++ = '\t';               // guide_mm_plus_gaps GA:105
-  w = put_int(w, ga_count(pg, pa, n, true, true, true, false)); *w++ = '\t';   // pam_mm GA:106
-  w = put_int(w, mm + gp); *w++ = '\t';                 // total_mm_plus_gaps = edits GA:101
-  w = copy_bytes(w, pg, n);
-  *w++ = '\t';
-  w = copy_bytes(w, pa, n);
-  *w++ = '\t';
-  w = copy_bytes(w, pt, n);
-  *w++ = '\t';
-  if (!minus) { w = put_bases(w, fwd, lo, as - 8, as, false); *w++ = '\t'; w = put_bases(w, fwd, lo, ae, ae + 8, false); }     // RH:243-244
-  else        { w = put_bases(w, fwd, lo, ae, ae + 8, true);  *w++ = '\t'; w = put_bases(w, fwd, lo, as - 8, as, true); }
-  *w++ = '\t';
-  for (int i = 0; i < n;) {                             // Cigar.coalesce + toString
-    int j = i;
-    while (j < n && ops[j] == ops[i]) j++;
-    w = put_int(w, j - i); *w++ = ops[i]; i = j;
-  }
-  *w++ = '\t';
-  w = put_int(w, g.L); *w++ = '\t';                     // unpadded_guide_sequence_length
-  w = put_int(w, utn); *w++ = '\t';
-  return (int)(w - out);
+// Read-only inputs of a row are the same for all lanes of its wave: through the constant address space they are scalar loads into
+// scalar registers (everything they point to was written by earlier kernels).
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* uniform_ptr(const T* p) {
+  return (const __attribute__((address_space(4))) T*)p;
 }
 
-__global__ __launch_bounds__(64) void mid_kernel(MidArgs a, uint8_t* stage, uint32_t* midlen, uint64_t* lens, uint32_t* flags) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64, k = row0 + lane;
-  int len = 0;
-  uint32_t name_len = 0;
-  const bool live = k < a.n && a.keep[k] != 0;
-  // constant strings (queries, PAMs) into LDS behind the 64 slots
-  uint8_t* blob = lds + 64 * a.slot_bytes;
-  for (uint32_t i = lane; i < a.blob_bytes; i += 64) blob[i] = (uint8_t)a.blob[i];
-  __syncthreads();
-  if (live) {
-    const uint32_t v = a.order[k];
-    const RawAln* rp = a.fin + v;
-    RowIn r;
-    const uint32_t* ow = reinterpret_cast<const uint32_t*>(rp->ops);   // RawAln::ops sits at a 4-byte aligned offset
-#pragma unroll
-    for (int j = 0; j < RAW_MAX_OPS / 16; j++) r.w[j] = ow[j];
-    r.n_ops = rp->n_ops; r.pam = rp->pam; r.offset = rp->offset; r.pam_x = rp->pam_x;
-    const uint32_t guide = rp->guide;
-    const HitRec h = a.hits[v];
-    uint8_t* out = lds + lane * a.slot_bytes;
-    len = format_middle(out, out + a.mid_bound, a, blob, r, h, a.guides[guide]);
-    if (len < 0 || len > (int)a.mid_bound) { atomicOr(flags, HITS_FLAG_ROW); len = 0; }
-    name_len = a.name_off[h.contig + 1] - a.name_off[h.contig];
-  }
+__device__ __forceinline__ void wave_lds_sync() {       // LDS writes of this wave visible to all its lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ unsigned long long bits_below(int i) { return i >= 64 ? ~0ull : (1ull << i) - 1ull; }
+// number of set bits of a wave-uniform mask below this lane: two instructions (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ int bits_before_lane(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// `v` (wave-uniform) in lane L, `old` elsewhere: one v_writelane_b32
+template <int L>
+__device__ __forceinline__ int set_lane(int v, int old) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(L));
+  return old;
+}
+
+// The middle part of one hits.txt row (RH:210-254, columns coordinate_start .. unpadded_target_sequence_length) in `line`, built by
+// the 64 lanes of a wave; every argument but `lane` is the same in all of them.  `fwd` holds MID_FWD bytes, `blob` is the LDS copy
+// of the constant strings.  Returns the length, or -1 when the row has more columns (or a longer span) than this path lays out.
+__device__ __forceinline__ int build_middle(uint8_t* line, uint8_t* fwd, const MidArgs& a, const uint8_t* blob, const RowIn r, const HitRec h,
+                                            const RowGuide g, const int lane) {
+  const int pam_len = g.pam_len, gap = r.pam >= 0 ? r.offset : 0;
+  const int ng = r.n_ops, n = ng + gap + pam_len;
+  const bool minus = h.minus != 0;
+  // one fetch covers the alignment and all four flanks (RH:213-216); a minus-strand hit keeps the complemented bases: every
+  // reader below wants them in guide orientation
+  const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
+  if (n > (int)a.n_max || n > MID_COLS || hi - lo > MID_FWD) return -1;
   {
-    const unsigned long long lv = __ballot(live);
-    if (lane == 0 && lv) atomicAdd(a.n_rows, (uint32_t)__popcll(lv));
+    const uint64_t c_gbase = uniform_ptr(a.ref.contigs)[h.contig].gbase, c_len = uniform_ptr(a.ref.contigs)[h.contig].len;
+    for (int x = lane; x < hi - lo; x += 64) {
+      const int64_t p = (int64_t)lo + x;
+      char b = 'N';                                                                          // RH:262-264
+      if (p >= 0 && p < (int64_t)c_len) b = base_upper_dev(a.ref, c_gbase + (uint64_t)p);
+      if (minus) b = comp_base(b);
+      fwd[x] = (uint8_t)b;
+    }
   }
-  if (k < a.n) {
-    midlen[k] = (uint32_t)len;
-    lens[k] = live ? (uint64_t)(a.rc.head_len + name_len + 1 + (uint32_t)len + a.rc.tail_len) : 0;
+  // ---- column `lane` of the alignment in guide orientation: guide part (stored in traceback order), gap to the PAM, PAM
+  //      (SGA:472-476); reversed for a 5' PAM (SGA:267-269)
+  const bool valid = lane < n;
+  int op = 0;                                             // 0 '=', 1 'X', 2 'I', 3 'D'
+  {
+    const int k = g.pam5 ? n - 1 - lane : lane;
+    const int guide_op = row_op(r.w0, r.w1, r.w2, r.w3, r.w4, ng - 1 - k), pam_op = (int)((r.pam_x >> ((k - ng - gap) & 15)) & 1u);
+    op = k < ng ? guide_op : k < ng + gap ? 3 : pam_op;
+    if (!valid) op = 0;
   }
+  const unsigned long long MX = __ballot(valid && op == 1), MI = __ballot(valid && op == 2), MD = __ballot(valid && op == 3);
+  const unsigned long long V = bits_below(n), nonD = V & ~MD, nonI = V & ~MI;
+  const int qi = bits_before_lane(nonD), ti = bits_before_lane(nonI);
+  // Alignment.paddedString (SGA:511): query, alignment and target character of this column
+  const uint8_t* q = blob + a.rc.q_off[r.pam + 1];
+  char qc = '-';
+  if (valid && op != 3) qc = (char)q[qi];
+  const bool q_low = valid && qc >= 'a', q_up = valid && qc >= 'A' && qc <= 'Z';   // (the query holds letters only: lower = the PAM)
+  const unsigned long long ML = __ballot(q_low), MU = __ballot(q_up);
+  const char ac = op == 0 ? '|' : op == 1 ? '.' : '~';
+  wave_lds_sync();                                        // fwd[] is complete
+  // j-th target base of the alignment in guide orientation
+  const int t_first = minus ? h.end - 1 - lo : h.start - lo, t_step = minus ? -1 : 1;
+  char tc = '-';
+  if (valid && op != 2) tc = (char)fwd[t_first + t_step * ti];
+  // unpaddedTargetWithoutPam (GA:111-115): the target bases under the first .. last upper-case query column
+  const int ps = MU ? __ffsll((long long)MU) - 1 : 0, pe = MU ? 63 - __clzll((long long)MU) : -1;
+  const unsigned long long span_cols = bits_below(pe + 1) & ~bits_below(ps);
+  const int utn = __popcll(nonI & span_cols), ut0 = __popcll(nonI & bits_below(ps));
+  // GuideAlignment.count (GA:139-163) as ballots.  Mismatches: '.' columns by the case of the query base.  Gaps ('~' columns): an
+  // inserted query base counts by its own case; a deleted one ('-' in the padded guide) by its nearest non-dash neighbours
+  // (previousNonDash / nextNonDash, GA:168-182: the scan stops at the first / last column, which is then a dash itself).
+  const int gmm = __popcll(MX & ~ML), pam_mm = __popcll(MX & ML), edits = __popcll(MX | MI | MD);
+  bool guide_gap = valid && op == 2 && !q_low;            // is_lower(pg[i]) == false
+  if (valid && op == 3) {                                 // (no lane gets here in a row without deletions)
+    const unsigned long long below = bits_below(lane), left = nonD & below, right = nonD & ~below;   // (this column is not in nonD)
+    const bool prev_up = left != 0 && ((MU >> (63 - __clzll((long long)left))) & 1ull);
+    const bool next_up = right != 0 && ((MU >> (__ffsll((long long)right) - 1)) & 1ull);
+    guide_gap = prev_up || next_up;                       // both_sides = false, lower = false: an upper-case letter on either side
+  }
+  const int ggp = __popcll(__ballot(guide_gap));
+  // Cigar.coalesce + toString: a run starts where the op changes; its text is the length and the op letter
+  const int op_prev = __builtin_amdgcn_update_dpp(op, op, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const bool run_start = valid && (lane == 0 || op != op_prev);
+  const unsigned long long RS = __ballot(run_start);
+  int run_len = 0;
+  {
+    // next run start above this lane: clear bits 0..lane of RS (lane-dependent shift of a uniform mask)
+    const unsigned long long nx = lane >= 63 ? 0ull : (RS >> (lane + 1));
+    run_len = nx ? __ffsll((long long)nx) : n - lane;
+  }
+  const unsigned long long RL = __ballot(run_start && run_len >= 10);       // (a run has at most 64 columns: one or two digits)
+  const int cigar_len = 2 * __popcll(RS) + __popcll(RL);
+  // ---- the 25 fields: lane f holds the length of field f (every field is followed by a tab) and, for a number, its value
+  const int pu_len = (int)a.rc.pu_len[r.pam + 1];
+  int flen = 0, val = 0;
+  flen = set_lane<2>(1, flen);                            // strand
+  flen = set_lane<3>(utn, flen);                          // unpadded target without PAM
+  flen = set_lane<4>(10, flen); flen = set_lane<5>(10, flen);    // 10-base flanks of the hit (RH:227-228)
+  flen = set_lane<6>(pu_len, flen);                       // pam_used; 7-10: variant_id, variant_description, variant_vcf, allele_frequency: None
+  flen = set_lane<17>(n, flen); flen = set_lane<18>(n, flen); flen = set_lane<19>(n, flen);   // padded guide, alignment string, padded target
+  flen = set_lane<20>(8, flen); flen = set_lane<21>(8, flen);    // 8-base flanks of the alignment (RH:243-244)
+  flen = set_lane<22>(cigar_len, flen);
+  val = set_lane<0>(h.gstart, val); val = set_lane<1>(h.gend, val); val = set_lane<11>(h.score, val);
+  val = set_lane<12>(gmm, val);                           // guide_mm GA:103
+  val = set_lane<13>(ggp, val);                           // guide_gaps GA:104
+  val = set_lane<14>(gmm + ggp, val);                     // guide_mm_plus_gaps GA:105
+  val = set_lane<15>(pam_mm, val);                        // pam_mm GA:106
+  val = set_lane<16>(edits, val);                         // total_mm_plus_gaps = edits GA:101
+  val = set_lane<23>(g.L, val);                           // unpadded_guide_sequence_length
+  val = set_lane<24>(utn, val);
+  const bool numeric = (0x0181F803u >> (lane & 31)) & (lane < 32 ? 1u : 0u);   // fields 0 1 11-16 23 24
+  unsigned uval = (unsigned)(val < 0 ? -val : val);
+  const int nd = 1 + (uval >= 10u) + (uval >= 100u) + (uval >= 1000u) + (uval >= 10000u) + (uval >= 100000u) + (uval >= 1000000u) +
+                 (uval >= 10000000u) + (uval >= 100000000u) + (uval >= 1000000000u);
+  if (numeric) flen = nd + (val < 0 ? 1 : 0);
+  int incl = lane < MID_FIELDS ? flen + 1 : 0;            // inclusive prefix sum over the field lanes
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  const int foff = incl - (flen + 1);
+  const int total = __builtin_amdgcn_readlane(incl, MID_FIELDS - 1);
+  if (total > (int)a.mid_bound) return -1;
+  if (lane < MID_FIELDS) line[foff + flen] = '\t';
+  if (numeric) {
+    uint8_t* w = line + foff;
+    if (val < 0) *w++ = '-';
+    for (int i = nd - 1; i >= 0; i--) { const unsigned t = uval / 10u; w[i] = (uint8_t)('0' + (uval - 10u * t)); uval = t; }
+  }
+  auto off_of = [&](int f) { return __builtin_amdgcn_readlane(foff, f); };
+  // bases [from, to) of the forward strand in guide orientation (flanks): a minus-strand hit reads them backwards
+  auto put_bases = [&](int off, int from, int to) {
+    if (lane < to - from) line[off + lane] = fwd[minus ? to - 1 - lane - lo : from + lane - lo];
+  };
+  const int o2 = off_of(2), o3 = off_of(3), o4 = off_of(4), o5 = off_of(5), o6 = off_of(6), o17 = off_of(17), o18 = off_of(18), o19 = off_of(19),
+            o20 = off_of(20), o21 = off_of(21), o22 = off_of(22);
+  if (lane == 0) line[o2] = minus ? '-' : '+';
+  if (lane < utn) line[o3 + lane] = fwd[t_first + t_step * (ut0 + lane)];
+  const int gs = h.gstart, ge = h.gend, as = h.start, ae = h.end;
+  if (!minus) { put_bases(o4, gs - 10, gs); put_bases(o5, ge, ge + 10); put_bases(o20, as - 8, as); put_bases(o21, ae, ae + 8); }
+  else        { put_bases(o4, ge, ge + 10); put_bases(o5, gs - 10, gs); put_bases(o20, ae, ae + 8); put_bases(o21, as - 8, as); }
+  if (lane < pu_len) line[o6 + lane] = blob[a.rc.pu_off[r.pam + 1] + lane];
+  if (valid) { line[o17 + lane] = (uint8_t)qc; line[o18 + lane] = (uint8_t)ac; line[o19 + lane] = (uint8_t)tc; }
+  if (run_start) {
+    uint8_t* w = line + o22 + 2 * bits_before_lane(RS) + bits_before_lane(RL);
+    if (run_len >= 10) *w++ = (uint8_t)('0' + run_len / 10);
+    *w++ = (uint8_t)('0' + run_len % 10);
+    *w = (uint8_t)op_letter(op);
+  }
+  return total;
+}
+
+__global__ __launch_bounds__(256) void mid_kernel(MidArgs a, uint8_t* stage, uint32_t* midlen, uint64_t* lens, uint32_t* flags) {
+  CALITAS_TAIL_PRIO();
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // per wave: line | fwd; then the constant strings (queries, PAMs)
+  __shared__ uint32_t s_live;
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* line = lds + wave * (MID_LINE + MID_FWD);
+  uint8_t* fwd = line + MID_LINE;
+  uint8_t* blob = lds + 4 * (MID_LINE + MID_FWD);
+  for (uint32_t i = threadIdx.x; i < a.blob_bytes; i += 256) blob[i] = (uint8_t)a.blob[i];
+  if (threadIdx.x == 0) s_live = 0;
   __syncthreads();
-  for (int r = 0; r < 64; r++) {
-    const int l = __shfl(len, r);
-    const uint32_t* src = (const uint32_t*)(lds + r * a.slot_bytes);
-    uint32_t* dst = (uint32_t*)(stage + (size_t)(row0 + r) * a.mid_bound);
-    for (int wd = lane; wd < (l + 3) / 4; wd += 64) dst[wd] = src[wd];
+  uint32_t live_rows = 0;
+  const uint32_t k0 = (blockIdx.x * 4 + wave) * MID_ROWS_PER_WAVE;
+  for (int rr = 0; rr < MID_ROWS_PER_WAVE; rr++) {
+    const uint32_t k = k0 + (uint32_t)rr;
+    if (k >= a.n) break;
+    int len = 0;
+    uint32_t name_len = 0;
+    const bool live = uniform_ptr(a.keep)[k] != 0;
+    if (live) {
+      const uint32_t v = uniform_ptr(a.order)[k];
+      const auto* rp = uniform_ptr(a.fin) + v;
+      RowIn r;
+      const auto* ow = (const __attribute__((address_space(4))) uint32_t*)rp->ops;   // RawAln::ops sits at a 4-byte aligned offset
+      r.w0 = ow[0]; r.w1 = ow[1]; r.w2 = ow[2]; r.w3 = ow[3]; r.w4 = ow[4];
+      r.n_ops = rp->n_ops; r.pam = rp->pam; r.offset = rp->offset; r.pam_x = rp->pam_x;
+      const auto* hp = uniform_ptr(a.hits) + v;
+      HitRec h;
+      h.contig = hp->contig; h.start = hp->start; h.end = hp->end; h.gstart = hp->gstart; h.gend = hp->gend; h.score = hp->score;
+      h.rh_end = hp->rh_end; h.minus = hp->minus;
+      const auto* gp = uniform_ptr(a.guides) + rp->guide;
+      RowGuide g;
+      g.L = gp->L; g.pam5 = gp->pam5; g.pam_len = r.pam >= 0 ? gp->pam_len[r.pam] : 0;
+      wave_lds_sync();                                    // the copy-out of the previous row is done with line[]
+      len = build_middle(line, fwd, a, blob, r, h, g, lane);
+      if (len < 0) { if (lane == 0) atomicOr(flags, HITS_FLAG_ROW); len = 0; }
+      name_len = uniform_ptr(a.name_off)[h.contig + 1] - uniform_ptr(a.name_off)[h.contig];
+      live_rows++;
+      wave_lds_sync();
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(line);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (size_t)k * a.mid_bound);
+      for (int wd = lane; wd < (len + 3) / 4; wd += 64) dst[wd] = src[wd];
+    }
+    if (lane == 0) {
+      midlen[k] = (uint32_t)len;
+      lens[k] = live ? (uint64_t)(a.rc.head_len + name_len + 1 + (uint32_t)len + a.rc.tail_len) : 0;
+    }
   }
+  if (lane == 0 && live_rows) atomicAdd(&s_live, live_rows);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_live) atomicAdd(a.n_rows, s_live);
 }
 
 struct OutArgs {
@@ -476,6 +482,7 @@ struct OutArgs {
 constexpr int OUT_ROWS_PER_WAVE = 8;
 
 __global__ __launch_bounds__(256) void out_kernel(OutArgs a, char* text) {
+  CALITAS_TAIL_PRIO();
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // head | tail
   for (uint32_t i = threadIdx.x; i < a.rc.head_len; i += 256) lds[i] = (uint8_t)a.blob[a.rc.head_off + i];
   for (uint32_t i = threadIdx.x; i < a.rc.tail_len; i += 256) lds[a.rc.head_len + i] = (uint8_t)a.blob[a.rc.tail_off + i];
@@ -640,27 +647,24 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   hipLaunchKernelGGL(cluster_kernel, grid, block, 0, stream, (const int32_t*)w.s_start, (const int32_t*)w.s_end, (const int32_t*)w.s_score,
                      (const uint32_t*)w.s_cs, (const uint8_t*)w.head, n_in, max_overlap, w.keep, d_flags);
   // 4: rows
-  const uint32_t n_max = (uint32_t)std::min<int>(CALITAS_MAX_OPS, std::max(1, max_ops));
+  // (a row with more padded columns than a wave has lanes raises HITS_FLAG_ROW and the caller finishes on the host)
+  const uint32_t n_max = (uint32_t)std::min<int>(MID_COLS, std::max(1, max_ops));
   const uint32_t mid_bound = (6 * n_max + 128 + 3) & ~3u;
-  uint32_t slot = mid_bound + ((5 * n_max + 24 + 3) & ~3u) + 4 * MID_WORDS;   // output | ops, padded strings, fetched bases | staged reference words
-  if (((slot / 4) & 1) == 0) slot += 4;
-  const uint32_t mid_lds = 64 * slot + (uint32_t)((blob_bytes + 15) & ~(size_t)15);
-  if (mid_lds > 64 * 1024) {   // beyond the default dynamic LDS limit: ask for more (160 KB per CU on gfx950) or decline
-    if (mid_lds > 160 * 1024 ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds) != hipSuccess) {
-      (void)hipGetLastError();
-      TRY(hipStreamSynchronize(stream));
-      res->flags = HITS_FLAG_ROW;
-      return hipSuccess;
-    }
+  const uint32_t mid_lds = 4 * (MID_LINE + MID_FWD) + (uint32_t)((blob_bytes + 15) & ~(size_t)15);   // four waves' line buffers | constant strings
+  if (mid_lds > 64 * 1024) {   // beyond the default dynamic LDS limit (absurdly long parameter strings): decline
+    TRY(hipStreamSynchronize(stream));
+    res->flags = HITS_FLAG_ROW;
+    return hipSuccess;
   }
   const size_t n_pad = (n + 63) / 64 * 64;
   TRY(grow(&w.stage, w.stage_cap, n_pad * mid_bound));
   TRY(grow(&w.midlen, w.midlen_cap, n_pad));
   MidArgs ma{};
   ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
-  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.slot_bytes = slot; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
-  hipLaunchKernelGGL(mid_kernel, dim3((unsigned)(n_pad / 64)), dim3(64), mid_lds, stream, ma, w.stage, w.midlen, w.lens, d_flags);
+  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
+  const unsigned rows_per_mid_block = 4 * MID_ROWS_PER_WAVE;
+  hipLaunchKernelGGL(mid_kernel, dim3((unsigned)((n + rows_per_mid_block - 1) / rows_per_mid_block)), dim3(256), mid_lds, stream, ma, w.stage, w.midlen,
+                     w.lens, d_flags);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts);

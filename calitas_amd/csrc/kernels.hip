@@ -295,6 +295,7 @@ __device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
 // (s_fin3, the larger item stage) would cost the default reading a workgroup per CU (43 -> 66 KB: 153 -> 243 us per launch).
 template <bool PM>
 __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a) {
+  CALITAS_TAIL_PRIO();
   constexpr int STAGE = ITEM_STAGE<PM>;
   // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the 32 lanes over the banks
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
@@ -611,6 +612,7 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
 // '='/'X' ops, extendAndFilterRight (SequentialGuideAligner.scala:433-492), one RawAln per (candidate, PAM).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
+  CALITAS_TAIL_PRIO();
   __shared__ uint8_t s_qmask[MAX_GUIDES][MAX_L];
   __shared__ uint8_t s_pam[MAX_GUIDES][MAX_PAMS][MAX_PAM_LEN];
   __shared__ uint8_t s_pamlen[MAX_GUIDES][MAX_PAMS];
@@ -695,6 +697,7 @@ __global__ void dpp_selftest_kernel(int* out) {
 // mailbox (mailbox.hpp)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void mailbox_kernel(const uint32_t* src, int n, uint32_t* box, uint32_t seq) {
+  CALITAS_TAIL_PRIO();
   for (int i = 0; i < n; i++) box[1 + i] = src[i];
   __threadfence_system();
   __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -24,14 +24,15 @@ struct HostMarks {
   bool on = false;
   std::chrono::steady_clock::time_point t0;
   std::string line;
-  void start() { const char* e = std::getenv("CALITAS_TRACE"); on = e && std::atoi(e) >= 2; line.clear(); t0 = std::chrono::steady_clock::now(); }
+  void start() { start_at(std::chrono::steady_clock::now()); }
+  void start_at(std::chrono::steady_clock::time_point t) { const char* e = std::getenv("CALITAS_TRACE"); on = e && std::atoi(e) >= 2; line.clear(); t0 = t; }
   void mark(const char* what) {
     if (!on) return;
     char b[64];
     std::snprintf(b, sizeof b, " %s %.0f", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     line += b;
   }
-  void dump() { if (on) std::fprintf(stderr, "[calitas] host marks (us):%s\n", line.c_str()); }
+  void dump(int lane = -1) { if (on) std::fprintf(stderr, "[calitas] host marks (us)%s%s:%s\n", lane >= 0 ? " lane " : "", lane >= 0 ? std::to_string(lane).c_str() : "", line.c_str()); }
 };
 thread_local HostMarks g_marks;
 }  // namespace
@@ -374,8 +375,10 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     ScanArgs sa; AlignArgs aa;
     fill_kernel_args(ctx, pl, sa, aa);
-    HIP_TRY(ctx, launch_align(aa, 1024, ctx->stream));
-    HIP_TRY(ctx, launch_trace(aa, 2048, ctx->stream, ctx->ev[2]));
+    static const int align_blocks = std::getenv("CALITAS_ALIGN_BLOCKS") ? std::atoi(std::getenv("CALITAS_ALIGN_BLOCKS")) : 1024;
+    static const int trace_blocks = std::getenv("CALITAS_TRACE_BLOCKS") ? std::atoi(std::getenv("CALITAS_TRACE_BLOCKS")) : 2048;
+    HIP_TRY(ctx, launch_align(aa, align_blocks, ctx->stream));
+    HIP_TRY(ctx, launch_trace(aa, trace_blocks, ctx->stream, ctx->ev[2]));
     HIP_TRY(ctx, mailbox_post(ctx->mbox, ctx->d_counters, 8, ctx->stream));
     g_marks.mark("queued-scan-align-trace");
     HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
@@ -647,8 +650,10 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
   }
   if (owner->dma.usable()) {
     HIP_TRY(lane, calitas_spin_sync(lane->stream));
+    g_marks.mark("rows-done");
     const auto t0 = std::chrono::steady_clock::now();
     if (owner->dma.copy_to_host(dst, src, n)) {
+      g_marks.mark("copied");
       if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       return CALITAS_OK;
     }
@@ -1082,9 +1087,16 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   int rc = plan_search(ctx, 1, guide, params, pl);
   if (rc) return rc;
   const PackedRef& ref = ctx->ref;
+  // The constant pieces of a row.  A chunked search builds them after its scans are queued: nothing on the device needs them before
+  // the first range's rows, and the first scan should not wait for string formatting on the host.
   std::string version, stamp;
-  calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
-  const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+  RowStrings rs;
+  size_t hlen = 0;
+  auto make_rows = [&] {
+    calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+    rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+    hlen = rs.header.size();
+  };
   const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -1112,7 +1124,6 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   std::vector<calitas_ctx*> lanes(K, ctx);
   char* text = nullptr;
   size_t capacity = 0;
-  const size_t hlen = rs.header.size();
   std::mutex copy_mu;
   auto alloc_text = [&](size_t body) {
     if (user_dst) {                                   // the caller's buffer: as much room as it has
@@ -1142,6 +1153,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   };
 
   bool chunked = K > 1;
+  g_marks.mark("planned");
   if (chunked) {
     rc = ensure_lanes(ctx, K);
     if (rc) return rc;
@@ -1172,13 +1184,23 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     };
     // (The inputs of all ranges queued ahead of the first scan, so that the scans run back to back: tried again with the row-wise
     // scan, 2.71 vs 2.68-2.72 ms per pass -- the scans then take 6 % longer beside the tails and nothing is won.)
+    g_marks.mark("lanes-ready");
+    const bool inputs_first = std::getenv("CALITAS_INPUTS_FIRST") != nullptr;
+    if (inputs_first)
+      for (size_t c = 0; c < K && !rc; c++) { rc = queue_scan_inputs(lanes[c], plans[c], ctx->scan_stream); if (rc) ctx->err = lanes[c]->err; }
     for (size_t c = 0; c < K && !rc; c++) {
-      if (device_rows) rc = hip_rc(hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream), "hits_prepare");   // before the wait below is queued
-      if (rc) break;
-      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);                         // records lanes[c]->scan_done
-      if (rc) { ctx->err = lanes[c]->err; break; }
-      rc = hip_rc(hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0), "hipStreamWaitEvent");
+      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, inputs_first);           // records lanes[c]->scan_done
+      if (rc) ctx->err = lanes[c]->err;
+      g_marks.mark("scan-queued");
     }
+    if (!rc) make_rows();
+    g_marks.mark("row-strings");
+    for (size_t c = 0; c < K && !rc; c++) {
+      // the row constants of a range go onto its stream before the wait for its scan: in place while the scan runs
+      if (device_rows) rc = hip_rc(hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream), "hits_prepare");
+      if (!rc) rc = hip_rc(hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0), "hipStreamWaitEvent");
+    }
+    g_marks.mark("rows-prepared");
     if (rc) { (void)hipDeviceSynchronize(); return rc; }
     auto guess = [](size_t last) { return last + last / 4 + (1u << 20); };   // the next call's text is about as long as the last one's
     if (!alloc_text(guess(ctx->last_text_bytes))) {
@@ -1193,6 +1215,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     auto lane_body = [&](size_t c) {
       {
         (void)hipSetDevice(ctx->device);
+        if (c) g_marks.start_at(t_call);
         LaneText& lt = parts[c];
         lt.rc = lane_rows(lanes[c], plans[c], true, rs, guide_id, version, stamp, lt, device_rows);
         size_t offset = 0;
@@ -1208,11 +1231,15 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
           int r = place(c, offset);
           if (r) lt.rc = r; else placed[c] = 1;
         }
+        if (c) g_marks.dump((int)c);
       }
     };
+    g_marks.mark("text-allocated");
     for (size_t c = 1; c < K; c++) threads.emplace_back(lane_body, c);
+    g_marks.mark("threads-started");
     lane_body(0);                                        // the calling thread drives the first lane itself
     for (auto& t : threads) t.join();
+    g_marks.mark("joined");
     rc = CALITAS_OK;
     bool overflow = false;
     for (size_t c = 0; c < K; c++) {
@@ -1251,7 +1278,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     }
   }
   if (!chunked) {
-    g_marks.mark("planned");
+    if (rs.header.empty()) make_rows();
     rc = lane_rows(ctx, pl, false, rs, guide_id, version, stamp, parts[0]);
     if (rc) return rc;
     g_marks.mark("lane-done");

@@ -43,6 +43,7 @@ struct Derived {
 
 __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
                              uint32_t window_lo, uint32_t windows_per_guide, Derived* der, uint32_t* cnt, uint32_t* counts) {
+  CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; }      // survivors, flags, big groups: nobody reads them before step 4
   if (i >= n) return;
@@ -70,6 +71,7 @@ __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guid
 // ders[] = der[] in slot order: the filter kernels read a window's records as one contiguous run
 __global__ void scatter_kernel(const Derived* der, uint32_t n, const uint32_t* offs, uint32_t* cnt, uint32_t* slot, Derived* ders,
                                uint8_t* taken, uint32_t* counts) {
+  CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Derived d = der[i];
@@ -87,6 +89,7 @@ __global__ void scatter_kernel(const Derived* der, uint32_t n, const uint32_t* o
 // their alignment indices, in output order, go to out_idx[s .. s + kept[s]).
 __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const uint32_t* offs, uint32_t n, int max_total_diffs, int max_overlap, uint8_t* taken,
                                                      uint32_t* kept, uint32_t* out_pos, uint32_t* counts, uint32_t* big) {
+  CALITAS_TAIL_PRIO();
   // The block's 256 records (a window's records are consecutive slots) and their "taken" flags are staged in LDS: the greedy below
   // visits every record of the window once per round, and as loads from global memory those visits were a chain of dependent round
   // trips (33-60 us for windows of two or three records).  Slots beyond the block (a window that starts here and ends in the next
@@ -154,6 +157,7 @@ constexpr uint32_t BIG_KEPT = 512;         // kept alignments per strand list
 
 __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, const uint32_t* offs, int max_total_diffs, int max_overlap,
                                                         uint32_t* kept, uint32_t* out_pos, uint32_t* counts, const uint32_t* big) {
+  CALITAS_TAIL_PRIO();
   __shared__ uint32_t s_taken[BIG_MAX / 32];
   __shared__ int s_ks[BIG_KEPT], s_ke[BIG_KEPT];
   const uint32_t lane = threadIdx.x;
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, con
 
 __global__ void gather_kernel(const RawAln* raw, const uint32_t* slot, const uint32_t* kept, const uint32_t* koffs, const uint32_t* out_pos,
                               uint32_t n, RawAln* final_out, uint32_t* counts) {
+  CALITAS_TAIL_PRIO();
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const uint32_t nk = kept[s], d = koffs[s];
