@@ -16,6 +16,7 @@
 //                Only columns [j - span - 1, j] are filled: by the locality argument in DESIGN.md this reproduces
 //                the value and the trace of every cell on the optimal path of a candidate (L, j) bit for bit.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
@@ -260,7 +261,8 @@ constexpr int NEG = -(1 << 20);                      // "minus infinity" that su
 constexpr int JOBS_PER_BLOCK = 2;
 // per wave: flush threshold + the most one record iteration can add (2 jobs x 8 windows x 16 candidates; x 3 when every matrix
 // of a cell is an alignment of its own)
-template <bool PM> constexpr int ITEM_STAGE = 64 + (PM ? 3 : 1) * 2 * 8 * 16;
+constexpr int STAGE_FLUSH = 16;
+template <bool PM> constexpr int ITEM_STAGE = STAGE_FLUSH + (PM ? 3 : 1) * 2 * 8 * 16;
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
 constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
 constexpr int TR_STRIDE = 100;                       // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; lane r writes byte 99r + t)
@@ -300,8 +302,9 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
   // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the 32 lanes over the banks
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tbm[JOBS_PER_BLOCK][TB_LEN];
   __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
-  __shared__ int s_fin3[PM ? JOBS_PER_BLOCK : 1][3][STRIP_MAX_COLS + 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
+  __shared__ int s_fin3[PM ? JOBS_PER_BLOCK : 1][3][PM ? STRIP_MAX_COLS + 1 : 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
   // passing candidates are staged per wave and appended to a.items with one global atomic per flush: trace_kernel then
   // runs one lane per *passing* candidate instead of one per candidate slot (4 % of the slots pass at d = 5)
   __shared__ uint64_t s_items[JOBS_PER_BLOCK / 2][STAGE];
@@ -336,17 +339,18 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
   };
   uint8_t (*tr)[TR_STRIDE] = s_tr[job];
   uint8_t* tb = s_tb[job];
+  uint8_t* tbm = s_tbm[job];
   int* fin = s_fin[job];
-  int (*fin3)[STRIP_MAX_COLS + 1] = s_fin3[PM ? job : 0];
+  int (*fin3)[PM ? STRIP_MAX_COLS + 1 : 1] = s_fin3[PM ? job : 0];
 
   uint32_t n_recs = *a.rec_count;
   if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
-  const uint32_t total_jobs = gridDim.x * JOBS_PER_BLOCK;
   const SearchDev& sp = a.sp;
   const int W = sp.window_size, step = sp.step;
 
+  const uint32_t total_jobs = gridDim.x * JOBS_PER_BLOCK;
   for (uint32_t ri = blockIdx.x * JOBS_PER_BLOCK + job; ri < n_recs; ri += total_jobs) {
-    flush_items(64);                         // a record adds at most 2 jobs x 8 windows x 16 candidates per wave
+    flush_items(STAGE_FLUSH);                // a record adds at most 2 jobs x 8 windows x 16 candidates per wave
     const ScanRecord rec = a.recs[ri];
     const uint32_t cmask = rec.info & 0xFFFFu;
     const int dir = (rec.info >> 16) & 1;
@@ -393,48 +397,78 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
       if (look > n) look = n;
       const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
 
-      // ---- stage target masks ----
+      // ---- stage target masks: tb[] as trace_kernel reads them, tbm[] = the bases a column matches (none for an N) ----
       for (int x = r; x < ntb; x += 32) {
         int col = c0 + 1 + x;                                 // 1-based strand-space column
         int64_t pos = dir ? (wb - col) : (wa + col - 1);
-        tb[x] = (uint8_t)fetch_tmask(a, gbase + (uint64_t)pos, dir);
+        const int tm = fetch_tmask(a, gbase + (uint64_t)pos, dir);
+        tb[x] = (uint8_t)tm;
+        tbm[x] = (uint8_t)((tm & 16) ? 0 : (tm & 15));
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
       // ---- fill: antidiagonal wavefront, lane r = row r+1 ----
+      // A cell of a matrix is kept as score * 4 + the matrix's code (TR_DIAG 2 > TR_LEFT 1 > TR_UP 0): the max of two cells breaks
+      // ties the way fgbio does (Diag over Left over Up) and the code bits of the winner say which one it was -- one max where
+      // there was a max, a compare and a select.
       const int i_row = r + 1;
-      int curD = NEG, curL = NEG, curU = true_border ? i_row * sp.target_gap : NEG;
-      int curP = max(max(curD * 4 + TR_DIAG, curL * 4 + TR_LEFT), curU * 4 + TR_UP);
-      int inP = shift_up_lane(curP), inPprev;
+      const int tgap4 = sp.target_gap * 4, qgap4 = sp.query_gap * 4;
+      const int match_t = sp.match * 4 + TR_DIAG, mismatch_t = sp.mismatch * 4 + TR_DIAG;
+      int curD = NEG * 4 + TR_DIAG, curL = NEG * 4 + TR_LEFT, curU = (true_border ? i_row * sp.target_gap : NEG) * 4 + TR_UP;
+      // "Row 0" (score 0 in all three matrices, ties -> Diag) is what row 1 finds above it: lane 0 gets it as the `old` operand of the
+      // lane shift; lane 32 (row 1 of the wave's second job) reads lane 31, which is no row of the first job when that guide is
+      // shorter than 32 and then simply holds row 0.  (A 32-base guide in the first job: lane 32 is patched in the loop.)
+      const bool row0_in_lane31 = __builtin_amdgcn_readlane(L, 0) < 32;
+      if (row0_in_lane31 && threadIdx.x == 31) { curD = TR_DIAG; curL = NEG * 4 + TR_LEFT; curU = TR_UP; }
+      int curP = max(max(curD, curL), curU);
+      const int t_first = r + 1, t_last = r < L ? r + ncols : -1;     // the steps at which this row has a column of the strip
       const int nsteps = ncols + L - 1;
-      for (int t = 1; t <= nsteps; t++) {
-        inPprev = inP;
-        inP = shift_up_lane(curP);
-        int inD = shift_up_lane(curD);
-        int inU = shift_up_lane(curU);
-        if (r == 0) { inPprev = TR_DIAG; inD = 0; inU = 0; }  // row 0: score 0 in all three matrices, ties -> Diag
-        const int c = t - r;                                  // strip column 1..ncols
-        if (c >= 1 && c <= ncols && r < L) {
-          const int tm = tb[c - 1];
-          const bool match = ((qm & tm & 15) != 0) && !(tm & 16);
-          const int add = match ? sp.match : sp.mismatch;
-          const int newD = (inPprev >> 2) + add;
-          const int dtr = inPprev & 3;
-          const int newU = max(inD, inU) + sp.target_gap;
-          const int utr = (inD >= inU) ? 0 : 1;
-          const int newL = max(curD, curL) + sp.query_gap;
-          const int ltr = (curD >= curL) ? 0 : 1;
-          tr[r][c] = (uint8_t)(dtr | (utr << 2) | (ltr << 3));
-          curD = newD; curL = newL; curU = newU;
-          curP = max(max(newD * 4 + TR_DIAG, newL * 4 + TR_LEFT), newU * 4 + TR_UP);
+      // what the lane above holds: refreshed by a lane shift per step.  Lane 0 has no lane above and keeps what is there -- row 0,
+      // put there once; so does a lane whose upper neighbour is switched off (lane 32 when the first job has nothing to do).
+      int inD = TR_DIAG, inU = TR_UP, inPa = TR_DIAG, inPb = TR_DIAG;
+      int add_match = match_t, add_mismatch = mismatch_t;
+      asm volatile("" : "+v"(add_match), "+v"(add_mismatch));        // in vector registers once, not re-materialised per step
+      auto shift_in = [](int& dst, int src) { dst = __builtin_amdgcn_update_dpp(dst, src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); };
+      // the column's target mask comes from LDS two steps ahead of its use (an LDS round trip is longer than a step); lanes that are
+      // not on the strip yet read a few bytes below tbm[] -- the arrays before it -- and ignore them
+      const uint8_t* tbm_r = tbm - r - 1;                     // tbm_r[t] = mask of the column this row is at in step t
+      int m_a = tbm_r[1], m_b = tbm_r[2];
+      auto cell = [&](const int t, int inPp, int& m_cur, auto patch_lane32) {
+        shift_in(inD, curD);
+        shift_in(inU, curU);
+        if (decltype(patch_lane32)::value && threadIdx.x == 32) { inPp = TR_DIAG; inD = TR_DIAG; inU = TR_UP; }
+        const int m = m_cur;
+        m_cur = tbm_r[t + 2];
+        if (t >= t_first && t <= t_last) {
+          const int c = t - r;                                // strip column 1..ncols
+          const int add_t = (qm & m) ? add_match : add_mismatch;
+          const int newD = (inPp & ~3) + add_t;
+          const int newU = max(inD, inU) + tgap4;             // code bits: TR_DIAG = from Diag, TR_UP = from Up
+          const int newL = max(curD, curL) + qgap4;           // code bits: TR_DIAG = from Diag, TR_LEFT = from Left
+          // trace byte: bits 0-1 where Diag came from, bit 2 Up came from Diag (else Up), bit 3 Left came from Left (else Diag)
+          tr[r][c] = (uint8_t)((((newL & 1) << 3) | (inPp & 3)) | ((newU & 2) << 1));
+          curD = newD; curU = newU & ~3; curL = (newL & ~3) | TR_LEFT;
+          curP = max(max(curD, curL), curU);
           if (r == L - 1) {
             fin[c] = curP;
-            if (PM) { fin3[0][c] = newD; fin3[1][c] = newL; fin3[2][c] = newU; }
+            if (PM) { fin3[0][c] = curD >> 2; fin3[1][c] = curL >> 2; fin3[2][c] = curU >> 2; }
           }
         }
-      }
+      };
+      auto fill = [&](auto patch_lane32) {
+        shift_in(inPa, curP);
+        int t = 1;
+        for (; t + 1 <= nsteps; t += 2) {                    // two steps per round: the shifted curP of one is the "previous" of the next
+          shift_in(inPb, curP);
+          cell(t, inPa, m_a, patch_lane32);
+          shift_in(inPa, curP);
+          cell(t + 1, inPb, m_b, patch_lane32);
+        }
+        if (t <= nsteps) cell(t, inPa, m_a, patch_lane32);
+      };
+      if (row0_in_lane31) fill(std::false_type{}); else fill(std::true_type{});
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -548,7 +582,7 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
           op = eq ? 0 : 1;
           m = t8 & 3; i--; c--;
         } else if (m == TR_UP) {
-          op = 2; m = ((t8 >> 2) & 1) ? TR_UP : TR_DIAG; i--;
+          op = 2; m = ((t8 >> 2) & 1) ? TR_DIAG : TR_UP; i--;       // bit 2: Up came from Diag
         } else {
           op = 3; m = ((t8 >> 3) & 1) ? TR_LEFT : TR_DIAG; c--;
         }

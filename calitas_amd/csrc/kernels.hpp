@@ -37,6 +37,7 @@ struct AlignArgs {
   RawAln* out;
   uint32_t* out_count;
   uint32_t* anomalies;
+  uint32_t* next_rec;       // align_kernel's work counter (zero at launch): jobs take records in turn
   uint8_t* slab;            // strips handed from align_kernel to trace_kernel: rec_capacity x slots_per_rec slabs
   uint32_t* cand_count;     // statistics only
   uint64_t* items;          // passing candidates, (slab index << 4 | candidate slot): align_kernel appends, trace_kernel consumes
