@@ -61,6 +61,7 @@ struct calitas_ctx {
   // chunked calitas_search_hits: the parent owns the lanes and the stream all scans are queued on
   calitas_ctx* parent = nullptr;    // set in a lane: the context whose reference and window table it uses
   std::vector<calitas_ctx*> lanes;
+  struct LaneThreads* lane_threads = nullptr;   // parent: the host threads that drive lanes 1.. (search.cpp)
   hipStream_t scan_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // parent: the text copies of all lanes
   hipEvent_t scan_done = nullptr;   // lane: recorded on the parent's scan stream after this lane's scan

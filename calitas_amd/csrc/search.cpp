@@ -12,6 +12,7 @@
 #include <cstring>
 #include <ctime>
 #include <mutex>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -324,7 +325,9 @@ static int queue_scan_inputs(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t
   // from the context's pinned copy (an async copy from pageable memory may wait for the stream to drain)
   std::memcpy(ctx->h_guides, pl.gd.data(), sizeof(GuideDev) * pl.n_guides);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_guides, ctx->h_guides, sizeof(GuideDev) * pl.n_guides, hipMemcpyHostToDevice, stream));
+  g_marks.mark("guides");
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(uint32_t), stream));
+  g_marks.mark("counters");
   return CALITAS_OK;
 }
 
@@ -755,6 +758,52 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   return CALITAS_OK;
 }
 
+// The host threads behind lanes 1..K-1 of a chunked search (the caller's thread drives lane 0).  They live as long as the lanes:
+// starting two threads took ~110 us of every call and joining them ~40 us after the last copy had finished -- on the caller's clock.
+struct LaneThreads {
+  std::vector<std::thread> threads;
+  std::mutex m;
+  std::condition_variable cv;
+  unsigned long gen = 0;
+  bool stop = false;
+  size_t k = 0;                                    // lanes of the current job (worker i runs job(i) when i < k)
+  std::function<void(size_t)> job;
+  std::atomic<size_t> remaining{0};
+  ~LaneThreads() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; gen++; }
+    cv.notify_all();
+    for (auto& t : threads) t.join();
+  }
+  void ensure(size_t lanes) {                      // workers for lanes 1 .. lanes-1
+    while (threads.size() + 1 < lanes) {
+      const size_t i = threads.size() + 1;
+      threads.emplace_back([this, i] {
+        unsigned long seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return gen != seen; });
+            seen = gen;
+            if (stop) return;
+            if (i >= k) continue;
+          }
+          job(i);
+          remaining.fetch_sub(1, std::memory_order_release);
+        }
+      });
+    }
+  }
+  void start(size_t lanes, std::function<void(size_t)> fn) {
+    { std::lock_guard<std::mutex> lk(m); job = std::move(fn); k = lanes; remaining.store(lanes - 1, std::memory_order_relaxed); gen++; }
+    cv.notify_all();
+  }
+  void wait() {                                    // polls: the last lane to finish is the end of the call
+    for (unsigned spins = 0; remaining.load(std::memory_order_acquire) != 0; spins++) {
+      if (spins < (1u << 16)) __builtin_ia32_pause(); else sched_yield();
+    }
+  }
+};
+
 // Child contexts of a chunked search: own stream (high priority), buffers and scratch; the parent's reference.
 static int ensure_lanes(calitas_ctx* ctx, size_t k) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -768,6 +817,8 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
   // timeline: a 5 us merge pass took 370 us); on the lowest priority the lanes' kernels get their slots first.  A copy kernel of
   // our own with a small grid reached the same 55 GB/s but slowed the other lane more, so the runtime's copy stays.
   if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, least));
+  if (!ctx->lane_threads) ctx->lane_threads = new LaneThreads();
+  ctx->lane_threads->ensure(k);
   while (ctx->lanes.size() < k) {
     calitas_ctx* c = new calitas_ctx();
     c->device = ctx->device; c->parent = ctx;
@@ -786,6 +837,7 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
 }
 
 void calitas_destroy_lanes(calitas_ctx* ctx) {
+  delete ctx->lane_threads; ctx->lane_threads = nullptr;
   for (calitas_ctx* c : ctx->lanes) calitas_destroy(c);
   ctx->lanes.clear();
   if (ctx->scan_stream) { (void)hipStreamDestroy(ctx->scan_stream); ctx->scan_stream = nullptr; }
@@ -1212,7 +1264,6 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     std::condition_variable cv;
     std::vector<char> done(K, 0);
     std::vector<char> placed(K, 0);
-    std::vector<std::thread> threads;
     auto lane_body = [&](size_t c) {
       {
         (void)hipSetDevice(ctx->device);
@@ -1236,10 +1287,10 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       }
     };
     g_marks.mark("text-allocated");
-    for (size_t c = 1; c < K; c++) threads.emplace_back(lane_body, c);
+    ctx->lane_threads->start(K, lane_body);
     g_marks.mark("threads-started");
     lane_body(0);                                        // the calling thread drives the first lane itself
-    for (auto& t : threads) t.join();
+    ctx->lane_threads->wait();
     g_marks.mark("joined");
     rc = CALITAS_OK;
     bool overflow = false;
