@@ -510,7 +510,17 @@ __global__ __launch_bounds__(256) void out_kernel(OutArgs a, char* text) {
   }
 }
 
-__global__ void total_kernel(const uint64_t* offs, const uint64_t* lens, uint32_t n, uint64_t* total) { *total = offs[n - 1] + lens[n - 1]; }
+// Length of the text = end of the last row; posted with the other two counts (rows, flags) to the host's mailbox (mailbox.hpp) by the
+// same thread -- a kernel of its own for the post was one more launch on the path every call waits for.
+__global__ void total_kernel(const uint64_t* offs, const uint64_t* lens, uint32_t n, uint64_t* counts, uint32_t* box, uint32_t seq) {
+  CALITAS_TAIL_PRIO();
+  counts[0] = offs[n - 1] + lens[n - 1];
+  __threadfence();
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(counts);
+  for (int i = 0; i < 6; i++) box[1 + i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rows and flags come from other kernels' atomics
+  __threadfence_system();
+  __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 template <typename T>
 hipError_t grow(T** p, size_t& cap, size_t need) {
@@ -667,8 +677,10 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
                      w.lens, d_flags);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
-  hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts);
-  TRY(mailbox_post(w.mbox, reinterpret_cast<const uint32_t*>(w.d_counts), 6, stream));
+  TRY(mailbox_open(w.mbox));
+  w.mbox.seq++;
+  hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts, w.mbox.dev, w.mbox.seq);
+  TRY(hipGetLastError());
   TRY(mailbox_wait(w.mbox, stream));
   for (int k = 0; k < 3; k++) w.h_counts[k] = (uint64_t)w.mbox.host[1 + 2 * k] | ((uint64_t)w.mbox.host[2 + 2 * k] << 32);
   TRY(hipGetLastError());

@@ -645,7 +645,7 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
 // trace_kernel: one lane per passing candidate end column -- traceback through the strip's trace matrix (slab in HBM),
 // '='/'X' ops, extendAndFilterRight (SequentialGuideAligner.scala:433-492), one RawAln per (candidate, PAM).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
+__global__ __launch_bounds__(256) void trace_kernel(AlignArgs a, uint32_t* box, uint32_t seq) {
   CALITAS_TAIL_PRIO();
   __shared__ uint8_t s_qmask[MAX_GUIDES][MAX_L];
   __shared__ uint8_t s_pam[MAX_GUIDES][MAX_PAMS][MAX_PAM_LEN];
@@ -706,6 +706,19 @@ __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a) {
   }
   flush();
   if (threadIdx.x == 0 && s_ncand) atomicAdd(a.cand_count, s_ncand);
+  if (box) {
+    // the last workgroup to get here posts the call's counters (records, alignments, anomalies, candidates, ...) to the host: no
+    // launch of its own for that on the path the host waits on
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(a.trace_done, 1u) == gridDim.x - 1) {
+        for (int i = 0; i < 8; i++) box[1 + i] = __hip_atomic_load(a.rec_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // Window table of windowIterator (SearchReference.scala:39-71) for one (window size, step): out[win_base[c] + k] = N-trimmed
@@ -812,8 +825,15 @@ hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t strea
   return hipGetLastError();
 }
 
-hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop) {
-  hipExtLaunchKernelGGL(trace_kernel, dim3(n_blocks), dim3(256), 0, stream, nullptr, stop, 0, a);
+hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop, Mailbox* post) {
+  uint32_t* box = nullptr;
+  uint32_t seq = 0;
+  if (post) {
+    hipError_t e = mailbox_open(*post);
+    if (e != hipSuccess) return e;
+    box = post->dev; seq = ++post->seq;
+  }
+  hipExtLaunchKernelGGL(trace_kernel, dim3(n_blocks), dim3(256), 0, stream, nullptr, stop, 0, a, box, seq);
   return hipGetLastError();
 }
 

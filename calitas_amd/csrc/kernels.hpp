@@ -1,5 +1,6 @@
 // kernels.hpp -- launch interface of kernels.hip (device pointers only).
 #pragma once
+#include "mailbox.hpp"
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
@@ -37,7 +38,7 @@ struct AlignArgs {
   RawAln* out;
   uint32_t* out_count;
   uint32_t* anomalies;
-  uint32_t* next_rec;       // align_kernel's work counter (zero at launch): jobs take records in turn
+  uint32_t* trace_done;     // trace_kernel: workgroups finished (zero at launch); the last one posts the counters to the mailbox
   uint8_t* slab;            // strips handed from align_kernel to trace_kernel: rec_capacity x slots_per_rec slabs
   uint32_t* cand_count;     // statistics only
   uint64_t* items;          // passing candidates, (slab index << 4 | candidate slot): align_kernel appends, trace_kernel consumes
@@ -57,7 +58,8 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
 hipError_t launch_scan_rows(const ScanArgs& a, int chunk, int warm_words, uint32_t n_tiles, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_planes(const uint32_t* codes, uint2* planes, uint64_t n32, hipStream_t stream);
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
-hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop = nullptr);
+// post: the kernel's last workgroup publishes the eight counters at a.rec_count to that mailbox (mailbox.hpp) -- wait for it with mailbox_wait
+hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop = nullptr, Mailbox* post = nullptr);
 hipError_t launch_window_table(const Run* runs, int64_t n_runs, const ContigInfo* contigs, const uint64_t* win_base, int n_contigs,
                                uint64_t n_windows, int W, int step, int2* out, hipStream_t stream);
 hipError_t launch_dpp_selftest(int* out, hipStream_t stream);

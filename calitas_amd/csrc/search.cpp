@@ -280,7 +280,7 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.codes = o->d_codes; aa.mask = o->d_mask; aa.runs = o->d_runs; aa.n_runs = (int64_t)ref.runs.size();
   aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
   aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
-  aa.next_rec = ctx->d_counters + 5;
+  aa.trace_done = ctx->d_counters + 5;
   aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
   aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
   aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
@@ -382,6 +382,8 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     static const int align_blocks = std::getenv("CALITAS_ALIGN_BLOCKS") ? std::atoi(std::getenv("CALITAS_ALIGN_BLOCKS")) : 1024;
     static const int trace_blocks = std::getenv("CALITAS_TRACE_BLOCKS") ? std::atoi(std::getenv("CALITAS_TRACE_BLOCKS")) : 2048;
     HIP_TRY(ctx, launch_align(aa, align_blocks, ctx->stream));
+    // (trace_kernel can post the counters itself from its last workgroup -- launch_trace's `post` -- but finding the last of 2048
+    // workgroups is 2048 atomics on one word, ~8 ns each: 20-30 us against the ~10 us of this launch)
     HIP_TRY(ctx, launch_trace(aa, trace_blocks, ctx->stream, ctx->ev[2]));
     HIP_TRY(ctx, mailbox_post(ctx->mbox, ctx->d_counters, 8, ctx->stream));
     g_marks.mark("queued-scan-align-trace");
@@ -419,9 +421,8 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     const RawAln* d_final = nullptr;
     const uint32_t* d_cnt = nullptr;
     HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
-                            p.max_overlap, ctx->stream, &d_final, &d_cnt));
+                            p.max_overlap, ctx->stream, &d_final, &d_cnt, &ctx->mbox));   // its last kernel posts the three counts
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    HIP_TRY(ctx, mailbox_post(ctx->mbox, d_cnt, 3, ctx->stream));
     g_marks.mark("queued-filter");
     HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
     g_marks.mark("counts2");

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const 
   // trips (33-60 us for windows of two or three records).  Slots beyond the block (a window that starts here and ends in the next
   // block) are read from global memory as before; only this window's lane touches them.
   __shared__ Derived s_d[256];
+  __shared__ uint32_t s_out[256];                   // out_pos[] of the block's slots: the clash test reads what this lane just wrote
   __shared__ uint8_t s_taken[256];
   const uint32_t base = blockIdx.x * blockDim.x, s = base + threadIdx.x;
   if (s < n) s_d[threadIdx.x] = ders[s];
@@ -136,13 +137,16 @@ __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const 
       if (b_edits > max_total_diffs) continue;
       bool clash = false;
       for (uint32_t k = first_kept; k < nk; k++) {
-        const uint32_t kp = out_pos[s + k];
+        const uint32_t kp = s + k < lim ? s_out[s + k - base] : out_pos[s + k];
         int ks, ke;
         if (kp < lim) { ks = s_d[kp - base].start; ke = s_d[kp - base].end; } else { ks = ders[kp].start; ke = ders[kp].end; }
         const int o = min(b_end, ke) - max(b_start, ks);   // GA:119-122
         if (o > max_overlap) { clash = true; break; }
       }
-      if (!clash) out_pos[s + nk++] = (uint32_t)best;
+      if (!clash) {
+        if (s + nk < lim) s_out[s + nk - base] = (uint32_t)best;
+        out_pos[s + nk++] = (uint32_t)best;
+      }
     }
   }
   kept[s] = nk;
@@ -215,14 +219,26 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, con
   }
 }
 
+// box: the thread that knows the total also posts the stage's three counts to the host's mailbox (mailbox.hpp).  The flags and the
+// number of big groups were final when the filter kernels ended; the host only uses the counts to queue the next kernels on this
+// stream, behind this one.
 __global__ void gather_kernel(const RawAln* raw, const uint32_t* slot, const uint32_t* kept, const uint32_t* koffs, const uint32_t* out_pos,
-                              uint32_t n, RawAln* final_out, uint32_t* counts) {
+                              uint32_t n, RawAln* final_out, uint32_t* counts, uint32_t* box, uint32_t seq) {
   CALITAS_TAIL_PRIO();
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const uint32_t nk = kept[s], d = koffs[s];
+  if (s == n - 1) {
+    counts[0] = d + nk;                                // total survivors
+    if (box) {
+      box[1] = d + nk;
+      box[2] = __hip_atomic_load(counts + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      box[3] = __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   for (uint32_t r = 0; r < nk; r++) final_out[d + r] = raw[slot[out_pos[s + r]]];
-  if (s == n - 1) counts[0] = d + nk;                  // total survivors
 }
 
 // zero_on: clear the new buffer, ordered on the stream that will use it.  (hipMemset on the null stream is asynchronous to the
@@ -276,7 +292,7 @@ void select_done(SelectWork* w) { if (w) w->cnt_dirty = false; }
 
 hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
-                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts) {
+                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post) {
   if (!*pw) *pw = new SelectWork();
   SelectWork& w = **pw;
   hipError_t e;
@@ -285,7 +301,11 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   if (!w.counts) { TRY(hipMalloc((void**)&w.counts, 3 * sizeof(uint32_t))); TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream)); }
   *d_final = nullptr; *d_counts = w.counts;
-  if (n == 0) { TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream)); return hipSuccess; }
+  if (n == 0) {
+    TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream));
+    if (post) TRY(mailbox_post(*post, w.counts, 3, stream));
+    return hipSuccess;
+  }
   const size_t cnt_cap_before = w.cnt_cap;
   TRY(grow(&w.cnt, w.cnt_cap, nw + 1, stream, true));
   if (w.cnt_dirty && w.cnt_cap == cnt_cap_before) TRY(hipMemsetAsync(w.cnt, 0, w.cnt_cap * sizeof(uint32_t), stream));
@@ -310,8 +330,11 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
                      (const uint32_t*)w.offs, max_total_diffs, max_overlap, w.kept, w.out_idx, w.counts, (const uint32_t*)w.big);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.kept, w.koffs, 0u, n, rocprim::plus<uint32_t>(), stream));
+  uint32_t* box = nullptr;
+  uint32_t seq = 0;
+  if (post) { TRY(mailbox_open(*post)); box = post->dev; seq = ++post->seq; }
   hipLaunchKernelGGL(gather_kernel, grid_n, block, 0, stream, d_raw, (const uint32_t*)w.slot, (const uint32_t*)w.kept, (const uint32_t*)w.koffs,
-                     (const uint32_t*)w.out_idx, n_raw, w.final_out, w.counts);
+                     (const uint32_t*)w.out_idx, n_raw, w.final_out, w.counts, box, seq);
   TRY(hipGetLastError());
 #undef TRY
   *d_final = w.final_out;

@@ -4,6 +4,7 @@
 #include <hip/hip_vector_types.h>
 
 #include "common.hpp"
+#include "mailbox.hpp"
 
 namespace calitas {
 
@@ -21,9 +22,10 @@ bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides)
 // (stream-ordered) *d_final holds the accepted alignments in (guide, contig, window, retval) order and (*d_counts)[0] their
 // number; (*d_counts)[1] != 0 means a window exceeded the kernels' limits and the result must not be used.  Call select_done
 // once the stream has been synchronised without error (it certifies that the per-window counters are back to zero).
+// post: the last kernel also publishes (*d_counts)[0..3) to that mailbox -- wait for it with mailbox_wait.
 hipError_t select_run(SelectWork** work, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
-                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts);
+                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post = nullptr);
 void select_done(SelectWork* work);
 void select_destroy(SelectWork* work);
 
