@@ -41,6 +41,14 @@ struct Derived {
   uint32_t widx;      // global window index
 };
 
+// The order in which the per-window greedy takes records (score desc, gap bases asc (GA:125-129), then the enumeration order: a
+// stable sort), as a number: the larger, the earlier.  Bit 63 = strand list (the two lists are filtered one after the other), bit 0
+// set so that no record has key 0.  ekey is unique inside a window, so the order is total.
+__device__ __forceinline__ unsigned long long order_key(const Derived& d) {
+  return ((unsigned long long)(d.ekey >> 19) << 63) | ((unsigned long long)(uint32_t)(d.score + (1 << 21)) << 40) |
+         ((unsigned long long)(0xFFFFu - d.gaps) << 24) | ((unsigned long long)(0x7FFFFu - (d.ekey & 0x7FFFFu)) << 1) | 1ull;
+}
+
 __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
                              uint32_t window_lo, uint32_t windows_per_guide, Derived* der, uint32_t* cnt, uint32_t* counts) {
   CALITAS_TAIL_PRIO();
@@ -95,11 +103,10 @@ __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const 
   // trips (33-60 us for windows of two or three records).  Slots beyond the block (a window that starts here and ends in the next
   // block) are read from global memory as before; only this window's lane touches them.
   __shared__ Derived s_d[256];
+  __shared__ unsigned long long s_key[256];         // the greedy's order as one number per record (0 = taken), see order_key()
   __shared__ uint32_t s_out[256];                   // out_pos[] of the block's slots: the clash test reads what this lane just wrote
-  __shared__ uint8_t s_taken[256];
   const uint32_t base = blockIdx.x * blockDim.x, s = base + threadIdx.x;
-  if (s < n) s_d[threadIdx.x] = ders[s];
-  s_taken[threadIdx.x] = 0;
+  if (s < n) { const Derived d = ders[s]; s_d[threadIdx.x] = d; s_key[threadIdx.x] = order_key(d); }
   __syncthreads();
   if (s >= n) return;
   const uint32_t w = s_d[threadIdx.x].widx;
@@ -111,29 +118,21 @@ __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const 
   for (uint32_t list = 0; list < 2; list++) {
     const uint32_t first_kept = nk;                   // overlaps are only tested against the same strand (SGA:317)
     for (uint32_t round = s; round < e; round++) {
-      // scalars, not a struct copy: the comparison below is what the whole stage hangs on
-      int best = -1, b_score = 0, b_gaps = 0, b_start = 0, b_end = 0, b_edits = 0;
-      uint32_t b_ekey = 0;
+      // best remaining record of this list: the largest key.  One LDS read per record -- the loop is a chain of LDS round trips
+      // and the whole stage hangs on its length (it read the taken flag, then the fields: 30 us for a window of six records).
+      unsigned long long bk = 0;
+      uint32_t best = 0;
       for (uint32_t m = s; m < e; m++) {
-        uint32_t ek;
-        int sc, gp, st, en, ed;
-        if (m < lim) {                                  // two explicit branches: one generic pointer would make every access a flat load
-          if (s_taken[m - base]) continue;
-          const Derived& d = s_d[m - base];
-          ek = d.ekey; sc = d.score; gp = d.gaps; st = d.start; en = d.end; ed = d.edits;
-        } else {
-          if (taken[m]) continue;
-          const Derived& d = ders[m];
-          ek = d.ekey; sc = d.score; gp = d.gaps; st = d.start; en = d.end; ed = d.edits;
-        }
-        if ((ek >> 19) != list) continue;
-        // score desc, gap bases asc (GA:125-129), then the enumeration order (stable sort)
-        const bool first = best < 0;
-        const bool wins = sc > b_score || (sc == b_score && (gp < b_gaps || (gp == b_gaps && ek < b_ekey)));
-        if (first || wins) { best = (int)m; b_score = sc; b_gaps = gp; b_ekey = ek; b_start = st; b_end = en; b_edits = ed; }
+        unsigned long long k;
+        if (m < lim) k = s_key[m - base];               // two explicit branches: one generic pointer would make every access a flat load
+        else k = taken[m] ? 0ull : order_key(ders[m]);
+        if ((uint32_t)(k >> 63) != list || k == 0) continue;
+        if (k > bk) { bk = k; best = m; }
       }
-      if (best < 0) break;
-      if ((uint32_t)best < lim) s_taken[(uint32_t)best - base] = 1; else taken[best] = 1;
+      if (bk == 0) break;
+      int b_start, b_end, b_edits;
+      if (best < lim) { s_key[best - base] = 0; b_start = s_d[best - base].start; b_end = s_d[best - base].end; b_edits = s_d[best - base].edits; }
+      else { taken[best] = 1; b_start = ders[best].start; b_end = ders[best].end; b_edits = ders[best].edits; }
       if (b_edits > max_total_diffs) continue;
       bool clash = false;
       for (uint32_t k = first_kept; k < nk; k++) {
@@ -144,8 +143,8 @@ __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const 
         if (o > max_overlap) { clash = true; break; }
       }
       if (!clash) {
-        if (s + nk < lim) s_out[s + nk - base] = (uint32_t)best;
-        out_pos[s + nk++] = (uint32_t)best;
+        if (s + nk < lim) s_out[s + nk - base] = best;
+        out_pos[s + nk++] = best;
       }
     }
   }
