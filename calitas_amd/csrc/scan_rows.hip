@@ -325,8 +325,7 @@ hipError_t launch_scan_rows(const ScanArgs& a, int chunk, int warm_words, uint32
     return stop ? hipEventRecord(stop, stream) : hipSuccess;
   }
   const dim3 grid(n_tiles), block(LANES_PER_TILE);
-  static const unsigned lds_pad = std::getenv("CALITAS_SCAN_LDS_PAD") ? (unsigned)std::atoi(std::getenv("CALITAS_SCAN_LDS_PAD")) : 0u;   // experiment
-#define CALITAS_LAUNCH_ROWS(NW, NWARM) hipExtLaunchKernelGGL((scan_rows_kernel<NW, NWARM>), grid, block, lds_pad, stream, start, stop, 0, a)
+#define CALITAS_LAUNCH_ROWS(NW, NWARM) hipExtLaunchKernelGGL((scan_rows_kernel<NW, NWARM>), grid, block, 0, stream, start, stop, 0, a)
   if (warm_words == 1) {
     switch (chunk) {
       case 64:  CALITAS_LAUNCH_ROWS(2, 1); break;

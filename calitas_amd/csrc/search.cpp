@@ -141,7 +141,7 @@ struct DeviceSel {
   bool valid = false;
   const RawAln* d_final = nullptr;
   uint32_t n_sel = 0;
-  bool crowded = false;    // some window held more records than one lane filters (select.hip GROUP_MAX)
+  bool crowded = false;    // some window held more records than a wave filters in registers (select.hip GROUP_MAX)
   std::chrono::steady_clock::time_point t_call;
 };
 
@@ -351,6 +351,9 @@ static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
   (void)hipEventElapsedTime(&ms, ctx->t_scan0, ctx->ev[3]); tm.gpu_total_ms = ms;
 }
 
+// grids of align_kernel (units of 256 lanes: 4 single-wave workgroups each; 4096 workgroups are what the CUs hold at once) and trace_kernel
+constexpr int kAlignBlocks = 1024, kTraceBlocks = 2048;
+
 // calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
 // (dev->valid), and *out stays NULL.  prelaunched: the scan stage of this lane was queued by the caller on another stream
 // and ctx->stream already waits for it; an overflow then fails the call instead of retrying.
@@ -379,12 +382,10 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     ScanArgs sa; AlignArgs aa;
     fill_kernel_args(ctx, pl, sa, aa);
-    static const int align_blocks = std::getenv("CALITAS_ALIGN_BLOCKS") ? std::atoi(std::getenv("CALITAS_ALIGN_BLOCKS")) : 1024;
-    static const int trace_blocks = std::getenv("CALITAS_TRACE_BLOCKS") ? std::atoi(std::getenv("CALITAS_TRACE_BLOCKS")) : 2048;
-    HIP_TRY(ctx, launch_align(aa, align_blocks, ctx->stream));
+    HIP_TRY(ctx, launch_align(aa, kAlignBlocks, ctx->stream));
     // (trace_kernel can post the counters itself from its last workgroup -- launch_trace's `post` -- but finding the last of 2048
     // workgroups is 2048 atomics on one word, ~8 ns each: 20-30 us against the ~10 us of this launch)
-    HIP_TRY(ctx, launch_trace(aa, trace_blocks, ctx->stream, ctx->ev[2]));
+    HIP_TRY(ctx, launch_trace(aa, kTraceBlocks, ctx->stream, ctx->ev[2]));
     HIP_TRY(ctx, mailbox_post(ctx->mbox, ctx->d_counters, 8, ctx->stream));
     g_marks.mark("queued-scan-align-trace");
     HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
@@ -1239,11 +1240,10 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     // (The inputs of all ranges queued ahead of the first scan, so that the scans run back to back: tried again with the row-wise
     // scan, 2.71 vs 2.68-2.72 ms per pass -- the scans then take 6 % longer beside the tails and nothing is won.)
     g_marks.mark("lanes-ready");
-    const bool inputs_first = std::getenv("CALITAS_INPUTS_FIRST") != nullptr;
-    if (inputs_first)
-      for (size_t c = 0; c < K && !rc; c++) { rc = queue_scan_inputs(lanes[c], plans[c], ctx->scan_stream); if (rc) ctx->err = lanes[c]->err; }
+    // (Holding the scan of a range back until the aligner kernels of the range before it are done -- they take half as long again
+    // beside a scan, the scan twice as long beside them -- was tried: 2.77 against 2.55 ms per pass.)
     for (size_t c = 0; c < K && !rc; c++) {
-      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, inputs_first);           // records lanes[c]->scan_done
+      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);           // records lanes[c]->scan_done
       if (rc) ctx->err = lanes[c]->err;
       g_marks.mark("scan-queued");
     }

@@ -12,9 +12,9 @@
 //                      enumeration order on ties = the reference's stable sort (GA:125-129) --, kept if edits <= maxTotalDiffs and
 //                      no kept alignment of the same list overlaps it by more than maxOverlap;
 //   5. exclusive scan of the kept counts, gather_kernel: accepted alignments in (guide, contig, window, output) order.
-// Windows with more than GROUP_MAX alignments (satellite repeats, PAM-less dense searches) go to filter_big_kernel, one wave
-// per window; only beyond 16 384 records or 512 kept alignments per strand in one window does a flag send the caller to the host
-// implementation of the same stage for this search.  (A first version radix-sorted 64-bit keys: eight more launches per call,
+// Windows with more than LANE_MAX alignments (planted or repeated sites, PAM-less dense searches) go to filter_wave_kernel, one wave
+// per window (in registers up to GROUP_MAX of them); only beyond 16 384 records or 512 kept alignments per strand in one window
+// does a flag send the caller to the host implementation of the same stage for this search.  (A first version radix-sorted 64-bit keys: eight more launches per call,
 // which is what a lane's tail is made of -- DESIGN.md 4.5.)
 #include <algorithm>
 #include <cstdio>
@@ -32,7 +32,8 @@ namespace calitas {
 
 namespace {
 
-constexpr uint32_t GROUP_MAX = 256;
+constexpr uint32_t LANE_MAX = 8;      // records of a window one lane filters on its own (filter_kernel); larger windows get a wave
+constexpr uint32_t GROUP_MAX = 256;   // records of a window a wave holds in registers (filter_wave_kernel); beyond: its global-memory loop
 
 struct Derived {
   int32_t start, end, score;
@@ -53,7 +54,7 @@ __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guid
                              uint32_t window_lo, uint32_t windows_per_guide, Derived* der, uint32_t* cnt, uint32_t* counts) {
   CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; }      // survivors, flags, big groups: nobody reads them before step 4
+  if (i == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; counts[3] = 0; }   // survivors, flags, listed windows, crowded windows: nobody reads them before step 4
   if (i >= n) return;
   const RawAln* rp = raw + i;
   const uint32_t contig = rp->contig, window_k = rp->window_k, guide = rp->guide;
@@ -112,7 +113,25 @@ __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const 
   const uint32_t w = s_d[threadIdx.x].widx;
   if (offs[w] != s) { kept[s] = 0; return; }
   const uint32_t e = offs[w + 1];
-  if (e - s > GROUP_MAX) { big[atomicAdd(counts + 2, 1u)] = s; kept[s] = 0; return; }   // left to filter_big_kernel
+  // A window of more than LANE_MAX records is left to filter_wave_kernel (the greedy below is quadratic in the window's size, and
+  // alone in its wave for that long: a PAM-less search at eight differences has ~170 alignments per window and spent 3.6 of its
+  // 4.5 device-seconds here).  One append per wave.
+  {
+    const bool listed = e - s > LANE_MAX;
+    const unsigned long long lm = __ballot(listed);
+    if (lm) {
+      const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)lm) - 1;
+      uint32_t at = 0;
+      if (lane == leader) at = atomicAdd(counts + 2, (uint32_t)__popcll(lm));
+      at = __shfl(at, leader);
+      if (listed) {
+        big[at + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = s;
+        kept[s] = 0;
+        if (e - s > GROUP_MAX) atomicAdd(counts + 3, 1u);
+        return;
+      }
+    }
+  }
   const uint32_t lim = base + 256;                  // slots [base, lim) are in LDS
   uint32_t nk = 0;
   for (uint32_t list = 0; list < 2; list++) {
@@ -151,15 +170,29 @@ __global__ __launch_bounds__(256) void filter_kernel(const Derived* ders, const 
   kept[s] = nk;
 }
 
-// Windows with more than GROUP_MAX records: one wave per window, same greedy.  The "taken" bits and the kept intervals of the
-// current strand list live in LDS; a window beyond those capacities raises the flag.
-// LDS is what a workgroup of this kernel has to wait for while the scan of the next lane fills the CUs (4 x 37 KB of 160 KB): kept
-// to 6 KB, because the kernel is launched on every call and usually has nothing to do.
+// Windows with more than LANE_MAX records: one wave per window, same greedy.
+//   up to GROUP_MAX records: every lane holds four of them in registers; a round is a wave-wide maximum of the order keys, the
+//     winner's interval broadcast from its lane, and the clash test spread over the lanes (kept intervals in LDS);
+//   beyond (satellite repeats): the records stay in global memory, "taken" bits and kept intervals in LDS; a window beyond those
+//     capacities raises the flag.
+// LDS is what a workgroup of this kernel has to wait for while the scan of the next lane fills the CUs: kept to 6 KB, because the
+// kernel is launched on every call and usually has little to do.
 constexpr uint32_t BIG_MAX = 1u << 14;     // records per window
 constexpr uint32_t BIG_KEPT = 512;         // kept alignments per strand list
+static_assert(GROUP_MAX == 4 * 64 && GROUP_MAX <= BIG_KEPT, "filter_wave_kernel holds four records per lane");
 
-__global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, const uint32_t* offs, int max_total_diffs, int max_overlap,
-                                                        uint32_t* kept, uint32_t* out_pos, uint32_t* counts, const uint32_t* big) {
+// 64-bit wave maximum (all lanes get it)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void filter_wave_kernel(const Derived* ders, const uint32_t* offs, int max_total_diffs, int max_overlap,
+                                                         uint32_t* kept, uint32_t* out_pos, uint32_t* counts, const uint32_t* big) {
   CALITAS_TAIL_PRIO();
   __shared__ uint32_t s_taken[BIG_MAX / 32];
   __shared__ int s_ks[BIG_KEPT], s_ke[BIG_KEPT];
@@ -169,6 +202,48 @@ __global__ __launch_bounds__(64) void filter_big_kernel(const Derived* ders, con
     const uint32_t s = big[g];
     const uint32_t e = offs[ders[s].widx + 1];
     if (e - s > BIG_MAX) { if (lane == 0) { atomicOr(counts + 1, 1u); kept[s] = 0; } continue; }
+    if (e - s <= GROUP_MAX) {
+      // ---- the window in registers: lane holds records s + lane + 64 q ----
+      unsigned long long key[4];
+      int st[4], en[4], ed[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t m = s + lane + 64u * (uint32_t)q;
+        key[q] = 0; st[q] = 0; en[q] = 0; ed[q] = 0;
+        if (m < e) { const Derived d = ders[m]; key[q] = order_key(d); st[q] = d.start; en[q] = d.end; ed[q] = d.edits; }
+      }
+      uint32_t nk = 0;
+      for (uint32_t list = 0; list < 2; list++) {
+        const uint32_t first_kept = nk;                 // overlaps are only tested against the same strand (SGA:317)
+        for (;;) {
+          unsigned long long mine = 0;                  // this lane's best remaining record of the list (keys are unique and not 0)
+#pragma unroll
+          for (int q = 0; q < 4; q++) if ((uint32_t)(key[q] >> 63) == list && key[q] > mine) mine = key[q];
+          const unsigned long long bk = wave_max_u64(mine);
+          if (bk == 0) break;
+          const int owner = __ffsll((long long)__ballot(mine == bk)) - 1;
+          int b_start = 0, b_end = 0, b_edits = 0, b_q = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) if (key[q] == bk) { b_start = st[q]; b_end = en[q]; b_edits = ed[q]; b_q = q; key[q] = 0; }   // the owner takes it
+          b_start = __shfl(b_start, owner); b_end = __shfl(b_end, owner); b_edits = __shfl(b_edits, owner); b_q = __shfl(b_q, owner);
+          if (b_edits > max_total_diffs) continue;
+          bool clash = false;
+          for (uint32_t k = first_kept + lane; k < nk; k += 64) {
+            const int o = min(b_end, s_ke[k]) - max(b_start, s_ks[k]);   // GA:119-122
+            clash = clash || o > max_overlap;
+          }
+          if (__ballot(clash) == 0) {
+            if (lane == 0) { out_pos[s + nk] = s + (uint32_t)owner + 64u * (uint32_t)b_q; s_ks[nk] = b_start; s_ke[nk] = b_end; }
+            nk++;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // one wave: the LDS writes above before the next round's reads
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+        }
+      }
+      if (lane == 0) kept[s] = nk;
+      continue;
+    }
     for (uint32_t i = lane; i < (e - s + 31) / 32; i += 64) s_taken[i] = 0;
     __syncthreads();
     uint32_t nk = 0;
@@ -232,7 +307,7 @@ __global__ void gather_kernel(const RawAln* raw, const uint32_t* slot, const uin
     if (box) {
       box[1] = d + nk;
       box[2] = __hip_atomic_load(counts + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      box[3] = __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      box[3] = __hip_atomic_load(counts + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // windows beyond GROUP_MAX ("crowded")
       __threadfence_system();
       __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -271,7 +346,7 @@ struct SelectWork {
   bool cnt_dirty = false;      // a call was cut short between count_kernel and scatter_kernel: cnt must be cleared
   RawAln* final_out = nullptr; size_t final_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
-  uint32_t* counts = nullptr;   // [0] survivors, [1] flags, [2] windows left to filter_big_kernel
+  uint32_t* counts = nullptr;   // [0] survivors, [1] flags, [2] windows left to filter_wave_kernel, [3] those of them beyond GROUP_MAX
 };
 
 void select_destroy(SelectWork* w) {
@@ -298,10 +373,10 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   const size_t n = n_raw;
   const size_t nw = (size_t)windows_per_guide * (size_t)n_guides;
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-  if (!w.counts) { TRY(hipMalloc((void**)&w.counts, 3 * sizeof(uint32_t))); TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream)); }
+  if (!w.counts) { TRY(hipMalloc((void**)&w.counts, 4 * sizeof(uint32_t))); TRY(hipMemsetAsync(w.counts, 0, 4 * sizeof(uint32_t), stream)); }
   *d_final = nullptr; *d_counts = w.counts;
   if (n == 0) {
-    TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), stream));
+    TRY(hipMemsetAsync(w.counts, 0, 4 * sizeof(uint32_t), stream));
     if (post) TRY(mailbox_post(*post, w.counts, 3, stream));
     return hipSuccess;
   }
@@ -310,7 +385,7 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   if (w.cnt_dirty && w.cnt_cap == cnt_cap_before) TRY(hipMemsetAsync(w.cnt, 0, w.cnt_cap * sizeof(uint32_t), stream));
   TRY(grow(&w.offs, w.offs_cap, nw + 1)); TRY(grow(&w.kept, w.kept_cap, n)); TRY(grow(&w.koffs, w.koffs_cap, n));
   TRY(grow(&w.der, w.der_cap, n)); TRY(grow(&w.ders, w.ders_cap, n)); TRY(grow(&w.slot, w.slot_cap, n)); TRY(grow(&w.out_idx, w.out_idx_cap, n));
-  TRY(grow(&w.taken, w.taken_cap, n)); TRY(grow(&w.big, w.big_cap, n / GROUP_MAX + 1)); TRY(grow(&w.final_out, w.final_cap, n));
+  TRY(grow(&w.taken, w.taken_cap, n)); TRY(grow(&w.big, w.big_cap, n / (LANE_MAX + 1) + 1)); TRY(grow(&w.final_out, w.final_cap, n));
   size_t t1 = 0, t2 = 0;
   TRY(rocprim::exclusive_scan(nullptr, t1, w.cnt, w.offs, 0u, nw + 1, rocprim::plus<uint32_t>(), stream));
   TRY(rocprim::exclusive_scan(nullptr, t2, w.kept, w.koffs, 0u, n, rocprim::plus<uint32_t>(), stream));
@@ -325,7 +400,7 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   hipLaunchKernelGGL(scatter_kernel, grid_n, block, 0, stream, (const Derived*)w.der, n_raw, (const uint32_t*)w.offs, w.cnt, w.slot, w.ders, w.taken, w.counts);
   hipLaunchKernelGGL(filter_kernel, grid_n, block, 0, stream, (const Derived*)w.ders, (const uint32_t*)w.offs, n_raw, max_total_diffs,
                      max_overlap, w.taken, w.kept, w.out_idx, w.counts, w.big);
-  hipLaunchKernelGGL(filter_big_kernel, dim3((unsigned)std::min<size_t>(n / GROUP_MAX + 1, 2048)), dim3(64), 0, stream, (const Derived*)w.ders,
+  hipLaunchKernelGGL(filter_wave_kernel, dim3((unsigned)std::min<size_t>(n / (LANE_MAX + 1) + 1, 8192)), dim3(64), 0, stream, (const Derived*)w.ders,
                      (const uint32_t*)w.offs, max_total_diffs, max_overlap, w.kept, w.out_idx, w.counts, (const uint32_t*)w.big);
   ts = w.temp_cap;
   TRY(rocprim::exclusive_scan(w.temp, ts, w.kept, w.koffs, 0u, n, rocprim::plus<uint32_t>(), stream));
