@@ -424,6 +424,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
                             p.max_overlap, ctx->stream, &d_final, &d_cnt, &ctx->mbox));   // its last kernel posts the three counts
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (g_marks.on) { char b[48]; std::snprintf(b, sizeof b, " (first-launch +%.0f)", g_select_prelaunch_us); g_marks.line += b; }
     g_marks.mark("queued-filter");
     HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
     g_marks.mark("counts2");
@@ -1168,8 +1169,10 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     }
     if (weights.size() == 1) { int k = std::max(1, std::min(16, (int)weights[0])); weights.assign((size_t)k, 1.0); }
     for (double w : weights) if (!(w > 0)) { weights.clear(); break; }
-  } else if (ref.total_bases >= (512ull << 20)) {
+  } else if (ref.total_bases >= (2048ull << 20)) {
     weights = {5, 3, 2};   // measured on hg38-sized input: the last range small, its tail is what nothing hides
+  } else if (ref.total_bases >= (512ull << 20)) {
+    weights = {3, 2};      // a half or a quarter of it (a rank's share on 2 or 4 GPUs): 1.49 / 0.90 ms against 1.53 / 1.02 with three ranges
   }
   std::vector<std::pair<int, int>> ranges;
   if (weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);

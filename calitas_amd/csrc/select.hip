@@ -17,6 +17,7 @@
 // does a flag send the caller to the host implementation of the same stage for this search.  (A first version radix-sorted 64-bit keys: eight more launches per call,
 // which is what a lane's tail is made of -- DESIGN.md 4.5.)
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -362,11 +363,14 @@ bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides)
          windows_per_guide > 0 && windows_per_guide * (uint64_t)n_guides < (1ull << 31) && n_guides <= 64;
 }
 
+thread_local double g_select_prelaunch_us = 0;
+
 void select_done(SelectWork* w) { if (w) w->cnt_dirty = false; }
 
 hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
                       hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post) {
+  const auto t_enter = std::chrono::steady_clock::now();
   if (!*pw) *pw = new SelectWork();
   SelectWork& w = **pw;
   hipError_t e;
@@ -393,6 +397,7 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   if (t1 > w.temp_cap) { (void)hipFree(w.temp); w.temp = nullptr; w.temp_cap = 0; TRY(hipMalloc(&w.temp, t1)); w.temp_cap = t1; }
   const dim3 block(256), grid_n((unsigned)((n + 255) / 256));
   w.cnt_dirty = true;
+  g_select_prelaunch_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
   hipLaunchKernelGGL(count_kernel, grid_n, block, 0, stream, d_raw, n_raw, d_guides, d_win_base, d_win, (uint32_t)window_lo, (uint32_t)windows_per_guide, w.der,
                      w.cnt, w.counts);
   size_t ts = w.temp_cap;

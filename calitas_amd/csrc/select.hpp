@@ -27,6 +27,7 @@ hipError_t select_run(SelectWork** work, const RawAln* d_raw, uint32_t n_raw, co
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
                       hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post = nullptr);
 void select_done(SelectWork* work);
+extern thread_local double g_select_prelaunch_us;   // host time of the last select_run before its first launch (CALITAS_TRACE=2)
 void select_destroy(SelectWork* work);
 
 }  // namespace calitas

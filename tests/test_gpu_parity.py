@@ -138,6 +138,7 @@ CONFIGS = [
     ("per-matrix-5prime", "tttvAACCAACCAACCGGTTACGT", (), dict(d=4, p=1, g=2, O=60, switches=1)),
     ("short-guide-12", "GCAGTAACCTGAnrg", (), dict(d=2, p=1, g=1)),
     ("long-guide-32", "CTTGCCCCACAGGGCAGTAACGGTTCAATGCA", (), dict(d=6)),               # the scan's 32 rows, PAM-less
+    ("long-guide-31-pam", "CTTGCCCCACAGGGCAGTAACGGTTCAATGCngg", (), dict(d=5, p=1, g=2)),   # 31 rows: lane 31 of a half wave is no row (align_kernel)
     ("long-pam-8", "CTTGCCCCACAGGGCAGTAAnnagaawn", (), dict(d=4, p=2, g=2)),
     ("three-strands-of-limits", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=6, p=3, g=4, D=7, O=1)),
 ]
