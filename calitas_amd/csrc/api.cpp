@@ -189,6 +189,7 @@ void calitas_destroy(calitas_ctx* c) {
     calitas_destroy_lanes(c);
     select_destroy(c->select);
     hits_destroy(c->hits);
+    hits_destroy(c->hits_alt);
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);
     if (c->rows_ready) (void)hipEventDestroy(c->rows_ready);
     if (c->h_counters) (void)hipHostFree(c->h_counters);

@@ -58,6 +58,8 @@ struct calitas_ctx {
   SelectWork* select = nullptr;     // GPU per-window filter scratch
   HitsWork* hits = nullptr;         // GPU removeOverlaps / sort / rows scratch
   uint64_t ref_serial = 0, hits_names_serial = ~0ull;
+  HitsWork* hits_alt = nullptr;     // second row-stage scratch of the per-contig passes: contig c+1's rows are built while contig c's text is copied
+  uint64_t hits_alt_names_serial = ~0ull;
   // chunked calitas_search_hits: the parent owns the lanes and the stream all scans are queued on
   calitas_ctx* parent = nullptr;    // set in a lane: the context whose reference and window table it uses
   std::vector<calitas_ctx*> lanes;

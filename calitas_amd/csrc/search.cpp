@@ -646,7 +646,8 @@ void calitas_default_version_and_stamp(const char* aligner_version, const char* 
 // The finished text of a lane, device -> page-locked host.  Preferred: an SDMA engine through the HSA runtime (dma.hpp), after
 // waiting for the lane's row kernels -- the CUs stay with the search kernels.  Otherwise the runtime's copy (a blit kernel) on the
 // owner's low-priority copy stream (chunked / batch calls: one stream for all lanes) or on the lane's own stream.
-static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const char* src, size_t n, std::mutex* copy_mu, double* ms_out) {
+static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const char* src, size_t n, std::mutex* copy_mu, double* ms_out,
+                        hipEvent_t rows_done = nullptr) {
   if (!owner->dma_tried) {
     std::lock_guard<std::mutex> lk(owner->host_mu);
     if (!owner->dma_tried) {
@@ -656,7 +657,8 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
     }
   }
   if (owner->dma.usable()) {
-    HIP_TRY(lane, calitas_spin_sync(lane->stream));
+    // (rows_done: the caller recorded it behind the row kernels and other work may already be queued behind it on the stream)
+    if (rows_done) HIP_TRY(lane, calitas_spin_sync(rows_done)); else HIP_TRY(lane, calitas_spin_sync(lane->stream));
     g_marks.mark("rows-done");
     const auto t0 = std::chrono::steady_clock::now();
     if (owner->dma.copy_to_host(dst, src, n)) {
@@ -881,6 +883,7 @@ static void release_scratch(calitas_ctx* ctx) {
   if (ctx->h_raw) { (void)hipHostFree(ctx->h_raw); ctx->h_raw = nullptr; ctx->h_raw_cap = 0; }
   select_destroy(ctx->select); ctx->select = nullptr;
   hits_destroy(ctx->hits); ctx->hits = nullptr; ctx->hits_names_serial = ~0ull;
+  hits_destroy(ctx->hits_alt); ctx->hits_alt = nullptr; ctx->hits_alt_names_serial = ~0ull;
 }
 
 // calitas_search_hits when one pass does not fit the device (a PAM-less search at max-guide-diffs 8 on a whole genome keeps 2.4 KB of
@@ -917,68 +920,140 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   uint64_t rows = 0;
   std::mutex copy_mu;
   const int n_contigs = (int)ref.contigs.size();
-  uint64_t win_lo = 0, bases_done = 0;
+  uint64_t bases_done = 0;
   uint32_t n_passes = 0;
   double ms_rows = 0;              // inside lane_rows: kernels, their host round trips and every (re)allocation of scratch
-  for (int c = 0; c < n_contigs; c++) {
-    const uint64_t win_n = window_count(ref.contigs[c].len, pl.step);
-    if (pl.p.chrom_index < 0 || pl.p.chrom_index == c) {
-      n_passes++;
-      SearchPlan q = pl;
-      q.tile_lo = (uint32_t)(ref.contigs[c].gbase / ref.tile);
-      const uint32_t tile_hi = c + 1 < n_contigs ? (uint32_t)(ref.contigs[c + 1].gbase / ref.tile) : (uint32_t)ref.tiles.size();
-      q.n_tiles = tile_hi - q.tile_lo;
-      q.bases = ref.contigs[c].len; q.win_lo = win_lo; q.win_n = win_n;
-      // buffers sized from the estimate that sent this search here: no retry round per contig
-      if (ctx->seq_recs_per_tile > 0 && ctx->seq_pams == pl.gd[0].n_pams && ctx->seq_L == pl.gd[0].L && pl.gd[0].min_guide_score == ctx->seq_min_score)
-        q.rec_hint = (uint64_t)(ctx->seq_recs_per_tile * (double)q.n_tiles) + 1;
-      LaneText lt;
-      const auto t_rows = std::chrono::steady_clock::now();
-      rc = lane_rows(ctx, q, false, rs, guide_id, version, stamp, lt);
-      if (rc) { drop(); return rc; }
-      ms_rows += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count();
-      bases_done += ref.contigs[c].len;
-      if (lt.bytes) {
-        // room for this contig, and -- extrapolating from the bases done so far -- for the rest
-        const double per_base = (double)(total - hlen + lt.bytes) / (double)std::max<uint64_t>(1, bases_done);
-        const size_t guess = pl.p.chrom_index >= 0 ? 0 : (size_t)(per_base * 1.05 * (double)(ref.total_bases - bases_done));
-        if (!sink) {
-          char* grown = (char*)calitas_out_grow(text, total, total + (size_t)lt.bytes + 1 + guess);
-          if (!grown) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
-          text = grown;
-        }
-        if (lt.on_host) {
-          if (!sink) std::memcpy(text + total, lt.host_rows.data(), (size_t)lt.bytes);
-          else if (sink(lt.host_rows.data(), lt.bytes, sink_user) != 0) { drop(); return fail(ctx, CALITAS_EIO, "the text sink reported an error"); }
-        } else {
-          const size_t kPiece = 1ull << 30;             // bounce buffer: at most 1 GB page-locked
-          for (size_t off = 0; off < (size_t)lt.bytes; off += kPiece) {
-            const size_t n = std::min(kPiece, (size_t)lt.bytes - off);
-            if (n > bounce_cap) { calitas_free(bounce); bounce = (char*)calitas_out_alloc_pinned(n); bounce_cap = bounce ? n : 0; }
-            if (!bounce) { drop(); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
-            double ms = 0;
-            rc = text_to_host(ctx, ctx, bounce, lt.d_text + off, n, &copy_mu, &ms);
-            if (rc) { drop(); return rc; }
-            lt.tm.hits_copy_ms += ms;
-            if (sink) {
-              if (sink(bounce, n, sink_user) != 0) { drop(); return fail(ctx, CALITAS_EIO, "the text sink reported an error"); }
-              continue;
-            }
-            char* dst = text + total + off;
-            const char* src = bounce;
-            ctx->pool->for_blocks(n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
-          }
-        }
-        total += (size_t)lt.bytes;
+  // The passes: one plan per selected contig.
+  std::vector<SearchPlan> passes;
+  std::vector<int> pass_contig;
+  {
+    uint64_t win_lo = 0;
+    for (int c = 0; c < n_contigs; c++) {
+      const uint64_t win_n = window_count(ref.contigs[c].len, pl.step);
+      if (pl.p.chrom_index < 0 || pl.p.chrom_index == c) {
+        SearchPlan q = pl;
+        q.tile_lo = (uint32_t)(ref.contigs[c].gbase / ref.tile);
+        const uint32_t tile_hi = c + 1 < n_contigs ? (uint32_t)(ref.contigs[c + 1].gbase / ref.tile) : (uint32_t)ref.tiles.size();
+        q.n_tiles = tile_hi - q.tile_lo;
+        q.bases = ref.contigs[c].len; q.win_lo = win_lo; q.win_n = win_n;
+        // buffers sized from the estimate that sent this search here: no retry round per contig
+        if (ctx->seq_recs_per_tile > 0 && ctx->seq_pams == pl.gd[0].n_pams && ctx->seq_L == pl.gd[0].L && pl.gd[0].min_guide_score == ctx->seq_min_score)
+          q.rec_hint = (uint64_t)(ctx->seq_recs_per_tile * (double)q.n_tiles) + 1;
+        passes.push_back(q); pass_contig.push_back(c);
       }
-      rows += lt.rows;
-      tm.scan_kernel_ms += lt.tm.scan_kernel_ms; tm.align_kernel_ms += lt.tm.align_kernel_ms; tm.gpu_total_ms += lt.tm.gpu_total_ms;
-      tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
-      tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
-      tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+      win_lo += win_n;
     }
-    win_lo += win_n;
   }
+  n_passes = (uint32_t)passes.size();
+  // Two row-stage scratch sets (ctx->hits / hits_alt) take turns: a helper thread runs the device stages of pass i+1 while this thread
+  // copies the text of pass i over PCIe and hands it on -- the copy is 1.5 of the 2.7 s of a PAM-less d = 8 search on an hg38-sized
+  // genome, the device stages 1.0.  The sink is only ever called from this (the caller's) thread.
+  struct Slot { LaneText lt; int rc = CALITAS_OK; double ms = 0; hipEvent_t rows_done = nullptr; int state = 0; };   // 0 free, 1 rows queued
+  Slot slots[2];
+  for (auto& sl : slots)
+    if (hipEventCreateWithFlags(&sl.rows_done, hipEventDisableTiming) != hipSuccess) {
+      for (auto& s2 : slots) if (s2.rows_done) (void)hipEventDestroy(s2.rows_done);
+      drop();
+      return fail(ctx, CALITAS_EHIP, "hipEventCreateWithFlags failed");
+    }
+  std::mutex mu;
+  std::condition_variable cv;
+  bool abort_passes = false;
+  std::thread producer([&] {
+    (void)hipSetDevice(ctx->device);
+    HitsWork* work[2] = {ctx->hits, ctx->hits_alt};
+    uint64_t serial[2] = {ctx->hits_names_serial, ctx->hits_alt_names_serial};
+    for (size_t i = 0; i < passes.size(); i++) {
+      Slot& sl = slots[i & 1];
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return sl.state == 0 || abort_passes; });
+        if (abort_passes) break;
+      }
+      ctx->hits = work[i & 1]; ctx->hits_names_serial = serial[i & 1];
+      sl.lt = LaneText();
+      const auto t_rows = std::chrono::steady_clock::now();
+      sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt);
+      if (sl.rc == CALITAS_OK && hipEventRecord(sl.rows_done, ctx->stream) != hipSuccess) sl.rc = fail(ctx, CALITAS_EHIP, "hipEventRecord failed");
+      sl.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count();
+      work[i & 1] = ctx->hits; serial[i & 1] = ctx->hits_names_serial;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        sl.state = 1;
+      }
+      cv.notify_all();
+      if (sl.rc) break;
+    }
+    ctx->hits = work[0]; ctx->hits_names_serial = serial[0];
+    ctx->hits_alt = work[1]; ctx->hits_alt_names_serial = serial[1];
+  });
+  auto stop_producer = [&] {
+    { std::lock_guard<std::mutex> lk(mu); abort_passes = true; }
+    cv.notify_all();
+    producer.join();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& sl : slots) (void)hipEventDestroy(sl.rows_done);
+  };
+  rc = CALITAS_OK;
+  for (size_t i = 0; i < passes.size() && !rc; i++) {
+    Slot& sl = slots[i & 1];
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return sl.state == 1; });
+    }
+    if (sl.rc) { rc = sl.rc; break; }
+    LaneText& lt = sl.lt;
+    const int c = pass_contig[i];
+    ms_rows += sl.ms;
+    bases_done += ref.contigs[c].len;
+    if (lt.bytes) {
+      // room for this contig, and -- extrapolating from the bases done so far -- for the rest
+      const double per_base = (double)(total - hlen + lt.bytes) / (double)std::max<uint64_t>(1, bases_done);
+      const size_t guess = pl.p.chrom_index >= 0 ? 0 : (size_t)(per_base * 1.05 * (double)(ref.total_bases - bases_done));
+      if (!sink) {
+        char* grown = (char*)calitas_out_grow(text, total, total + (size_t)lt.bytes + 1 + guess);
+        if (!grown) { rc = fail(ctx, CALITAS_EINVAL, "out of memory"); break; }
+        text = grown;
+      }
+      if (lt.on_host) {
+        if (!sink) std::memcpy(text + total, lt.host_rows.data(), (size_t)lt.bytes);
+        else if (sink(lt.host_rows.data(), lt.bytes, sink_user) != 0) { rc = fail(ctx, CALITAS_EIO, "the text sink reported an error"); break; }
+      } else {
+        const size_t kPiece = 1ull << 30;             // bounce buffer: at most 1 GB page-locked
+        for (size_t off = 0; off < (size_t)lt.bytes && !rc; off += kPiece) {
+          const size_t n = std::min(kPiece, (size_t)lt.bytes - off);
+          if (n > bounce_cap) { calitas_free(bounce); bounce = (char*)calitas_out_alloc_pinned(n); bounce_cap = bounce ? n : 0; }
+          if (!bounce) { rc = fail(ctx, CALITAS_EINVAL, "out of memory"); break; }
+          double ms = 0;
+          rc = text_to_host(ctx, ctx, bounce, lt.d_text + off, n, &copy_mu, &ms, sl.rows_done);
+          if (rc) break;
+          lt.tm.hits_copy_ms += ms;
+          if (sink) {
+            if (sink(bounce, n, sink_user) != 0) rc = fail(ctx, CALITAS_EIO, "the text sink reported an error");
+            continue;
+          }
+          char* dst = text + total + off;
+          const char* src = bounce;
+          std::lock_guard<std::mutex> host_lock(ctx->host_mu);      // the helper thread's host stages (if any) use the same pool
+          ctx->pool->for_blocks(n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
+        }
+        if (rc) break;
+      }
+      total += (size_t)lt.bytes;
+    }
+    rows += lt.rows;
+    tm.scan_kernel_ms += lt.tm.scan_kernel_ms; tm.align_kernel_ms += lt.tm.align_kernel_ms; tm.gpu_total_ms += lt.tm.gpu_total_ms;
+    tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
+    tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
+    tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      sl.state = 0;
+    }
+    cv.notify_all();
+  }
+  stop_producer();
+  if (rc) { drop(); return rc; }
   calitas_free(bounce);
   if (!sink) {
     char* grown = (char*)calitas_out_grow(text, total, total + 1);
