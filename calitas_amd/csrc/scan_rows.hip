@@ -93,47 +93,157 @@ __device__ __noinline__ void resolve_suspect(const RecordSink sink, uint32_t w32
   if (hm >> 16) stage_scan_record(sink, gword + 1u, (hm >> 16) | tag);
 }
 
-// One row of the recurrence over a chain of NC words (word 0 = lowest text position in chain order).
-//   x  = eq & pv;  t = x + pv (carry runs along the chain)
-//   xh = (t ^ pv) | eq;  mh = pv & xh;  ph = mv | ~(xh | pv);  xv = eq | mv
-//   ph, mh shift up one position (a 1 enters ph at the chain's low end: the DP column left of the chain is 0, 1, .., L)
-//   pv = mh | ~(xv | ph);  mv = ph & xv
-// One row of the recurrence over a chain of NC words (word 0 = lowest text position in chain order), in two parts.
-// Part 1 needs the row's Eq vector (the bit-plane of its base) and is instantiated per base, reading the plane where it lies:
-//   x = eq & pv;   xv = eq | mv
-// Part 2 is common to all rows.  Where mv = 1 (so pv = 0) the textbook's xh = (t ^ pv) | eq is irrelevant to both of its uses
-// (ph = mv | ~(xh | pv) is 1 there, mh = pv & xh is 0), and where mv = 0, eq = xv; so Eq itself is not needed again:
+// One row of the recurrence over a chain of NC words (word 0 = lowest text position in chain order):
+//   x  = eq & pv;   xv = eq | mv
 //   t  = x + pv                         (the carry chain runs along the text: v_addc_co_u32)
 //   mh = pv & ((t ^ pv) | xv);   ph = mv | (~pv & ~t & ~xv)
 //   ph, mh move up one position (a 1 enters ph at the chain's low end: the DP column left of the chain is 0, 1, .., L)
 //   pv = mh | ~(xv | ph);   mv = ph & xv
-// (Inline assembly with the plane's number as an immediate operand: written as plain C++ the four instantiations are identical
-// up to their source registers, and the compiler sinks them into one copy behind the switch -- fed by 17 v_mov per row.)
-template <int NC, int PLANE>
-__device__ __forceinline__ void myers_row_part1(const uint32_t (&plane)[NC], const uint32_t (&pv)[NC], const uint32_t (&mv)[NC],
-                                                uint32_t (&x)[NC], uint32_t (&xv)[NC]) {
+// (Where mv = 1 (so pv = 0) the textbook's xh = (t ^ pv) | eq is irrelevant to both of its uses -- ph = mv | ~(xh | pv) is 1 there,
+// mh = pv & xh is 0 -- and where mv = 0, eq = xv; so Eq itself is not needed after the first line.)
+//
+// Eq comes straight from the two bit-planes of the text (lo, hi: bit j = low / high bit of base j): eq = [~]hi & [~]lo folds into the
+// two instructions that use it -- x and xv are three-input functions of (lo, hi, pv) and (lo, hi, mv), one v_bitop3_b32 each with
+// the row's base in the truth table.  (Round 2's first version kept four precomputed planes per word and the x / xv arrays of a row
+// in registers: 166 VGPRs, three waves per SIMD.)  The truth table's bit (s0 << 2 | s1 << 1 | s2) is the result; s0 = lo, s1 = hi.
+// Written as inline assembly for two reasons: as C++ the compiler hoists eq out of the row loop (four planes per word in registers
+// again), and without the unused operand `after` -- the sum of the word before -- it computes the x / xv of all NC words ahead of
+// the carry chain and keeps them live.
+template <int BASE> constexpr int eq_table() { return BASE == 0 ? 0x03 : BASE == 1 ? 0x30 : BASE == 2 ? 0x0C : 0xC0; }   // A C G T
+
+// the rest of a word's row once x and xv exist
+#define CALITAS_MYERS_WORD_TAIL(w)                                          \
+  uint32_t cout;                                                            \
+  const uint32_t t = __builtin_addc(x, pv[w], carry, &cout);                \
+  carry = cout; after = t;                                                  \
+  const uint32_t mh = pv[w] & ((t ^ pv[w]) | xv);                           \
+  const uint32_t ph = mv[w] | (~pv[w] & ~t & ~xv);                          \
+  const uint32_t phs = __builtin_amdgcn_alignbit(ph, php, 31);              \
+  const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mhp, 31);              \
+  php = ph; mhp = mh;                                                       \
+  pv[w] = mhs | ~(xv | phs);                                                \
+  mv[w] = phs & xv;
+
+// A row whose protospacer base is one of A C G T.  MASKED: the tile has exception bases (exc: N, padding, IUPAC codes in the text):
+// code 0 never matches, code 1 ("wild": ~hi & lo as stored, hi & ~lo after the reverse strand's complement) matches every row and
+// the aligner decides exactly -- still one three-input function of (lo, hi, exc).
+template <int NC, int BASE, bool MASKED, int DIR>
+__device__ __forceinline__ void myers_row_base(const uint32_t (&lo)[NC], const uint32_t (&hi)[NC], const uint32_t (&exc)[MASKED ? NC : 1],
+                                               uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
+  constexpr int EQ = eq_table<BASE>();
+  constexpr int TT_X = EQ & 0xAA, TT_XV = EQ | 0xAA;                       // eq & pv, eq | mv            (s2 = pv / mv)
+  constexpr int TT_EM = (EQ & 0x55) | (DIR ? 0x08 : 0x20);                 // (eq & ~exc) | (exc & wild)  (s2 = exc)
+  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u, after = 0u;
 #pragma unroll
   for (int w = 0; w < NC; w++) {
-    asm("v_and_b32 %0, %2, %3 ; plane %5\n\tv_or_b32 %1, %2, %4"
-        : "=&v"(x[w]), "=v"(xv[w]) : "v"(plane[w]), "v"(pv[w]), "v"(mv[w]), "n"(PLANE));
+    uint32_t x, xv;
+    if (MASKED) {
+      uint32_t em;
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(em) : "v"(lo[w]), "v"(hi[w]), "v"(exc[w]), "n"(TT_EM), "v"(after));
+      x = em & pv[w]; xv = em | mv[w];
+    } else {
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(x) : "v"(lo[w]), "v"(hi[w]), "v"(pv[w]), "n"(TT_X), "v"(after));
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(xv) : "v"(lo[w]), "v"(hi[w]), "v"(mv[w]), "n"(TT_XV), "v"(after));
+    }
+    CALITAS_MYERS_WORD_TAIL(w)
   }
 }
 
-template <int NC>
-__device__ __forceinline__ void myers_row_part2(const uint32_t (&x)[NC], const uint32_t (&xv)[NC], uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
-  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u;
+// A row whose protospacer base is an IUPAC letter: union of the bases in its set (A=1 C=2 G=4 T=8).
+template <int NC, bool MASKED, int DIR>
+__device__ __forceinline__ void myers_row_set(const uint32_t (&lo)[NC], const uint32_t (&hi)[NC], const uint32_t (&exc)[MASKED ? NC : 1],
+                                              const uint32_t set, uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
+  // all-ones / all-zeros per base of the set, in vector registers (an instruction takes one scalar operand at most)
+  uint32_t ka = 0u - (set & 1u), kc = 0u - ((set >> 1) & 1u), kg = 0u - ((set >> 2) & 1u), kt = 0u - ((set >> 3) & 1u);
+  asm("" : "+v"(ka), "+v"(kc), "+v"(kg), "+v"(kt));
+  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u, after = 0u;
 #pragma unroll
   for (int w = 0; w < NC; w++) {
-    uint32_t cout;
-    const uint32_t t = __builtin_addc(x[w], pv[w], carry, &cout);
-    carry = cout;
-    const uint32_t mh = pv[w] & ((t ^ pv[w]) | xv[w]);
-    const uint32_t ph = mv[w] | (~pv[w] & ~t & ~xv[w]);
-    const uint32_t phs = __builtin_amdgcn_alignbit(ph, php, 31);
-    const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mhp, 31);
-    php = ph; mhp = mh;
-    pv[w] = mhs | ~(xv[w] | phs);
-    mv[w] = phs & xv[w];
+    // eq = hi ? (lo ? kt : kg) : (lo ? kc : ka): three selections (truth table 0xCA = s0 ? s1 : s2).  Inline assembly with the
+    // `after` operand like the rows above: (~hi & ~lo & ka) | ... in C++ leaves ~lo, ~hi and the exception term of every word in
+    // registers across the rows.
+    uint32_t hi1, hi0, eq;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca ; after %4" : "=v"(hi1) : "v"(lo[w]), "v"(kt), "v"(kg), "v"(after));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca ; after %4" : "=v"(hi0) : "v"(lo[w]), "v"(kc), "v"(ka), "v"(after));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(eq) : "v"(hi[w]), "v"(hi1), "v"(hi0));
+    if (MASKED) {
+      uint32_t wt;                                        // exc & wild
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(wt) : "v"(lo[w]), "v"(hi[w]), "v"(exc[w]), "n"(DIR ? 0x08 : 0x20), "v"(after));
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xba" : "=v"(eq) : "v"(eq), "v"(exc[w]), "v"(wt));   // (eq & ~exc) | wt
+    }
+    const uint32_t x = eq & pv[w], xv = eq | mv[w];
+    CALITAS_MYERS_WORD_TAIL(w)
+  }
+}
+#undef CALITAS_MYERS_WORD_TAIL
+
+// One strand of one wave's share of a tile (DIR 0: the text as it is, left to right; DIR 1: its reverse complement).
+template <int NW, int NWARM, bool MASKED, int DIR>
+__device__ __forceinline__ void scan_wave_strand(const ScanArgs& a, int wave, int wl, uint32_t w32_base, const uint2* s_pl, SuspectWord* s_q,
+                                                 uint32_t* s_qn, const RecordSink sink) {
+  constexpr int NC = NW + NWARM;            // words of a lane's chain
+  constexpr int CSTR = NW + 1;              // uint2 per staged chunk (padded: lane l reads 8-byte word l * CSTR + k, conflict-free)
+  const int tid = wave * 64 + wl;           // lane of the tile
+  const GuideConst* guides = (const GuideConst*)(a.guides);   // constant address space: scalar loads
+  // ---- the two bit-planes of this lane's chain (and its exception bases) ----
+  uint32_t lo[NC], hi[NC], exc[MASKED ? NC : 1];
+#pragma unroll
+  for (int v = 0; v < NC; v++) {
+    // text word behind chain word v: DIR 0 reads left to right (warm-up = tail of the left neighbour's chunk),
+    // DIR 1 right to left (warm-up = head of the right neighbour's chunk)
+    int chunk, k;
+    if (DIR == 0) { chunk = (v < NWARM) ? wl : wl + 1; k = (v < NWARM) ? NW - NWARM + v : v - NWARM; }
+    else          { chunk = (v < NWARM) ? wl + 2 : wl + 1; k = (v < NWARM) ? NWARM - 1 - v : NW - 1 - (v - NWARM); }
+    const uint2 x = s_pl[chunk * CSTR + k];
+    lo[v] = x.x; hi[v] = x.y;
+    if (MASKED) exc[v] = a.mask[(int64_t)w32_base + (int64_t)((wave * 64 + chunk - 1) * NW + k)];
+    if (DIR) {                                // reverse strand: complemented text, read right to left
+      lo[v] = ~__builtin_bitreverse32(lo[v]); hi[v] = ~__builtin_bitreverse32(hi[v]);
+      if (MASKED) exc[v] = __builtin_bitreverse32(exc[v]);
+    }
+  }
+
+  for (int gi = 0; gi < a.n_guides; gi++) {
+    const int L = guides[gi].L, E = guides[gi].scan_max_edits;
+    const uint64_t rows_lo = guides[gi].row_sets[0], rows_hi = guides[gi].row_sets[1];   // 4-bit base set per protospacer row
+    uint32_t pv[NC], mv[NC];
+#pragma unroll
+    for (int v = 0; v < NC; v++) { pv[v] = 0u; mv[v] = 0u; }          // row 0 of the DP is all zeros (free start in the text)
+    for (int i = 0; i < L; i++) {
+      const uint32_t set = (uint32_t)(((i < 16 ? rows_lo : rows_hi) >> ((i & 15) * 4)) & 15u);
+      switch (set) {
+        case 1: myers_row_base<NC, 0, MASKED, DIR>(lo, hi, exc, pv, mv); break;
+        case 2: myers_row_base<NC, 1, MASKED, DIR>(lo, hi, exc, pv, mv); break;
+        case 4: myers_row_base<NC, 2, MASKED, DIR>(lo, hi, exc, pv, mv); break;
+        case 8: myers_row_base<NC, 3, MASKED, DIR>(lo, hi, exc, pv, mv); break;
+        default: myers_row_set<NC, MASKED, DIR>(lo, hi, exc, set, pv, mv);
+      }
+    }
+    // ---- bottom row: value before chain word 0 is L; hunt for values <= E ----
+    int s = L - (E + 1);
+#pragma unroll
+    for (int v = 0; v < NWARM; v++) s += __builtin_popcount(pv[v]) - __builtin_popcount(mv[v]);
+#pragma unroll
+    for (int v = NWARM; v < NC; v++) {
+      const uint32_t P = pv[v], M = mv[v];
+      const int u1 = __builtin_popcount(P & 0xFFu) + s, u2 = __builtin_popcount(P & 0xFFFFu) + s, u3 = __builtin_popcount(P & 0xFFFFFFu) + s;
+      const int d1 = __builtin_popcount(M & 0xFFu), d2 = __builtin_popcount(M & 0xFFFFu), d3 = __builtin_popcount(M & 0xFFFFFFu);
+      const int d4 = __builtin_popcount(M);
+      // lower bound of the running value inside each byte: its value at the byte's start minus the -1 steps in the byte
+      const int lb = min(min(s - d1, u1 - d2), min(u2 - d3, u3 - d4));
+      if (lb < 0) {
+        SuspectWord q;
+        q.p = P; q.m = M; q.s = s;
+        const int k = v - NWARM;
+        int lane_of_tile = tid;
+        asm volatile("" : "+v"(lane_of_tile));          // computed here, not once per word ahead of the loops (16 registers)
+        q.id = (uint32_t)(lane_of_tile * NW + (DIR ? NW - 1 - k : k)) | ((uint32_t)DIR << 16) | ((uint32_t)gi << 17);
+        const uint32_t slot = atomicAdd(s_qn, 1u);     // LDS atomic
+        if (slot < (uint32_t)ROWS_QCAP) s_q[slot] = q;
+        else resolve_suspect(sink, w32_base, q);        // queue full (dense repeats): resolve in place
+      }
+      s += __builtin_popcount(P) - d4;
+    }
   }
 }
 
@@ -142,88 +252,9 @@ __device__ __forceinline__ void myers_row_part2(const uint32_t (&x)[NC], const u
 template <int NW, int NWARM, bool MASKED>
 __device__ __forceinline__ void scan_wave_rows(const ScanArgs& a, uint32_t tile, int wave, int wl, const uint2* s_pl, SuspectWord* s_q,
                                                uint32_t* s_qn, const RecordSink sink) {
-  constexpr int NC = NW + NWARM;            // words of a lane's chain
-  constexpr int CSTR = NW + 1;              // uint2 per staged chunk (padded: lane l reads 8-byte word l * CSTR + k, conflict-free)
-  const int tid = wave * 64 + wl;           // lane of the tile
   const uint32_t w32_base = tile * (uint32_t)(LANES_PER_TILE * NW);   // first 32-base word of the tile
-  const GuideConst* guides = (const GuideConst*)(a.guides);   // constant address space: scalar loads
-
-  for (int dir = 0; dir < 2; dir++) {
-    // ---- bit-planes of this lane's chain for this strand ----
-    uint32_t pl[4][NC];
-#pragma unroll
-    for (int v = 0; v < NC; v++) {
-      // text word behind chain word v: dir 0 reads left to right (warm-up = tail of the left neighbour's chunk),
-      // dir 1 right to left (warm-up = head of the right neighbour's chunk)
-      int chunk, k;
-      if (dir == 0) { chunk = (v < NWARM) ? wl : wl + 1; k = (v < NWARM) ? NW - NWARM + v : v - NWARM; }
-      else          { chunk = (v < NWARM) ? wl + 2 : wl + 1; k = (v < NWARM) ? NWARM - 1 - v : NW - 1 - (v - NWARM); }
-      const uint2 x = s_pl[chunk * CSTR + k];
-      uint32_t lo = x.x, hi = x.y, exc = 0u, wild = 0u;
-      if (MASKED) {
-        // exception bases (N, padding, IUPAC codes): code 0 never matches, code 1 matches every row (the aligner decides exactly)
-        exc = a.mask[(int64_t)w32_base + (int64_t)((wave * 64 + chunk - 1) * NW + k)];
-        wild = exc & ~hi & lo;
-      }
-      if (dir) {                              // reverse strand: complemented text, read right to left
-        lo = ~__builtin_bitreverse32(lo); hi = ~__builtin_bitreverse32(hi);
-        if (MASKED) { exc = __builtin_bitreverse32(exc); wild = __builtin_bitreverse32(wild); }
-      }
-      pl[0][v] = ~hi & ~lo; pl[1][v] = ~hi & lo; pl[2][v] = hi & ~lo; pl[3][v] = hi & lo;
-      if (MASKED) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) pl[c][v] = (pl[c][v] & ~exc) | wild;
-      }
-    }
-
-    for (int gi = 0; gi < a.n_guides; gi++) {
-      const int L = guides[gi].L, E = guides[gi].scan_max_edits;
-      const uint64_t rows_lo = guides[gi].row_sets[0], rows_hi = guides[gi].row_sets[1];   // 4-bit base set per protospacer row
-      uint32_t pv[NC], mv[NC];
-#pragma unroll
-      for (int v = 0; v < NC; v++) { pv[v] = 0u; mv[v] = 0u; }          // row 0 of the DP is all zeros (free start in the text)
-      for (int i = 0; i < L; i++) {
-        const uint32_t set = (uint32_t)(((i < 16 ? rows_lo : rows_hi) >> ((i & 15) * 4)) & 15u);
-        uint32_t x[NC], xv[NC];
-        switch (set) {
-          case 1: myers_row_part1<NC, 0>(pl[0], pv, mv, x, xv); break;
-          case 2: myers_row_part1<NC, 1>(pl[1], pv, mv, x, xv); break;
-          case 4: myers_row_part1<NC, 2>(pl[2], pv, mv, x, xv); break;
-          case 8: myers_row_part1<NC, 3>(pl[3], pv, mv, x, xv); break;
-          default: {   // an IUPAC letter in the protospacer: union of the planes in its set (A=1 C=2 G=4 T=8)
-            const uint32_t ka = 0u - (set & 1u), kc = 0u - ((set >> 1) & 1u), kg = 0u - ((set >> 2) & 1u), kt = 0u - ((set >> 3) & 1u);
-            uint32_t eqs[NC];
-            _Pragma("unroll") for (int w = 0; w < NC; w++) eqs[w] = (pl[0][w] & ka) | (pl[1][w] & kc) | (pl[2][w] & kg) | (pl[3][w] & kt);
-            myers_row_part1<NC, 4>(eqs, pv, mv, x, xv);
-          }
-        }
-        myers_row_part2<NC>(x, xv, pv, mv);
-      }
-      // ---- bottom row: value before chain word 0 is L; hunt for values <= E ----
-      int s = L - (E + 1);
-#pragma unroll
-      for (int v = 0; v < NWARM; v++) s += __builtin_popcount(pv[v]) - __builtin_popcount(mv[v]);
-#pragma unroll
-      for (int v = NWARM; v < NC; v++) {
-        const uint32_t P = pv[v], M = mv[v];
-        const int u1 = __builtin_popcount(P & 0xFFu) + s, u2 = __builtin_popcount(P & 0xFFFFu) + s, u3 = __builtin_popcount(P & 0xFFFFFFu) + s;
-        const int d1 = __builtin_popcount(M & 0xFFu), d2 = __builtin_popcount(M & 0xFFFFu), d3 = __builtin_popcount(M & 0xFFFFFFu);
-        const int d4 = __builtin_popcount(M);
-        // lower bound of the running value inside each byte: its value at the byte's start minus the -1 steps in the byte
-        const int lb = min(min(s - d1, u1 - d2), min(u2 - d3, u3 - d4));
-        if (lb < 0) {
-          SuspectWord q;
-          q.p = P; q.m = M; q.s = s;
-          const int k = v - NWARM;
-          q.id = (uint32_t)(tid * NW + (dir ? NW - 1 - k : k)) | ((uint32_t)dir << 16) | ((uint32_t)gi << 17);
-          const uint32_t slot = atomicAdd(s_qn, 1u);     // LDS atomic
-          if (slot < (uint32_t)ROWS_QCAP) s_q[slot] = q;
-          else resolve_suspect(sink, w32_base, q);        // queue full (dense repeats): resolve in place
-        }
-        s += __builtin_popcount(P) - d4;
-      }
-    }
-  }
+  scan_wave_strand<NW, NWARM, MASKED, 0>(a, wave, wl, w32_base, s_pl, s_q, s_qn, sink);
+  scan_wave_strand<NW, NWARM, MASKED, 1>(a, wave, wl, w32_base, s_pl, s_q, s_qn, sink);
 }
 
 __device__ __forceinline__ void wave_sync_lds() {   // orders this wave's LDS writes before its later LDS reads
