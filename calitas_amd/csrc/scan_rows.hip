@@ -106,76 +106,77 @@ __device__ __noinline__ void resolve_suspect(const RecordSink sink, uint32_t w32
 // two instructions that use it -- x and xv are three-input functions of (lo, hi, pv) and (lo, hi, mv), one v_bitop3_b32 each with
 // the row's base in the truth table.  (Round 2's first version kept four precomputed planes per word and the x / xv arrays of a row
 // in registers: 166 VGPRs, three waves per SIMD.)  The truth table's bit (s0 << 2 | s1 << 1 | s2) is the result; s0 = lo, s1 = hi.
-// Written as inline assembly for two reasons: as C++ the compiler hoists eq out of the row loop (four planes per word in registers
-// again), and without the unused operand `after` -- the sum of the word before -- it computes the x / xv of all NC words ahead of
-// the carry chain and keeps them live.
+// The row is in two parts.  Part 1 -- x and xv of every word -- exists once per base (its truth tables are immediates) and is inline
+// assembly: as C++ the compiler hoists eq out of the row loop (four planes per word in registers again).  Part 2 is one copy of code
+// for all rows: with four copies of the *whole* row behind the switch the compiler keeps the state in two register sets and moves all
+// 2 NC words at the loop's back edge (34 v_mov per row and 34 more registers at NC = 17).
 template <int BASE> constexpr int eq_table() { return BASE == 0 ? 0x03 : BASE == 1 ? 0x30 : BASE == 2 ? 0x0C : 0xC0; }   // A C G T
-
-// the rest of a word's row once x and xv exist
-#define CALITAS_MYERS_WORD_TAIL(w)                                          \
-  uint32_t cout;                                                            \
-  const uint32_t t = __builtin_addc(x, pv[w], carry, &cout);                \
-  carry = cout; after = t;                                                  \
-  const uint32_t mh = pv[w] & ((t ^ pv[w]) | xv);                           \
-  const uint32_t ph = mv[w] | (~pv[w] & ~t & ~xv);                          \
-  const uint32_t phs = __builtin_amdgcn_alignbit(ph, php, 31);              \
-  const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mhp, 31);              \
-  php = ph; mhp = mh;                                                       \
-  pv[w] = mhs | ~(xv | phs);                                                \
-  mv[w] = phs & xv;
 
 // A row whose protospacer base is one of A C G T.  MASKED: the tile has exception bases (exc: N, padding, IUPAC codes in the text):
 // code 0 never matches, code 1 ("wild": ~hi & lo as stored, hi & ~lo after the reverse strand's complement) matches every row and
 // the aligner decides exactly -- still one three-input function of (lo, hi, exc).
 template <int NC, int BASE, bool MASKED, int DIR>
-__device__ __forceinline__ void myers_row_base(const uint32_t (&lo)[NC], const uint32_t (&hi)[NC], const uint32_t (&exc)[MASKED ? NC : 1],
-                                               uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
+__device__ __forceinline__ void myers_row_part1(const uint32_t (&lo)[NC], const uint32_t (&hi)[NC], const uint32_t (&exc)[MASKED ? NC : 1],
+                                                const uint32_t (&pv)[NC], const uint32_t (&mv)[NC], uint32_t (&x)[NC], uint32_t (&xv)[NC]) {
   constexpr int EQ = eq_table<BASE>();
   constexpr int TT_X = EQ & 0xAA, TT_XV = EQ | 0xAA;                       // eq & pv, eq | mv            (s2 = pv / mv)
   constexpr int TT_EM = (EQ & 0x55) | (DIR ? 0x08 : 0x20);                 // (eq & ~exc) | (exc & wild)  (s2 = exc)
-  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u, after = 0u;
 #pragma unroll
   for (int w = 0; w < NC; w++) {
-    uint32_t x, xv;
     if (MASKED) {
       uint32_t em;
-      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(em) : "v"(lo[w]), "v"(hi[w]), "v"(exc[w]), "n"(TT_EM), "v"(after));
-      x = em & pv[w]; xv = em | mv[w];
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(em) : "v"(lo[w]), "v"(hi[w]), "v"(exc[w]), "n"(TT_EM));
+      asm("v_and_b32 %0, %1, %2 ; base %3" : "=v"(x[w]) : "v"(em), "v"(pv[w]), "n"(BASE));
+      asm("v_or_b32 %0, %1, %2 ; base %3" : "=v"(xv[w]) : "v"(em), "v"(mv[w]), "n"(BASE));
     } else {
-      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(x) : "v"(lo[w]), "v"(hi[w]), "v"(pv[w]), "n"(TT_X), "v"(after));
-      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(xv) : "v"(lo[w]), "v"(hi[w]), "v"(mv[w]), "n"(TT_XV), "v"(after));
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(x[w]) : "v"(lo[w]), "v"(hi[w]), "v"(pv[w]), "n"(TT_X));
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(xv[w]) : "v"(lo[w]), "v"(hi[w]), "v"(mv[w]), "n"(TT_XV));
     }
-    CALITAS_MYERS_WORD_TAIL(w)
   }
 }
 
-// A row whose protospacer base is an IUPAC letter: union of the bases in its set (A=1 C=2 G=4 T=8).
+// Part 1 of a row whose protospacer base is an IUPAC letter: union of the bases in its set (A=1 C=2 G=4 T=8).
 template <int NC, bool MASKED, int DIR>
-__device__ __forceinline__ void myers_row_set(const uint32_t (&lo)[NC], const uint32_t (&hi)[NC], const uint32_t (&exc)[MASKED ? NC : 1],
-                                              const uint32_t set, uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
+__device__ __forceinline__ void myers_row_part1_set(const uint32_t (&lo)[NC], const uint32_t (&hi)[NC], const uint32_t (&exc)[MASKED ? NC : 1],
+                                                    const uint32_t set, const uint32_t (&pv)[NC], const uint32_t (&mv)[NC], uint32_t (&x)[NC],
+                                                    uint32_t (&xv)[NC]) {
   // all-ones / all-zeros per base of the set, in vector registers (an instruction takes one scalar operand at most)
   uint32_t ka = 0u - (set & 1u), kc = 0u - ((set >> 1) & 1u), kg = 0u - ((set >> 2) & 1u), kt = 0u - ((set >> 3) & 1u);
   asm("" : "+v"(ka), "+v"(kc), "+v"(kg), "+v"(kt));
-  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u, after = 0u;
 #pragma unroll
   for (int w = 0; w < NC; w++) {
-    // eq = hi ? (lo ? kt : kg) : (lo ? kc : ka): three selections (truth table 0xCA = s0 ? s1 : s2).  Inline assembly with the
-    // `after` operand like the rows above: (~hi & ~lo & ka) | ... in C++ leaves ~lo, ~hi and the exception term of every word in
-    // registers across the rows.
+    // eq = hi ? (lo ? kt : kg) : (lo ? kc : ka): three selections (truth table 0xCA = s0 ? s1 : s2); as (~hi & ~lo & ka) | ... in
+    // C++ the compiler keeps ~lo, ~hi and the exception term of every word in registers across the rows
     uint32_t hi1, hi0, eq;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca ; after %4" : "=v"(hi1) : "v"(lo[w]), "v"(kt), "v"(kg), "v"(after));
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca ; after %4" : "=v"(hi0) : "v"(lo[w]), "v"(kc), "v"(ka), "v"(after));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(hi1) : "v"(lo[w]), "v"(kt), "v"(kg));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(hi0) : "v"(lo[w]), "v"(kc), "v"(ka));
     asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(eq) : "v"(hi[w]), "v"(hi1), "v"(hi0));
     if (MASKED) {
-      uint32_t wt;                                        // exc & wild
-      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; after %5" : "=v"(wt) : "v"(lo[w]), "v"(hi[w]), "v"(exc[w]), "n"(DIR ? 0x08 : 0x20), "v"(after));
+      uint32_t wt;                                        // exc & wild; kt rides along so that the term is not loop-invariant
+      asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4 ; %5" : "=v"(wt) : "v"(lo[w]), "v"(hi[w]), "v"(exc[w]), "n"(DIR ? 0x08 : 0x20), "v"(kt));
       asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xba" : "=v"(eq) : "v"(eq), "v"(exc[w]), "v"(wt));   // (eq & ~exc) | wt
     }
-    const uint32_t x = eq & pv[w], xv = eq | mv[w];
-    CALITAS_MYERS_WORD_TAIL(w)
+    x[w] = eq & pv[w]; xv[w] = eq | mv[w];
   }
 }
-#undef CALITAS_MYERS_WORD_TAIL
+
+template <int NC>
+__device__ __forceinline__ void myers_row_part2(const uint32_t (&x)[NC], const uint32_t (&xv)[NC], uint32_t (&pv)[NC], uint32_t (&mv)[NC]) {
+  uint32_t carry = 0u, php = 0x80000000u, mhp = 0u;
+#pragma unroll
+  for (int w = 0; w < NC; w++) {
+    uint32_t cout;
+    const uint32_t t = __builtin_addc(x[w], pv[w], carry, &cout);
+    carry = cout;
+    const uint32_t mh = pv[w] & ((t ^ pv[w]) | xv[w]);
+    const uint32_t ph = mv[w] | (~pv[w] & ~t & ~xv[w]);
+    const uint32_t phs = __builtin_amdgcn_alignbit(ph, php, 31);
+    const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mhp, 31);
+    php = ph; mhp = mh;
+    pv[w] = mhs | ~(xv[w] | phs);
+    mv[w] = phs & xv[w];
+  }
+}
 
 // One strand of one wave's share of a tile (DIR 0: the text as it is, left to right; DIR 1: its reverse complement).
 template <int NW, int NWARM, bool MASKED, int DIR>
@@ -211,13 +212,15 @@ __device__ __forceinline__ void scan_wave_strand(const ScanArgs& a, int wave, in
     for (int v = 0; v < NC; v++) { pv[v] = 0u; mv[v] = 0u; }          // row 0 of the DP is all zeros (free start in the text)
     for (int i = 0; i < L; i++) {
       const uint32_t set = (uint32_t)(((i < 16 ? rows_lo : rows_hi) >> ((i & 15) * 4)) & 15u);
+      uint32_t x[NC], xv[NC];
       switch (set) {
-        case 1: myers_row_base<NC, 0, MASKED, DIR>(lo, hi, exc, pv, mv); break;
-        case 2: myers_row_base<NC, 1, MASKED, DIR>(lo, hi, exc, pv, mv); break;
-        case 4: myers_row_base<NC, 2, MASKED, DIR>(lo, hi, exc, pv, mv); break;
-        case 8: myers_row_base<NC, 3, MASKED, DIR>(lo, hi, exc, pv, mv); break;
-        default: myers_row_set<NC, MASKED, DIR>(lo, hi, exc, set, pv, mv);
+        case 1: myers_row_part1<NC, 0, MASKED, DIR>(lo, hi, exc, pv, mv, x, xv); break;
+        case 2: myers_row_part1<NC, 1, MASKED, DIR>(lo, hi, exc, pv, mv, x, xv); break;
+        case 4: myers_row_part1<NC, 2, MASKED, DIR>(lo, hi, exc, pv, mv, x, xv); break;
+        case 8: myers_row_part1<NC, 3, MASKED, DIR>(lo, hi, exc, pv, mv, x, xv); break;
+        default: myers_row_part1_set<NC, MASKED, DIR>(lo, hi, exc, set, pv, mv, x, xv);
       }
+      myers_row_part2<NC>(x, xv, pv, mv);
     }
     // ---- bottom row: value before chain word 0 is L; hunt for values <= E ----
     int s = L - (E + 1);
