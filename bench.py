@@ -449,9 +449,14 @@ def main():
             step()
         # ... and the device is at its sustained clocks: the first process on an idle box measured 2.52-2.54 ms per pass after six
         # calls, the same command right after it 2.35.  Untimed, like the contract's warm-up steps that follow.
-        t_prime = time.perf_counter() + args.prime_seconds
-        while time.perf_counter() < t_prime:
-            step()
+        # (a fixed number of calls when there are several ranks: a step may contain a collective, so all ranks make the same calls)
+        if world > 1:
+            for _ in range(int(args.prime_seconds * 400)):
+                step()
+        else:
+            t_prime = time.perf_counter() + args.prime_seconds
+            while time.perf_counter() < t_prime:
+                step()
         for _ in range(args.warmup):
             step()
         for k in phase:
@@ -624,7 +629,7 @@ def main():
             return tm
 
         seq = 0
-        for _ in range(3 + args.warmup):
+        for _ in range(3 + args.warmup + int(args.prime_seconds * 400)):
             seq += 1
             step(seq)
         for k in phase:
