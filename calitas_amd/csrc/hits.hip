@@ -50,11 +50,10 @@ struct RowConstDev {
   uint32_t q_off[MAX_PAMS + 1], q_len[MAX_PAMS + 1], pu_off[MAX_PAMS + 1], pu_len[MAX_PAMS + 1];
 };
 
-__global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
-                           int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* wks, uint32_t* flags) {
-  CALITAS_TAIL_PRIO();
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// (The four stages below exist as functions of one index: each has a kernel of its own, and hits_small_kernel runs them one after
+// the other in a single workgroup when the call has at most HITS_SMALL alignments -- four launches less on the path of a small call.)
+__device__ __forceinline__ void hit_body(const uint32_t i, const RawAln* fin, const GuideDev* guides, const uint64_t* win_base, const int2* win,
+                                         int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* wks, uint32_t* flags) {
   const RawAln* rp = fin + i;
   struct { uint32_t contig, window_k; int32_t score; int t_start, t_end_guide, dir, guide, pam, offset, n_ops; } r;
   r.contig = rp->contig; r.window_k = rp->window_k; r.score = rp->score; r.t_start = rp->t_start; r.t_end_guide = rp->t_end_guide;
@@ -89,16 +88,20 @@ __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides
   wks[i] = r.window_k;
 }
 
+__global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
+                           int score_hi, HitRec* hits, uint64_t* keys, uint32_t* vals, uint32_t* wks, uint32_t* flags) {
+  CALITAS_TAIL_PRIO();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hit_body(i, fin, guides, win_base, win, score_hi, hits, keys, vals, wks, flags);
+}
+
 // ReferenceHit.sort without a sort.  The accepted alignments arrive in (contig, window, ...) order, and hits of two windows that
 // share no base cannot be out of order relative to each other (a hit starts inside its window): with reach = the number of
 // window steps after which two windows are disjoint, hit i only has to be compared with the hits of the windows less than
 // `reach` steps away.  rank(i) = i - (earlier neighbours with a greater key) + (later neighbours with a smaller key); equal keys
 // keep their arrival order, as a stable sort would.  One launch instead of the seven of a 64-bit radix / merge sort; the caller
 // takes the general sort when a window holds more records than a lane should walk past.
-__global__ void rank_kernel(const uint64_t* keys, const uint32_t* wks, uint32_t n, uint32_t reach, uint32_t* order) {
-  CALITAS_TAIL_PRIO();
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void rank_body(const uint32_t i, const uint64_t* keys, const uint32_t* wks, uint32_t n, uint32_t reach, uint32_t* order) {
   const uint64_t k = keys[i];
   const uint64_t contig = k >> 46;
   const uint32_t wk = wks[i];
@@ -116,13 +119,16 @@ __global__ void rank_kernel(const uint64_t* keys, const uint32_t* wks, uint32_t 
   order[rank] = i;
 }
 
-constexpr int HIT_MAX_LEN = CALITAS_MAX_OPS;   // a hit covers at most this many reference bases (ReferenceHit.end - start + 1)
-
-__global__ void prep_kernel(const HitRec* hits, const uint32_t* order, uint32_t n, int max_overlap, int32_t* s_start, int32_t* s_end,
-                            int32_t* s_score, uint32_t* s_cs, uint8_t* head, uint8_t* keep) {
+__global__ void rank_kernel(const uint64_t* keys, const uint32_t* wks, uint32_t n, uint32_t reach, uint32_t* order) {
   CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) rank_body(i, keys, wks, n, reach, order);
+}
+
+constexpr int HIT_MAX_LEN = CALITAS_MAX_OPS;   // a hit covers at most this many reference bases (ReferenceHit.end - start + 1)
+
+__device__ __forceinline__ void prep_body(const uint32_t i, const HitRec* hits, const uint32_t* order, int max_overlap, int32_t* s_start, int32_t* s_end,
+                                          int32_t* s_score, uint32_t* s_cs, uint8_t* head, uint8_t* keep) {
   const HitRec h = hits[order[i]];
   const uint32_t cs = ((uint32_t)h.contig << 1) | h.minus;
   s_start[i] = h.gstart; s_end[i] = h.rh_end; s_score[i] = h.score; s_cs[i] = cs;
@@ -137,11 +143,16 @@ __global__ void prep_kernel(const HitRec* hits, const uint32_t* order, uint32_t 
   head[i] = is_head ? 1 : 0;
 }
 
-__global__ void cluster_kernel(const int32_t* s_start, const int32_t* s_end, const int32_t* s_score, const uint32_t* s_cs,
-                               const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+__global__ void prep_kernel(const HitRec* hits, const uint32_t* order, uint32_t n, int max_overlap, int32_t* s_start, int32_t* s_end,
+                            int32_t* s_score, uint32_t* s_cs, uint8_t* head, uint8_t* keep) {
   CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !head[i]) return;
+  if (i < n) prep_body(i, hits, order, max_overlap, s_start, s_end, s_score, s_cs, head, keep);
+}
+
+__device__ __forceinline__ void cluster_body(const uint32_t i, const int32_t* s_start, const int32_t* s_end, const int32_t* s_score, const uint32_t* s_cs,
+                                             const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+  if (!head[i]) return;
   const uint32_t cs = s_cs[i];
   // next hit of this (contig, strand) group after position j, or n
   auto next = [&](uint32_t j) {
@@ -172,6 +183,46 @@ __global__ void cluster_kernel(const int32_t* s_start, const int32_t* s_end, con
     if (!more) return;
     if (++steps > CLUSTER_MAX) { atomicOr(flags, HITS_FLAG_CLUSTER); return; }
   }
+}
+
+__global__ void cluster_kernel(const int32_t* s_start, const int32_t* s_end, const int32_t* s_score, const uint32_t* s_cs,
+                               const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+  CALITAS_TAIL_PRIO();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cluster_body(i, s_start, s_end, s_score, s_cs, head, n, max_overlap, keep, flags);
+}
+
+// At most this many accepted alignments: coordinates, order, restart points and the removeOverlaps walk in ONE launch of one
+// workgroup (the stages talk through global memory; between two of them a device-scope fence and a barrier), and the row offsets in
+// another (offs_small_kernel).  An E. coli-sized call has 20-40 alignments and ~20 dependent launches of 3-5 us, with 4-10 us between
+// any two: the launches are its run time.
+constexpr uint32_t HITS_SMALL = 1024;
+
+struct HitsSmallArgs {
+  const RawAln* fin; const GuideDev* guides; const uint64_t* win_base; const int2* win;
+  HitRec* hits; uint64_t* keys; uint32_t *vals, *wks, *order;
+  int32_t *s_start, *s_end, *s_score; uint32_t* s_cs; uint8_t *head, *keep;
+  uint32_t* flags;
+  uint32_t n, reach;
+  int score_hi, max_overlap;
+};
+
+__device__ __forceinline__ void stage_sync() {   // what one stage wrote, the next one reads -- possibly in another wave of the workgroup
+  __threadfence();
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(HITS_SMALL) void hits_small_kernel(HitsSmallArgs a) {
+  CALITAS_TAIL_PRIO();
+  const uint32_t i = threadIdx.x;
+  const bool mine = i < a.n;
+  if (mine) hit_body(i, a.fin, a.guides, a.win_base, a.win, a.score_hi, a.hits, a.keys, a.vals, a.wks, a.flags);
+  stage_sync();
+  if (mine) rank_body(i, a.keys, a.wks, a.n, a.reach, a.order);
+  stage_sync();
+  if (mine) prep_body(i, a.hits, a.order, a.max_overlap, a.s_start, a.s_end, a.s_score, a.s_cs, a.head, a.keep);
+  stage_sync();
+  if (mine) cluster_body(i, a.s_start, a.s_end, a.s_score, a.s_cs, a.head, a.n, a.max_overlap, a.keep, a.flags);
 }
 
 // ---- rows ------------------------------------------------------------------------------------------------------------
@@ -522,6 +573,33 @@ __global__ void total_kernel(const uint64_t* offs, const uint64_t* lens, uint32_
   __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Row offsets, the length of the text and the post to the host for at most HITS_SMALL rows: one workgroup instead of the scan's two
+// launches and total_kernel.
+__global__ __launch_bounds__(HITS_SMALL) void offs_small_kernel(const uint64_t* lens, uint32_t n, uint64_t* offs, uint64_t* counts, uint32_t* box,
+                                                                uint32_t seq) {
+  CALITAS_TAIL_PRIO();
+  __shared__ uint64_t s_sum[HITS_SMALL];
+  const uint32_t i = threadIdx.x;
+  const uint64_t mine = i < n ? lens[i] : 0;
+  s_sum[i] = mine;
+  __syncthreads();
+  for (uint32_t d = 1; d < HITS_SMALL; d <<= 1) {       // inclusive scan, Hillis-Steele
+    const uint64_t add = i >= d ? s_sum[i - d] : 0;
+    __syncthreads();
+    s_sum[i] += add;
+    __syncthreads();
+  }
+  if (i < n) offs[i] = s_sum[i] - mine;
+  if (i == 0) {
+    counts[0] = s_sum[HITS_SMALL - 1];
+    __threadfence();
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(counts);
+    for (int k = 0; k < 6; k++) box[1 + k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <typename T>
 hipError_t grow(T** p, size_t& cap, size_t need) {
   if (need <= cap) return hipSuccess;
@@ -643,6 +721,14 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   }
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
   size_t ts;
+  const bool small = n_in <= HITS_SMALL && window_reach != 0;
+  if (small) {          // 1-3 in one launch
+    HitsSmallArgs sa{};
+    sa.fin = d_final; sa.guides = d_guides; sa.win_base = d_win_base; sa.win = d_win; sa.hits = w.hits; sa.keys = w.keys; sa.vals = w.vals;
+    sa.wks = w.wks; sa.order = w.vals2; sa.s_start = w.s_start; sa.s_end = w.s_end; sa.s_score = w.s_score; sa.s_cs = w.s_cs; sa.head = w.head;
+    sa.keep = w.keep; sa.flags = d_flags; sa.n = n_in; sa.reach = window_reach; sa.score_hi = score_hi; sa.max_overlap = max_overlap;
+    hipLaunchKernelGGL(hits_small_kernel, dim3(1), dim3(HITS_SMALL), 0, stream, sa);
+  } else {
   // 1: coordinates and the final order
   hipLaunchKernelGGL(hit_kernel, grid, block, 0, stream, d_final, n_in, d_guides, d_win_base, d_win, score_hi, w.hits, w.keys, w.vals, w.wks, d_flags);
   if (window_reach) {   // the order by counting among the neighbouring windows (rank_kernel)
@@ -656,6 +742,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
                      w.s_score, w.s_cs, w.head, w.keep);
   hipLaunchKernelGGL(cluster_kernel, grid, block, 0, stream, (const int32_t*)w.s_start, (const int32_t*)w.s_end, (const int32_t*)w.s_score,
                      (const uint32_t*)w.s_cs, (const uint8_t*)w.head, n_in, max_overlap, w.keep, d_flags);
+  }
   // 4: rows
   // (a row with more padded columns than a wave has lanes raises HITS_FLAG_ROW and the caller finishes on the host)
   const uint32_t n_max = (uint32_t)std::min<int>(MID_COLS, std::max(1, max_ops));
@@ -675,11 +762,15 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   const unsigned rows_per_mid_block = 4 * MID_ROWS_PER_WAVE;
   hipLaunchKernelGGL(mid_kernel, dim3((unsigned)((n + rows_per_mid_block - 1) / rows_per_mid_block)), dim3(256), mid_lds, stream, ma, w.stage, w.midlen,
                      w.lens, d_flags);
-  ts = w.temp_cap;
-  TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
   TRY(mailbox_open(w.mbox));
   w.mbox.seq++;
-  hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts, w.mbox.dev, w.mbox.seq);
+  if (small) {
+    hipLaunchKernelGGL(offs_small_kernel, dim3(1), dim3(HITS_SMALL), 0, stream, (const uint64_t*)w.lens, n_in, w.offs, w.d_counts, w.mbox.dev, w.mbox.seq);
+  } else {
+    ts = w.temp_cap;
+    TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
+    hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts, w.mbox.dev, w.mbox.seq);
+  }
   TRY(hipGetLastError());
   TRY(mailbox_wait(w.mbox, stream));
   for (int k = 0; k < 3; k++) w.h_counts[k] = (uint64_t)w.mbox.host[1 + 2 * k] | ((uint64_t)w.mbox.host[2 + 2 * k] << 32);

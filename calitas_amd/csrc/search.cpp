@@ -421,13 +421,15 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   if (gpu_select) {
     const RawAln* d_final = nullptr;
     const uint32_t* d_cnt = nullptr;
-    HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
-                            p.max_overlap, ctx->stream, &d_final, &d_cnt, &ctx->mbox));   // its last kernel posts the three counts
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (g_marks.on) { char b[48]; std::snprintf(b, sizeof b, " (first-launch +%.0f)", g_select_prelaunch_us); g_marks.line += b; }
-    g_marks.mark("queued-filter");
-    HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
-    g_marks.mark("counts2");
+    for (bool general = false;; general = true) {   // (second round: the one-workgroup version met a window it leaves to the general kernels)
+      HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
+                              p.max_overlap, ctx->stream, &d_final, &d_cnt, &ctx->mbox, general));   // its last kernel posts the three counts
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      g_marks.mark("queued-filter");
+      HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
+      g_marks.mark("counts2");
+      if (general || !(ctx->mbox.host[2] & SELECT_FLAG_RETRY)) break;
+    }
     ctx->h_counters[5] = ctx->mbox.host[1]; ctx->h_counters[6] = ctx->mbox.host[2]; ctx->h_counters[7] = ctx->mbox.host[3];
     select_done(ctx->select);
     if (ctx->h_counters[6] & SELECT_FLAG_INTERNAL)

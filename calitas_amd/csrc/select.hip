@@ -51,13 +51,9 @@ __device__ __forceinline__ unsigned long long order_key(const Derived& d) {
          ((unsigned long long)(0xFFFFu - d.gaps) << 24) | ((unsigned long long)(0x7FFFFu - (d.ekey & 0x7FFFFu)) << 1) | 1ull;
 }
 
-__global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
-                             uint32_t window_lo, uint32_t windows_per_guide, Derived* der, uint32_t* cnt, uint32_t* counts) {
-  CALITAS_TAIL_PRIO();
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; counts[3] = 0; }   // survivors, flags, listed windows, crowded windows: nobody reads them before step 4
-  if (i >= n) return;
-  const RawAln* rp = raw + i;
+// What the filter looks at, from one raw alignment.
+__device__ __forceinline__ Derived derive(const RawAln* rp, const GuideDev* guides, const uint64_t* win_base, const int2* win, uint32_t window_lo,
+                                          uint32_t windows_per_guide) {
   const uint32_t contig = rp->contig, window_k = rp->window_k, guide = rp->guide;
   const int pam = rp->pam, offset = rp->offset, n_ops = rp->n_ops, dir = rp->dir;
   const OpCounts oc = count_ops(load_ops_words(rp->ops), n_ops);
@@ -74,6 +70,16 @@ __global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guid
   const uint32_t list = pam5 ? (dir == 1 ? 0u : 1u) : (dir == 0 ? 0u : 1u);   // 0 = forward-strand list (SGA:316)
   d.ekey = (list << 19) | ((uint32_t)rp->t_end_guide << 6) | ((uint32_t)rp->pad << 4) | (uint32_t)(pam + 1);
   d.widx = guide * windows_per_guide + ((uint32_t)wi - window_lo);
+  return d;
+}
+
+__global__ void count_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, const uint64_t* win_base, const int2* win,
+                             uint32_t window_lo, uint32_t windows_per_guide, Derived* der, uint32_t* cnt, uint32_t* counts) {
+  CALITAS_TAIL_PRIO();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; counts[3] = 0; }   // survivors, flags, listed windows, crowded windows: nobody reads them before step 4
+  if (i >= n) return;
+  const Derived d = derive(raw + i, guides, win_base, win, window_lo, windows_per_guide);
   der[i] = d;
   atomicAdd(&cnt[d.widx], 1u);
 }
@@ -294,6 +300,96 @@ __global__ __launch_bounds__(64) void filter_wave_kernel(const Derived* ders, co
   }
 }
 
+// The whole stage for at most SELECT_SMALL raw alignments in one workgroup (an E. coli-sized call has ~45): grouping by window is a
+// rank by counting in LDS instead of the dense per-window counters and their scan over the window table, the greedy is filter_kernel's
+// on LDS arrays, the compaction a scan in LDS -- one launch instead of nine, and between dependent launches lie 4-10 us each.  A window
+// with more than SMALL_WINDOW_MAX records (the greedy is quadratic and one lane runs it) raises SELECT_FLAG_RETRY: the caller runs the
+// general kernels for this call.
+constexpr uint32_t SELECT_SMALL = 1024, SMALL_WINDOW_MAX = 32;
+
+__global__ __launch_bounds__(SELECT_SMALL) void select_small_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, const uint64_t* win_base,
+                                                                    const int2* win, uint32_t window_lo, uint32_t windows_per_guide,
+                                                                    int max_total_diffs, int max_overlap, RawAln* final_out, uint32_t* counts,
+                                                                    uint32_t* box, uint32_t seq) {
+  CALITAS_TAIL_PRIO();
+  __shared__ uint32_t s_widx[SELECT_SMALL];             // by arrival
+  __shared__ Derived s_d[SELECT_SMALL];                 // from here on by (window, arrival)
+  __shared__ unsigned long long s_key[SELECT_SMALL];    // order_key(), 0 = taken
+  __shared__ uint32_t s_src[SELECT_SMALL];              // arrival index
+  __shared__ uint32_t s_out[SELECT_SMALL];              // per window, from its first position: the kept positions in output order
+  __shared__ uint32_t s_sum[SELECT_SMALL];              // kept counts at the windows' first positions, then their inclusive scan
+  __shared__ uint32_t s_flags;
+  const uint32_t i = threadIdx.x;
+  const bool mine = i < n;
+  Derived d{};
+  if (mine) { d = derive(raw + i, guides, win_base, win, window_lo, windows_per_guide); s_widx[i] = d.widx; }
+  if (i == 0) s_flags = 0;
+  __syncthreads();
+  if (mine) {
+    uint32_t p = 0;
+    for (uint32_t j = 0; j < n; j++) { const uint32_t wj = s_widx[j]; p += (wj < d.widx || (wj == d.widx && j < i)) ? 1u : 0u; }
+    s_d[p] = d; s_key[p] = order_key(d); s_src[p] = i;
+  }
+  __syncthreads();
+  uint32_t nk = 0;
+  bool first = false;
+  if (mine) {
+    const uint32_t s = i, w = s_d[s].widx;
+    first = s == 0 || s_d[s - 1].widx != w;
+    if (first) {
+      uint32_t e = s + 1;
+      while (e < n && s_d[e].widx == w) e++;
+      if (e - s > SMALL_WINDOW_MAX) {
+        atomicOr(&s_flags, SELECT_FLAG_RETRY);
+      } else {
+        for (uint32_t list = 0; list < 2; list++) {
+          const uint32_t first_kept = nk;                 // overlaps are only tested against the same strand (SGA:317)
+          for (uint32_t round = s; round < e; round++) {
+            unsigned long long bk = 0;
+            uint32_t best = 0;
+            for (uint32_t m = s; m < e; m++) {
+              const unsigned long long k = s_key[m];
+              if ((uint32_t)(k >> 63) != list || k == 0) continue;
+              if (k > bk) { bk = k; best = m; }
+            }
+            if (bk == 0) break;
+            s_key[best] = 0;
+            if ((int)s_d[best].edits > max_total_diffs) continue;
+            bool clash = false;
+            for (uint32_t k = first_kept; k < nk; k++) {
+              const uint32_t kp = s_out[s + k];
+              const int o = min(s_d[best].end, s_d[kp].end) - max(s_d[best].start, s_d[kp].start);   // GA:119-122
+              if (o > max_overlap) { clash = true; break; }
+            }
+            if (!clash) s_out[s + nk++] = best;
+          }
+        }
+      }
+    }
+  }
+  s_sum[i] = nk;
+  __syncthreads();
+  for (uint32_t dd = 1; dd < SELECT_SMALL; dd <<= 1) {    // inclusive scan, Hillis-Steele
+    const uint32_t add = i >= dd ? s_sum[i - dd] : 0u;
+    __syncthreads();
+    s_sum[i] += add;
+    __syncthreads();
+  }
+  if (first && nk) {
+    const uint32_t at = s_sum[i] - nk;
+    for (uint32_t r = 0; r < nk; r++) final_out[at + r] = raw[s_src[s_out[i + r]]];
+  }
+  if (i == 0) {
+    const uint32_t total = s_sum[SELECT_SMALL - 1], flags = s_flags;
+    counts[0] = total; counts[1] = flags; counts[2] = 0; counts[3] = 0;
+    if (box) {
+      box[1] = total; box[2] = flags; box[3] = 0;
+      __threadfence_system();
+      __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // box: the thread that knows the total also posts the stage's three counts to the host's mailbox (mailbox.hpp).  The flags and the
 // number of big groups were final when the filter kernels ended; the host only uses the counts to queue the next kernels on this
 // stream, behind this one.
@@ -363,14 +459,11 @@ bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides)
          windows_per_guide > 0 && windows_per_guide * (uint64_t)n_guides < (1ull << 31) && n_guides <= 64;
 }
 
-thread_local double g_select_prelaunch_us = 0;
-
 void select_done(SelectWork* w) { if (w) w->cnt_dirty = false; }
 
 hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
-                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post) {
-  const auto t_enter = std::chrono::steady_clock::now();
+                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post, bool general) {
   if (!*pw) *pw = new SelectWork();
   SelectWork& w = **pw;
   hipError_t e;
@@ -382,6 +475,17 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   if (n == 0) {
     TRY(hipMemsetAsync(w.counts, 0, 4 * sizeof(uint32_t), stream));
     if (post) TRY(mailbox_post(*post, w.counts, 3, stream));
+    return hipSuccess;
+  }
+  if (n <= SELECT_SMALL && !general) {     // the one-workgroup version (select_small_kernel)
+    TRY(grow(&w.final_out, w.final_cap, n));
+    uint32_t* box = nullptr;
+    uint32_t seq = 0;
+    if (post) { TRY(mailbox_open(*post)); box = post->dev; seq = ++post->seq; }
+    hipLaunchKernelGGL(select_small_kernel, dim3(1), dim3(SELECT_SMALL), 0, stream, d_raw, n_raw, d_guides, d_win_base, d_win, (uint32_t)window_lo,
+                       (uint32_t)windows_per_guide, max_total_diffs, max_overlap, w.final_out, w.counts, box, seq);
+    TRY(hipGetLastError());
+    *d_final = w.final_out;
     return hipSuccess;
   }
   const size_t cnt_cap_before = w.cnt_cap;
@@ -397,7 +501,6 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
   if (t1 > w.temp_cap) { (void)hipFree(w.temp); w.temp = nullptr; w.temp_cap = 0; TRY(hipMalloc(&w.temp, t1)); w.temp_cap = t1; }
   const dim3 block(256), grid_n((unsigned)((n + 255) / 256));
   w.cnt_dirty = true;
-  g_select_prelaunch_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
   hipLaunchKernelGGL(count_kernel, grid_n, block, 0, stream, d_raw, n_raw, d_guides, d_win_base, d_win, (uint32_t)window_lo, (uint32_t)windows_per_guide, w.der,
                      w.cnt, w.counts);
   size_t ts = w.temp_cap;

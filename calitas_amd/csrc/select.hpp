@@ -13,6 +13,9 @@ struct SelectWork;   // device scratch, grown on demand and reused across search
 // bit of (*d_counts)[1]: the per-window counters were not zero when the stage started (an internal error, never a property of the
 // input): the caller fails the search instead of falling back to the host filter
 constexpr uint32_t SELECT_FLAG_INTERNAL = 0x80000000u;
+// bit of (*d_counts)[1]: the one-workgroup version of the stage (small inputs) met a window it does not filter: call select_run again
+// with general = true
+constexpr uint32_t SELECT_FLAG_RETRY = 0x40000000u;
 
 // True when the global window index (guide x windows) fits the counters and an end column fits the enumeration key.
 bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides);
@@ -25,9 +28,8 @@ bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides)
 // post: the last kernel also publishes (*d_counts)[0..3) to that mailbox -- wait for it with mailbox_wait.
 hipError_t select_run(SelectWork** work, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
-                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post = nullptr);
+                      hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post = nullptr, bool general = false);
 void select_done(SelectWork* work);
-extern thread_local double g_select_prelaunch_us;   // host time of the last select_run before its first launch (CALITAS_TRACE=2)
 void select_destroy(SelectWork* work);
 
 }  // namespace calitas

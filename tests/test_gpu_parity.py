@@ -198,6 +198,18 @@ def test_no_silent_truncation_on_dense_output(C, tmp_path):
     assert_same(prod, orac, "dense")
 
 
+def test_small_input_with_a_crowded_window(C, tmp_path):
+    """Fewer than 1024 raw alignments take the one-workgroup versions of the filter and hits stages (select_small_kernel,
+    hits_small_kernel); a window with more than 32 of them makes the filter hand the call back to the general kernels."""
+    unit = "ACGTTGCA"
+    seq = "T" * 300 + unit * 14 + "GTGACTTGAAGTCTCAGTATA" + "C" * 400 + "CTTGCCCCACAGGGCAGTAATGG" + "A" * 200
+    fa = write_fasta(str(tmp_path / "crowded_small.fa"), [("c1", seq), ("c2", "G" * 150 + "CTTGCCCCACAGGGCAGTTATGG" + "T" * 90)])
+    for guide, kw in (("ACGTTGCAACGTTGCAACGT", dict(d=6, O=100)), ("CTTGCCCCACAGGGCAGTAAnrg", dict(d=5, p=1, g=2))):
+        prod = product_rows(C, fa, guide, **kw)
+        orac = oracle_rows(fa, guide, **kw)
+        assert_same(prod, orac, guide)
+
+
 def test_device_filter_equals_host_filter(C, tmp_path, monkeypatch):
     """The per-window overlap filter (SGA:316-331) runs on the device by default and on the host when a window holds more
     alignments than one lane handles, or on request; both must return the same records in the same order."""
