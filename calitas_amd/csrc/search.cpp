@@ -375,6 +375,14 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   tm.bases_scanned = pl.bases;
   tm.packed_bytes = (tm.bases_scanned + 3) / 4;
   uint32_t n_rec = 0, n_raw = 0;
+  const calitas_ctx* own = ref_owner(ctx);
+  const bool device_filter = !std::getenv("CALITAS_HOST_FILTER") && select_supported(pl.win_n, p.window_size, n_guides);
+  // A small reference usually yields few alignments: the one-workgroup filter is queued right behind trace_kernel and reads the counts
+  // on the device, so the host hears about the counters and the filter's result in one round trip (select_run_speculative).
+  const bool speculate = !prelaunched && device_filter && pl.bases <= (64ull << 20);
+  const RawAln* d_spec = nullptr;
+  uint32_t spec_counts[3] = {0, 0, 0};
+  bool spec_done = false;
   for (;;) {
     if (!prelaunched) {
       int rc = launch_scan_stage(ctx, pl, ctx->stream);
@@ -386,11 +394,18 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     // (trace_kernel can post the counters itself from its last workgroup -- launch_trace's `post` -- but finding the last of 2048
     // workgroups is 2048 atomics on one word, ~8 ns each: 20-30 us against the ~10 us of this launch)
     HIP_TRY(ctx, launch_trace(aa, kTraceBlocks, ctx->stream, ctx->ev[2]));
-    HIP_TRY(ctx, mailbox_post(ctx->mbox, ctx->d_counters, 8, ctx->stream));
+    if (speculate) {
+      HIP_TRY(ctx, select_run_speculative(&ctx->select, ctx->d_raw, ctx->d_counters, ctx->rec_cap, ctx->raw_cap, ctx->item_cap, ctx->d_guides,
+                                          own->d_win_base, own->d_win, pl.win_lo, pl.win_n, max_total, p.max_overlap, ctx->stream, &d_spec, &ctx->mbox));
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    } else {
+      HIP_TRY(ctx, mailbox_post(ctx->mbox, ctx->d_counters, 8, ctx->stream));
+    }
     g_marks.mark("queued-scan-align-trace");
     HIP_TRY(ctx, mailbox_wait(ctx->mbox, ctx->stream));
     g_marks.mark("counts1");
     for (int k = 0; k < 8; k++) ctx->h_counters[k] = ctx->mbox.host[1 + k];
+    if (speculate) { for (int k = 0; k < 3; k++) spec_counts[k] = ctx->mbox.host[9 + k]; spec_done = !(spec_counts[1] & SELECT_FLAG_RETRY); }
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
     const uint32_t n_items = ctx->h_counters[3];
     if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
@@ -412,16 +427,20 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     break;
   }
-  const calitas_ctx* own = ref_owner(ctx);
   // ---- per-window filter (SGA:315-320): on the GPU (select.hip) unless the tiling does not fit its sort key, a window
   //      exceeds its group limit, or CALITAS_HOST_FILTER asks for the host implementation of the same stage ----
-  bool gpu_select = n_raw > 0 && !std::getenv("CALITAS_HOST_FILTER") && select_supported(pl.win_n, p.window_size, n_guides);
+  bool gpu_select = n_raw > 0 && device_filter;
   uint32_t n_sel = 0;
   const RawAln* d_sel = nullptr;
-  if (gpu_select) {
+  if (gpu_select && spec_done) {                    // the filter ran with the aligner kernels: its counts came with theirs
+    ctx->h_counters[5] = spec_counts[0]; ctx->h_counters[6] = spec_counts[1]; ctx->h_counters[7] = spec_counts[2];
+    n_sel = spec_counts[0];
+    d_sel = d_spec;
+  } else if (gpu_select) {
     const RawAln* d_final = nullptr;
     const uint32_t* d_cnt = nullptr;
-    for (bool general = false;; general = true) {   // (second round: the one-workgroup version met a window it leaves to the general kernels)
+    // (second round: the one-workgroup version met a window it leaves to the general kernels -- here, or already behind trace_kernel)
+    for (bool general = speculate && n_raw <= 1024;; general = true) {
       HIP_TRY(ctx, select_run(&ctx->select, ctx->d_raw, n_raw, ctx->d_guides, own->d_win_base, own->d_win, pl.win_lo, pl.win_n, n_guides, max_total,
                               p.max_overlap, ctx->stream, &d_final, &d_cnt, &ctx->mbox, general));   // its last kernel posts the three counts
       HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));

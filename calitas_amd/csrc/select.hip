@@ -310,8 +310,26 @@ constexpr uint32_t SELECT_SMALL = 1024, SMALL_WINDOW_MAX = 32;
 __global__ __launch_bounds__(SELECT_SMALL) void select_small_kernel(const RawAln* raw, uint32_t n, const GuideDev* guides, const uint64_t* win_base,
                                                                     const int2* win, uint32_t window_lo, uint32_t windows_per_guide,
                                                                     int max_total_diffs, int max_overlap, RawAln* final_out, uint32_t* counts,
-                                                                    uint32_t* box, uint32_t seq) {
+                                                                    uint32_t* box, uint32_t seq, const uint32_t* ctr, uint32_t rec_cap,
+                                                                    uint32_t raw_cap, uint32_t item_cap) {
   CALITAS_TAIL_PRIO();
+  // ctr: launched right behind trace_kernel, before the host has seen the call's counters (records, raw alignments, anomalies, passing
+  // candidates, ...: eight words).  The kernel takes the number of alignments from there, checks what the host would have checked
+  // (any overflow or anomaly, or more alignments than it handles: SELECT_FLAG_RETRY and nothing else done) and posts the counters
+  // together with its own three counts: one host round trip instead of two on the path of a small call.
+  if (ctr) {
+    n = ctr[1];
+    if (ctr[0] > rec_cap || n > raw_cap || ctr[3] > item_cap || ctr[2] != 0 || n > SELECT_SMALL) {
+      if (threadIdx.x == 0) {
+        counts[0] = 0; counts[1] = SELECT_FLAG_RETRY; counts[2] = 0; counts[3] = 0;
+        for (int k = 0; k < 8; k++) box[1 + k] = ctr[k];
+        box[9] = 0; box[10] = SELECT_FLAG_RETRY; box[11] = 0;
+        __threadfence_system();
+        __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
   __shared__ uint32_t s_widx[SELECT_SMALL];             // by arrival
   __shared__ Derived s_d[SELECT_SMALL];                 // from here on by (window, arrival)
   __shared__ unsigned long long s_key[SELECT_SMALL];    // order_key(), 0 = taken
@@ -383,7 +401,8 @@ __global__ __launch_bounds__(SELECT_SMALL) void select_small_kernel(const RawAln
     const uint32_t total = s_sum[SELECT_SMALL - 1], flags = s_flags;
     counts[0] = total; counts[1] = flags; counts[2] = 0; counts[3] = 0;
     if (box) {
-      box[1] = total; box[2] = flags; box[3] = 0;
+      if (ctr) { for (int k = 0; k < 8; k++) box[1 + k] = ctr[k]; box[9] = total; box[10] = flags; box[11] = 0; }
+      else { box[1] = total; box[2] = flags; box[3] = 0; }
       __threadfence_system();
       __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -461,6 +480,27 @@ bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides)
 
 void select_done(SelectWork* w) { if (w) w->cnt_dirty = false; }
 
+hipError_t select_run_speculative(SelectWork** pw, const RawAln* d_raw, const uint32_t* d_counters, uint32_t rec_cap, uint32_t raw_cap,
+                                  uint32_t item_cap, const GuideDev* d_guides, const uint64_t* d_win_base, const int2* d_win, uint64_t window_lo,
+                                  uint64_t windows_per_guide, int max_total_diffs, int max_overlap, hipStream_t stream,
+                                  const RawAln** d_final, Mailbox* post) {
+  if (!*pw) *pw = new SelectWork();
+  SelectWork& w = **pw;
+  hipError_t e;
+#define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+  if (!w.counts) { TRY(hipMalloc((void**)&w.counts, 4 * sizeof(uint32_t))); TRY(hipMemsetAsync(w.counts, 0, 4 * sizeof(uint32_t), stream)); }
+  TRY(grow(&w.final_out, w.final_cap, SELECT_SMALL));
+  TRY(mailbox_open(*post));
+  const uint32_t seq = ++post->seq;
+  hipLaunchKernelGGL(select_small_kernel, dim3(1), dim3(SELECT_SMALL), 0, stream, d_raw, 0u, d_guides, d_win_base, d_win, (uint32_t)window_lo,
+                     (uint32_t)windows_per_guide, max_total_diffs, max_overlap, w.final_out, w.counts, post->dev, seq, d_counters, rec_cap, raw_cap,
+                     item_cap);
+  TRY(hipGetLastError());
+#undef TRY
+  *d_final = w.final_out;
+  return hipSuccess;
+}
+
 hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
                       hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post, bool general) {
@@ -483,7 +523,7 @@ hipError_t select_run(SelectWork** pw, const RawAln* d_raw, uint32_t n_raw, cons
     uint32_t seq = 0;
     if (post) { TRY(mailbox_open(*post)); box = post->dev; seq = ++post->seq; }
     hipLaunchKernelGGL(select_small_kernel, dim3(1), dim3(SELECT_SMALL), 0, stream, d_raw, n_raw, d_guides, d_win_base, d_win, (uint32_t)window_lo,
-                       (uint32_t)windows_per_guide, max_total_diffs, max_overlap, w.final_out, w.counts, box, seq);
+                       (uint32_t)windows_per_guide, max_total_diffs, max_overlap, w.final_out, w.counts, box, seq, (const uint32_t*)nullptr, 0u, 0u, 0u);
     TRY(hipGetLastError());
     *d_final = w.final_out;
     return hipSuccess;

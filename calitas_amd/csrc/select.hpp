@@ -29,6 +29,14 @@ bool select_supported(uint64_t windows_per_guide, int window_size, int n_guides)
 hipError_t select_run(SelectWork** work, const RawAln* d_raw, uint32_t n_raw, const GuideDev* d_guides, const uint64_t* d_win_base,
                       const int2* d_win, uint64_t window_lo, uint64_t windows_per_guide, int n_guides, int max_total_diffs, int max_overlap,
                       hipStream_t stream, const RawAln** d_final, const uint32_t** d_counts, Mailbox* post = nullptr, bool general = false);
+// The same stage queued right behind trace_kernel, before the host knows the call's counters (d_counters: the eight words of
+// AlignArgs::rec_count .. ; the capacities are what the host would check them against): the one-workgroup kernel reads the number of
+// alignments there and posts the eight counters (mailbox words 1..8) together with its counts (words 9..11).  SELECT_FLAG_RETRY in
+// word 10: it did nothing -- an overflow, an anomaly, or more alignments than it takes -- and the caller goes on as if it had not run.
+hipError_t select_run_speculative(SelectWork** work, const RawAln* d_raw, const uint32_t* d_counters, uint32_t rec_cap, uint32_t raw_cap,
+                                  uint32_t item_cap, const GuideDev* d_guides, const uint64_t* d_win_base, const int2* d_win, uint64_t window_lo,
+                                  uint64_t windows_per_guide, int max_total_diffs, int max_overlap, hipStream_t stream,
+                                  const RawAln** d_final, Mailbox* post);
 void select_done(SelectWork* work);
 void select_destroy(SelectWork* work);
 
