@@ -9,11 +9,12 @@
 // 32-bit word and walked the text base by base: 13 VALU instructions per base and strand for L = 20 cells, 12 of the 32 bits idle,
 // plus a table lookup per base.  Here the bit-vector runs along the *text*: a lane owns NW consecutive 32-base words of the
 // reference as one long integer (plus NWARM warm-up words from its neighbour), and one step of the recurrence handles one
-// protospacer ROW for all of those positions -- every bit of every instruction is a DP cell.  Per 32-base word and row: one
-// v_and, one v_or, one v_addc_co (the carry chain runs along the text), three v_bitop3 and a second v_or, two v_alignbit (the
-// one-position shifts across word boundaries) and a last v_and = 10 instructions for 32 cells.  The Eq vector of a row is simply the bit-plane of its base ("is this
-// position an A"), so there is no table and no per-base index arithmetic: the four planes of a lane's words are built once per
-// tile and strand from the 2-bit reference, which the packed reference keeps as two bit-planes per 32 bases for this kernel.
+// protospacer ROW for all of those positions -- every bit of every instruction is a DP cell.  Per 32-base word and row: two
+// v_bitop3 (x and xv straight from the text's two bit-planes and the row's base), one v_addc_co (the carry chain runs along the
+// text), three more v_bitop3 and a v_or, two v_alignbit (the one-position shifts across word boundaries) and a v_and = 10
+// instructions for 32 cells.  The Eq vector of a row ("is this position an A") is a function of the two bit-planes the packed
+// reference keeps per 32 bases (low bits, high bits of the 2-bit codes) and never exists as a value: no table, no per-base index
+// arithmetic, no precomputed planes.
 // The reverse strand is the same recurrence on the bit-reversed, complemented words (right-to-left in the text).
 //
 // After the last row the lane holds the horizontal deltas of the bottom row; the bottom-row values are L + prefix sums of those
