@@ -197,19 +197,46 @@ def spawn_ranks(n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    import tempfile
+    import threading
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+        ef = tempfile.TemporaryFile()                       # every rank's stderr: shown when that rank fails
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    codes = [p.wait() for p in procs]
-    if any(codes):
-        for p in procs:
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef))
+    # rank 0's stdout is drained on a thread, so that this loop can watch ALL children: the first one that fails ends the job (the
+    # others would sit in the rendezvous or a barrier until somebody's time limit)
+    out0 = []
+    drain = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    drain.start()
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+        elif all(c == 0 for c in codes):
+            break
+        else:
+            time.sleep(0.05)
+    if failed is not None:
+        for p in procs:                                     # fresh children of this process: kill, never re-exec
             if p.poll() is None:
                 p.kill()
-        raise SystemExit("bench.py: rank exit codes %s" % codes)
+        for p in procs:
+            p.wait()
+        errs[failed].seek(0)
+        tail = errs[failed].read().decode(errors="replace")[-4000:]
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were stopped.  Its stderr (tail):\n%s\n"
+                         % (failed, procs[failed].returncode, tail))
+        raise SystemExit(procs[failed].returncode if 0 < procs[failed].returncode < 256 else 1)
+    drain.join()
+    errs[0].seek(0)
+    sys.stderr.write(errs[0].read().decode(errors="replace"))     # rank 0's log lines
+    out0 = (out0[0] if out0 else b"").decode()
     line = [ln for ln in out0.splitlines() if ln.startswith("{")]
     if not line:
         raise SystemExit("bench.py: rank 0 printed no result line")
@@ -231,7 +258,10 @@ def main():
                     help="N>1: contigs = consecutive contig ranges of one pass (strong scaling, BASELINE's partition); windows = consecutive "
                          "window ranges, contigs cut where the balance asks for it; guides = every rank its own guide pass over the whole genome (weak)")
     ap.add_argument("--cpu-sample-mb", type=float, default=-1, help="CPU baseline sample in Mb (<0: auto, 0: skip)")
-    ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second measurement (the mode that is not the headline)")
+    ap.add_argument("--secondary", action="store_true",
+                    help="N>1: also measure the partition mode that is not the headline (every rank regenerates and re-uploads the genome for it)")
+    ap.add_argument("--no-secondary", action="store_true", help=argparse.SUPPRESS)   # the default since round 3; accepted for old command lines
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank exits 3 before the rendezvous
     ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
     ap.add_argument("--guides-per-step", type=int, default=1,
                     help="config 3: guides each rank runs per step through calitas_search_hits_batch; the default 1 is the BASELINE metric's single-guide pass")
@@ -254,6 +284,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dry_run:
+        if rank == args.dry_run_fail_rank:
+            sys.stderr.write("bench.py: rank %d fails on request (--dry-run-fail-rank)\n" % rank)
+            raise SystemExit(3)
         import torch
         import torch.distributed as dist
         total = rank + 1
@@ -629,6 +662,8 @@ def main():
             return tm
 
         seq = 0
+        zero_tm = {k: 0 for k in ("scan_kernel_ms", "align_kernel_ms", "gpu_total_ms", "hits_kernel_ms", "hits_copy_ms", "host_post_ms",
+                                  "accepted_alignments", "raw_alignments", "scan_records", "hits_bytes", "packed_bytes", "lanes")}
         for _ in range(3 + args.warmup + int(args.prime_seconds * 400)):
             seq += 1
             step(seq)
@@ -640,7 +675,7 @@ def main():
         tm = None
         for _ in range(args.steps):
             seq += 1
-            tm = step(seq)
+            tm = step(seq) or zero_tm           # a rank whose range holds no window of its own (world > windows) has no timings
             acc["scan"] += tm["scan_kernel_ms"]; acc["align"] += tm["align_kernel_ms"]; acc["gpu"] += tm["gpu_total_ms"]
             acc["hitsk"] += tm["hits_kernel_ms"]; acc["copy"] += tm["hits_copy_ms"]
         sync()
@@ -669,7 +704,7 @@ def main():
         raise SystemExit("--shard windows is implemented for --config 3")
     m = measure_windows() if headline_mode == "windows" else measure(headline_mode, keep_text=(world == 1))
     second = None
-    if world > 1 and not args.no_secondary and args.config == 3:
+    if world > 1 and args.secondary and not args.no_secondary and args.config == 3:
         other = "guides" if headline_mode in ("contigs", "windows") else "contigs"
         s = measure(other)
         second = {"partition": other, "scaling": "weak" if other == "guides" else "strong",
@@ -711,7 +746,7 @@ def main():
             "scan_records_per_pass": tm["scan_records"],
             "hits_bytes_per_pass": tm["hits_bytes"],
             "host_phase_ms": {k: v / K * 1e3 for k, v in m["phase"].items() if v > 0},
-            "kernel_ms": {"scan": acc["scan"] / K, "align": acc["align"] / K, "search_gpu_total": acc["gpu"] / K, "hits_kernels": acc["hitsk"] / K,
+            "kernel_ms": {"scan": acc["scan"] / K, "align": acc["align"] / K, "search_gpu_total_sum_over_lanes": acc["gpu"] / K, "hits_kernels": acc["hitsk"] / K,
                           "text_copy": acc["copy"] / K, "host_convert": acc["post"] / K},
             "roofline": {"bound": "hbm", "kernel": "scan_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

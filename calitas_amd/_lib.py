@@ -8,7 +8,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcalitas_hip.so")
+# CALITAS_LIB_PATH: another build of the same library -- tools/sanitize.sh points it at the host-side sanitizer builds
+# (make SAN=address|thread).  Still a native library: there is no Python or CPU implementation to fall back to.
+LIB_PATH = os.environ.get("CALITAS_LIB_PATH") or os.path.join(HERE, "libcalitas_hip.so")
 
 MAX_OPS = 128
 OK, EINVAL, ENODEV, EHIP, EIO, ESTATE, ENOMEM = 0, 1, 2, 3, 4, 5, 6
@@ -56,7 +58,7 @@ class TimingT(ctypes.Structure):
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
            "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases",
-           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_into", "calitas_pin_host", "calitas_unpin_host", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
+           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_into", "calitas_pin_host", "calitas_unpin_host", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_scan_candidates_columnwise", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
 if not os.path.exists(LIB_PATH):
@@ -87,6 +89,7 @@ lib.calitas_search.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(G
                                ctypes.POINTER(ctypes.POINTER(AlnT)), ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_scan_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(GuideT), ctypes.POINTER(ParamsT),
                                         ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32)), ctypes.POINTER(ctypes.c_uint64)]
+lib.calitas_scan_candidates_columnwise.argtypes = lib.calitas_scan_candidates.argtypes
 lib.calitas_reference_tiles.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint64)] * 4
 lib.calitas_contig_packed_base.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_get_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(TimingT)]

@@ -255,8 +255,8 @@ class Context:
         lib.calitas_free(tsv)
         return nbytes.value, rows.value, nwin.value
 
-    def scan_candidates(self, guides, params):
-        """calitas_scan_candidates: the candidate filter alone.  Returns a sorted list of (contig_index, contig_offset, pass, guide):
+    def scan_candidates(self, guides, params, columnwise=False):
+        """calitas_scan_candidates: the candidate filter alone (columnwise: the same set from round 1's kernel, a test hook).  Returns a sorted list of (contig_index, contig_offset, pass, guide):
         one entry per end column whose seamless glocal bottom-row score reaches minGuideScore (pass 0 = target as is, the column
         is the alignment's last base; pass 1 = reverse-complemented target, the column is its first base in contig coordinates).
         Columns in the padding behind a contig are dropped."""
@@ -265,7 +265,8 @@ class Context:
         keep = [g.to_c() for g in guides]
         arr = (GuideT * n)(*keep)
         out, cnt = ctypes.POINTER(ctypes.c_uint32)(), ctypes.c_uint64()
-        _lib.check(self._h, lib.calitas_scan_candidates(self._h, n, arr, ctypes.byref(params), ctypes.byref(out), ctypes.byref(cnt)))
+        fn = lib.calitas_scan_candidates_columnwise if columnwise else lib.calitas_scan_candidates
+        _lib.check(self._h, fn(self._h, n, arr, ctypes.byref(params), ctypes.byref(out), ctypes.byref(cnt)))
         try:
             words = out[:2 * cnt.value]
         finally:

@@ -109,6 +109,9 @@ void* calitas_out_alloc_pinned(size_t size) { return out_alloc_impl(size, true);
 static void* out_alloc(size_t size) { return out_alloc_impl(size); }
 
 int calitas_fail(calitas_ctx* ctx, int code, const std::string& msg) {
+  // (a helper thread of a call may report on the same context as the caller's thread: the per-contig passes, the lanes' retries)
+  static std::mutex err_mu;
+  std::lock_guard<std::mutex> lk(err_mu);
   if (ctx) ctx->err = msg; else g_create_error = msg;
   return code;
 }
@@ -538,6 +541,11 @@ int calitas_search_hits_batch(calitas_ctx* ctx, int32_t n_guides, const calitas_
 int calitas_scan_candidates(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                             uint32_t** records, uint64_t* n_records) {
   return calitas_scan_candidates_impl(ctx, n_guides, guides, params, records, n_records);
+}
+
+int calitas_scan_candidates_columnwise(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                                       uint32_t** records, uint64_t* n_records) {
+  return calitas_scan_candidates_impl(ctx, n_guides, guides, params, records, n_records, true);
 }
 
 int calitas_reference_tiles(const calitas_ctx* ctx, uint64_t* n_tiles, uint64_t* n_dead, uint64_t* n_masked, uint64_t* tile_bases) {

@@ -103,7 +103,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
                                    const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
                                    uint64_t* tsv_bytes, uint64_t* n_rows);
 int calitas_scan_candidates_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
-                                 uint32_t** records, uint64_t* n_records);
+                                 uint32_t** records, uint64_t* n_records, bool columnwise = false);
 void calitas_destroy_lanes(calitas_ctx* ctx);
 void calitas_default_version_and_stamp(const char* aligner_version, const char* time_stamp, std::string& version, std::string& stamp);
 // Per-guide device constants for limits (d, p) and costs; returns an error text or "".

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <hip/hip_ext.h>
+#include <chrono>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -778,6 +779,10 @@ hipError_t mailbox_post(Mailbox& mb, const uint32_t* src, int n, hipStream_t str
 }
 
 hipError_t mailbox_wait(Mailbox& mb, hipStream_t stream) {
+  // Bounded: a kernel that never finishes would otherwise leave the caller (and every lane thread) spinning for good.  The limit is far
+  // beyond any legitimate wait (the longest device stage of a PAM-less whole-genome pass is under a second).
+  constexpr double kDeadlineSeconds = 120.0;
+  const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0; mb.host[0] != mb.seq; spins++) {
     if ((spins & 0x3FF) == 0x3FF) {            // now and then: is the stream still alive?
       const hipError_t e = hipStreamQuery(stream);
@@ -786,6 +791,7 @@ hipError_t mailbox_wait(Mailbox& mb, hipStream_t stream) {
         if (mb.host[0] == mb.seq) break;
         return hipErrorUnknown;
       }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kDeadlineSeconds) return hipErrorLaunchTimeOut;
       if (spins > (1u << 16)) sched_yield();
     } else {
       __builtin_ia32_pause();

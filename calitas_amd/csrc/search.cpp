@@ -312,14 +312,6 @@ static int lane_prepare(calitas_ctx* ctx, const SearchPlan& pl) {
 // whatever waited for the end of the scan by 60-90 us.
 // (Queuing the inputs of all ranges first and their scans back to back was tried as well: no gain, the pause between two scans is
 // where the previous range's tail gets onto the CUs.)
-// CALITAS_SCAN=columns selects the first-generation column-wise scan_kernel (kernels.hip) instead of scan_rows_kernel: the two
-// emit the same ScanRecords (tests/test_gpu_parity.py::test_scan_kernels_emit_the_same_records), so this is an A/B switch for
-// measurements, not a behaviour switch.
-static bool scan_columnwise() {
-  const char* e = std::getenv("CALITAS_SCAN");
-  return e && std::strcmp(e, "columns") == 0;
-}
-
 // The inputs of a lane's scan: guide constants and cleared counters, queued on `stream`.
 static int queue_scan_inputs(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream) {
   // from the context's pinned copy (an async copy from pageable memory may wait for the stream to drain)
@@ -331,14 +323,16 @@ static int queue_scan_inputs(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t
   return CALITAS_OK;
 }
 
-static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream, bool inputs_queued = false) {
+// columnwise: round 1's column-wise scan_kernel (kernels.hip) instead of scan_rows_kernel.  Only calitas_scan_candidates_columnwise
+// asks for it -- a test hook that holds the two kernels' record sets against each other; no search path does.
+static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream, bool inputs_queued = false, bool columnwise = false) {
   if (!inputs_queued) { int rc = queue_scan_inputs(ctx, pl, stream); if (rc) return rc; }
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(ctx, pl, sa, aa);
   ctx->t_scan0 = ctx->ev[0];
   ctx->t_scan1 = ctx->scan_done ? ctx->scan_done : ctx->ev[1];
   // the events ride on the dispatch
-  if (scan_columnwise()) HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream, ctx->t_scan0, ctx->t_scan1));
+  if (columnwise) HIP_TRY(ctx, launch_scan(sa, ref_owner(ctx)->ref.chunk, pl.n_tiles, stream, ctx->t_scan0, ctx->t_scan1));
   else HIP_TRY(ctx, launch_scan_rows(sa, ref_owner(ctx)->ref.chunk, pl.warm_words, pl.n_tiles, stream, ctx->t_scan0, ctx->t_scan1));
   return CALITAS_OK;
 }
@@ -612,7 +606,7 @@ int calitas_search_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_
 
 // calitas_scan_candidates: plan, scan stage, records back (sorted).  Test and profiling entry; no lanes.
 int calitas_scan_candidates_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
-                                 uint32_t** records, uint64_t* n_records) {
+                                 uint32_t** records, uint64_t* n_records, bool columnwise) {
   if (!ctx) return CALITAS_EINVAL;
   if (!records || !n_records) return fail(ctx, CALITAS_EINVAL, "NULL argument");
   *records = nullptr; *n_records = 0;
@@ -624,13 +618,15 @@ int calitas_scan_candidates_impl(calitas_ctx* ctx, int32_t n_guides, const calit
   if (rc) return rc;
   uint32_t n_rec = 0;
   for (;;) {
-    rc = launch_scan_stage(ctx, pl, ctx->stream);
+    rc = launch_scan_stage(ctx, pl, ctx->stream, false, columnwise);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     n_rec = ctx->h_counters[0];
     if (n_rec <= ctx->rec_cap) break;
-    rc = ensure_buffers(ctx, n_rec + n_rec / 4, ctx->raw_cap, pl.slab_per_rec, ctx->item_cap);
+    const uint64_t grown = (uint64_t)n_rec + n_rec / 4;        // 64-bit: a dense PAM-less scan can pass 3.4e9 records
+    if (grown > 0xFFFFFFF0ull) return fail(ctx, CALITAS_EINVAL, "result volume exceeds 2^32 records");
+    rc = ensure_buffers(ctx, (uint32_t)grown, ctx->raw_cap, pl.slab_per_rec, ctx->item_cap);
     if (rc) return rc;
   }
   static_assert(sizeof(ScanRecord) == 8, "two words per record");
@@ -689,11 +685,14 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
     }
     if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using hipMemcpyAsync\n", DmaCopier::last_reason());
   }
-  hipStream_t cs = (lane->parent && owner->copy_stream) ? owner->copy_stream : lane->stream;
+  // a stream of its own for the copy whenever other work may be queued behind the rows on the lane's stream: the lanes of a chunked /
+  // batch call, and the per-contig passes (rows_done given: the helper thread queues the next contig's kernels on ctx->stream)
+  hipStream_t cs = (owner->copy_stream && (lane->parent || rows_done)) ? owner->copy_stream : lane->stream;
   if (cs != lane->stream) {
-    HIP_TRY(lane, hipEventRecord(lane->rows_ready, lane->stream));
+    hipEvent_t ready = rows_done;
+    if (!ready) { HIP_TRY(lane, hipEventRecord(lane->rows_ready, lane->stream)); ready = lane->rows_ready; }
     std::lock_guard<std::mutex> lk(*copy_mu);
-    HIP_TRY(lane, hipStreamWaitEvent(cs, lane->rows_ready, 0));
+    HIP_TRY(lane, hipStreamWaitEvent(cs, ready, 0));
     HIP_TRY(lane, hipEventRecord(lane->ev[6], cs));
     HIP_TRY(lane, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, cs));
     HIP_TRY(lane, hipEventRecord(lane->ev[7], cs));
@@ -795,6 +794,7 @@ struct LaneThreads {
   size_t k = 0;                                    // lanes of the current job (worker i runs job(i) when i < k)
   std::function<void(size_t)> job;
   std::atomic<size_t> remaining{0};
+  std::atomic<bool> threw{false};                  // a job ended with an exception (std::bad_alloc, ...): the call fails with CALITAS_EHIP
   ~LaneThreads() {
     { std::lock_guard<std::mutex> lk(m); stop = true; gen++; }
     cv.notify_all();
@@ -813,14 +813,14 @@ struct LaneThreads {
             if (stop) return;
             if (i >= k) continue;
           }
-          job(i);
+          try { job(i); } catch (...) { threw.store(true, std::memory_order_relaxed); }   // an exception must not take the process down
           remaining.fetch_sub(1, std::memory_order_release);
         }
       });
     }
   }
   void start(size_t lanes, std::function<void(size_t)> fn) {
-    { std::lock_guard<std::mutex> lk(m); job = std::move(fn); k = lanes; remaining.store(lanes - 1, std::memory_order_relaxed); gen++; }
+    { std::lock_guard<std::mutex> lk(m); job = std::move(fn); k = lanes; remaining.store(lanes - 1, std::memory_order_relaxed); threw.store(false, std::memory_order_relaxed); gen++; }
     cv.notify_all();
   }
   void wait() {                                    // polls: the last lane to finish is the end of the call
@@ -925,6 +925,11 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->copy_stream) {   // the fallback of the SDMA copy must not share ctx->stream with the helper thread's next pass (text_to_host)
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, least));
+  }
   // The text grows in one pageable block (realloc: pages move, bytes are not copied); every contig's rows come over PCIe into a
   // reused page-locked bounce buffer and from there into the block on the worker pool (page-locking 40+ GB of pieces and
   // concatenating them afterwards took longer than the search).
@@ -1389,9 +1394,15 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     g_marks.mark("text-allocated");
     ctx->lane_threads->start(K, lane_body);
     g_marks.mark("threads-started");
-    lane_body(0);                                        // the calling thread drives the first lane itself
+    bool threw = false;
+    try { lane_body(0); } catch (...) { threw = true; }  // the calling thread drives the first lane itself
     ctx->lane_threads->wait();
     g_marks.mark("joined");
+    if (threw || ctx->lane_threads->threw.load()) {
+      (void)hipDeviceSynchronize();
+      free_text();
+      return fail(ctx, CALITAS_EHIP, "a lane of the search ended with an exception (out of host memory?)");
+    }
     rc = CALITAS_OK;
     bool overflow = false;
     for (size_t c = 0; c < K; c++) {

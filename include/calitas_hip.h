@@ -173,6 +173,10 @@ int calitas_get_timing(const calitas_ctx* ctx, calitas_timing_t* out);
  * be held against each other and against a plain dynamic-programming count in the tests; calitas_free releases *records. */
 int calitas_scan_candidates(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
                             uint32_t** records, uint64_t* n_records);
+/* Test hook only: the same record set from round 1's column-wise scan kernel (one DP column per 32-bit word, the text walked base by
+ * base).  No search entry point uses that kernel; it is kept as an independent second implementation of the filter for the tests. */
+int calitas_scan_candidates_columnwise(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const calitas_params_t* params,
+                                       uint32_t** records, uint64_t* n_records);
 /* Scan tiles of the resident reference: how many there are (contig tiles, padding excluded), how many of them the scan skips because
  * they hold nothing but upper-case N (no window can contain any of their bases, SearchReference.scala:58-59), how many carry
  * exception bases (N-run edges, IUPAC codes, contig ends), and the bases per tile. */

@@ -54,13 +54,28 @@ JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_setRe
   if (rc != CALITAS_OK) throw_state(env, calitas_last_error(ctx));
 }
 
-/* params: the 13 int fields of calitas_params_t in declaration order.  Returns a direct ByteBuffer over the
+/* Fills calitas_params_t from the caller's int[]: the fields in declaration order.  The struct has grown over time (13 ints at first,
+ * then first_window / n_windows); an older caller's shorter array leaves the trailing fields at zero, which is their "whole job"
+ * default.  Fewer than the original 13 is a caller bug.  Returns 0 on failure with a Java exception pending. */
+#define CALITAS_PARAMS_MIN_INTS 13
+static int read_params(JNIEnv* env, jintArray params, calitas_params_t* p) {
+  memset(p, 0, sizeof(*p));
+  if (!params) { throw_state(env, "params is null"); return 0; }
+  const jsize have = (*env)->GetArrayLength(env, params);
+  const jsize want = (jsize)(sizeof(*p) / sizeof(int32_t));
+  if (have < CALITAS_PARAMS_MIN_INTS) { throw_state(env, "params: at least 13 ints (the fields of calitas_params_t in declaration order)"); return 0; }
+  (*env)->GetIntArrayRegion(env, params, 0, have < want ? have : want, (jint*)p);
+  return (*env)->ExceptionCheck(env) ? 0 : 1;
+}
+
+/* params: the int fields of calitas_params_t in declaration order (read_params above).  Returns a direct ByteBuffer over the
  * library-owned calitas_aln_t array; NativeAligner hands the address back to `free` when done. */
 JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_search(JNIEnv* env, jobject self, jlong h,
     jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jintArray params) {
   calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
   calitas_guide_t g;
-  calitas_params_t p = {0};
+  calitas_params_t p;
+  if (!read_params(env, params, &p)) return NULL;          /* before anything is acquired: nothing to release on failure */
   const jsize np = (*env)->GetArrayLength(env, pams);
   const char* cp[CALITAS_MAX_PAMS];
   jstring jp[CALITAS_MAX_PAMS];
@@ -68,7 +83,6 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
   g.protospacer = (*env)->GetStringUTFChars(env, protospacer, NULL);
   for (jsize i = 0; i < np; i++) { jp[i] = (jstring)(*env)->GetObjectArrayElement(env, pams, i); cp[i] = (*env)->GetStringUTFChars(env, jp[i], NULL); }
   g.n_pams = (int32_t)np; g.pams = cp; g.pam_is_5prime = pam5 ? 1 : 0; g.cli_length = cliLength;
-  (*env)->GetIntArrayRegion(env, params, 0, (jsize)(sizeof(p) / sizeof(int32_t)), (jint*)&p);
   calitas_aln_t* alns = NULL;
   uint64_t n = 0;
   const int rc = calitas_search(ctx, 1, &g, &p, &alns, &n);
@@ -84,7 +98,8 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
     jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jstring guideId, jintArray params, jstring version) {
   calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
   calitas_guide_t g;
-  calitas_params_t p = {0};
+  calitas_params_t p;
+  if (!read_params(env, params, &p)) return NULL;          /* before anything is acquired: nothing to release on failure */
   const jsize np = (*env)->GetArrayLength(env, pams);
   const char* cp[CALITAS_MAX_PAMS];
   jstring jp[CALITAS_MAX_PAMS];
@@ -92,7 +107,6 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
   g.protospacer = (*env)->GetStringUTFChars(env, protospacer, NULL);
   for (jsize i = 0; i < np; i++) { jp[i] = (jstring)(*env)->GetObjectArrayElement(env, pams, i); cp[i] = (*env)->GetStringUTFChars(env, jp[i], NULL); }
   g.n_pams = (int32_t)np; g.pams = cp; g.pam_is_5prime = pam5 ? 1 : 0; g.cli_length = cliLength;
-  (*env)->GetIntArrayRegion(env, params, 0, (jsize)(sizeof(p) / sizeof(int32_t)), (jint*)&p);
   const char* gid = (*env)->GetStringUTFChars(env, guideId, NULL);
   const char* ver = version ? (*env)->GetStringUTFChars(env, version, NULL) : NULL;
   char* tsv = NULL;
@@ -113,7 +127,8 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
     jstring chrom, jstring vcfId, jstring version) {
   calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
   calitas_guide_t g;
-  calitas_params_t p = {0};
+  calitas_params_t p;
+  if (!read_params(env, params, &p)) return NULL;          /* before anything is acquired: nothing to release on failure */
   const jsize np = (*env)->GetArrayLength(env, pams);
   const char* cp[CALITAS_MAX_PAMS];
   jstring jp[CALITAS_MAX_PAMS];
@@ -121,7 +136,6 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
   g.protospacer = (*env)->GetStringUTFChars(env, protospacer, NULL);
   for (jsize i = 0; i < np; i++) { jp[i] = (jstring)(*env)->GetObjectArrayElement(env, pams, i); cp[i] = (*env)->GetStringUTFChars(env, jp[i], NULL); }
   g.n_pams = (int32_t)np; g.pams = cp; g.pam_is_5prime = pam5 ? 1 : 0; g.cli_length = cliLength;
-  (*env)->GetIntArrayRegion(env, params, 0, (jsize)(sizeof(p) / sizeof(int32_t)), (jint*)&p);
   const char* gid = (*env)->GetStringUTFChars(env, guideId, NULL);
   const char* vcf = (*env)->GetStringUTFChars(env, vcfPath, NULL);
   const char* vid = (*env)->GetStringUTFChars(env, vcfId, NULL);

@@ -150,6 +150,22 @@ def test_bench_spawns_its_own_ranks():
     assert bad.returncode != 0 and b"WORLD_SIZE=2" in bad.stderr
 
 
+def test_bench_launcher_stops_the_job_when_a_rank_dies():
+    """A rank that dies at start-up must not leave the others waiting in the rendezvous until someone's time limit: the launcher
+    watches all children, the first non-zero exit stops the rest, and the job returns that rank's code with its stderr."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--dry-run-fail-rank", "1"], env=env,
+                         capture_output=True, timeout=120)
+    dt = time.time() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr.decode()[-2000:])
+    assert b"rank 1 exited with code 3" in out.stderr and b"fails on request" in out.stderr
+    assert not any(ln.startswith(b"{") for ln in out.stdout.splitlines())
+    assert dt < 60, dt        # rank 0 sits in the gloo rendezvous waiting for rank 1: killed by the launcher, not by a time-out
+
+
 def _worker_windows(rank, world, port, outdir):
     """Window-range partition: this rank aligns the windows of its range (the oracle's per-window SequentialGuideAligner.align as
     compute), the alignments of every contig travel to the rank that owns it, and that rank runs the product's removeOverlaps /

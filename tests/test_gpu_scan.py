@@ -116,10 +116,8 @@ def test_scan_candidates_equal_plain_dp_and_columnwise_kernel(C, case, monkeypat
         ctx.set_reference([n for n, _ in contigs], [s.encode() for _, s in contigs])
         G = [C.Guide(g) for g in guides]              # PAM-less: the filter only sees the protospacer
         params = C.make_params(max_guide_diffs=d, max_pam_mismatches=0, max_gaps_between_guide_and_pam=0)
-        monkeypatch.delenv("CALITAS_SCAN", raising=False)
         rows_kernel = ctx.scan_candidates(G, params)
-        monkeypatch.setenv("CALITAS_SCAN", "columns")
-        cols_kernel = ctx.scan_candidates(G, params)
+        cols_kernel = ctx.scan_candidates(G, params, columnwise=True)   # round 1's kernel: an independent second implementation
     finally:
         ctx.close()
     want = dp_candidates(contigs, guides, d)          # default costs: a bottom-row score >= minGuideScore <=> <= d edits
