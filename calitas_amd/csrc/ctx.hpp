@@ -16,6 +16,7 @@
 #include "refpack.hpp"
 #include "select.hpp"
 #include "hits.hpp"
+#include "binned.hpp"
 #include "dma.hpp"
 #include "mailbox.hpp"
 
@@ -58,6 +59,15 @@ struct calitas_ctx {
   SelectWork* select = nullptr;     // GPU per-window filter scratch
   HitsWork* hits = nullptr;         // GPU removeOverlaps / sort / rows scratch
   uint64_t ref_serial = 0, hits_names_serial = ~0ull;
+  // binned tail (binned.hpp): the owner keeps the bins' geometry, every lane its own scratch
+  uint32_t* d_bin_base = nullptr;   // per contig: index of its first bin, for bin_shift (owner)
+  std::vector<uint32_t> bin_base;   // the same on the host
+  int bin_shift = 0;                // 0 = not built
+  BinnedWork* binned = nullptr;     // lane
+  bool binned_late_check = false;   // lane: the text being copied comes from the binned rows kernel (its late flags are checked after the copy's wait)
+  // the last search on this context the binned tail declined (crowded bins, a long repeat): protospacer length, PAMs, minGuideScore.
+  // A search at least as permissive goes to the general kernels directly.
+  int bin_decl_L = 0, bin_decl_pams = -1, bin_decl_min_score = 0;
   HitsWork* hits_alt = nullptr;     // second row-stage scratch of the per-contig passes: contig c+1's rows are built while contig c's text is copied
   uint64_t hits_alt_names_serial = ~0ull;
   // chunked calitas_search_hits: the parent owns the lanes and the stream all scans are queued on

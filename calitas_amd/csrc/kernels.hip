@@ -673,11 +673,18 @@ __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a, uint32_t* box, 
   if (n_items > a.item_capacity) n_items = a.item_capacity;
   const SearchDev& sp = a.sp;
   // Results are staged in LDS and flushed with one global atomic per flush (see stage_record above for why).
+  // ... and where an alignment lands in a.out[] is also listed in the bin its window starts in (binned.hip; returning atomics on
+  // distinct words: cheap)
+  auto to_bin = [&](uint32_t contig, uint32_t window_k, uint32_t g) {
+    const uint32_t bin = a.bin_base[contig] + (uint32_t)(((uint64_t)window_k * (uint64_t)(uint32_t)sp.step) >> a.bin_shift) - a.bin_first;
+    const uint32_t at = atomicAdd(a.bin_count + bin, 1u);
+    if (at < a.bin_cap) a.bin_idx[(size_t)bin * a.bin_cap + at] = g;
+  };
   auto emit = [&](const RawAln& o) {
     const uint32_t slot = atomicAdd(&s_nout, 1u);                     // LDS atomic
     if (slot < (uint32_t)TRACE_STAGE) { s_out[slot] = o; return; }
     const uint32_t g = atomicAdd(a.out_count, 1u);                    // stage full: append directly
-    if (g < a.out_capacity) a.out[g] = o;
+    if (g < a.out_capacity) { a.out[g] = o; if (a.bin_idx) to_bin(o.contig, o.window_k, g); }
   };
   auto flush = [&]() {                                                // block-uniform call sites only
     __syncthreads();
@@ -691,6 +698,9 @@ __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a, uint32_t* box, 
         const uint32_t g = s_obase + w / WPR;
         if (g < a.out_capacity) reinterpret_cast<uint32_t*>(a.out + g)[w % WPR] = src[w];
       }
+      if (a.bin_idx)
+        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x)
+          if (s_obase + k < a.out_capacity) to_bin(s_out[k].contig, s_out[k].window_k, s_obase + k);
       __syncthreads();
       if (threadIdx.x == 0) s_nout = 0;
       __syncthreads();

@@ -50,6 +50,14 @@ struct AlignArgs {
   uint32_t out_capacity;
   uint64_t gw_lo, gw_hi;   // global window indices [gw_lo, gw_hi) this call covers (calitas_params_t::first_window / n_windows)
   uint32_t tile_words;     // code words per scan tile
+  // Reference bins (binned.hip): trace_kernel also drops every alignment into the bin its window starts in, so that the stages behind
+  // it can work bin by bin without a global grouping step.  bin_idx == nullptr: off.
+  uint32_t* bin_idx;       // (n_bins of this lane's range) x bin_cap indices into out[]
+  uint32_t* bin_count;     // alignments per bin, zero at launch; may exceed bin_cap (the surplus is not stored: the bin is "crowded")
+  const uint32_t* bin_base;  // per contig: index of its first bin
+  uint32_t bin_first;      // first bin of this lane's range (bins / bin_count are indexed relative to it)
+  uint32_t bin_shift;      // log2 of the bases per bin
+  uint32_t bin_cap;
   SearchDev sp;
 };
 

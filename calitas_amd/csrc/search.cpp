@@ -134,7 +134,17 @@ struct SearchPlan {
   uint32_t tile_lo = 0, n_tiles = 0;
   uint64_t bases = 0;
   uint64_t win_lo = 0, win_n = 0;     // its entries of the device window table
+  // its reference bins (binned.hpp); bin_shift = 0: the binned tail does not take this window size
+  int bin_shift = 0;
+  uint32_t bin_first = 0, n_bins = 0;
 };
+
+// The bins of contigs [c0, c1) of the plan's geometry (the owner's bin_base must be built: ensure_bin_base).
+static void plan_bins(const calitas_ctx* owner, SearchPlan& q, int c0, int c1) {
+  if (!q.bin_shift || owner->bin_base.empty()) { q.bin_first = 0; q.n_bins = 0; return; }
+  q.bin_first = owner->bin_base[c0];
+  q.n_bins = owner->bin_base[c1] - q.bin_first;
+}
 
 // Accepted alignments left on the device by search_impl for calitas_search_hits.
 struct DeviceSel {
@@ -216,6 +226,7 @@ static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
   }
   pl.slab_per_rec = (uint64_t)pl.slab_bytes * pl.slots_per_rec;
   pl.tile_lo = 0; pl.n_tiles = (uint32_t)ref.tiles.size();
+  pl.bin_shift = binned_shift(p.window_size);
   pl.bases = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
   pl.win_lo = 0; pl.win_n = 0;
   for (auto& c : ref.contigs) pl.win_n += window_count(c.len, pl.step);
@@ -265,6 +276,27 @@ static int ensure_window_table(calitas_ctx* ctx, const SearchPlan& pl, hipStream
   HIP_TRY(ctx, launch_window_table(o->d_runs, (int64_t)ref.runs.size(), o->d_contigs, o->d_win_base, (int)ref.contigs.size(), nw,
                                    pl.p.window_size, pl.step, o->d_win, stream));
   o->win_W = pl.p.window_size; o->win_step = pl.step;
+  return CALITAS_OK;
+}
+
+// Per contig the index of its first bin (binned.hpp), for the plan's bin size; lives with the reference like the window table.
+static int ensure_bin_base(calitas_ctx* ctx, SearchPlan& pl, hipStream_t stream) {
+  calitas_ctx* o = ref_owner(ctx);
+  if (!pl.bin_shift) return CALITAS_OK;
+  const PackedRef& ref = o->ref;
+  if (o->bin_shift != pl.bin_shift || o->bin_base.size() != ref.contigs.size() + 1) {
+    std::vector<uint32_t> bb(ref.contigs.size() + 1, 0);
+    uint64_t acc = 0;
+    for (size_t c = 0; c < ref.contigs.size(); c++) { bb[c] = (uint32_t)acc; acc += (ref.contigs[c].len >> pl.bin_shift) + 1; }
+    bb[ref.contigs.size()] = (uint32_t)acc;
+    if (acc >= 0x7FFFFFFFull) { pl.bin_shift = 0; return CALITAS_OK; }
+    (void)hipFree(o->d_bin_base); o->d_bin_base = nullptr; o->bin_shift = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&o->d_bin_base, bb.size() * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemcpyAsync(o->d_bin_base, bb.data(), bb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));                                                                              // bb is a local
+    o->bin_base.swap(bb); o->bin_shift = pl.bin_shift;
+  }
+  if (pl.n_bins == 0) plan_bins(o, pl, pl.p.chrom_index >= 0 ? pl.p.chrom_index : 0, pl.p.chrom_index >= 0 ? pl.p.chrom_index + 1 : (int)ref.contigs.size());
   return CALITAS_OK;
 }
 
@@ -351,7 +383,10 @@ constexpr int kAlignBlocks = 1024, kTraceBlocks = 2048;
 // calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
 // (dev->valid), and *out stays NULL.  prelaunched: the scan stage of this lane was queued by the caller on another stream
 // and ctx->stream already waits for it; an overflow then fails the call instead of retrying.
-static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** out, uint64_t* n_out, DeviceSel* dev, bool prelaunched) {
+// resume: the stages through trace_kernel have run and the lane's counters are in ctx->h_counters (the binned tail declined, see
+// lane_rows_binned): the first round starts at the per-window filter.
+static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** out, uint64_t* n_out, DeviceSel* dev, bool prelaunched,
+                      bool resume = false) {
   const auto t_call = std::chrono::steady_clock::now();
   *out = nullptr; *n_out = 0;
   const calitas_params_t& p = pl.p;
@@ -373,11 +408,12 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   const bool device_filter = !std::getenv("CALITAS_HOST_FILTER") && select_supported(pl.win_n, p.window_size, n_guides);
   // A small reference usually yields few alignments: the one-workgroup filter is queued right behind trace_kernel and reads the counts
   // on the device, so the host hears about the counters and the filter's result in one round trip (select_run_speculative).
-  const bool speculate = !prelaunched && device_filter && pl.bases <= (64ull << 20);
+  const bool speculate = !prelaunched && !resume && device_filter && pl.bases <= (64ull << 20);
   const RawAln* d_spec = nullptr;
   uint32_t spec_counts[3] = {0, 0, 0};
   bool spec_done = false;
-  for (;;) {
+  for (bool first_round = true;; first_round = false) {
+    if (!(resume && first_round)) {
     if (!prelaunched) {
       int rc = launch_scan_stage(ctx, pl, ctx->stream);
       if (rc) return rc;
@@ -400,6 +436,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     g_marks.mark("counts1");
     for (int k = 0; k < 8; k++) ctx->h_counters[k] = ctx->mbox.host[1 + k];
     if (speculate) { for (int k = 0; k < 3; k++) spec_counts[k] = ctx->mbox.host[9 + k]; spec_done = !(spec_counts[1] & SELECT_FLAG_RETRY); }
+    }
     n_rec = ctx->h_counters[0]; n_raw = ctx->h_counters[1];
     const uint32_t n_items = ctx->h_counters[3];
     if (ctx->h_counters[2] != 0) return fail(ctx, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
@@ -678,6 +715,8 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
     if (rows_done) HIP_TRY(lane, calitas_spin_sync(rows_done)); else HIP_TRY(lane, calitas_spin_sync(lane->stream));
     g_marks.mark("rows-done");
     const auto t0 = std::chrono::steady_clock::now();
+    if (lane->binned_late_check && lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)
+      return fail(lane, CALITAS_EHIP, "binned rows kernel: a row's length differs between the two kernels (internal error)");
     if (owner->dma.copy_to_host(dst, src, n)) {
       g_marks.mark("copied");
       if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -702,6 +741,8 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
     HIP_TRY(lane, hipEventRecord(lane->ev[7], cs));
   }
   HIP_TRY(lane, calitas_spin_sync(lane->ev[7]));
+  if (lane->binned_late_check && lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)
+    return fail(lane, CALITAS_EHIP, "binned rows kernel: a row's length differs between the two kernels (internal error)");
   float ms = 0;
   (void)hipEventElapsedTime(&ms, lane->ev[6], lane->ev[7]);
   if (ms_out) *ms_out = ms;
@@ -720,6 +761,32 @@ struct LaneText {
   calitas_timing_t tm{};
 };
 
+// Whether this lane's search takes the binned tail (binned.hpp): one guide on the device path, a window size the bins handle, not
+// a search planned as dense (rec_hint: per-contig passes of a permissive PAM-less search would crowd every bin), and not one at least
+// as permissive as the last the bins declined on this reference.
+static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
+  const calitas_ctx* own = ref_owner(lane);
+  if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0 || pl.gw_lo != 0 || pl.gw_hi != ~0ull) return false;
+  if (std::getenv("CALITAS_HOST_FILTER") || std::getenv("CALITAS_HOST_HITS")) return false;
+  if (const char* e = std::getenv("CALITAS_BINNED")) if (std::atoi(e) == 0) return false;     // A/B: the general kernels
+  if (pl.p.max_overlap < 1 || own->ref.contigs.size() >= (1u << 18) - 1) return false;
+  const GuideDev& g = pl.gd[0];
+  if (own->bin_decl_pams == g.n_pams && own->bin_decl_L == g.L && g.min_guide_score <= own->bin_decl_min_score) return false;
+  return true;
+}
+
+// The per-call constants of a lane's row stage -- and the cleared scratch of the bins when the lane takes the binned tail --, queued on
+// its stream ahead of its kernels (callers that queue a wait for a scan on that stream do this first).
+static hipError_t queue_row_constants(calitas_ctx* lane, const SearchPlan& pl, const RowStrings& rs) {
+  hipError_t e = hits_prepare(&lane->hits, rs, lane->stream);
+  if (e == hipSuccess && binned_wanted(lane, pl)) e = binned_prepare(&lane->binned, pl.n_bins, lane->stream);
+  return e;
+}
+
+struct LaneText;
+static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, LaneText& lt, bool prepared,
+                            bool* declined);
+
 // One lane from the scan stage (queued here, or already queued by the caller) to its finished rows.
 // hits_prepared: the caller queued hits_prepare on the lane's stream already -- *before* the stream's wait for the scan, so that
 // the constants are in place while the scan runs instead of sitting between the end of the scan and align_kernel.
@@ -732,8 +799,18 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   DeviceSel dev;
   calitas_aln_t* alns = nullptr;
   uint64_t n_alns = 0;
+  bool resume = false;
+  lane->binned_late_check = false;
+  if (binned_wanted(lane, pl)) {
+    bool declined = false;
+    int rc = lane_rows_binned(lane, pl, prelaunched, rs, lt, hits_prepared, &declined);
+    if (rc || !declined) return rc;
+    // the bins declined: the raw alignments are where the general kernels expect them, the lane's counters in h_counters
+    resume = true;
+    hits_prepared = false;                                   // binned_run consumed the row constants
+  }
   if (!hits_prepared && !std::getenv("CALITAS_HOST_HITS")) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // ahead of the lane's kernels
-  int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched);
+  int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched, resume);
   if (rc) return rc;
   lt.tm = lane->timing;
   if (dev.valid && !std::getenv("CALITAS_HOST_HITS")) {
@@ -780,6 +857,86 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   lt.host_rows.assign(text + rs.header.size());
   calitas_free(text);
   lt.bytes = lt.host_rows.size(); lt.rows = rows;
+  return CALITAS_OK;
+}
+
+// The binned tail of one lane: scan (unless queued by the caller) -> align_kernel -> trace_kernel (alignments into the bins as well)
+// -> bin_hits_kernel -> bin_rows_kernel, ONE host round trip (the rows kernel posts counters, rows, bytes and flags as it starts).
+// prepared: the caller queued hits_prepare and binned_prepare on the lane's stream already, ahead of its wait for the scan.
+// *declined: a bin was crowded / a repeat outran the halo / a lane buffer overflowed: nothing is lost, the general kernels take over.
+static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, LaneText& lt, bool prepared,
+                            bool* declined) {
+  calitas_ctx* own = ref_owner(lane);
+  const PackedRef& ref = own->ref;
+  const calitas_params_t& p = pl.p;
+  const GuideHost& gh = pl.gh[0];
+  *declined = false;
+  HIP_TRY(lane, hipSetDevice(lane->device));
+  if (!prelaunched) {
+    int rc = lane_prepare(lane, pl);
+    if (rc) return rc;
+    rc = ensure_window_table(lane, pl, lane->stream);
+    if (rc) return rc;
+  }
+  if (!prepared) HIP_TRY(lane, queue_row_constants(lane, pl, rs));
+  if (lane->hits_names_serial != own->ref_serial) {
+    HIP_TRY(lane, hits_set_names(&lane->hits, ref.names, lane->stream));
+    lane->hits_names_serial = own->ref_serial;
+  }
+  int max_pam = 0;
+  for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
+  const BinnedGeometry geo{own->d_bin_base, (int)ref.contigs.size(), pl.bin_first, pl.n_bins, (uint32_t)pl.bin_shift};
+  const BinnedParams bp{p.window_size, pl.step, pl.max_total, p.max_overlap, pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam};
+  const HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
+  const auto t_call = std::chrono::steady_clock::now();
+  if (!prelaunched) {
+    int rc = launch_scan_stage(lane, pl, lane->stream);
+    if (rc) return rc;
+  }
+  ScanArgs sa; AlignArgs aa;
+  fill_kernel_args(lane, pl, sa, aa);
+  binned_fill_align_args(lane->binned, geo, aa);
+  HIP_TRY(lane, launch_align(aa, kAlignBlocks, lane->stream));
+  HIP_TRY(lane, launch_trace(aa, kTraceBlocks, lane->stream, lane->ev[2]));
+  HIP_TRY(lane, binned_run(lane->binned, &lane->hits, geo, hr, lane->d_raw, lane->d_guides, own->d_win_base, own->d_win, bp, lane->d_counters, lane->stream,
+                           &lane->mbox, lane->ev[3], lane->ev[4], lane->ev[5]));
+  g_marks.mark("queued-binned");
+  HIP_TRY(lane, mailbox_wait(lane->mbox, lane->stream));
+  g_marks.mark("binned-counts");
+  for (int k = 0; k < 8; k++) lane->h_counters[k] = lane->mbox.host[BIN_BOX_COUNTERS + k];
+  const uint32_t n_rec = lane->h_counters[0], n_raw = lane->h_counters[1], n_items = lane->h_counters[3];
+  if (lane->h_counters[2] != 0) return fail(lane, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
+  uint32_t flags = lane->mbox.host[BIN_BOX_FLAGS];
+  const bool overflow = n_rec > lane->rec_cap || n_raw > lane->raw_cap || n_items > lane->item_cap;
+  if (overflow || (flags & ~BIN_FLAG_TEXT)) {
+    if (!overflow) {   // a property of this search on this reference: remember it
+      own->bin_decl_L = pl.gd[0].L; own->bin_decl_pams = pl.gd[0].n_pams; own->bin_decl_min_score = pl.gd[0].min_guide_score;
+      if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] binned tail declined (flags %u): finishing on the general kernels\n", flags);
+    }
+    HIP_TRY(lane, calitas_spin_sync(lane->stream));          // the rows kernel returns at once; nothing of it may linger over the retry
+    *declined = true;
+    return CALITAS_OK;
+  }
+  uint64_t bytes = (uint64_t)lane->mbox.host[BIN_BOX_BYTES] | ((uint64_t)lane->mbox.host[BIN_BOX_BYTES + 1] << 32);
+  if (flags & BIN_FLAG_TEXT) {                               // the text buffer was a guess: grow it, the rows kernel once more
+    HIP_TRY(lane, binned_rerun_rows(lane->binned, &lane->hits, geo, hr, lane->d_raw, lane->d_guides, own->d_win_base, own->d_win, bp, lane->d_counters, bytes,
+                                    lane->stream, &lane->mbox, lane->ev[5]));
+    HIP_TRY(lane, mailbox_wait(lane->mbox, lane->stream));
+    flags = lane->mbox.host[BIN_BOX_FLAGS];
+    if (flags) return fail(lane, CALITAS_EHIP, "binned rows kernel: flags " + std::to_string(flags) + " after the text buffer was grown (internal error)");
+    HIP_TRY(lane, hipEventRecord(lane->ev[4], lane->stream));   // (keeps the pair ev[4] / ev[5] ordered for the timing query; the rerun is the rare path)
+  }
+  calitas_timing_t tm{};
+  tm.bases_scanned = pl.bases; tm.packed_bytes = (pl.bases + 3) / 4;
+  tm.scan_records = n_rec; tm.raw_alignments = n_raw; tm.candidate_columns = lane->h_counters[4];
+  tm.accepted_alignments = lane->mbox.host[BIN_BOX_ACCEPTED];
+  kernel_times(lane, tm);                                    // scan, align + trace, everything up to the end of bin_hits_kernel
+  tm.binned_lanes = 1;
+  lane->timing = tm;
+  lt.tm = tm;
+  lt.d_text = binned_text(lane->hits); lt.bytes = bytes; lt.rows = lane->mbox.host[BIN_BOX_ROWS];
+  lane->binned_late_check = true;
+  (void)t_call;
   return CALITAS_OK;
 }
 
@@ -905,6 +1062,7 @@ static void release_scratch(calitas_ctx* ctx) {
   select_destroy(ctx->select); ctx->select = nullptr;
   hits_destroy(ctx->hits); ctx->hits = nullptr; ctx->hits_names_serial = ~0ull;
   hits_destroy(ctx->hits_alt); ctx->hits_alt = nullptr; ctx->hits_alt_names_serial = ~0ull;
+  binned_destroy(ctx->binned); ctx->binned = nullptr;
 }
 
 // calitas_search_hits when one pass does not fit the device (a PAM-less search at max-guide-diffs 8 on a whole genome keeps 2.4 KB of
@@ -925,6 +1083,8 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = ensure_bin_base(ctx, pl, ctx->stream);
+  if (rc) return rc;
   if (!ctx->copy_stream) {   // the fallback of the SDMA copy must not share ctx->stream with the helper thread's next pass (text_to_host)
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -962,6 +1122,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
         const uint32_t tile_hi = c + 1 < n_contigs ? (uint32_t)(ref.contigs[c + 1].gbase / ref.tile) : (uint32_t)ref.tiles.size();
         q.n_tiles = tile_hi - q.tile_lo;
         q.bases = ref.contigs[c].len; q.win_lo = win_lo; q.win_n = win_n;
+        plan_bins(ctx, q, c, c + 1);
         // buffers sized from the estimate that sent this search here: no retry round per contig
         if (ctx->seq_recs_per_tile > 0 && ctx->seq_pams == pl.gd[0].n_pams && ctx->seq_L == pl.gd[0].L && pl.gd[0].min_guide_score == ctx->seq_min_score)
           q.rec_hint = (uint64_t)(ctx->seq_recs_per_tile * (double)q.n_tiles) + 1;
@@ -1072,6 +1233,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
     tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
     tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+    tm.binned_lanes += lt.tm.binned_lanes;
     {
       std::lock_guard<std::mutex> lk(mu);
       sl.state = 0;
@@ -1243,6 +1405,9 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   SearchPlan pl;
   int rc = plan_search(ctx, 1, guide, params, pl);
   if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = ensure_bin_base(ctx, pl, ctx->stream);                // (built once per reference and window size)
+  if (rc) return rc;
   const PackedRef& ref = ctx->ref;
   // The constant pieces of a row.  A chunked search builds them after its scans are queued: nothing on the device needs them before
   // the first range's rows, and the first scan should not wait for string formatting on the host.
@@ -1326,6 +1491,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       q.bases = 0; q.win_lo = 0; q.win_n = 0;
       for (int k = 0; k < ranges[c].first; k++) q.win_lo += window_count(ref.contigs[k].len, q.step);
       for (int k = ranges[c].first; k < ranges[c].second; k++) { q.bases += ref.contigs[k].len; q.win_n += window_count(ref.contigs[k].len, q.step); }
+      plan_bins(ctx, q, ranges[c].first, ranges[c].second);
       rc = lane_prepare(lanes[c], q);
       if (rc) ctx->err = lanes[c]->err;
     }
@@ -1355,7 +1521,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     g_marks.mark("row-strings");
     for (size_t c = 0; c < K && !rc; c++) {
       // the row constants of a range go onto its stream before the wait for its scan: in place while the scan runs
-      if (device_rows) rc = hip_rc(hits_prepare(&lanes[c]->hits, rs, lanes[c]->stream), "hits_prepare");
+      if (device_rows) rc = hip_rc(queue_row_constants(lanes[c], plans[c], rs), "hits_prepare");
       if (!rc) rc = hip_rc(hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0), "hipStreamWaitEvent");
     }
     g_marks.mark("rows-prepared");
@@ -1459,7 +1625,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
     tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
     tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries;
-    tm.hits_kernel_ms += lt.tm.hits_kernel_ms; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+    tm.hits_kernel_ms += lt.tm.hits_kernel_ms; tm.hits_copy_ms += lt.tm.hits_copy_ms; tm.binned_lanes += lt.tm.binned_lanes;
   }
   text[total] = 0;
   tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = (uint32_t)parts.size();
@@ -1511,6 +1677,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
       return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < n_guides; i++) { int rc = ensure_bin_base(ctx, plans[i], ctx->stream); if (rc) return rc; }
   int rc = ensure_lanes(ctx, (size_t)n_lanes);
   if (rc) return rc;
   for (int l = 0; l < n_lanes && !rc; l++) { rc = lane_prepare(ctx->lanes[l], plans[0]); if (rc) ctx->err = ctx->lanes[l]->err; }
@@ -1536,7 +1703,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
           {
             // the previous guide of this lane is completely done (its text was copied before the loop went on), so the
             // lane's buffers are free for this scan
-            if (device_rows) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // before the wait below is queued
+            if (device_rows) HIP_TRY(lane, queue_row_constants(lane, pl, rs));   // before the wait below is queued
             std::lock_guard<std::mutex> lk(scan_mu);
             int r = launch_scan_stage(lane, pl, ctx->scan_stream);   // records lane->scan_done
             if (r) return r;
@@ -1588,7 +1755,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
     tm.scan_kernel_ms += t.scan_kernel_ms; tm.align_kernel_ms += t.align_kernel_ms; tm.gpu_total_ms += t.gpu_total_ms;
     tm.bases_scanned += t.bases_scanned; tm.packed_bytes += t.packed_bytes; tm.scan_records += t.scan_records;
     tm.candidate_columns += t.candidate_columns; tm.raw_alignments += t.raw_alignments; tm.accepted_alignments += t.accepted_alignments;
-    tm.retries += t.retries; tm.hit_rows += t.hit_rows; tm.hits_bytes += t.hits_bytes;
+    tm.retries += t.retries; tm.hit_rows += t.hit_rows; tm.hits_bytes += t.hits_bytes; tm.binned_lanes += t.binned_lanes;
   }
   tm.lanes = (uint32_t)n_lanes;
   ctx->timing = tm;

@@ -118,7 +118,8 @@ typedef struct {
   uint64_t hit_rows;
   uint64_t hits_bytes;
   uint32_t contig_passes;        /* calitas_search_hits in one-pass-per-contig mode: passes run (0 otherwise) */
-  uint32_t reserved;
+  uint32_t binned_lanes;         /* calitas_search_hits*: contig ranges / passes / guides whose tail (per-window filter ... rows) ran on the
+                                  * per-bin kernels (binned.hpp); the others ran on the general kernels (same text) */
 } calitas_timing_t;
 
 /* Context ------------------------------------------------------------------------------------------------------- */

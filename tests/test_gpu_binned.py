@@ -1,0 +1,163 @@
+"""GPU: the per-bin tail (binned.hip) -- per-window filter, coordinates, ReferenceHit.sort, removeOverlaps and rows for the hits whose
+coordinate_start lies in an 8-kb bin, from the bin and the edges of its neighbours -- against the oracle and against the general
+device kernels it stands in front of, with the cases that stress what is new: hits and overlap clusters on bin boundaries, windows that
+straddle them, repeats long enough for a bin to decline (the call must then finish on the general kernels with the same text), the
+text buffer's regrow path."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fasta_util import write_fasta
+
+pytestmark = pytest.mark.gpu
+
+SKIP_COLS = {"aligner_version", "time_stamp"}
+BIN = 8192
+GUIDE = "CTTGCCCCACAGGGCAGTAAnrg"
+
+
+@pytest.fixture(scope="module")
+def C():
+    import calitas_amd
+    return calitas_amd
+
+
+def strip(rows):
+    return [{k: v for k, v in r.items() if k not in SKIP_COLS} for r in rows]
+
+
+def both_paths(C, fa, guide, monkeypatch, expect_binned=True, **pk):
+    """(rows, binned_lanes): the default call and the same call on the general kernels return the same text."""
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        monkeypatch.delenv("CALITAS_BINNED", raising=False)
+        text, n = C.SearchReference(guide=guide, guide_id="a", context=ctx, **pk).run("v0", "stamp")
+        lanes = ctx.timing()["binned_lanes"]
+        monkeypatch.setenv("CALITAS_BINNED", "0")
+        text0, n0 = C.SearchReference(guide=guide, guide_id="a", context=ctx, **pk).run("v0", "stamp")
+        assert ctx.timing()["binned_lanes"] == 0
+        monkeypatch.delenv("CALITAS_BINNED")
+    finally:
+        ctx.close()
+    assert text == text0 and n == n0
+    if expect_binned is not None:
+        assert (lanes > 0) == expect_binned, lanes
+    return C.read_hits(text), lanes
+
+
+def planted(rng, length, sites, site="CTTGCCCCACAGGGCAGTAATGG"):
+    """Random contig with (position, edits, reverse) sites planted: the site itself, mutated at `edits` protospacer positions."""
+    seq = rng.choice(list(b"ACGT"), size=length).astype(np.uint8)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    for pos, edits, rev in sites:
+        s = bytearray(site.encode())
+        for k in rng.choice(20, size=edits, replace=False):
+            s[k] = ord("ACGT"[("ACGT".index(chr(s[k])) + 1) % 4])
+        if rev:
+            s = bytearray(comp[c] for c in reversed(s))
+        seq[pos:pos + len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+    return seq.tobytes().decode()
+
+
+def test_hits_and_clusters_on_bin_boundaries(C, tmp_path, monkeypatch):
+    """Sites planted around every bin boundary of two contigs: starting just left of it, just right of it, straddling it, on both
+    strands, in overlapping pairs (one of each pair is removed by removeOverlaps, whichever bin its partner falls into), and around the
+    window starts nearest the boundary."""
+    rng = np.random.default_rng(1234)
+    sites = []
+    for b in (BIN, 2 * BIN, 3 * BIN):
+        for d in (-40, -23, -22, -12, -1, 0, 1, 7, 30):
+            sites.append((b + d, int(rng.integers(0, 4)), bool(rng.integers(0, 2))))
+    c1 = planted(rng, 3 * BIN + 9000, sites[:18] + [(3 * BIN + 5, 1, False)])
+    # overlapping pairs: the same site twice, 6 / 12 bases apart, across and next to a boundary (a fresh contig: no other sites around)
+    pairs = []
+    for b, off in ((BIN, -30), (BIN, -9), (BIN, 3), (2 * BIN, -15), (2 * BIN, 0)):
+        pairs += [(b + off, 0, False), (b + off + 29, 1, False)]            # overlap of the full alignments: 23 + 23 - 29 < 10: both stay
+    c2 = planted(rng, 2 * BIN + 5000, pairs + [(2 * BIN - 971 * 3 + k, 2, True) for k in (-20, 5)])
+    # tandem copies 8 bases apart (they overlap by more than maxOverlap): chains that cross the boundary
+    chain = [(BIN - 60 + 8 * k, 0, False) for k in range(14)]
+    c3 = planted(rng, BIN + 4000, [], site="A")                              # placeholder, filled below
+    seq3 = bytearray(c3.encode())
+    unit = b"CTTGCCCCACAGGGCAGTAATGG"
+    for pos, _, _ in chain:
+        seq3[pos:pos + len(unit)] = unit
+    fa = write_fasta(str(tmp_path / "edges.fa"), [("c1", c1), ("c2", c2), ("c3", seq3.decode()), ("short", "ACGT" * 30)])
+    for pk in (dict(max_gaps_between_guide_and_pam=2), dict(max_guide_diffs=3, max_overlap=3), dict(max_overlap=40)):
+        # (with -O 40 the chain of tandem copies keeps more alignments than a bin's wave holds: either tail may finish that call)
+        rows, lanes = both_paths(C, fa, GUIDE, monkeypatch, expect_binned=None if pk.get("max_overlap", 10) > 10 else True, **pk)
+        _, want, _ = O.search_reference(fa, GUIDE, "a", d=pk.get("max_guide_diffs", 5), g=pk.get("max_gaps_between_guide_and_pam", 3),
+                                        O=pk.get("max_overlap", 10), threads=4)
+        assert len(want) > 10
+        assert strip(rows) == strip(want), pk
+        assert {r["chromosome"] for r in rows} >= {"c1", "c2", "c3"}
+
+
+def test_long_repeat_declines_and_the_general_kernels_finish(C, tmp_path, monkeypatch):
+    """A 3-kb tandem array of the site itself: hundreds of alignments in one bin and a chain of overlapping hits longer than the
+    halo.  The bins decline (crowded / halo), the general kernels finish the call with the oracle's rows; the context remembers it
+    (the next, equally permissive search does not try the bins again) and a stricter search takes the bins again."""
+    rng = np.random.default_rng(77)
+    base = rng.choice(list(b"ACGT"), size=2 * BIN + 3000).astype(np.uint8)
+    unit = np.frombuffer(b"CTTGCCCCACAGGGCAGTAATGGAC", dtype=np.uint8)
+    rep = np.tile(unit, 130)                                             # 3250 bases
+    base[BIN - 1700:BIN - 1700 + len(rep)] = rep
+    fa = write_fasta(str(tmp_path / "repeat.fa"), [("r1", base.tobytes().decode()), ("r2", planted(rng, 40000, [(1000, 1, False), (33000, 2, True)]))])
+    rows, lanes = both_paths(C, fa, GUIDE, monkeypatch, expect_binned=False, max_gaps_between_guide_and_pam=2)
+    _, want, _ = O.search_reference(fa, GUIDE, "a", g=2, threads=4)
+    assert len(want) > 100 and strip(rows) == strip(want)
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        sr = C.SearchReference(guide=GUIDE, guide_id="a", context=ctx, max_gaps_between_guide_and_pam=2)
+        t1, _ = sr.run("v0", "stamp")
+        assert ctx.timing()["binned_lanes"] == 0
+        t2, _ = sr.run("v0", "stamp")                                    # remembered: straight to the general kernels
+        assert ctx.timing()["binned_lanes"] == 0 and t2 == t1
+        strict = C.SearchReference(guide="GTGACTTGAAGTCTCAGTATAnrg", guide_id="b", context=ctx, max_guide_diffs=2)
+        strict.run("v0", "stamp")                                        # another guide length: not covered by the memory
+        assert ctx.timing()["binned_lanes"] == 1
+    finally:
+        ctx.close()
+
+
+def test_text_buffer_regrow(C, tmp_path, monkeypatch):
+    """The rows kernel writes into a buffer sized by a guess; a text that does not fit makes it return at once (BIN_FLAG_TEXT), the
+    host grows the buffer and launches it again.  Forced with a 1-KB first guess."""
+    rng = np.random.default_rng(5)
+    sites = [(int(p), int(rng.integers(0, 5)), bool(rng.integers(0, 2))) for p in rng.integers(200, 95000, size=80)]
+    fa = write_fasta(str(tmp_path / "regrow.fa"), [("c", planted(rng, 100000, sites))])
+    monkeypatch.setenv("CALITAS_BINNED_TEXT_KB", "1")
+    rows, lanes = both_paths(C, fa, GUIDE, monkeypatch, max_gaps_between_guide_and_pam=2)
+    _, want, _ = O.search_reference(fa, GUIDE, "a", g=2, threads=4)
+    assert len(want) > 40 and strip(rows) == strip(want)
+
+
+def test_lanes_and_batch_take_the_binned_tail(C, tmp_path, monkeypatch):
+    """Contig ranges (lanes) and a guide batch: every lane / guide reports the binned tail, same bytes as one pass."""
+    rng = np.random.default_rng(9)
+    contigs = []
+    for ci, length in enumerate((70000, 40000, 90000, 33000)):
+        sites = [(int(p), int(rng.integers(0, 5)), bool(rng.integers(0, 2))) for p in rng.integers(100, length - 100, size=25)]
+        contigs.append(("k%d" % ci, planted(rng, length, sites)))
+    fa = write_fasta(str(tmp_path / "lanes.fa"), contigs)
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        sr = C.SearchReference(guide=GUIDE, guide_id="a", context=ctx, max_gaps_between_guide_and_pam=2)
+        one, _ = sr.run("v0", "stamp")
+        assert ctx.timing()["binned_lanes"] == 1
+        monkeypatch.setenv("CALITAS_CHUNKS", "3")
+        three, _ = sr.run("v0", "stamp")
+        assert ctx.timing()["binned_lanes"] == 3 and three == one
+        monkeypatch.delenv("CALITAS_CHUNKS")
+        G = [C.Guide(GUIDE), C.Guide("GTGACTTGAAGTCTCAGTATnrg"), C.Guide(GUIDE)]
+        res = ctx.search_hits_batch(G, ["a", "b", "a"], C.make_params(max_gaps_between_guide_and_pam=2), "v0", "stamp")
+        assert ctx.timing()["binned_lanes"] == 3
+        assert res[0][0] == one and res[2][0] == one
+    finally:
+        ctx.close()
+    _, want, _ = O.search_reference(fa, GUIDE, "a", g=2, threads=4)
+    assert strip(C.read_hits(one)) == strip(want)

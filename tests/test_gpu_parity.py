@@ -24,6 +24,9 @@ def C():
     return calitas_amd
 
 
+PATHS = []   # binned_lanes of every fused call of product_rows (which tail ran): see test_most_searches_take_the_binned_tail
+
+
 def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
     pk = dict(window_size=kw.get("window_size", 1000), max_guide_diffs=kw.get("d", 5), max_pam_mismatches=kw.get("p", 1),
               max_gaps_between_guide_and_pam=kw.get("g", 3), max_total_diffs=kw.get("D"), max_overlap=kw.get("O", 10),
@@ -37,10 +40,19 @@ def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
     ctx.set_reference_fasta(fasta)
     try:
         text, n = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, **pk).run("v0", "stamp")
+        PATHS.append(ctx.timing()["binned_lanes"])
         text2, n2 = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, two_stage=True, **pk).run("v0", "stamp")
+        # ... and so must the general device kernels (select.hip / hits.hip), which the per-bin kernels (binned.hip) stand in front of
+        os.environ["CALITAS_BINNED"] = "0"
+        try:
+            text3, n3 = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, **pk).run("v0", "stamp")
+            assert ctx.timing()["binned_lanes"] == 0
+        finally:
+            del os.environ["CALITAS_BINNED"]
     finally:
         ctx.close()
-    assert n == n2
+    assert n == n2 == n3
+    assert text3 == text, "binned and general device kernels differ"
     if text != text2:
         a, b = text.splitlines(), text2.splitlines()
         diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y][:2]
@@ -554,3 +566,11 @@ def test_search_hits_stream(C, tmp_path, monkeypatch):
         assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp", decode="bytes") == (want, n)
     finally:
         ctx.close()
+
+
+def test_most_searches_take_the_binned_tail():
+    """Which tail finished the fused calls of this module's product_rows (calitas_timing_t.binned_lanes): the per-bin kernels must be
+    what the parity suite exercises, not a path that always declines.  (The dense / crowded cases are expected to decline.)"""
+    assert len(PATHS) >= 15
+    taken = sum(1 for x in PATHS if x > 0)
+    assert taken >= 0.7 * len(PATHS), (taken, len(PATHS), PATHS)
