@@ -121,7 +121,7 @@ static void free_reference_device(calitas_ctx* c) {
   if (c->device < 0) return;
   (void)hipFree(c->d_codes); (void)hipFree(c->d_planes); (void)hipFree(c->d_mask); (void)hipFree(c->d_runs); (void)hipFree(c->d_contigs); (void)hipFree(c->d_tiles); (void)hipFree(c->d_tile_list); (void)hipFree(c->d_win_base); (void)hipFree(c->d_win);
   c->d_win_base = nullptr; c->d_win = nullptr; c->win_cap = 0; c->win_W = c->win_step = 0;
-  (void)hipFree(c->d_bin_base); c->d_bin_base = nullptr; c->bin_shift = 0; c->bin_base.clear(); c->bin_decl_pams = -1;
+  (void)hipFree(c->d_bin_base); c->d_bin_base = nullptr; (void)hipFree(c->d_bin_contig); c->d_bin_contig = nullptr; c->bin_shift = 0; c->bin_base.clear(); c->bin_decl_pams = -1;
   c->d_codes = c->d_mask = nullptr; c->d_planes = nullptr; c->d_runs = nullptr; c->d_contigs = nullptr; c->d_tiles = nullptr; c->d_tile_list = nullptr;
 }
 

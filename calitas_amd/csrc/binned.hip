@@ -33,9 +33,10 @@ namespace calitas {
 
 namespace {
 
-constexpr int BIN_WAVES = 4;            // waves (= bins) per workgroup
+constexpr int BIN_WAVES = 1;            // waves (= bins) per workgroup: waves never wait for each other, and a one-wave workgroup gives its slot back when its bin is done
 constexpr uint32_t ACC_MAX = 64;        // accepted alignments of a bin's context: one per lane
-constexpr uint32_t CHUNK_SHIFT = 8;     // bins per chunk of the two-level sum that places the bins' text
+constexpr uint32_t CHUNK_SHIFT = 8;     // bins per chunk / chunks per super-chunk of the three-level sum that places the bins' text
+constexpr uint32_t SUPER_SHIFT = 2 * CHUNK_SHIFT;
 static_assert(BIN_CAP == 64, "a lane holds one alignment of each of the three bins of a context");
 
 struct BinRow {            // a kept hit of a bin, in final order
@@ -48,6 +49,7 @@ struct BinArgs {
   const uint32_t* bin_idx;           // n_bins x BIN_CAP indices into raw[]
   const uint32_t* bin_count;
   const uint32_t* bin_base;          // per contig (n_contigs + 1), absolute bin indices
+  const uint32_t* bin_contig;        // per bin (absolute index): its contig
   int n_contigs;
   uint32_t bin_first, n_bins, bin_shift;
   const GuideDev* guides;
@@ -58,9 +60,12 @@ struct BinArgs {
   uint32_t* bin_rows;                // per bin: kept rows
   uint32_t* bin_bytes;               // per bin: their text bytes
   unsigned long long* chunk_bytes;   // per 256 bins (zero at launch)
+  unsigned long long* super_bytes;   // per 65536 bins (zero at launch)
   uint32_t* chunk_rows;
   uint32_t* chunk_acc;               // accepted alignments (after the per-window filter) of the windows that start in the chunk's bins
   uint32_t* flags;
+  uint32_t* rows_list;               // bins with rows, in no particular order (one append per wave)
+  uint32_t* rows_count;              // (zero at launch)
 };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -78,16 +83,66 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
-// contig of an absolute bin index: last c with bin_base[c] <= bin
-__device__ __forceinline__ int bin_contig(const uint32_t* bin_base, int n_contigs, uint32_t bin) {
-  int lo = 0, hi = n_contigs;
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bin_base[mid] <= bin) lo = mid; else hi = mid; }
-  return lo;
+// What the filter looks at of a raw alignment of a contig whose windows start at wbase in the window table (select_dev.hpp derive()
+// without the dependent load of win_base[contig]: the contig is the bin's).
+__device__ __forceinline__ Derived derive_in_contig(const RawAln* rp, const GuideDev* guides, uint32_t wbase, const int2* win) {
+  const uint32_t window_k = rp->window_k, guide = rp->guide;
+  const int pam = rp->pam, offset = rp->offset, n_ops = rp->n_ops, dir = rp->dir;
+  const OpCounts oc = count_ops(load_ops_words(rp->ops), n_ops);
+  int diffs = oc.non_eq, gaps = oc.gaps, pam_len = 0;
+  if (pam >= 0) { pam_len = guides[guide].pam_len[pam]; diffs += offset + __popc((unsigned)rp->pam_x); gaps += offset; }
+  const uint32_t wi = wbase + window_k;
+  const int2 w = win[wi];
+  const int start_s = (int)rp->t_start - 1, end_s = (int)rp->t_end_guide + offset + pam_len;
+  Derived d;
+  if (dir == 0) { d.start = w.x + start_s; d.end = w.x + end_s; }
+  else          { d.start = w.y - end_s;   d.end = w.y - start_s; }
+  d.score = rp->score; d.gaps = (uint16_t)gaps; d.edits = (uint16_t)diffs;
+  const uint32_t pam5 = guides[guide].pam5;
+  const uint32_t list = pam5 ? (dir == 1 ? 0u : 1u) : (dir == 0 ? 0u : 1u);   // 0 = forward-strand list (SGA:316)
+  d.ekey = (list << 19) | ((uint32_t)rp->t_end_guide << 6) | ((uint32_t)rp->pad << 4) | (uint32_t)(pam + 1);
+  d.widx = wi;
+  return d;
 }
 
-__global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, MidArgs m) {
+// Length of the middle part of a row = what build_middle computes with ballots, for one lane: the field lengths of RH:210-254 from
+// the alignment's op counts (GA:99-115, 139-183) and the run-length encoding of its cigar.  -1: the row builder does not lay it out.
+__device__ __forceinline__ int middle_length(const RawAln* rp, const HitRec& h, int L, int pam_len, int pu_len, int n_max, int mid_bound) {
+  const int ng = rp->n_ops, pam = rp->pam;
+  const int gap = pam >= 0 ? rp->offset : 0;
+  const uint32_t pam_x = rp->pam_x;
+  const int n = ng + gap + pam_len;
+  const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
+  if (n > n_max || n > MID_COLS || hi - lo > MID_FWD) return -1;
+  const OpsWords ow = load_ops_words(rp->ops);
+  const OpCounts oc = count_ops(ow, ng);
+  const int utn = oc.not_ins - oc.lead_d - oc.trail_d;                 // target bases under the first .. last protospacer column (GA:111-115)
+  const int gmm = oc.non_eq - oc.gaps, pam_mm = pam >= 0 ? __popc(pam_x) : 0;   // 'X' columns by the case of the query base (GA:103, 106)
+  const int ggp = oc.gaps + gap;                                       // every gap column has a protospacer base on one side (GA:104, 168-182)
+  const int edits = oc.non_eq + gap + pam_mm;                          // GA:101
+  // Cigar.coalesce + toString over the columns: guide part (aligner order = traceback order reversed), the gap, the PAM; the number of
+  // runs and of two-digit run lengths does not depend on the direction the columns are read in (5' PAM)
+  int runs = 0, long_runs = 0, prev = -1, len = 0;
+  for (int k = 0; k < n; k++) {
+    const int op = k < ng ? ow.op(ng - 1 - k) : k < ng + gap ? 3 : (int)((pam_x >> ((k - ng - gap) & 15)) & 1u);
+    if (op != prev) { if (len >= 10) long_runs++; runs++; len = 0; prev = op; }
+    len++;
+  }
+  if (len >= 10) long_runs++;
+  const int cigar_len = 2 * runs + long_runs;
+  auto digits = [](int v) {
+    const unsigned u = (unsigned)(v < 0 ? -v : v);
+    return (v < 0 ? 1 : 0) + 1 + (u >= 10u) + (u >= 100u) + (u >= 1000u) + (u >= 10000u) + (u >= 100000u) + (u >= 1000000u) + (u >= 10000000u) +
+           (u >= 100000000u) + (u >= 1000000000u);
+  };
+  const int total = MID_FIELDS + digits(h.gstart) + digits(h.gend) + 1 + utn + 10 + 10 + pu_len + digits(h.score) + digits(gmm) + digits(ggp) +
+                    digits(gmm + ggp) + digits(pam_mm) + digits(edits) + 3 * n + 8 + 8 + cigar_len + digits(L) + digits(utn);
+  return total > mid_bound ? -1 : total;
+}
+
+// One wave per bin, for the bins bin_hits_small_kernel listed (n_list on the device; the grid is fixed and strides over the list).
+__global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, MidArgs m, const uint32_t* list, const uint32_t* n_list) {
   CALITAS_TAIL_PRIO();
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_blob[];     // the constant strings (queries: the case of a column's query base)
   __shared__ int32_t k_s[BIN_WAVES][ACC_MAX], k_e[BIN_WAVES][ACC_MAX];  // kept intervals of the window being filtered
   __shared__ uint32_t acc[BIN_WAVES][ACC_MAX];                          // accepted alignments in arrival order: index into raw[]
   // accepted alignments by arrival (t_*) and in ReferenceHit.sort order (s_*)
@@ -95,30 +150,36 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
   __shared__ int32_t s_start[BIN_WAVES][ACC_MAX], s_end[BIN_WAVES][ACC_MAX], s_score[BIN_WAVES][ACC_MAX];
   __shared__ uint8_t t_minus[BIN_WAVES][ACC_MAX], s_cs[BIN_WAVES][ACC_MAX], s_idx[BIN_WAVES][ACC_MAX], s_head[BIN_WAVES][ACC_MAX],
       s_keep[BIN_WAVES][ACC_MAX], s_done[BIN_WAVES][ACC_MAX];
-  for (uint32_t i = threadIdx.x; i < m.blob_bytes; i += 64 * BIN_WAVES) s_blob[i] = (uint8_t)m.blob[i];
-  __syncthreads();
   const int lane = (int)(threadIdx.x & 63);
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t rel = blockIdx.x * BIN_WAVES + wv;                     // bin of this wave, relative to the range
-  if (rel >= a.n_bins) return;
+  const uint32_t n_todo = *n_list;
+  for (uint32_t it = blockIdx.x * BIN_WAVES + wv; it < n_todo; it += gridDim.x * BIN_WAVES) {
+  wave_lds_sync();                                                      // the previous bin of this wave is done with the arrays
+  const uint32_t rel = list[it];                                        // bin of this round, relative to the range
+  if (rel >= a.n_bins) continue;
   const uint32_t b = a.bin_first + rel;
   auto finish = [&](uint32_t n_rows, uint32_t bytes, uint32_t n_acc) {
     if (lane == 0) {
       a.bin_rows[rel] = n_rows; a.bin_bytes[rel] = bytes;
-      if (n_rows) { atomicAdd(a.chunk_rows + (rel >> CHUNK_SHIFT), n_rows); atomicAdd(a.chunk_bytes + (rel >> CHUNK_SHIFT), (unsigned long long)bytes); }
+      if (n_rows) {
+        atomicAdd(a.chunk_rows + (rel >> CHUNK_SHIFT), n_rows); atomicAdd(a.chunk_bytes + (rel >> CHUNK_SHIFT), (unsigned long long)bytes);
+        atomicAdd(a.super_bytes + (rel >> SUPER_SHIFT), (unsigned long long)bytes);
+        a.rows_list[atomicAdd(a.rows_count, 1u)] = rel;
+      }
       if (n_acc) atomicAdd(a.chunk_acc + (rel >> CHUNK_SHIFT), n_acc);
     }
   };
   auto decline = [&](uint32_t why) { if (lane == 0) atomicOr(a.flags, why); finish(0, 0, 0); };
   const uint32_t n_own = a.bin_count[rel];
   const uint32_t n_prev_raw = rel > 0 ? a.bin_count[rel - 1] : 0u;
-  if (n_prev_raw == 0 && n_own == 0) { finish(0, 0, 0); return; }       // no window that could hold a hit of this bin has alignments
-  const int c = bin_contig(a.bin_base, a.n_contigs, b);
+  if (n_prev_raw == 0 && n_own == 0) { finish(0, 0, 0); continue; }       // no window that could hold a hit of this bin has alignments
+  const uint32_t c = a.bin_contig[b];
+  const uint32_t wbase = (uint32_t)a.win_base[c];                       // the contig's first entry of the window table
   const uint32_t bb = b - a.bin_base[c];                                // bin inside its contig
   const bool has_prev = bb > 0 && rel > 0, has_next = b + 1 < a.bin_base[c + 1] && rel + 1 < a.n_bins;
   const uint32_t n_prev = has_prev ? n_prev_raw : 0u, n_next = has_next ? a.bin_count[rel + 1] : 0u;
-  if (n_prev == 0 && n_own == 0) { finish(0, 0, 0); return; }
-  if (n_prev > BIN_CAP || n_own > BIN_CAP || n_next > BIN_CAP) { decline(BIN_FLAG_CROWDED); return; }
+  if (n_prev == 0 && n_own == 0) { finish(0, 0, 0); continue; }
+  if (n_prev > BIN_CAP || n_own > BIN_CAP || n_next > BIN_CAP) { decline(BIN_FLAG_CROWDED); continue; }
   const int64_t lo = (int64_t)bb << a.bin_shift, hi = lo + ((int64_t)1 << a.bin_shift);
   const int64_t ctx_lo = lo - 2 * (int64_t)a.W, ctx_hi = hi + HIT_MAX_LEN;
   // hits are all known from here on; restart points are certain HIT_MAX_LEN further right.  At the start of a contig nothing is missing.
@@ -139,7 +200,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
       const uint32_t window_k = rp->window_k;
       const int64_t ws = (int64_t)window_k * (int64_t)a.step;            // where the window starts on the contig
       if (ws >= ctx_lo && ws < ctx_hi) {
-        const Derived d = derive(rp, a.guides, a.win_base, a.win, 0u, 0u);   // widx = the window's index in the table
+        const Derived d = derive_in_contig(rp, a.guides, wbase, a.win);      // widx = the window's index in the table
         key[q] = order_key(d); st[q] = d.start; en[q] = d.end; ed[q] = d.edits; widx[q] = d.widx; src[q] = idx; wk[q] = window_k;
       }
     }
@@ -189,8 +250,8 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
       }
     }
   }
-  if (over) { decline(BIN_FLAG_CROWDED); return; }
-  if (nA == 0) { finish(0, 0, 0); return; }
+  if (over) { decline(BIN_FLAG_CROWDED); continue; }
+  if (nA == 0) { finish(0, 0, 0); continue; }
   wave_lds_sync();
 
   // ---- 3. GuideAlignment coordinates of the accepted alignments (lane i = arrival i) ----
@@ -202,9 +263,10 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
     h = hit_record(a.raw + hsrc, a.guides, a.win_base, a.win);
     t_start[wv][lane] = h.gstart; t_score[wv][lane] = h.score; t_minus[wv][lane] = (uint8_t)h.minus;
   }
-  if (__ballot(isA && h.gstart < 0) != 0) { decline(BIN_FLAG_RANGE); return; }
+  if (__ballot(isA && h.gstart < 0) != 0) { decline(BIN_FLAG_RANGE); continue; }
   wave_lds_sync();
   // ---- 4. ReferenceHit.sort among them by counting (equal keys keep their arrival order: a stable sort), restart points, walks ----
+  uint32_t my_rank = 0;                                                 // lane i (arrival) -> its sorted position
   if (isA) {
     uint32_t rank = 0;
     for (uint32_t j = 0; j < nA; j++) {
@@ -216,9 +278,10 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
     }
     s_start[wv][rank] = h.gstart; s_end[wv][rank] = h.rh_end; s_score[wv][rank] = h.score; s_cs[wv][rank] = (uint8_t)h.minus;
     s_idx[wv][rank] = (uint8_t)lane;
+    my_rank = rank;
   }
   wave_lds_sync();
-  const uint32_t r = (uint32_t)lane;                                    // from here on a lane is a sorted position
+  const uint32_t r = (uint32_t)lane;                                    // from here on a lane is (also) a sorted position
   bool head = false;
   if (r < nA) {
     head = true;                                                        // hits.hip prep_body on the wave's arrays
@@ -256,38 +319,285 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
   }
   wave_lds_sync();
   const bool mine = r < nA && (int64_t)s_start[wv][r] >= lo && (int64_t)s_start[wv][r] < hi;
-  if (__ballot(mine && !s_done[wv][r]) != 0) { decline(BIN_FLAG_HALO); return; }
+  if (__ballot(mine && !s_done[wv][r]) != 0) { decline(BIN_FLAG_HALO); continue; }
   const unsigned long long kept = __ballot(mine && s_keep[wv][r] != 0);
   const uint32_t n_rows = (uint32_t)__popcll(kept);
-  if (n_rows > BIN_ROWS) { decline(BIN_FLAG_CROWDED); return; }
+  if (n_rows > BIN_ROWS) { decline(BIN_FLAG_CROWDED); continue; }
 
-  // ---- 5. the kept hits of the bin in final order: which alignment, and the length of the row's middle part ----
-  uint32_t bytes = 0, k = 0;
-  bool bad_row = false;
-  for (unsigned long long rest = kept; rest != 0; rest &= rest - 1, k++) {
-    const int pos = __ffsll((long long)rest) - 1;                       // sorted position
-    const int from = (int)s_idx[wv][pos];                               // the lane that holds its HitRec
-    HitRec hh;                                                          // wave-uniform, in scalar registers (build_middle's set_lane wants them there)
-    auto from_lane = [&](int v) { return __builtin_amdgcn_readfirstlane(__shfl(v, from)); };
-    hh.contig = from_lane(h.contig); hh.start = from_lane(h.start); hh.end = from_lane(h.end); hh.gstart = from_lane(h.gstart);
-    hh.gend = from_lane(h.gend); hh.score = from_lane(h.score); hh.rh_end = from_lane(h.rh_end); hh.minus = (uint32_t)from_lane((int)h.minus);
-    const uint32_t rsrc = (uint32_t)from_lane((int)hsrc);
-    const auto* rp = uniform_ptr(a.raw) + rsrc;
-    RowIn rin;
-    const auto* ow = (const __attribute__((address_space(4))) uint32_t*)rp->ops;
-    rin.w0 = ow[0]; rin.w1 = ow[1]; rin.w2 = ow[2]; rin.w3 = ow[3]; rin.w4 = ow[4];
-    rin.n_ops = rp->n_ops; rin.pam = rp->pam; rin.offset = rp->offset; rin.pam_x = rp->pam_x;
-    const auto* gp = uniform_ptr(a.guides) + rp->guide;
-    RowGuide g;
-    g.L = gp->L; g.pam5 = gp->pam5; g.pam_len = rin.pam >= 0 ? gp->pam_len[rin.pam] : 0;
-    const int len = build_middle<false>(nullptr, nullptr, m, s_blob, rin, hh, g, lane);
-    if (len < 0) { bad_row = true; break; }
-    const uint32_t name_len = uniform_ptr(m.name_off)[hh.contig + 1] - uniform_ptr(m.name_off)[hh.contig];
-    bytes += m.rc.head_len + name_len + 1u + (uint32_t)len + m.rc.tail_len;
-    if (lane == 0) a.rows[(size_t)rel * BIN_ROWS + k] = BinRow{rsrc, (uint32_t)len};
+  // ---- 5. the kept hits of the bin in final order: which alignment, and the length of the row's middle part -- every kept hit in
+  //         the lane that holds its record (arrival lane), all of them at once ----
+  const bool kept_here = isA && ((kept >> my_rank) & 1ull);
+  int len = 0;
+  uint32_t row_bytes = 0;
+  if (kept_here) {
+    const RawAln* rp = a.raw + hsrc;
+    const GuideDev* gp = a.guides + rp->guide;
+    const int pam = rp->pam;
+    len = middle_length(rp, h, gp->L, pam >= 0 ? gp->pam_len[pam] : 0, (int)m.rc.pu_len[pam + 1], (int)m.n_max, (int)m.mid_bound);
+    if (len >= 0) {
+      const uint32_t name_len = m.name_off[h.contig + 1] - m.name_off[h.contig];
+      row_bytes = m.rc.head_len + name_len + 1u + (uint32_t)len + m.rc.tail_len;
+      a.rows[(size_t)rel * BIN_ROWS + (uint32_t)__popcll(kept & bits_below((int)my_rank))] = BinRow{hsrc, (uint32_t)len};
+    }
   }
-  if (bad_row) { decline(BIN_FLAG_ROW); return; }
+  const bool bad_row = __ballot(kept_here && len < 0) != 0;
+  const uint32_t bytes = (uint32_t)wave_sum_u64(row_bytes);
+  if (bad_row) { decline(BIN_FLAG_ROW); continue; }
   finish(n_rows, bytes, nA_own);
+  }
+}
+
+// ---- the common case, one LANE per bin ------------------------------------------------------------------------------------------
+// At max-guide-diffs 5 on a genome-sized reference a bin's context holds 0-4 raw alignments (0.4 on average), and a wave per bin spends
+// its time in dependent loads and wave-wide reductions over two or three records.  bin_hits_small_kernel gives every bin one lane:
+// a context of at most SMALL_MAX alignments runs the same five steps in registers (fixed-size arrays, constant indices only);
+// everything else goes to a list that bin_hits_kernel works off with a wave per bin.
+
+constexpr int SMALL_MAX = 4;
+
+struct SmallArgs {
+  uint32_t* complex_list;      // bins left to bin_hits_kernel
+  uint32_t* complex_count;
+  uint32_t force_complex;      // tests: every bin with alignments goes to the list
+};
+
+__global__ __launch_bounds__(64) void bin_hits_small_kernel(BinArgs a, MidArgs m, SmallArgs sa) {
+  CALITAS_TAIL_PRIO();
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t rel = blockIdx.x * 64 + threadIdx.x;
+  const bool in_range = rel < a.n_bins;
+  bool is_complex = false;
+  uint32_t out_rows = 0, out_bytes = 0, out_acc = 0, out_flags = 0;
+  BinRow out_row[SMALL_MAX];
+#pragma unroll
+  for (int k = 0; k < SMALL_MAX; k++) out_row[k] = BinRow{0u, 0u};
+  if (in_range) {
+    const uint32_t b = a.bin_first + rel;
+    const uint32_t n_own = a.bin_count[rel];
+    const uint32_t n_prev_raw = rel > 0 ? a.bin_count[rel - 1] : 0u;
+    if (n_prev_raw != 0 || n_own != 0) {
+      const uint32_t c = a.bin_contig[b];
+      const uint32_t wbase = (uint32_t)a.win_base[c];
+      const uint32_t bb = b - a.bin_base[c];
+      const bool has_prev = bb > 0 && rel > 0, has_next = b + 1 < a.bin_base[c + 1] && rel + 1 < a.n_bins;
+      const uint32_t n_prev = has_prev ? n_prev_raw : 0u, n_next = has_next ? a.bin_count[rel + 1] : 0u;
+      if (n_prev != 0 || n_own != 0) {
+        if (n_prev + n_own + n_next > (uint32_t)SMALL_MAX || sa.force_complex) is_complex = true;
+        else {
+          const int64_t lo = (int64_t)bb << a.bin_shift, hi = lo + ((int64_t)1 << a.bin_shift);
+          const int64_t ctx_lo = lo - 2 * (int64_t)a.W, ctx_hi = hi + HIT_MAX_LEN;
+          const int64_t known_from = ctx_lo <= 0 ? -((int64_t)1 << 40) : lo - (int64_t)a.W;
+          // ---- 1. context: candidate j of (previous | own | next) bin ----
+          unsigned long long key[SMALL_MAX];
+          int st[SMALL_MAX], en[SMALL_MAX];
+          uint32_t ed[SMALL_MAX], widx[SMALL_MAX], src[SMALL_MAX], wk[SMALL_MAX];
+#pragma unroll
+          for (int j = 0; j < SMALL_MAX; j++) {
+            key[j] = 0; st[j] = 0; en[j] = 0; ed[j] = 0; widx[j] = 0xFFFFFFFFu; src[j] = 0; wk[j] = 0;
+            const uint32_t uj = (uint32_t)j;
+            if (uj < n_prev + n_own + n_next) {
+              const int q = uj < n_prev ? 0 : uj < n_prev + n_own ? 1 : 2;
+              const uint32_t e = q == 0 ? uj : q == 1 ? uj - n_prev : uj - n_prev - n_own;
+              const uint32_t idx = a.bin_idx[(size_t)((int64_t)rel + q - 1) * BIN_CAP + e];
+              const RawAln* rp = a.raw + idx;
+              const uint32_t window_k = rp->window_k;
+              const int64_t ws = (int64_t)window_k * (int64_t)a.step;
+              if (ws >= ctx_lo && ws < ctx_hi) {
+                const Derived d = derive_in_contig(rp, a.guides, wbase, a.win);
+                key[j] = order_key(d); st[j] = d.start; en[j] = d.end; ed[j] = d.edits; widx[j] = d.widx; src[j] = idx; wk[j] = window_k;
+              }
+            }
+          }
+          // ---- 2. the greedy of SGA:315-320 window by window; acc_*[] = accepted alignments in arrival order ----
+          uint32_t acc_src[SMALL_MAX];
+#pragma unroll
+          for (int k = 0; k < SMALL_MAX; k++) acc_src[k] = 0;
+          uint32_t nA = 0;
+          uint32_t cur = 0;
+#pragma unroll
+          for (int wround = 0; wround < SMALL_MAX; wround++) {             // at most SMALL_MAX distinct windows
+            uint32_t w = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < SMALL_MAX; j++) if (widx[j] != 0xFFFFFFFFu && widx[j] >= cur && widx[j] < w) w = widx[j];
+            if (w != 0xFFFFFFFFu) {
+              cur = w + 1u;
+              int ks[SMALL_MAX], ke[SMALL_MAX];
+#pragma unroll
+              for (int k = 0; k < SMALL_MAX; k++) { ks[k] = 0; ke[k] = 0; }
+              uint32_t nk = 0;
+#pragma unroll
+              for (int list = 0; list < 2; list++) {
+                const uint32_t first_kept = nk;
+#pragma unroll
+                for (int round = 0; round < SMALL_MAX; round++) {
+                  unsigned long long bk = 0;
+#pragma unroll
+                  for (int j = 0; j < SMALL_MAX; j++) if (widx[j] == w && (uint32_t)(key[j] >> 63) == (uint32_t)list && key[j] > bk) bk = key[j];
+                  if (bk != 0) {
+                    int b_start = 0, b_end = 0;
+                    uint32_t b_edits = 0, b_src = 0, b_wk = 0;
+#pragma unroll
+                    for (int j = 0; j < SMALL_MAX; j++)
+                      if (widx[j] == w && key[j] == bk) { b_start = st[j]; b_end = en[j]; b_edits = ed[j]; b_src = src[j]; b_wk = wk[j]; key[j] = 0; }
+                    if ((int)b_edits <= a.max_total_diffs) {
+                      bool clash = false;
+#pragma unroll
+                      for (int k = 0; k < SMALL_MAX; k++)
+                        if ((uint32_t)k >= first_kept && (uint32_t)k < nk) clash = clash || (min(b_end, ke[k]) - max(b_start, ks[k]) > a.max_overlap);   // GA:119-122
+                      if (!clash) {
+#pragma unroll
+                        for (int k = 0; k < SMALL_MAX; k++) {
+                          if ((uint32_t)k == nk) { ks[k] = b_start; ke[k] = b_end; }
+                          if ((uint32_t)k == nA) acc_src[k] = b_src;
+                        }
+                        nk++; nA++;
+                        const int64_t ws = (int64_t)b_wk * (int64_t)a.step;
+                        if (ws >= lo && ws < hi) out_acc++;
+                      }
+                    }
+                  }
+                }
+              }
+            }
+          }
+          // ---- 3. coordinates; 4. order by counting, restart points, the walk of SR:661-671 over the (at most four) sorted hits ----
+          HitRec hr[SMALL_MAX];
+#pragma unroll
+          for (int i = 0; i < SMALL_MAX; i++) {
+            hr[i] = HitRec{};
+            if ((uint32_t)i < nA) { hr[i] = hit_record(a.raw + acc_src[i], a.guides, a.win_base, a.win); if (hr[i].gstart < 0) out_flags |= BIN_FLAG_RANGE; }
+          }
+          int s_start[SMALL_MAX], s_end[SMALL_MAX], s_score[SMALL_MAX], s_arr[SMALL_MAX];
+          uint32_t s_cs[SMALL_MAX];
+#pragma unroll
+          for (int p = 0; p < SMALL_MAX; p++) { s_start[p] = 0; s_end[p] = 0; s_score[p] = 0; s_cs[p] = 0; s_arr[p] = 0; }
+#pragma unroll
+          for (int i = 0; i < SMALL_MAX; i++) {
+            if ((uint32_t)i < nA) {
+              uint32_t rank = 0;
+#pragma unroll
+              for (int j = 0; j < SMALL_MAX; j++) {
+                if ((uint32_t)j < nA) {
+                  const bool less = hr[j].gstart < hr[i].gstart ||
+                                    (hr[j].gstart == hr[i].gstart && (hr[j].minus < hr[i].minus || (hr[j].minus == hr[i].minus && hr[j].score > hr[i].score)));
+                  const bool same = hr[j].gstart == hr[i].gstart && hr[j].minus == hr[i].minus && hr[j].score == hr[i].score;
+                  rank += (less || (same && j < i)) ? 1u : 0u;
+                }
+              }
+#pragma unroll
+              for (int p = 0; p < SMALL_MAX; p++)
+                if ((uint32_t)p == rank) { s_start[p] = hr[i].gstart; s_end[p] = hr[i].rh_end; s_score[p] = hr[i].score; s_cs[p] = hr[i].minus; s_arr[p] = i; }
+            }
+          }
+          bool head[SMALL_MAX], keep[SMALL_MAX], done[SMALL_MAX];
+#pragma unroll
+          for (int p = 0; p < SMALL_MAX; p++) {
+            head[p] = (uint32_t)p < nA; keep[p] = false; done[p] = false;
+            bool stop = false;                                            // hits.hip prep_body: look back over the hits that can reach into this one
+#pragma unroll
+            for (int j = SMALL_MAX - 1; j >= 0; j--) {
+              if (j < p && (uint32_t)p < nA && !stop) {
+                if (s_start[j] + HIT_MAX_LEN - 1 - s_start[p] < a.max_overlap) stop = true;
+                else if (s_cs[j] == s_cs[p] && s_end[j] - s_start[p] >= a.max_overlap) { head[p] = false; stop = true; }
+              }
+            }
+          }
+#pragma unroll
+          for (uint32_t cs = 0; cs < 2; cs++) {                            // one (chromosome, strand) group after the other, left to right
+            int curp = -1;                                                // position of the walk's current hit (cluster_body's `hit`)
+            bool active = false;                                          // the walk started at a certain restart point
+            int c_s = 0, c_e = 0, c_sc = 0;
+#pragma unroll
+            for (int p = 0; p < SMALL_MAX; p++) {
+              if ((uint32_t)p < nA && s_cs[p] == cs) {
+                if (head[p]) {
+                  if (curp >= 0 && active) {                              // the cluster before ends: !more
+#pragma unroll
+                    for (int k = 0; k < SMALL_MAX; k++) if (k == curp) keep[k] = true;
+                  }
+                  active = (int64_t)s_start[p] >= known_from + HIT_MAX_LEN;
+                  curp = p; c_s = s_start[p]; c_e = s_end[p]; c_sc = s_score[p];
+                  if (active) done[p] = true;
+                } else if (active) {
+                  const int ov = max(0, min(s_end[p], c_e) - max(s_start[p], c_s));   // RH:141-144
+                  done[p] = true;
+                  if (!(ov >= a.max_overlap && s_score[p] <= c_sc)) {      // not swallowed: the walk goes on from here
+                    if (ov < a.max_overlap) {
+#pragma unroll
+                      for (int k = 0; k < SMALL_MAX; k++) if (k == curp) keep[k] = true;
+                    }
+                    curp = p; c_s = s_start[p]; c_e = s_end[p]; c_sc = s_score[p];
+                  }
+                }
+              }
+            }
+            if (curp >= 0 && active) {
+#pragma unroll
+              for (int k = 0; k < SMALL_MAX; k++) if (k == curp) keep[k] = true;
+            }
+          }
+          // ---- 5. the bin's kept hits in final order ----
+#pragma unroll
+          for (int p = 0; p < SMALL_MAX; p++) {
+            const bool mine = (uint32_t)p < nA && (int64_t)s_start[p] >= lo && (int64_t)s_start[p] < hi;
+            if (mine && !done[p]) out_flags |= BIN_FLAG_HALO;
+            if (mine && keep[p]) {
+              uint32_t rsrc = 0;
+              HitRec hh{};
+#pragma unroll
+              for (int i = 0; i < SMALL_MAX; i++) if (s_arr[p] == i) { rsrc = acc_src[i]; hh = hr[i]; }
+              const RawAln* rp = a.raw + rsrc;
+              const GuideDev* gp = a.guides + rp->guide;
+              const int pam = rp->pam;
+              const int len = middle_length(rp, hh, gp->L, pam >= 0 ? gp->pam_len[pam] : 0, (int)m.rc.pu_len[pam + 1], (int)m.n_max, (int)m.mid_bound);
+              if (len < 0) out_flags |= BIN_FLAG_ROW;
+              else {
+                const uint32_t name_len = m.name_off[hh.contig + 1] - m.name_off[hh.contig];
+                out_bytes += m.rc.head_len + name_len + 1u + (uint32_t)len + m.rc.tail_len;
+#pragma unroll
+                for (int k = 0; k < SMALL_MAX; k++) if ((uint32_t)k == out_rows) out_row[k] = BinRow{rsrc, (uint32_t)len};
+                out_rows++;
+              }
+            }
+          }
+          if (out_flags) { out_rows = 0; out_bytes = 0; out_acc = 0; }
+        }
+      }
+    }
+  }
+  // ---- results: per bin (the list's bins are written by bin_hits_kernel), per chunk (one atomic per wave and sum: the 64 bins of a
+  //      wave lie in one chunk), flags, the list ----
+  if (in_range && !is_complex) {
+    a.bin_rows[rel] = out_rows; a.bin_bytes[rel] = out_bytes;
+#pragma unroll
+    for (int k = 0; k < SMALL_MAX; k++) if ((uint32_t)k < out_rows) a.rows[(size_t)rel * BIN_ROWS + k] = out_row[k];
+  }
+  const unsigned long long wbytes = wave_sum_u64(out_bytes);
+  const uint32_t wrows = (uint32_t)wave_sum_u64(out_rows), wacc = (uint32_t)wave_sum_u64(out_acc);
+  const unsigned long long fl = __ballot(out_flags != 0);
+  if (fl) { uint32_t f = out_flags; for (int off = 32; off > 0; off >>= 1) f |= (uint32_t)__shfl_xor((int)f, off); if (lane == 0) atomicOr(a.flags, f); }
+  if (lane == 0) {
+    const uint32_t rel0 = blockIdx.x * 64;
+    if (wrows) {
+      atomicAdd(a.chunk_rows + (rel0 >> CHUNK_SHIFT), wrows); atomicAdd(a.chunk_bytes + (rel0 >> CHUNK_SHIFT), wbytes);
+      atomicAdd(a.super_bytes + (rel0 >> SUPER_SHIFT), wbytes);
+    }
+    if (wacc) atomicAdd(a.chunk_acc + (rel0 >> CHUNK_SHIFT), wacc);
+  }
+  const unsigned long long rm = __ballot(out_rows != 0);
+  if (rm) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.rows_count, (uint32_t)__popcll(rm));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (out_rows != 0) a.rows_list[base + (uint32_t)__popcll(rm & bits_below(lane))] = rel;
+  }
+  const unsigned long long cm = __ballot(is_complex);
+  if (cm) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(sa.complex_count, (uint32_t)__popcll(cm));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (is_complex) sa.complex_list[base + (uint32_t)__popcll(cm & bits_below(lane))] = rel;
+  }
 }
 
 struct RowsArgs {
@@ -298,7 +608,7 @@ struct RowsArgs {
   const uint32_t* counters;     // the lane's eight counters, posted with the result
   uint32_t* box;                // mailbox (device view)
   uint32_t seq;
-  uint32_t n_chunks;
+  uint32_t n_chunks, n_supers;
 };
 
 // One wave per bin: where the bin's text starts = bytes of the chunks before its chunk + bytes of the bins before it in its chunk;
@@ -306,28 +616,32 @@ struct RowsArgs {
 // The first wave of the grid also posts the totals (final since bin_hits_kernel ended) to the host when it starts.
 __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, MidArgs m, RowsArgs o) {
   CALITAS_TAIL_PRIO();
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // per wave: line | fwd; then the constant strings
+  __shared__ __attribute__((aligned(16))) uint8_t lds[BIN_WAVES * (MID_LINE + MID_FWD)];   // per wave: line | fwd
   const int lane = (int)(threadIdx.x & 63);
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* line = lds + wv * (MID_LINE + MID_FWD);
   uint8_t* fwd = line + MID_LINE;
-  uint8_t* blob = lds + BIN_WAVES * (MID_LINE + MID_FWD);
-  for (uint32_t i = threadIdx.x; i < m.blob_bytes; i += 64 * BIN_WAVES) blob[i] = (uint8_t)m.blob[i];
-  __syncthreads();
-  const uint32_t rel = blockIdx.x * BIN_WAVES + wv;
-  // totals, and the bytes ahead of this bin's chunk
-  const uint32_t my_chunk = rel >> CHUNK_SHIFT;
+  const uint8_t* blob = reinterpret_cast<const uint8_t*>(m.blob);     // constant strings straight from global memory (cache-resident)
+  const uint32_t n_todo = *a.rows_count;                              // bins with rows (bin_hits_small_kernel / bin_hits_kernel listed them)
+  const bool posts = blockIdx.x == 0;                                 // the first wave of the grid also posts the totals
+  for (uint32_t it = blockIdx.x; it < n_todo || (posts && it == 0); it += gridDim.x) {
+  const uint32_t rel = it < n_todo ? a.rows_list[it] : 0u;
+  const uint32_t n = it < n_todo ? a.bin_rows[rel] : 0u;
+  // where the bin's text starts: super-chunks before its super-chunk + chunks before its chunk + bins before it -- all loads independent
+  const uint32_t my_chunk = rel >> CHUNK_SHIFT, my_super = rel >> SUPER_SHIFT;
   unsigned long long tot = 0, before = 0;
-  uint32_t rows_tot = 0, acc_tot = 0;
-  for (uint32_t ch = (uint32_t)lane; ch < o.n_chunks; ch += 64) {
-    const unsigned long long v = a.chunk_bytes[ch];
+  for (uint32_t sc = (uint32_t)lane; sc < o.n_supers; sc += 64) {
+    const unsigned long long v = a.super_bytes[sc];
     tot += v;
-    if (ch < my_chunk) before += v;
-    if (rel == 0) { rows_tot += a.chunk_rows[ch]; acc_tot += a.chunk_acc[ch]; }
+    if (sc < my_super) before += v;
   }
+  for (uint32_t ch = (my_super << CHUNK_SHIFT) + (uint32_t)lane; ch < my_chunk; ch += 64) before += a.chunk_bytes[ch];
+  for (uint32_t x = (my_chunk << CHUNK_SHIFT) + (uint32_t)lane; x < rel; x += 64) before += a.bin_bytes[x];
   tot = wave_sum_u64(tot); before = wave_sum_u64(before);
   const uint32_t flags = *a.flags | (tot > o.text_cap ? BIN_FLAG_TEXT : 0u);
-  if (rel == 0) {
+  if (posts && it == 0) {
+    uint32_t rows_tot = 0, acc_tot = 0;
+    for (uint32_t ch = (uint32_t)lane; ch < o.n_chunks; ch += 64) { rows_tot += a.chunk_rows[ch]; acc_tot += a.chunk_acc[ch]; }
     rows_tot = (uint32_t)wave_sum_u64(rows_tot); acc_tot = (uint32_t)wave_sum_u64(acc_tot);
     if (lane == 0) {
       for (int i = 0; i < 8; i++) o.box[BIN_BOX_COUNTERS + i] = __hip_atomic_load(o.counters + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -337,14 +651,8 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
       __hip_atomic_store(o.box, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  if (rel >= a.n_bins || flags != 0) return;
-  const uint32_t n = a.bin_rows[rel];
-  if (n == 0) return;
-  {
-    unsigned long long part = 0;
-    for (uint32_t x = (my_chunk << CHUNK_SHIFT) + (uint32_t)lane; x < rel; x += 64) part += a.bin_bytes[x];
-    before += wave_sum_u64(part);
-  }
+  if (flags != 0) return;
+  if (n == 0) continue;
   const uint8_t* head = reinterpret_cast<const uint8_t*>(m.blob) + o.rc.head_off;     // constant pieces straight from global memory (L2-resident)
   const uint8_t* tail = reinterpret_cast<const uint8_t*>(m.blob) + o.rc.tail_off;
   unsigned long long at = before;
@@ -387,6 +695,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
     }
     at += total;
   }
+  }
 }
 
 template <typename T>
@@ -406,14 +715,18 @@ struct BinnedWork {
   // one allocation for everything that is cleared per call: bin_count[n_bins] | chunk_bytes | chunk_rows | chunk_acc | flags
   uint8_t* clear = nullptr; size_t clear_cap = 0;
   uint32_t *bin_count = nullptr, *chunk_rows = nullptr, *chunk_acc = nullptr, *flags = nullptr;
-  unsigned long long* chunk_bytes = nullptr;
+  unsigned long long *chunk_bytes = nullptr, *super_bytes = nullptr;
   uint32_t *bin_rows = nullptr, *bin_bytes = nullptr; size_t bin_rows_cap = 0, bin_bytes_cap = 0;
-  uint32_t n_bins = 0, n_chunks = 0;
+  uint32_t* rows_list = nullptr; size_t rows_list_cap = 0;    // bins with rows
+  uint32_t* rows_count = nullptr;                             // (inside `clear`)
+  uint32_t* complex_list = nullptr; size_t complex_cap = 0;   // bins bin_hits_small_kernel leaves to bin_hits_kernel
+  uint32_t* complex_count = nullptr;                          // (inside `clear`)
+  uint32_t n_bins = 0, n_chunks = 0, n_supers = 0;
 };
 
 void binned_destroy(BinnedWork* w) {
   if (!w) return;
-  (void)hipFree(w->bin_idx); (void)hipFree(w->rows); (void)hipFree(w->clear); (void)hipFree(w->bin_rows); (void)hipFree(w->bin_bytes);
+  (void)hipFree(w->bin_idx); (void)hipFree(w->rows); (void)hipFree(w->clear); (void)hipFree(w->bin_rows); (void)hipFree(w->bin_bytes); (void)hipFree(w->complex_list); (void)hipFree(w->rows_list);
   delete w;
 }
 
@@ -435,15 +748,21 @@ hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) 
   TRY(grow_to(&w.rows, w.rows_cap, (size_t)n_bins * BIN_ROWS));
   TRY(grow_to(&w.bin_rows, w.bin_rows_cap, (size_t)n_bins));
   TRY(grow_to(&w.bin_bytes, w.bin_bytes_cap, (size_t)n_bins));
-  // chunk_bytes first (8-byte aligned), then the 32-bit arrays; the whole block is a multiple of 16 bytes (MI355X_MICROARCH: memset sizes)
-  const size_t bytes = (((size_t)n_chunks * 8 + (size_t)n_chunks * 4 * 2 + (size_t)n_bins * 4 + 4) + 15) & ~(size_t)15;
+  TRY(grow_to(&w.complex_list, w.complex_cap, (size_t)n_bins));
+  TRY(grow_to(&w.rows_list, w.rows_list_cap, (size_t)n_bins));
+  // the 64-bit sums first, then the 32-bit arrays; the whole block is a multiple of 16 bytes (MI355X_MICROARCH: memset sizes)
+  const uint32_t n_supers = (n_bins >> SUPER_SHIFT) + 1;
+  const size_t bytes = (((size_t)(n_chunks + n_supers) * 8 + (size_t)n_chunks * 4 * 2 + (size_t)n_bins * 4 + 12) + 15) & ~(size_t)15;
   TRY(grow_to(&w.clear, w.clear_cap, bytes));
   w.chunk_bytes = reinterpret_cast<unsigned long long*>(w.clear);
-  w.chunk_rows = reinterpret_cast<uint32_t*>(w.clear + (size_t)n_chunks * 8);
+  w.super_bytes = w.chunk_bytes + n_chunks;
+  w.chunk_rows = reinterpret_cast<uint32_t*>(w.super_bytes + n_supers);
   w.chunk_acc = w.chunk_rows + n_chunks;
   w.flags = w.chunk_acc + n_chunks;
-  w.bin_count = w.flags + 1;
-  w.n_bins = n_bins; w.n_chunks = n_chunks;
+  w.complex_count = w.flags + 1;
+  w.rows_count = w.flags + 2;
+  w.bin_count = w.flags + 3;
+  w.n_bins = n_bins; w.n_chunks = n_chunks; w.n_supers = n_supers;
   return hipMemsetAsync(w.clear, 0, bytes, stream);
 }
 
@@ -460,22 +779,21 @@ static hipError_t launch_rows(BinnedWork& w, HitsWork& hw, const BinArgs& ba, co
   TRY(mailbox_open(*post));
   RowsArgs ro{};
   ro.rc = hw.rc; ro.names = hw.names; ro.text = hw.text; ro.text_cap = hw.text_cap; ro.counters = d_counters; ro.box = post->dev; ro.seq = ++post->seq;
-  ro.n_chunks = w.n_chunks;
+  ro.n_chunks = w.n_chunks; ro.n_supers = w.n_supers;
   post->host[BIN_BOX_LATE] = 0;                              // raised by any wave while rows are written; read when the stream is done
-  const uint32_t lds = BIN_WAVES * (MID_LINE + MID_FWD) + (uint32_t)((hw.blob_bytes + 15) & ~(size_t)15);
-  const unsigned grid = (std::max<uint32_t>(w.n_bins, 1u) + BIN_WAVES - 1) / BIN_WAVES;
-  hipExtLaunchKernelGGL(bin_rows_kernel, dim3(grid), dim3(64 * BIN_WAVES), lds, stream, ev_start, ev_done, 0, ba, ma, ro);
+  const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(w.n_bins, 1u), 16384u);      // strides over the list of bins with rows
+  hipExtLaunchKernelGGL(bin_rows_kernel, dim3(grid), dim3(64), 0, stream, ev_start, ev_done, 0, ba, ma, ro);
   return hipGetLastError();
 }
 
 static void fill_args(BinnedWork& w, HitsWork& hw, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
                       const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, BinArgs& ba, MidArgs& ma) {
   ba = BinArgs{};
-  ba.raw = d_raw; ba.bin_idx = w.bin_idx; ba.bin_count = w.bin_count; ba.bin_base = geo.d_bin_base; ba.n_contigs = geo.n_contigs; ba.bin_first = geo.bin_first;
+  ba.raw = d_raw; ba.bin_idx = w.bin_idx; ba.bin_count = w.bin_count; ba.bin_base = geo.d_bin_base; ba.bin_contig = geo.d_bin_contig; ba.n_contigs = geo.n_contigs; ba.bin_first = geo.bin_first;
   ba.n_bins = geo.n_bins; ba.bin_shift = geo.bin_shift; ba.guides = d_guides; ba.win_base = d_win_base; ba.win = d_win;
   ba.W = p.window_size; ba.step = p.step; ba.max_total_diffs = p.max_total_diffs; ba.max_overlap = p.max_overlap;
-  ba.rows = w.rows; ba.bin_rows = w.bin_rows; ba.bin_bytes = w.bin_bytes; ba.chunk_bytes = w.chunk_bytes; ba.chunk_rows = w.chunk_rows;
-  ba.chunk_acc = w.chunk_acc; ba.flags = w.flags;
+  ba.rows = w.rows; ba.bin_rows = w.bin_rows; ba.bin_bytes = w.bin_bytes; ba.chunk_bytes = w.chunk_bytes; ba.super_bytes = w.super_bytes; ba.chunk_rows = w.chunk_rows;
+  ba.chunk_acc = w.chunk_acc; ba.flags = w.flags; ba.rows_list = w.rows_list; ba.rows_count = w.rows_count;
   const uint32_t n_max = (uint32_t)std::min<int>(MID_COLS, std::max(1, p.max_ops));
   ma = MidArgs{};
   ma.ref = ref; ma.rc = hw.rc; ma.blob = hw.blob; ma.name_off = hw.name_off; ma.guides = d_guides;
@@ -497,10 +815,20 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
   }
   BinArgs ba; MidArgs ma;
   fill_args(w, hw, geo, ref, d_raw, d_guides, d_win_base, d_win, p, ba, ma);
-  const uint32_t lds = (uint32_t)((hw.blob_bytes + 15) & ~(size_t)15);
-  if (lds + BIN_WAVES * (MID_LINE + MID_FWD) > 48 * 1024) return hipErrorInvalidValue;      // absurdly long parameter strings: the caller takes the general path
-  const unsigned grid = (std::max<uint32_t>(geo.n_bins, 1u) + BIN_WAVES - 1) / BIN_WAVES;
-  hipExtLaunchKernelGGL(bin_hits_kernel, dim3(grid), dim3(64 * BIN_WAVES), lds, stream, nullptr, ev_hits_done, 0, ba, ma);
+  // (a null table here would be a wild read on the device, not an error code: refuse on the host)
+  if (!ba.raw || !ba.bin_idx || !ba.bin_count || !ba.bin_base || !ba.bin_contig || !ba.guides || !ba.win_base || !ba.win || !ba.rows || !ba.bin_rows ||
+      !ba.bin_bytes || !ba.chunk_bytes || !ba.super_bytes || !ba.chunk_rows || !ba.chunk_acc || !ba.flags || !ba.rows_list || !ba.rows_count || !ma.blob || !ma.name_off || !hw.names ||
+      !hw.text || w.n_bins < geo.n_bins)
+    return hipErrorInvalidValue;
+  SmallArgs sa{w.complex_list, w.complex_count, 0u};
+  if (const char* env = std::getenv("CALITAS_BINNED_COMPLEX")) sa.force_complex = std::atoi(env) != 0;   // tests: the wave-per-bin kernel for every bin
+  if (!sa.complex_list || !sa.complex_count) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bin_hits_small_kernel, dim3((std::max<uint32_t>(geo.n_bins, 1u) + 63) / 64), dim3(64), 0, stream, ba, ma, sa);
+  TRY(hipGetLastError());
+  // the listed bins: a fixed grid that strides over the list (its length is on the device)
+  const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(geo.n_bins, 1u), 2048u);
+  hipExtLaunchKernelGGL(bin_hits_kernel, dim3(grid), dim3(64 * BIN_WAVES), 0, stream, nullptr, ev_hits_done, 0, ba, ma, (const uint32_t*)w.complex_list,
+                        (const uint32_t*)w.complex_count);
   TRY(hipGetLastError());
   return launch_rows(w, hw, ba, ma, d_counters, stream, post, ev_rows_start, ev_rows_done);
 }

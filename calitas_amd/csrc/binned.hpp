@@ -42,6 +42,7 @@ int binned_shift(int window_size);
 
 struct BinnedGeometry {      // where the bins of a lane's range lie
   const uint32_t* d_bin_base;   // per contig (n_contigs + 1)
+  const uint32_t* d_bin_contig; // per bin: its contig
   int n_contigs;
   uint32_t bin_first, n_bins;   // the range's bins
   uint32_t bin_shift;

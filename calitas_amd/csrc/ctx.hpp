@@ -61,6 +61,7 @@ struct calitas_ctx {
   uint64_t ref_serial = 0, hits_names_serial = ~0ull;
   // binned tail (binned.hpp): the owner keeps the bins' geometry, every lane its own scratch
   uint32_t* d_bin_base = nullptr;   // per contig: index of its first bin, for bin_shift (owner)
+  uint32_t* d_bin_contig = nullptr; // per bin: its contig
   std::vector<uint32_t> bin_base;   // the same on the host
   int bin_shift = 0;                // 0 = not built
   BinnedWork* binned = nullptr;     // lane

@@ -137,6 +137,8 @@ struct SearchPlan {
   // its reference bins (binned.hpp); bin_shift = 0: the binned tail does not take this window size
   int bin_shift = 0;
   uint32_t bin_first = 0, n_bins = 0;
+  bool narrow_tail = false;           // a range of a chunked call that is not the last: its tail shares the chip with the next scan
+  bool three_ranges = false;          // a range of a call cut into three or more
 };
 
 // The bins of contigs [c0, c1) of the plan's geometry (the owner's bin_base must be built: ensure_bin_base).
@@ -291,9 +293,14 @@ static int ensure_bin_base(calitas_ctx* ctx, SearchPlan& pl, hipStream_t stream)
     bb[ref.contigs.size()] = (uint32_t)acc;
     if (acc >= 0x7FFFFFFFull) { pl.bin_shift = 0; return CALITAS_OK; }
     (void)hipFree(o->d_bin_base); o->d_bin_base = nullptr; o->bin_shift = 0;
+    (void)hipFree(o->d_bin_contig); o->d_bin_contig = nullptr;
+    std::vector<uint32_t> bc((size_t)acc + 1, 0);
+    for (size_t c = 0; c < ref.contigs.size(); c++) std::fill(bc.begin() + bb[c], bc.begin() + bb[c + 1], (uint32_t)c);
     HIP_TRY(ctx, hipMalloc((void**)&o->d_bin_base, bb.size() * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&o->d_bin_contig, bc.size() * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMemcpyAsync(o->d_bin_base, bb.data(), bb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(ctx, hipStreamSynchronize(stream));                                                                              // bb is a local
+    HIP_TRY(ctx, hipMemcpyAsync(o->d_bin_contig, bc.data(), bc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));                                                                              // bb / bc are locals
     o->bin_base.swap(bb); o->bin_shift = pl.bin_shift;
   }
   if (pl.n_bins == 0) plan_bins(o, pl, pl.p.chrom_index >= 0 ? pl.p.chrom_index : 0, pl.p.chrom_index >= 0 ? pl.p.chrom_index + 1 : (int)ref.contigs.size());
@@ -379,6 +386,14 @@ static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
 
 // grids of align_kernel (units of 256 lanes: 4 single-wave workgroups each; 4096 workgroups are what the CUs hold at once) and trace_kernel
 constexpr int kAlignBlocks = 1024, kTraceBlocks = 2048;
+// ... and of a range whose tail runs beside the scan of the next one (narrow_tail).  All 4096 align_kernel workgroups resident at once
+// hold the whole LDS of every CU (16 x 10 KB), trace_kernel's 28.7 KB workgroups likewise; narrower grids for those ranges were
+// measured (CALITAS_ALIGN_BLOCKS_NARROW / CALITAS_TRACE_BLOCKS_NARROW): 2.42-2.55 ms per hg38-sized pass for 128-1024 / 512-2048, no
+// gain -- the default stays the wide grid.
+static int narrow_blocks(const char* env, int wide, int narrow) {
+  if (const char* e = std::getenv(env)) { const int v = std::atoi(e); if (v >= 1 && v <= wide) return v; }
+  return narrow;
+}
 
 // calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
 // (dev->valid), and *out stays NULL.  prelaunched: the scan stage of this lane was queued by the caller on another stream
@@ -420,10 +435,10 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     ScanArgs sa; AlignArgs aa;
     fill_kernel_args(ctx, pl, sa, aa);
-    HIP_TRY(ctx, launch_align(aa, kAlignBlocks, ctx->stream));
+    HIP_TRY(ctx, launch_align(aa, pl.narrow_tail ? narrow_blocks("CALITAS_ALIGN_BLOCKS_NARROW", kAlignBlocks, kAlignBlocks) : kAlignBlocks, ctx->stream));
     // (trace_kernel can post the counters itself from its last workgroup -- launch_trace's `post` -- but finding the last of 2048
     // workgroups is 2048 atomics on one word, ~8 ns each: 20-30 us against the ~10 us of this launch)
-    HIP_TRY(ctx, launch_trace(aa, kTraceBlocks, ctx->stream, ctx->ev[2]));
+    HIP_TRY(ctx, launch_trace(aa, pl.narrow_tail ? narrow_blocks("CALITAS_TRACE_BLOCKS_NARROW", kTraceBlocks, kTraceBlocks) : kTraceBlocks, ctx->stream, ctx->ev[2]));
     if (speculate) {
       HIP_TRY(ctx, select_run_speculative(&ctx->select, ctx->d_raw, ctx->d_counters, ctx->rec_cap, ctx->raw_cap, ctx->item_cap, ctx->d_guides,
                                           own->d_win_base, own->d_win, pl.win_lo, pl.win_n, max_total, p.max_overlap, ctx->stream, &d_spec, &ctx->mbox));
@@ -768,7 +783,17 @@ static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
   const calitas_ctx* own = ref_owner(lane);
   if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0 || pl.gw_lo != 0 || pl.gw_hi != ~0ull) return false;
   if (std::getenv("CALITAS_HOST_FILTER") || std::getenv("CALITAS_HOST_HITS")) return false;
-  if (const char* e = std::getenv("CALITAS_BINNED")) if (std::atoi(e) == 0) return false;     // A/B: the general kernels
+  // Which tail by default: the per-bin kernels wherever a call is one pass or two ranges (references up to 2 Gb: a rank's share of a
+  // genome on 2-8 GPUs, a bacterial genome) -- 0.58 against 0.62 ms for an eighth of the hg38-sized genome, 0.164 against 0.190 ms for
+  // an E. coli-sized one.  A call cut into three ranges (the whole hg38-sized genome on one GPU) is bound by its scans, and those
+  // lose more to the per-bin kernels running beside them (many short waves) than the last range's tail gains: 2.39 ms per pass on
+  // the general kernels against 2.45-2.53 (tools/sweep_lanes.py, profiles/r03_*).  CALITAS_BINNED=1 / 0 / last force a choice.
+  bool want = !pl.three_ranges;
+  if (const char* e = std::getenv("CALITAS_BINNED")) {
+    if (std::strcmp(e, "last") == 0) want = !pl.narrow_tail;
+    else want = std::atoi(e) != 0;
+  }
+  if (!want) return false;
   if (pl.p.max_overlap < 1 || own->ref.contigs.size() >= (1u << 18) - 1) return false;
   const GuideDev& g = pl.gd[0];
   if (own->bin_decl_pams == g.n_pams && own->bin_decl_L == g.L && g.min_guide_score <= own->bin_decl_min_score) return false;
@@ -885,7 +910,7 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   }
   int max_pam = 0;
   for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
-  const BinnedGeometry geo{own->d_bin_base, (int)ref.contigs.size(), pl.bin_first, pl.n_bins, (uint32_t)pl.bin_shift};
+  const BinnedGeometry geo{own->d_bin_base, own->d_bin_contig, (int)ref.contigs.size(), pl.bin_first, pl.n_bins, (uint32_t)pl.bin_shift};
   const BinnedParams bp{p.window_size, pl.step, pl.max_total, p.max_overlap, pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam};
   const HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
   const auto t_call = std::chrono::steady_clock::now();
@@ -896,8 +921,8 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(lane, pl, sa, aa);
   binned_fill_align_args(lane->binned, geo, aa);
-  HIP_TRY(lane, launch_align(aa, kAlignBlocks, lane->stream));
-  HIP_TRY(lane, launch_trace(aa, kTraceBlocks, lane->stream, lane->ev[2]));
+  HIP_TRY(lane, launch_align(aa, pl.narrow_tail ? narrow_blocks("CALITAS_ALIGN_BLOCKS_NARROW", kAlignBlocks, kAlignBlocks) : kAlignBlocks, lane->stream));
+  HIP_TRY(lane, launch_trace(aa, pl.narrow_tail ? narrow_blocks("CALITAS_TRACE_BLOCKS_NARROW", kTraceBlocks, kTraceBlocks) : kTraceBlocks, lane->stream, lane->ev[2]));
   HIP_TRY(lane, binned_run(lane->binned, &lane->hits, geo, hr, lane->d_raw, lane->d_guides, own->d_win_base, own->d_win, bp, lane->d_counters, lane->stream,
                            &lane->mbox, lane->ev[3], lane->ev[4], lane->ev[5]));
   g_marks.mark("queued-binned");
@@ -1005,7 +1030,9 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
   while (ctx->lanes.size() < k) {
     calitas_ctx* c = new calitas_ctx();
     c->device = ctx->device; c->parent = ctx;
-    bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) == hipSuccess;
+    int lane_prio = greatest;
+    if (const char* e = std::getenv("CALITAS_LANE_PRIO")) if (std::strcmp(e, "low") == 0) lane_prio = least;   // experiment: the tails do not outrank the scan
+    bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, lane_prio) == hipSuccess;
     for (int i = 0; i < 8; i++) ok = ok && hipEventCreateWithFlags(&c->ev[i], i < 6 ? hipEventReleaseToDevice : hipEventDefault) == hipSuccess;   // as in calitas_create
     ok = ok && hipEventCreateWithFlags(&c->scan_done, hipEventReleaseToDevice) == hipSuccess;   // timed: it also brackets the scan
     ok = ok && hipEventCreateWithFlags(&c->rows_ready, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
@@ -1492,6 +1519,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       for (int k = 0; k < ranges[c].first; k++) q.win_lo += window_count(ref.contigs[k].len, q.step);
       for (int k = ranges[c].first; k < ranges[c].second; k++) { q.bases += ref.contigs[k].len; q.win_n += window_count(ref.contigs[k].len, q.step); }
       plan_bins(ctx, q, ranges[c].first, ranges[c].second);
+      q.narrow_tail = c + 1 < K; q.three_ranges = K >= 3;
       rc = lane_prepare(lanes[c], q);
       if (rc) ctx->err = lanes[c]->err;
     }
@@ -1512,8 +1540,14 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     g_marks.mark("lanes-ready");
     // (Holding the scan of a range back until the aligner kernels of the range before it are done -- they take half as long again
     // beside a scan, the scan twice as long beside them -- was tried: 2.77 against 2.55 ms per pass.)
+    // The inputs of all ranges (guide constants, cleared counters: a 272-byte upload and a fill per lane, 60-140 us of the scan stream
+    // each when they sit between two scans) are queued ahead of the first scan; CALITAS_INPUTS_FIRST=0: each before its own scan.
+    bool inputs_first = true;
+    if (const char* e = std::getenv("CALITAS_INPUTS_FIRST")) inputs_first = std::atoi(e) != 0;
+    if (inputs_first)
+      for (size_t c = 0; c < K && !rc; c++) { rc = queue_scan_inputs(lanes[c], plans[c], ctx->scan_stream); if (rc) ctx->err = lanes[c]->err; }
     for (size_t c = 0; c < K && !rc; c++) {
-      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream);           // records lanes[c]->scan_done
+      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, inputs_first);           // records lanes[c]->scan_done
       if (rc) ctx->err = lanes[c]->err;
       g_marks.mark("scan-queued");
     }

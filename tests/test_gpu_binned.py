@@ -40,9 +40,15 @@ def both_paths(C, fa, guide, monkeypatch, expect_binned=True, **pk):
         text0, n0 = C.SearchReference(guide=guide, guide_id="a", context=ctx, **pk).run("v0", "stamp")
         assert ctx.timing()["binned_lanes"] == 0
         monkeypatch.delenv("CALITAS_BINNED")
+        # every bin through the wave-per-bin kernel (by default only the bins with more than four alignments in their context get there)
+        monkeypatch.setenv("CALITAS_BINNED_COMPLEX", "1")
+        text1, n1 = C.SearchReference(guide=guide, guide_id="a", context=ctx, **pk).run("v0", "stamp")
+        lanes1 = ctx.timing()["binned_lanes"]
+        monkeypatch.delenv("CALITAS_BINNED_COMPLEX")
     finally:
         ctx.close()
     assert text == text0 and n == n0
+    assert text1 == text0 and lanes1 == lanes
     if expect_binned is not None:
         assert (lanes > 0) == expect_binned, lanes
     return C.read_hits(text), lanes
