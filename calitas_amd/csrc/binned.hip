@@ -64,6 +64,9 @@ struct BinArgs {
   uint32_t* chunk_rows;
   uint32_t* chunk_acc;               // accepted alignments (after the per-window filter) of the windows that start in the chunk's bins
   uint32_t* flags;
+  // the hits this call owns, as keys (contig << 32 | coordinate_start): [own_lo, own_hi); everything by default.  A process of a
+  // multi-GPU job owns a stretch of the genome that may begin and end anywhere (binned.hpp, BinnedParams)
+  unsigned long long own_lo, own_hi;
   uint32_t* rows_list;               // bins with rows, in no particular order (one append per wave)
   uint32_t* rows_count;              // (zero at launch)
 };
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
     }
   }
   wave_lds_sync();
-  const bool mine = r < nA && (int64_t)s_start[wv][r] >= lo && (int64_t)s_start[wv][r] < hi;
+  const unsigned long long okey = r < nA ? (((unsigned long long)c << 32) | (unsigned long long)(uint32_t)s_start[wv][r]) : 0ull;
+  const bool mine = r < nA && (int64_t)s_start[wv][r] >= lo && (int64_t)s_start[wv][r] < hi && okey >= a.own_lo && okey < a.own_hi;
   if (__ballot(mine && !s_done[wv][r]) != 0) { decline(BIN_FLAG_HALO); continue; }
   const unsigned long long kept = __ballot(mine && s_keep[wv][r] != 0);
   const uint32_t n_rows = (uint32_t)__popcll(kept);
@@ -539,7 +543,8 @@ __global__ __launch_bounds__(64) void bin_hits_small_kernel(BinArgs a, MidArgs m
           // ---- 5. the bin's kept hits in final order ----
 #pragma unroll
           for (int p = 0; p < SMALL_MAX; p++) {
-            const bool mine = (uint32_t)p < nA && (int64_t)s_start[p] >= lo && (int64_t)s_start[p] < hi;
+            const unsigned long long okey = ((unsigned long long)c << 32) | (unsigned long long)(uint32_t)s_start[p];
+            const bool mine = (uint32_t)p < nA && (int64_t)s_start[p] >= lo && (int64_t)s_start[p] < hi && okey >= a.own_lo && okey < a.own_hi;
             if (mine && !done[p]) out_flags |= BIN_FLAG_HALO;
             if (mine && keep[p]) {
               uint32_t rsrc = 0;
@@ -767,7 +772,8 @@ hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) 
 }
 
 void binned_fill_align_args(const BinnedWork* w, const BinnedGeometry& geo, AlignArgs& aa) {
-  aa.bin_idx = w->bin_idx; aa.bin_count = w->bin_count; aa.bin_base = geo.d_bin_base; aa.bin_first = geo.bin_first; aa.bin_shift = geo.bin_shift;
+  aa.bin_idx = w->bin_idx; aa.bin_count = w->bin_count; aa.bin_base = geo.d_bin_base; aa.bin_first = geo.bin_first; aa.bin_n = geo.n_bins;
+  aa.bin_shift = geo.bin_shift;
   aa.bin_cap = BIN_CAP;
 }
 
@@ -792,6 +798,7 @@ static void fill_args(BinnedWork& w, HitsWork& hw, const BinnedGeometry& geo, co
   ba.raw = d_raw; ba.bin_idx = w.bin_idx; ba.bin_count = w.bin_count; ba.bin_base = geo.d_bin_base; ba.bin_contig = geo.d_bin_contig; ba.n_contigs = geo.n_contigs; ba.bin_first = geo.bin_first;
   ba.n_bins = geo.n_bins; ba.bin_shift = geo.bin_shift; ba.guides = d_guides; ba.win_base = d_win_base; ba.win = d_win;
   ba.W = p.window_size; ba.step = p.step; ba.max_total_diffs = p.max_total_diffs; ba.max_overlap = p.max_overlap;
+  ba.own_lo = p.own_lo; ba.own_hi = p.own_hi;
   ba.rows = w.rows; ba.bin_rows = w.bin_rows; ba.bin_bytes = w.bin_bytes; ba.chunk_bytes = w.chunk_bytes; ba.super_bytes = w.super_bytes; ba.chunk_rows = w.chunk_rows;
   ba.chunk_acc = w.chunk_acc; ba.flags = w.flags; ba.rows_list = w.rows_list; ba.rows_count = w.rows_count;
   const uint32_t n_max = (uint32_t)std::min<int>(MID_COLS, std::max(1, p.max_ops));

@@ -56,6 +56,11 @@ void binned_fill_align_args(const BinnedWork* work, const BinnedGeometry& geo, A
 
 struct BinnedParams {
   int window_size, step, max_total_diffs, max_overlap, max_ops;
+  // The rows this call owns: hits whose (contig << 32 | coordinate_start) lies in [own_lo, own_hi) -- 0 / ~0 for a whole reference.
+  // A window range of calitas_search_hits (calitas_params_t::first_window / n_windows) becomes such a stretch: from the start of its
+  // first window to the start of the window behind its last.  The caller's bin range covers the stretch plus one bin on each side
+  // (the context of the first and the last owned bin), and the aligner ran on every window those bins' contexts reach.
+  unsigned long long own_lo, own_hi;
 };
 
 // Queues the two kernels behind trace_kernel.  hits: the lane's HitsWork after hits_prepare / hits_set_names (constant row pieces, contig

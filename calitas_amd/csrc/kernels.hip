@@ -677,6 +677,7 @@ __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a, uint32_t* box, 
   // distinct words: cheap)
   auto to_bin = [&](uint32_t contig, uint32_t window_k, uint32_t g) {
     const uint32_t bin = a.bin_base[contig] + (uint32_t)(((uint64_t)window_k * (uint64_t)(uint32_t)sp.step) >> a.bin_shift) - a.bin_first;
+    if (bin >= a.bin_n) { atomicAdd(a.anomalies, 1u); return; }      // (the host plans the windows from the bins: an internal error, reported)
     const uint32_t at = atomicAdd(a.bin_count + bin, 1u);
     if (at < a.bin_cap) a.bin_idx[(size_t)bin * a.bin_cap + at] = g;
   };

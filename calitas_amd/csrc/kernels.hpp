@@ -56,6 +56,7 @@ struct AlignArgs {
   uint32_t* bin_count;     // alignments per bin, zero at launch; may exceed bin_cap (the surplus is not stored: the bin is "crowded")
   const uint32_t* bin_base;  // per contig: index of its first bin
   uint32_t bin_first;      // first bin of this lane's range (bins / bin_count are indexed relative to it)
+  uint32_t bin_n;          // bins of the range (an alignment whose window starts outside is not listed: cannot happen, checked)
   uint32_t bin_shift;      // log2 of the bases per bin
   uint32_t bin_cap;
   SearchDev sp;

@@ -137,6 +137,9 @@ struct SearchPlan {
   // its reference bins (binned.hpp); bin_shift = 0: the binned tail does not take this window size
   int bin_shift = 0;
   uint32_t bin_first = 0, n_bins = 0;
+  // calitas_search_hits on a window range (a process of a multi-GPU job): the rows it owns, as keys (contig << 32 | coordinate_start)
+  bool owned = false;
+  uint64_t own_lo = 0, own_hi = ~0ull;
   bool narrow_tail = false;           // a range of a chunked call that is not the last: its tail shares the chip with the next scan
   bool three_ranges = false;          // a range of a call cut into three or more
 };
@@ -781,14 +784,15 @@ struct LaneText {
 // as permissive as the last the bins declined on this reference.
 static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
   const calitas_ctx* own = ref_owner(lane);
-  if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0 || pl.gw_lo != 0 || pl.gw_hi != ~0ull) return false;
+  if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0) return false;
+  if (!pl.owned && (pl.gw_lo != 0 || pl.gw_hi != ~0ull)) return false;   // (a window range of calitas_search: alignment records, no rows)
   if (std::getenv("CALITAS_HOST_FILTER") || std::getenv("CALITAS_HOST_HITS")) return false;
   // Which tail by default: the per-bin kernels wherever a call is one pass or two ranges (references up to 2 Gb: a rank's share of a
   // genome on 2-8 GPUs, a bacterial genome) -- 0.58 against 0.62 ms for an eighth of the hg38-sized genome, 0.164 against 0.190 ms for
   // an E. coli-sized one.  A call cut into three ranges (the whole hg38-sized genome on one GPU) is bound by its scans, and those
   // lose more to the per-bin kernels running beside them (many short waves) than the last range's tail gains: 2.39 ms per pass on
   // the general kernels against 2.45-2.53 (tools/sweep_lanes.py, profiles/r03_*).  CALITAS_BINNED=1 / 0 / last force a choice.
-  bool want = !pl.three_ranges;
+  bool want = !pl.three_ranges || pl.owned;                    // (a stretch that cuts a contig: only the bins can own it)
   if (const char* e = std::getenv("CALITAS_BINNED")) {
     if (std::strcmp(e, "last") == 0) want = !pl.narrow_tail;
     else want = std::atoi(e) != 0;
@@ -911,7 +915,8 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   int max_pam = 0;
   for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
   const BinnedGeometry geo{own->d_bin_base, own->d_bin_contig, (int)ref.contigs.size(), pl.bin_first, pl.n_bins, (uint32_t)pl.bin_shift};
-  const BinnedParams bp{p.window_size, pl.step, pl.max_total, p.max_overlap, pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam};
+  const BinnedParams bp{p.window_size, pl.step, pl.max_total, p.max_overlap, pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam,
+                        pl.own_lo, pl.own_hi};
   const HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
   const auto t_call = std::chrono::steady_clock::now();
   if (!prelaunched) {
@@ -1369,6 +1374,8 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
   g_marks.start();
   struct Dump { ~Dump() { g_marks.mark("return"); g_marks.dump(); } } dump_at_exit;
   int rc = CALITAS_ENOMEM;
+  if (params && (params->first_window != 0 || params->n_windows != 0))     // a process's stretch of a multi-GPU job: one pass, no per-contig mode
+    return search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
   if (!known_not_to_fit(ctx, guide, params, false) && !predicted_not_to_fit(ctx, guide, params)) {
     rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
     if (rc != CALITAS_ENOMEM) return rc;
@@ -1420,11 +1427,192 @@ int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* gui
   return rc;
 }
 
+// ---- calitas_search_hits on a window range ------------------------------------------------------------------------------
+// A process of a multi-GPU job owns a stretch of the genome: the rows whose coordinate_start lies at or behind the start of window
+// first_window and before the start of window first_window + n_windows (windowIterator's sequence over the whole reference,
+// SearchReference.scala:39-71).  coordinate_start is the first key of ReferenceHit.sort, so the stretches of consecutive ranges are
+// consecutive pieces of hits.txt, wherever the cuts fall -- inside a contig, inside a repeat.  The per-bin kernels decide a bin's
+// hits from the bin and the edges of its neighbours (binned.hip), so the call aligns the windows the stretch's bins (plus one on
+// either side) reach and keeps the rows of the stretch; nothing is exchanged between the processes.  When a bin declines (crowded,
+// a chain of hits longer than the halo) the contigs the stretch touches are searched whole on the general kernels and their rows
+// filtered by position on the host: slower, same rows.
+
+// The plan of a stretch: bins, the windows their contexts reach, the tiles those windows lie in.
+static bool plan_owned_range(const calitas_ctx* ctx, SearchPlan& pl, uint64_t first, uint64_t count) {
+  const PackedRef& ref = ctx->ref;
+  const int nc = (int)ref.contigs.size();
+  if (!pl.bin_shift || ctx->bin_base.size() != (size_t)nc + 1) return false;
+  std::vector<uint64_t> wb((size_t)nc + 1, 0);
+  for (int c = 0; c < nc; c++) wb[c + 1] = wb[c] + window_count(ref.contigs[c].len, pl.step);
+  const uint64_t total = wb[nc];
+  if (count == 0 || first + count > total) return false;
+  auto locate = [&](uint64_t w, int& c, uint64_t& pos) {       // start of global window w; w == total: the end of the reference
+    if (w >= total) { c = nc; pos = 0; return; }
+    c = (int)(std::upper_bound(wb.begin(), wb.end(), w) - wb.begin()) - 1;
+    pos = (w - wb[c]) * (uint64_t)pl.step;
+  };
+  int c_lo = 0, c_hi = 0;
+  uint64_t p_lo = 0, p_hi = 0;
+  locate(first, c_lo, p_lo);
+  locate(first + count, c_hi, p_hi);
+  // a stretch that starts with the first window of a contig owns the contig from base 0, one that ends at a contig's first window
+  // owns the contig before it to its end -- (c, 0) keys say exactly that
+  pl.owned = true;
+  pl.own_lo = ((uint64_t)c_lo << 32) | p_lo;
+  pl.own_hi = ((uint64_t)c_hi << 32) | p_hi;
+  // last owned position
+  int c_last = c_hi;
+  uint64_t p_last = p_hi;
+  if (p_hi == 0) { c_last = c_hi - 1; while (c_last > c_lo && ref.contigs[c_last].len == 0) c_last--; p_last = ref.contigs[c_last].len; }
+  if (p_last > 0) p_last--;
+  const uint64_t bin = 1ull << pl.bin_shift;
+  uint32_t b_lo = ctx->bin_base[c_lo] + (uint32_t)(p_lo >> pl.bin_shift), b_hi = ctx->bin_base[c_last] + (uint32_t)(p_last >> pl.bin_shift);
+  if (b_lo > ctx->bin_base[c_lo]) b_lo--;                      // one bin of context on either side, inside the contig
+  if (b_hi + 1 < ctx->bin_base[c_last + 1]) b_hi++;
+  pl.bin_first = b_lo; pl.n_bins = b_hi - b_lo + 1;
+  // the windows that start in those bins: the context of the first owned bin (two windows to the left) lies in the bin before it, that
+  // of the last one (the longest hit to the right) in the bin behind it (binned.hip) -- and trace_kernel lists an alignment in the
+  // bin its window starts in, which must be one of the lane's
+  const int64_t ctx_lo = (int64_t)((uint64_t)(b_lo - ctx->bin_base[c_lo]) << pl.bin_shift);
+  const uint64_t ctx_hi = std::min<uint64_t>(ref.contigs[c_last].len, ((uint64_t)(b_hi - ctx->bin_base[c_last]) + 1) << pl.bin_shift);
+  const uint64_t k_lo = ((uint64_t)ctx_lo + (uint64_t)pl.step - 1) / (uint64_t)pl.step;
+  const uint64_t nw_last = wb[c_last + 1] - wb[c_last];
+  const uint64_t k_hi = ctx_hi == 0 ? 0 : std::min<uint64_t>(nw_last, (ctx_hi - 1) / (uint64_t)pl.step + 1);
+  pl.gw_lo = std::min(wb[c_lo] + k_lo, wb[c_lo + 1]);
+  pl.gw_hi = wb[c_last] + k_hi;
+  if (pl.gw_hi < pl.gw_lo) pl.gw_hi = pl.gw_lo;
+  // tiles those windows lie in
+  const uint64_t g_lo = ref.contigs[c_lo].gbase + (uint64_t)ctx_lo;
+  const uint64_t g_hi = ref.contigs[c_last].gbase + std::min<uint64_t>(ref.contigs[c_last].len, ctx_hi + (uint64_t)pl.p.window_size);
+  pl.tile_lo = (uint32_t)(g_lo / ref.tile);
+  pl.n_tiles = (uint32_t)((g_hi + ref.tile - 1) / ref.tile) - pl.tile_lo;
+  uint64_t bases = 0;
+  for (int c = c_lo; c <= c_last; c++) bases += ref.contigs[c].len;
+  if (c_lo == c_last) bases = std::min<uint64_t>(ref.contigs[c_lo].len, ctx_hi + (uint64_t)pl.p.window_size) - (uint64_t)ctx_lo;
+  pl.bases = bases;
+  pl.win_lo = pl.gw_lo; pl.win_n = pl.gw_hi - pl.gw_lo;
+  (void)bin;
+  return true;
+}
+
+static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
+                               char* user_dst, uint64_t user_cap);
+
+static int search_hits_owned(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                             const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
+                             char* user_dst, uint64_t user_cap) {
+  *tsv = nullptr;
+  if (tsv_bytes) *tsv_bytes = 0;
+  if (n_rows) *n_rows = 0;
+  calitas_params_t whole = *params;
+  whole.first_window = 0; whole.n_windows = 0;
+  if (whole.chrom_index >= 0) return fail(ctx, CALITAS_EINVAL, "a window range and chrom_index exclude each other");
+  SearchPlan pl;
+  int rc = plan_search(ctx, 1, guide, &whole, pl);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = ensure_bin_base(ctx, pl, ctx->stream);
+  if (rc) return rc;
+  const PackedRef& ref = ctx->ref;
+  if (params->first_window < 0 || params->n_windows <= 0 || (uint64_t)params->first_window + (uint64_t)params->n_windows > pl.win_n)
+    return fail(ctx, CALITAS_EINVAL, "first_window / n_windows outside the window table (" + std::to_string(pl.win_n) + " windows)");
+  std::string version, stamp;
+  calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
+  const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+  const size_t hlen = rs.header.size();
+  std::mutex copy_mu;
+  const bool planned = plan_owned_range(ctx, pl, (uint64_t)params->first_window, (uint64_t)params->n_windows);
+  if (planned && binned_wanted(ctx, pl)) {
+    LaneText lt;
+    bool declined = false;
+    rc = lane_rows_binned(ctx, pl, false, rs, lt, false, &declined);
+    if (rc) return rc;
+    if (!declined) {
+      const size_t total = hlen + (size_t)lt.bytes;
+      if (user_dst && user_cap < total + 1) return fail(ctx, CALITAS_EINVAL, "the caller's buffer is too small for the text");
+      char* text = user_dst ? user_dst : (char*)calitas_out_alloc_pinned(total + 1);
+      if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
+      std::memcpy(text, rs.header.data(), hlen);
+      if (lt.bytes) {
+        rc = text_to_host(ctx, ctx, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+        if (rc) { if (!user_dst) calitas_free(text); return rc; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]); lt.tm.hits_kernel_ms = ms;
+      }
+      text[total] = 0;
+      calitas_timing_t tm = lt.tm;
+      tm.hit_rows = lt.rows; tm.hits_bytes = total; tm.lanes = 1;
+      ctx->timing = tm;
+      *tsv = text;
+      if (tsv_bytes) *tsv_bytes = total;
+      if (n_rows) *n_rows = lt.rows;
+      return CALITAS_OK;
+    }
+    HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
+  }
+  // ---- the contigs the stretch touches, whole, on the general kernels; their rows filtered by position ----
+  if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits on a window range: the bins declined, searching the touched contigs whole\n");
+  std::vector<uint64_t> wb(ref.contigs.size() + 1, 0);
+  for (size_t c = 0; c < ref.contigs.size(); c++) wb[c + 1] = wb[c] + window_count(ref.contigs[c].len, pl.step);
+  const uint64_t first = (uint64_t)params->first_window, last = first + (uint64_t)params->n_windows;
+  auto key_of = [&](uint64_t w) {
+    if (w >= wb.back()) return (uint64_t)ref.contigs.size() << 32;
+    const size_t c = (size_t)(std::upper_bound(wb.begin(), wb.end(), w) - wb.begin()) - 1;
+    return ((uint64_t)c << 32) | ((w - wb[c]) * (uint64_t)pl.step);
+  };
+  const uint64_t own_lo = key_of(first), own_hi = key_of(last);
+  std::string body;
+  uint64_t rows = 0;
+  calitas_timing_t tm{};
+  for (size_t c = 0; c < ref.contigs.size(); c++) {
+    if (wb[c + 1] <= first || wb[c] >= last || wb[c + 1] == wb[c]) continue;
+    calitas_params_t pc = whole;
+    pc.chrom_index = (int32_t)c;
+    char* t = nullptr;
+    uint64_t tb = 0, tr = 0;
+    rc = search_hits_attempt(ctx, guide, guide_id, &pc, version.c_str(), stamp.c_str(), &t, &tb, &tr, nullptr, 0);
+    if (rc) return rc;
+    // rows: chromosome is column 4, coordinate_start column 5 (RH:99-132); the contig is c, so only the position decides
+    const char* q = t + hlen;
+    const char* end = t + tb;
+    while (q < end) {
+      const char* nl = (const char*)std::memchr(q, '\n', (size_t)(end - q));
+      const char* row_end = nl ? nl + 1 : end;
+      const char* f = q;
+      for (int k = 0; k < 4 && f < row_end; k++) { const char* tab = (const char*)std::memchr(f, '\t', (size_t)(row_end - f)); f = tab ? tab + 1 : row_end; }
+      const uint64_t pos = std::strtoull(f, nullptr, 10);
+      const uint64_t key = ((uint64_t)c << 32) | pos;
+      if (key >= own_lo && key < own_hi) { body.append(q, (size_t)(row_end - q)); rows++; }
+      q = row_end;
+    }
+    calitas_free(t);
+    tm.scan_kernel_ms += ctx->timing.scan_kernel_ms; tm.align_kernel_ms += ctx->timing.align_kernel_ms; tm.gpu_total_ms += ctx->timing.gpu_total_ms;
+    tm.bases_scanned += ctx->timing.bases_scanned; tm.packed_bytes += ctx->timing.packed_bytes; tm.scan_records += ctx->timing.scan_records;
+    tm.raw_alignments += ctx->timing.raw_alignments; tm.accepted_alignments += ctx->timing.accepted_alignments;
+  }
+  const size_t total = hlen + body.size();
+  if (user_dst && user_cap < total + 1) return fail(ctx, CALITAS_EINVAL, "the caller's buffer is too small for the text");
+  char* text = user_dst ? user_dst : (char*)calitas_out_alloc_pinned(total + 1);
+  if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
+  std::memcpy(text, rs.header.data(), hlen);
+  std::memcpy(text + hlen, body.data(), body.size());
+  text[total] = 0;
+  tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1;
+  ctx->timing = tm;
+  *tsv = text;
+  if (tsv_bytes) *tsv_bytes = total;
+  if (n_rows) *n_rows = rows;
+  return CALITAS_OK;
+}
+
 // user_dst: the text goes into this caller-owned buffer of user_cap bytes (calitas_search_hits_into) instead of a block of the
 // library; CALITAS_EINVAL when it is too small.
 static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
                                char* user_dst, uint64_t user_cap) {
+  if (params && (params->first_window != 0 || params->n_windows != 0))
+    return search_hits_owned(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, user_dst, user_cap);
   const auto t_call = std::chrono::steady_clock::now();
   *tsv = nullptr;
   if (tsv_bytes) *tsv_bytes = 0;

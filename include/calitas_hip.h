@@ -71,11 +71,16 @@ typedef struct {
                                             * bit 1 (2): one alignment per bottom-row matrix cell (Diag, Left, Up) that reaches minScore
                                             *            instead of one per end column from the best of the three (U1) */
   int32_t max_variants;                    /* -V  only echoed into aligner_other_parameters */
-  /* calitas_search only: restrict the call to windows [first_window, first_window + n_windows) of windowIterator's sequence for this
-   * (window size, step) over the whole reference, contigs in order (the index calitas_window_table lists them in when min_length is 0);
-   * n_windows = 0 means all of them.  The piece of a job one process of a window-range partition runs (calitas_amd/shard.py
-   * window_partition): the alignments of consecutive ranges, concatenated, are the alignments of the whole call.  The calls that
-   * go on to removeOverlaps (calitas_search_hits*) refuse a range: a contig that is cut needs its other part first. */
+  /* A window range [first_window, first_window + n_windows) of windowIterator's sequence for this (window size, step) over the whole
+   * reference, contigs in order (the index calitas_window_table lists them in when min_length is 0); n_windows = 0 means all of
+   * them.  The piece of a job one process of a multi-GPU partition runs (calitas_amd/shard.py window_partition):
+   *  - calitas_search aligns exactly those windows: the alignments of consecutive ranges, concatenated, are those of the whole call;
+   *  - calitas_search_hits / calitas_search_hits_into return the rows the range OWNS: the hits whose coordinate_start lies at or
+   *    behind the start of window first_window and before the start of window first_window + n_windows.  coordinate_start is the
+   *    first sort key of hits.txt, so the texts of consecutive ranges (minus their header lines) concatenate to the text of the
+   *    whole call, wherever the cuts fall; removeOverlaps is exact across a cut because every process also aligns the windows
+   *    around its stretch that can decide its hits.
+   * The stream and batch calls refuse a range. */
   int32_t first_window;
   int32_t n_windows;
 } calitas_params_t;

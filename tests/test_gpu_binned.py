@@ -155,9 +155,16 @@ def test_lanes_and_batch_take_the_binned_tail(C, tmp_path, monkeypatch):
         sr = C.SearchReference(guide=GUIDE, guide_id="a", context=ctx, max_gaps_between_guide_and_pam=2)
         one, _ = sr.run("v0", "stamp")
         assert ctx.timing()["binned_lanes"] == 1
-        monkeypatch.setenv("CALITAS_CHUNKS", "3")
+        monkeypatch.setenv("CALITAS_CHUNKS", "2")
+        two, _ = sr.run("v0", "stamp")
+        assert ctx.timing()["binned_lanes"] == 2 and two == one
+        monkeypatch.setenv("CALITAS_CHUNKS", "3")                 # three ranges: the general kernels by default ...
+        three, _ = sr.run("v0", "stamp")
+        assert ctx.timing()["binned_lanes"] == 0 and three == one
+        monkeypatch.setenv("CALITAS_BINNED", "1")                 # ... the per-bin ones on request
         three, _ = sr.run("v0", "stamp")
         assert ctx.timing()["binned_lanes"] == 3 and three == one
+        monkeypatch.delenv("CALITAS_BINNED")
         monkeypatch.delenv("CALITAS_CHUNKS")
         G = [C.Guide(GUIDE), C.Guide("GTGACTTGAAGTCTCAGTATnrg"), C.Guide(GUIDE)]
         res = ctx.search_hits_batch(G, ["a", "b", "a"], C.make_params(max_gaps_between_guide_and_pam=2), "v0", "stamp")
@@ -167,3 +174,50 @@ def test_lanes_and_batch_take_the_binned_tail(C, tmp_path, monkeypatch):
         ctx.close()
     _, want, _ = O.search_reference(fa, GUIDE, "a", g=2, threads=4)
     assert strip(C.read_hits(one)) == strip(want)
+
+
+@pytest.mark.parametrize("cuts", [2, 3, 8])
+def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts):
+    """calitas_search_hits on a window range returns the rows whose coordinate_start lies in the range's stretch of the genome: the
+    texts of consecutive ranges (minus their header lines) are the text of the whole call, wherever the cuts fall -- inside a contig,
+    between two overlapping hits, inside a chain of tandem copies (there the bins decline and the stretch's contigs are searched whole
+    and filtered: same rows).  Cut points are chosen to fall on such places."""
+    from calitas_amd import shard
+    rng = np.random.default_rng(100 + cuts)
+    step = 1000 - (len(GUIDE) + 5 + 2 - 1)
+    # contig a: sites around the window starts the cuts will fall on; contig b: a chain of tandem copies over a cut; c: plain; d: tiny
+    la, lb, lc = 61000, 45000, 30000
+    sites_a = [(int(p), int(rng.integers(0, 4)), bool(rng.integers(0, 2))) for p in rng.integers(200, la - 200, size=40)]
+    ca = planted(rng, la, sites_a)
+    cb = bytearray(planted(rng, lb, [(int(p), int(rng.integers(0, 4)), bool(rng.integers(0, 2))) for p in rng.integers(200, lb - 200, size=20)]).encode())
+    unit = b"CTTGCCCCACAGGGCAGTAATGG"
+    for k in range(12):
+        cb[22 * step - 70 + 9 * k: 22 * step - 70 + 9 * k + len(unit)] = unit
+    cc = planted(rng, lc, [(int(p), 1, False) for p in rng.integers(200, lc - 200, size=10)])
+    fa = write_fasta(str(tmp_path / "ranges.fa"), [("a", ca), ("b", cb.decode()), ("c", cc), ("d", "ACGT" * 20)])
+    lengths = [la, lb, lc, 80]
+    n_win = sum(shard.window_counts(lengths, step))
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        G = C.Guide(GUIDE)
+        pk = dict(max_gaps_between_guide_and_pam=2)
+        whole, n_whole = ctx.search_hits(G, "a", C.make_params(**pk), "v0", "stamp")
+        # cut points: equal parts, one moved onto the chain of contig b, one onto a contig boundary
+        wa = shard.window_counts(lengths, step)[0]
+        bounds = sorted(set([0, n_win] + [n_win * i // cuts for i in range(1, cuts)] + ([wa + 22] if cuts > 2 else []) + ([wa] if cuts > 3 else [])))
+        for mode in ("default", "general"):
+            if mode == "general":
+                monkeypatch.setenv("CALITAS_BINNED", "0")        # the fallback: whole contigs on the general kernels, rows filtered by position
+            pieces, rows = [], 0
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                text, n = ctx.search_hits(G, "a", C.make_params(first_window=lo, n_windows=hi - lo, **pk), "v0", "stamp")
+                head, _, body = text.partition("\n")
+                assert head + "\n" == whole[:len(head) + 1]
+                pieces.append(body); rows += n
+            monkeypatch.delenv("CALITAS_BINNED", raising=False)
+            assert rows == n_whole and whole == whole[:whole.index("\n") + 1] + "".join(pieces), (mode, bounds)
+    finally:
+        ctx.close()
+    _, want, _ = O.search_reference(fa, GUIDE, "a", g=2, threads=4)
+    assert n_whole > 60 and strip(C.read_hits(whole)) == strip(want)
