@@ -9,11 +9,13 @@ scan kernel + aligner kernels + per-window filter + removeOverlaps / sort / all 
 
 --gpus N > 1: one process per GPU.  Started by a launcher (torchrun: WORLD_SIZE / RANK / LOCAL_RANK in the environment) the script
 is one rank; started plainly (`python bench.py --gpus 8`) it spawns the N ranks itself -- fresh child processes, decided before
-this process touches a GPU -- and prints rank 0's line.  RCCL carries the barriers around the timed region; there is no data-path
-collective.  The N > 1 headline is BASELINE's partition: the contigs of ONE pass are divided over the ranks (--shard contigs,
-strong scaling; every rank packs only its slice and the ranks' texts are concatenated in one shared-memory file); the same run
-then measures the guide-sharded mode (every rank holds the genome and runs its own guide pass, weak scaling) and reports it in the
-labelled field "guide_sharded".  --shard guides makes that mode the headline instead.
+this process touches a GPU, the first one that fails stops the others -- and prints rank 0's line.  RCCL carries the barriers around
+the timed region; there is no data-path collective.  The N > 1 headline is ONE pass divided over the ranks (strong scaling):
+--shard windows (default) cuts windowIterator's windows into N equal consecutive ranges, every rank returns the rows whose
+coordinate_start lies in its stretch (calitas_search_hits_into on a window range) straight into its slot of one shared-memory file,
+and rank 0 checks the gathered file against a single-process search byte for byte after the timed region; --shard contigs gives every
+rank whole contigs (BASELINE's wording; 1.20x off balance at 8 ranks); --shard guides is the weak-scaling mode (every rank its own
+guide pass over the whole genome), also measured as a labelled second figure with --secondary.
 
 --config 4: BASELINE config 4, the 96-guide batch (guide #0 + 95 random 20-mers, seed 0xC4) through calitas_search_hits_batch;
 a step = all 96 guides.  --config 5: BASELINE config 5's shape, PAM-less 20-mer, max-guide-diffs 8, with a synthetic VCF
@@ -254,9 +256,10 @@ def main():
                     help="untimed calls before the warm-up steps until the device runs at its sustained clocks (default 0.75 s for config 3, 0 otherwise)")
     ap.add_argument("--config", type=int, choices=[3, 4, 5], default=3, help="BASELINE config: 3 one guide (the metric's), 4 the 96-guide batch, 5 PAM-less d=8 + VCF")
     ap.add_argument("--scale", type=float, default=None, help="genome size relative to hg38 (1.0 = 3.09 Gb; default 1.0, config 5: 0.05)")
-    ap.add_argument("--shard", choices=["contigs", "windows", "guides"], default="contigs",
-                    help="N>1: contigs = consecutive contig ranges of one pass (strong scaling, BASELINE's partition); windows = consecutive "
-                         "window ranges, contigs cut where the balance asks for it; guides = every rank its own guide pass over the whole genome (weak)")
+    ap.add_argument("--shard", choices=["contigs", "windows", "guides"], default="windows",
+                    help="N>1: windows (default) = consecutive window ranges of ONE pass, equal to within a window, contigs cut where the balance asks "
+                         "for it (strong scaling; every rank owns the rows of its stretch); contigs = consecutive whole-contig ranges of one pass "
+                         "(BASELINE's wording; 1.20x off balance at 8 ranks); guides = every rank its own guide pass over the whole genome (weak)")
     ap.add_argument("--cpu-sample-mb", type=float, default=-1, help="CPU baseline sample in Mb (<0: auto, 0: skip)")
     ap.add_argument("--secondary", action="store_true",
                     help="N>1: also measure the partition mode that is not the headline (every rank regenerates and re-uploads the genome for it)")
@@ -356,6 +359,12 @@ def main():
             gl = all_guides[:1]
         else:
             gl = None
+        if world > 1 and mode == "windows":
+            # windowIterator's windows in N consecutive ranges of equal size, cut wherever that falls (max / mean of the bases per rank
+            # 1.0000-1.0005): every rank holds the whole packed genome, scans its stretch and returns the rows whose coordinate_start
+            # lies in it (calitas_search_hits_into on a window range) -- consecutive pieces of hits.txt, no exchange between the ranks
+            g = [GUIDE0]
+            return None, g, 1, sum(lengths)
         if world > 1 and mode == "contigs":
             mine = shard.contiguous_partition(lengths, world)[rank]        # consecutive ranges: the gather is a concatenation
             g = gl or [GUIDE0]
@@ -387,8 +396,15 @@ def main():
     def measure(mode, keep_text=False):
         """K timed steps of one partition mode, bracketed by barrier + synchronize; the MAX over ranks is the job's time."""
         mine, my_guides, passes_per_step, bases_per_step_total = partition_mode(mode)
-        contig_mode = world > 1 and mode == "contigs"
+        contig_mode = world > 1 and mode in ("contigs", "windows")
         ctx, names, seqs = make_context(mine)
+        params_rank = params
+        if world > 1 and mode == "windows":
+            step_w = 1000 - (len(GUIDE0) + params_kw["max_guide_diffs"] + params_kw["max_gaps_between_guide_and_pam"] - 1)
+            first_w, n_w = shard.window_partition(lengths, world, step_w)[rank]
+            params_rank = C.make_params(first_window=first_w, n_windows=n_w, **params_kw)
+            loads = [shard.range_bases(lengths, step_w, 1000, f, n) for f, n in shard.window_partition(lengths, world, step_w)]
+            log("window partition: bases per rank max / mean = %.4f" % (max(loads) / (sum(loads) / world)))
         G = [C.Guide(g) for g in my_guides]
         ids = ["bench%d" % i for i in range(len(G))]
         phase = {"search_hits": 0.0, "gather": 0.0, "search": 0.0, "hits": 0.0, "free": 0.0}
@@ -396,6 +412,7 @@ def main():
         # rank; every rank maps it, page-locks its slot and has the library deliver its piece of hits.txt straight into the slot
         # (calitas_search_hits_into); hits.txt = rank 0's slot followed by the other slots without their header line.
         shm = None
+        partition_check = {}
         if contig_mode and len(G) == 1 and args.config == 3:
             import mmap
             import ctypes
@@ -449,7 +466,7 @@ def main():
                 phase["search_hits"] += tp1 - tp0
                 return tm, tm["accepted_alignments"], total_rows(sum(r for _, r in res))
             if shm is not None and not (args.no_hits or args.two_stage):
-                nbytes, rows = ctx.search_hits_into(G[0], "bench", params, shm["slot_addr"], shm["slot_bytes"], "bench", "bench")
+                nbytes, rows = ctx.search_hits_into(G[0], "bench", params_rank, shm["slot_addr"], shm["slot_bytes"], "bench", "bench")
                 tp1 = time.perf_counter()
                 tm = ctx.timing()
                 shm["table"][2 * rank] = nbytes; shm["table"][2 * rank + 1] = rows      # the gather: the text is in place already
@@ -532,7 +549,15 @@ def main():
                     n_lines += piece.count(b"\n"); n_bytes += len(piece)
                 total = int(sum(int(tb[2 * r + 1]) for r in range(world)))
                 assert n_lines == total + 1, (n_lines, total)
-                log("contig partition: hits.txt gathered in shared memory has %d rows (%d bytes) from %d ranks" % (total, n_bytes, world))
+                log("%s partition: hits.txt gathered in shared memory has %d rows (%d bytes) from %d ranks" % (mode, total, n_bytes, world))
+                if mode == "windows":
+                    # rank 0 holds the whole genome: the gathered file against ONE process's search, byte for byte (outside the timed region)
+                    import zlib
+                    gathered = b"".join((mm[4096 + r * shm["slot_bytes"]: 4096 + r * shm["slot_bytes"] + int(tb[2 * r])] if r == 0 else
+                                         mm[4096 + r * shm["slot_bytes"]: 4096 + r * shm["slot_bytes"] + int(tb[2 * r])].split(b"\n", 1)[1]) for r in range(world))
+                    single, n_single = ctx.search_hits(G[0], "bench", params, "bench", "bench", decode="bytes")
+                    partition_check.update(rows=n_single, crc_single=zlib.crc32(single), crc_gathered=zlib.crc32(gathered), identical=bool(single == gathered))
+                    log("window partition: gathered text identical to a single-process search: %s (%d rows)" % (single == gathered, n_single))
             ctx.unpin_host(shm["slot_addr"])
             dist.barrier(group=gloo)
             del shm["table"]
@@ -544,165 +569,12 @@ def main():
             os.unlink(vcf_path)
         return dict(dt=dt, acc=acc, last=last, phase=phase, my_guides=my_guides, passes_per_step=passes_per_step,
                     bases_per_step_total=bases_per_step_total, names=names, seqs=seqs, text=text, tiles=tiles, n_variants=n_variants,
-                    mine=mine)
-
-    def measure_windows():
-        """--shard windows (config 3): consecutive window ranges of equal size (shard.window_partition).  A rank finishes the contigs
-        that lie entirely inside its range with calitas_search_hits (text into its slot of the shared mapping); of a contig that is cut it
-        aligns its windows with calitas_search (first_window / n_windows), the parts' alignment records meet in shared memory at the
-        lowest rank that touches the contig, and that rank runs removeOverlaps / sort / rows on them (calitas_hits_tsv)."""
-        import ctypes
-        import mmap
-        import numpy as np
-        import torch.distributed as dist
-        AlnT = C._lib.AlnT
-        rec_size = ctypes.sizeof(AlnT)
-        step_w = 1000 - (len(GUIDE0) + params_kw["max_guide_diffs"] + params_kw["max_gaps_between_guide_and_pam"] - 1)
-        ranges = shard.window_partition(lengths, world, step_w)
-        parts_all = [shard.range_contigs(lengths, step_w, f, n) for f, n in ranges]
-        owner = shard.contig_owner(parts_all)
-        mine_parts = parts_all[rank]
-        whole_ids = [ci for ci, _, _, w in mine_parts if w]
-        cut = [(ci, k0, n) for ci, k0, n, w in mine_parts if not w]
-        cut_ids = sorted({ci for ci, _, _ in cut})
-        G0 = C.Guide(GUIDE0)
-        ctx_a = ctx_b = None
-        t_gen = time.perf_counter()
-        if whole_ids:
-            na, sa = build_genome(args.scale, device, contig_indices=whole_ids, guides=[GUIDE0], log=None)
-            ctx_a = C.Context(local_rank); ctx_a.set_reference(na, sa, genome_build="synthetic-hg38-sized"); del sa
-        if cut_ids:
-            nb, sb = build_genome(args.scale, device, contig_indices=cut_ids, guides=[GUIDE0], log=None)
-            ctx_b = C.Context(local_rank); ctx_b.set_reference(nb, sb, genome_build="synthetic-hg38-sized"); del sb
-        log("window partition: rank 0 holds %d whole contigs and %d cut ones, set up in %.1f s" % (len(whole_ids), len(cut_ids), time.perf_counter() - t_gen))
-        # window index of a cut contig's first window inside ctx_b's own window table
-        b_base, acc = {}, 0
-        for ci in cut_ids:
-            b_base[ci] = acc
-            acc += shard.window_counts([lengths[ci]], step_w)[0]
-        # shared mapping: table (8 words per rank), text slot and record slot per rank
-        slot_bytes = ((max(8 << 20, int(160e6 * args.scale / world) * 2)) + 4095) & ~4095
-        rec_slot = 8 << 20
-        shm_path = "/dev/shm/calitas_bench_win_%s.bin" % os.environ.get("MASTER_PORT", "0")
-        size = 4096 + world * (slot_bytes + rec_slot)
-        if rank == 0:
-            with open(shm_path, "wb") as f:
-                f.truncate(size)
-        dist.barrier(group=gloo)
-        fd = os.open(shm_path, os.O_RDWR)
-        mm = mmap.mmap(fd, size)
-        os.close(fd)
-        table = np.frombuffer(mm, dtype=np.uint64, count=world * 8).reshape(world, 8)   # text bytes, rows, cut rows, records, rec seq, done seq
-        base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
-        text_addr = lambda r: base + 4096 + r * (slot_bytes + rec_slot)
-        rec_addr = lambda r: text_addr(r) + slot_bytes
-        if ctx_a is not None:
-            ctx_a.pin_host(text_addr(rank), slot_bytes)
-        sends = [(ci, k0, n) for ci, k0, n in cut if owner[ci] != rank]            # at most one: the head part of this rank's range
-        owned = [(ci, k0, n) for ci, k0, n in cut if owner[ci] == rank]
-        feeders = {ci: [q for q in range(world) if q != rank and any(c == ci for c, _, _, _ in parts_all[q])] for ci, _, _ in owned}
-        phase = {"search_hits": 0.0, "cut_search": 0.0, "exchange": 0.0, "cut_rows": 0.0}
-
-        def spin(cond):
-            n = 0
-            while not cond():
-                n += 1
-                if n > 200000000:
-                    raise SystemExit("bench.py: a rank stopped answering in the window-partition exchange")
-
-        def step(seq):
-            t0 = time.perf_counter()
-            rows_a = nbytes = 0
-            tm = None
-            if ctx_a is not None:
-                nbytes, rows_a = ctx_a.search_hits_into(G0, "bench", params, text_addr(rank), slot_bytes, "bench", "bench")
-                tm = ctx_a.timing()
-            t1 = time.perf_counter()
-            mine_recs = {}
-            for ci, k0, n in cut:
-                out, cnt = ctx_b.search_raw([G0], C.make_params(first_window=b_base[ci] + k0, n_windows=n, **params_kw))
-                mine_recs[ci] = (out, cnt)
-                if tm is None:
-                    tm = ctx_b.timing()
-            t2 = time.perf_counter()
-            for ci, k0, n in sends:                       # this part's records to the owner, through the record slot
-                out, cnt = mine_recs[ci]
-                o = owner[ci]
-                spin(lambda: int(table[o, 5]) >= seq - 1)         # the owner is done with the previous step's records
-                if cnt * rec_size > rec_slot:
-                    raise SystemExit("bench.py: record slot too small")
-                ctypes.memmove(rec_addr(rank), out, cnt * rec_size)
-                table[rank, 3] = cnt
-                table[rank, 4] = seq
-            rows_c = 0
-            t3 = time.perf_counter()
-            for ci, k0, n in owned:
-                out, cnt = mine_recs[ci]
-                pieces = [(ctypes.addressof(out.contents) if cnt else 0, cnt)]
-                for q in feeders[ci]:
-                    spin(lambda: int(table[q, 4]) >= seq)
-                    pieces.append((rec_addr(q), int(table[q, 3])))
-                total = sum(c for _, c in pieces)
-                arr = (AlnT * max(1, total))()
-                off = 0
-                for addr, c in pieces:
-                    if c:
-                        ctypes.memmove(ctypes.addressof(arr) + off * rec_size, addr, c * rec_size)
-                    off += c
-                if total:                                   # the feeders number the contig differently in their own context
-                    np.frombuffer(arr, dtype=np.int32).reshape(-1, rec_size // 4)[:total, 1] = cut_ids.index(ci)
-                _, r = ctx_b.hits_tsv_raw(G0, "bench", params, arr, total, "bench", "bench", decode=False)
-                rows_c += r
-            table[rank, 0] = nbytes; table[rank, 1] = rows_a; table[rank, 2] = rows_c
-            table[rank, 5] = seq
-            for out, _ in mine_recs.values():
-                C._lib.lib.calitas_free(out)
-            t4 = time.perf_counter()
-            phase["search_hits"] += t1 - t0; phase["cut_search"] += t2 - t1; phase["exchange"] += t3 - t2; phase["cut_rows"] += t4 - t3
-            return tm
-
-        seq = 0
-        zero_tm = {k: 0 for k in ("scan_kernel_ms", "align_kernel_ms", "gpu_total_ms", "hits_kernel_ms", "hits_copy_ms", "host_post_ms",
-                                  "accepted_alignments", "raw_alignments", "scan_records", "hits_bytes", "packed_bytes", "lanes")}
-        for _ in range(3 + args.warmup + int(args.prime_seconds * 400)):
-            seq += 1
-            step(seq)
-        for k in phase:
-            phase[k] = 0.0
-        sync()
-        t0 = time.perf_counter()
-        acc = {"scan": 0.0, "align": 0.0, "post": 0.0, "gpu": 0.0, "hitsk": 0.0, "copy": 0.0}
-        tm = None
-        for _ in range(args.steps):
-            seq += 1
-            tm = step(seq) or zero_tm           # a rank whose range holds no window of its own (world > windows) has no timings
-            acc["scan"] += tm["scan_kernel_ms"]; acc["align"] += tm["align_kernel_ms"]; acc["gpu"] += tm["gpu_total_ms"]
-            acc["hitsk"] += tm["hits_kernel_ms"]; acc["copy"] += tm["hits_copy_ms"]
-        sync()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        dist.barrier(group=gloo)
-        rows = int(table[:, 1].sum() + table[:, 2].sum())
-        loads = [shard.range_bases(lengths, step_w, 1000, f, n) for f, n in ranges]
-        log("window partition: %d rows over %d ranks; bases per rank max / mean = %.4f" % (rows, world, max(loads) / (sum(loads) / world)))
-        tiles = (ctx_a or ctx_b).tile_census()
-        if ctx_a is not None:
-            ctx_a.unpin_host(text_addr(rank)); ctx_a.close()
-        if ctx_b is not None:
-            ctx_b.close()
-        dist.barrier(group=gloo)
-        del table
-        if rank == 0:
-            os.unlink(shm_path)
-        return dict(dt=dt, acc=acc, last=(tm, tm["accepted_alignments"], rows), phase=phase, my_guides=[GUIDE0], passes_per_step=1,
-                    bases_per_step_total=sum(lengths), names=[], seqs=[], text=None, tiles=tiles, n_variants=0, mine=None)
+                    mine=mine, partition_check=partition_check)
 
     headline_mode = args.shard if world > 1 else "none"
     if headline_mode == "windows" and args.config != 3:
-        raise SystemExit("--shard windows is implemented for --config 3")
-    m = measure_windows() if headline_mode == "windows" else measure(headline_mode, keep_text=(world == 1))
+        headline_mode = "contigs"             # the guide batch and the variant branch are partitioned by contigs
+    m = measure(headline_mode, keep_text=(world == 1))
     second = None
     if world > 1 and args.secondary and not args.no_secondary and args.config == 3:
         other = "guides" if headline_mode in ("contigs", "windows") else "contigs"
@@ -781,6 +653,11 @@ def main():
                     "peak_measured_note": "v_and / v_add streams on all 1024 SIMDs, profiles/r01_valu_rates.txt"}
         except Exception:
             pass
+        if m.get("partition_check"):
+            result["partition_check"] = m["partition_check"]     # the gathered hits.txt of the N ranks against one process's search
+            if not m["partition_check"].get("identical", True):
+                print(json.dumps(result), flush=True)
+                raise SystemExit("bench.py: the gathered text of the window partition differs from a single-process search")
         if second is not None:
             result["guide_sharded" if second["partition"] == "guides" else "contig_sharded"] = second
         mb = args.cpu_sample_mb

@@ -143,3 +143,26 @@ def contig_owner(parts_per_rank):
         for ci, _, _, _ in parts:
             owner.setdefault(ci, r)
     return owner
+
+
+def owned_stretch(lengths, step, first_window, n_windows):
+    """The stretch of the genome a window range OWNS under calitas_search_hits (include/calitas_hip.h, calitas_params_t.first_window):
+    the hits whose coordinate_start lies at or behind the start of window first_window and before the start of window
+    first_window + n_windows.  Returns ((contig, position), (contig, position)) -- a half-open interval of (contig, position) keys;
+    the end of the reference is (number of contigs, 0).  Consecutive ranges own consecutive stretches, so their hits.txt texts
+    concatenate (coordinate_start is the first key of ReferenceHit.sort)."""
+    counts = window_counts(lengths, step)
+
+    def start_of(w):
+        base = 0
+        for ci, nw in enumerate(counts):
+            if w < base + nw:
+                return (ci, (w - base) * step)
+            base += nw
+        return (len(lengths), 0)
+    return start_of(first_window), start_of(first_window + n_windows)
+
+
+def owns(stretch, contig, position):
+    """Whether a hit at (contig index, coordinate_start) belongs to the stretch of owned_stretch()."""
+    return stretch[0] <= (contig, position) < stretch[1]

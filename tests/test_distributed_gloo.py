@@ -251,3 +251,68 @@ def test_window_partition_cuts_a_contig_and_reproduces_the_rows():
         loads = [shard.range_bases(synth.HG38_LENGTHS, 971, 1000, f, k) for f, k in shard.window_partition(synth.HG38_LENGTHS, n, 971)]
         assert max(loads) <= 1.02 * sum(loads) / n, (n, loads)
         assert max(loads) <= 1.0005 * sum(loads) / n
+
+
+def _worker_owned(rank, world, port, outdir):
+    """The partition bench.py --shard windows runs on the GPUs: every rank owns a stretch of the genome (shard.owned_stretch of its
+    window range) and returns the rows whose coordinate_start lies in it; here the oracle computes the rows of the contigs a rank
+    touches (the GPU path decides them from the stretch plus a halo, tests/test_gpu_binned.py holds that against this definition),
+    the ranks' pieces are gathered over gloo and concatenated in rank order."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    import calitas_amd as C
+    from calitas_amd import shard
+    from fasta_util import write_fasta
+    names, seqs = _genome()
+    lengths = [len(s) for s in seqs]
+    step = 1000 - (C.Guide(GUIDE).cli_length + 4 + 2 - 1)
+    first, n = shard.window_partition(lengths, world, step)[rank]
+    stretch = shard.owned_stretch(lengths, step, first, n)
+    touched = sorted({ci for ci, _, _, _ in shard.range_contigs(lengths, step, first, n)})
+    fa = write_fasta(os.path.join(outdir, "owned_%d.fa" % rank), [(names[ci], seqs[ci].decode()) for ci in touched])
+    _, rows, _ = O.search_reference(fa, GUIDE, "a", d=4, p=1, g=2, D=7, threads=2)
+    mine = [r for r in rows if shard.owns(stretch, names.index(r["chromosome"]), int(r["coordinate_start"]))]
+    pieces = [None] * world if rank == 0 else None
+    dist.gather_object(mine, pieces, dst=0)
+    if rank == 0:
+        import json
+        with open(os.path.join(outdir, "owned.json"), "w") as f:
+            json.dump([r for piece in pieces for r in piece], f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owned_stretches_concatenate_to_the_whole_job():
+    """world_size 2 over gloo: the window partition cuts a contig; each rank keeps the rows its stretch owns; the concatenation in rank
+    order is the single-process hits.txt, row for row and in order.  And the stretches of hg38's 8-way partition tile the genome."""
+    sys.path.insert(0, HERE)
+    import json
+    import oracle_lib as O
+    import calitas_amd as C
+    from calitas_amd import shard, synth
+    from fasta_util import write_fasta
+    names, seqs = _genome()
+    lengths = [len(s) for s in seqs]
+    step = 1000 - (C.Guide(GUIDE).cli_length + 4 + 2 - 1)
+    with tempfile.TemporaryDirectory() as d:
+        port = 33500 + os.getpid() % 2000
+        mp.start_processes(_worker_owned, args=(2, port, d), nprocs=2, join=True, start_method="spawn")
+        got = json.load(open(os.path.join(d, "owned.json")))
+        fa = write_fasta(os.path.join(d, "whole.fa"), [(n, s.decode()) for n, s in zip(names, seqs)])
+        _, want, _ = O.search_reference(fa, GUIDE, "a", d=4, p=1, g=2, D=7, threads=2)
+    skip = {"aligner_version", "time_stamp"}
+    strip = lambda rows: [{k: v for k, v in r.items() if k not in skip} for r in rows]
+    assert len(want) > 5 and strip(got) == strip(want)
+    # hg38, 8 ranks: the stretches are consecutive, start at (0, 0), end at the end of the reference, and every cut is a window start
+    hstep = 971
+    parts = shard.window_partition(synth.HG38_LENGTHS, 8, hstep)
+    st = [shard.owned_stretch(synth.HG38_LENGTHS, hstep, f, n) for f, n in parts]
+    assert st[0][0] == (0, 0) and st[-1][1] == (len(synth.HG38_LENGTHS), 0)
+    for a, b in zip(st[:-1], st[1:]):
+        assert a[1] == b[0] and a[1][1] % hstep == 0
+    loads = [shard.range_bases(synth.HG38_LENGTHS, hstep, 1000, f, n) for f, n in parts]
+    assert max(loads) / (sum(loads) / 8) < 1.001
