@@ -219,8 +219,8 @@ def test_failed_reference_upload_leaves_no_half_set_reference(C, tmp_path, monke
 def test_window_ranges_of_calitas_search_concatenate_to_the_whole_call(C, tmp_path):
     """calitas_params_t first_window / n_windows (the piece of a job one rank of a window-range partition runs, shard.window_partition):
     the alignments of consecutive ranges -- cuts inside contigs, inside an N block, one range a single window -- concatenate to the
-    alignments of the whole call, record for record, and calitas_hits_tsv on them gives calitas_search_hits' bytes.  The calls that
-    run removeOverlaps themselves refuse a range."""
+    alignments of the whole call, record for record, and calitas_hits_tsv on them gives calitas_search_hits' bytes; calitas_search_hits
+    on a range returns the rows whose coordinate_start lies in the range's stretch (their texts concatenate as well)."""
     import test_gpu_parity as P
     from calitas_amd import shard
     fa = P.synth_fasta(tmp_path, 73, [GUIDE0], lengths=(1_400_000, 300_000, 90_000, 700, 26), n_block=40_000)
@@ -243,8 +243,18 @@ def test_window_ranges_of_calitas_search_concatenate_to_the_whole_call(C, tmp_pa
             assert [key(a) for a in got] == [key(a) for a in whole], cuts
         assert len(whole) > 60
         assert ctx.hits_tsv(G, "a", params, got, "v0", "stamp") == want_text
-        with pytest.raises(C.CalitasError, match="calitas_search only"):
-            ctx.search_hits(G, "a", C.make_params(first_window=0, n_windows=10, **kw))
+        # calitas_search_hits on a range returns the rows the range OWNS (coordinate_start inside its stretch): consecutive ranges'
+        # texts concatenate to the whole text, cuts inside contigs and inside the N block included
+        for cuts in (shard.window_partition(ctx.contig_lengths, 3, step), [(0, 700), (700, 1), (701, total - 701)],
+                     shard.window_partition(ctx.contig_lengths, 8, step)):
+            body, rows = "", 0
+            for f, n in cuts:
+                text, nr = ctx.search_hits(G, "a", C.make_params(first_window=f, n_windows=n, **kw), "v0", "stamp")
+                body += text.split("\n", 1)[1]
+                rows += nr
+            assert want_text[0].split("\n", 1)[0] + "\n" + body == want_text[0] and rows == want_text[1], cuts
+        with pytest.raises(C.CalitasError, match="window range"):          # the stream and batch calls refuse a range
+            ctx.search_hits_batch([G, G], ["a", "b"], C.make_params(first_window=0, n_windows=10, **kw), "v0", "stamp")
         with pytest.raises(C.CalitasError, match="outside the window table"):
             ctx.search([G], C.make_params(first_window=total - 5, n_windows=10, **kw))
     finally:
