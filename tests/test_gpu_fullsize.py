@@ -65,6 +65,35 @@ def test_hg38_size_paths_agree_and_rows_are_ordered(world, monkeypatch):
     assert perfect >= 3
 
 
+def test_hg38_size_window_partition_concatenates_to_the_whole_text(world, monkeypatch):
+    """The multi-GPU partition at BASELINE's size on one card: windowIterator's 3.18 M windows in 8 equal consecutive ranges
+    (shard.window_partition: the cuts fall inside chromosomes), every range through calitas_search_hits on its window range (the rows whose
+    coordinate_start lies in its stretch); the eight texts, concatenated, are the single-call text byte for byte -- with the per-bin
+    kernels deciding each stretch from its own bins plus a halo, and with the whole-contig fallback."""
+    from calitas_amd import shard
+    C, ctx, names, seqs, guide = world
+    kw = dict(max_guide_diffs=5, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2)
+    G = C.Guide(guide)
+    whole, n = ctx.search_hits(G, "a", C.make_params(**kw), "v0", "stamp", decode="bytes")
+    lengths = [len(s) for s in seqs]
+    parts = shard.window_partition(lengths, 8, 971)
+    assert sum(k for _, k in parts) == sum(shard.window_counts(lengths, 971)) > 3_000_000
+    head = whole[:whole.index(b"\n") + 1]
+    pieces, rows, binned = [], 0, 0
+    for first, count in parts:
+        text, k = ctx.search_hits(G, "a", C.make_params(first_window=first, n_windows=count, **kw), "v0", "stamp", decode="bytes")
+        assert text.startswith(head)
+        pieces.append(text[len(head):]); rows += k; binned += ctx.timing()["binned_lanes"]
+    assert rows == n and head + b"".join(pieces) == whole
+    assert binned == 8                                              # every stretch was decided by the per-bin kernels
+    # two of the stretches again on the fallback (the touched contigs searched whole on the general kernels, rows filtered by position)
+    monkeypatch.setenv("CALITAS_BINNED", "0")
+    for i in (2, 7):
+        first, count = parts[i]
+        text, k = ctx.search_hits(G, "a", C.make_params(first_window=first, n_windows=count, **kw), "v0", "stamp", decode="bytes")
+        assert text[len(head):] == pieces[i]
+
+
 def test_hg38_size_whole_chromosomes_against_the_oracle(world):
     """chr19-chr22 and chrM of the full-size run (about 220 Mb), every column, against the oracle run on those contigs alone:
     windows, removeOverlaps groups and the sort never cross a contig, so the rows must be identical."""
