@@ -69,6 +69,7 @@ struct BinArgs {
   unsigned long long own_lo, own_hi;
   uint32_t* rows_list;               // bins with rows, in no particular order (one append per wave)
   uint32_t* rows_count;              // (zero at launch)
+  uint32_t dbg;                      // timing experiments (CALITAS_BINNED_SKIP)
 };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -614,6 +615,7 @@ struct RowsArgs {
   uint32_t* box;                // mailbox (device view)
   uint32_t seq;
   uint32_t n_chunks, n_supers;
+  const uint32_t* complex_count;   // (statistics) bins that took a whole wave
 };
 
 // One wave per bin: where the bin's text starts = bytes of the chunks before its chunk + bytes of the bins before it in its chunk;
@@ -651,12 +653,12 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
     if (lane == 0) {
       for (int i = 0; i < 8; i++) o.box[BIN_BOX_COUNTERS + i] = __hip_atomic_load(o.counters + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       o.box[BIN_BOX_ROWS] = rows_tot; o.box[BIN_BOX_BYTES] = (uint32_t)tot; o.box[BIN_BOX_BYTES + 1] = (uint32_t)(tot >> 32);
-      o.box[BIN_BOX_FLAGS] = flags; o.box[BIN_BOX_ACCEPTED] = acc_tot;
+      o.box[BIN_BOX_FLAGS] = flags; o.box[BIN_BOX_ACCEPTED] = acc_tot; o.box[BIN_BOX_COMPLEX] = *o.complex_count;
       __threadfence_system();
       __hip_atomic_store(o.box, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  if (flags != 0) return;
+  if (flags != 0 || (a.dbg & 2u)) return;
   if (n == 0) continue;
   const uint8_t* head = reinterpret_cast<const uint8_t*>(m.blob) + o.rc.head_off;     // constant pieces straight from global memory (L2-resident)
   const uint8_t* tail = reinterpret_cast<const uint8_t*>(m.blob) + o.rc.tail_off;
@@ -785,7 +787,7 @@ static hipError_t launch_rows(BinnedWork& w, HitsWork& hw, const BinArgs& ba, co
   TRY(mailbox_open(*post));
   RowsArgs ro{};
   ro.rc = hw.rc; ro.names = hw.names; ro.text = hw.text; ro.text_cap = hw.text_cap; ro.counters = d_counters; ro.box = post->dev; ro.seq = ++post->seq;
-  ro.n_chunks = w.n_chunks; ro.n_supers = w.n_supers;
+  ro.n_chunks = w.n_chunks; ro.n_supers = w.n_supers; ro.complex_count = w.complex_count;
   post->host[BIN_BOX_LATE] = 0;                              // raised by any wave while rows are written; read when the stream is done
   const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(w.n_bins, 1u), 16384u);      // strides over the list of bins with rows
   hipExtLaunchKernelGGL(bin_rows_kernel, dim3(grid), dim3(64), 0, stream, ev_start, ev_done, 0, ba, ma, ro);
@@ -833,7 +835,11 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
   hipLaunchKernelGGL(bin_hits_small_kernel, dim3((std::max<uint32_t>(geo.n_bins, 1u) + 63) / 64), dim3(64), 0, stream, ba, ma, sa);
   TRY(hipGetLastError());
   // the listed bins: a fixed grid that strides over the list (its length is on the device)
-  const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(geo.n_bins, 1u), 2048u);
+  const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(geo.n_bins, 1u), 1024u);
+  int skip = 0;                                              // timing experiments only (the text is wrong): 1 = no wave-per-bin kernel, 2 = rows kernel posts and returns
+  if (const char* env = std::getenv("CALITAS_BINNED_SKIP")) skip = std::atoi(env);
+  ba.dbg = (skip & 2) ? 2u : 0u;
+  if (!(skip & 1))
   hipExtLaunchKernelGGL(bin_hits_kernel, dim3(grid), dim3(64 * BIN_WAVES), 0, stream, nullptr, ev_hits_done, 0, ba, ma, (const uint32_t*)w.complex_list,
                         (const uint32_t*)w.complex_count);
   TRY(hipGetLastError());

@@ -34,7 +34,7 @@ constexpr uint32_t BIN_FLAG_INTERNAL = 32;  // a row's length differs between th
 // Mailbox words of the post of the rows kernel (after the sequence word).
 constexpr int BIN_BOX_COUNTERS = 1;         // 1..8: the eight counters of the lane (scan records, raw alignments, anomalies, ...)
 constexpr int BIN_BOX_ROWS = 9, BIN_BOX_BYTES = 10 /* and 11 */, BIN_BOX_FLAGS = 12, BIN_BOX_LATE = 13 /* flags raised while rows are written */,
-              BIN_BOX_ACCEPTED = 14;
+              BIN_BOX_ACCEPTED = 14, BIN_BOX_COMPLEX = 15 /* statistics: bins that took a whole wave */;
 
 // Bases per bin for a window size: the smallest power of two that leaves room for two windows of context on the left and the longest
 // hit on the right, at least 8 kb; 0 = this window size is not handled.

@@ -960,6 +960,9 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   tm.bases_scanned = pl.bases; tm.packed_bytes = (pl.bases + 3) / 4;
   tm.scan_records = n_rec; tm.raw_alignments = n_raw; tm.candidate_columns = lane->h_counters[4];
   tm.accepted_alignments = lane->mbox.host[BIN_BOX_ACCEPTED];
+  if (std::getenv("CALITAS_TRACE"))
+    std::fprintf(stderr, "[calitas] binned tail: %u bins, %u of them by a whole wave, %u rows, %llu bytes\n", pl.n_bins, (unsigned)lane->mbox.host[BIN_BOX_COMPLEX],
+                 (unsigned)lane->mbox.host[BIN_BOX_ROWS], (unsigned long long)bytes);
   kernel_times(lane, tm);                                    // scan, align + trace, everything up to the end of bin_hits_kernel
   tm.binned_lanes = 1;
   lane->timing = tm;
@@ -1853,6 +1856,11 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = (uint32_t)parts.size();
   ctx->timing = tm;
   ctx->last_text_bytes = total;
+  if (trace && parts.size() > 1) {
+    std::string per;
+    for (auto& lt : parts) { char b[96]; std::snprintf(b, sizeof b, " [scan %.3f align+trace %.3f rows %.3f copy %.3f]", lt.tm.scan_kernel_ms, lt.tm.align_kernel_ms, lt.tm.hits_kernel_ms, lt.tm.hits_copy_ms); per += b; }
+    std::fprintf(stderr, "[calitas] search_hits lanes (ms):%s\n", per.c_str());
+  }
   if (trace)
     std::fprintf(stderr, "[calitas] search_hits: %zu lane(s), scan %.3f ms, align %.3f ms, hits kernels %.3f ms, text copy %.3f ms (sums over lanes), call %.3f ms (%llu accepted, %llu rows, %zu bytes)\n",
                  parts.size(), tm.scan_kernel_ms, tm.align_kernel_ms, tm.hits_kernel_ms, tm.hits_copy_ms,
