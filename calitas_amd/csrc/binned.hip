@@ -424,6 +424,7 @@ __global__ __launch_bounds__(64) void bin_hits_small_kernel(BinArgs a, MidArgs m
             uint32_t w = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < SMALL_MAX; j++) if (widx[j] != 0xFFFFFFFFu && widx[j] >= cur && widx[j] < w) w = widx[j];
+            if (__ballot(w != 0xFFFFFFFFu) == 0) break;                     // (wave-uniform: no lane of the wave has another window)
             if (w != 0xFFFFFFFFu) {
               cur = w + 1u;
               int ks[SMALL_MAX], ke[SMALL_MAX];
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(64) void bin_hits_small_kernel(BinArgs a, MidArgs m
                   unsigned long long bk = 0;
 #pragma unroll
                   for (int j = 0; j < SMALL_MAX; j++) if (widx[j] == w && (uint32_t)(key[j] >> 63) == (uint32_t)list && key[j] > bk) bk = key[j];
+                  if (__ballot(bk != 0) == 0) break;                        // (no lane has another alignment in this list)
                   if (bk != 0) {
                     int b_start = 0, b_end = 0;
                     uint32_t b_edits = 0, b_src = 0, b_wk = 0;
@@ -468,8 +470,10 @@ __global__ __launch_bounds__(64) void bin_hits_small_kernel(BinArgs a, MidArgs m
           // ---- 3. coordinates; 4. order by counting, restart points, the walk of SR:661-671 over the (at most four) sorted hits ----
           HitRec hr[SMALL_MAX];
 #pragma unroll
+          for (int i = 0; i < SMALL_MAX; i++) hr[i] = HitRec{};
+#pragma unroll
           for (int i = 0; i < SMALL_MAX; i++) {
-            hr[i] = HitRec{};
+            if (__ballot((uint32_t)i < nA) == 0) break;                   // (no lane accepted that many)
             if ((uint32_t)i < nA) { hr[i] = hit_record(a.raw + acc_src[i], a.guides, a.win_base, a.win); if (hr[i].gstart < 0) out_flags |= BIN_FLAG_RANGE; }
           }
           int s_start[SMALL_MAX], s_end[SMALL_MAX], s_score[SMALL_MAX], s_arr[SMALL_MAX];
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(64) void bin_hits_small_kernel(BinArgs a, MidArgs m
           for (int p = 0; p < SMALL_MAX; p++) { s_start[p] = 0; s_end[p] = 0; s_score[p] = 0; s_cs[p] = 0; s_arr[p] = 0; }
 #pragma unroll
           for (int i = 0; i < SMALL_MAX; i++) {
+            if (__ballot((uint32_t)i < nA) == 0) break;
             if ((uint32_t)i < nA) {
               uint32_t rank = 0;
 #pragma unroll

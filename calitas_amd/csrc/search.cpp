@@ -1655,8 +1655,10 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     for (double w : weights) if (!(w > 0)) { weights.clear(); break; }
   } else if (ref.total_bases >= (2048ull << 20)) {
     weights = {5, 3, 2};   // measured on hg38-sized input: the last range small, its tail is what nothing hides
-  } else if (ref.total_bases >= (512ull << 20)) {
-    weights = {3, 2};      // a half or a quarter of it (a rank's share on 2 or 4 GPUs): 1.49 / 0.90 ms against 1.53 / 1.02 with three ranges
+  } else if (ref.total_bases >= (256ull << 20)) {
+    // a half, a quarter or an eighth of it (a rank's share on 2, 4 or 8 GPUs).  Round 3, with the per-bin tail: 1.41 / 0.86 / 0.58 ms
+    // for two equal ranges against 1.46 / 0.89 / 0.62 for 3:2 and 1.53 / 0.96 / 0.72 for three; one pass: - / 0.90 / 0.60
+    weights = {1, 1};
   }
   std::vector<std::pair<int, int>> ranges;
   if (weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);
