@@ -144,9 +144,9 @@ __device__ __forceinline__ int middle_length(const RawAln* rp, const HitRec& h, 
   return total > mid_bound ? -1 : total;
 }
 
-// One wave per bin, for the bins bin_hits_small_kernel listed (n_list on the device; the grid is fixed and strides over the list).
-__global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, MidArgs m, const uint32_t* list, const uint32_t* n_list) {
-  CALITAS_TAIL_PRIO();
+// One bin by a whole wave: the bins whose context holds more than SMALL_MAX alignments (bin_hits_kernel's waves stride over the
+// list bin_hits_small_kernel made of them).
+__device__ __forceinline__ void bin_hits_wave(const BinArgs& a, const MidArgs& m, const uint32_t rel, const int lane) {
   __shared__ int32_t k_s[BIN_WAVES][ACC_MAX], k_e[BIN_WAVES][ACC_MAX];  // kept intervals of the window being filtered
   __shared__ uint32_t acc[BIN_WAVES][ACC_MAX];                          // accepted alignments in arrival order: index into raw[]
   // accepted alignments by arrival (t_*) and in ReferenceHit.sort order (s_*)
@@ -154,13 +154,9 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
   __shared__ int32_t s_start[BIN_WAVES][ACC_MAX], s_end[BIN_WAVES][ACC_MAX], s_score[BIN_WAVES][ACC_MAX];
   __shared__ uint8_t t_minus[BIN_WAVES][ACC_MAX], s_cs[BIN_WAVES][ACC_MAX], s_idx[BIN_WAVES][ACC_MAX], s_head[BIN_WAVES][ACC_MAX],
       s_keep[BIN_WAVES][ACC_MAX], s_done[BIN_WAVES][ACC_MAX];
-  const int lane = (int)(threadIdx.x & 63);
-  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t n_todo = *n_list;
-  for (uint32_t it = blockIdx.x * BIN_WAVES + wv; it < n_todo; it += gridDim.x * BIN_WAVES) {
+  constexpr uint32_t wv = 0;                                            // one wave per workgroup
   wave_lds_sync();                                                      // the previous bin of this wave is done with the arrays
-  const uint32_t rel = list[it];                                        // bin of this round, relative to the range
-  if (rel >= a.n_bins) continue;
+  if (rel >= a.n_bins) return;
   const uint32_t b = a.bin_first + rel;
   auto finish = [&](uint32_t n_rows, uint32_t bytes, uint32_t n_acc) {
     if (lane == 0) {
@@ -176,14 +172,14 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
   auto decline = [&](uint32_t why) { if (lane == 0) atomicOr(a.flags, why); finish(0, 0, 0); };
   const uint32_t n_own = a.bin_count[rel];
   const uint32_t n_prev_raw = rel > 0 ? a.bin_count[rel - 1] : 0u;
-  if (n_prev_raw == 0 && n_own == 0) { finish(0, 0, 0); continue; }       // no window that could hold a hit of this bin has alignments
+  if (n_prev_raw == 0 && n_own == 0) { finish(0, 0, 0); return; }       // no window that could hold a hit of this bin has alignments
   const uint32_t c = a.bin_contig[b];
   const uint32_t wbase = (uint32_t)a.win_base[c];                       // the contig's first entry of the window table
   const uint32_t bb = b - a.bin_base[c];                                // bin inside its contig
   const bool has_prev = bb > 0 && rel > 0, has_next = b + 1 < a.bin_base[c + 1] && rel + 1 < a.n_bins;
   const uint32_t n_prev = has_prev ? n_prev_raw : 0u, n_next = has_next ? a.bin_count[rel + 1] : 0u;
-  if (n_prev == 0 && n_own == 0) { finish(0, 0, 0); continue; }
-  if (n_prev > BIN_CAP || n_own > BIN_CAP || n_next > BIN_CAP) { decline(BIN_FLAG_CROWDED); continue; }
+  if (n_prev == 0 && n_own == 0) { finish(0, 0, 0); return; }
+  if (n_prev > BIN_CAP || n_own > BIN_CAP || n_next > BIN_CAP) { decline(BIN_FLAG_CROWDED); return; }
   const int64_t lo = (int64_t)bb << a.bin_shift, hi = lo + ((int64_t)1 << a.bin_shift);
   const int64_t ctx_lo = lo - 2 * (int64_t)a.W, ctx_hi = hi + HIT_MAX_LEN;
   // hits are all known from here on; restart points are certain HIT_MAX_LEN further right.  At the start of a contig nothing is missing.
@@ -254,8 +250,8 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
       }
     }
   }
-  if (over) { decline(BIN_FLAG_CROWDED); continue; }
-  if (nA == 0) { finish(0, 0, 0); continue; }
+  if (over) { decline(BIN_FLAG_CROWDED); return; }
+  if (nA == 0) { finish(0, 0, 0); return; }
   wave_lds_sync();
 
   // ---- 3. GuideAlignment coordinates of the accepted alignments (lane i = arrival i) ----
@@ -267,7 +263,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
     h = hit_record(a.raw + hsrc, a.guides, a.win_base, a.win);
     t_start[wv][lane] = h.gstart; t_score[wv][lane] = h.score; t_minus[wv][lane] = (uint8_t)h.minus;
   }
-  if (__ballot(isA && h.gstart < 0) != 0) { decline(BIN_FLAG_RANGE); continue; }
+  if (__ballot(isA && h.gstart < 0) != 0) { decline(BIN_FLAG_RANGE); return; }
   wave_lds_sync();
   // ---- 4. ReferenceHit.sort among them by counting (equal keys keep their arrival order: a stable sort), restart points, walks ----
   uint32_t my_rank = 0;                                                 // lane i (arrival) -> its sorted position
@@ -324,10 +320,10 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
   wave_lds_sync();
   const unsigned long long okey = r < nA ? (((unsigned long long)c << 32) | (unsigned long long)(uint32_t)s_start[wv][r]) : 0ull;
   const bool mine = r < nA && (int64_t)s_start[wv][r] >= lo && (int64_t)s_start[wv][r] < hi && okey >= a.own_lo && okey < a.own_hi;
-  if (__ballot(mine && !s_done[wv][r]) != 0) { decline(BIN_FLAG_HALO); continue; }
+  if (__ballot(mine && !s_done[wv][r]) != 0) { decline(BIN_FLAG_HALO); return; }
   const unsigned long long kept = __ballot(mine && s_keep[wv][r] != 0);
   const uint32_t n_rows = (uint32_t)__popcll(kept);
-  if (n_rows > BIN_ROWS) { decline(BIN_FLAG_CROWDED); continue; }
+  if (n_rows > BIN_ROWS) { decline(BIN_FLAG_CROWDED); return; }
 
   // ---- 5. the kept hits of the bin in final order: which alignment, and the length of the row's middle part -- every kept hit in
   //         the lane that holds its record (arrival lane), all of them at once ----
@@ -347,10 +343,18 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_hits_kernel(BinArgs a, Mid
   }
   const bool bad_row = __ballot(kept_here && len < 0) != 0;
   const uint32_t bytes = (uint32_t)wave_sum_u64(row_bytes);
-  if (bad_row) { decline(BIN_FLAG_ROW); continue; }
+  if (bad_row) { decline(BIN_FLAG_ROW); return; }
   finish(n_rows, bytes, nA_own);
-  }
 }
+
+// The listed bins: a fixed grid strides over the list (its length is on the device).
+__global__ __launch_bounds__(64) void bin_hits_kernel(BinArgs a, MidArgs m, const uint32_t* list, const uint32_t* n_list) {
+  CALITAS_TAIL_PRIO();
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t n_todo = *n_list;
+  for (uint32_t it = blockIdx.x; it < n_todo; it += gridDim.x) bin_hits_wave(a, m, list[it], lane);
+}
+
 
 // ---- the common case, one LANE per bin ------------------------------------------------------------------------------------------
 // At max-guide-diffs 5 on a genome-sized reference a bin's context holds 0-4 raw alignments (0.4 on average), and a wave per bin spends
@@ -616,6 +620,8 @@ struct RowsArgs {
   const char* names;
   char* text;
   unsigned long long text_cap;
+  char* host_text;              // page-locked host memory: a text of up to host_cap bytes is written there, over the bus, and needs no copy
+  unsigned long long host_cap;
   const uint32_t* counters;     // the lane's eight counters, posted with the result
   uint32_t* box;                // mailbox (device view)
   uint32_t seq;
@@ -650,7 +656,8 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
   for (uint32_t ch = (my_super << CHUNK_SHIFT) + (uint32_t)lane; ch < my_chunk; ch += 64) before += a.chunk_bytes[ch];
   for (uint32_t x = (my_chunk << CHUNK_SHIFT) + (uint32_t)lane; x < rel; x += 64) before += a.bin_bytes[x];
   tot = wave_sum_u64(tot); before = wave_sum_u64(before);
-  const uint32_t flags = *a.flags | (tot > o.text_cap ? BIN_FLAG_TEXT : 0u);
+  const bool to_host = tot <= o.host_cap;                             // (the same for every wave of the grid; the host decides by the posted bytes)
+  const uint32_t flags = *a.flags | (!to_host && tot > o.text_cap ? BIN_FLAG_TEXT : 0u);
   if (posts && it == 0) {
     uint32_t rows_tot = 0, acc_tot = 0;
     for (uint32_t ch = (uint32_t)lane; ch < o.n_chunks; ch += 64) { rows_tot += a.chunk_rows[ch]; acc_tot += a.chunk_acc[ch]; }
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
     wave_lds_sync();
     const uint32_t nb = uniform_ptr(m.name_off)[h.contig], nl = uniform_ptr(m.name_off)[h.contig + 1] - nb;
     const uint32_t s0 = o.rc.head_len, s1 = s0 + nl + 1, s2 = s1 + (uint32_t)len, total = s2 + o.rc.tail_len;
-    char* dst = o.text + at;
+    char* dst = (to_host ? o.host_text : o.text) + at;
     for (uint32_t x = (uint32_t)lane; x < total; x += 64) {
       uint8_t ch;
       if (x < s0) ch = head[x];
@@ -707,6 +714,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
     }
     at += total;
   }
+  if (to_host) __threadfence_system();                                // the rows are in host memory before the kernel counts as done
   }
 }
 
@@ -734,10 +742,18 @@ struct BinnedWork {
   uint32_t* complex_list = nullptr; size_t complex_cap = 0;   // bins bin_hits_small_kernel leaves to bin_hits_kernel
   uint32_t* complex_count = nullptr;                          // (inside `clear`)
   uint32_t n_bins = 0, n_chunks = 0, n_supers = 0;
+  // A short text (most calls on a bacterial genome, a rare guide on a slice of a large one) is written straight into page-locked host
+  // memory by the rows kernel: the device-to-host copy of such a call -- waiting for the kernel, starting the copy engine, waiting
+  // for it -- cost 25 of its 165 us.
+  char* host_text = nullptr; unsigned long long host_cap = 0;
 };
+
+const char* binned_host_text(const BinnedWork* w) { return w ? w->host_text : nullptr; }
+unsigned long long binned_host_cap(const BinnedWork* w) { return w && w->host_text ? w->host_cap : 0; }
 
 void binned_destroy(BinnedWork* w) {
   if (!w) return;
+  if (w->host_text) (void)hipHostFree(w->host_text);
   (void)hipFree(w->bin_idx); (void)hipFree(w->rows); (void)hipFree(w->clear); (void)hipFree(w->bin_rows); (void)hipFree(w->bin_bytes); (void)hipFree(w->complex_list); (void)hipFree(w->rows_list);
   delete w;
 }
@@ -775,6 +791,14 @@ hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) 
   w.rows_count = w.flags + 2;
   w.bin_count = w.flags + 3;
   w.n_bins = n_bins; w.n_chunks = n_chunks; w.n_supers = n_supers;
+  if (!w.host_text && hipHostMalloc((void**)&w.host_text, BIN_HOST_TEXT, hipHostMallocDefault) != hipSuccess) {   // (coherent: the device writes through)
+    w.host_text = nullptr;                                   // not an error: every text takes the copy then
+    (void)hipGetLastError();
+  }
+  w.host_cap = BIN_HOST_TEXT;
+  // (tests: CALITAS_BINNED_TEXT_KB forces the regrow path of the device buffer, CALITAS_BINNED_HOST_TEXT=0 the copy for every text)
+  if (std::getenv("CALITAS_BINNED_TEXT_KB")) w.host_cap = 0;
+  if (const char* env = std::getenv("CALITAS_BINNED_HOST_TEXT")) w.host_cap = std::atoi(env) != 0 ? BIN_HOST_TEXT : 0;
   return hipMemsetAsync(w.clear, 0, bytes, stream);
 }
 
@@ -791,7 +815,8 @@ static hipError_t launch_rows(BinnedWork& w, HitsWork& hw, const BinArgs& ba, co
   hipError_t e;
   TRY(mailbox_open(*post));
   RowsArgs ro{};
-  ro.rc = hw.rc; ro.names = hw.names; ro.text = hw.text; ro.text_cap = hw.text_cap; ro.counters = d_counters; ro.box = post->dev; ro.seq = ++post->seq;
+  ro.rc = hw.rc; ro.names = hw.names; ro.text = hw.text; ro.text_cap = hw.text_cap; ro.host_text = w.host_text; ro.host_cap = w.host_text ? w.host_cap : 0;
+  ro.counters = d_counters; ro.box = post->dev; ro.seq = ++post->seq;
   ro.n_chunks = w.n_chunks; ro.n_supers = w.n_supers; ro.complex_count = w.complex_count;
   post->host[BIN_BOX_LATE] = 0;                              // raised by any wave while rows are written; read when the stream is done
   const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(w.n_bins, 1u), 16384u);      // strides over the list of bins with rows
@@ -837,16 +862,20 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
   SmallArgs sa{w.complex_list, w.complex_count, 0u};
   if (const char* env = std::getenv("CALITAS_BINNED_COMPLEX")) sa.force_complex = std::atoi(env) != 0;   // tests: the wave-per-bin kernel for every bin
   if (!sa.complex_list || !sa.complex_count) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(bin_hits_small_kernel, dim3((std::max<uint32_t>(geo.n_bins, 1u) + 63) / 64), dim3(64), 0, stream, ba, ma, sa);
+  // (the listed bins inside the lane kernel -- its waves doing the bins their lanes left over, one launch less -- measured slower at
+  // every size: 0.176 against 0.165 ms for an E. coli-sized call, 0.685 against 0.588 ms for an eighth of the hg38-sized genome: the
+  // lanes of a wave that does a listed bin wait for it, and the listed bins of a wave run one after the other)
+  const dim3 sgrid((std::max<uint32_t>(geo.n_bins, 1u) + 63) / 64);
+  hipLaunchKernelGGL(bin_hits_small_kernel, sgrid, dim3(64), 0, stream, ba, ma, sa);
   TRY(hipGetLastError());
   // the listed bins: a fixed grid that strides over the list (its length is on the device)
   const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(geo.n_bins, 1u), 1024u);
-  int skip = 0;                                              // timing experiments only (the text is wrong): 1 = no wave-per-bin kernel, 2 = rows kernel posts and returns
+  int skip = 0;                                            // timing experiments only (the text is wrong): 1 = no wave-per-bin kernel, 2 = rows kernel posts and returns
   if (const char* env = std::getenv("CALITAS_BINNED_SKIP")) skip = std::atoi(env);
   ba.dbg = (skip & 2) ? 2u : 0u;
   if (!(skip & 1))
-  hipExtLaunchKernelGGL(bin_hits_kernel, dim3(grid), dim3(64 * BIN_WAVES), 0, stream, nullptr, ev_hits_done, 0, ba, ma, (const uint32_t*)w.complex_list,
-                        (const uint32_t*)w.complex_count);
+    hipExtLaunchKernelGGL(bin_hits_kernel, dim3(grid), dim3(64), 0, stream, nullptr, ev_hits_done, 0, ba, ma, (const uint32_t*)w.complex_list,
+                          (const uint32_t*)w.complex_count);
   TRY(hipGetLastError());
   return launch_rows(w, hw, ba, ma, d_counters, stream, post, ev_rows_start, ev_rows_done);
 }

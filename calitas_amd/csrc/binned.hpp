@@ -23,6 +23,7 @@ struct BinnedWork;   // per-lane device scratch
 
 constexpr uint32_t BIN_CAP = 64;            // raw alignments listed per bin (a bin with more is "crowded": the call declines)
 constexpr uint32_t BIN_ROWS = 32;           // rows (kept hits) per bin
+constexpr unsigned long long BIN_HOST_TEXT = 128u << 10;   // a text up to this size is written into page-locked host memory by the rows kernel itself
 
 constexpr uint32_t BIN_FLAG_CROWDED = 1;    // a bin, its context, its accepted alignments or its rows exceed what one wave holds
 constexpr uint32_t BIN_FLAG_HALO = 2;       // removeOverlaps: a hit of the bin hangs on a cluster that starts left of the known context
@@ -74,7 +75,11 @@ hipError_t binned_run(BinnedWork* work, HitsWork** hits, const BinnedGeometry& g
 hipError_t binned_rerun_rows(BinnedWork* work, HitsWork** hits, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
                              const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, const uint32_t* d_counters,
                              uint64_t bytes, hipStream_t stream, Mailbox* post, hipEvent_t ev_rows_done);
+// Where the text is: in the lane's page-locked host buffer when the posted byte count is <= binned_host_cap() (complete when the
+// stream is; no copy), else in the device buffer of `hits`.
 const char* binned_text(const HitsWork* hits);
+const char* binned_host_text(const BinnedWork* work);
+unsigned long long binned_host_cap(const BinnedWork* work);
 void binned_destroy(BinnedWork* work);
 
 }  // namespace calitas

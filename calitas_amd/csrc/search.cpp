@@ -728,6 +728,15 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
       owner->dma_tried = true;
     }
   }
+  if (lane->binned_late_check && src && src == binned_host_text(lane->binned)) {   // the rows kernel wrote the text into host memory itself
+    if (rows_done) HIP_TRY(lane, calitas_spin_sync(rows_done)); else HIP_TRY(lane, calitas_spin_sync(lane->stream));
+    g_marks.mark("rows-done");
+    if (lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)
+      return fail(lane, CALITAS_EHIP, "binned rows kernel: a row's length differs between the two kernels (internal error)");
+    std::memcpy(dst, src, n);
+    if (ms_out) *ms_out = 0;
+    return CALITAS_OK;
+  }
   if (owner->dma.usable()) {
     // (rows_done: the caller recorded it behind the row kernels and other work may already be queued behind it on the stream)
     if (rows_done) HIP_TRY(lane, calitas_spin_sync(rows_done)); else HIP_TRY(lane, calitas_spin_sync(lane->stream));
@@ -967,7 +976,9 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   tm.binned_lanes = 1;
   lane->timing = tm;
   lt.tm = tm;
-  lt.d_text = binned_text(lane->hits); lt.bytes = bytes; lt.rows = lane->mbox.host[BIN_BOX_ROWS];
+  // (a short text is already on its way into the lane's page-locked buffer: text_to_host only waits for the kernel)
+  lt.d_text = bytes <= binned_host_cap(lane->binned) ? binned_host_text(lane->binned) : binned_text(lane->hits);
+  lt.bytes = bytes; lt.rows = lane->mbox.host[BIN_BOX_ROWS];
   lane->binned_late_check = true;
   (void)t_call;
   return CALITAS_OK;

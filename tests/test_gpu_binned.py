@@ -45,10 +45,20 @@ def both_paths(C, fa, guide, monkeypatch, expect_binned=True, **pk):
         text1, n1 = C.SearchReference(guide=guide, guide_id="a", context=ctx, **pk).run("v0", "stamp")
         lanes1 = ctx.timing()["binned_lanes"]
         monkeypatch.delenv("CALITAS_BINNED_COMPLEX")
+        # a text of up to 128 KB is written into page-locked host memory by the rows kernel; this one takes the device buffer and the copy
+        had = os.environ.get("CALITAS_BINNED_HOST_TEXT")
+        monkeypatch.setenv("CALITAS_BINNED_HOST_TEXT", "0")
+        text2, n2 = C.SearchReference(guide=guide, guide_id="a", context=ctx, **pk).run("v0", "stamp")
+        lanes2 = ctx.timing()["binned_lanes"]
+        if had is None:
+            monkeypatch.delenv("CALITAS_BINNED_HOST_TEXT")
+        else:
+            monkeypatch.setenv("CALITAS_BINNED_HOST_TEXT", had)
     finally:
         ctx.close()
     assert text == text0 and n == n0
     assert text1 == text0 and lanes1 == lanes
+    assert text2 == text0 and lanes2 == lanes
     if expect_binned is not None:
         assert (lanes > 0) == expect_binned, lanes
     return C.read_hits(text), lanes
