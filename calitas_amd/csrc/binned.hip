@@ -69,6 +69,7 @@ struct BinArgs {
   unsigned long long own_lo, own_hi;
   uint32_t* rows_list;               // bins with rows, in no particular order (one append per wave)
   uint32_t* rows_count;              // (zero at launch)
+  unsigned long long* stamps;        // [0] align_kernel's start (written there), [1] bin_hits_small_kernel's: the device's wall clock
   uint32_t dbg;                      // timing experiments (CALITAS_BINNED_SKIP)
 };
 
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(64) void bin_hits_small_kernel(BinArgs a, MidArgs m
   const int lane = (int)(threadIdx.x & 63);
   const uint32_t rel = blockIdx.x * 64 + threadIdx.x;
   const bool in_range = rel < a.n_bins;
+  if (rel == 0) a.stamps[1] = (unsigned long long)wall_clock64();
   bool is_complex = false;
   uint32_t out_rows = 0, out_bytes = 0, out_acc = 0, out_flags = 0;
   BinRow out_row[SMALL_MAX];
@@ -666,6 +668,11 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
       for (int i = 0; i < 8; i++) o.box[BIN_BOX_COUNTERS + i] = __hip_atomic_load(o.counters + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       o.box[BIN_BOX_ROWS] = rows_tot; o.box[BIN_BOX_BYTES] = (uint32_t)tot; o.box[BIN_BOX_BYTES + 1] = (uint32_t)(tot >> 32);
       o.box[BIN_BOX_FLAGS] = flags; o.box[BIN_BOX_ACCEPTED] = acc_tot; o.box[BIN_BOX_COMPLEX] = *o.complex_count;
+      const unsigned long long now = (unsigned long long)wall_clock64();
+      for (int i = 0; i < 3; i++) {
+        const unsigned long long t = i < 2 ? a.stamps[i] : now;
+        o.box[BIN_BOX_STAMPS + 2 * i] = (uint32_t)t; o.box[BIN_BOX_STAMPS + 2 * i + 1] = (uint32_t)(t >> 32);
+      }
       __threadfence_system();
       __hip_atomic_store(o.box, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -746,7 +753,16 @@ struct BinnedWork {
   // memory by the rows kernel: the device-to-host copy of such a call -- waiting for the kernel, starting the copy engine, waiting
   // for it -- cost 25 of its 165 us.
   char* host_text = nullptr; unsigned long long host_cap = 0;
+  unsigned long long* stamps = nullptr;                       // (BinArgs::stamps)
+  double stamp_khz = 0;                                       // the wall clock's rate
 };
+
+double binned_stamp_ms(const BinnedWork* w, const Mailbox& box, int from, int to) {
+  if (!w || !box.host || w->stamp_khz <= 0) return 0;
+  auto at = [&](int i) { return (unsigned long long)box.host[BIN_BOX_STAMPS + 2 * i] | ((unsigned long long)box.host[BIN_BOX_STAMPS + 2 * i + 1] << 32); };
+  const unsigned long long a = at(from), b = at(to);
+  return b > a ? (double)(b - a) / w->stamp_khz : 0.0;
+}
 
 const char* binned_host_text(const BinnedWork* w) { return w ? w->host_text : nullptr; }
 unsigned long long binned_host_cap(const BinnedWork* w) { return w && w->host_text ? w->host_cap : 0; }
@@ -754,6 +770,7 @@ unsigned long long binned_host_cap(const BinnedWork* w) { return w && w->host_te
 void binned_destroy(BinnedWork* w) {
   if (!w) return;
   if (w->host_text) (void)hipHostFree(w->host_text);
+  (void)hipFree(w->stamps);
   (void)hipFree(w->bin_idx); (void)hipFree(w->rows); (void)hipFree(w->clear); (void)hipFree(w->bin_rows); (void)hipFree(w->bin_bytes); (void)hipFree(w->complex_list); (void)hipFree(w->rows_list);
   delete w;
 }
@@ -796,6 +813,13 @@ hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) 
     (void)hipGetLastError();
   }
   w.host_cap = BIN_HOST_TEXT;
+  if (!w.stamps) {
+    TRY(hipMalloc((void**)&w.stamps, 4 * sizeof(unsigned long long)));
+    int dev = 0, khz = 0;
+    TRY(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { khz = 100000; (void)hipGetLastError(); }   // 100 MHz on CDNA
+    w.stamp_khz = khz;
+  }
   // (tests: CALITAS_BINNED_TEXT_KB forces the regrow path of the device buffer, CALITAS_BINNED_HOST_TEXT=0 the copy for every text)
   if (std::getenv("CALITAS_BINNED_TEXT_KB")) w.host_cap = 0;
   if (const char* env = std::getenv("CALITAS_BINNED_HOST_TEXT")) w.host_cap = std::atoi(env) != 0 ? BIN_HOST_TEXT : 0;
@@ -806,6 +830,7 @@ void binned_fill_align_args(const BinnedWork* w, const BinnedGeometry& geo, Alig
   aa.bin_idx = w->bin_idx; aa.bin_count = w->bin_count; aa.bin_base = geo.d_bin_base; aa.bin_first = geo.bin_first; aa.bin_n = geo.n_bins;
   aa.bin_shift = geo.bin_shift;
   aa.bin_cap = BIN_CAP;
+  aa.stamps = w->stamps;
 }
 
 const char* binned_text(const HitsWork* hits) { return hits ? hits->text : nullptr; }
@@ -832,7 +857,7 @@ static void fill_args(BinnedWork& w, HitsWork& hw, const BinnedGeometry& geo, co
   ba.W = p.window_size; ba.step = p.step; ba.max_total_diffs = p.max_total_diffs; ba.max_overlap = p.max_overlap;
   ba.own_lo = p.own_lo; ba.own_hi = p.own_hi;
   ba.rows = w.rows; ba.bin_rows = w.bin_rows; ba.bin_bytes = w.bin_bytes; ba.chunk_bytes = w.chunk_bytes; ba.super_bytes = w.super_bytes; ba.chunk_rows = w.chunk_rows;
-  ba.chunk_acc = w.chunk_acc; ba.flags = w.flags; ba.rows_list = w.rows_list; ba.rows_count = w.rows_count;
+  ba.chunk_acc = w.chunk_acc; ba.flags = w.flags; ba.rows_list = w.rows_list; ba.rows_count = w.rows_count; ba.stamps = w.stamps;
   const uint32_t n_max = (uint32_t)std::min<int>(MID_COLS, std::max(1, p.max_ops));
   ma = MidArgs{};
   ma.ref = ref; ma.rc = hw.rc; ma.blob = hw.blob; ma.name_off = hw.name_off; ma.guides = d_guides;
@@ -856,7 +881,7 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
   fill_args(w, hw, geo, ref, d_raw, d_guides, d_win_base, d_win, p, ba, ma);
   // (a null table here would be a wild read on the device, not an error code: refuse on the host)
   if (!ba.raw || !ba.bin_idx || !ba.bin_count || !ba.bin_base || !ba.bin_contig || !ba.guides || !ba.win_base || !ba.win || !ba.rows || !ba.bin_rows ||
-      !ba.bin_bytes || !ba.chunk_bytes || !ba.super_bytes || !ba.chunk_rows || !ba.chunk_acc || !ba.flags || !ba.rows_list || !ba.rows_count || !ma.blob || !ma.name_off || !hw.names ||
+      !ba.bin_bytes || !ba.chunk_bytes || !ba.super_bytes || !ba.chunk_rows || !ba.chunk_acc || !ba.flags || !ba.rows_list || !ba.rows_count || !ba.stamps || !ma.blob || !ma.name_off || !hw.names ||
       !hw.text || w.n_bins < geo.n_bins)
     return hipErrorInvalidValue;
   SmallArgs sa{w.complex_list, w.complex_count, 0u};

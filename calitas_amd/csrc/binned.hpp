@@ -35,7 +35,9 @@ constexpr uint32_t BIN_FLAG_INTERNAL = 32;  // a row's length differs between th
 // Mailbox words of the post of the rows kernel (after the sequence word).
 constexpr int BIN_BOX_COUNTERS = 1;         // 1..8: the eight counters of the lane (scan records, raw alignments, anomalies, ...)
 constexpr int BIN_BOX_ROWS = 9, BIN_BOX_BYTES = 10 /* and 11 */, BIN_BOX_FLAGS = 12, BIN_BOX_LATE = 13 /* flags raised while rows are written */,
-              BIN_BOX_ACCEPTED = 14, BIN_BOX_COMPLEX = 15 /* statistics: bins that took a whole wave */;
+              BIN_BOX_ACCEPTED = 14, BIN_BOX_COMPLEX = 15 /* statistics: bins that took a whole wave */,
+              BIN_BOX_STAMPS = 16 /* .. 21: the device's wall clock (two words each) at the start of align_kernel, of bin_hits_small_kernel and of
+                                     the rows kernel -- the lane's kernel times without an event on any dispatch between them */;
 
 // Bases per bin for a window size: the smallest power of two that leaves room for two windows of context on the left and the longest
 // hit on the right, at least 8 kb; 0 = this window size is not handled.
@@ -67,7 +69,7 @@ struct BinnedParams {
 // Queues the two kernels behind trace_kernel.  hits: the lane's HitsWork after hits_prepare / hits_set_names (constant row pieces, contig
 // names, the text buffer).  d_counters: the lane's eight counters (posted with the result).  The rows kernel posts rows, bytes and
 // flags to `post` when it STARTS (they are final then); the text is complete when the stream is.  ev_*: optional timing events that
-// ride on the dispatches.
+// ride on the dispatches (each costs the kernel behind it ~5 us of its start: pass nullptr and take the times from the posted stamps).
 hipError_t binned_run(BinnedWork* work, HitsWork** hits, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
                       const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, const uint32_t* d_counters, hipStream_t stream,
                       Mailbox* post, hipEvent_t ev_hits_done, hipEvent_t ev_rows_start, hipEvent_t ev_rows_done);
@@ -80,6 +82,8 @@ hipError_t binned_rerun_rows(BinnedWork* work, HitsWork** hits, const BinnedGeom
 const char* binned_text(const HitsWork* hits);
 const char* binned_host_text(const BinnedWork* work);
 unsigned long long binned_host_cap(const BinnedWork* work);
+// Milliseconds between two posted stamps (BIN_BOX_STAMPS + 2 * from / to) of the lane's last post.
+double binned_stamp_ms(const BinnedWork* work, const Mailbox& box, int from, int to);
 void binned_destroy(BinnedWork* work);
 
 }  // namespace calitas

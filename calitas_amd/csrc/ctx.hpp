@@ -65,6 +65,8 @@ struct calitas_ctx {
   std::vector<uint32_t> bin_base;   // the same on the host
   int bin_shift = 0;                // 0 = not built
   BinnedWork* binned = nullptr;     // lane
+  double align_ms_by_stamps = -1;   // lane: >= 0: align_kernel + trace_kernel of the current search ran without an event behind them (binned.hpp, BIN_BOX_STAMPS)
+  int rows_ev0 = 4;                 // lane: ev[rows_ev0] .. ev[5] bracket the row stage of the last call
   bool binned_late_check = false;   // lane: the text being copied comes from the binned rows kernel (its late flags are checked after the copy's wait)
   // the last search on this context the binned tail declined (crowded bins, a long repeat): protospacer length, PAMs, minGuideScore.
   // A search at least as permissive goes to the general kernels directly.

@@ -299,6 +299,7 @@ __device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
 template <bool PM>
 __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a) {
   CALITAS_TAIL_PRIO();
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[0] = (unsigned long long)wall_clock64();   // (binned.hpp, BIN_BOX_STAMPS)
   constexpr int STAGE = ITEM_STAGE<PM>;
   // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the 32 lanes over the banks
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];

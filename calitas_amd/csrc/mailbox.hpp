@@ -11,7 +11,7 @@
 
 namespace calitas {
 
-constexpr int MAILBOX_WORDS = 15;
+constexpr int MAILBOX_WORDS = 21;
 
 struct Mailbox {
   volatile uint32_t* host = nullptr;   // [0] sequence, [1..] payload

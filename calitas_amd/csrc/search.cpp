@@ -383,7 +383,8 @@ static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t
 static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->t_scan0, ctx->t_scan1); tm.scan_kernel_ms = ms;
-  (void)hipEventElapsedTime(&ms, ctx->t_scan1, ctx->ev[2]); tm.align_kernel_ms = ms;
+  if (ctx->align_ms_by_stamps >= 0) tm.align_kernel_ms = ctx->align_ms_by_stamps;   // (a search the binned tail started and declined: no ev[2])
+  else { (void)hipEventElapsedTime(&ms, ctx->t_scan1, ctx->ev[2]); tm.align_kernel_ms = ms; }
   (void)hipEventElapsedTime(&ms, ctx->t_scan0, ctx->ev[3]); tm.gpu_total_ms = ms;
 }
 
@@ -407,6 +408,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
                       bool resume = false) {
   const auto t_call = std::chrono::steady_clock::now();
   *out = nullptr; *n_out = 0;
+  if (!resume) ctx->align_ms_by_stamps = -1;
   const calitas_params_t& p = pl.p;
   const PackedRef& ref = ref_owner(ctx)->ref;
   const int n_guides = pl.n_guides, step = pl.step, max_total = pl.max_total;
@@ -432,6 +434,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   bool spec_done = false;
   for (bool first_round = true;; first_round = false) {
     if (!(resume && first_round)) {
+    ctx->align_ms_by_stamps = -1;                     // (this round's trace_kernel carries ev[2])
     if (!prelaunched) {
       int rc = launch_scan_stage(ctx, pl, ctx->stream);
       if (rc) return rc;
@@ -788,6 +791,16 @@ struct LaneText {
   calitas_timing_t tm{};
 };
 
+// Kernel time of a lane's row stage once its last kernel is done.  General kernels: ev[4] .. ev[5] around hits_run.  Binned tail: no event
+// sits between its kernels, so: end of the scan .. end of the rows kernel, less align_kernel + trace_kernel (by the stamps) -- the two bin
+// kernels, the rows kernel and the kernel boundaries of the chain.
+static double rows_stage_ms(calitas_ctx* lane, const calitas_timing_t& tm) {
+  float ms = 0;
+  if (lane->rows_ev0 >= 0) { (void)hipEventElapsedTime(&ms, lane->ev[lane->rows_ev0], lane->ev[5]); return ms; }
+  (void)hipEventElapsedTime(&ms, lane->t_scan1, lane->ev[5]);
+  return std::max(0.0, (double)ms - tm.align_kernel_ms);
+}
+
 // Whether this lane's search takes the binned tail (binned.hpp): one guide on the device path, a window size the bins handle, not
 // a search planned as dense (rec_hint: per-contig passes of a permissive PAM-less search would crowd every bin), and not one at least
 // as permissive as the last the bins declined on this reference.
@@ -866,6 +879,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
       HitsResult res{};
       HIP_TRY(lane, hipEventRecord(lane->ev[4], lane->stream));
+      lane->rows_ev0 = 4;
       HIP_TRY(lane, hits_run(&lane->hits, hr, dev.d_final, dev.n_sel, lane->d_guides, own->d_win_base, own->d_win, rs, p.max_overlap, score_hi,
                              pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, dev.crowded ? 0u : (uint32_t)((p.window_size + pl.step - 1) / pl.step),
                              lane->stream, &res));
@@ -936,13 +950,16 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   fill_kernel_args(lane, pl, sa, aa);
   binned_fill_align_args(lane->binned, geo, aa);
   HIP_TRY(lane, launch_align(aa, pl.narrow_tail ? narrow_blocks("CALITAS_ALIGN_BLOCKS_NARROW", kAlignBlocks, kAlignBlocks) : kAlignBlocks, lane->stream));
-  HIP_TRY(lane, launch_trace(aa, pl.narrow_tail ? narrow_blocks("CALITAS_TRACE_BLOCKS_NARROW", kTraceBlocks, kTraceBlocks) : kTraceBlocks, lane->stream, lane->ev[2]));
+  // (no events on these dispatches: each would hold back the kernel behind it by ~5 us; the kernels stamp the device's wall clock instead)
+  HIP_TRY(lane, launch_trace(aa, pl.narrow_tail ? narrow_blocks("CALITAS_TRACE_BLOCKS_NARROW", kTraceBlocks, kTraceBlocks) : kTraceBlocks, lane->stream, nullptr));
   HIP_TRY(lane, binned_run(lane->binned, &lane->hits, geo, hr, lane->d_raw, lane->d_guides, own->d_win_base, own->d_win, bp, lane->d_counters, lane->stream,
-                           &lane->mbox, lane->ev[3], lane->ev[4], lane->ev[5]));
+                           &lane->mbox, nullptr, nullptr, lane->ev[5]));
+  lane->rows_ev0 = -1;                                       // (the row stage's time: binned_rows_ms)
   g_marks.mark("queued-binned");
   HIP_TRY(lane, mailbox_wait(lane->mbox, lane->stream));
   g_marks.mark("binned-counts");
   for (int k = 0; k < 8; k++) lane->h_counters[k] = lane->mbox.host[BIN_BOX_COUNTERS + k];
+  lane->align_ms_by_stamps = binned_stamp_ms(lane->binned, lane->mbox, 0, 1);                    // align_kernel + trace_kernel
   const uint32_t n_rec = lane->h_counters[0], n_raw = lane->h_counters[1], n_items = lane->h_counters[3];
   if (lane->h_counters[2] != 0) return fail(lane, CALITAS_EHIP, "aligner kernel reported an inconsistent traceback (internal error)");
   uint32_t flags = lane->mbox.host[BIN_BOX_FLAGS];
@@ -963,7 +980,6 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
     HIP_TRY(lane, mailbox_wait(lane->mbox, lane->stream));
     flags = lane->mbox.host[BIN_BOX_FLAGS];
     if (flags) return fail(lane, CALITAS_EHIP, "binned rows kernel: flags " + std::to_string(flags) + " after the text buffer was grown (internal error)");
-    HIP_TRY(lane, hipEventRecord(lane->ev[4], lane->stream));   // (keeps the pair ev[4] / ev[5] ordered for the timing query; the rerun is the rare path)
   }
   calitas_timing_t tm{};
   tm.bases_scanned = pl.bases; tm.packed_bytes = (pl.bases + 3) / 4;
@@ -972,7 +988,12 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   if (std::getenv("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] binned tail: %u bins, %u of them by a whole wave, %u rows, %llu bytes\n", pl.n_bins, (unsigned)lane->mbox.host[BIN_BOX_COMPLEX],
                  (unsigned)lane->mbox.host[BIN_BOX_ROWS], (unsigned long long)bytes);
-  kernel_times(lane, tm);                                    // scan, align + trace, everything up to the end of bin_hits_kernel
+  {                                                          // scan: its events; the kernels behind it: their stamps
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, lane->t_scan0, lane->t_scan1); tm.scan_kernel_ms = ms;
+    tm.align_kernel_ms = lane->align_ms_by_stamps;
+    tm.gpu_total_ms = tm.scan_kernel_ms + binned_stamp_ms(lane->binned, lane->mbox, 0, 2);       // ... + the bin kernels, up to the start of the rows kernel
+  }
   tm.binned_lanes = 1;
   lane->timing = tm;
   lt.tm = tm;
@@ -1551,8 +1572,7 @@ static int search_hits_owned(calitas_ctx* ctx, const calitas_guide_t* guide, con
       if (lt.bytes) {
         rc = text_to_host(ctx, ctx, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
         if (rc) { if (!user_dst) calitas_free(text); return rc; }
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]); lt.tm.hits_kernel_ms = ms;
+        lt.tm.hits_kernel_ms = rows_stage_ms(ctx, lt.tm);
       }
       text[total] = 0;
       calitas_timing_t tm = lt.tm;
@@ -1702,8 +1722,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     calitas_ctx* lane = lanes[c];
     int r = text_to_host(ctx, lane, text + hlen + offset, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
     if (r) return r;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, lane->ev[4], lane->ev[5]); lt.tm.hits_kernel_ms = ms;   // recorded around hits_run by lane_rows
+    lt.tm.hits_kernel_ms = rows_stage_ms(lane, lt.tm);   // recorded around hits_run by lane_rows
     return CALITAS_OK;
   };
 
