@@ -752,7 +752,7 @@ struct BinnedWork {
   // A short text (most calls on a bacterial genome, a rare guide on a slice of a large one) is written straight into page-locked host
   // memory by the rows kernel: the device-to-host copy of such a call -- waiting for the kernel, starting the copy engine, waiting
   // for it -- cost 25 of its 165 us.
-  char* host_text = nullptr; unsigned long long host_cap = 0;
+  char* host_text = nullptr; unsigned long long host_cap = 0, host_alloc = 0;
   unsigned long long* stamps = nullptr;                       // (BinArgs::stamps)
   double stamp_khz = 0;                                       // the wall clock's rate
 };
@@ -808,11 +808,16 @@ hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) 
   w.rows_count = w.flags + 2;
   w.bin_count = w.flags + 3;
   w.n_bins = n_bins; w.n_chunks = n_chunks; w.n_supers = n_supers;
-  if (!w.host_text && hipHostMalloc((void**)&w.host_text, BIN_HOST_TEXT, hipHostMallocDefault) != hipSuccess) {   // (coherent: the device writes through)
-    w.host_text = nullptr;                                   // not an error: every text takes the copy then
-    (void)hipGetLastError();
+  unsigned long long host_want = BIN_HOST_TEXT;
+  if (const char* env = std::getenv("CALITAS_BINNED_HOST_TEXT_KB")) host_want = (unsigned long long)std::max(0, std::atoi(env)) << 10;   // (experiments)
+  if (w.host_text && w.host_alloc < host_want) { (void)hipHostFree(w.host_text); w.host_text = nullptr; }
+  if (!w.host_text && host_want) {
+    if (hipHostMalloc((void**)&w.host_text, host_want, hipHostMallocDefault) != hipSuccess) {   // (coherent: the device writes through)
+      w.host_text = nullptr;                                 // not an error: every text takes the copy then
+      (void)hipGetLastError();
+    } else w.host_alloc = host_want;
   }
-  w.host_cap = BIN_HOST_TEXT;
+  w.host_cap = host_want;
   if (!w.stamps) {
     TRY(hipMalloc((void**)&w.stamps, 4 * sizeof(unsigned long long)));
     int dev = 0, khz = 0;
@@ -822,7 +827,7 @@ hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) 
   }
   // (tests: CALITAS_BINNED_TEXT_KB forces the regrow path of the device buffer, CALITAS_BINNED_HOST_TEXT=0 the copy for every text)
   if (std::getenv("CALITAS_BINNED_TEXT_KB")) w.host_cap = 0;
-  if (const char* env = std::getenv("CALITAS_BINNED_HOST_TEXT")) w.host_cap = std::atoi(env) != 0 ? BIN_HOST_TEXT : 0;
+  if (const char* env = std::getenv("CALITAS_BINNED_HOST_TEXT")) w.host_cap = std::atoi(env) != 0 ? host_want : 0;
   return hipMemsetAsync(w.clear, 0, bytes, stream);
 }
 

@@ -257,13 +257,16 @@ __global__ __launch_bounds__(LANES_PER_TILE) void scan_kernel(ScanArgs a) {
 
 constexpr int TR_UP = 0, TR_LEFT = 1, TR_DIAG = 2;   // ordered so that max() of (score*4 + code) breaks ties Diag > Left > Up
 constexpr int NEG = -(1 << 20);                      // "minus infinity" that survives a few hundred additions
-// one job per 32-lane half wave; one wave per workgroup: 10 KB of LDS, which fits on a CU next to four scan workgroups (37 KB each
-// of 160 KB) -- a 256-thread workgroup (40 KB) had to wait until the scan of the next range let go of a CU
-constexpr int JOBS_PER_BLOCK = 2;
-// per wave: flush threshold + the most one record iteration can add (2 jobs x 8 windows x 16 candidates; x 3 when every matrix
+// A job (one scan record: its windows one after the other) takes LPJ lanes of a wave, lane r of them = query row r + 1.  LPJ = 32: two
+// jobs per wave, guides up to 32 rows.  LPJ = 21: THREE jobs per wave (lanes 0-20, 21-41, 42-62; lane 63 idles) for guides of up to
+// 20 rows -- every search with the usual 20-nt protospacer: 60 of 64 lanes hold a row instead of 40, a third fewer wave instructions
+// for the same cells.  (Lane LPJ - 1 of a job is never a row then: it holds "row 0" for the job above it, see the fill.)
+// One wave per workgroup: ~11 KB of LDS, which fits on a CU next to four scan workgroups (37 KB each of 160 KB) -- a 256-thread
+// workgroup (40 KB) had to wait until the scan of the next range let go of a CU.
+// per wave: flush threshold + the most one record iteration can add (jobs x 8 windows x 16 candidates; x 3 when every matrix
 // of a cell is an alignment of its own)
 constexpr int STAGE_FLUSH = 16;
-template <bool PM> constexpr int ITEM_STAGE = STAGE_FLUSH + (PM ? 3 : 1) * 2 * 8 * 16;
+template <bool PM, int LPJ> constexpr int ITEM_STAGE = STAGE_FLUSH + (PM ? 3 : 1) * (64 / LPJ) * 8 * 16;
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
 constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
 constexpr int TR_STRIDE = 100;                       // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; lane r writes byte 99r + t)
@@ -296,24 +299,27 @@ __device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
 
 // PM: the per-matrix reading of fgbio's enumeration.  A template parameter, not a run-time branch: its LDS
 // (s_fin3, the larger item stage) would cost the default reading a workgroup per CU (43 -> 66 KB: 153 -> 243 us per launch).
-template <bool PM>
-__global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a) {
+template <bool PM, int LPJ>
+__global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
   CALITAS_TAIL_PRIO();
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[0] = (unsigned long long)wall_clock64();   // (binned.hpp, BIN_BOX_STAMPS)
-  constexpr int STAGE = ITEM_STAGE<PM>;
-  // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the 32 lanes over the banks
-  __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS_PER_BLOCK][MAX_L][TR_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS_PER_BLOCK][TB_LEN];
-  __shared__ __attribute__((aligned(16))) uint8_t s_tbm[JOBS_PER_BLOCK][TB_LEN];
-  __shared__ int s_fin[JOBS_PER_BLOCK][STRIP_MAX_COLS + 1];
-  __shared__ int s_fin3[PM ? JOBS_PER_BLOCK : 1][3][PM ? STRIP_MAX_COLS + 1 : 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
+  static_assert(LPJ == 32 || LPJ == 21, "two or three jobs per wave");
+  constexpr int JOBS = 64 / LPJ;            // jobs per wave (= per workgroup)
+  constexpr int ROWS = LPJ == 32 ? MAX_L : LPJ - 1;   // rows a job can have
+  constexpr int STAGE = ITEM_STAGE<PM, LPJ>;
+  // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the lanes of a job over the banks
+  __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS][ROWS][TR_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS][TB_LEN];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tbm[JOBS][TB_LEN];
+  __shared__ int s_fin[JOBS][STRIP_MAX_COLS + 1];
+  __shared__ int s_fin3[PM ? JOBS : 1][3][PM ? STRIP_MAX_COLS + 1 : 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
   // passing candidates are staged per wave and appended to a.items with one global atomic per flush: trace_kernel then
   // runs one lane per *passing* candidate instead of one per candidate slot (4 % of the slots pass at d = 5)
-  __shared__ uint64_t s_items[JOBS_PER_BLOCK / 2][STAGE];
-  __shared__ uint32_t s_nitems[JOBS_PER_BLOCK / 2];
-  const int job = threadIdx.x >> 5;
-  const int r = threadIdx.x & 31;           // lane within the job = query row r+1
-  const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63;
+  __shared__ uint64_t s_items[1][STAGE];
+  __shared__ uint32_t s_nitems[1];
+  const int job = LPJ == 32 ? (int)(threadIdx.x >> 5) : (int)(threadIdx.x >= 21) + (int)(threadIdx.x >= 42) + (int)(threadIdx.x >= 63);
+  const int r = (int)threadIdx.x - job * LPJ;   // lane within the job = query row r+1
+  const int wave = 0, wlane = threadIdx.x & 63;
   if (wlane == 0) s_nitems[wave] = 0;
   __syncthreads();
   // all lanes of the wave that are still in the record loop call this together
@@ -350,8 +356,9 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
   const SearchDev& sp = a.sp;
   const int W = sp.window_size, step = sp.step;
 
-  const uint32_t total_jobs = gridDim.x * JOBS_PER_BLOCK;
-  for (uint32_t ri = blockIdx.x * JOBS_PER_BLOCK + job; ri < n_recs; ri += total_jobs) {
+  const uint32_t total_jobs = gridDim.x * JOBS;
+  // (lane 63 of a three-job wave belongs to no job)
+  for (uint32_t ri = job < JOBS ? blockIdx.x * JOBS + (uint32_t)job : n_recs; ri < n_recs; ri += total_jobs) {
     flush_items(STAGE_FLUSH);                // a record adds at most 2 jobs x 8 windows x 16 candidates per wave
     const ScanRecord rec = a.recs[ri];
     const uint32_t cmask = rec.info & 0xFFFFu;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
       const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
 
       // ---- stage target masks: tb[] as trace_kernel reads them, tbm[] = the bases a column matches (none for an N) ----
-      for (int x = r; x < ntb; x += 32) {
+      for (int x = r; x < ntb; x += LPJ) {
         int col = c0 + 1 + x;                                 // 1-based strand-space column
         int64_t pos = dir ? (wb - col) : (wa + col - 1);
         const int tm = fetch_tmask(a, gbase + (uint64_t)pos, dir);
@@ -420,10 +427,11 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
       const int match_t = sp.match * 4 + TR_DIAG, mismatch_t = sp.mismatch * 4 + TR_DIAG;
       int curD = NEG * 4 + TR_DIAG, curL = NEG * 4 + TR_LEFT, curU = (true_border ? i_row * sp.target_gap : NEG) * 4 + TR_UP;
       // "Row 0" (score 0 in all three matrices, ties -> Diag) is what row 1 finds above it: lane 0 gets it as the `old` operand of the
-      // lane shift; lane 32 (row 1 of the wave's second job) reads lane 31, which is no row of the first job when that guide is
-      // shorter than 32 and then simply holds row 0.  (A 32-base guide in the first job: lane 32 is patched in the loop.)
-      const bool row0_in_lane31 = __builtin_amdgcn_readlane(L, 0) < 32;
-      if (row0_in_lane31 && threadIdx.x == 31) { curD = TR_DIAG; curL = NEG * 4 + TR_LEFT; curU = TR_UP; }
+      // lane shift; the first lane of a later job reads the last lane of the job before it, which is no row of that job when its guide
+      // is shorter than LPJ and then simply holds row 0 -- always so with three jobs per wave (the host picks LPJ = 21 for guides of
+      // up to 20 rows only).  (Two jobs, a 32-base guide in the first: lane 32 is patched in the loop.)
+      const bool row0_in_lane31 = LPJ != 32 || __builtin_amdgcn_readlane(L, 0) < 32;
+      if (row0_in_lane31 && r == LPJ - 1) { curD = TR_DIAG; curL = NEG * 4 + TR_LEFT; curU = TR_UP; }
       int curP = max(max(curD, curL), curU);
       const int t_first = r + 1, t_last = r < L ? r + ncols : -1;     // the steps at which this row has a column of the strip
       const int nsteps = ncols + L - 1;
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
         }
         if (t <= nsteps) cell(t, inPa, m_a, patch_lane32);
       };
-      if (row0_in_lane31) fill(std::false_type{}); else fill(std::true_type{});
+      if (LPJ != 32 || row0_in_lane31) fill(std::false_type{}); else fill(std::true_type{});
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
         }
       }
       const unsigned long long bal = __ballot(pass);
-      const uint32_t mine = (uint32_t)(bal >> (threadIdx.x & 32));     // this job's 32 lanes (only lanes 0..15 can pass)
+      const uint32_t mine = (uint32_t)(bal >> (job * LPJ)) & 0xFFFFu;  // this job's lanes (only lanes 0..15 can pass)
       if (mine != 0u) {
         uint8_t* slab = a.slab + ((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) * a.slab_bytes;
         SlabHeader* hd = reinterpret_cast<SlabHeader*>(slab);
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(32 * JOBS_PER_BLOCK) void align_kernel(AlignArgs a)
         }
         uint32_t* dtb = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader));
         const uint32_t* stb = reinterpret_cast<const uint32_t*>(tb);
-        for (uint32_t x = r; x < tb_bytes / 4; x += 32) dtb[x] = stb[x];
+        for (uint32_t x = r; x < tb_bytes / 4; x += LPJ) dtb[x] = stb[x];
         if (r < L) {
           uint32_t* drow = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader) + tb_bytes + (uint32_t)(r * stride));
           const uint32_t* srow = reinterpret_cast<const uint32_t*>(&tr[r][0]);
@@ -837,9 +845,17 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
 
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
   // n_blocks counts 256-lane units (8 jobs)
-  const dim3 grid(n_blocks * (8 / JOBS_PER_BLOCK)), block(32 * JOBS_PER_BLOCK);
-  if (a.sp.per_matrix) hipLaunchKernelGGL(align_kernel<true>, grid, block, 0, stream, a);
-  else hipLaunchKernelGGL(align_kernel<false>, grid, block, 0, stream, a);
+  const dim3 grid(n_blocks * 4), block(64);                  // one wave per workgroup
+  // three jobs per wave when no guide has more than 20 rows (max_guide_len 0: unknown)
+  bool three = a.max_guide_len > 0 && a.max_guide_len <= 20;
+  if (const char* env = std::getenv("CALITAS_ALIGN_LPJ")) three = three && std::atoi(env) == 21;   // (tests / measurements: 32 forces two jobs)
+  if (a.sp.per_matrix) {
+    if (three) hipLaunchKernelGGL((align_kernel<true, 21>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((align_kernel<true, 32>), grid, block, 0, stream, a);
+  } else {
+    if (three) hipLaunchKernelGGL((align_kernel<false, 21>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((align_kernel<false, 32>), grid, block, 0, stream, a);
+  }
   return hipGetLastError();
 }
 

@@ -323,6 +323,7 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
   aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
   aa.trace_done = ctx->d_counters + 5;
+  for (int g = 0; g < pl.n_guides; g++) aa.max_guide_len = std::max<int32_t>(aa.max_guide_len, pl.gd[g].L);
   aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
   aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
   aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
@@ -388,14 +389,16 @@ static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
   (void)hipEventElapsedTime(&ms, ctx->t_scan0, ctx->ev[3]); tm.gpu_total_ms = ms;
 }
 
-// grids of align_kernel (units of 256 lanes: 4 single-wave workgroups each; 4096 workgroups are what the CUs hold at once) and trace_kernel
-constexpr int kAlignBlocks = 1024, kTraceBlocks = 2048;
-// ... and of a range whose tail runs beside the scan of the next one (narrow_tail).  All 4096 align_kernel workgroups resident at once
-// hold the whole LDS of every CU (16 x 10 KB), trace_kernel's 28.7 KB workgroups likewise; narrower grids for those ranges were
-// measured (CALITAS_ALIGN_BLOCKS_NARROW / CALITAS_TRACE_BLOCKS_NARROW): 2.42-2.55 ms per hg38-sized pass for 128-1024 / 512-2048, no
-// gain -- the default stays the wide grid.
+// Grids of align_kernel (units of four one-wave workgroups) and trace_kernel.  align_kernel: 2048 workgroups = 8 per CU, each looping
+// over its share of the records.  4096 (all the CUs can hold next to nothing else: 16 x ~11 KB of LDS) was round 2's choice; swept again
+// with three jobs per wave (tools/sweep_align.sh, profiles/r03_sweep_align.txt): 384-683 units beat 1024 at every size -- 2.33-2.35
+// against 2.42 ms for the hg38-sized call, 0.77 against 0.87 ms for a quarter, 0.51 against 0.53 ms for an eighth -- because the
+// scan of the next range keeps more of each CU while the tail runs beside it, and below 256 units the aligner itself runs out of waves.
+// trace_kernel's grid makes no difference between 512 and 2048 (256 costs 0.3 ms at full size).
+// CALITAS_ALIGN_BLOCKS / CALITAS_TRACE_BLOCKS (and ..._NARROW for the ranges whose tail runs beside the next range's scan) override.
+constexpr int kAlignBlocks = 512, kTraceBlocks = 2048;
 static int narrow_blocks(const char* env, int wide, int narrow) {
-  if (const char* e = std::getenv(env)) { const int v = std::atoi(e); if (v >= 1 && v <= wide) return v; }
+  if (const char* e = std::getenv(env)) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) return v; }
   return narrow;
 }
 
@@ -441,10 +444,10 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     ScanArgs sa; AlignArgs aa;
     fill_kernel_args(ctx, pl, sa, aa);
-    HIP_TRY(ctx, launch_align(aa, pl.narrow_tail ? narrow_blocks("CALITAS_ALIGN_BLOCKS_NARROW", kAlignBlocks, kAlignBlocks) : kAlignBlocks, ctx->stream));
+    HIP_TRY(ctx, launch_align(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_ALIGN_BLOCKS_NARROW" : "CALITAS_ALIGN_BLOCKS", kAlignBlocks, kAlignBlocks), ctx->stream));
     // (trace_kernel can post the counters itself from its last workgroup -- launch_trace's `post` -- but finding the last of 2048
     // workgroups is 2048 atomics on one word, ~8 ns each: 20-30 us against the ~10 us of this launch)
-    HIP_TRY(ctx, launch_trace(aa, pl.narrow_tail ? narrow_blocks("CALITAS_TRACE_BLOCKS_NARROW", kTraceBlocks, kTraceBlocks) : kTraceBlocks, ctx->stream, ctx->ev[2]));
+    HIP_TRY(ctx, launch_trace(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_TRACE_BLOCKS_NARROW" : "CALITAS_TRACE_BLOCKS", kTraceBlocks, kTraceBlocks), ctx->stream, ctx->ev[2]));
     if (speculate) {
       HIP_TRY(ctx, select_run_speculative(&ctx->select, ctx->d_raw, ctx->d_counters, ctx->rec_cap, ctx->raw_cap, ctx->item_cap, ctx->d_guides,
                                           own->d_win_base, own->d_win, pl.win_lo, pl.win_n, max_total, p.max_overlap, ctx->stream, &d_spec, &ctx->mbox));
@@ -949,9 +952,9 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(lane, pl, sa, aa);
   binned_fill_align_args(lane->binned, geo, aa);
-  HIP_TRY(lane, launch_align(aa, pl.narrow_tail ? narrow_blocks("CALITAS_ALIGN_BLOCKS_NARROW", kAlignBlocks, kAlignBlocks) : kAlignBlocks, lane->stream));
+  HIP_TRY(lane, launch_align(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_ALIGN_BLOCKS_NARROW" : "CALITAS_ALIGN_BLOCKS", kAlignBlocks, kAlignBlocks), lane->stream));
   // (no events on these dispatches: each would hold back the kernel behind it by ~5 us; the kernels stamp the device's wall clock instead)
-  HIP_TRY(lane, launch_trace(aa, pl.narrow_tail ? narrow_blocks("CALITAS_TRACE_BLOCKS_NARROW", kTraceBlocks, kTraceBlocks) : kTraceBlocks, lane->stream, nullptr));
+  HIP_TRY(lane, launch_trace(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_TRACE_BLOCKS_NARROW" : "CALITAS_TRACE_BLOCKS", kTraceBlocks, kTraceBlocks), lane->stream, nullptr));
   HIP_TRY(lane, binned_run(lane->binned, &lane->hits, geo, hr, lane->d_raw, lane->d_guides, own->d_win_base, own->d_win, bp, lane->d_counters, lane->stream,
                            &lane->mbox, nullptr, nullptr, lane->ev[5]));
   lane->rows_ev0 = -1;                                       // (the row stage's time: binned_rows_ms)
