@@ -361,7 +361,8 @@ static size_t row_bound(const PackedRef& ref, const RowStrings& rc) {
 
 char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
-               uint64_t* n_rows, WorkerPool* pool, void* (*alloc)(size_t), const calitas_ext_hit_t* ext, uint64_t n_ext) {
+               uint64_t* n_rows, WorkerPool* pool, void* (*alloc)(size_t), const calitas_ext_hit_t* ext, uint64_t n_ext, ExtRowFn ext_row,
+               void* ext_user) {
   WorkerPool serial(1);
   if (!pool) pool = &serial;
   const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
@@ -395,8 +396,8 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
     const calitas_ext_hit_t& x = ext[e];
     if (x.contig_index < 0 || x.contig_index >= n_contigs) continue;
     const Lite l{x.contig_index, x.coordinate_start, x.end, (char)x.strand, x.score, n + e};
-    const std::string desc = x.variant_description ? x.variant_description : "";
-    if (desc.empty()) { groups[(size_t)x.contig_index * 2 + (x.strand == '-' ? 1 : 0)].push_back(l); continue; }
+    if (!x.variant_description || !*x.variant_description) { groups[(size_t)x.contig_index * 2 + (x.strand == '-' ? 1 : 0)].push_back(l); continue; }
+    const std::string desc = x.variant_description;
     const std::string key = std::to_string(x.contig_index) + ":" + (char)x.strand + ":" + desc;
     auto it = desc_group.find(key);
     if (it == desc_group.end()) { it = desc_group.emplace(key, groups.size()).first; groups.emplace_back(); }
@@ -458,12 +459,24 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
         if (b >= n_blocks) break;
         const size_t e = std::min(keepers.size(), (b + 1) * BLOCK);
         size_t need = 0;
-        for (size_t i = b * BLOCK; i < e; i++) need += keepers[i].idx < n ? bound : std::strlen(ext[keepers[i].idx - n].row) + 1;
+        std::vector<std::string> made;                     // rows of the caller's hits that come without text
+        for (size_t i = b * BLOCK; i < e; i++) {
+          if (keepers[i].idx < n) { need += bound; continue; }
+          const calitas_ext_hit_t& x = ext[keepers[i].idx - n];
+          if (x.row) { need += std::strlen(x.row) + 1; continue; }
+          made.emplace_back();
+          if (ext_row) ext_row(ext_user, keepers[i].idx - n, made.back());
+          need += made.back().size() + 1;
+        }
         parts[b].buf.reset(new char[need]);
         char* w = parts[b].buf.get();
+        size_t mi = 0;
         for (size_t i = b * BLOCK; i < e; i++) {
-          if (keepers[i].idx < n) w = write_row(w, ref, rc, alns[keepers[i].idx]);
-          else { const char* r = ext[keepers[i].idx - n].row; w = put_mem(w, r, std::strlen(r)); *w++ = '\n'; }
+          if (keepers[i].idx < n) { w = write_row(w, ref, rc, alns[keepers[i].idx]); continue; }
+          const char* r = ext[keepers[i].idx - n].row;
+          if (r) w = put_mem(w, r, std::strlen(r));
+          else { w = put_mem(w, made[mi].data(), made[mi].size()); mi++; }
+          *w++ = '\n';
         }
         parts[b].len = (size_t)(w - parts[b].buf.get());
       }

@@ -48,10 +48,14 @@ struct RowStrings {
 RowStrings make_row_strings(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                             const std::string& version, const std::string& time_stamp);
 
+// Text of the row of ext[e] (without the newline), for hits whose calitas_ext_hit_t::row is NULL: called from the worker pool, only for
+// the hits removeOverlaps kept -- a caller with millions of hits of its own (the variant branch) builds no text for the ones that go.
+typedef void (*ExtRowFn)(void* user, uint64_t e, std::string& row);
+
 // hits.txt text for one guide's alignments: malloc'd, NUL-terminated (nullptr when out of memory).
 char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                const calitas_aln_t* alns, uint64_t n, const std::string& version, const std::string& time_stamp,
                uint64_t* n_rows, WorkerPool* pool = nullptr, void* (*alloc)(size_t) = nullptr, const calitas_ext_hit_t* ext = nullptr,
-               uint64_t n_ext = 0);
+               uint64_t n_ext = 0, ExtRowFn ext_row = nullptr, void* ext_user = nullptr);
 
 }  // namespace calitas

@@ -279,7 +279,6 @@ int ga_count(const char* pg, const char* pa, int len, bool lower, bool both_side
   return n;
 }
 
-struct ExtRow { int contig, start, end, score; char strand; std::string desc, row; };
 
 // MD5 (RFC 1321) of a file, hex: the second half of ReferenceHit's VCF identifier "name:md5" (RH:175-183).
 std::string md5_file(const char* path, std::string& hex) {
@@ -399,9 +398,15 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   calitas_params_t ap = p;                                                                         // the explicit-target pass
   ap.chrom_index = -1;
 
-  std::deque<ExtRow> rows;
-  const size_t kBatch = 16384;
-  std::vector<Window> batch(kBatch + 1);                                                             // reused: their vectors keep their capacity
+  // Every alignment of every variant window is a hit as far as removeOverlaps goes, but most of them repeat a reference hit (the part
+  // of the window the variant does not touch) and lose against it there: a hit gets its key here -- lifted coordinates, score,
+  // variant_description -- on the worker pool, and its row only if it is kept (make_row, called back from the row stage of hits_tsv).
+  struct ExtHit { const Window* w; const calitas_aln_t* a; int gstart, tlen; std::string desc; };
+  std::vector<ExtHit> hits;
+  std::deque<std::vector<Window>> kept_windows;                                                      // the windows and alignment records behind the hits
+  std::vector<calitas_aln_t*> kept_out;
+  const size_t kBatch = 65536;
+  std::vector<Window> batch(kBatch + 1);
   size_t nb = 0;
   uint64_t windows_total = 0;
   std::string err;
@@ -415,35 +420,22 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     return minus ? revcomp(b) : b;
   };
 
-  auto flush = [&]() -> int {
-    if (nb == 0) return CALITAS_OK;
-    const size_t n = nb;
-    std::vector<calitas_guide_t> guides(n, *guide);
-    std::vector<const uint8_t*> targets(n);
-    std::vector<uint32_t> lens(n);
-    std::vector<int32_t> offs(n, 0);
-    for (size_t i = 0; i < n; i++) { targets[i] = reinterpret_cast<const uint8_t*>(batch[i].bases.data()); lens[i] = (uint32_t)batch[i].bases.size(); }
-    calitas_aln_t* out = nullptr;
-    uint64_t n_out = 0;
-    uint32_t* counts = nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    int r = calitas_align_windows(ctx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &out, &n_out, &counts);
-    if (r) return r;
-    ms_align += ms_since(t0);
-    const auto t1 = std::chrono::steady_clock::now();
-    size_t k = 0;
-    for (size_t t = 0; t < n && err.empty(); t++) {
-      const Window& w = batch[t];
-      const int wl = (int)w.bases.size();
-      for (uint32_t c = 0; c < counts[t] && err.empty(); c++, k++) {
-        const calitas_aln_t& a = out[k];
-        const bool minus = a.strand == '-';
+  // lifted coordinates of an alignment of a window (SR:615-620); false: "Query bases can't be present at operator D."
+  auto lift = [](const Window& w, const calitas_aln_t& a, int& start, int& end, int& gstart, int& gend) {
+    return ref_offset_at(w, a.start_offset, true, start) && ref_offset_at(w, a.end_offset, false, end) &&
+           ref_offset_at(w, a.guide_start_offset, true, gstart) && ref_offset_at(w, a.guide_end_offset, false, gend);
+  };
+
+  // the row of a kept hit (RH:210-254 with the window's own bases, SR:598-613)
+  auto make_row = [&](const ExtHit& h, std::string& row) {
+        const Window& w = *h.w;
+        const calitas_aln_t& a = *h.a;
+        const int wl = (int)w.bases.size();
         const int gs = a.guide_start_offset, ge = a.guide_end_offset, as = a.start_offset, ae = a.end_offset;   // window-local
-        int start = 0, end = 0, gstart = 0, gend = 0;                                              // lifted back (SR:615-620)
-        if (!ref_offset_at(w, as, true, start) || !ref_offset_at(w, ae, false, end) || !ref_offset_at(w, gs, true, gstart) ||
-            !ref_offset_at(w, ge, false, gend)) { err = "Query bases can't be present at operator D."; break; }
-        // flanks from the window where it reaches far enough, from the reference otherwise (SR:598-613)
+        int start = 0, end = 0, gstart = 0, gend = 0;
+        (void)lift(w, a, start, end, gstart, gend);                                                 // (succeeded when the hit was keyed)
         auto flank = [&](int from, int to, bool have) { return have ? w.bases.substr((size_t)from, (size_t)(to - from)) : std::string(); };
+        const bool minus = a.strand == '-';
         const bool h_l10 = gs >= 10, h_r10 = wl - ge >= 10, h_l8 = as >= 8, h_r8 = wl - ae >= 8;
         std::string l10 = flank(gs - 10, gs, h_l10), r10 = flank(ge, ge + 10, h_r10), l8 = flank(as - 8, as, h_l8), r8 = flank(ae, ae + 8, h_r8);
         bool v_l10 = h_l10, v_r10 = h_r10, v_l8 = h_l8, v_r8 = h_r8;
@@ -468,13 +460,13 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         const int n_ops = a.n_ops;
         char pg[CALITAS_MAX_OPS + 1], pa[CALITAS_MAX_OPS + 1], pt[CALITAS_MAX_OPS + 1];
         size_t qi = 0, ti = 0;
-        int mm = 0, gp = 0, tlen = 0;
+        int mm = 0, gp = 0;
         for (int i = 0; i < n_ops; i++) {
           switch (a.ops[i]) {
             case 'I': pg[i] = q[qi++]; pa[i] = '~'; pt[i] = '-'; gp++; break;
-            case 'D': pg[i] = '-'; pa[i] = '~'; pt[i] = t[ti++]; gp++; tlen++; break;
-            case '=': pg[i] = q[qi++]; pa[i] = '|'; pt[i] = t[ti++]; tlen++; break;
-            default:  pg[i] = q[qi++]; pa[i] = '.'; pt[i] = t[ti++]; mm++; tlen++; break;
+            case 'D': pg[i] = '-'; pa[i] = '~'; pt[i] = t[ti++]; gp++; break;
+            case '=': pg[i] = q[qi++]; pa[i] = '|'; pt[i] = t[ti++]; break;
+            default:  pg[i] = q[qi++]; pa[i] = '.'; pt[i] = t[ti++]; mm++; break;
           }
         }
         int ps = -1, pe = -1;                                                                       // GA:111-115
@@ -494,7 +486,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         const int gmm = ga_count(pg, pa, n_ops, false, false, true, false), ggp = ga_count(pg, pa, n_ops, false, false, false, true);
         std::string cigar;
         for (int i = 0; i < n_ops;) { int j = i; while (j < n_ops && a.ops[j] == a.ops[i]) j++; cigar += std::to_string(j - i); cigar += (char)a.ops[i]; i = j; }
-        std::string row;
+        row.clear();
         row.reserve(640);
         auto add = [&](const std::string& s) { row += s; row += '\t'; };
         add(gid); add(gh.protospacer); add(ref.genome_build + (vs.empty() ? "" : "+variants")); add(ref.names[w.contig]);
@@ -506,10 +498,52 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         add(c5_8); add(c3_8); add(cigar); add(rs.proto_len); add(std::to_string(unpadded_target.size()));
         row += rs.tail;                                                                             // aligner .. time_stamp + '\n'
         if (!row.empty() && row.back() == '\n') row.pop_back();
-        rows.push_back(ExtRow{w.contig, gstart, gstart + tlen - 1, a.score, (char)a.strand, descs, std::move(row)});
+  };
+
+  auto flush = [&]() -> int {
+    if (nb == 0) return CALITAS_OK;
+    const size_t n = nb;
+    std::vector<calitas_guide_t> guides(n, *guide);
+    std::vector<const uint8_t*> targets(n);
+    std::vector<uint32_t> lens(n);
+    std::vector<int32_t> offs(n, 0);
+    for (size_t i = 0; i < n; i++) { targets[i] = reinterpret_cast<const uint8_t*>(batch[i].bases.data()); lens[i] = (uint32_t)batch[i].bases.size(); }
+    calitas_aln_t* out = nullptr;
+    uint64_t n_out = 0;
+    uint32_t* counts = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    int r = calitas_align_windows(ctx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &out, &n_out, &counts);
+    if (r) return r;
+    ms_align += ms_since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    // the batch's windows and records stay until the rows are written; a fresh batch for the producer
+    kept_windows.emplace_back(std::move(batch));
+    batch.assign(kBatch + 1, Window());
+    const std::vector<Window>& wins = kept_windows.back();
+    kept_out.push_back(out);
+    std::vector<uint64_t> first(n + 1, 0);
+    for (size_t t = 0; t < n; t++) first[t + 1] = first[t] + counts[t];
+    const size_t base = hits.size();
+    hits.resize(base + (size_t)n_out);
+    std::vector<std::string> errs((size_t)ctx->pool->size());
+    ctx->pool->for_blocks(n, [&](size_t tb, size_t te, int tid) {
+      for (size_t t = tb; t < te && errs[(size_t)tid].empty(); t++) {
+        const Window& w = wins[t];
+        for (uint64_t k = first[t]; k < first[t + 1]; k++) {
+          const calitas_aln_t& a = out[k];
+          ExtHit& h = hits[base + (size_t)k];
+          h.w = &w; h.a = &a;
+          int start = 0, end = 0, gend = 0;
+          if (!lift(w, a, start, end, h.gstart, gend)) { errs[(size_t)tid] = "Query bases can't be present at operator D."; break; }
+          h.tlen = 0;
+          for (int i = 0; i < a.n_ops; i++) if (a.ops[i] != 'I') h.tlen++;
+          // variants under the hit (RH:211): their display strings are the hit's removeOverlaps group (SR:656)
+          bool any = false;
+          for (const Allele& al : w.variants) if (start <= al.v->pos - 1 && al.v->pos - 1 <= end) { if (any) h.desc += ';'; h.desc += display_string(al); any = true; }
+        }
       }
-    }
-    calitas_free(out);
+    });
+    for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
     calitas_free(counts);
     nb = 0;
     ms_rows += ms_since(t1);
@@ -580,21 +614,21 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     return rc != CALITAS_OK ? rc : calitas_fail(ctx, CALITAS_EINVAL, err);
   }
 
-  // merge: removeOverlaps + sort over everything (SR:641-648)
-  std::vector<calitas_ext_hit_t> ext(rows.size());
-  {
-    size_t k = 0;
-    for (const ExtRow& r : rows) {
-      ext[k].contig_index = r.contig; ext[k].coordinate_start = r.start; ext[k].end = r.end; ext[k].score = r.score; ext[k].strand = (int8_t)r.strand;
-      ext[k].variant_description = r.desc.c_str(); ext[k].row = r.row.c_str();
-      k++;
-    }
+  // merge: removeOverlaps + sort over everything (SR:641-648); the rows of the kept variant-window hits are made on the way out
+  std::vector<calitas_ext_hit_t> ext(hits.size());
+  for (size_t k = 0; k < hits.size(); k++) {
+    const ExtHit& h = hits[k];
+    ext[k].contig_index = h.w->contig; ext[k].coordinate_start = h.gstart; ext[k].end = h.gstart + h.tlen - 1; ext[k].score = h.a->score;
+    ext[k].strand = (int8_t)h.a->strand; ext[k].variant_description = h.desc.empty() ? nullptr : h.desc.c_str(); ext[k].row = nullptr;
   }
+  struct RowMaker { decltype(make_row)* fn; const std::vector<ExtHit>* hits; } maker{&make_row, &hits};
   uint64_t nr = 0;
   const auto t_merge = std::chrono::steady_clock::now();
-  rc = calitas_hits_tsv_ext(ctx, guide, gid.c_str(), params, ref_alns, n_ref, ext.data(), (uint64_t)ext.size(), version.c_str(), stamp.c_str(), tsv, &nr);
+  *tsv = hits_tsv(ref, gh, gid, p, ref_alns, n_ref, version, stamp, &nr, ctx->pool, calitas_out_alloc, ext.data(), (uint64_t)ext.size(),
+                  [](void* user, uint64_t e, std::string& row) { auto* m = static_cast<RowMaker*>(user); (*m->fn)((*m->hits)[(size_t)e], row); }, &maker);
   calitas_free(ref_alns);
-  if (rc) return rc;
+  for (calitas_aln_t* o : kept_out) calitas_free(o);
+  if (!*tsv) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
   if (tsv_bytes) *tsv_bytes = std::strlen(*tsv);
   if (n_rows) *n_rows = nr;
   if (n_windows) *n_windows = windows_total;
