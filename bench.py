@@ -651,6 +651,21 @@ def main():
                     "peak_measured": 1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"],
                     "frac_of_measured": ach / (1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"]),
                     "peak_measured_note": "v_and / v_add streams on all 1024 SIMDs, profiles/r01_valu_rates.txt"}
+                # What the kernel's OWN instruction mix can issue at: not every integer instruction runs at the v_and rate on gfx950
+                # (measured per instruction, profiles/r01_valu_rates.txt, ns per wave-instruction per SIMD: v_bitop3 1.35, v_and / v_or 1.2,
+                # v_addc_co 1.88, v_alignbit 1.97).  One row of the recurrence over one 32-base word is 5 + 2 + 1 + 2 of those = 14.97 ns;
+                # a wave's strand of a tile = 20 rows x 9 words of that + the bottom-row test (8 words x 28 instructions at ~1.6) + the
+                # staging reads and the reverse strand's bit reversal (~60): DESIGN.md 4.1.
+                row_ns = 5 * 1.35 + 2 * 1.2 + 1.88 + 2 * 1.97
+                strand_ns = 20 * 9 * row_ns + 8 * 28 * 1.6 + 60.0
+                bases_per_ns = 1024 * (64 * 8 * 32) / (2 * strand_ns)
+                live = 1.0 - tiles["dead"] / max(1, tiles["tiles"])
+                mix_ms = sum(lengths) * live / bases_per_ns * 1e-6
+                result["roofline"]["valu"]["mix_limit"] = {
+                    "ns_per_word_row": round(row_ns, 2), "scan_ms_at_limit": round(mix_ms, 4),
+                    "frac": round(mix_ms / (acc["scan"] / K / max(1, n_guides_rank)), 4),
+                    "note": "issue time of the kernel's instruction mix at the per-instruction rates of profiles/r01_valu_rates.txt; frac = that "
+                            "time / the measured scan time per pass (sum over the launches of a call, which share the chip with the tails)"}
         except Exception:
             pass
         if m.get("partition_check"):

@@ -11,6 +11,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -620,6 +621,28 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     const ExtHit& h = hits[k];
     ext[k].contig_index = h.w->contig; ext[k].coordinate_start = h.gstart; ext[k].end = h.gstart + h.tlen - 1; ext[k].score = h.a->score;
     ext[k].strand = (int8_t)h.a->strand; ext[k].variant_description = h.desc.empty() ? nullptr : h.desc.c_str(); ext[k].row = nullptr;
+  }
+  if (std::getenv("CALITAS_TWIN_STATS")) {   // how many hits of variant windows that touch no variant repeat a reference hit exactly
+    std::vector<std::array<int64_t, 3>> keys(n_ref);
+    for (uint64_t i = 0; i < n_ref; i++) {
+      const calitas_aln_t& a = ref_alns[i];
+      int tl = 0;
+      for (int k = 0; k < a.n_ops; k++) if (a.ops[k] != 'I') tl++;
+      keys[i] = {((int64_t)a.contig_index << 32) | (uint32_t)a.guide_start_offset, ((int64_t)(a.guide_start_offset + tl - 1) << 8) | (uint8_t)a.strand, a.score};
+    }
+    std::sort(keys.begin(), keys.end());
+    uint64_t plain = 0, twins = 0, with_desc = 0, shown = 0;
+    for (const ExtHit& h : hits) {
+      if (!h.desc.empty()) { with_desc++; continue; }
+      plain++;
+      const std::array<int64_t, 3> k{((int64_t)h.w->contig << 32) | (uint32_t)h.gstart, ((int64_t)(h.gstart + h.tlen - 1) << 8) | (uint8_t)h.a->strand, h.a->score};
+      if (std::binary_search(keys.begin(), keys.end(), k)) twins++;
+      else if (shown++ < 8)
+        std::fprintf(stderr, "[calitas] no twin: contig %d start %d len %d strand %c score %d, window start %d len %zu, aln offsets %d..%d\n", h.w->contig, h.gstart, h.tlen,
+                     (char)h.a->strand, h.a->score, h.w->start, h.w->bases.size(), h.a->start_offset, h.a->end_offset);
+    }
+    std::fprintf(stderr, "[calitas] variant-window hits: %zu, %llu with a description, %llu without, of those %llu repeat a reference hit\n", hits.size(),
+                 (unsigned long long)with_desc, (unsigned long long)plain, (unsigned long long)twins);
   }
   struct RowMaker { decltype(make_row)* fn; const std::vector<ExtHit>* hits; } maker{&make_row, &hits};
   uint64_t nr = 0;

@@ -55,6 +55,15 @@ def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
         finally:
             del os.environ["CALITAS_BINNED_COMPLEX"]
         assert text4 == text
+        # align_kernel packs three jobs of 21 lanes into a wave for guides of up to 20 rows; two jobs of 32 lanes must give the same bytes
+        os.environ["CALITAS_ALIGN_LPJ"] = "32"
+        try:
+            text5, _ = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, **pk).run("v0", "stamp")
+        finally:
+            del os.environ["CALITAS_ALIGN_LPJ"]
+        assert text5 == text, "align_kernel with two and with three jobs per wave differ"
+        tm = ctx.timing()
+        assert tm["scan_kernel_ms"] > 0 and tm["align_kernel_ms"] > 0 and tm["gpu_total_ms"] >= tm["align_kernel_ms"]   # (stamps or events)
     finally:
         ctx.close()
     assert n == n2 == n3
