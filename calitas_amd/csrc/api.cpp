@@ -197,6 +197,7 @@ void calitas_destroy(calitas_ctx* c) {
     binned_destroy(c->binned);
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);
     if (c->rows_ready) (void)hipEventDestroy(c->rows_ready);
+    if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     mailbox_close(c->mbox);
     if (c->h_guides) (void)hipHostFree(c->h_guides);

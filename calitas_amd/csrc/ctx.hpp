@@ -82,6 +82,7 @@ struct calitas_ctx {
   hipEvent_t scan_done = nullptr;   // lane: recorded on the parent's scan stream after this lane's scan
   hipEvent_t t_scan0 = nullptr, t_scan1 = nullptr;   // the two events that bracket the last scan kernel (ev[0] / ev[1], or scan_done events)
   hipEvent_t rows_ready = nullptr;  // lane: recorded on its stream after its row kernels
+  hipEvent_t inputs_ready = nullptr;  // lane: its scan's inputs (guide constants, cleared counters) are in place (queued on the lane's own stream)
   uint64_t last_text_bytes = 0;
   // the last search that had to run one pass per contig: protospacer length, number of PAMs, minGuideScore (a search at least as
   // permissive goes there directly instead of finding out again)

@@ -933,6 +933,13 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
     rc = ensure_window_table(lane, pl, lane->stream);
     if (rc) return rc;
   }
+  const auto t_call = std::chrono::steady_clock::now();
+  if (!prelaunched) {
+    // the scan goes out first: it needs the guide constants and the counters only, and while it runs the host queues the rest --
+    // with the row constants and the bins' clear ahead of it the device sat idle between those small commands (~10 us of a short call)
+    int rc = launch_scan_stage(lane, pl, lane->stream);
+    if (rc) return rc;
+  }
   if (!prepared) HIP_TRY(lane, queue_row_constants(lane, pl, rs));
   if (lane->hits_names_serial != own->ref_serial) {
     HIP_TRY(lane, hits_set_names(&lane->hits, ref.names, lane->stream));
@@ -944,11 +951,6 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   const BinnedParams bp{p.window_size, pl.step, pl.max_total, p.max_overlap, pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam,
                         pl.own_lo, pl.own_hi};
   const HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
-  const auto t_call = std::chrono::steady_clock::now();
-  if (!prelaunched) {
-    int rc = launch_scan_stage(lane, pl, lane->stream);
-    if (rc) return rc;
-  }
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(lane, pl, sa, aa);
   binned_fill_align_args(lane->binned, geo, aa);
@@ -1079,6 +1081,7 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
     for (int i = 0; i < 8; i++) ok = ok && hipEventCreateWithFlags(&c->ev[i], i < 6 ? hipEventReleaseToDevice : hipEventDefault) == hipSuccess;   // as in calitas_create
     ok = ok && hipEventCreateWithFlags(&c->scan_done, hipEventReleaseToDevice) == hipSuccess;   // timed: it also brackets the scan
     ok = ok && hipEventCreateWithFlags(&c->rows_ready, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->inputs_ready, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES) == hipSuccess;
@@ -1767,13 +1770,29 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     // (Holding the scan of a range back until the aligner kernels of the range before it are done -- they take half as long again
     // beside a scan, the scan twice as long beside them -- was tried: 2.77 against 2.55 ms per pass.)
     // The inputs of all ranges (guide constants, cleared counters: a 272-byte upload and a fill per lane, 60-140 us of the scan stream
-    // each when they sit between two scans) are queued ahead of the first scan; CALITAS_INPUTS_FIRST=0: each before its own scan.
+    // each when they sit between two scans) are queued ahead of the scans; CALITAS_INPUTS_FIRST=0: each before its own scan, 1: all of
+    // them ahead of the first scan on the scan stream (round 2), 2 (default, round 3: 2.320 against 2.335 ms per hg38-sized call, 0.510
+    // against 0.517 for an eighth, interleaved):
     bool inputs_first = true;
-    if (const char* e = std::getenv("CALITAS_INPUTS_FIRST")) inputs_first = std::atoi(e) != 0;
+    int inputs_mode = 2;
+    if (const char* e = std::getenv("CALITAS_INPUTS_FIRST")) { inputs_mode = std::atoi(e); inputs_first = inputs_mode != 0; }
+    // mode 2: the first range's inputs ahead of its scan on the scan stream, the later ranges' on their own streams (which have nothing
+    // else to do yet); the scan stream waits for each with an event that has long fired when its turn comes
     if (inputs_first)
-      for (size_t c = 0; c < K && !rc; c++) { rc = queue_scan_inputs(lanes[c], plans[c], ctx->scan_stream); if (rc) ctx->err = lanes[c]->err; }
-    for (size_t c = 0; c < K && !rc; c++) {
-      rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, inputs_first);           // records lanes[c]->scan_done
+      for (size_t c = 0; c < K && !rc; c++) {
+        const bool own = inputs_mode == 2 && c > 0;
+        rc = queue_scan_inputs(lanes[c], plans[c], own ? lanes[c]->stream : ctx->scan_stream);
+        if (!rc && own) rc = hip_rc(hipEventRecord(lanes[c]->inputs_ready, lanes[c]->stream), "hipEventRecord");
+        if (rc) ctx->err = lanes[c]->err;
+        if (inputs_mode == 2 && c == 0 && !rc) {             // ... and the first scan goes out before the others' inputs are queued
+          rc = launch_scan_stage(lanes[0], plans[0], ctx->scan_stream, true);
+          if (rc) ctx->err = lanes[0]->err;
+          g_marks.mark("scan-queued");
+        }
+      }
+    for (size_t c = (inputs_mode == 2 ? 1 : 0); c < K && !rc; c++) {
+      if (inputs_mode == 2) rc = hip_rc(hipStreamWaitEvent(ctx->scan_stream, lanes[c]->inputs_ready, 0), "hipStreamWaitEvent");
+      if (!rc) rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, inputs_first);           // records lanes[c]->scan_done
       if (rc) ctx->err = lanes[c]->err;
       g_marks.mark("scan-queued");
     }
