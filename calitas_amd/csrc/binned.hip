@@ -785,6 +785,13 @@ int binned_shift(int window_size) {
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
 
 hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) {
+  void* clear = nullptr;
+  size_t bytes = 0;
+  hipError_t e = binned_prepare_host(pw, n_bins, &clear, &bytes);
+  return e == hipSuccess ? hipMemsetAsync(clear, 0, bytes, stream) : e;
+}
+
+hipError_t binned_prepare_host(BinnedWork** pw, uint32_t n_bins, void** clear, size_t* clear_bytes) {
   if (!*pw) *pw = new BinnedWork();
   BinnedWork& w = **pw;
   hipError_t e;
@@ -828,7 +835,8 @@ hipError_t binned_prepare(BinnedWork** pw, uint32_t n_bins, hipStream_t stream) 
   // (tests: CALITAS_BINNED_TEXT_KB forces the regrow path of the device buffer, CALITAS_BINNED_HOST_TEXT=0 the copy for every text)
   if (std::getenv("CALITAS_BINNED_TEXT_KB")) w.host_cap = 0;
   if (const char* env = std::getenv("CALITAS_BINNED_HOST_TEXT")) w.host_cap = std::atoi(env) != 0 ? host_want : 0;
-  return hipMemsetAsync(w.clear, 0, bytes, stream);
+  *clear = w.clear; *clear_bytes = bytes;
+  return hipSuccess;
 }
 
 void binned_fill_align_args(const BinnedWork* w, const BinnedGeometry& geo, AlignArgs& aa) {

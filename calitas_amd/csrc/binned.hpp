@@ -54,6 +54,9 @@ struct BinnedGeometry {      // where the bins of a lane's range lie
 // Scratch for n_bins bins; the bin counters, chunk sums and flags are cleared on `stream`.  Call at the start of a search, ahead of
 // the kernels (nothing of it has to sit between the end of the scan and align_kernel).
 hipError_t binned_prepare(BinnedWork** work, uint32_t n_bins, hipStream_t stream);
+// The same without the clear: *clear / *clear_bytes (a multiple of 16) is what the caller has to zero ahead of trace_kernel -- the
+// lane's setup kernel does it together with the other small inputs of a call (kernels.hpp, LaneSetupArgs).
+hipError_t binned_prepare_host(BinnedWork** work, uint32_t n_bins, void** clear, size_t* clear_bytes);
 // Where trace_kernel drops the alignments.
 void binned_fill_align_args(const BinnedWork* work, const BinnedGeometry& geo, AlignArgs& aa);
 

@@ -349,12 +349,19 @@ hipError_t hits_set_names(HitsWork** pw, const std::vector<std::string>& names, 
 // The per-call constants (row pieces, cleared counters), queued on `stream` ahead of everything else of the call so that nothing of
 // it sits between the filter stage and hit_kernel.  The host copy of the strings lives in the work until the next call.
 hipError_t hits_prepare(HitsWork** pw, const RowStrings& st, hipStream_t stream) {
+  HitsSetup hs{};
+  hipError_t e;
+  TRY(hits_prepare_host(pw, st, &hs));
+  TRY(hipMemsetAsync(hs.d_counts, 0, 3 * sizeof(uint64_t), stream));
+  return hipMemcpyAsync(hs.d_blob, hs.blob, hs.blob_bytes, hipMemcpyHostToDevice, stream);
+}
+
+hipError_t hits_prepare_host(HitsWork** pw, const RowStrings& st, HitsSetup* out) {
   if (!*pw) *pw = new HitsWork();
   HitsWork& w = **pw;
   hipError_t e;
   if (!w.d_counts) TRY(hipMalloc((void**)&w.d_counts, 3 * sizeof(uint64_t)));
   if (!w.h_counts) TRY(hipHostMalloc((void**)&w.h_counts, 3 * sizeof(uint64_t), hipHostMallocDefault));
-  TRY(hipMemsetAsync(w.d_counts, 0, 3 * sizeof(uint64_t), stream));
   RowConstDev rc{};
   std::string& blob = w.blob_host;
   blob.clear();
@@ -365,8 +372,8 @@ hipError_t hits_prepare(HitsWork** pw, const RowStrings& st, hipStream_t stream)
     add(st.pam_used[i], rc.pu_off[i], rc.pu_len[i]);
   }
   TRY(grow(&w.blob, w.blob_cap, blob.size() + 1));
-  TRY(hipMemcpyAsync(w.blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
   w.rc = rc; w.blob_bytes = blob.size(); w.prepared = true;
+  out->blob = blob.data(); out->blob_bytes = (uint32_t)blob.size(); out->d_blob = w.blob; out->d_counts = w.d_counts;
   return hipSuccess;
 }
 

@@ -45,6 +45,11 @@ hipError_t hits_set_names(HitsWork** work, const std::vector<std::string>& names
 // The call's constant row pieces and cleared counters, queued on `stream`: call it at the start of a search_hits call, ahead of the
 // search kernels; hits_run does it itself otherwise.
 hipError_t hits_prepare(HitsWork** work, const RowStrings& strings, hipStream_t stream);
+// The same without the two stream commands: the caller clears d_counts[0..3) and brings blob[0..blob_bytes) to d_blob itself -- the
+// lane's setup kernel does it together with the other small inputs of a call (kernels.hpp, LaneSetupArgs).  `blob` stays valid until
+// the next hits_prepare* on this work.
+struct HitsSetup { const char* blob; uint32_t blob_bytes; char* d_blob; uint64_t* d_counts; };
+hipError_t hits_prepare_host(HitsWork** work, const RowStrings& strings, HitsSetup* out);
 
 // d_final[0..n): accepted alignments of ONE guide in calitas_search order (device memory).  Stream-ordered except for one
 // synchronisation to learn the text size.  max_ops bounds the padded columns of any alignment of this search (it sizes the

@@ -19,6 +19,7 @@
 #include <type_traits>
 #include <hip/hip_ext.h>
 #include <chrono>
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -840,6 +841,29 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
     case 512: hipExtLaunchKernelGGL(scan_kernel<512>, grid, block, pad, stream, start, stop, 0, a); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void lane_setup_kernel(LaneSetupArgs a) {
+  if (blockIdx.x == 0) {
+    if (a.d_guides) {                                          // (null: the row stage's inputs only, the scan's went ahead)
+      const uint32_t* g = reinterpret_cast<const uint32_t*>(&a.guide);
+      uint32_t* dg = reinterpret_cast<uint32_t*>(a.d_guides);
+      for (uint32_t i = threadIdx.x; i < sizeof(GuideDev) / 4; i += 256) dg[i] = g[i];
+      if (threadIdx.x < 8) a.d_counters[threadIdx.x] = 0u;
+    }
+    if (a.d_row_counts && threadIdx.x < 6) reinterpret_cast<uint32_t*>(a.d_row_counts)[threadIdx.x] = 0u;
+    if (a.d_blob) for (uint32_t i = threadIdx.x; i < a.blob_bytes; i += 256) a.d_blob[i] = (char)a.blob[i];
+  }
+  if (a.clear)
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.clear_bytes / 16; i += gridDim.x * 256) a.clear[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+hipError_t launch_lane_setup(const LaneSetupArgs& a, hipStream_t stream) {
+  static_assert(sizeof(GuideDev) % 4 == 0 && sizeof(LaneSetupArgs) <= 4096, "the lane's small inputs travel as kernel arguments");
+  if ((a.d_guides != nullptr) != (a.d_counters != nullptr) || a.blob_bytes > LANE_SETUP_BLOB || (a.clear_bytes & 15u)) return hipErrorInvalidValue;
+  const unsigned grid = a.clear ? std::min<unsigned>(256u, std::max<unsigned>(1u, a.clear_bytes / (16u * 256u))) : 1u;
+  hipLaunchKernelGGL(lane_setup_kernel, dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -64,6 +64,24 @@ struct AlignArgs {
   SearchDev sp;
 };
 
+// The small inputs of one lane's search in ONE launch: the guide's constants, the lane's eight counters cleared, the row stage's three
+// counts cleared, the constant row strings, the bins' scratch cleared.  As separate stream commands (two uploads, three or four fills)
+// they took ~4.5 us each on the device and as long again on the host: 28 of the 140 us of an E. coli-sized call.  Everything travels
+// in the kernel's argument block (one guide, row strings up to LANE_SETUP_BLOB bytes); callers fall back to the commands otherwise.
+constexpr uint32_t LANE_SETUP_BLOB = 1536;
+struct LaneSetupArgs {
+  GuideDev guide;
+  GuideDev* d_guides;              // (both null: the row stage's part only)
+  uint32_t* d_counters;            // 8 words
+  uint64_t* d_row_counts;          // 3 x 64 bit, or null
+  char* d_blob;                    // or null
+  uint4* clear;                    // or null; clear_bytes is a multiple of 16
+  uint32_t clear_bytes;
+  uint32_t blob_bytes;
+  uint8_t blob[LANE_SETUP_BLOB];
+};
+hipError_t launch_lane_setup(const LaneSetupArgs& a, hipStream_t stream);
+
 hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // scan_rows.hip: the row-wise scan (default) and the one-off conversion codes[] -> planes[] at upload time
 hipError_t launch_scan_rows(const ScanArgs& a, int chunk, int warm_words, uint32_t n_tiles, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);

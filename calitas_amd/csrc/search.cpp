@@ -837,6 +837,39 @@ static hipError_t queue_row_constants(calitas_ctx* lane, const SearchPlan& pl, c
   return e;
 }
 
+// Everything small a lane's search needs on the device in one launch (kernels.hpp, LaneSetupArgs): guide constants, cleared counters,
+// and -- rs given -- what queue_row_constants would queue (constant row strings, the row stage's counts, the bins' scratch).  Returns
+// false when the search does not fit that form (several guides, very long parameter strings, CALITAS_LANE_SETUP=0): the caller queues
+// the separate commands then (*done = false).
+static int queue_lane_setup(calitas_ctx* lane, const SearchPlan& pl, const RowStrings* rs, hipStream_t stream, bool* done, bool with_scan_inputs = true) {
+  *done = false;
+  if (pl.n_guides != 1) return CALITAS_OK;
+  if (const char* e = std::getenv("CALITAS_LANE_SETUP")) if (std::atoi(e) == 0) return CALITAS_OK;
+  LaneSetupArgs a{};
+  if (rs) {
+    HitsSetup hs{};
+    HIP_TRY(lane, hits_prepare_host(&lane->hits, *rs, &hs));
+    if (hs.blob_bytes > LANE_SETUP_BLOB) {                      // (the strings are assembled: bring them over the usual way)
+      HIP_TRY(lane, hits_prepare(&lane->hits, *rs, stream));
+    } else {
+      std::memcpy(a.blob, hs.blob, hs.blob_bytes);
+      a.blob_bytes = hs.blob_bytes; a.d_blob = hs.d_blob; a.d_row_counts = hs.d_counts;
+    }
+    if (binned_wanted(lane, pl)) {
+      void* clear = nullptr;
+      size_t bytes = 0;
+      HIP_TRY(lane, binned_prepare_host(&lane->binned, pl.n_bins, &clear, &bytes));
+      if (bytes > 0xFFFFFFF0u) HIP_TRY(lane, hipMemsetAsync(clear, 0, bytes, stream));
+      else { a.clear = static_cast<uint4*>(clear); a.clear_bytes = (uint32_t)bytes; }
+    }
+  }
+  if (with_scan_inputs) { a.guide = pl.gd[0]; a.d_guides = lane->d_guides; a.d_counters = lane->d_counters; }
+  HIP_TRY(lane, launch_lane_setup(a, stream));
+  g_marks.mark("lane-setup");
+  *done = true;
+  return CALITAS_OK;
+}
+
 struct LaneText;
 static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, LaneText& lt, bool prepared,
                             bool* declined);
@@ -935,9 +968,12 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   }
   const auto t_call = std::chrono::steady_clock::now();
   if (!prelaunched) {
-    // the scan goes out first: it needs the guide constants and the counters only, and while it runs the host queues the rest --
-    // with the row constants and the bins' clear ahead of it the device sat idle between those small commands (~10 us of a short call)
-    int rc = launch_scan_stage(lane, pl, lane->stream);
+    // one launch for everything small the lane needs (guide constants, cleared counters, row constants, the bins' scratch), then the scan
+    bool one = false;
+    int rc = prepared ? CALITAS_OK : queue_lane_setup(lane, pl, &rs, lane->stream, &one);
+    if (rc) return rc;
+    if (one) prepared = true;
+    rc = launch_scan_stage(lane, pl, lane->stream, one);
     if (rc) return rc;
   }
   if (!prepared) HIP_TRY(lane, queue_row_constants(lane, pl, rs));
@@ -1777,30 +1813,53 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     int inputs_mode = 2;
     if (const char* e = std::getenv("CALITAS_INPUTS_FIRST")) { inputs_mode = std::atoi(e); inputs_first = inputs_mode != 0; }
     // mode 2: the first range's inputs ahead of its scan on the scan stream, the later ranges' on their own streams (which have nothing
-    // else to do yet); the scan stream waits for each with an event that has long fired when its turn comes
-    if (inputs_first)
-      for (size_t c = 0; c < K && !rc; c++) {
-        const bool own = inputs_mode == 2 && c > 0;
-        rc = queue_scan_inputs(lanes[c], plans[c], own ? lanes[c]->stream : ctx->scan_stream);
-        if (!rc && own) rc = hip_rc(hipEventRecord(lanes[c]->inputs_ready, lanes[c]->stream), "hipEventRecord");
-        if (rc) ctx->err = lanes[c]->err;
-        if (inputs_mode == 2 && c == 0 && !rc) {             // ... and the first scan goes out before the others' inputs are queued
-          rc = launch_scan_stage(lanes[0], plans[0], ctx->scan_stream, true);
-          if (rc) ctx->err = lanes[0]->err;
-          g_marks.mark("scan-queued");
-        }
-      }
-    for (size_t c = (inputs_mode == 2 ? 1 : 0); c < K && !rc; c++) {
-      if (inputs_mode == 2) rc = hip_rc(hipStreamWaitEvent(ctx->scan_stream, lanes[c]->inputs_ready, 0), "hipStreamWaitEvent");
-      if (!rc) rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, inputs_first);           // records lanes[c]->scan_done
-      if (rc) ctx->err = lanes[c]->err;
+    // else to do yet); the scan stream waits for each with an event that has long fired when its turn comes.  A range's small inputs
+    // are ONE launch (queue_lane_setup) where they used to be two stream commands for the scan and three or four for the row stage.
+    std::vector<char> rows_queued(K, 0);                      // the lane's row constants went out with its scan inputs (one launch for both)
+    const bool device_rows_early = !std::getenv("CALITAS_HOST_HITS");
+    if (inputs_mode == 2) {
+      // the first range: its scan inputs (one launch: queue_lane_setup) and its scan, before anything else is prepared
+      bool one = false;
+      rc = queue_lane_setup(lanes[0], plans[0], nullptr, ctx->scan_stream, &one);
+      if (!rc && !one) rc = queue_scan_inputs(lanes[0], plans[0], ctx->scan_stream);
+      if (!rc) rc = launch_scan_stage(lanes[0], plans[0], ctx->scan_stream, true);
+      if (rc) ctx->err = lanes[0]->err;
       g_marks.mark("scan-queued");
+      if (!rc) make_rows();
+      g_marks.mark("row-strings");
+      // the later ranges: scan inputs and row constants in one launch on the range's own stream, then its scan behind the event
+      for (size_t c = 1; c < K && !rc; c++) {
+        one = false;
+        if (device_rows_early) rc = queue_lane_setup(lanes[c], plans[c], &rs, lanes[c]->stream, &one);
+        if (!rc && one) rows_queued[c] = 1;
+        if (!rc && !one) rc = queue_scan_inputs(lanes[c], plans[c], lanes[c]->stream);
+        if (!rc) rc = hip_rc(hipEventRecord(lanes[c]->inputs_ready, lanes[c]->stream), "hipEventRecord");
+        if (!rc) rc = hip_rc(hipStreamWaitEvent(ctx->scan_stream, lanes[c]->inputs_ready, 0), "hipStreamWaitEvent");
+        if (!rc) rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, true);           // records lanes[c]->scan_done
+        if (rc && ctx->err.empty()) ctx->err = lanes[c]->err;
+        g_marks.mark("scan-queued");
+      }
+      // ... and the first range's row constants (its tail starts when its scan ends)
+      if (!rc && device_rows_early) {
+        one = false;
+        rc = queue_lane_setup(lanes[0], plans[0], &rs, lanes[0]->stream, &one, false);
+        if (!rc && one) rows_queued[0] = 1;
+        if (rc) ctx->err = lanes[0]->err;
+      }
+    } else {
+      if (inputs_first)
+        for (size_t c = 0; c < K && !rc; c++) { rc = queue_scan_inputs(lanes[c], plans[c], ctx->scan_stream); if (rc) ctx->err = lanes[c]->err; }
+      for (size_t c = 0; c < K && !rc; c++) {
+        rc = launch_scan_stage(lanes[c], plans[c], ctx->scan_stream, inputs_first);           // records lanes[c]->scan_done
+        if (rc) ctx->err = lanes[c]->err;
+        g_marks.mark("scan-queued");
+      }
+      if (!rc) make_rows();
+      g_marks.mark("row-strings");
     }
-    if (!rc) make_rows();
-    g_marks.mark("row-strings");
     for (size_t c = 0; c < K && !rc; c++) {
       // the row constants of a range go onto its stream before the wait for its scan: in place while the scan runs
-      if (device_rows) rc = hip_rc(queue_row_constants(lanes[c], plans[c], rs), "hits_prepare");
+      if (device_rows && !rows_queued[c]) rc = hip_rc(queue_row_constants(lanes[c], plans[c], rs), "hits_prepare");
       if (!rc) rc = hip_rc(hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0), "hipStreamWaitEvent");
     }
     g_marks.mark("rows-prepared");
@@ -1914,6 +1973,15 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     std::string per;
     for (auto& lt : parts) { char b[96]; std::snprintf(b, sizeof b, " [scan %.3f align+trace %.3f rows %.3f copy %.3f]", lt.tm.scan_kernel_ms, lt.tm.align_kernel_ms, lt.tm.hits_kernel_ms, lt.tm.hits_copy_ms); per += b; }
     std::fprintf(stderr, "[calitas] search_hits lanes (ms):%s\n", per.c_str());
+    if (chunked) {                                             // what the scan stream lost between two scans: end of one .. start of the next
+      std::string gaps;
+      for (size_t c = 0; c + 1 < lanes.size() && c + 1 < K; c++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, lanes[c]->t_scan1, lanes[c + 1]->t_scan0) != hipSuccess) { (void)hipGetLastError(); continue; }
+        char b[32]; std::snprintf(b, sizeof b, " %.1f", ms * 1e3); gaps += b;
+      }
+      std::fprintf(stderr, "[calitas] search_hits: scan stream idle between the scans (us):%s\n", gaps.c_str());
+    }
   }
   if (trace)
     std::fprintf(stderr, "[calitas] search_hits: %zu lane(s), scan %.3f ms, align %.3f ms, hits kernels %.3f ms, text copy %.3f ms (sums over lanes), call %.3f ms (%llu accepted, %llu rows, %zu bytes)\n",
