@@ -371,7 +371,7 @@ hipError_t hits_prepare_host(HitsWork** pw, const RowStrings& st, HitsSetup* out
     add(st.query[i], rc.q_off[i], rc.q_len[i]);
     add(st.pam_used[i], rc.pu_off[i], rc.pu_len[i]);
   }
-  TRY(grow(&w.blob, w.blob_cap, blob.size() + 1));
+  TRY(grow(&w.blob, w.blob_cap, blob.size() + 16));          // (the lane's setup kernel writes it in 16-byte pieces)
   w.rc = rc; w.blob_bytes = blob.size(); w.prepared = true;
   out->blob = blob.data(); out->blob_bytes = (uint32_t)blob.size(); out->d_blob = w.blob; out->d_counts = w.d_counts;
   return hipSuccess;

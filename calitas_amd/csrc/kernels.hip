@@ -846,21 +846,30 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
 
 __global__ __launch_bounds__(256) void lane_setup_kernel(LaneSetupArgs a) {
   if (blockIdx.x == 0) {
+    // The argument block is host memory: a load from it crosses the bus.  16 bytes per lane, all of them in flight at once -- byte by
+    // byte the 700 bytes of a typical call took 15 us.
+    const uint8_t* args = (const uint8_t*)__builtin_amdgcn_kernarg_segment_ptr();   // (a C-style cast: out of the constant address space)
     if (a.d_guides) {                                          // (null: the row stage's inputs only, the scan's went ahead)
-      const uint32_t* g = reinterpret_cast<const uint32_t*>(&a.guide);
+      const uint32_t* g = reinterpret_cast<const uint32_t*>(args + offsetof(LaneSetupArgs, guide));
       uint32_t* dg = reinterpret_cast<uint32_t*>(a.d_guides);
-      for (uint32_t i = threadIdx.x; i < sizeof(GuideDev) / 4; i += 256) dg[i] = g[i];
-      if (threadIdx.x < 8) a.d_counters[threadIdx.x] = 0u;
+      constexpr uint32_t n4 = sizeof(GuideDev) / 16, rest = (sizeof(GuideDev) % 16) / 4;
+      if (threadIdx.x < n4) reinterpret_cast<uint4*>(dg)[threadIdx.x] = reinterpret_cast<const uint4*>(g)[threadIdx.x];
+      else if (threadIdx.x < n4 + rest) dg[n4 * 4 + (threadIdx.x - n4)] = g[n4 * 4 + (threadIdx.x - n4)];
+      if (threadIdx.x >= 64 && threadIdx.x < 72) a.d_counters[threadIdx.x - 64] = 0u;
     }
-    if (a.d_row_counts && threadIdx.x < 6) reinterpret_cast<uint32_t*>(a.d_row_counts)[threadIdx.x] = 0u;
-    if (a.d_blob) for (uint32_t i = threadIdx.x; i < a.blob_bytes; i += 256) a.d_blob[i] = (char)a.blob[i];
+    if (a.d_row_counts && threadIdx.x >= 72 && threadIdx.x < 78) reinterpret_cast<uint32_t*>(a.d_row_counts)[threadIdx.x - 72] = 0u;
+    if (a.d_blob && threadIdx.x >= 128) {
+      const uint4* b = reinterpret_cast<const uint4*>(args + offsetof(LaneSetupArgs, blob));
+      for (uint32_t i = threadIdx.x - 128; i < (a.blob_bytes + 15) / 16; i += 128) reinterpret_cast<uint4*>(a.d_blob)[i] = b[i];
+    }
   }
   if (a.clear)
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.clear_bytes / 16; i += gridDim.x * 256) a.clear[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 hipError_t launch_lane_setup(const LaneSetupArgs& a, hipStream_t stream) {
-  static_assert(sizeof(GuideDev) % 4 == 0 && sizeof(LaneSetupArgs) <= 4096, "the lane's small inputs travel as kernel arguments");
+  static_assert(sizeof(GuideDev) % 4 == 0 && sizeof(GuideDev) / 16 + 4 <= 64 && sizeof(LaneSetupArgs) <= 4096 && offsetof(LaneSetupArgs, guide) % 16 == 0 &&
+                offsetof(LaneSetupArgs, blob) % 16 == 0, "the lane's small inputs travel as kernel arguments, read in 16-byte pieces");
   if ((a.d_guides != nullptr) != (a.d_counters != nullptr) || a.blob_bytes > LANE_SETUP_BLOB || (a.clear_bytes & 15u)) return hipErrorInvalidValue;
   const unsigned grid = a.clear ? std::min<unsigned>(256u, std::max<unsigned>(1u, a.clear_bytes / (16u * 256u))) : 1u;
   hipLaunchKernelGGL(lane_setup_kernel, dim3(grid), dim3(256), 0, stream, a);

@@ -70,15 +70,15 @@ struct AlignArgs {
 // in the kernel's argument block (one guide, row strings up to LANE_SETUP_BLOB bytes); callers fall back to the commands otherwise.
 constexpr uint32_t LANE_SETUP_BLOB = 1536;
 struct LaneSetupArgs {
-  GuideDev guide;
+  alignas(16) GuideDev guide;      // (16-byte aligned: the kernel reads its argument block in 16-byte pieces -- it lives in host memory)
   GuideDev* d_guides;              // (both null: the row stage's part only)
   uint32_t* d_counters;            // 8 words
   uint64_t* d_row_counts;          // 3 x 64 bit, or null
   char* d_blob;                    // or null
   uint4* clear;                    // or null; clear_bytes is a multiple of 16
   uint32_t clear_bytes;
-  uint32_t blob_bytes;
-  uint8_t blob[LANE_SETUP_BLOB];
+  uint32_t blob_bytes;             // d_blob has room for this rounded up to 16
+  alignas(16) uint8_t blob[LANE_SETUP_BLOB];
 };
 hipError_t launch_lane_setup(const LaneSetupArgs& a, hipStream_t stream);
 
