@@ -168,6 +168,15 @@ def test_lanes_and_batch_take_the_binned_tail(C, tmp_path, monkeypatch):
         monkeypatch.setenv("CALITAS_CHUNKS", "2")
         two, _ = sr.run("v0", "stamp")
         assert ctx.timing()["binned_lanes"] == 2 and two == one
+        # where the ranges' scan inputs are queued (search.cpp: each before its own scan / all ahead of the first / on the ranges' own
+        # streams, the default) and whether they are one setup launch or separate commands
+        for mode, setup in (("0", "1"), ("1", "1"), ("2", "0"), ("1", "0")):
+            monkeypatch.setenv("CALITAS_INPUTS_FIRST", mode)
+            monkeypatch.setenv("CALITAS_LANE_SETUP", setup)
+            again, _ = sr.run("v0", "stamp")
+            assert again == one, (mode, setup)
+        monkeypatch.delenv("CALITAS_INPUTS_FIRST")
+        monkeypatch.delenv("CALITAS_LANE_SETUP")
         monkeypatch.setenv("CALITAS_CHUNKS", "3")                 # three ranges: the general kernels by default ...
         three, _ = sr.run("v0", "stamp")
         assert ctx.timing()["binned_lanes"] == 0 and three == one

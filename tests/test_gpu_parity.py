@@ -62,6 +62,13 @@ def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
         finally:
             del os.environ["CALITAS_ALIGN_LPJ"]
         assert text5 == text, "align_kernel with two and with three jobs per wave differ"
+        # the lane's small inputs as separate stream commands instead of the one setup launch (kernels.hpp, LaneSetupArgs)
+        os.environ["CALITAS_LANE_SETUP"] = "0"
+        try:
+            text6, _ = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, **pk).run("v0", "stamp")
+        finally:
+            del os.environ["CALITAS_LANE_SETUP"]
+        assert text6 == text, "setup launch and separate input commands differ"
         tm = ctx.timing()
         assert tm["scan_kernel_ms"] > 0 and tm["align_kernel_ms"] > 0 and tm["gpu_total_ms"] >= tm["align_kernel_ms"]   # (stamps or events)
     finally:
