@@ -103,7 +103,11 @@ typedef struct {
 } calitas_aln_t;
 
 /* Timing and volume of the last calitas_search on this context; kernel times are HIP-event measurements on the
- * stream the kernels were launched on. */
+ * stream the kernels were launched on.  Exception, for ranges whose tail ran on the per-bin kernels (binned_lanes): no event sits
+ * between those kernels (each would hold the next kernel back by ~5 us), so align_kernel_ms is the difference of two stamps of the
+ * device's wall clock taken by the kernels themselves, gpu_total_ms = the scan + the stamps' span up to the start of the row kernel,
+ * and hits_kernel_ms = (end of the scan .. end of the row kernel, by events) - align_kernel_ms, which includes the kernel boundaries
+ * of the chain.  scan_kernel_ms is always a pair of events riding on the scan's dispatch. */
 typedef struct {
   double scan_kernel_ms;       /* bit-vector scan over the packed reference (both strands, all guides of the batch) */
   double align_kernel_ms;      /* banded glocal DP + traceback + PAM extension on the scan's candidates */
