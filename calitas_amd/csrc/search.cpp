@@ -870,6 +870,8 @@ static int queue_lane_setup(calitas_ctx* lane, const SearchPlan& pl, const RowSt
   return CALITAS_OK;
 }
 
+constexpr int kOwnedDeclined = -1000;   // (internal) a lane of an owned range (SearchPlan::owned) met bins it leaves to the general kernels
+
 struct LaneText;
 static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, LaneText& lt, bool prepared,
                             bool* declined);
@@ -888,10 +890,12 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   uint64_t n_alns = 0;
   bool resume = false;
   lane->binned_late_check = false;
+  if (pl.owned && !binned_wanted(lane, pl)) return kOwnedDeclined;   // (the general kernels return whole windows, not a stretch's rows)
   if (binned_wanted(lane, pl)) {
     bool declined = false;
     int rc = lane_rows_binned(lane, pl, prelaunched, rs, lt, hits_prepared, &declined);
     if (rc || !declined) return rc;
+    if (pl.owned) return kOwnedDeclined;
     // the bins declined: the raw alignments are where the general kernels expect them, the lane's counters in h_counters
     resume = true;
     hits_prepared = false;                                   // binned_run consumed the row constants
@@ -1371,9 +1375,11 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   return CALITAS_OK;
 }
 
+// owned: {first window, windows} of a window range (calitas_params_t::first_window / n_windows) whose rows the call returns, all of it
+// on the per-bin kernels; *owned_declined: they could not decide it (the caller then takes the slow path), nothing is returned.
 static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
-                               char* user_dst = nullptr, uint64_t user_cap = 0);
+                               char* user_dst = nullptr, uint64_t user_cap = 0, const uint64_t* owned = nullptr, bool* owned_declined = nullptr);
 
 // Whether this search is known not to fit one pass: forced (CALITAS_SEQUENTIAL, tests), or at least as permissive as the last one on
 // this context that did not.  remember = true records the search as such.
@@ -1572,9 +1578,6 @@ static bool plan_owned_range(const calitas_ctx* ctx, SearchPlan& pl, uint64_t fi
   return true;
 }
 
-static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
-                               const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
-                               char* user_dst, uint64_t user_cap);
 
 static int search_hits_owned(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                              const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
@@ -1598,33 +1601,12 @@ static int search_hits_owned(calitas_ctx* ctx, const calitas_guide_t* guide, con
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
   const size_t hlen = rs.header.size();
-  std::mutex copy_mu;
-  const bool planned = plan_owned_range(ctx, pl, (uint64_t)params->first_window, (uint64_t)params->n_windows);
-  if (planned && binned_wanted(ctx, pl)) {
-    LaneText lt;
+  {
+    // the stretch on the per-bin kernels, cut into lanes like any other call (search_hits_attempt): everything it returns is final
+    const uint64_t range[2] = {(uint64_t)params->first_window, (uint64_t)params->n_windows};
     bool declined = false;
-    rc = lane_rows_binned(ctx, pl, false, rs, lt, false, &declined);
-    if (rc) return rc;
-    if (!declined) {
-      const size_t total = hlen + (size_t)lt.bytes;
-      if (user_dst && user_cap < total + 1) return fail(ctx, CALITAS_EINVAL, "the caller's buffer is too small for the text");
-      char* text = user_dst ? user_dst : (char*)calitas_out_alloc_pinned(total + 1);
-      if (!text) return fail(ctx, CALITAS_EINVAL, "out of memory");
-      std::memcpy(text, rs.header.data(), hlen);
-      if (lt.bytes) {
-        rc = text_to_host(ctx, ctx, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
-        if (rc) { if (!user_dst) calitas_free(text); return rc; }
-        lt.tm.hits_kernel_ms = rows_stage_ms(ctx, lt.tm);
-      }
-      text[total] = 0;
-      calitas_timing_t tm = lt.tm;
-      tm.hit_rows = lt.rows; tm.hits_bytes = total; tm.lanes = 1;
-      ctx->timing = tm;
-      *tsv = text;
-      if (tsv_bytes) *tsv_bytes = total;
-      if (n_rows) *n_rows = lt.rows;
-      return CALITAS_OK;
-    }
+    rc = search_hits_attempt(ctx, guide, guide_id, &whole, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, user_dst, user_cap, range, &declined);
+    if (rc || !declined) return rc;
     HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
   }
   // ---- the contigs the stretch touches, whole, on the general kernels; their rows filtered by position ----
@@ -1686,9 +1668,10 @@ static int search_hits_owned(calitas_ctx* ctx, const calitas_guide_t* guide, con
 // library; CALITAS_EINVAL when it is too small.
 static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
-                               char* user_dst, uint64_t user_cap) {
-  if (params && (params->first_window != 0 || params->n_windows != 0))
+                               char* user_dst, uint64_t user_cap, const uint64_t* owned, bool* owned_declined) {
+  if (!owned && params && (params->first_window != 0 || params->n_windows != 0))
     return search_hits_owned(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, user_dst, user_cap);
+  if (owned_declined) *owned_declined = false;
   const auto t_call = std::chrono::steady_clock::now();
   *tsv = nullptr;
   if (tsv_bytes) *tsv_bytes = 0;
@@ -1700,6 +1683,8 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   rc = ensure_bin_base(ctx, pl, ctx->stream);                // (built once per reference and window size)
   if (rc) return rc;
   const PackedRef& ref = ctx->ref;
+  const SearchPlan whole = pl;
+  if (owned && (!plan_owned_range(ctx, pl, owned[0], owned[1]) || !binned_wanted(ctx, pl))) { if (owned_declined) *owned_declined = true; return CALITAS_OK; }
   // The constant pieces of a row.  A chunked search builds them after its scans are queued: nothing on the device needs them before
   // the first range's rows, and the first scan should not wait for string formatting on the host.
   std::string version, stamp;
@@ -1726,16 +1711,35 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     }
     if (weights.size() == 1) { int k = std::max(1, std::min(16, (int)weights[0])); weights.assign((size_t)k, 1.0); }
     for (double w : weights) if (!(w > 0)) { weights.clear(); break; }
-  } else if (ref.total_bases >= (2048ull << 20)) {
+  } else if ((owned ? owned[1] * (uint64_t)pl.step : ref.total_bases) >= (2048ull << 20)) {
     weights = {5, 3, 2};   // measured on hg38-sized input: the last range small, its tail is what nothing hides
-  } else if (ref.total_bases >= (256ull << 20)) {
+  } else if ((owned ? owned[1] * (uint64_t)pl.step : ref.total_bases) >= (256ull << 20)) {
     // a half, a quarter or an eighth of it (a rank's share on 2, 4 or 8 GPUs).  Round 3, with the per-bin tail: 1.41 / 0.86 / 0.58 ms
     // for two equal ranges against 1.46 / 0.89 / 0.62 for 3:2 and 1.53 / 0.96 / 0.72 for three; one pass: - / 0.90 / 0.60
     weights = {1, 1};
   }
   std::vector<std::pair<int, int>> ranges;
-  if (weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);
-  const size_t K = ranges.size() > 1 ? ranges.size() : 1;
+  if (!owned && weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);
+  // A window range of a multi-GPU job is cut into consecutive window ranges the same way (a rank of two searches half the genome: one
+  // pass took 1.68 ms, scan, tail and copy one after the other): each piece owns its stretch, the texts concatenate (coordinate_start
+  // is the first sort key), and a piece whose bins decline declines the call.
+  std::vector<SearchPlan> owned_plans;
+  if (owned && weights.size() > 1) {
+    double wsum = 0, acc = 0;
+    for (double w : weights) wsum += w;
+    uint64_t first = owned[0];
+    for (size_t c = 0; c < weights.size(); c++) {
+      acc += weights[c];
+      const uint64_t end = c + 1 == weights.size() ? owned[0] + owned[1] : owned[0] + (uint64_t)((double)owned[1] * acc / wsum);
+      if (end <= first) continue;
+      SearchPlan q = whole;
+      if (!plan_owned_range(ctx, q, first, end - first) || !binned_wanted(ctx, q)) { if (owned_declined) *owned_declined = true; return CALITAS_OK; }
+      owned_plans.push_back(q);
+      first = end;
+    }
+    if (owned_plans.size() < 2) owned_plans.clear();
+  }
+  const size_t K = !owned_plans.empty() ? owned_plans.size() : ranges.size() > 1 ? ranges.size() : 1;
 
   std::vector<LaneText> parts(K);
   std::vector<calitas_ctx*> lanes(K, ctx);
@@ -1777,6 +1781,8 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     for (size_t c = 0; c < K && !rc; c++) {
       lanes[c] = ctx->lanes[c];
       SearchPlan& q = plans[c];
+      if (!owned_plans.empty()) q = owned_plans[c];            // (a piece of a window range: planned above)
+      else {
       q.tile_lo = (uint32_t)(ref.contigs[ranges[c].first].gbase / ref.tile);
       const uint32_t tile_hi = ranges[c].second < (int)ref.contigs.size() ? (uint32_t)(ref.contigs[ranges[c].second].gbase / ref.tile) : (uint32_t)ref.tiles.size();
       q.n_tiles = tile_hi - q.tile_lo;
@@ -1784,6 +1790,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       for (int k = 0; k < ranges[c].first; k++) q.win_lo += window_count(ref.contigs[k].len, q.step);
       for (int k = ranges[c].first; k < ranges[c].second; k++) { q.bases += ref.contigs[k].len; q.win_n += window_count(ref.contigs[k].len, q.step); }
       plan_bins(ctx, q, ranges[c].first, ranges[c].second);
+      }
       q.narrow_tail = c + 1 < K; q.three_ranges = K >= 3;
       rc = lane_prepare(lanes[c], q);
       if (rc) ctx->err = lanes[c]->err;
@@ -1913,6 +1920,12 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       if (parts[c].rc == CALITAS_ESTATE) overflow = true;
       else if (parts[c].rc && !rc) { rc = parts[c].rc; ctx->err = lanes[c]->err; }
     }
+    if (rc == kOwnedDeclined || (owned && overflow)) {          // a piece of the window range could not be decided bin by bin: the caller's slow path
+      (void)hipDeviceSynchronize();
+      free_text();
+      if (owned_declined) *owned_declined = true;
+      return CALITAS_OK;
+    }
     if (rc || overflow) {
       (void)hipDeviceSynchronize();
       free_text();
@@ -1947,6 +1960,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   if (!chunked) {
     if (rs.header.empty()) make_rows();
     rc = lane_rows(ctx, pl, false, rs, guide_id, version, stamp, parts[0]);
+    if (rc == kOwnedDeclined) { if (owned_declined) *owned_declined = true; return CALITAS_OK; }
     if (rc) return rc;
     g_marks.mark("lane-done");
     if (!alloc_text((size_t)parts[0].bytes) || parts[0].bytes > capacity) return fail(ctx, CALITAS_EINVAL, user_dst ? no_room : "out of memory");

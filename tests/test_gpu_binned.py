@@ -225,9 +225,11 @@ def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts
         # cut points: equal parts, one moved onto the chain of contig b, one onto a contig boundary
         wa = shard.window_counts(lengths, step)[0]
         bounds = sorted(set([0, n_win] + [n_win * i // cuts for i in range(1, cuts)] + ([wa + 22] if cuts > 2 else []) + ([wa] if cuts > 3 else [])))
-        for mode in ("default", "general"):
+        for mode in ("default", "general", "two lanes", "three lanes"):
             if mode == "general":
                 monkeypatch.setenv("CALITAS_BINNED", "0")        # the fallback: whole contigs on the general kernels, rows filtered by position
+            if mode.endswith("lanes"):                           # the range cut once more into pipelined pieces, as a rank's share of a large genome is
+                monkeypatch.setenv("CALITAS_CHUNKS", "2" if mode.startswith("two") else "5:3:2")
             pieces, rows = [], 0
             for lo, hi in zip(bounds[:-1], bounds[1:]):
                 text, n = ctx.search_hits(G, "a", C.make_params(first_window=lo, n_windows=hi - lo, **pk), "v0", "stamp")
@@ -235,6 +237,7 @@ def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts
                 assert head + "\n" == whole[:len(head) + 1]
                 pieces.append(body); rows += n
             monkeypatch.delenv("CALITAS_BINNED", raising=False)
+            monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
             assert rows == n_whole and whole == whole[:whole.index("\n") + 1] + "".join(pieces), (mode, bounds)
     finally:
         ctx.close()

@@ -79,13 +79,22 @@ def test_hg38_size_window_partition_concatenates_to_the_whole_text(world, monkey
     parts = shard.window_partition(lengths, 8, 971)
     assert sum(k for _, k in parts) == sum(shard.window_counts(lengths, 971)) > 3_000_000
     head = whole[:whole.index(b"\n") + 1]
-    pieces, rows, binned = [], 0, 0
+    pieces, rows = [], 0
     for first, count in parts:
         text, k = ctx.search_hits(G, "a", C.make_params(first_window=first, n_windows=count, **kw), "v0", "stamp", decode="bytes")
         assert text.startswith(head)
-        pieces.append(text[len(head):]); rows += k; binned += ctx.timing()["binned_lanes"]
+        pieces.append(text[len(head):]); rows += k
+        tm = ctx.timing()
+        assert tm["lanes"] == 2 and tm["binned_lanes"] == 2          # a 386-Mb stretch runs as two pipelined pieces, both decided by the per-bin kernels
     assert rows == n and head + b"".join(pieces) == whole
-    assert binned == 8                                              # every stretch was decided by the per-bin kernels
+    # the two halves a rank of two searches (1.5 Gb each: two pieces as well)
+    halves = shard.window_partition(lengths, 2, 971)
+    both = []
+    for first, count in halves:
+        text, k = ctx.search_hits(G, "a", C.make_params(first_window=first, n_windows=count, **kw), "v0", "stamp", decode="bytes")
+        both.append(text[len(head):])
+        assert ctx.timing()["binned_lanes"] == ctx.timing()["lanes"] == 2
+    assert head + b"".join(both) == whole
     # two of the stretches again on the fallback (the touched contigs searched whole on the general kernels, rows filtered by position)
     monkeypatch.setenv("CALITAS_BINNED", "0")
     for i in (2, 7):
