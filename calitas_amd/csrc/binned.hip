@@ -721,7 +721,6 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void bin_rows_kernel(BinArgs a, Mid
     }
     at += total;
   }
-  if (to_host) __threadfence_system();                                // the rows are in host memory before the kernel counts as done
   }
 }
 
@@ -849,11 +848,12 @@ void binned_fill_align_args(const BinnedWork* w, const BinnedGeometry& geo, Alig
 const char* binned_text(const HitsWork* hits) { return hits ? hits->text : nullptr; }
 
 static hipError_t launch_rows(BinnedWork& w, HitsWork& hw, const BinArgs& ba, const MidArgs& ma, const uint32_t* d_counters, hipStream_t stream,
-                              Mailbox* post, hipEvent_t ev_start, hipEvent_t ev_done) {
+                              Mailbox* post, hipEvent_t ev_start, hipEvent_t ev_done, char* host_dst = nullptr, unsigned long long host_dst_cap = 0) {
   hipError_t e;
   TRY(mailbox_open(*post));
   RowsArgs ro{};
   ro.rc = hw.rc; ro.names = hw.names; ro.text = hw.text; ro.text_cap = hw.text_cap; ro.host_text = w.host_text; ro.host_cap = w.host_text ? w.host_cap : 0;
+  if (host_dst) { ro.host_text = host_dst; ro.host_cap = host_dst_cap; }   // the caller's page-locked destination: the text's final place
   ro.counters = d_counters; ro.box = post->dev; ro.seq = ++post->seq;
   ro.n_chunks = w.n_chunks; ro.n_supers = w.n_supers; ro.complex_count = w.complex_count;
   post->host[BIN_BOX_LATE] = 0;                              // raised by any wave while rows are written; read when the stream is done
@@ -879,7 +879,7 @@ static void fill_args(BinnedWork& w, HitsWork& hw, const BinnedGeometry& geo, co
 
 hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
                       const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, const uint32_t* d_counters, hipStream_t stream,
-                      Mailbox* post, hipEvent_t ev_hits_done, hipEvent_t ev_rows_start, hipEvent_t ev_rows_done) {
+                      Mailbox* post, hipEvent_t ev_hits_done, hipEvent_t ev_rows_start, hipEvent_t ev_rows_done, bool with_rows) {
   if (!pw || !*phw || !(*phw)->prepared) return hipErrorInvalidValue;
   BinnedWork& w = *pw;
   HitsWork& hw = **phw;
@@ -915,7 +915,20 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
     hipExtLaunchKernelGGL(bin_hits_kernel, dim3(grid), dim3(64), 0, stream, nullptr, ev_hits_done, 0, ba, ma, (const uint32_t*)w.complex_list,
                           (const uint32_t*)w.complex_count);
   TRY(hipGetLastError());
+  if (!with_rows) return hipSuccess;                         // (the caller launches them itself: binned_rows)
   return launch_rows(w, hw, ba, ma, d_counters, stream, post, ev_rows_start, ev_rows_done);
+}
+
+hipError_t binned_rows(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
+                       const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, const uint32_t* d_counters, hipStream_t stream,
+                       Mailbox* post, hipEvent_t ev_rows_done, char* host_dst, unsigned long long host_dst_cap) {
+  if (!pw || !*phw) return hipErrorInvalidValue;
+  BinArgs ba; MidArgs ma;
+  fill_args(*pw, **phw, geo, ref, d_raw, d_guides, d_win_base, d_win, p, ba, ma);
+  int skip = 0;
+  if (const char* env = std::getenv("CALITAS_BINNED_SKIP")) skip = std::atoi(env);
+  ba.dbg = (skip & 2) ? 2u : 0u;
+  return launch_rows(*pw, **phw, ba, ma, d_counters, stream, post, nullptr, ev_rows_done, host_dst, host_dst_cap);
 }
 
 hipError_t binned_rerun_rows(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,

@@ -75,7 +75,14 @@ struct BinnedParams {
 // ride on the dispatches (each costs the kernel behind it ~5 us of its start: pass nullptr and take the times from the posted stamps).
 hipError_t binned_run(BinnedWork* work, HitsWork** hits, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
                       const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, const uint32_t* d_counters, hipStream_t stream,
-                      Mailbox* post, hipEvent_t ev_hits_done, hipEvent_t ev_rows_start, hipEvent_t ev_rows_done);
+                      Mailbox* post, hipEvent_t ev_hits_done, hipEvent_t ev_rows_start, hipEvent_t ev_rows_done, bool with_rows = true);
+// The rows kernel by itself, behind a binned_run(..., with_rows = false): host_dst / host_dst_cap (may be null / 0) is page-locked memory
+// of the caller the device can address -- the place the text finally goes.  A text of up to host_dst_cap bytes is written there by the
+// kernel (46-49 GB/s for rows of ~520 bytes, tools/host_write_bench.hip: the copy engine's rate, without the copy's start-up and the
+// wait between the kernel and it); a longer one goes to the device buffer as usual.  The posted byte count tells which.
+hipError_t binned_rows(BinnedWork* work, HitsWork** hits, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
+                       const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, const uint32_t* d_counters, hipStream_t stream,
+                       Mailbox* post, hipEvent_t ev_rows_done, char* host_dst, unsigned long long host_dst_cap);
 // After BIN_FLAG_TEXT: the text buffer grown to `bytes`, the rows kernel once more.
 hipError_t binned_rerun_rows(BinnedWork* work, HitsWork** hits, const BinnedGeometry& geo, const HitsRef& ref, const RawAln* d_raw, const GuideDev* d_guides,
                              const uint64_t* d_win_base, const int2* d_win, const BinnedParams& p, const uint32_t* d_counters,
