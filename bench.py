@@ -193,6 +193,85 @@ def cpu_baseline(names, seqs, guides, params_kw, budget_bases, guide_ids=None):
     return report, whole, rows_by_guide
 
 
+def cpu_baseline_c5(names, seqs, guide, params_kw, budget_bases, parity_bases=16_000_000):
+    """BASELINE config 5's CPU leg: the oracle's SearchReference --variants (search_reference_vcf) on a prefix of the first contig with
+    a synthetic VCF of the same density, one worker per host core; and, on a shorter prefix, the GPU path (calitas_search_variants on a
+    context of its own) against the oracle's rows -- as a MULTISET: rows whose sort keys tie between a variant group and the reference
+    group come in a hash-map order in the reference (SearchReference.scala:656), neither side pins it.  Returns (report, parity)."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from fasta_util import write_fasta
+    import calitas_amd as C
+    from calitas_amd import _lib
+    cores = min(host_cores(), 16)
+    kw = dict(d=params_kw["max_guide_diffs"], p=params_kw["max_pam_mismatches"], g=params_kw["max_gaps_between_guide_and_pam"])
+    tmp = "/dev/shm/calitas_bench_c5cpu_%d" % os.getpid()
+    os.makedirs(tmp, exist_ok=True)
+    made = []
+
+    def sample(n_bases, tag):
+        take = min(len(seqs[0]), n_bases)
+        seq = bytes(seqs[0][:take])
+        fa = write_fasta(os.path.join(tmp, tag + ".fa"), [(names[0], seq.decode())])
+        vcf = os.path.join(tmp, tag + ".vcf")
+        n_var = synthetic_vcf(vcf, [names[0]], [seq])
+        made.extend([fa, fa + ".fai", os.path.splitext(fa)[0] + ".dict", vcf])
+        return fa, vcf, seq, n_var, take
+
+    try:
+        fa, vcf, _, n_var, take = sample(budget_bases, "time")
+        t0 = time.perf_counter()
+        _, rows, nwin = O.search_reference_vcf(fa, vcf, guide, "bench", threads=cores, **kw)
+        dt = time.perf_counter() - t0
+        report = {"value": 2 * take / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+                  "sample": "%d bp of %s with a synthetic VCF (%d variants; %d windows, %d hits) in %.1f s; oracle/ C++ restatement of "
+                            "SearchReference --variants, %d threads" % (take, names[0], n_var, nwin, len(rows), dt, cores),
+                  "bases_per_s": take / dt}
+        del rows
+        # parity on a shorter prefix
+        fa2, vcf2, seq2, n_var2, take2 = sample(parity_bases, "parity")
+        _, want, _ = O.search_reference_vcf(fa2, vcf2, guide, "bench", threads=cores, **kw)
+        ctx = C.Context(0)
+        try:
+            ctx.set_reference([names[0]], [seq2], genome_build="testassembly")
+            g = C.Guide(guide).to_c()
+            params = C.make_params(**params_kw)
+            tsv, nbytes, nrows, nw = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+            _lib.check(ctx._h, _lib.lib.calitas_search_variants(ctx._h, ctypes.byref(g), b"bench", ctypes.byref(params), vcf2.encode(), None, None, b"v", b"t",
+                                                              ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(nrows), ctypes.byref(nw)))
+            text = ctypes.string_at(tsv.value, nbytes.value).decode()
+            _lib.lib.calitas_free(tsv)
+        finally:
+            ctx.close()
+        skip = {"aligner_version", "time_stamp"}
+
+        def norm(rs):
+            out = []
+            for r in rs:
+                r = {k: v for k, v in r.items() if k not in skip}
+                if r.get("variant_vcf"):
+                    r["variant_vcf"] = r["variant_vcf"].split(":")[0]            # the oracle leaves the md5 out
+                out.append(json.dumps(r, sort_keys=True))
+            return sorted(out)
+        got = C.read_hits(text)
+        same = norm(got) == norm(want)
+        parity = {"contigs": ["%s[:%d]" % (names[0], take2)], "guides": 1, "rows": len(want), "variants": n_var2, "identical": bool(same),
+                  "compared_as": "multiset (rows whose sort keys tie between a variant group and the reference group have no pinned order, SR:656)",
+                  "rows_with_a_variant": sum(1 for r in got if r.get("variant_id"))}
+        return report, parity
+    finally:
+        for f in made:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        try:
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: N fresh rank processes (this one has not imported torch or touched a GPU),
     rank 0's JSON line passed through.  A failing rank fails the run."""
@@ -679,7 +758,19 @@ def main():
         if mb < 0:
             # the oracle runs ~2.7 Mb/s per core and guide pass on the GPU box: ~15 s of CPU work
             mb = 40.0 * min(host_cores(), 16) / (2 if args.config == 4 else 4 if args.config == 5 else 1)
-        if mb > 0 and world == 1:
+        if mb > 0 and world == 1 and args.config == 5:
+            try:
+                report, parity = cpu_baseline_c5(m["names"], m["seqs"], m["my_guides"][0], params_kw, int(mb * 1e6))
+                result["cpu_baseline"] = report
+                result["parity_sample"] = parity
+                if not parity["identical"]:
+                    print(json.dumps(result), flush=True)
+                    raise SystemExit("bench.py: GPU rows of the variant search differ from the oracle's on the parity sample")
+            except SystemExit:
+                raise
+            except Exception as e:
+                result["cpu_baseline"] = {"error": str(e)}
+        elif mb > 0 and world == 1:
             try:
                 cg = m["my_guides"][:2] if args.config == 4 else m["my_guides"][:1]
                 report, whole, oracle_rows = cpu_baseline(m["names"], m["seqs"], cg, params_kw, int(mb * 1e6),
