@@ -2108,9 +2108,11 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
   std::vector<std::string> errs((size_t)n_guides);   // a failed guide's message, kept apart from its lane (a retry below destroys the lanes)
   std::vector<calitas_timing_t> tms((size_t)n_guides);
-  std::vector<std::thread> threads;
-  for (int l = 0; l < n_lanes; l++) {
-    threads.emplace_back([&, l] {
+  // one host thread per lane: the caller drives lane 0, the context's lane threads (they live as long as the lanes: starting a thread
+  // per lane and call cost ~100 us) the others
+  auto lane_job = [&](size_t l_) {
+    {
+      const int l = (int)l_;
       (void)hipSetDevice(ctx->device);
       calitas_ctx* lane = ctx->lanes[l];
       for (int g = l; g < n_guides; g += n_lanes) {
@@ -2152,9 +2154,17 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
           (void)hipStreamSynchronize(lane->stream);   // leave the lane quiet before its next guide
         }
       }
-    });
+    }
+  };
+  ctx->lane_threads->start((size_t)n_lanes, lane_job);
+  bool threw = false;
+  try { lane_job(0); } catch (...) { threw = true; }
+  ctx->lane_threads->wait();
+  if (threw || ctx->lane_threads->threw.load()) {
+    (void)hipDeviceSynchronize();
+    release();
+    return fail(ctx, CALITAS_EHIP, "a lane of the batch ended with an exception (out of host memory?)");
   }
-  for (auto& t : threads) t.join();
   for (int g = 0; g < n_guides; g++) {
     if (rcs[g] == CALITAS_OK) continue;
     if (rcs[g] == CALITAS_ESTATE || rcs[g] == CALITAS_ENOMEM) {   // a lane's buffers overflowed / did not fit: this guide again through calitas_search_hits (retry logic, per-contig passes)
