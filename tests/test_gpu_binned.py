@@ -177,6 +177,22 @@ def test_lanes_and_batch_take_the_binned_tail(C, tmp_path, monkeypatch):
             assert again == one, (mode, setup)
         monkeypatch.delenv("CALITAS_INPUTS_FIRST")
         monkeypatch.delenv("CALITAS_LANE_SETUP")
+        # the last range's text written to its final place by the rows kernel (default) against the copy, into the library's buffer
+        # and into a page-locked buffer of the caller
+        monkeypatch.setenv("CALITAS_TEXT_IN_PLACE_OFF", "1")
+        copied, _ = sr.run("v0", "stamp")
+        monkeypatch.delenv("CALITAS_TEXT_IN_PLACE_OFF")
+        assert copied == one
+        buf = np.zeros(1 << 22, dtype=np.uint8)
+        ctx.pin_host(buf.ctypes.data, buf.nbytes)
+        try:
+            params = C.make_params(max_gaps_between_guide_and_pam=2)
+            for _ in range(3):
+                buf[:] = 0
+                nb, nr = ctx.search_hits_into(C.Guide(GUIDE), "a", params, buf.ctypes.data, buf.nbytes, "v0", "stamp")
+                assert bytes(buf[:nb]).decode() == one
+        finally:
+            ctx.unpin_host(buf.ctypes.data)
         monkeypatch.setenv("CALITAS_CHUNKS", "3")                 # three ranges: the general kernels by default ...
         three, _ = sr.run("v0", "stamp")
         assert ctx.timing()["binned_lanes"] == 0 and three == one
