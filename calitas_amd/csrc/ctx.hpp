@@ -113,6 +113,11 @@ int calitas_search_hits_into_impl(calitas_ctx* ctx, const calitas_guide_t* guide
 int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                     const char* aligner_version, const char* time_stamp, calitas_text_sink_t sink, void* user,
                                     uint64_t* tsv_bytes, uint64_t* n_rows);
+// hits of the caller's own (one HitsExt per contig, hits.hpp) brought into every contig's device row stage; *declined (with CALITAS_ESTATE):
+// a stage left the device path and nothing is returned -- the caller merges on the host
+int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                                 const char* aligner_version, const char* time_stamp, const std::vector<HitsExt>& ext_by_contig, char** tsv,
+                                 uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined);
 int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
                                    const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
                                    uint64_t* tsv_bytes, uint64_t* n_rows);

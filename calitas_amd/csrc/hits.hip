@@ -45,6 +45,24 @@ __global__ void hit_kernel(const RawAln* fin, uint32_t n, const GuideDev* guides
   if (i < n) hit_body(i, fin, guides, win_base, win, score_hi, hits, keys, vals, wks, flags);
 }
 
+// The caller's own hits (HitsExt) behind the device's n_dev: record, sort key, value.  HitRec::minus carries the strand in bit 0 and
+// "placed only" in bit 1; start / end / gend are not used for them (their rows come finished).
+__global__ void ext_kernel(const HitsExtKey* ext, uint32_t n_ext, uint32_t n_dev, int32_t contig, int score_hi, HitRec* hits, uint64_t* keys,
+                           uint32_t* vals, uint32_t* flags) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ext) return;
+  const HitsExtKey x = ext[e];
+  HitRec h;
+  h.contig = contig; h.start = x.coordinate_start; h.end = x.end + 1; h.gstart = x.coordinate_start; h.gend = x.end + 1; h.score = x.score;
+  h.rh_end = x.end; h.minus = x.flags & 3u;
+  int sb = score_hi - h.score;
+  if (sb < 0 || sb >= (1 << SCORE_BITS) || h.gstart < 0) { atomicOr(flags, HITS_FLAG_SCORE_RANGE); sb = 0; }
+  const uint32_t i = n_dev + e;
+  hits[i] = h;
+  keys[i] = ((uint64_t)(uint32_t)h.contig << 46) | ((uint64_t)(uint32_t)h.gstart << 15) | ((uint64_t)(h.minus & 1u) << 14) | (uint64_t)sb;
+  vals[i] = i;
+}
+
 // ReferenceHit.sort without a sort.  The accepted alignments arrive in (contig, window, ...) order, and hits of two windows that
 // share no base cannot be out of order relative to each other (a hit starts inside its window): with reach = the number of
 // window steps after which two windows are disjoint, hit i only has to be compared with the hits of the windows less than
@@ -79,8 +97,9 @@ __global__ void rank_kernel(const uint64_t* keys, const uint32_t* wks, uint32_t 
 __device__ __forceinline__ void prep_body(const uint32_t i, const HitRec* hits, const uint32_t* order, int max_overlap, int32_t* s_start, int32_t* s_end,
                                           int32_t* s_score, uint32_t* s_cs, uint8_t* head, uint8_t* keep) {
   const HitRec h = hits[order[i]];
-  const uint32_t cs = ((uint32_t)h.contig << 1) | h.minus;
+  const uint32_t cs = ((uint32_t)h.contig << 2) | h.minus;   // (contig, strand) group; bit 1: a hit of another group, placed only (HitsExt)
   s_start[i] = h.gstart; s_end[i] = h.rh_end; s_score[i] = h.score; s_cs[i] = cs;
+  if (h.minus & 2u) { keep[i] = 1; head[i] = 0; return; }   // kept by its own group's walk; no walk starts at it or passes through it
   keep[i] = 0;
   // restart point?  look back over the hits of this contig that start close enough to reach maxOverlap bases into this one
   bool is_head = true;
@@ -108,7 +127,7 @@ __device__ __forceinline__ void cluster_body(const uint32_t i, const int32_t* s_
     for (j++; j < n; j++) {
       const uint32_t c = s_cs[j];
       if (c == cs) return j;
-      if ((c >> 1) != (cs >> 1)) break;
+      if ((c >> 2) != (cs >> 2)) break;
     }
     return n;
   };
@@ -194,8 +213,17 @@ __global__ __launch_bounds__(256) void mid_kernel(MidArgs a, uint8_t* stage, uin
     int len = 0;
     uint32_t name_len = 0;
     const bool live = uniform_ptr(a.keep)[k] != 0;
+    const uint32_t v = uniform_ptr(a.order)[k];
+    if (v >= a.n_dev) {                                  // the caller's own hit: its row comes finished (HitsExt), out_kernel copies it
+      if (lane == 0) {
+        midlen[k] = live ? 0xFFFFFFFFu : 0u;
+        lens[k] = live ? uniform_ptr(a.ext_off)[v - a.n_dev + 1] - uniform_ptr(a.ext_off)[v - a.n_dev] : 0;
+        if (live) atomicAdd(a.ext_kept, 1u);
+      }
+      live_rows += live ? 1u : 0u;
+      continue;
+    }
     if (live) {
-      const uint32_t v = uniform_ptr(a.order)[k];
       const auto* rp = uniform_ptr(a.fin) + v;
       RowIn r;
       const auto* ow = (const __attribute__((address_space(4))) uint32_t*)rp->ops;   // RawAln::ops sits at a 4-byte aligned offset
@@ -239,6 +267,9 @@ struct OutArgs {
   const uint64_t* offs;
   const uint8_t* stage;
   uint32_t n, mid_bound;       // n sorted positions; dropped hits have midlen 0
+  uint32_t n_dev;              // order[k] >= n_dev: the caller's own hit (HitsExt), midlen 0xFFFFFFFF when kept: copy its finished row
+  const uint64_t* ext_off;
+  const char* ext_rows;
 };
 
 constexpr int OUT_ROWS_PER_WAVE = 8;
@@ -256,6 +287,13 @@ __global__ __launch_bounds__(256) void out_kernel(OutArgs a, char* text) {
     const uint32_t k = wave * OUT_ROWS_PER_WAVE + rr;
     if (k >= a.n) return;
     if (a.midlen[k] == 0) continue;                     // dropped by removeOverlaps
+    if (a.midlen[k] == 0xFFFFFFFFu) {
+      const uint32_t e = a.order[k] - a.n_dev;
+      const uint64_t b0 = a.ext_off[e], nb = a.ext_off[e + 1] - b0;
+      char* dst = text + a.offs[k];
+      for (uint64_t b = lane; b < nb; b += 64) dst[b] = a.ext_rows[b0 + b];
+      continue;
+    }
     const uint32_t contig = (uint32_t)a.hits[a.order[k]].contig;
     const uint32_t nb = a.name_off[contig], nl = a.name_off[contig + 1] - nb;
     const uint32_t s0 = a.rc.head_len, s1 = s0 + nl + 1, s2 = s1 + a.midlen[k], total = s2 + a.rc.tail_len;
@@ -319,7 +357,7 @@ void hits_destroy(HitsWork* w) {
   (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_cs); (void)hipFree(w->wks); (void)hipFree(w->s_start); (void)hipFree(w->s_end);
   (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->head); (void)hipFree(w->temp); (void)hipFree(w->text);
   (void)hipFree(w->stage); (void)hipFree(w->midlen); (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off);
-  (void)hipFree(w->d_counts);
+  (void)hipFree(w->d_counts); (void)hipFree(w->ext_keys); (void)hipFree(w->ext_off); (void)hipFree(w->ext_rows);
   if (w->h_counts) (void)hipHostFree(w->h_counts);
   mailbox_close(w->mbox);
   delete w;
@@ -379,13 +417,19 @@ hipError_t hits_prepare_host(HitsWork** pw, const RowStrings& st, HitsSetup* out
 
 hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, uint32_t n_in, const GuideDev* d_guides,
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& st, int max_overlap, int score_hi,
-                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res) {
+                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res, const HitsExt* ext) {
   if (!*pw) *pw = new HitsWork();
   HitsWork& w = **pw;
   hipError_t e;
   *res = HitsResult{};
-  const size_t n = n_in;
+  const uint32_t n_ext = ext ? ext->n : 0;
+  if (ext && ext->kept) *ext->kept = 0;
+  if ((uint64_t)n_in + n_ext > 0xFFFFFFF0ull) { res->flags = HITS_FLAG_CLUSTER; return hipSuccess; }
+  const size_t n = (size_t)n_in + n_ext;
   if (n == 0) return hipSuccess;
+  if (n_ext) window_reach = 0;                         // the caller's hits have no window: the general stable sort
+  n_in = (uint32_t)n;                                  // every stage behind hit_kernel runs over both; n_dev is the device's share
+  const uint32_t n_dev = (uint32_t)(n - n_ext);
   if (!w.prepared) TRY(hits_prepare(pw, st, stream));  // normally done at the start of the call
   w.prepared = false;
   const RowConstDev rc = w.rc;
@@ -406,6 +450,14 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   }
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
   size_t ts;
+  if (n_ext) {
+    const size_t row_bytes = (size_t)ext->row_off[n_ext];
+    TRY(grow(&w.ext_keys, w.ext_keys_cap, (size_t)n_ext)); TRY(grow(&w.ext_off, w.ext_off_cap, (size_t)n_ext + 1));
+    TRY(grow(&w.ext_rows, w.ext_rows_cap, std::max<size_t>(1, row_bytes)));
+    TRY(hipMemcpyAsync(w.ext_keys, ext->keys, (size_t)n_ext * sizeof(HitsExtKey), hipMemcpyHostToDevice, stream));
+    TRY(hipMemcpyAsync(w.ext_off, ext->row_off, ((size_t)n_ext + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (row_bytes) TRY(hipMemcpyAsync(w.ext_rows, ext->rows, row_bytes, hipMemcpyHostToDevice, stream));
+  }
   const bool small = n_in <= HITS_SMALL && window_reach != 0;
   if (small) {          // 1-3 in one launch
     HitsSmallArgs sa{};
@@ -415,7 +467,8 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
     hipLaunchKernelGGL(hits_small_kernel, dim3(1), dim3(HITS_SMALL), 0, stream, sa);
   } else {
   // 1: coordinates and the final order
-  hipLaunchKernelGGL(hit_kernel, grid, block, 0, stream, d_final, n_in, d_guides, d_win_base, d_win, score_hi, w.hits, w.keys, w.vals, w.wks, d_flags);
+  if (n_dev) hipLaunchKernelGGL(hit_kernel, dim3((n_dev + 255) / 256), block, 0, stream, d_final, n_dev, d_guides, d_win_base, d_win, score_hi, w.hits, w.keys, w.vals, w.wks, d_flags);
+  if (n_ext) hipLaunchKernelGGL(ext_kernel, dim3((n_ext + 255) / 256), block, 0, stream, (const HitsExtKey*)w.ext_keys, n_ext, n_dev, ext->contig, score_hi, w.hits, w.keys, w.vals, d_flags);
   if (window_reach) {   // the order by counting among the neighbouring windows (rank_kernel)
     hipLaunchKernelGGL(rank_kernel, grid, block, 0, stream, (const uint64_t*)w.keys, (const uint32_t*)w.wks, n_in, window_reach, w.vals2);
   } else {              // a window is too crowded for that: the general stable sort
@@ -443,7 +496,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(grow(&w.midlen, w.midlen_cap, n_pad));
   MidArgs ma{};
   ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
-  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
+  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.n_dev = n_dev; ma.ext_off = w.ext_off; ma.ext_kept = d_kept + 1; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
   const unsigned rows_per_mid_block = 4 * MID_ROWS_PER_WAVE;
   hipLaunchKernelGGL(mid_kernel, dim3((unsigned)((n + rows_per_mid_block - 1) / rows_per_mid_block)), dim3(256), mid_lds, stream, ma, w.stage, w.midlen,
                      w.lens, d_flags);
@@ -463,12 +516,13 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   res->flags = (uint32_t)w.h_counts[2];
   if (res->flags) return hipSuccess;
   res->n_rows = (uint32_t)w.h_counts[1];
+  if (ext && ext->kept) *ext->kept = (uint32_t)(w.h_counts[1] >> 32);
   res->text_bytes = w.h_counts[0];
   TRY(grow(&w.text, w.text_cap, std::max<size_t>(1, (size_t)res->text_bytes)));
   if (res->n_rows) {
     OutArgs oa{};
     oa.rc = rc; oa.blob = w.blob; oa.names = w.names; oa.name_off = w.name_off; oa.hits = w.hits; oa.order = w.vals2; oa.midlen = w.midlen;
-    oa.offs = w.offs; oa.stage = w.stage; oa.n = n_in; oa.mid_bound = mid_bound;
+    oa.offs = w.offs; oa.stage = w.stage; oa.n = n_in; oa.mid_bound = mid_bound; oa.n_dev = n_dev; oa.ext_off = w.ext_off; oa.ext_rows = w.ext_rows;
     const unsigned rows_per_block = 4 * OUT_ROWS_PER_WAVE;
     hipLaunchKernelGGL(out_kernel, dim3((n_in + rows_per_block - 1) / rows_per_block), dim3(256), rc.head_len + rc.tail_len, stream, oa, w.text);
   }

@@ -51,6 +51,24 @@ hipError_t hits_prepare(HitsWork** work, const RowStrings& strings, hipStream_t 
 struct HitsSetup { const char* blob; uint32_t blob_bytes; char* d_blob; uint64_t* d_counts; };
 hipError_t hits_prepare_host(HitsWork** work, const RowStrings& strings, HitsSetup* out);
 
+// Hits the caller built itself and wants placed among (and, for the reference's removeOverlaps group, walked with) the device's: the
+// hits of variant windows (SearchReference.scala:570-630).  They arrive after every hit of the reference windows (SR:622), so among
+// equal ReferenceHit.sort keys they follow the device's hits, in the order given here.  An entry without HITS_EXT_PLACED belongs to the
+// group "chromosome : strand : no variant_description" (SR:656) and takes part in that group's walk like any reference hit; an entry
+// with it was kept by a walk of its own group on the host and is only given its place in the order.  Every entry brings its finished
+// row (text + newline): the rows kernel copies the rows of the entries that survive to their place in the text.  Host memory; contig
+// is the one contig all of them (and all of d_final's alignments) lie on.
+constexpr uint32_t HITS_EXT_MINUS = 1, HITS_EXT_PLACED = 2;
+struct HitsExtKey { int32_t coordinate_start, end, score; uint32_t flags; };
+struct HitsExt {
+  int32_t contig = 0;
+  uint32_t n = 0;
+  const HitsExtKey* keys = nullptr;
+  const uint64_t* row_off = nullptr;   // n + 1 offsets into rows
+  const char* rows = nullptr;
+  uint32_t* kept = nullptr;            // out (optional): how many of the entries were kept
+};
+
 // d_final[0..n): accepted alignments of ONE guide in calitas_search order (device memory).  Stream-ordered except for one
 // synchronisation to learn the text size.  max_ops bounds the padded columns of any alignment of this search (it sizes the
 // per-row LDS slots).  window_reach: the number of window steps after which two windows share no base (the final order then comes
@@ -58,7 +76,7 @@ hipError_t hits_prepare_host(HitsWork** work, const RowStrings& strings, HitsSet
 // final order.
 hipError_t hits_run(HitsWork** work, const HitsRef& ref, const RawAln* d_final, uint32_t n, const GuideDev* d_guides,
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& strings, int max_overlap, int score_hi,
-                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res);
+                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res, const HitsExt* ext = nullptr);
 void hits_destroy(HitsWork* work);
 
 }  // namespace calitas

@@ -132,6 +132,9 @@ struct MidArgs {
   uint32_t n_max;            // most padded columns a row of this search can have (<= MID_COLS)
   uint32_t blob_bytes;       // constant strings, copied to LDS by each block
   uint32_t* n_rows;          // out: number of live rows
+  uint32_t n_dev;            // order[k] >= n_dev: a hit the caller built (HitsExt) -- no row to build, its length comes from ext_off
+  const uint64_t* ext_off;
+  uint32_t* ext_kept;        // out: how many of those were kept
 };
 
 static_assert(offsetof(RawAln, ops) % 4 == 0 && sizeof(RawAln) % 4 == 0, "RawAln::ops must be word aligned");
@@ -345,7 +348,10 @@ struct HitsWork {
   char* blob = nullptr; size_t blob_cap = 0;
   char* names = nullptr; size_t names_cap = 0;
   uint32_t* name_off = nullptr; size_t name_off_cap = 0;
-  uint64_t* d_counts = nullptr;   // [0] text bytes, [1] low word: kept rows, [2] low word: flags
+  HitsExtKey* ext_keys = nullptr; size_t ext_keys_cap = 0;   // the caller's own hits of this call (HitsExt)
+  uint64_t* ext_off = nullptr; size_t ext_off_cap = 0;
+  char* ext_rows = nullptr; size_t ext_rows_cap = 0;
+  uint64_t* d_counts = nullptr;   // [0] text bytes, [1] low word: kept rows, high word: kept hits of the caller's own, [2] low word: flags
   uint64_t* h_counts = nullptr;   // pinned
   Mailbox mbox;                   // carries d_counts to the host (mailbox.hpp)
   RowConstDev rc{};               // set by hits_prepare

@@ -142,6 +142,7 @@ struct SearchPlan {
   uint64_t own_lo = 0, own_hi = ~0ull;
   bool narrow_tail = false;           // a range of a chunked call that is not the last: its tail shares the chip with the next scan
   bool three_ranges = false;          // a range of a call cut into three or more
+  bool general_tail = false;          // the caller brings hits of its own into the row stage (HitsExt): the general kernels take them, the bins do not
 };
 
 // The bins of contigs [c0, c1) of the plan's geometry (the owner's bin_base must be built: ensure_bin_base).
@@ -810,7 +811,7 @@ static double rows_stage_ms(calitas_ctx* lane, const calitas_timing_t& tm) {
 // as permissive as the last the bins declined on this reference.
 static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
   const calitas_ctx* own = ref_owner(lane);
-  if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0) return false;
+  if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0 || pl.general_tail) return false;
   if (!pl.owned && (pl.gw_lo != 0 || pl.gw_hi != ~0ull)) return false;   // (a window range of calitas_search: alignment records, no rows)
   if (std::getenv("CALITAS_HOST_FILTER") || std::getenv("CALITAS_HOST_HITS")) return false;
   // Which tail by default: the per-bin kernels wherever a call is one pass or two ranges (references up to 2 Gb: a rank's share of a
@@ -876,6 +877,7 @@ static int queue_lane_setup(calitas_ctx* lane, const SearchPlan& pl, const RowSt
 struct LaneDest { std::function<bool(char** dst, uint64_t* cap)> get; };
 
 constexpr int kOwnedDeclined = -1000;   // (internal) a lane of an owned range (SearchPlan::owned) met bins it leaves to the general kernels
+constexpr int kExtDeclined = -1001;     // (internal) a pass that brings hits of the caller's (HitsExt) met a stage the device declines: the caller merges on the host
 
 struct LaneText;
 static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, LaneText& lt, bool prepared,
@@ -885,7 +887,8 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
 // hits_prepared: the caller queued hits_prepare on the lane's stream already -- *before* the stream's wait for the scan, so that
 // the constants are in place while the scan runs instead of sitting between the end of the scan and align_kernel.
 static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, const std::string& guide_id,
-                     const std::string& version, const std::string& stamp, LaneText& lt, bool hits_prepared = false, const LaneDest* dest = nullptr) {
+                     const std::string& version, const std::string& stamp, LaneText& lt, bool hits_prepared = false, const LaneDest* dest = nullptr,
+                     const HitsExt* ext = nullptr) {
   calitas_ctx* own = ref_owner(lane);
   const PackedRef& ref = own->ref;
   const calitas_params_t& p = pl.p;
@@ -909,6 +912,10 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched, resume);
   if (rc) return rc;
   lt.tm = lane->timing;
+  if (ext && !dev.valid && n_alns == 0) {   // nothing of the reference's own on this contig: the row stage still places the caller's hits
+    dev.valid = true; dev.d_final = nullptr; dev.n_sel = 0; dev.crowded = true;
+  }
+  if (ext && (!dev.valid || std::getenv("CALITAS_HOST_HITS"))) { calitas_free(alns); return kExtDeclined; }
   if (dev.valid && !std::getenv("CALITAS_HOST_HITS")) {
     // removeOverlaps, ReferenceHit.sort and the rows on the device (hits.hip); only text crosses PCIe
     int max_pam = 0;
@@ -927,7 +934,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       lane->rows_ev0 = 4;
       HIP_TRY(lane, hits_run(&lane->hits, hr, dev.d_final, dev.n_sel, lane->d_guides, own->d_win_base, own->d_win, rs, p.max_overlap, score_hi,
                              pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, dev.crowded ? 0u : (uint32_t)((p.window_size + pl.step - 1) / pl.step),
-                             lane->stream, &res));
+                             lane->stream, &res, ext));
       HIP_TRY(lane, hipEventRecord(lane->ev[5], lane->stream));
       g_marks.mark("rows-queued");
       kernel_times(lane, lt.tm);          // while out_kernel runs
@@ -937,6 +944,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       }
       if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
     }
+    if (ext) return kExtDeclined;
   }
   // host tail: the same stages as calitas_hits_tsv (one lane at a time: they share the owner's worker pool)
   std::lock_guard<std::mutex> host_lock(own->host_mu);
@@ -1201,7 +1209,7 @@ static void release_scratch(calitas_ctx* ctx) {
 // collected: no text block at all, *tsv stays NULL.
 static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                   const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
-                                  calitas_text_sink_t sink = nullptr, void* sink_user = nullptr) {
+                                  calitas_text_sink_t sink = nullptr, void* sink_user = nullptr, const std::vector<HitsExt>* ext_by_contig = nullptr) {
   const auto t_call = std::chrono::steady_clock::now();
   SearchPlan pl;
   int rc = plan_search(ctx, 1, guide, params, pl);
@@ -1288,7 +1296,9 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       ctx->hits = work[i & 1]; ctx->hits_names_serial = serial[i & 1];
       sl.lt = LaneText();
       const auto t_rows = std::chrono::steady_clock::now();
-      sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt);
+      const HitsExt* ext = ext_by_contig && (*ext_by_contig)[(size_t)pass_contig[i]].n ? &(*ext_by_contig)[(size_t)pass_contig[i]] : nullptr;
+      passes[i].general_tail = ext != nullptr;
+      sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt, false, nullptr, ext);
       if (sl.rc == CALITAS_OK && hipEventRecord(sl.rows_done, ctx->stream) != hipSuccess) sl.rc = fail(ctx, CALITAS_EHIP, "hipEventRecord failed");
       sl.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count();
       work[i & 1] = ctx->hits; serial[i & 1] = ctx->hits_names_serial;
@@ -1484,6 +1494,22 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
   *tsv = nullptr;
   rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
   if (rc == CALITAS_ENOMEM) release_scratch(ctx);   // leave the context usable for smaller searches
+  return rc;
+}
+
+// calitas_search_hits with hits of the caller's own brought into every contig's row stage (the variant branch, variants.cpp): one pass per
+// contig on the general kernels.  kExtDeclined is returned as CALITAS_ESTATE + *declined: a stage left the device path, the caller
+// merges on the host instead.
+int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
+                                 const char* aligner_version, const char* time_stamp, const std::vector<HitsExt>& ext_by_contig, char** tsv,
+                                 uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined) {
+  *declined = false;
+  *tsv = nullptr;
+  if (ext_by_contig.size() != ctx->ref.contigs.size()) return fail(ctx, CALITAS_EINVAL, "one HitsExt per contig expected");
+  if (!known_not_to_fit(ctx, guide, params, false)) (void)predicted_not_to_fit(ctx, guide, params);   // (sizes the passes' buffers when the search is a dense one)
+  int rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, nullptr, nullptr, &ext_by_contig);
+  if (rc == kExtDeclined) { *declined = true; *tsv = nullptr; return CALITAS_ESTATE; }
+  if (rc == CALITAS_ENOMEM) release_scratch(ctx);
   return rc;
 }
 

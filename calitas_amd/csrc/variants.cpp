@@ -17,7 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <deque>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -376,13 +378,9 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   const auto t_call = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   double ms_ref = 0, ms_parse = 0, ms_align = 0, ms_rows = 0, ms_merge = 0;
-
-  // reference windows on the GPU (SR:527-561)
-  calitas_aln_t* ref_alns = nullptr;
+  calitas_aln_t* ref_alns = nullptr;                                                               // (host merge only, below)
   uint64_t n_ref = 0;
-  int rc = calitas_search_impl(ctx, 1, guide, params, &ref_alns, &n_ref);
-  if (rc) return rc;
-  ms_ref = ms_since(t_call);
+  int rc = CALITAS_OK;
 
   std::vector<Var> vcf;
   {
@@ -615,7 +613,124 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     return rc != CALITAS_OK ? rc : calitas_fail(ctx, CALITAS_EINVAL, err);
   }
 
-  // merge: removeOverlaps + sort over everything (SR:641-648); the rows of the kept variant-window hits are made on the way out
+  // ---- the reference windows (SR:527-561) and the merge (SR:641-648) ------------------------------------------------------------
+  // On the device: the reference's own hits never leave it.  A hit of a variant window that touches no variant joins the removeOverlaps
+  // group of the reference hits of its chromosome and strand (SR:656) -- most of them repeat a reference hit and lose against it there,
+  // the ones an edge of their window cut short do not -- so every one of them goes into the device's walk of that group (hits.hpp,
+  // HitsExt), behind the reference hits with the same sort key as SR:622 has them arrive.  The groups of the hits that do touch variants
+  // hold nothing else: they are walked here, and what they keep is handed to the device for its place in ReferenceHit.sort's order only.
+  // The device then writes every surviving row, its own and these, into one text per contig.  Ties between rows of different groups
+  // follow calitas_hits_tsv_ext (the reference leaves them to a hash map): the reference group first, then the variant groups in order
+  // of first appearance.
+  const char* force_host = std::getenv("CALITAS_VARIANTS_HOST");
+  if (!(force_host && std::atoi(force_host) != 0) && p.max_overlap >= 1) {
+    const auto t_dev = std::chrono::steady_clock::now();
+    const size_t nc = ref.contigs.size();
+    struct Lite { int start, end, score; uint32_t idx; };
+    std::vector<std::vector<uint32_t>> by_contig(nc);
+    if (hits.size() >= 0xFFFFFFF0ull) return calitas_fail(ctx, CALITAS_EINVAL, "more than 2^32 hits of variant windows");
+    for (size_t k = 0; k < hits.size(); k++) by_contig[(size_t)hits[k].w->contig].push_back((uint32_t)k);
+    std::vector<std::vector<uint32_t>> order(nc);                                                   // per contig: the entries in tie order
+    std::vector<std::vector<uint8_t>> placed(nc);
+    {
+      std::atomic<size_t> next(0);
+      ctx->pool->run([&](int) {
+        for (;;) {
+          const size_t c = next.fetch_add(1);
+          if (c >= nc) break;
+          std::unordered_map<std::string, uint32_t> group_of;
+          std::vector<std::vector<Lite>> groups;
+          auto& ord = order[c];
+          for (uint32_t k : by_contig[c]) {
+            const ExtHit& h = hits[k];
+            if (h.desc.empty()) { ord.push_back(k); continue; }
+            std::string key(1, (char)h.a->strand);
+            key += h.desc;
+            auto it = group_of.find(key);
+            if (it == group_of.end()) { it = group_of.emplace(std::move(key), (uint32_t)groups.size()).first; groups.emplace_back(); }
+            groups[it->second].push_back(Lite{h.gstart, h.gstart + h.tlen - 1, h.a->score, k});
+          }
+          placed[c].assign(ord.size(), 0);
+          for (auto& hs : groups) {                                                                // removeOverlaps SR:653-675 on one group
+            std::stable_sort(hs.begin(), hs.end(), [](const Lite& x, const Lite& y) { return x.start != y.start ? x.start < y.start : -x.score < -y.score; });
+            auto overlap = [](const Lite& x, const Lite& y) { return std::max(0, std::min(x.end, y.end) - std::max(x.start, y.start)); };   // RH:141-144
+            size_t i = 0;
+            while (i < hs.size()) {
+              const Lite hit = hs[i++];
+              while (i < hs.size() && overlap(hs[i], hit) >= p.max_overlap && hs[i].score <= hit.score) i++;
+              if (i >= hs.size() || overlap(hs[i], hit) < p.max_overlap) { ord.push_back(hit.idx); placed[c].push_back(1); }
+            }
+          }
+        }
+      });
+    }
+    // the entries' rows and keys
+    std::vector<std::vector<HitsExtKey>> keys(nc);
+    std::vector<std::vector<uint64_t>> row_off(nc);
+    std::vector<std::string> blobs(nc);
+    std::vector<HitsExt> ext_by_contig(nc);
+    {
+      std::vector<size_t> first(nc + 1, 0);
+      for (size_t c = 0; c < nc; c++) first[c + 1] = first[c] + order[c].size();
+      std::vector<std::string> rows(first[nc]);
+      ctx->pool->for_blocks(first[nc], [&](size_t b, size_t e, int) {
+        size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
+        for (size_t i = b; i < e; i++) {
+          while (i >= first[c + 1]) c++;
+          make_row(hits[order[c][i - first[c]]], rows[i]);
+          rows[i] += '\n';
+        }
+      });
+      for (size_t c = 0; c < nc; c++) {
+        const size_t n = order[c].size();
+        keys[c].resize(n); row_off[c].assign(n + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+          const ExtHit& h = hits[order[c][i]];
+          keys[c][i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (placed[c][i] ? HITS_EXT_PLACED : 0u)};
+          row_off[c][i + 1] = row_off[c][i] + rows[first[c] + i].size();
+        }
+        blobs[c].resize((size_t)row_off[c][n]);
+      }
+      ctx->pool->for_blocks(first[nc], [&](size_t b, size_t e, int) {
+        size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
+        for (size_t i = b; i < e; i++) {
+          while (i >= first[c + 1]) c++;
+          std::memcpy(&blobs[c][(size_t)row_off[c][i - first[c]]], rows[i].data(), rows[i].size());
+        }
+      });
+      for (size_t c = 0; c < nc; c++) {
+        HitsExt& x = ext_by_contig[c];
+        x.contig = (int32_t)c; x.n = (uint32_t)order[c].size(); x.keys = keys[c].data(); x.row_off = row_off[c].data(); x.rows = blobs[c].data();
+      }
+    }
+    const double ms_ext = ms_since(t_dev);
+    bool declined = false;
+    uint64_t bytes = 0, nr = 0;
+    const auto t_search = std::chrono::steady_clock::now();
+    rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), ext_by_contig, tsv, &bytes, &nr, &declined);
+    if (rc == CALITAS_OK) {
+      for (calitas_aln_t* o : kept_out) calitas_free(o);
+      if (tsv_bytes) *tsv_bytes = bytes;
+      if (n_rows) *n_rows = nr;
+      if (n_windows) *n_windows = windows_total;
+      if (std::getenv("CALITAS_TRACE"))
+        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: align %.1f ms, keys %.1f ms, groups + rows of %zu hits %.1f ms, "
+                             "reference search with them on the device %.1f ms, call %.1f ms\n",
+                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, hits.size(), ms_ext, ms_since(t_search), ms_since(t_call));
+      return CALITAS_OK;
+    }
+    if (!declined) { for (calitas_aln_t* o : kept_out) calitas_free(o); return rc; }
+    if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
+  }
+  // On the host (a stage the device declines: -O 0, a window beyond the device filter, an overlap cluster beyond one lane's walk):
+  // reference windows on the GPU, their alignment records back, removeOverlaps + sort over everything.
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = calitas_search_impl(ctx, 1, guide, params, &ref_alns, &n_ref);
+    if (rc) { for (calitas_aln_t* o : kept_out) calitas_free(o); return rc; }
+    ms_ref = ms_since(t0);
+  }
+  // the rows of the kept variant-window hits are made on the way out
   std::vector<calitas_ext_hit_t> ext(hits.size());
   for (size_t k = 0; k < hits.size(); k++) {
     const ExtHit& h = hits[k];

@@ -88,6 +88,7 @@ def search_variants(sr, ctx, vcf_path, chrom_index=-1, version=None, time_stamp=
     finally:
         lib.calitas_free(tsv)
     sr.variant_windows = nwin.value
+    sr.timing = ctx.timing()                                   # contig_passes > 0: the reference rows were built on the device
     return text, rows.value
 
 

@@ -172,6 +172,79 @@ def test_many_batches_equal_python_twin(C, tmp_path):
     assert sorted(map(key, _norm(got))) == sorted(map(key, _norm(want)))      # ties between groups may come in another order (SR:656)
 
 
+def _dense_case(C, tmp_path, sizes, every, seed):
+    """A PAM-less search permissive enough that every window holds alignments (BASELINE config 5's shape) + a VCF of SNVs and indels."""
+    from calitas_amd import synth
+    rng = np.random.default_rng(seed)
+    names, seqs = synth.make_genome(sizes, seed=seed, guides=[("CTTGCCCCACAGGGCAGTAA", "", False)], sites_per_guide=40, n_run_ends=100,
+                                    n_block=600, softmask=0.3)
+    contigs = [(n, s.tobytes().decode()) for n, s in zip(names, seqs)]
+    fa = write_fasta(str(tmp_path / "d.fa"), contigs)
+    variants, afs = [], []
+    for name, seq in contigs:
+        U, pos = seq.upper(), 40
+        while pos < len(U) - 60:
+            pos += int(rng.integers(1, 2 * every))
+            if pos >= len(U) - 10:
+                break
+            rb = U[pos - 1]
+            if rb not in "ACGT":
+                continue
+            others = [b for b in "ACGT" if b != rb]
+            k = rng.random()
+            if k < 0.7:
+                ref, alts = rb, [others[int(rng.integers(0, 3))]]
+            elif k < 0.85:
+                ref, alts = rb, [rb + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 4))))]
+            else:
+                ln = int(rng.integers(2, 5))
+                ref = U[pos - 1:pos - 1 + ln]
+                if any(c not in "ACGT" for c in ref):
+                    continue
+                alts = [rb]
+            variants.append((name, pos, "rs%d" % len(variants), ref, alts))
+            afs.append([round(float(rng.uniform(0.01, 0.5)), 4) for _ in alts])
+            pos += len(ref)
+    return fa, write_vcf(str(tmp_path / "d.vcf"), variants, afs)
+
+
+@pytest.mark.parametrize("d,overlap", [(7, 10), (8, 10), (8, 25), (7, 1)])
+def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_path, monkeypatch):
+    """calitas_search_variants keeps the reference's own hits on the device: the hits of variant windows enter the device's
+    removeOverlaps walk / order as key-only entries with finished rows (hits.hpp, HitsExt).  Same bytes as the host merge of
+    alignment records (CALITAS_VARIANTS_HOST=1, the path the oracle comparisons of this file pinned), with and without a contig whose
+    reference windows yield nothing, and the oracle's rows as a multiset (ties between groups: SR:656)."""
+    fa, vcf = _dense_case(C, tmp_path, [("chr1", 60000), ("tiny", 90), ("chr2", 21000)], 80, seed=100 + d)
+    kw = dict(guide="CTTGCCCCACAGGGCAGTAA", guide_id="c5", ref=fa, variants=vcf, max_guide_diffs=d, max_pam_mismatches=0,
+              max_gaps_between_guide_and_pam=3, max_overlap=overlap)
+    sr = C.SearchReference(**kw)
+    text, n = sr.run("v0", "stamp")
+    assert sr.timing["contig_passes"] == 3                      # one pass per contig, none declined
+    monkeypatch.setenv("CALITAS_VARIANTS_HOST", "1")
+    sh = C.SearchReference(**kw)
+    text_h, n_h = sh.run("v0", "stamp")
+    assert sh.timing["contig_passes"] == 0
+    assert (text, n) == (text_h, n_h)
+    got = C.read_hits(text)
+    with_variant = sum(1 for r in got if r["variant_description"])
+    assert with_variant > 20 and len(got) > 200, (with_variant, len(got))
+    _, want, _ = O.search_reference_vcf(fa, vcf, kw["guide"], "c5", d=d, p=0, g=3, O=overlap)
+    key = lambda r: json.dumps(r, sort_keys=True)
+    assert sorted(map(key, _norm(got))) == sorted(map(key, _norm(want)))
+
+
+def test_device_merge_declines_to_the_host(C, tmp_path):
+    """-O 0 is beyond the device's row stage: the call merges on the host, same rows as the oracle."""
+    fa, vcf = _dense_case(C, tmp_path, [("chr1", 30000)], 300, seed=77)
+    sr = C.SearchReference(guide="CTTGCCCCACAGGGCAGTAA", guide_id="c5", ref=fa, variants=vcf, max_guide_diffs=5, max_pam_mismatches=0,
+                           max_gaps_between_guide_and_pam=3, max_overlap=0)
+    text, n = sr.run("v0", "stamp")
+    assert sr.timing["contig_passes"] == 0
+    _, want, _ = O.search_reference_vcf(fa, vcf, "CTTGCCCCACAGGGCAGTAA", "c5", d=5, p=0, g=3, O=0)
+    key = lambda r: json.dumps(r, sort_keys=True)
+    assert sorted(map(key, _norm(C.read_hits(text)))) == sorted(map(key, _norm(want)))
+
+
 def test_cpp_cli_with_variants(C, tmp_path):
     """`calitas SearchReference --variants` (the C++ front end; the library computes the VCF's name:md5 identifier itself) writes the
     rows the Python API returns, whose identifier comes from hashlib."""
