@@ -486,7 +486,7 @@ def main():
             log("window partition: bases per rank max / mean = %.4f" % (max(loads) / (sum(loads) / world)))
         G = [C.Guide(g) for g in my_guides]
         ids = ["bench%d" % i for i in range(len(G))]
-        phase = {"search_hits": 0.0, "gather": 0.0, "search": 0.0, "hits": 0.0, "free": 0.0}
+        phase = {"search_hits": 0.0, "gather": 0.0, "search": 0.0, "hits": 0.0, "free": 0.0, "free_text": 0.0}
         # Contig partition, host-side gather without a second copy: one file in shared memory holds a size table and a fixed slot per
         # rank; every rank maps it, page-locks its slot and has the library deliver its piece of hits.txt straight into the slot
         # (calitas_search_hits_into); hits.txt = rank 0's slot followed by the other slots without their header line.
@@ -536,6 +536,7 @@ def main():
                 tm["hits_bytes"] = text
                 tm["variant_windows"] = nwin
                 phase["search_hits"] += tp1 - tp0
+                phase["free_text"] += ctx.last_free_ms / 1e3   # (inside search_hits: calitas_free of the text block)
                 return tm, tm["accepted_alignments"], total_rows(rows)
             if len(G) > 1 and not (args.no_hits or args.two_stage):
                 # a batch of guides, pipelined through the device stages (calitas_search_hits_batch)

@@ -252,7 +252,9 @@ class Context:
                                                         chrom.encode() if chrom is not None else None, None,
                                                         version.encode() if version else None, time_stamp.encode() if time_stamp else None,
                                                         ctypes.byref(tsv), ctypes.byref(nbytes), ctypes.byref(rows), ctypes.byref(nwin)))
+        t_free = time.perf_counter()
         lib.calitas_free(tsv)
+        self.last_free_ms = (time.perf_counter() - t_free) * 1e3    # (a hits.txt of tens of gigabytes: handing the block back is not free)
         return nbytes.value, rows.value, nwin.value
 
     def scan_candidates(self, guides, params, columnwise=False):

@@ -211,38 +211,50 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
 
     ms_gpu += ms_since(t_sec); t_sec = clk::now();
     // ---- host: enumeration order per task, conversion, SGA:315-320 ----
-    std::vector<uint32_t> order(n_raw);
-    std::iota(order.begin(), order.end(), 0u);
+    // The records are grouped by task (a counting sort: a record's contig is its task's place in this chunk); the workers then take
+    // consecutive blocks of tasks -- order within the task, conversion, filter -- and their results are joined in block order.
     auto list_of = [&](const RawAln& r) { const bool pam5 = gh[t0 + (int)r.contig].pam5; return pam5 ? (r.dir == 1 ? 0 : 1) : (r.dir == 0 ? 0 : 1); };
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-      const RawAln &a = raw[x], &b = raw[y];
-      if (a.contig != b.contig) return a.contig < b.contig;
-      const int la = list_of(a), lb = list_of(b);
-      if (la != lb) return la < lb;
-      if (a.t_end_guide != b.t_end_guide) return a.t_end_guide < b.t_end_guide;
-      if (a.pad != b.pad) return a.pad < b.pad;               // per-matrix enumeration: Diag, Left, Up
-      return a.pam < b.pam;
-    });
-    std::vector<calitas_aln_t> win;
-    std::vector<int> kept;
-    size_t i = 0;
-    while (i < order.size()) {
-      const uint32_t c = raw[order[i]].contig;
-      size_t j = i;
-      while (j < order.size() && raw[order[j]].contig == c) j++;
-      const int t = t0 + (int)c;
-      const int64_t off = target_offsets ? target_offsets[t] : 0;
-      win.resize(j - i);
-      for (size_t k = i; k < j; k++) {
-        raw_to_aln(raw[order[k]], gh[t], off, off + (int64_t)lens[c], win[k - i]);
-        win[k - i].contig_index = t;       // task index
-        win[k - i].guide_index = t;
-      }
-      window_filter(win.data(), (int)win.size(), task_D[t], task_O[t], kept);
-      for (int k : kept) result.push_back(win[k]);
-      per_task[t] = (uint32_t)kept.size();
-      i = j;
+    std::vector<uint32_t> first((size_t)nt + 1, 0);
+    for (uint32_t i = 0; i < n_raw; i++) first[(size_t)raw[i].contig + 1]++;
+    for (int c = 0; c < nt; c++) first[(size_t)c + 1] += first[(size_t)c];
+    std::vector<uint32_t> order(n_raw);
+    {
+      std::vector<uint32_t> cur(first.begin(), first.end() - 1);
+      for (uint32_t i = 0; i < n_raw; i++) order[cur[raw[i].contig]++] = i;
     }
+    WorkerPool serial(1);
+    WorkerPool* pool = (ctx->pool && n_raw >= 4096) ? ctx->pool : &serial;
+    std::vector<std::vector<calitas_aln_t>> part((size_t)pool->size());
+    pool->for_blocks((size_t)nt, [&](size_t cb, size_t ce, int tid) {
+      std::vector<calitas_aln_t> win;
+      std::vector<int> kept;
+      auto& mine = part[(size_t)tid];
+      for (size_t c = cb; c < ce; c++) {
+        const uint32_t i = first[c], j = first[c + 1];
+        if (i == j) continue;
+        std::sort(order.begin() + i, order.begin() + j, [&](uint32_t x, uint32_t y) {
+          const RawAln &a = raw[x], &b = raw[y];
+          const int la = list_of(a), lb = list_of(b);
+          if (la != lb) return la < lb;
+          if (a.t_end_guide != b.t_end_guide) return a.t_end_guide < b.t_end_guide;
+          if (a.pad != b.pad) return a.pad < b.pad;               // per-matrix enumeration: Diag, Left, Up
+          if (a.pam != b.pam) return a.pam < b.pam;
+          return x < y;
+        });
+        const int t = t0 + (int)c;
+        const int64_t off = target_offsets ? target_offsets[t] : 0;
+        win.resize(j - i);
+        for (uint32_t k = i; k < j; k++) {
+          raw_to_aln(raw[order[k]], gh[t], off, off + (int64_t)lens[c], win[k - i]);
+          win[k - i].contig_index = t;       // task index
+          win[k - i].guide_index = t;
+        }
+        window_filter(win.data(), (int)win.size(), task_D[t], task_O[t], kept);
+        for (int k : kept) mine.push_back(win[k]);
+        per_task[t] = (uint32_t)kept.size();
+      }
+    });
+    for (auto& v : part) result.insert(result.end(), v.begin(), v.end());
     t0 = t1;
     ms_post += ms_since(t_sec);
   }

@@ -39,7 +39,21 @@ constexpr uint64_t kPoolBytes = 24ull << 30;   // ... of ~180 MB each at hg38 si
 
 void release_block(BlockHeader* h) {
   h->magic = 0;
-  if (h->pinned) (void)hipHostFree(h); else std::free(h);
+  if (h->pinned) { (void)hipHostFree(h); return; }
+  // A text of tens of gigabytes: the kernel clears pages as it takes them back (16 GB: 0.77 s inside free() on the GPU boxes, huge
+  // pages or not).  MADV_DONTNEED takes the address-space lock shared, so the workers hand the pages back side by side first
+  // (0.135 s, tools/thp_bench.cpp) and free() then unmaps an empty range.
+  const uint64_t cap = h->capacity;
+  if (cap >= (1ull << 30)) {
+    const uintptr_t lo = ((uintptr_t)h + 2 * 4096) & ~(uintptr_t)4095, hi = ((uintptr_t)h + sizeof(BlockHeader) + cap) & ~(uintptr_t)4095;
+    const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t per = (((hi - lo) / (size_t)T) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([=] { const uintptr_t a = lo + per * (size_t)t, b = std::min<uintptr_t>(hi, a + per); if (a < b) (void)madvise((void*)a, b - a, MADV_DONTNEED); });
+    for (auto& x : th) x.join();
+  }
+  std::free(h);
 }
 
 // pinned: page-locked memory (hipHostMalloc) -- the destination of the text copy-back, so that the copy is one DMA at

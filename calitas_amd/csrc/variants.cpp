@@ -42,12 +42,16 @@ struct Allele {                            // VariantAllele SR:105-110
 
 struct CigarEl { char op; int n; };
 
-struct Window {                            // VariantWindow SR:118-157
+// VariantWindow SR:118-157.  A view: alleles, cigar and bases live in the arena of the worker that built the window (three million
+// windows with three small heap blocks each cost more to allocate and free than to align).
+struct Window {
   int contig = 0, start = 0;               // start: 1-based reference position of the first base
-  std::vector<Allele> variants;
-  std::vector<CigarEl> cigar;
-  std::string bases;
+  const Allele* variants = nullptr; int nv = 0;
+  const CigarEl* cigar = nullptr; int nc = 0;
+  const char* bases = nullptr; int len = 0;
 };
+struct Arena { std::vector<char> bases; std::vector<Allele> alleles; std::vector<CigarEl> cigars; };
+struct ArenaMark { size_t bases, alleles, cigars; };   // where a window's pieces start in its arena (pointers are set once the arena is complete)
 
 std::vector<std::string> split(const std::string& s, char sep) {
   std::vector<std::string> out;
@@ -174,43 +178,50 @@ void upper_span(const PackedRef& ref, int contig, long s, long e, std::string& o
   }
 }
 
-// buildVariantWindow SR:263-323
-std::string build_window(const Var* const* variants, const int* alleles, size_t nv, int contig, const PackedRef& ref, int padding, Window& w) {
+// buildVariantWindow SR:263-323.  The window's pieces are appended to A (w gets the counts, `mark` where they start); tmp / ctmp are scratch.
+std::string build_window(const Var* const* variants, const int* alleles, size_t nv, int contig, const PackedRef& ref, int padding, Arena& A,
+                         std::string& tmp, std::vector<CigarEl>& ctmp, Window& w, ArenaMark& mark) {
   const int window_start = std::max(1, variants[0]->pos - padding);
   const int window_end = std::min((int)ref.contigs[contig].len, variants[nv - 1]->end + padding);
   w.contig = contig; w.start = window_start;
-  upper_span(ref, contig, window_start - 1, std::max(window_start - 1, window_end), w.bases);
-  w.variants.clear(); w.cigar.clear();
+  mark = ArenaMark{A.bases.size(), A.alleles.size(), A.cigars.size()};
+  upper_span(ref, contig, window_start - 1, std::max(window_start - 1, window_end), tmp);
   for (size_t i = 0; i < nv; i++) {
     const Var* v = variants[i];
     const int a = alleles[i] - 1;
-    w.variants.push_back(Allele{v, a, (size_t)a < v->afs.size() ? v->afs[a] : 0.0f});
+    A.alleles.push_back(Allele{v, a, (size_t)a < v->afs.size() ? v->afs[a] : 0.0f});
   }
-  for (size_t k = w.variants.size(); k-- > 0;) {     // right to left, so earlier offsets stay valid
-    const Allele& al = w.variants[k];
+  const Allele* const wv = A.alleles.data() + mark.alleles;
+  w.nv = (int)nv;
+  for (size_t k = nv; k-- > 0;) {                     // right to left, so earlier offsets stay valid
+    const Allele& al = wv[k];
     const int i = al.v->pos - window_start;
-    if (i < 0 || (size_t)i > w.bases.size()) return "variant outside its window";
-    w.bases.replace((size_t)i, std::min(al.v->ref.size(), w.bases.size() - (size_t)i), al.v->alts[al.alt]);
+    if (i < 0 || (size_t)i > tmp.size()) return "variant outside its window";
+    tmp.replace((size_t)i, std::min(al.v->ref.size(), tmp.size() - (size_t)i), al.v->alts[al.alt]);
   }
-  std::vector<CigarEl> cigar;
+  ctmp.clear();
   int ref_pos = window_start, base_off = 0;
-  for (const Allele& al : w.variants) {
+  for (size_t k = 0; k < nv; k++) {
+    const Allele& al = wv[k];
     const int pm = al.v->pos - ref_pos;
-    if (pm > 0) { cigar.push_back({'M', pm}); ref_pos += pm; base_off += pm; }
+    if (pm > 0) { ctmp.push_back({'M', pm}); ref_pos += pm; base_off += pm; }
     const int rl = (int)al.v->ref.size(), alen = (int)al.v->alts[al.alt].size();
-    if (rl == alen) cigar.push_back({'M', rl});
-    else if (rl == 1 && alen > 1) { cigar.push_back({'M', 1}); cigar.push_back({'I', alen - 1}); }
-    else if (rl > 1 && alen == 1) { cigar.push_back({'M', 1}); cigar.push_back({'D', rl - 1}); }
-    else { cigar.push_back({'D', rl}); cigar.push_back({'I', alen}); }
+    if (rl == alen) ctmp.push_back({'M', rl});
+    else if (rl == 1 && alen > 1) { ctmp.push_back({'M', 1}); ctmp.push_back({'I', alen - 1}); }
+    else if (rl > 1 && alen == 1) { ctmp.push_back({'M', 1}); ctmp.push_back({'D', rl - 1}); }
+    else { ctmp.push_back({'D', rl}); ctmp.push_back({'I', alen}); }
     ref_pos += rl; base_off += alen;
   }
-  cigar.push_back({'M', (int)w.bases.size() - base_off});
-  for (const CigarEl& e : cigar) {                    // Cigar.coalesce
-    if (!w.cigar.empty() && w.cigar.back().op == e.op) w.cigar.back().n += e.n; else w.cigar.push_back(e);
+  ctmp.push_back({'M', (int)tmp.size() - base_off});
+  for (const CigarEl& e : ctmp) {                      // Cigar.coalesce
+    if (A.cigars.size() > mark.cigars && A.cigars.back().op == e.op) A.cigars.back().n += e.n; else A.cigars.push_back(e);
   }
+  w.nc = (int)(A.cigars.size() - mark.cigars);
   long on_query = 0;
-  for (const CigarEl& e : w.cigar) if (e.op == 'M' || e.op == 'I') on_query += e.n;
-  if (on_query != (long)w.bases.size()) return "requirement failed: cigar length on query != bases";
+  for (size_t k = mark.cigars; k < A.cigars.size(); k++) if (A.cigars[k].op == 'M' || A.cigars[k].op == 'I') on_query += A.cigars[k].n;
+  if (on_query != (long)tmp.size()) return "requirement failed: cigar length on query != bases";
+  A.bases.insert(A.bases.end(), tmp.begin(), tmp.end());
+  w.len = (int)tmp.size();
   return "";
 }
 
@@ -218,16 +229,16 @@ std::string build_window(const Var* const* variants, const int* alleles, size_t 
 bool ref_offset_at(const Window& w, int offset, bool preceding, int& out) {
   auto on_q = [](const CigarEl& e) { return (e.op == 'M' || e.op == 'I') ? e.n : 0; };
   auto on_t = [](const CigarEl& e) { return (e.op == 'M' || e.op == 'D') ? e.n : 0; };
-  if (offset == (int)w.bases.size()) {
+  if (offset == w.len) {
     int t = 0;
-    for (const CigarEl& e : w.cigar) t += on_t(e);
+    for (int k = 0; k < w.nc; k++) t += on_t(w.cigar[k]);
     out = w.start - 1 + t;
     return true;
   }
   int ref_off = w.start - 1, base_off = 0;
-  size_t k = 0;
-  while (k < w.cigar.size() && offset >= base_off + on_q(w.cigar[k])) { ref_off += on_t(w.cigar[k]); base_off += on_q(w.cigar[k]); k++; }
-  if (k >= w.cigar.size()) return false;
+  int k = 0;
+  while (k < w.nc && offset >= base_off + on_q(w.cigar[k])) { ref_off += on_t(w.cigar[k]); base_off += on_q(w.cigar[k]); k++; }
+  if (k >= w.nc) return false;
   const char op = w.cigar[k].op;
   if (op == 'I') { out = preceding ? ref_off - 1 : ref_off; return true; }
   if (op == 'M') { out = ref_off + (offset - base_off); return true; }
@@ -402,10 +413,13 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // variant_description -- on the worker pool, and its row only if it is kept (make_row, called back from the row stage of hits_tsv).
   struct ExtHit { const Window* w; const calitas_aln_t* a; int gstart, tlen; std::string desc; };
   std::vector<ExtHit> hits;
-  std::deque<std::vector<Window>> kept_windows;                                                      // the windows and alignment records behind the hits
+  struct Batch { std::vector<Window> wins; std::vector<Arena> arenas; };
+  std::deque<Batch> kept_windows;                                                                    // the windows and alignment records behind the hits
   std::vector<calitas_aln_t*> kept_out;
   const size_t kBatch = 65536;
-  std::vector<Window> batch(kBatch + 1);
+  Batch batch;
+  batch.wins.resize(kBatch + 1);
+  batch.arenas.resize((size_t)ctx->pool->size());
   size_t nb = 0;
   uint64_t windows_total = 0;
   std::string err;
@@ -429,11 +443,11 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   auto make_row = [&](const ExtHit& h, std::string& row) {
         const Window& w = *h.w;
         const calitas_aln_t& a = *h.a;
-        const int wl = (int)w.bases.size();
+        const int wl = w.len;
         const int gs = a.guide_start_offset, ge = a.guide_end_offset, as = a.start_offset, ae = a.end_offset;   // window-local
         int start = 0, end = 0, gstart = 0, gend = 0;
         (void)lift(w, a, start, end, gstart, gend);                                                 // (succeeded when the hit was keyed)
-        auto flank = [&](int from, int to, bool have) { return have ? w.bases.substr((size_t)from, (size_t)(to - from)) : std::string(); };
+        auto flank = [&](int from, int to, bool have) { return have ? std::string(w.bases + from, (size_t)(to - from)) : std::string(); };
         const bool minus = a.strand == '-';
         const bool h_l10 = gs >= 10, h_r10 = wl - ge >= 10, h_l8 = as >= 8, h_r8 = wl - ae >= 8;
         std::string l10 = flank(gs - 10, gs, h_l10), r10 = flank(ge, ge + 10, h_r10), l8 = flank(as - 8, as, h_l8), r8 = flank(ae, ae + 8, h_r8);
@@ -454,7 +468,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         const std::string c3_8 = v_r8 ? r8 : (!minus ? eight_right() : eight_left());
         // padded strings from the window's own bases (SGA:511; '-' strand: revcomp of the window span)
         const std::string& q = rs.query[a.pam_index + 1];
-        std::string t = w.bases.substr((size_t)as, (size_t)(ae - as));
+        std::string t(w.bases + as, (size_t)(ae - as));
         if (minus) t = revcomp(t);
         const int n_ops = a.n_ops;
         char pg[CALITAS_MAX_OPS + 1], pa[CALITAS_MAX_OPS + 1], pt[CALITAS_MAX_OPS + 1];
@@ -474,7 +488,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target += pt[i];
         // variants under the hit (RH:211) and their columns (RH:211-233)
         std::vector<const Allele*> vs;
-        for (const Allele& al : w.variants) if (start <= al.v->pos - 1 && al.v->pos - 1 <= end) vs.push_back(&al);
+        for (int k = 0; k < w.nv; k++) { const Allele& al = w.variants[k]; if (start <= al.v->pos - 1 && al.v->pos - 1 <= end) vs.push_back(&al); }
         std::string ids, descs, af;
         if (!vs.empty()) {
           const Allele* mn = vs[0];
@@ -506,7 +520,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     std::vector<const uint8_t*> targets(n);
     std::vector<uint32_t> lens(n);
     std::vector<int32_t> offs(n, 0);
-    for (size_t i = 0; i < n; i++) { targets[i] = reinterpret_cast<const uint8_t*>(batch[i].bases.data()); lens[i] = (uint32_t)batch[i].bases.size(); }
+    for (size_t i = 0; i < n; i++) { targets[i] = reinterpret_cast<const uint8_t*>(batch.wins[i].bases); lens[i] = (uint32_t)batch.wins[i].len; }
     calitas_aln_t* out = nullptr;
     uint64_t n_out = 0;
     uint32_t* counts = nullptr;
@@ -516,9 +530,11 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     ms_align += ms_since(t0);
     const auto t1 = std::chrono::steady_clock::now();
     // the batch's windows and records stay until the rows are written; a fresh batch for the producer
-    kept_windows.emplace_back(std::move(batch));
-    batch.assign(kBatch + 1, Window());
-    const std::vector<Window>& wins = kept_windows.back();
+    kept_windows.emplace_back(std::move(batch));                  // (vectors move: the views keep pointing into the arenas)
+    batch = Batch();
+    batch.wins.resize(kBatch + 1);
+    batch.arenas.resize((size_t)ctx->pool->size());
+    const std::vector<Window>& wins = kept_windows.back().wins;
     kept_out.push_back(out);
     std::vector<uint64_t> first(n + 1, 0);
     for (size_t t = 0; t < n; t++) first[t + 1] = first[t] + counts[t];
@@ -538,7 +554,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
           for (int i = 0; i < a.n_ops; i++) if (a.ops[i] != 'I') h.tlen++;
           // variants under the hit (RH:211): their display strings are the hit's removeOverlaps group (SR:656)
           bool any = false;
-          for (const Allele& al : w.variants) if (start <= al.v->pos - 1 && al.v->pos - 1 <= end) { if (any) h.desc += ';'; h.desc += display_string(al); any = true; }
+          for (int q = 0; q < w.nv; q++) { const Allele& al = w.variants[q]; if (start <= al.v->pos - 1 && al.v->pos - 1 <= end) { if (any) h.desc += ';'; h.desc += display_string(al); any = true; } }
         }
       }
     });
@@ -559,9 +575,18 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     if (nb == 0) return CALITAS_OK;
     std::vector<std::string> errs((size_t)ctx->pool->size());
     ctx->pool->for_blocks(nb, [&](size_t b, size_t e, int tid) {
+      Arena& A = batch.arenas[(size_t)tid];
+      std::string tmp;
+      std::vector<CigarEl> ctmp;
+      std::vector<ArenaMark> marks(e - b);
+      A.bases.reserve((e - b) * (size_t)(2 * padding + 8));
       for (size_t k = b; k < e && errs[(size_t)tid].empty(); k++)
         errs[(size_t)tid] = build_window(spec_v.data() + spec_off[k], spec_a.data() + spec_off[k], spec_off[k + 1] - spec_off[k], spec_contig[k], ref,
-                                         padding, batch[k]);
+                                         padding, A, tmp, ctmp, batch.wins[k], marks[k - b]);
+      for (size_t k = b; k < e; k++) {                           // the arena is complete: the views get their pointers
+        Window& w = batch.wins[k];
+        w.bases = A.bases.data() + marks[k - b].bases; w.variants = A.alleles.data() + marks[k - b].alleles; w.cigar = A.cigars.data() + marks[k - b].cigars;
+      }
     });
     for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
     spec_off.assign(1, 0u); spec_v.clear(); spec_a.clear(); spec_contig.clear();
@@ -613,6 +638,18 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     return rc != CALITAS_OK ? rc : calitas_fail(ctx, CALITAS_EINVAL, err);
   }
 
+  // What the variant half built is millions of small heap blocks (descriptions, VCF records, arenas): handed back by all workers, not
+  // by the one thread that happens to leave the function.
+  auto teardown = [&] {
+    const auto t0 = std::chrono::steady_clock::now();
+    ctx->pool->for_blocks(hits.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) std::string().swap(hits[k].desc); });
+    ctx->pool->for_blocks(vcf.size(), [&](size_t b, size_t e, int) {
+      for (size_t k = b; k < e; k++) { Var& v = vcf[k]; std::string().swap(v.chrom); std::string().swap(v.id); std::string().swap(v.ref); std::vector<std::string>().swap(v.alts); std::vector<float>().swap(v.afs); }
+    });
+    ctx->pool->for_blocks(kept_windows.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) kept_windows[k] = Batch(); });
+    ctx->pool->for_blocks(kept_out.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) { calitas_free(kept_out[k]); kept_out[k] = nullptr; } });
+    if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: teardown %.1f ms\n", ms_since(t0));
+  };
   // ---- the reference windows (SR:527-561) and the merge (SR:641-648) ------------------------------------------------------------
   // On the device: the reference's own hits never leave it.  A hit of a variant window that touches no variant joins the removeOverlaps
   // group of the reference hits of its chromosome and strand (SR:656) -- most of them repeat a reference hit and lose against it there,
@@ -664,43 +701,69 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         }
       });
     }
-    // the entries' rows and keys
+    const double ms_groups = ms_since(t_dev);
+    double ms_make = 0;
+    // the entries' rows and keys.  Every worker writes the rows of a consecutive block of entries into one buffer of its own; the
+    // contigs' blobs are then filled from those (a row is copied once; nothing is allocated per row).
     std::vector<std::vector<HitsExtKey>> keys(nc);
     std::vector<std::vector<uint64_t>> row_off(nc);
-    std::vector<std::string> blobs(nc);
+    struct Blob { char* p = nullptr; ~Blob() { std::free(p); } };
+    std::vector<Blob> blobs(nc);
     std::vector<HitsExt> ext_by_contig(nc);
     {
       std::vector<size_t> first(nc + 1, 0);
       for (size_t c = 0; c < nc; c++) first[c + 1] = first[c] + order[c].size();
-      std::vector<std::string> rows(first[nc]);
-      ctx->pool->for_blocks(first[nc], [&](size_t b, size_t e, int) {
+      const size_t n_all = first[nc];
+      std::vector<uint32_t> row_len(n_all);
+      const size_t T = (size_t)ctx->pool->size();
+      std::vector<std::string> local(T);
+      std::vector<std::pair<size_t, size_t>> local_range(T, {0, 0});
+      ctx->pool->for_blocks(n_all, [&](size_t b, size_t e, int tid) {
         size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
+        std::string& buf = local[(size_t)tid];
+        buf.reserve((e - b) * 640);
+        std::string row;
+        local_range[(size_t)tid] = {b, e};
         for (size_t i = b; i < e; i++) {
           while (i >= first[c + 1]) c++;
-          make_row(hits[order[c][i - first[c]]], rows[i]);
-          rows[i] += '\n';
+          make_row(hits[order[c][i - first[c]]], row);
+          row += '\n';
+          row_len[i] = (uint32_t)row.size();
+          buf += row;
         }
       });
-      for (size_t c = 0; c < nc; c++) {
-        const size_t n = order[c].size();
-        keys[c].resize(n); row_off[c].assign(n + 1, 0);
-        for (size_t i = 0; i < n; i++) {
-          const ExtHit& h = hits[order[c][i]];
-          keys[c][i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (placed[c][i] ? HITS_EXT_PLACED : 0u)};
-          row_off[c][i + 1] = row_off[c][i] + rows[first[c] + i].size();
+      ms_make = ms_since(t_dev) - ms_groups;
+      ctx->pool->for_blocks(nc, [&](size_t cb, size_t ce, int) {
+        for (size_t c = cb; c < ce; c++) {
+          const size_t n = order[c].size();
+          keys[c].resize(n); row_off[c].resize(n + 1);
+          row_off[c][0] = 0;
+          for (size_t i = 0; i < n; i++) {
+            const ExtHit& h = hits[order[c][i]];
+            keys[c][i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (placed[c][i] ? HITS_EXT_PLACED : 0u)};
+            row_off[c][i + 1] = row_off[c][i] + row_len[first[c] + i];
+          }
+          blobs[c].p = (char*)std::malloc(std::max<size_t>(1, (size_t)row_off[c][n]));
         }
-        blobs[c].resize((size_t)row_off[c][n]);
-      }
-      ctx->pool->for_blocks(first[nc], [&](size_t b, size_t e, int) {
-        size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
-        for (size_t i = b; i < e; i++) {
-          while (i >= first[c + 1]) c++;
-          std::memcpy(&blobs[c][(size_t)row_off[c][i - first[c]]], rows[i].data(), rows[i].size());
+      });
+      for (size_t c = 0; c < nc; c++) if (!blobs[c].p) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
+      ctx->pool->run([&](int tid) {                                 // a worker's buffer holds entries [b, e): one piece per contig they touch
+        const size_t b = local_range[(size_t)tid].first, e = local_range[(size_t)tid].second;
+        const char* src = local[(size_t)tid].data();
+        size_t i = b;
+        while (i < e) {
+          const size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), i) - first.begin()) - 1;
+          const size_t j = std::min(e, first[c + 1]);
+          const size_t bytes = (size_t)(row_off[c][j - first[c]] - row_off[c][i - first[c]]);
+          std::memcpy(blobs[c].p + row_off[c][i - first[c]], src, bytes);
+          src += bytes;
+          i = j;
         }
+        std::string().swap(local[(size_t)tid]);
       });
       for (size_t c = 0; c < nc; c++) {
         HitsExt& x = ext_by_contig[c];
-        x.contig = (int32_t)c; x.n = (uint32_t)order[c].size(); x.keys = keys[c].data(); x.row_off = row_off[c].data(); x.rows = blobs[c].data();
+        x.contig = (int32_t)c; x.n = (uint32_t)order[c].size(); x.keys = keys[c].data(); x.row_off = row_off[c].data(); x.rows = blobs[c].p;
       }
     }
     const double ms_ext = ms_since(t_dev);
@@ -709,17 +772,17 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     const auto t_search = std::chrono::steady_clock::now();
     rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), ext_by_contig, tsv, &bytes, &nr, &declined);
     if (rc == CALITAS_OK) {
-      for (calitas_aln_t* o : kept_out) calitas_free(o);
+      teardown();
       if (tsv_bytes) *tsv_bytes = bytes;
       if (n_rows) *n_rows = nr;
       if (n_windows) *n_windows = windows_total;
       if (std::getenv("CALITAS_TRACE"))
-        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: align %.1f ms, keys %.1f ms, groups + rows of %zu hits %.1f ms, "
+        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: align %.1f ms, keys %.1f ms, groups %.1f + rows %.1f of %zu hits, with their blobs %.1f ms, "
                              "reference search with them on the device %.1f ms, call %.1f ms\n",
-                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, hits.size(), ms_ext, ms_since(t_search), ms_since(t_call));
+                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_groups, ms_make, hits.size(), ms_ext, ms_since(t_search), ms_since(t_call));
       return CALITAS_OK;
     }
-    if (!declined) { for (calitas_aln_t* o : kept_out) calitas_free(o); return rc; }
+    if (!declined) { teardown(); return rc; }
     if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
   }
   // On the host (a stage the device declines: -O 0, a window beyond the device filter, an overlap cluster beyond one lane's walk):
@@ -727,7 +790,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   {
     const auto t0 = std::chrono::steady_clock::now();
     rc = calitas_search_impl(ctx, 1, guide, params, &ref_alns, &n_ref);
-    if (rc) { for (calitas_aln_t* o : kept_out) calitas_free(o); return rc; }
+    if (rc) { teardown(); return rc; }
     ms_ref = ms_since(t0);
   }
   // the rows of the kept variant-window hits are made on the way out
@@ -754,7 +817,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       if (std::binary_search(keys.begin(), keys.end(), k)) twins++;
       else if (shown++ < 8)
         std::fprintf(stderr, "[calitas] no twin: contig %d start %d len %d strand %c score %d, window start %d len %zu, aln offsets %d..%d\n", h.w->contig, h.gstart, h.tlen,
-                     (char)h.a->strand, h.a->score, h.w->start, h.w->bases.size(), h.a->start_offset, h.a->end_offset);
+                     (char)h.a->strand, h.a->score, h.w->start, (size_t)h.w->len, h.a->start_offset, h.a->end_offset);
     }
     std::fprintf(stderr, "[calitas] variant-window hits: %zu, %llu with a description, %llu without, of those %llu repeat a reference hit\n", hits.size(),
                  (unsigned long long)with_desc, (unsigned long long)plain, (unsigned long long)twins);
@@ -765,7 +828,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   *tsv = hits_tsv(ref, gh, gid, p, ref_alns, n_ref, version, stamp, &nr, ctx->pool, calitas_out_alloc, ext.data(), (uint64_t)ext.size(),
                   [](void* user, uint64_t e, std::string& row) { auto* m = static_cast<RowMaker*>(user); (*m->fn)((*m->hits)[(size_t)e], row); }, &maker);
   calitas_free(ref_alns);
-  for (calitas_aln_t* o : kept_out) calitas_free(o);
+  teardown();
   if (!*tsv) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
   if (tsv_bytes) *tsv_bytes = std::strlen(*tsv);
   if (n_rows) *n_rows = nr;
