@@ -22,11 +22,21 @@ namespace {
 struct TempDevice {
   uint32_t* codes = nullptr; uint32_t* mask = nullptr; Run* runs = nullptr; ContigInfo* contigs = nullptr; TileInfo* tiles = nullptr;
   uint64_t* win_base = nullptr; int2* win = nullptr; GuideDev* guides = nullptr;
-  ~TempDevice() {
-    (void)hipFree(codes); (void)hipFree(mask); (void)hipFree(runs); (void)hipFree(contigs); (void)hipFree(tiles);
-    (void)hipFree(win_base); (void)hipFree(win); (void)hipFree(guides);
-  }
 };
+
+// Slot k of the context's scratch (ctx.hpp, AlignScratch) with room for `bytes`, grown with a margin when it is too small.
+template <typename T>
+hipError_t scratch(calitas_ctx* ctx, int k, size_t bytes, T** out) {
+  if (bytes > ctx->aw.cap[k]) {
+    (void)hipFree(ctx->aw.p[k]); ctx->aw.p[k] = nullptr; ctx->aw.cap[k] = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&ctx->aw.p[k], want);
+    if (e != hipSuccess) return e;
+    ctx->aw.cap[k] = want;
+  }
+  *out = static_cast<T*>(ctx->aw.p[k]);
+  return hipSuccess;
+}
 
 }  // namespace
 
@@ -158,14 +168,14 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
     std::iota(wbase.begin(), wbase.end(), 0ull);
     std::vector<int2> wins(nt);
     for (int i = 0; i < nt; i++) wins[i] = make_int2(0, (int)lens[i]);
-    HIP_TRY(ctx, hipMalloc((void**)&td.codes, ref.codes.size() * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&td.mask, ref.mask.size() * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&td.runs, nruns * sizeof(Run)));
-    HIP_TRY(ctx, hipMalloc((void**)&td.contigs, ref.contigs.size() * sizeof(ContigInfo)));
-    HIP_TRY(ctx, hipMalloc((void**)&td.tiles, ref.tiles.size() * sizeof(TileInfo)));
-    HIP_TRY(ctx, hipMalloc((void**)&td.win_base, wbase.size() * sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMalloc((void**)&td.win, std::max<size_t>(1, wins.size()) * sizeof(int2)));
-    HIP_TRY(ctx, hipMalloc((void**)&td.guides, sizeof(GuideDev) * ns));
+    HIP_TRY(ctx, scratch(ctx, 0, ref.codes.size() * 4, &td.codes));
+    HIP_TRY(ctx, scratch(ctx, 1, ref.mask.size() * 4, &td.mask));
+    HIP_TRY(ctx, scratch(ctx, 2, nruns * sizeof(Run), &td.runs));
+    HIP_TRY(ctx, scratch(ctx, 3, ref.contigs.size() * sizeof(ContigInfo), &td.contigs));
+    HIP_TRY(ctx, scratch(ctx, 4, ref.tiles.size() * sizeof(TileInfo), &td.tiles));
+    HIP_TRY(ctx, scratch(ctx, 5, wbase.size() * sizeof(uint64_t), &td.win_base));
+    HIP_TRY(ctx, scratch(ctx, 6, std::max<size_t>(1, wins.size()) * sizeof(int2), &td.win));
+    HIP_TRY(ctx, scratch(ctx, 7, sizeof(GuideDev) * ns, &td.guides));
     HIP_TRY(ctx, hipMemcpyAsync(td.codes, ref.codes.data(), ref.codes.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(td.mask, ref.mask.data(), ref.mask.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ref.runs.empty()) HIP_TRY(ctx, hipMemcpyAsync(td.runs, ref.runs.data(), ref.runs.size() * sizeof(Run), hipMemcpyHostToDevice, ctx->stream));
@@ -223,7 +233,8 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       for (uint32_t i = 0; i < n_raw; i++) order[cur[raw[i].contig]++] = i;
     }
     WorkerPool serial(1);
-    WorkerPool* pool = (ctx->pool && n_raw >= 4096) ? ctx->pool : &serial;
+    WorkerPool* const owners = (ctx->parent ? ctx->parent : ctx)->pool;   // (a child context works on its parent's pool)
+    WorkerPool* pool = (owners && n_raw >= 4096) ? owners : &serial;
     std::vector<std::vector<calitas_aln_t>> part((size_t)pool->size());
     pool->for_blocks((size_t)nt, [&](size_t cb, size_t ce, int tid) {
       std::vector<calitas_aln_t> win;

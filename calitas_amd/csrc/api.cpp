@@ -205,6 +205,8 @@ void calitas_destroy(calitas_ctx* c) {
     (void)hipFree(c->d_guides); (void)hipFree(c->d_recs); (void)hipFree(c->d_raw); (void)hipFree(c->d_counters);
     (void)hipFree(c->d_slab); (void)hipFree(c->d_items);
     calitas_destroy_lanes(c);
+    if (c->side) { calitas_destroy(c->side); c->side = nullptr; }
+    for (void* q : c->aw.p) (void)hipFree(q);
     select_destroy(c->select);
     hits_destroy(c->hits);
     hits_destroy(c->hits_alt);

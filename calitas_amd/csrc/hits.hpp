@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,10 @@ struct HitsExt {
   const char* rows = nullptr;
   uint32_t* kept = nullptr;            // out (optional): how many of the entries were kept
 };
+
+// Where a per-contig pass gets its HitsExt from: get(contig, &ext) is called right before the contig's row stage and may block until the
+// caller has finished the contig's entries (*ext = nullptr: none).  A return value != 0 means the caller gave up: the search stops.
+struct HitsExtSource { std::function<int(int contig, const HitsExt** ext)> get; };
 
 // d_final[0..n): accepted alignments of ONE guide in calitas_search order (device memory).  Stream-ordered except for one
 // synchronisation to learn the text size.  max_ops bounds the padded columns of any alignment of this search (it sizes the

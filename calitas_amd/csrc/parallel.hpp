@@ -30,8 +30,11 @@ class WorkerPool {
   int size() const { return n_; }
 
   // Runs fn(tid) on every worker (tid 0 is the calling thread) and waits for all of them.
+  // (Callers on different threads take turns: the variant branch builds windows and rows while the reference passes of the same
+  // call copy their text, variants.cpp.)
   void run(const std::function<void(int)>& fn) {
     if (n_ == 1) { fn(0); return; }
+    std::lock_guard<std::mutex> turn(run_mu_);
     {
       std::lock_guard<std::mutex> lk(m_);
       fn_ = &fn;
@@ -81,7 +84,7 @@ class WorkerPool {
   }
   int n_ = 1;
   std::vector<std::thread> threads_;
-  std::mutex m_;
+  std::mutex m_, run_mu_;
   std::condition_variable cv_, done_cv_;
   const std::function<void(int)>* fn_ = nullptr;
   unsigned long gen_ = 0;

@@ -888,7 +888,7 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
 // the constants are in place while the scan runs instead of sitting between the end of the scan and align_kernel.
 static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, const std::string& guide_id,
                      const std::string& version, const std::string& stamp, LaneText& lt, bool hits_prepared = false, const LaneDest* dest = nullptr,
-                     const HitsExt* ext = nullptr) {
+                     const HitsExtSource* ext_source = nullptr, int ext_contig = 0) {
   calitas_ctx* own = ref_owner(lane);
   const PackedRef& ref = own->ref;
   const calitas_params_t& p = pl.p;
@@ -912,6 +912,8 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched, resume);
   if (rc) return rc;
   lt.tm = lane->timing;
+  const HitsExt* ext = nullptr;             // the caller's own hits of this contig: asked for now, the search kernels of the pass are behind us
+  if (ext_source && ext_source->get(ext_contig, &ext) != 0) { calitas_free(alns); return kExtDeclined; }
   if (ext && !dev.valid && n_alns == 0) {   // nothing of the reference's own on this contig: the row stage still places the caller's hits
     dev.valid = true; dev.d_final = nullptr; dev.n_sel = 0; dev.crowded = true;
   }
@@ -944,7 +946,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       }
       if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
     }
-    if (ext) return kExtDeclined;
+    if (ext) return kExtDeclined;       // (a contig without hits of the caller's needs no merge: any tail writes its text)
   }
   // host tail: the same stages as calitas_hits_tsv (one lane at a time: they share the owner's worker pool)
   std::lock_guard<std::mutex> host_lock(own->host_mu);
@@ -1155,6 +1157,27 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
   return CALITAS_OK;
 }
 
+// ctx->side: a child context with a stream and buffers of its own, the parent's reference and worker pool (see ctx.hpp).
+int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side) {
+  *side = nullptr;
+  if (ctx->device < 0) return fail(ctx, CALITAS_ENODEV, "host-only context");
+  if (!ctx->side) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    calitas_ctx* c = new calitas_ctx();
+    c->device = ctx->device; c->parent = ctx;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 8; i++) ok = ok && hipEventCreateWithFlags(&c->ev[i], i < 6 ? hipEventReleaseToDevice : hipEventDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_guides, sizeof(GuideDev) * MAX_GUIDES, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); calitas_destroy(c); return fail(ctx, CALITAS_EHIP, "could not create the side context"); }
+    ctx->side = c;
+  }
+  *side = ctx->side;
+  return CALITAS_OK;
+}
+
 void calitas_destroy_lanes(calitas_ctx* ctx) {
   delete ctx->lane_threads; ctx->lane_threads = nullptr;
   for (calitas_ctx* c : ctx->lanes) calitas_destroy(c);
@@ -1209,7 +1232,7 @@ static void release_scratch(calitas_ctx* ctx) {
 // collected: no text block at all, *tsv stays NULL.
 static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                   const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
-                                  calitas_text_sink_t sink = nullptr, void* sink_user = nullptr, const std::vector<HitsExt>* ext_by_contig = nullptr) {
+                                  calitas_text_sink_t sink = nullptr, void* sink_user = nullptr, const HitsExtSource* ext_source = nullptr) {
   const auto t_call = std::chrono::steady_clock::now();
   SearchPlan pl;
   int rc = plan_search(ctx, 1, guide, params, pl);
@@ -1296,9 +1319,8 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       ctx->hits = work[i & 1]; ctx->hits_names_serial = serial[i & 1];
       sl.lt = LaneText();
       const auto t_rows = std::chrono::steady_clock::now();
-      const HitsExt* ext = ext_by_contig && (*ext_by_contig)[(size_t)pass_contig[i]].n ? &(*ext_by_contig)[(size_t)pass_contig[i]] : nullptr;
-      passes[i].general_tail = ext != nullptr;
-      sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt, false, nullptr, ext);
+      passes[i].general_tail = ext_source != nullptr;
+      sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt, false, nullptr, ext_source, pass_contig[i]);
       if (sl.rc == CALITAS_OK && hipEventRecord(sl.rows_done, ctx->stream) != hipSuccess) sl.rc = fail(ctx, CALITAS_EHIP, "hipEventRecord failed");
       sl.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count();
       work[i & 1] = ctx->hits; serial[i & 1] = ctx->hits_names_serial;
@@ -1501,13 +1523,12 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
 // contig on the general kernels.  kExtDeclined is returned as CALITAS_ESTATE + *declined: a stage left the device path, the caller
 // merges on the host instead.
 int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
-                                 const char* aligner_version, const char* time_stamp, const std::vector<HitsExt>& ext_by_contig, char** tsv,
+                                 const char* aligner_version, const char* time_stamp, const HitsExtSource& source, char** tsv,
                                  uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined) {
   *declined = false;
   *tsv = nullptr;
-  if (ext_by_contig.size() != ctx->ref.contigs.size()) return fail(ctx, CALITAS_EINVAL, "one HitsExt per contig expected");
   if (!known_not_to_fit(ctx, guide, params, false)) (void)predicted_not_to_fit(ctx, guide, params);   // (sizes the passes' buffers when the search is a dense one)
-  int rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, nullptr, nullptr, &ext_by_contig);
+  int rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, nullptr, nullptr, &source);
   if (rc == kExtDeclined) { *declined = true; *tsv = nullptr; return CALITAS_ESTATE; }
   if (rc == CALITAS_ENOMEM) release_scratch(ctx);
   return rc;

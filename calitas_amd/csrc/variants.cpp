@@ -18,7 +18,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <string>
 #include <vector>
@@ -46,6 +49,7 @@ struct CigarEl { char op; int n; };
 // windows with three small heap blocks each cost more to allocate and free than to align).
 struct Window {
   int contig = 0, start = 0;               // start: 1-based reference position of the first base
+  uint32_t chunk = 0;                      // serial number of the nextChunk() cluster it came from: windows of two chunks share no variant
   const Allele* variants = nullptr; int nv = 0;
   const CigarEl* cigar = nullptr; int nc = 0;
   const char* bases = nullptr; int len = 0;
@@ -104,7 +108,21 @@ bool parse_record(const char* b, const char* e, const char* chrom, size_t chrom_
 // start in its byte range, and the per-worker lists are joined in file order.
 std::string read_vcf(const char* path, const char* chrom, calitas::WorkerPool* pool, std::vector<Var>& out) {
   std::string data;
-  {
+  bool plain = false;
+  if (FILE* f = std::fopen(path, "rb")) {    // a plain file is read in one piece (zlib's transparent mode copies it at ~1 GB/s)
+    unsigned char magic[2] = {0, 0};
+    const size_t got = std::fread(magic, 1, 2, f);
+    if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && std::fseek(f, 0, SEEK_END) == 0) {
+      const long size = std::ftell(f);
+      if (size >= 0 && std::fseek(f, 0, SEEK_SET) == 0) {
+        data.resize((size_t)size);
+        plain = std::fread(&data[0], 1, (size_t)size, f) == (size_t)size;
+        if (!plain) data.clear();
+      }
+    }
+    std::fclose(f);
+  }
+  if (!plain) {
     gzFile f = gzopen(path, "rb");           // transparent for plain text
     if (!f) return std::string("cannot read ") + path;
     gzbuffer(f, 1 << 20);
@@ -374,12 +392,17 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   }
   const std::string gid = guide_id ? guide_id : "";
   std::string vid = vcf_id ? vcf_id : "";
-  if (!vcf_id) {                                                                                   // ReferenceHit.scala:175-183: file name and md5
-    std::string hex, e = md5_file(vcf_path, hex);
-    if (!e.empty()) return calitas_fail(ctx, CALITAS_EIO, e);
-    const char* slash = std::strrchr(vcf_path, '/');
-    vid = std::string(slash ? slash + 1 : vcf_path) + ":" + hex;
-  }
+  std::string md5_err;
+  std::thread md5_thread;                                                                          // ReferenceHit.scala:175-183: file name and md5,
+  if (!vcf_id)                                                                                     // needed when the first row is written
+    md5_thread = std::thread([&] {
+      std::string hex;
+      md5_err = md5_file(vcf_path, hex);
+      const char* slash = std::strrchr(vcf_path, '/');
+      vid = std::string(slash ? slash + 1 : vcf_path) + ":" + hex;
+    });
+  struct JoinMd5 { std::thread& t; ~JoinMd5() { if (t.joinable()) t.join(); } } join_md5{md5_thread};
+  auto need_vid = [&]() -> bool { if (md5_thread.joinable()) md5_thread.join(); return md5_err.empty(); };
   std::string version, stamp;
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const int d = p.max_guide_diffs, g = p.max_gaps_between_guide_and_pam;
@@ -392,6 +415,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   calitas_aln_t* ref_alns = nullptr;                                                               // (host merge only, below)
   uint64_t n_ref = 0;
   int rc = CALITAS_OK;
+  calitas_ctx* actx = ctx;                                                                         // where the variant windows are aligned (below)
 
   std::vector<Var> vcf;
   {
@@ -525,8 +549,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     uint64_t n_out = 0;
     uint32_t* counts = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    int r = calitas_align_windows(ctx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &out, &n_out, &counts);
-    if (r) return r;
+    int r = calitas_align_windows(actx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &out, &n_out, &counts);
+    if (r) { if (actx != ctx) calitas_fail(ctx, r, calitas_last_error(actx)); return r; }
     ms_align += ms_since(t0);
     const auto t1 = std::chrono::steady_clock::now();
     // the batch's windows and records stay until the rows are written; a fresh batch for the producer
@@ -570,6 +594,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   std::vector<uint32_t> spec_off{0};
   std::vector<const Var*> spec_v;
   std::vector<int> spec_a, spec_contig;
+  std::vector<uint32_t> spec_chunk;
+  uint32_t chunk_serial = 0;
   auto build_and_flush = [&]() -> int {
     nb = spec_contig.size();
     if (nb == 0) return CALITAS_OK;
@@ -585,11 +611,12 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
                                          padding, A, tmp, ctmp, batch.wins[k], marks[k - b]);
       for (size_t k = b; k < e; k++) {                           // the arena is complete: the views get their pointers
         Window& w = batch.wins[k];
+        w.chunk = spec_chunk[k];
         w.bases = A.bases.data() + marks[k - b].bases; w.variants = A.alleles.data() + marks[k - b].alleles; w.cigar = A.cigars.data() + marks[k - b].cigars;
       }
     });
     for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
-    spec_off.assign(1, 0u); spec_v.clear(); spec_a.clear(); spec_contig.clear();
+    spec_off.assign(1, 0u); spec_v.clear(); spec_a.clear(); spec_contig.clear(); spec_chunk.clear();
     if (!err.empty()) { nb = 0; return CALITAS_OK; }
     return flush();
   };
@@ -598,9 +625,170 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     spec_a.insert(spec_a.end(), al, al + nv);
     spec_off.push_back((uint32_t)spec_v.size());
     spec_contig.push_back(contig);
+    spec_chunk.push_back(chunk_serial);
     windows_total++;
     return spec_contig.size() >= kBatch ? build_and_flush() : CALITAS_OK;
   };
+  // ---- the reference windows (SR:527-561) and the merge (SR:641-648) on the device, beside the variant windows --------------------
+  // The reference's own hits never leave the device.  A hit of a variant window that touches no variant joins the removeOverlaps
+  // group of the reference hits of its chromosome and strand (SR:656) -- most of them repeat a reference hit and lose against it there,
+  // the ones an edge of their window cut short do not -- so every one of them goes into the device's walk of that group (hits.hpp,
+  // HitsExt), behind the reference hits with the same sort key as SR:622 has them arrive.  The groups of the hits that do touch variants
+  // hold nothing else: they are walked here, and what they keep is handed to the device for its place in ReferenceHit.sort's order only.
+  // The device then writes every surviving row, its own and these, into one text per contig.  Ties between rows of different groups
+  // follow calitas_hits_tsv_ext (the reference leaves them to a hash map): the reference group first, then the variant groups in order
+  // of first appearance.
+  // The two halves run side by side: this thread produces, aligns (on a side context: a stream and buffers of its own) and keys the
+  // variant windows contig by contig -- host work, mostly -- while a helper thread drives the reference's per-contig passes (device work
+  // and the text over PCIe); the row stage of contig c waits until this thread has published the contig's entries.
+  const char* force_host = std::getenv("CALITAS_VARIANTS_HOST");
+  const bool device_merge = !(force_host && std::atoi(force_host) != 0) && p.max_overlap >= 1;
+  if (device_merge) { rc = calitas_side_context(ctx, &actx); if (rc) return rc; }
+  const size_t nc = ref.contigs.size();
+  struct Blob { char* p = nullptr; ~Blob() { std::free(p); } };
+  struct ContigExt { std::vector<HitsExtKey> keys; std::vector<uint64_t> row_off; Blob blob; HitsExt ext; };
+  std::vector<ContigExt> cx(nc);
+  std::mutex pub_mu;
+  std::condition_variable pub_cv;
+  size_t published = 0;                                                                            // contigs [0, published) have their entries
+  bool give_up = false;
+  struct HelperResult { int rc = CALITAS_OK; bool declined = false; char* tsv = nullptr; uint64_t bytes = 0, rows = 0; double ms = 0; } hr;
+  std::thread helper;
+  auto publish = [&](size_t upto, bool quit) {
+    { std::lock_guard<std::mutex> lk(pub_mu); published = std::max(published, upto); give_up = give_up || quit; }
+    pub_cv.notify_all();
+  };
+  HitsExtSource source;
+  struct JoinHelper {                                                                               // (declared behind everything the helper thread uses)
+    std::thread& t; decltype(publish)& pub; size_t all;
+    ~JoinHelper() { if (t.joinable()) { pub(all, true); t.join(); } }
+  } join_helper{helper, publish, nc};
+  source.get = [&](int c, const HitsExt** e) -> int {
+    std::unique_lock<std::mutex> lk(pub_mu);
+    pub_cv.wait(lk, [&] { return published > (size_t)c || give_up; });
+    if (published <= (size_t)c) return 1;
+    *e = cx[(size_t)c].ext.n ? &cx[(size_t)c].ext : nullptr;
+    return 0;
+  };
+  if (device_merge)
+    helper = std::thread([&] {
+      const auto t0 = std::chrono::steady_clock::now();
+      (void)hipSetDevice(ctx->device);
+      hr.rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), source, &hr.tsv, &hr.bytes, &hr.rows, &hr.declined);
+      hr.ms = ms_since(t0);
+    });
+
+  // The entries of contig c -- hits[h0, h1), in arrival order -- for the device: the groups' walks, every entry's row and key.
+  double ms_groups = 0, ms_make = 0, ms_blob = 0;
+  auto finish_contig = [&](size_t c, size_t h0, size_t h1) -> int {
+    if (h1 == h0) return CALITAS_OK;
+    if (h1 - h0 >= 0xFFFFFFF0ull) return calitas_fail(ctx, CALITAS_EINVAL, "more than 2^32 hits of variant windows on one contig");
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t T = (size_t)ctx->pool->size();
+    // blocks of hits cut where the chunk changes: hits of two chunks share no variant, hence no group
+    std::vector<size_t> cut(T + 1, h1);
+    cut[0] = h0;
+    for (size_t t = 1; t < T; t++) {
+      size_t k = std::max(cut[t - 1], h0 + (h1 - h0) * t / T);
+      while (k < h1 && k > h0 && hits[k].w->chunk == hits[k - 1].w->chunk) k++;
+      cut[t] = k;
+    }
+    struct Lite { int start, end, score; uint32_t idx; };
+    std::vector<std::vector<uint32_t>> plain(T), kept(T);
+    ctx->pool->run([&](int tid) {
+      const size_t b = cut[(size_t)tid], e = cut[(size_t)tid + 1];
+      if (b >= e) return;
+      std::unordered_map<std::string, uint32_t> group_of;
+      std::vector<std::vector<Lite>> groups;
+      std::string key;
+      for (size_t k = b; k < e; k++) {
+        const ExtHit& h = hits[k];
+        if (h.desc.empty()) { plain[(size_t)tid].push_back((uint32_t)(k - h0)); continue; }
+        key.assign(1, (char)h.a->strand);
+        key += h.desc;
+        auto it = group_of.find(key);
+        if (it == group_of.end()) { it = group_of.emplace(key, (uint32_t)groups.size()).first; groups.emplace_back(); }
+        groups[it->second].push_back(Lite{h.gstart, h.gstart + h.tlen - 1, h.a->score, (uint32_t)(k - h0)});
+      }
+      for (auto& hs : groups) {                                                                    // removeOverlaps SR:653-675 on one group
+        std::stable_sort(hs.begin(), hs.end(), [](const Lite& x, const Lite& y) { return x.start != y.start ? x.start < y.start : -x.score < -y.score; });
+        auto overlap = [](const Lite& x, const Lite& y) { return std::max(0, std::min(x.end, y.end) - std::max(x.start, y.start)); };   // RH:141-144
+        size_t i = 0;
+        while (i < hs.size()) {
+          const Lite hit = hs[i++];
+          while (i < hs.size() && overlap(hs[i], hit) >= p.max_overlap && hs[i].score <= hit.score) i++;
+          if (i >= hs.size() || overlap(hs[i], hit) < p.max_overlap) kept[(size_t)tid].push_back(hit.idx);
+        }
+      }
+    });
+    std::vector<uint32_t> order;                                                                    // the entries in tie order (as offsets from h0)
+    for (auto& v : plain) order.insert(order.end(), v.begin(), v.end());
+    const size_t n_plain = order.size();
+    for (auto& v : kept) order.insert(order.end(), v.begin(), v.end());
+    const size_t n = order.size();
+    ms_groups += ms_since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (!need_vid()) return calitas_fail(ctx, CALITAS_EIO, md5_err);
+    // rows: every worker writes the rows of a consecutive block of entries into one buffer of its own; the blob is filled from those
+    ContigExt& x = cx[c];
+    std::vector<uint32_t> row_len(n);
+    std::vector<std::string> local(T);
+    std::vector<std::pair<size_t, size_t>> local_range(T, {0, 0});
+    ctx->pool->for_blocks(n, [&](size_t b, size_t e, int tid) {
+      std::string& buf = local[(size_t)tid];
+      buf.reserve((e - b) * 640);
+      std::string row;
+      local_range[(size_t)tid] = {b, e};
+      for (size_t i = b; i < e; i++) {
+        make_row(hits[h0 + order[i]], row);
+        row += '\n';
+        row_len[i] = (uint32_t)row.size();
+        buf += row;
+      }
+    });
+    ms_make += ms_since(t1);
+    const auto t2 = std::chrono::steady_clock::now();
+    x.keys.resize(n); x.row_off.resize(n + 1);
+    x.row_off[0] = 0;
+    for (size_t i = 0; i < n; i++) {
+      const ExtHit& h = hits[h0 + order[i]];
+      x.keys[i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (i >= n_plain ? HITS_EXT_PLACED : 0u)};
+      x.row_off[i + 1] = x.row_off[i] + row_len[i];
+    }
+    x.blob.p = (char*)std::malloc(std::max<size_t>(1, (size_t)x.row_off[n]));
+    if (!x.blob.p) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
+    ctx->pool->run([&](int tid) {
+      const size_t b = local_range[(size_t)tid].first, e = local_range[(size_t)tid].second;
+      if (b < e) std::memcpy(x.blob.p + x.row_off[b], local[(size_t)tid].data(), (size_t)(x.row_off[e] - x.row_off[b]));
+      std::string().swap(local[(size_t)tid]);
+    });
+    x.ext.contig = (int32_t)c; x.ext.n = (uint32_t)n; x.ext.keys = x.keys.data(); x.ext.row_off = x.row_off.data(); x.ext.rows = x.blob.p;
+    ms_blob += ms_since(t2);
+    return CALITAS_OK;
+  };
+  // The contigs before `upto` have all their windows emitted: align what is pending, finish and publish them.
+  size_t contigs_done = 0, hits_done = 0;
+  auto finish_contigs = [&](size_t upto) -> int {
+    if (upto <= contigs_done) return CALITAS_OK;
+    int r = build_and_flush();
+    if (r || !err.empty()) return r;
+    if (device_merge) {
+      // hits[hits_done, ...) lie on contigs [contigs_done, upto), in contig order
+      size_t h = hits_done;
+      for (size_t c = contigs_done; c < upto; c++) {
+        size_t e = h;
+        while (e < hits.size() && (size_t)hits[e].w->contig == c) e++;
+        r = finish_contig(c, h, e);
+        if (r) return r;
+        h = e;
+        publish(c + 1, false);
+      }
+    }
+    hits_done = hits.size();
+    contigs_done = upto;
+    return CALITAS_OK;
+  };
+
   const int max_variants = p.max_variants;
   size_t ci = 0, i = 0;
   while (i < vcf.size() && err.empty() && rc == CALITAS_OK) {
@@ -612,6 +800,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     if (ci >= order.size()) { err = "next on empty iterator (VCF contig " + chunk[0]->chrom + " not in reference order)"; break; }
     int contig = -1;
     for (size_t k = 0; k < ref.names.size(); k++) if (ref.names[k] == order[ci]) { contig = (int)k; break; }
+    chunk_serial++;
+    if ((size_t)contig > contigs_done) { rc = finish_contigs((size_t)contig); if (rc || !err.empty()) break; }   // the contigs before this one are complete
     for (size_t s = 0; s < chunk.size() && err.empty() && rc == CALITAS_OK; s++) {
       std::vector<const Var*> sub;
       for (size_t k = s; k < chunk.size(); k++) { if (chunk[k]->pos - chunk[s]->end > padding) break; sub.push_back(chunk[k]); }
@@ -632,11 +822,14 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       }
     }
   }
-  if (rc == CALITAS_OK && err.empty()) rc = build_and_flush();
+  if (rc == CALITAS_OK && err.empty()) rc = finish_contigs(nc);
   if (rc != CALITAS_OK || !err.empty()) {
-    calitas_free(ref_alns);
+    publish(nc, true);
+    if (helper.joinable()) helper.join();
+    calitas_free(hr.tsv);
     return rc != CALITAS_OK ? rc : calitas_fail(ctx, CALITAS_EINVAL, err);
   }
+  const double ms_variant_half = ms_since(t_call);
 
   // What the variant half built is millions of small heap blocks (descriptions, VCF records, arenas): handed back by all workers, not
   // by the one thread that happens to leave the function.
@@ -650,139 +843,22 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     ctx->pool->for_blocks(kept_out.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) { calitas_free(kept_out[k]); kept_out[k] = nullptr; } });
     if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: teardown %.1f ms\n", ms_since(t0));
   };
-  // ---- the reference windows (SR:527-561) and the merge (SR:641-648) ------------------------------------------------------------
-  // On the device: the reference's own hits never leave it.  A hit of a variant window that touches no variant joins the removeOverlaps
-  // group of the reference hits of its chromosome and strand (SR:656) -- most of them repeat a reference hit and lose against it there,
-  // the ones an edge of their window cut short do not -- so every one of them goes into the device's walk of that group (hits.hpp,
-  // HitsExt), behind the reference hits with the same sort key as SR:622 has them arrive.  The groups of the hits that do touch variants
-  // hold nothing else: they are walked here, and what they keep is handed to the device for its place in ReferenceHit.sort's order only.
-  // The device then writes every surviving row, its own and these, into one text per contig.  Ties between rows of different groups
-  // follow calitas_hits_tsv_ext (the reference leaves them to a hash map): the reference group first, then the variant groups in order
-  // of first appearance.
-  const char* force_host = std::getenv("CALITAS_VARIANTS_HOST");
-  if (!(force_host && std::atoi(force_host) != 0) && p.max_overlap >= 1) {
-    const auto t_dev = std::chrono::steady_clock::now();
-    const size_t nc = ref.contigs.size();
-    struct Lite { int start, end, score; uint32_t idx; };
-    std::vector<std::vector<uint32_t>> by_contig(nc);
-    if (hits.size() >= 0xFFFFFFF0ull) return calitas_fail(ctx, CALITAS_EINVAL, "more than 2^32 hits of variant windows");
-    for (size_t k = 0; k < hits.size(); k++) by_contig[(size_t)hits[k].w->contig].push_back((uint32_t)k);
-    std::vector<std::vector<uint32_t>> order(nc);                                                   // per contig: the entries in tie order
-    std::vector<std::vector<uint8_t>> placed(nc);
-    {
-      std::atomic<size_t> next(0);
-      ctx->pool->run([&](int) {
-        for (;;) {
-          const size_t c = next.fetch_add(1);
-          if (c >= nc) break;
-          std::unordered_map<std::string, uint32_t> group_of;
-          std::vector<std::vector<Lite>> groups;
-          auto& ord = order[c];
-          for (uint32_t k : by_contig[c]) {
-            const ExtHit& h = hits[k];
-            if (h.desc.empty()) { ord.push_back(k); continue; }
-            std::string key(1, (char)h.a->strand);
-            key += h.desc;
-            auto it = group_of.find(key);
-            if (it == group_of.end()) { it = group_of.emplace(std::move(key), (uint32_t)groups.size()).first; groups.emplace_back(); }
-            groups[it->second].push_back(Lite{h.gstart, h.gstart + h.tlen - 1, h.a->score, k});
-          }
-          placed[c].assign(ord.size(), 0);
-          for (auto& hs : groups) {                                                                // removeOverlaps SR:653-675 on one group
-            std::stable_sort(hs.begin(), hs.end(), [](const Lite& x, const Lite& y) { return x.start != y.start ? x.start < y.start : -x.score < -y.score; });
-            auto overlap = [](const Lite& x, const Lite& y) { return std::max(0, std::min(x.end, y.end) - std::max(x.start, y.start)); };   // RH:141-144
-            size_t i = 0;
-            while (i < hs.size()) {
-              const Lite hit = hs[i++];
-              while (i < hs.size() && overlap(hs[i], hit) >= p.max_overlap && hs[i].score <= hit.score) i++;
-              if (i >= hs.size() || overlap(hs[i], hit) < p.max_overlap) { ord.push_back(hit.idx); placed[c].push_back(1); }
-            }
-          }
-        }
-      });
-    }
-    const double ms_groups = ms_since(t_dev);
-    double ms_make = 0;
-    // the entries' rows and keys.  Every worker writes the rows of a consecutive block of entries into one buffer of its own; the
-    // contigs' blobs are then filled from those (a row is copied once; nothing is allocated per row).
-    std::vector<std::vector<HitsExtKey>> keys(nc);
-    std::vector<std::vector<uint64_t>> row_off(nc);
-    struct Blob { char* p = nullptr; ~Blob() { std::free(p); } };
-    std::vector<Blob> blobs(nc);
-    std::vector<HitsExt> ext_by_contig(nc);
-    {
-      std::vector<size_t> first(nc + 1, 0);
-      for (size_t c = 0; c < nc; c++) first[c + 1] = first[c] + order[c].size();
-      const size_t n_all = first[nc];
-      std::vector<uint32_t> row_len(n_all);
-      const size_t T = (size_t)ctx->pool->size();
-      std::vector<std::string> local(T);
-      std::vector<std::pair<size_t, size_t>> local_range(T, {0, 0});
-      ctx->pool->for_blocks(n_all, [&](size_t b, size_t e, int tid) {
-        size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
-        std::string& buf = local[(size_t)tid];
-        buf.reserve((e - b) * 640);
-        std::string row;
-        local_range[(size_t)tid] = {b, e};
-        for (size_t i = b; i < e; i++) {
-          while (i >= first[c + 1]) c++;
-          make_row(hits[order[c][i - first[c]]], row);
-          row += '\n';
-          row_len[i] = (uint32_t)row.size();
-          buf += row;
-        }
-      });
-      ms_make = ms_since(t_dev) - ms_groups;
-      ctx->pool->for_blocks(nc, [&](size_t cb, size_t ce, int) {
-        for (size_t c = cb; c < ce; c++) {
-          const size_t n = order[c].size();
-          keys[c].resize(n); row_off[c].resize(n + 1);
-          row_off[c][0] = 0;
-          for (size_t i = 0; i < n; i++) {
-            const ExtHit& h = hits[order[c][i]];
-            keys[c][i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (placed[c][i] ? HITS_EXT_PLACED : 0u)};
-            row_off[c][i + 1] = row_off[c][i] + row_len[first[c] + i];
-          }
-          blobs[c].p = (char*)std::malloc(std::max<size_t>(1, (size_t)row_off[c][n]));
-        }
-      });
-      for (size_t c = 0; c < nc; c++) if (!blobs[c].p) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
-      ctx->pool->run([&](int tid) {                                 // a worker's buffer holds entries [b, e): one piece per contig they touch
-        const size_t b = local_range[(size_t)tid].first, e = local_range[(size_t)tid].second;
-        const char* src = local[(size_t)tid].data();
-        size_t i = b;
-        while (i < e) {
-          const size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), i) - first.begin()) - 1;
-          const size_t j = std::min(e, first[c + 1]);
-          const size_t bytes = (size_t)(row_off[c][j - first[c]] - row_off[c][i - first[c]]);
-          std::memcpy(blobs[c].p + row_off[c][i - first[c]], src, bytes);
-          src += bytes;
-          i = j;
-        }
-        std::string().swap(local[(size_t)tid]);
-      });
-      for (size_t c = 0; c < nc; c++) {
-        HitsExt& x = ext_by_contig[c];
-        x.contig = (int32_t)c; x.n = (uint32_t)order[c].size(); x.keys = keys[c].data(); x.row_off = row_off[c].data(); x.rows = blobs[c].p;
-      }
-    }
-    const double ms_ext = ms_since(t_dev);
-    bool declined = false;
-    uint64_t bytes = 0, nr = 0;
-    const auto t_search = std::chrono::steady_clock::now();
-    rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), ext_by_contig, tsv, &bytes, &nr, &declined);
-    if (rc == CALITAS_OK) {
+  if (device_merge) {
+    helper.join();
+    if (hr.rc == CALITAS_OK) {
       teardown();
-      if (tsv_bytes) *tsv_bytes = bytes;
-      if (n_rows) *n_rows = nr;
+      *tsv = hr.tsv;
+      if (tsv_bytes) *tsv_bytes = hr.bytes;
+      if (n_rows) *n_rows = hr.rows;
       if (n_windows) *n_windows = windows_total;
       if (std::getenv("CALITAS_TRACE"))
-        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: align %.1f ms, keys %.1f ms, groups %.1f + rows %.1f of %zu hits, with their blobs %.1f ms, "
-                             "reference search with them on the device %.1f ms, call %.1f ms\n",
-                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_groups, ms_make, hits.size(), ms_ext, ms_since(t_search), ms_since(t_call));
+        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: align %.1f ms, keys %.1f ms, groups %.1f + rows %.1f + blobs %.1f ms of %zu hits, "
+                             "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms\n",
+                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_groups, ms_make, ms_blob, hits.size(), ms_variant_half, hr.ms, ms_since(t_call));
       return CALITAS_OK;
     }
-    if (!declined) { teardown(); return rc; }
+    calitas_free(hr.tsv);
+    if (!hr.declined) { teardown(); return hr.rc; }
     if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
   }
   // On the host (a stage the device declines: -O 0, a window beyond the device filter, an overlap cluster beyond one lane's walk):

@@ -20,8 +20,8 @@ _lib = None
 
 
 def build():
-    src = os.path.join(ORACLE_DIR, "calitas_oracle.cpp")
-    if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("calitas_oracle.cpp", "check_hits.cpp")]
+    if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
@@ -35,6 +35,8 @@ def lib():
                      "oracle_variant_window", "oracle_align_to_reference"]:
             getattr(L, name).restype = ctypes.c_void_p
         L.oracle_free.argtypes = [ctypes.c_void_p]
+        L.oracle_check_hits_text.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+        L.oracle_check_hits_text.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -132,6 +134,22 @@ def search_reference_vcf(fasta, vcf, guide, guide_id="a", aux=(), chrom="", **kw
     header = lines[0].split("\t")
     rows = [dict(zip(header, ln.split("\t"))) for ln in lines[1:]]
     return header, rows, nwin.value
+
+
+def check_hits_text(text, names, max_overlap=10, threads=16, nbytes=None):
+    """Properties of a finished hits.txt (oracle/check_hits.cpp): ReferenceHit.sort order (RH:284), consecutive kept hits of a
+    (chromosome, strand, variant_description) group overlapping by less than maxOverlap (SR:653-675, RH:135-144), 34 columns.
+    text: bytes, or an address with nbytes (a text of gigabytes stays where the library put it).  Returns a dict of counts."""
+    out = (ctypes.c_uint64 * 6)()
+    if isinstance(text, (bytes, bytearray)):
+        held = bytes(text)                                     # (stays alive for the call)
+        buf, n = ctypes.cast(ctypes.c_char_p(held), ctypes.c_void_p), len(held)
+    else:
+        buf, n = ctypes.c_void_p(text), nbytes
+    rc = lib().oracle_check_hits_text(buf, n, "\n".join(names).encode(), max_overlap, threads, out)
+    if rc != 0:
+        raise RuntimeError("not a hits.txt (no header line)")
+    return dict(zip(("rows", "rows_with_variant", "out_of_order", "overlapping", "malformed", "threads"), [int(x) for x in out]))
 
 
 def align_to_reference(fasta, input_tsv, limits=None, g=3, D=-1, window_size=0, costs=DEFAULT_COSTS, switches=0):

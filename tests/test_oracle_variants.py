@@ -58,3 +58,41 @@ def test_e4_flanks_for_ref_and_variant_windows(tmp_path):
     assert [r["variant_id"] for r in rows] == ["", "", "insGAGGCGT", "insTCGCCCC"]
     assert rows[2]["genome_build"].endswith("+variants") and not rows[0]["genome_build"].endswith("+variants")
     assert rows[2]["variant_description"] == "insGAGGCGT:238:A>AGAGGCGT:0.000"
+
+
+def test_hits_text_property_checker(tmp_path):
+    """oracle/check_hits.cpp (what the full-size GPU tests hold a 21.8 GB hits.txt against): the oracle's own output of a dense search
+    with a VCF has no row out of ReferenceHit.sort order (RH:284) and no two consecutive kept hits of a group overlapping by maxOverlap
+    or more (SR:653-675); swapped rows, a duplicated row and a cut column are counted; any thread count gives the same answer."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    contigs = [("c1", "".join(rng.choice(list("ACGT"), size=30000))), ("c2", "".join(rng.choice(list("ACGT"), size=9000)))]
+    fa = write_fasta(str(tmp_path / "p.fa"), contigs)
+    variants = []
+    for name, seq in contigs:
+        for pos in range(150, len(seq) - 100, 130):
+            rb = seq[pos - 1]
+            variants.append((name, pos, "rs%d" % len(variants), rb, ["ACGT"[("ACGT".index(rb) + 1) % 4]]))
+    vcf = write_vcf(str(tmp_path / "p.vcf"), variants, [[0.1]] * len(variants))
+    header, rows, _ = O.search_reference_vcf(fa, vcf, "CTTGCCCCACAGGGCAGTAA", "a", d=8, p=0, g=3)
+    assert len(rows) > 300 and sum(1 for r in rows if r["variant_description"]) > 10
+    lines = ["\t".join(r[h] for h in header) for r in rows]
+    text = ("\t".join(header) + "\n" + "\n".join(lines) + "\n").encode()
+    names = [n for n, _ in contigs]
+    for threads in (1, 3, 16):
+        got = O.check_hits_text(text, names, 10, threads)
+        assert got == dict(rows=len(rows), rows_with_variant=sum(1 for r in rows if r["variant_description"]), out_of_order=0, overlapping=0,
+                           malformed=0, threads=threads), threads
+    # planted faults
+    k = next(i for i in range(len(rows) - 1) if rows[i]["coordinate_start"] != rows[i + 1]["coordinate_start"] and rows[i]["chromosome"] == rows[i + 1]["chromosome"])
+    swapped = lines[:k] + [lines[k + 1], lines[k]] + lines[k + 2:]
+    bad = O.check_hits_text(("\t".join(header) + "\n" + "\n".join(swapped) + "\n").encode(), names, 10, 4)
+    assert bad["out_of_order"] >= 1
+    dup = lines[:k + 1] + [lines[k]] + lines[k + 1:]                    # the same hit twice: overlaps itself by its whole length
+    bad = O.check_hits_text(("\t".join(header) + "\n" + "\n".join(dup) + "\n").encode(), names, 10, 4)
+    assert bad["overlapping"] >= 1 and bad["out_of_order"] == 0
+    cutcol = lines[:k] + ["\t".join(lines[k].split("\t")[:-1])] + lines[k + 1:]
+    bad = O.check_hits_text(("\t".join(header) + "\n" + "\n".join(cutcol) + "\n").encode(), names, 10, 4)
+    assert bad["malformed"] == 1
+    bad = O.check_hits_text(text, names[::-1], 10, 4)                    # another dictionary order: the contigs are out of order
+    assert bad["out_of_order"] >= 1
