@@ -1087,6 +1087,20 @@ struct LaneThreads {
   std::function<void(size_t)> job;
   std::atomic<size_t> remaining{0};
   std::atomic<bool> threw{false};                  // a job ended with an exception (std::bad_alloc, ...): the call fails with CALITAS_EHIP
+  std::string what;                                // ... and says which (the first one's text; under m)
+  void note(const char* text) {
+    std::lock_guard<std::mutex> lk(m);
+    if (!threw.load(std::memory_order_relaxed)) what = text ? text : "";
+    threw.store(true, std::memory_order_relaxed);
+  }
+  // Runs fn: an exception must not take the process down (a lane thread has no caller to unwind to), and must not be lost either.
+  template <typename F>
+  void guarded(F&& fn) {
+    try { fn(); }
+    catch (const std::exception& e) { note(e.what()); }
+    catch (...) { note("an exception that is not a std::exception"); }
+  }
+  std::string failure() { std::lock_guard<std::mutex> lk(m); return "a lane of the search ended with an exception: " + (what.empty() ? std::string("(no text)") : what); }
   ~LaneThreads() {
     { std::lock_guard<std::mutex> lk(m); stop = true; gen++; }
     cv.notify_all();
@@ -1105,7 +1119,7 @@ struct LaneThreads {
             if (stop) return;
             if (i >= k) continue;
           }
-          try { job(i); } catch (...) { threw.store(true, std::memory_order_relaxed); }   // an exception must not take the process down
+          guarded([&] { job(i); });
           remaining.fetch_sub(1, std::memory_order_release);
         }
       });
@@ -1320,7 +1334,11 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       sl.lt = LaneText();
       const auto t_rows = std::chrono::steady_clock::now();
       passes[i].general_tail = ext_source != nullptr;
-      sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt, false, nullptr, ext_source, pass_contig[i]);
+      try {
+        sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt, false, nullptr, ext_source, pass_contig[i]);
+      } catch (const std::exception& e) {                      // (this thread has no caller to unwind to)
+        sl.rc = fail(ctx, CALITAS_EHIP, std::string("a contig pass ended with an exception: ") + e.what());
+      }
       if (sl.rc == CALITAS_OK && hipEventRecord(sl.rows_done, ctx->stream) != hipSuccess) sl.rc = fail(ctx, CALITAS_EHIP, "hipEventRecord failed");
       sl.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rows).count();
       work[i & 1] = ctx->hits; serial[i & 1] = ctx->hits_names_serial;
@@ -2002,14 +2020,13 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     g_marks.mark("text-allocated");
     ctx->lane_threads->start(K, lane_body);
     g_marks.mark("threads-started");
-    bool threw = false;
-    try { lane_body(0); } catch (...) { threw = true; }  // the calling thread drives the first lane itself
+    ctx->lane_threads->guarded([&] { lane_body(0); });         // the calling thread drives the first lane itself
     ctx->lane_threads->wait();
     g_marks.mark("joined");
-    if (threw || ctx->lane_threads->threw.load()) {
+    if (ctx->lane_threads->threw.load()) {
       (void)hipDeviceSynchronize();
       free_text();
-      return fail(ctx, CALITAS_EHIP, "a lane of the search ended with an exception (out of host memory?)");
+      return fail(ctx, CALITAS_EHIP, ctx->lane_threads->failure());
     }
     rc = CALITAS_OK;
     bool overflow = false;
@@ -2204,13 +2221,12 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
     }
   };
   ctx->lane_threads->start((size_t)n_lanes, lane_job);
-  bool threw = false;
-  try { lane_job(0); } catch (...) { threw = true; }
+  ctx->lane_threads->guarded([&] { lane_job(0); });
   ctx->lane_threads->wait();
-  if (threw || ctx->lane_threads->threw.load()) {
+  if (ctx->lane_threads->threw.load()) {
     (void)hipDeviceSynchronize();
     release();
-    return fail(ctx, CALITAS_EHIP, "a lane of the batch ended with an exception (out of host memory?)");
+    return fail(ctx, CALITAS_EHIP, ctx->lane_threads->failure());
   }
   for (int g = 0; g < n_guides; g++) {
     if (rcs[g] == CALITAS_OK) continue;

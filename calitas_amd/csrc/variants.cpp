@@ -674,7 +674,11 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     helper = std::thread([&] {
       const auto t0 = std::chrono::steady_clock::now();
       (void)hipSetDevice(ctx->device);
-      hr.rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), source, &hr.tsv, &hr.bytes, &hr.rows, &hr.declined);
+      try {
+        hr.rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), source, &hr.tsv, &hr.bytes, &hr.rows, &hr.declined);
+      } catch (const std::exception& e) {                                                           // (a thread of its own has no caller to unwind to)
+        hr.rc = calitas_fail(ctx, CALITAS_EHIP, std::string("the reference passes ended with an exception: ") + e.what());
+      }
       hr.ms = ms_since(t0);
     });
 

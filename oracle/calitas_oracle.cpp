@@ -46,7 +46,10 @@
 
 namespace oracle {
 
-enum { SW_PER_MATRIX = 1, SW_EQX_BY_SCORE = 2 };
+// SW_NO_SHARED_CELLS: a third reading of U1, in the oracle only (the product has no such switch): the cells of the bottom row that reach
+// minScore are taken best score first, and an alignment whose traceback meets a cell an earlier one went through is dropped.  It exists
+// so that tests/golden/u_probe.json can tell an integrator with fgbio at hand which of three readings fgbio implements.
+enum { SW_PER_MATRIX = 1, SW_EQX_BY_SCORE = 2, SW_NO_SHARED_CELLS = 4 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // fgbio util.Sequences: IUPAC masks, compatible(), complement(), revcomp()
@@ -303,6 +306,41 @@ static std::vector<Alignment> glocal_align(const std::string& query, const std::
     out.push_back(std::move(a));
   };
 
+  if (switches & SW_NO_SHARED_CELLS) {
+    struct End { int score, j, dir; };
+    std::vector<End> ends;
+    for (int j = 1; j <= W; j++) {
+      const size_t c = m.at(L, j);
+      int d = D[c], l = Lf[c], u = U[c];
+      int mx = std::max(std::max(d, l), u);
+      if (mx >= minScore) ends.push_back({mx, j, (d == mx) ? DIAG : (l == mx) ? LEFT : UP});
+    }
+    std::stable_sort(ends.begin(), ends.end(), [](const End& a, const End& b) { return a.score > b.score; });   // ties: ascending end column
+    std::vector<uint8_t> used((size_t)(L + 1) * C, 0);
+    std::vector<std::pair<int, Alignment>> kept;
+    for (const End& e : ends) {
+      bool shared = false;
+      std::vector<size_t> path;
+      int ci = L, cj = e.j, cd = e.dir;
+      for (;;) {
+        const size_t c = m.at(ci, cj);
+        const uint8_t next = m.tr[cd][c];
+        if (next == DONE) break;
+        if (used[c]) { shared = true; break; }
+        path.push_back(c);
+        if (cd == UP) ci--; else if (cd == LEFT) cj--; else { ci--; cj--; }
+        cd = next;
+      }
+      if (shared) continue;
+      for (size_t c : path) used[c] = 1;
+      traceback(e.j, e.dir);
+      kept.emplace_back(e.j, std::move(out.back()));
+      out.pop_back();
+    }
+    std::stable_sort(kept.begin(), kept.end(), [](const std::pair<int, Alignment>& a, const std::pair<int, Alignment>& b) { return a.first < b.first; });
+    for (auto& k : kept) out.push_back(std::move(k.second));
+    return out;
+  }
   for (int j = 1; j <= W; j++) {
     const size_t c = m.at(L, j);
     if (switches & SW_PER_MATRIX) {
@@ -1156,6 +1194,21 @@ char* oracle_align(const char* guide, const char* aux_pams_csv, const char* targ
                         max_total_diffs, max_overlap);
     std::string out;
     for (auto& r : res) out += ga_row(r);
+    return dup_out(out);
+  } catch (std::exception& e) { return dup_out(std::string("ERROR\t") + e.what()); }
+}
+
+// fgbio's Aligner(scorer, useEqualsAndX = true, Mode.Glocal).align(query, target, minScore) by itself (SGA:210, 295): one line
+// "targetStart-targetEnd:score:cigar" per returned alignment, in the returned order -- what the probe of tests/golden/u_probe.json prints
+// on the Scala side.  The query's case decides guide / PAM scores as in SGA:139-147.
+char* oracle_glocal(const char* query, const char* target, int min_score, const int* costs, int switches) {
+  try {
+    const Scorer sc(costs[0], costs[2], costs[3], costs[1]);
+    Matrices m;
+    const std::string q(query), t(target);
+    std::string out;
+    for (const Alignment& a : glocal_align(q, t, min_score, sc, switches, m))
+      out += std::to_string(a.targetStart) + "-" + std::to_string(a.targetEnd()) + ":" + std::to_string(a.score) + ":" + cigar_string(a.cigar) + "\n";
     return dup_out(out);
   } catch (std::exception& e) { return dup_out(std::string("ERROR\t") + e.what()); }
 }

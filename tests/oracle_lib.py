@@ -32,7 +32,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         for name in ["oracle_align", "oracle_align_best", "oracle_align_to_ref", "oracle_guide_alignment", "oracle_windows",
                      "oracle_search_reference", "oracle_search_memory", "oracle_search_reference_vcf", "oracle_allele_combos",
-                     "oracle_variant_window", "oracle_align_to_reference"]:
+                     "oracle_variant_window", "oracle_align_to_reference", "oracle_glocal"]:
             getattr(L, name).restype = ctypes.c_void_p
         L.oracle_free.argtypes = [ctypes.c_void_p]
         L.oracle_check_hits_text.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
@@ -68,6 +68,11 @@ def align(guide, target, d, g, p, D, O=0, off=0, aux=(), name="n/a", costs=DEFAU
     t = target.encode() if isinstance(target, str) else bytes(target)
     ptr = lib().oracle_align(guide.encode(), ",".join(aux).encode(), t, len(t), name.encode(), off, d, g, p, D, O, _costs(costs), switches)
     return _rows(_take(ptr))
+
+
+def glocal(query, target, min_score, costs=DEFAULT_COSTS, switches=0):
+    """fgbio Aligner(Glocal).align(query, target, minScore) as the oracle restates it: ["targetStart-targetEnd:score:cigar", ...]."""
+    return _take(lib().oracle_glocal(query.encode(), target.encode(), min_score, _costs(costs), switches)).split()
 
 
 def align_best(guide, target, aux=(), g=3, costs=DEFAULT_COSTS, switches=0):

@@ -14,7 +14,7 @@ SGA = json.load(open(os.path.join(GOLD, "kat_sga.json")))
 GA = json.load(open(os.path.join(GOLD, "kat_ga.json")))
 SR = json.load(open(os.path.join(GOLD, "kat_sr.json")))
 
-SWITCHES = [0, 1, 2, 3]
+SWITCHES = [0, 1, 2, 3, 4, 6]          # bit 0: U1-b one alignment per matrix, bit 1: U2 by score, bit 2: U1-c no shared traceback cells (oracle only: a probe, tests/golden/u_probe.json)
 
 
 def rc(s):
@@ -142,3 +142,29 @@ def test_align_to_reference_tool_restatement_is_consistent(tmp_path):
     assert all("max-guide-diffs=Some(5)" in r["aligner_other_parameters"] and "max-overlap=Some(10)" in r["aligner_other_parameters"] for r in rows)
     keys = [(int(r["coordinate_start"]), r["strand"], -int(r["score"])) for r in rows]
     assert keys == sorted(keys)
+
+
+def test_u_probe_vectors():
+    """tests/golden/u_probe.json (made by make_u_probe.py): the inputs an integrator with fgbio at hand runs once to settle U1 / U2.
+    The oracle reproduces each listed output under the matching switch, the listed outputs differ pairwise, and the product's two
+    switches map to the first two readings (the third exists in the oracle only)."""
+    P = json.load(open(os.path.join(GOLD, "u_probe.json")))
+    u1, u2 = P["U1"], P["U2"]
+    sw_of = {"U1-a": 0, "U1-b": 1, "U1-c": 4, "U2-a": 0, "U2-b": 2}
+    for u in (u1, u2):
+        seen = []
+        for label, want in u["expect"].items():
+            sw = sw_of[label.split(" ")[0]]
+            assert O.glocal(u["query"], u["target"], u["min_score"], switches=sw) == want, label
+            assert want not in seen
+            seen.append(want)
+        rows = []
+        for key in [k for k in u["align"] if k.startswith("U")]:
+            d = u["max_guide_diffs"]
+            got = [{k: r[k] for k in ("strand", "start", "end", "score", "cigar")}
+                   for r in O.align(u["query"], u["target"], d, 0, 0, d, O=u["align"]["max_overlap"], switches=sw_of[key])]
+            assert got == u["align"][key], key
+            assert got not in rows
+            rows.append(got)
+    assert len(u1["expect"]) == 3 and len(u2["expect"]) == 2
+    assert u1["min_score"] == 60 * len(u1["query"]) - 122 * u1["max_guide_diffs"]      # minGuideScore, SGA:239-243
