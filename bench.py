@@ -731,20 +731,23 @@ def main():
                     "peak_measured": 1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"],
                     "frac_of_measured": ach / (1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"]),
                     "peak_measured_note": "v_and / v_add streams on all 1024 SIMDs, profiles/r01_valu_rates.txt"}
-                # What the kernel's OWN instruction mix can issue at: not every integer instruction runs at the v_and rate on gfx950
-                # (measured per instruction, profiles/r01_valu_rates.txt, ns per wave-instruction per SIMD: v_bitop3 1.35, v_and / v_or 1.2,
-                # v_addc_co 1.88, v_alignbit 1.97).  One row of the recurrence over one 32-base word is 5 + 2 + 1 + 2 of those = 14.97 ns;
-                # a wave's strand of a tile = 20 rows x 9 words of that + the bottom-row test (8 words x 28 instructions at ~1.6) + the
-                # staging reads and the reverse strand's bit reversal (~60): DESIGN.md 4.1.
-                row_ns = 5 * 1.35 + 2 * 1.2 + 1.88 + 2 * 1.97
-                strand_ns = 20 * 9 * row_ns + 8 * 28 * 1.6 + 60.0
+                # What the kernel's OWN instruction mix can issue at: not every integer instruction runs at the v_and rate on gfx950.  The
+                # census comes from the compiler's output for scan_rows_kernel<8, 1> and the per-instruction issue times from the
+                # micro-benchmarks (tools/scan_census.py -> profiles/r04_scan_census.json; rates: profiles/valu_rates.json): per wave, a strand
+                # of a tile = L rows of the row loop + the rest of the guide x strand (the bottom-row test) + its share of what runs once.
+                cen = json.load(open(os.path.join(ROOT, "profiles", "r04_scan_census.json")))
+                L_rows = len(GUIDE0) - 3 if args.config != 5 else 20
+                row_ns = sum(cen["ns_per_word_row"]) / len(cen["ns_per_word_row"])
+                strand_ns = (sum(L_rows * r + g for r, g in zip(cen["row_iteration_ns"], cen["guide_strand_rest_ns"])) + cen["once_per_wave_ns"]) / 2
                 bases_per_ns = 1024 * (64 * 8 * 32) / (2 * strand_ns)
                 live = 1.0 - tiles["dead"] / max(1, tiles["tiles"])
                 mix_ms = sum(lengths) * live / bases_per_ns * 1e-6
                 result["roofline"]["valu"]["mix_limit"] = {
                     "ns_per_word_row": round(row_ns, 2), "scan_ms_at_limit": round(mix_ms, 4),
                     "frac": round(mix_ms / (acc["scan"] / K / max(1, n_guides_rank)), 4),
-                    "note": "issue time of the kernel's instruction mix at the per-instruction rates of profiles/r01_valu_rates.txt; frac = that "
+                    "valu_per_word_row": round(sum(cen["valu_per_row_iteration"]) / len(cen["valu_per_row_iteration"]) / cen["words_per_lane"], 2),
+                    "census": "profiles/r04_scan_census.json (tools/scan_census.py: the compiler's output for " + cen["kernel"] + ")",
+                    "note": "issue time of the kernel's instruction mix at the per-instruction rates of profiles/valu_rates.json; frac = that "
                             "time / the measured scan time per pass (sum over the launches of a call, which share the chip with the tails)"}
         except Exception:
             pass

@@ -236,3 +236,21 @@ def test_module_cli_parses_the_reference_flags():
     with pytest.raises(SystemExit) as e:
         main(["SearchReference", "-i", "ACGTnrg"])    # -I and -r are required (SearchReference.scala:452-455)
     assert e.value.code != 0
+
+
+def test_scan_census_follows_the_kernel(tmp_path):
+    """bench.py's roofline.valu.mix_limit prices the scan kernel's own instruction mix from profiles/r04_scan_census.json; the file is
+    what tools/scan_census.py makes of the compiler's output for calitas_amd/csrc/scan_rows.hip today (a change to the kernel without a
+    fresh census fails here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "census.json")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "scan_census.py"), "-o", out], stdout=subprocess.DEVNULL)
+    fresh, kept = json.load(open(out)), json.load(open(os.path.join(root, "profiles", "r04_scan_census.json")))
+    for k in ("kernel", "words_per_lane", "row_iteration_ns", "guide_strand_rest_ns", "once_per_wave_ns", "valu_per_row_iteration"):
+        assert fresh[k] == kept[k], k
+    row = kept["strands"][0]["row_iteration"]
+    assert row["v_addc_co_u32"] + row.get("v_add_co_u32", 0) == kept["words_per_lane"]      # the carry chain: one add per word
+    assert 9 <= kept["valu_per_row_iteration"][0] / kept["words_per_lane"] <= 12
