@@ -539,7 +539,7 @@ int calitas_search_hits_stream(calitas_ctx* ctx, const calitas_guide_t* guide, c
   if (tsv_bytes) *tsv_bytes = 0;
   if (n_rows) *n_rows = 0;
   if (params->first_window != 0 || params->n_windows != 0)
-    return fail(ctx, CALITAS_EINVAL, "a window range (first_window / n_windows) is for calitas_search, calitas_search_hits and calitas_search_hits_into");
+    return fail(ctx, CALITAS_EINVAL, "a window range (first_window / n_windows) is for calitas_search, calitas_search_hits(_into) and calitas_search_hits_batch");
   return calitas_search_hits_stream_impl(ctx, guide, guide_id ? guide_id : "", params, aligner_version, time_stamp, sink, user, tsv_bytes, n_rows);
 }
 
@@ -548,8 +548,6 @@ int calitas_search_hits_batch(calitas_ctx* ctx, int32_t n_guides, const calitas_
                               uint64_t* tsv_bytes, uint64_t* n_rows) {
   if (!ctx) return CALITAS_EINVAL;
   if (n_guides <= 0 || !guides || !params || !tsv) return fail(ctx, CALITAS_EINVAL, "bad argument");
-  if (params->first_window != 0 || params->n_windows != 0)
-    return fail(ctx, CALITAS_EINVAL, "a window range (first_window / n_windows) is for calitas_search, calitas_search_hits and calitas_search_hits_into");
   return calitas_search_hits_batch_impl(ctx, n_guides, guides, guide_ids, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
 }
 

@@ -2151,15 +2151,28 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
     return CALITAS_OK;
   }
   // plans first: every guide is validated before anything is queued, and all must share one window tiling
+  // A window range (a process's stretch of a multi-GPU job): every guide's plan is the stretch's -- the rows it owns, decided by the
+  // per-bin kernels (plan_owned_range); a guide whose bins decline goes through calitas_search_hits on the range afterwards.
+  const bool ranged = params && (params->first_window != 0 || params->n_windows != 0);
+  calitas_params_t whole = *params;
+  whole.first_window = 0; whole.n_windows = 0;
+  if (ranged && whole.chrom_index >= 0) return fail(ctx, CALITAS_EINVAL, "a window range and chrom_index exclude each other");
   std::vector<SearchPlan> plans((size_t)n_guides);
   for (int i = 0; i < n_guides; i++) {
-    int rc = plan_search(ctx, 1, &guides[i], params, plans[i]);
+    int rc = plan_search(ctx, 1, &guides[i], &whole, plans[i]);
     if (rc) return rc;
     if (plans[i].step != plans[0].step)
       return fail(ctx, CALITAS_EINVAL, "all guides of one batch must have the same length (same window tiling, SearchReference.scala:529)");
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < n_guides; i++) { int rc = ensure_bin_base(ctx, plans[i], ctx->stream); if (rc) return rc; }
+  std::vector<char> owned_ok((size_t)n_guides, 1);
+  if (ranged) {
+    if (params->first_window < 0 || params->n_windows <= 0 || (uint64_t)params->first_window + (uint64_t)params->n_windows > plans[0].win_n)
+      return fail(ctx, CALITAS_EINVAL, "first_window / n_windows outside the window table (" + std::to_string(plans[0].win_n) + " windows)");
+    for (int i = 0; i < n_guides; i++)
+      owned_ok[(size_t)i] = plan_owned_range(ctx, plans[i], (uint64_t)params->first_window, (uint64_t)params->n_windows) && binned_wanted(ctx, plans[i]);
+  }
   int rc = ensure_lanes(ctx, (size_t)n_lanes);
   if (rc) return rc;
   for (int l = 0; l < n_lanes && !rc; l++) { rc = lane_prepare(ctx->lanes[l], plans[0]); if (rc) ctx->err = ctx->lanes[l]->err; }
@@ -2181,6 +2194,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
       calitas_ctx* lane = ctx->lanes[l];
       for (int g = l; g < n_guides; g += n_lanes) {
         const SearchPlan& pl = plans[g];
+        if (!owned_ok[(size_t)g]) { rcs[g] = kOwnedDeclined; continue; }   // (the stretch is not one for the bins: below, one guide at a time)
         const std::string gid = guide_ids && guide_ids[g] ? guide_ids[g] : "";
         const RowStrings rs = make_row_strings(ref, pl.gh[0], gid, pl.p, version, stamp);
         auto step = [&]() -> int {
@@ -2230,7 +2244,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   }
   for (int g = 0; g < n_guides; g++) {
     if (rcs[g] == CALITAS_OK) continue;
-    if (rcs[g] == CALITAS_ESTATE || rcs[g] == CALITAS_ENOMEM) {   // a lane's buffers overflowed / did not fit: this guide again through calitas_search_hits (retry logic, per-contig passes)
+    if (rcs[g] == CALITAS_ESTATE || rcs[g] == CALITAS_ENOMEM || rcs[g] == kOwnedDeclined) {   // a lane's buffers overflowed / did not fit / the bins declined a stretch: this guide again through calitas_search_hits (retry logic, per-contig passes, the whole-contig path of a stretch)
       int r = calitas_search_hits_impl(ctx, &guides[g], guide_ids && guide_ids[g] ? guide_ids[g] : "", params, version.c_str(), stamp.c_str(), &tsv[g],
                                tsv_bytes ? &tsv_bytes[g] : nullptr, n_rows ? &n_rows[g] : nullptr);
       if (r) { release(); return r; }

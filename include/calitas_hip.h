@@ -80,7 +80,9 @@ typedef struct {
    *    first sort key of hits.txt, so the texts of consecutive ranges (minus their header lines) concatenate to the text of the
    *    whole call, wherever the cuts fall; removeOverlaps is exact across a cut because every process also aligns the windows
    *    around its stretch that can decide its hits.
-   * The stream and batch calls refuse a range. */
+   *  - calitas_search_hits_batch does the same for every guide of the batch (round 4: BASELINE config 4 on several GPUs is every
+   *    process running all guides on its stretch), guides pipelined through the device stages as in the whole-genome batch.
+   * The stream call refuses a range. */
   int32_t first_window;
   int32_t n_windows;
 } calitas_params_t;

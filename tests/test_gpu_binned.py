@@ -255,6 +255,15 @@ def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts
             monkeypatch.delenv("CALITAS_BINNED", raising=False)
             monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
             assert rows == n_whole and whole == whole[:whole.index("\n") + 1] + "".join(pieces), (mode, bounds)
+        # calitas_search_hits_batch on a window range (BASELINE config 4 on several GPUs: every process runs all guides on its stretch):
+        # per guide the text of calitas_search_hits on the same range -- on the per-bin kernels and, where the bins decline a stretch (the
+        # chain of tandem copies of contig b lies on a cut), through the per-guide fallback
+        G3 = [G, C.Guide("GTGACTTGAAGTCTCAGTATnrg"), G]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            pr = C.make_params(first_window=lo, n_windows=hi - lo, **pk)
+            got = ctx.search_hits_batch(G3, ["a", "b", "a"], pr, "v0", "stamp")
+            for g, gid, (text, n) in zip(G3, ["a", "b", "a"], got):
+                assert (text, n) == ctx.search_hits(g, gid, pr, "v0", "stamp"), (lo, hi, gid)
     finally:
         ctx.close()
     _, want, _ = O.search_reference(fa, GUIDE, "a", g=2, threads=4)
