@@ -343,6 +343,10 @@ def main():
     ap.add_argument("--secondary", action="store_true",
                     help="N>1: also measure the partition mode that is not the headline (every rank regenerates and re-uploads the genome for it)")
     ap.add_argument("--no-secondary", action="store_true", help=argparse.SUPPRESS)   # the default since round 3; accepted for old command lines
+    ap.add_argument("--batch-sharded", dest="batch_sharded", action="store_true", default=None,
+                    help="also measure BASELINE config 4's shape on this partition: every rank runs all 96 guides on its window range "
+                         "(calitas_search_hits_batch on a range), a sample of guides checked against single-process calls; default for N > 1")
+    ap.add_argument("--no-batch-sharded", dest="batch_sharded", action="store_false")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank exits 3 before the rendezvous
     ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
     ap.add_argument("--guides-per-step", type=int, default=1,
@@ -390,6 +394,19 @@ def main():
         args.prime_seconds = 0.75 if args.config == 3 else 0.0
     if args.scale is None:
         args.scale = 0.05 if args.config == 5 else 1.0
+
+    # N > 1: every rank on the CPUs of its GPU's NUMA node (a rank's slice is bound by host round trips, and one from the far socket
+    # costs a quarter more: DESIGN.md 4.7), its share of them when several GPUs hang off one node -- before anything starts a thread.
+    # (calitas_amd/shard.py loaded by path: the package itself loads the HIP library, which has to come after torch.)
+    pinned = None
+    if world > 1 and not args.rehearse_on_one_gpu and os.environ.get("CALITAS_BENCH_PIN", "1") != "0":
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_calitas_shard", os.path.join(ROOT, "calitas_amd", "shard.py"))
+        shard_mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(shard_mod)
+        pinned = shard_mod.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        if pinned and "CALITAS_THREADS" not in os.environ:
+            os.environ["CALITAS_THREADS"] = str(min(16, len(pinned)))       # the library's worker pool: one thread per CPU it may use
 
     import torch
     if not torch.cuda.is_available():
@@ -471,6 +488,62 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    def measure_batch_sharded(ctx, params_rank, names, seqs):
+        """BASELINE config 4 on this job's partition: every rank runs ALL 96 guides on its window range (calitas_search_hits_batch on a
+        range: the rows it owns per guide, guides pipelined through the device stages), nothing exchanged; a step ends when the slowest
+        rank has its 96 texts.  A sample of guides is then held against single-process calls on rank 0, which has the whole genome: a rank's
+        text of guide g must be the header plus its consecutive piece of the whole text (CRC and length per rank)."""
+        import zlib
+        G96 = [C.Guide(g) for g in all_guides]
+        ids96 = ["g%02d" % i for i in range(len(G96))]
+        ctx.search_hits_batch(G96, ids96, params_rank, "bench", "bench", decode=False)          # untimed: text blocks, lane buffers
+        steps_b = 2
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps_b):
+            res = ctx.search_hits_batch(G96, ids96, params_rank, "bench", "bench", decode=False)
+        sync()
+        dt = time.perf_counter() - t0
+        tm = ctx.timing()
+        rows_rank, bytes_rank = sum(r for _, r in res), sum(b for b, _ in res)
+        sample = [0, 37, 95]
+        mine = ctx.search_hits_batch([G96[i] for i in sample], [ids96[i] for i in sample], params_rank, "bench", "bench", decode="digest")
+        stats = [dt, float(rows_rank), float(bytes_rank)] + [float(x) for (crc, nb), rows in mine for x in (crc, nb, rows)]
+        allst = [stats]
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor(stats, dtype=torch.float64)
+            gathered = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t, group=gloo)
+            allst = [g.tolist() for g in gathered]
+        if rank != 0:
+            return None
+        dt_max = max(a[0] for a in allst)
+        check = {"guides": sample, "identical": True, "rows": 0}
+        for k, gi in enumerate(sample):
+            whole, n_whole = ctx.search_hits(G96[gi], ids96[gi], params, "bench", "bench", decode="bytes")
+            head = whole[:whole.index(b"\n") + 1]
+            off = len(head)
+            for r in range(world):
+                crc, nb, rows = (int(allst[r][3 + 3 * k + j]) for j in range(3))
+                piece = whole[off: off + nb - len(head)]
+                off += nb - len(head)
+                if zlib.crc32(head + piece) != crc:
+                    check["identical"] = False
+            if off != len(whole) or sum(int(allst[r][3 + 3 * k + 2]) for r in range(world)) != n_whole:
+                check["identical"] = False
+            check["rows"] += n_whole
+        total_bases = sum(lengths)
+        block = {"workload": "SearchReference: 96-guide batch (BASELINE config 4), every rank all guides on its window range",
+                 "guides_per_step": len(G96), "steps": steps_b, "ms_per_step": dt_max / steps_b * 1e3,
+                 "value": 2.0 * total_bases * len(G96) * steps_b / dt_max, "unit": "candidates/s", "scaling": "strong",
+                 "rows_per_step": int(sum(a[1] for a in allst)), "text_bytes_per_step": int(sum(a[2] for a in allst)),
+                 "rank_seconds": [round(a[0], 4) for a in allst], "lanes": tm.get("lanes"), "binned_lanes_rank0": tm.get("binned_lanes"),
+                 "check": check}
+        log("batch_sharded: %.1f ms per 96-guide step on %d rank(s), sample of guides identical to single-process calls: %s"
+            % (block["ms_per_step"], world, check["identical"]))
+        return block
 
     def measure(mode, keep_text=False):
         """K timed steps of one partition mode, bracketed by barrier + synchronize; the MAX over ranks is the job's time."""
@@ -644,10 +717,14 @@ def main():
             if rank == 0:
                 os.unlink(shm["path"])
                 last = (last[0], last[1], total)
+        batch_block = None
+        want_batch = args.batch_sharded if args.batch_sharded is not None else world > 1
+        if want_batch and args.config == 3 and mode in ("windows", "none") and not (args.no_hits or args.two_stage):
+            batch_block = measure_batch_sharded(ctx, params_rank, names, seqs)
         ctx.close()
         if vcf_path:
             os.unlink(vcf_path)
-        return dict(dt=dt, acc=acc, last=last, phase=phase, my_guides=my_guides, passes_per_step=passes_per_step,
+        return dict(dt=dt, acc=acc, batch_block=batch_block, last=last, phase=phase, my_guides=my_guides, passes_per_step=passes_per_step,
                     bases_per_step_total=bases_per_step_total, names=names, seqs=seqs, text=text, tiles=tiles, n_variants=n_variants,
                     mine=mine, partition_check=partition_check)
 
@@ -751,6 +828,11 @@ def main():
                             "time / the measured scan time per pass (sum over the launches of a call, which share the chip with the tails)"}
         except Exception:
             pass
+        if m.get("batch_block"):
+            result["batch_sharded"] = m["batch_block"]          # BASELINE config 4's shape on this partition (labelled; `value` stays the one-pass headline)
+            if not m["batch_block"]["check"]["identical"]:
+                print(json.dumps(result), flush=True)
+                raise SystemExit("bench.py: a rank's text of the sharded batch differs from the single-process search")
         if m.get("partition_check"):
             result["partition_check"] = m["partition_check"]     # the gathered hits.txt of the N ranks against one process's search
             if not m["partition_check"].get("identical", True):

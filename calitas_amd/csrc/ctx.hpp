@@ -71,6 +71,8 @@ struct calitas_ctx {
   // the last search on this context the binned tail declined (crowded bins, a long repeat): protospacer length, PAMs, minGuideScore.
   // A search at least as permissive goes to the general kernels directly.
   int bin_decl_L = 0, bin_decl_pams = -1, bin_decl_min_score = 0;
+  uint64_t bin_decl_guide = 0;      // ... of which guide (a hash of its row sets and PAM masks): a crowded bin is where THIS guide meets a repeat, and a
+                                    // batch of 96 guides must not lose the bins for all because one of them did
   HitsWork* hits_alt = nullptr;     // second row-stage scratch of the per-contig passes: contig c+1's rows are built while contig c's text is copied
   uint64_t hits_alt_names_serial = ~0ull;
   // chunked calitas_search_hits: the parent owns the lanes and the stream all scans are queued on

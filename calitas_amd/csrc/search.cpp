@@ -809,6 +809,15 @@ static double rows_stage_ms(calitas_ctx* lane, const calitas_timing_t& tm) {
 // Whether this lane's search takes the binned tail (binned.hpp): one guide on the device path, a window size the bins handle, not
 // a search planned as dense (rec_hint: per-contig passes of a permissive PAM-less search would crowd every bin), and not one at least
 // as permissive as the last the bins declined on this reference.
+static uint64_t guide_hash(const GuideDev& g) {
+  uint64_t h = 1469598103934665603ull;                       // FNV-1a over what the kernels see of the guide
+  auto mix = [&](uint64_t v) { for (int k = 0; k < 8; k++) { h ^= (v >> (8 * k)) & 0xFF; h *= 1099511628211ull; } };
+  mix((uint64_t)g.L); mix((uint64_t)g.n_pams); mix((uint64_t)g.pam5);
+  for (int i = 0; i < g.L; i++) mix(g.qmask[i]);
+  for (int p = 0; p < g.n_pams; p++) { mix(g.pam_len[p]); for (int k = 0; k < g.pam_len[p]; k++) mix(g.pam_mask[p][k]); }
+  return h;
+}
+
 static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
   const calitas_ctx* own = ref_owner(lane);
   if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0 || pl.general_tail) return false;
@@ -827,7 +836,7 @@ static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
   if (!want) return false;
   if (pl.p.max_overlap < 1 || own->ref.contigs.size() >= (1u << 18) - 1) return false;
   const GuideDev& g = pl.gd[0];
-  if (own->bin_decl_pams == g.n_pams && own->bin_decl_L == g.L && g.min_guide_score <= own->bin_decl_min_score) return false;
+  if (own->bin_decl_pams == g.n_pams && own->bin_decl_L == g.L && g.min_guide_score <= own->bin_decl_min_score && own->bin_decl_guide == guide_hash(g)) return false;
   return true;
 }
 
@@ -1036,6 +1045,7 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   if (overflow || (flags & ~BIN_FLAG_TEXT)) {
     if (!overflow) {   // a property of this search on this reference: remember it
       own->bin_decl_L = pl.gd[0].L; own->bin_decl_pams = pl.gd[0].n_pams; own->bin_decl_min_score = pl.gd[0].min_guide_score;
+      own->bin_decl_guide = guide_hash(pl.gd[0]);
       if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] binned tail declined (flags %u): finishing on the general kernels\n", flags);
     }
     HIP_TRY(lane, calitas_spin_sync(lane->stream));          // the rows kernel returns at once; nothing of it may linger over the retry

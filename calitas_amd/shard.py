@@ -166,3 +166,88 @@ def owned_stretch(lengths, step, first_window, n_windows):
 def owns(stretch, contig, position):
     """Whether a hit at (contig index, coordinate_start) belongs to the stretch of owned_stretch()."""
     return stretch[0] <= (contig, position) < stretch[1]
+
+
+# ---- where a rank's host threads run -------------------------------------------------------------------------------------
+# A rank's call is bound by host round trips once its slice is small (an eighth of a genome: 0.5 ms, five dependent launches), and a
+# round trip from the far socket costs a quarter more (DESIGN.md 4.7).  The reference pins nothing (one JVM, one pool:
+# SearchReference.scala:75-94); a job of one process per GPU has to.
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _cpulist(text):
+    out = []
+    for part in (text or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_nodes(root="/"):
+    """NUMA node of every GPU in HIP's device order: the KFD topology lists the GPUs in that order (nodes with simd_count > 0), each
+    with the minor of its DRM render node, whose PCI device says which NUMA node it hangs off.  [] when the machine has no KFD
+    topology (no GPU), None entries where the kernel does not say (-1)."""
+    import os
+    top = os.path.join(root, "sys/class/kfd/kfd/topology/nodes")
+    try:
+        ids = sorted(int(d) for d in os.listdir(top) if d.isdigit())
+    except OSError:
+        return []
+    out = []
+    for i in ids:
+        props = dict(ln.split(None, 1) for ln in (_read(os.path.join(top, str(i), "properties")) or "").splitlines() if " " in ln)
+        if int(props.get("simd_count", "0")) <= 0:
+            continue
+        node = _read(os.path.join(root, "sys/class/drm/renderD%s/device/numa_node" % props.get("drm_render_minor", "-1")))
+        out.append(int(node) if node is not None and int(node) >= 0 else None)
+    return out
+
+
+def rank_cpus(local_rank, n_local, allowed, root="/", visible=None, min_cpus=2):
+    """The CPUs rank `local_rank` of `n_local` ranks on this machine should run on: those of its GPU's NUMA node that the process may
+    use at all (`allowed`: os.sched_getaffinity), shared out evenly among the ranks whose GPUs hang off the same node.  `visible`: the
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES list when one is set (rank r then uses GPU visible[r]).  None: leave the process alone
+    (no topology, the node unknown, or fewer than min_cpus CPUs for a rank)."""
+    import os
+    nodes = gpu_numa_nodes(root)
+    gpu_of = lambda r: (visible[r] if visible and r < len(visible) else r)
+    if not nodes or gpu_of(local_rank) >= len(nodes) or nodes[gpu_of(local_rank)] is None:
+        return None
+    mine = nodes[gpu_of(local_rank)]
+    cpus = [c for c in _cpulist(_read(os.path.join(root, "sys/devices/system/node/node%d/cpulist" % mine))) if c in allowed]
+    peers = [r for r in range(n_local) if gpu_of(r) < len(nodes) and nodes[gpu_of(r)] == mine]
+    if local_rank not in peers:
+        return None
+    per = len(cpus) // len(peers)
+    if per < min_cpus:
+        return None
+    k = peers.index(local_rank)
+    return cpus[k * per:(k + 1) * per]
+
+
+def pin_rank(local_rank, n_local):
+    """sched_setaffinity for this process (before any thread pool exists) per rank_cpus; returns the CPU list or None."""
+    import os
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    try:
+        visible = [int(x) for x in vis.split(",")] if vis else None
+    except ValueError:
+        visible = None                                         # (UUIDs: no way to map them here)
+        if vis:
+            return None
+    try:
+        cpus = rank_cpus(local_rank, n_local, os.sched_getaffinity(0), visible=visible)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, AttributeError, ValueError):
+        return None

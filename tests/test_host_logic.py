@@ -254,3 +254,36 @@ def test_scan_census_follows_the_kernel(tmp_path):
     row = kept["strands"][0]["row_iteration"]
     assert row["v_addc_co_u32"] + row.get("v_add_co_u32", 0) == kept["words_per_lane"]      # the carry chain: one add per word
     assert 9 <= kept["valu_per_row_iteration"][0] / kept["words_per_lane"] <= 12
+
+
+def test_rank_cpus_from_a_sysfs_tree(tmp_path):
+    """calitas_amd.shard.rank_cpus: a rank's CPUs = those of its GPU's NUMA node, shared among the ranks on that node (bench.py pins
+    every rank of an N > 1 job before it starts a thread).  A fake /sys: 8 GPUs, four per socket, 32 CPUs per socket, two CPU-only
+    KFD nodes in front (as on the MI355X boxes)."""
+    from calitas_amd import shard
+    root = tmp_path
+    def put(rel, text):
+        p = root / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(text)
+    for i in range(2):
+        put("sys/class/kfd/kfd/topology/nodes/%d/properties" % i, "cpu_cores_count 32\nsimd_count 0\ndrm_render_minor -1\n")
+    for g in range(8):
+        put("sys/class/kfd/kfd/topology/nodes/%d/properties" % (2 + g), "cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % (128 + g))
+        put("sys/class/drm/renderD%d/device/numa_node" % (128 + g), "%d\n" % (g // 4))
+    put("sys/devices/system/node/node0/cpulist", "0-15,64-79\n")
+    put("sys/devices/system/node/node1/cpulist", "16-31,80-95\n")
+    assert shard.gpu_numa_nodes(str(root)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = set(range(128))
+    sets = [shard.rank_cpus(r, 8, allowed, str(root)) for r in range(8)]
+    assert all(len(s) == 8 for s in sets) and len(set(c for s in sets for c in s)) == 64          # disjoint shares
+    assert set(sets[0] + sets[1] + sets[2] + sets[3]) == set(range(0, 16)) | set(range(64, 80))
+    assert set(sets[5]) <= set(range(16, 32)) | set(range(80, 96))
+    # two ranks on one box: GPUs 0 and 1 share node 0 -> half of the node each; a cpuset that leaves a rank one CPU: left alone
+    two = [shard.rank_cpus(r, 2, allowed, str(root)) for r in range(2)]
+    assert len(two[0]) == len(two[1]) == 16 and not set(two[0]) & set(two[1])
+    assert shard.rank_cpus(0, 8, {0, 1, 2, 3}, str(root)) is None
+    # HIP_VISIBLE_DEVICES=4,5: rank 0 sits on GPU 4 = node 1
+    assert set(shard.rank_cpus(0, 2, allowed, str(root), visible=[4, 5])) <= set(range(16, 32)) | set(range(80, 96))
+    # no KFD topology (this container): nothing to do
+    assert shard.gpu_numa_nodes(str(tmp_path / "nowhere")) == [] and shard.rank_cpus(0, 2, allowed, str(tmp_path / "nowhere")) is None
