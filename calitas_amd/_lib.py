@@ -52,7 +52,8 @@ class TimingT(ctypes.Structure):
                 ("scan_records", ctypes.c_uint64), ("candidate_columns", ctypes.c_uint64), ("raw_alignments", ctypes.c_uint64),
                 ("accepted_alignments", ctypes.c_uint64), ("retries", ctypes.c_uint32), ("lanes", ctypes.c_uint32),
                 ("hits_kernel_ms", ctypes.c_double), ("hits_copy_ms", ctypes.c_double), ("hit_rows", ctypes.c_uint64),
-                ("hits_bytes", ctypes.c_uint64), ("contig_passes", ctypes.c_uint32), ("binned_lanes", ctypes.c_uint32)]
+                ("hits_bytes", ctypes.c_uint64), ("contig_passes", ctypes.c_uint32), ("binned_lanes", ctypes.c_uint32),
+                ("owned_general_lanes", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 # every symbol include/calitas_hip.h declares

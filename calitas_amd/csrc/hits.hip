@@ -119,9 +119,12 @@ __global__ void prep_kernel(const HitRec* hits, const uint32_t* order, uint32_t 
 }
 
 __device__ __forceinline__ void cluster_body(const uint32_t i, const int32_t* s_start, const int32_t* s_end, const int32_t* s_score, const uint32_t* s_cs,
-                                             const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+                                             const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags, const HitsOwn own = HitsOwn()) {
   if (!head[i]) return;
   const uint32_t cs = s_cs[i];
+  // HitsOwn: a walk that starts where hits may be missing must not decide an owned hit
+  const bool unsure = (((unsigned long long)(cs >> 2) << 32) | (uint32_t)s_start[i]) < own.safe;
+  auto owned = [&](uint32_t j) { const unsigned long long k = ((unsigned long long)(cs >> 2) << 32) | (uint32_t)s_start[j]; return k >= own.lo && k < own.hi; };
   // next hit of this (contig, strand) group after position j, or n
   auto next = [&](uint32_t j) {
     for (j++; j < n; j++) {
@@ -134,6 +137,7 @@ __device__ __forceinline__ void cluster_body(const uint32_t i, const int32_t* s_
   uint32_t j = i, steps = 0;
   for (;;) {                                            // SR:661-671
     const uint32_t hit = j;
+    if (unsure && owned(hit)) { atomicOr(flags, HITS_FLAG_HALO); return; }
     j = next(j);
     const int hs = s_start[hit], he = s_end[hit], hsc = s_score[hit];
     bool more = false;
@@ -143,6 +147,7 @@ __device__ __forceinline__ void cluster_body(const uint32_t i, const int32_t* s_
       if (!more) break;
       ov = max(0, min(s_end[j], he) - max(s_start[j], hs));   // RH:141-144
       if (!(ov >= max_overlap && s_score[j] <= hsc)) break;
+      if (unsure && owned(j)) { atomicOr(flags, HITS_FLAG_HALO); return; }
       j = next(j);
       if (++steps > CLUSTER_MAX) break;
     }
@@ -154,10 +159,10 @@ __device__ __forceinline__ void cluster_body(const uint32_t i, const int32_t* s_
 }
 
 __global__ void cluster_kernel(const int32_t* s_start, const int32_t* s_end, const int32_t* s_score, const uint32_t* s_cs,
-                               const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags) {
+                               const uint8_t* head, uint32_t n, int max_overlap, uint8_t* keep, uint32_t* flags, const HitsOwn own) {
   CALITAS_TAIL_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) cluster_body(i, s_start, s_end, s_score, s_cs, head, n, max_overlap, keep, flags);
+  if (i < n) cluster_body(i, s_start, s_end, s_score, s_cs, head, n, max_overlap, keep, flags, own);
 }
 
 // At most this many accepted alignments: coordinates, order, restart points and the removeOverlaps walk in ONE launch of one
@@ -212,8 +217,13 @@ __global__ __launch_bounds__(256) void mid_kernel(MidArgs a, uint8_t* stage, uin
     if (k >= a.n) break;
     int len = 0;
     uint32_t name_len = 0;
-    const bool live = uniform_ptr(a.keep)[k] != 0;
+    bool live = uniform_ptr(a.keep)[k] != 0;
     const uint32_t v = uniform_ptr(a.order)[k];
+    if (live && v < a.n_dev && (a.own_lo != 0 || a.own_hi != ~0ull)) {   // HitsOwn: rows of the stretch only
+      const auto* hq = uniform_ptr(a.hits) + v;
+      const unsigned long long key = ((unsigned long long)(uint32_t)hq->contig << 32) | (uint32_t)hq->gstart;
+      live = key >= a.own_lo && key < a.own_hi;
+    }
     if (v >= a.n_dev) {                                  // the caller's own hit: its row comes finished (HitsExt), out_kernel copies it
       if (lane == 0) {
         midlen[k] = live ? 0xFFFFFFFFu : 0u;
@@ -417,7 +427,7 @@ hipError_t hits_prepare_host(HitsWork** pw, const RowStrings& st, HitsSetup* out
 
 hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, uint32_t n_in, const GuideDev* d_guides,
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& st, int max_overlap, int score_hi,
-                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res, const HitsExt* ext) {
+                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res, const HitsExt* ext, const HitsOwn* own) {
   if (!*pw) *pw = new HitsWork();
   HitsWork& w = **pw;
   hipError_t e;
@@ -458,7 +468,8 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
     TRY(hipMemcpyAsync(w.ext_off, ext->row_off, ((size_t)n_ext + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     if (row_bytes) TRY(hipMemcpyAsync(w.ext_rows, ext->rows, row_bytes, hipMemcpyHostToDevice, stream));
   }
-  const bool small = n_in <= HITS_SMALL && window_reach != 0;
+  const bool small = n_in <= HITS_SMALL && window_reach != 0 && !own;
+  const HitsOwn ho = own ? *own : HitsOwn();
   if (small) {          // 1-3 in one launch
     HitsSmallArgs sa{};
     sa.fin = d_final; sa.guides = d_guides; sa.win_base = d_win_base; sa.win = d_win; sa.hits = w.hits; sa.keys = w.keys; sa.vals = w.vals;
@@ -479,7 +490,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   hipLaunchKernelGGL(prep_kernel, grid, block, 0, stream, (const HitRec*)w.hits, (const uint32_t*)w.vals2, n_in, max_overlap, w.s_start, w.s_end,
                      w.s_score, w.s_cs, w.head, w.keep);
   hipLaunchKernelGGL(cluster_kernel, grid, block, 0, stream, (const int32_t*)w.s_start, (const int32_t*)w.s_end, (const int32_t*)w.s_score,
-                     (const uint32_t*)w.s_cs, (const uint8_t*)w.head, n_in, max_overlap, w.keep, d_flags);
+                     (const uint32_t*)w.s_cs, (const uint8_t*)w.head, n_in, max_overlap, w.keep, d_flags, ho);
   }
   // 4: rows
   // (a row with more padded columns than a wave has lanes raises HITS_FLAG_ROW and the caller finishes on the host)
@@ -496,7 +507,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   TRY(grow(&w.midlen, w.midlen_cap, n_pad));
   MidArgs ma{};
   ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
-  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.n_dev = n_dev; ma.ext_off = w.ext_off; ma.ext_kept = d_kept + 1; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
+  ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.n_dev = n_dev; ma.ext_off = w.ext_off; ma.ext_kept = d_kept + 1; ma.own_lo = ho.lo; ma.own_hi = ho.hi; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
   const unsigned rows_per_mid_block = 4 * MID_ROWS_PER_WAVE;
   hipLaunchKernelGGL(mid_kernel, dim3((unsigned)((n + rows_per_mid_block - 1) / rows_per_mid_block)), dim3(256), mid_lds, stream, ma, w.stage, w.midlen,
                      w.lens, d_flags);

@@ -36,6 +36,7 @@ constexpr uint32_t HITS_FLAG_SCORE_RANGE = 1;   // a score fell outside the sort
 constexpr uint32_t HITS_FLAG_CLUSTER = 2;       // an overlap cluster is longer than one lane should walk
 
 constexpr uint32_t HITS_FLAG_ROW = 4;           // a row has more padded columns than max_ops allows
+constexpr uint32_t HITS_FLAG_HALO = 8;          // HitsOwn: an owned hit hangs on a removeOverlaps cluster that starts where not every hit is known
 
 // Whether the sort keys can represent this search at all.
 bool hits_supported(uint64_t n_contigs, int max_overlap, int score_lo, int score_hi);
@@ -70,6 +71,13 @@ struct HitsExt {
   uint32_t* kept = nullptr;            // out (optional): how many of the entries were kept
 };
 
+// The alignments given to hits_run are those of a window range of a larger job (a process's stretch of a multi-GPU partition plus the
+// context around it), and only the rows the stretch OWNS are wanted: hits whose key (contig << 32 | coordinate_start) lies in [lo, hi).
+// removeOverlaps is exact for them as long as the cluster an owned hit belongs to starts at a hit from `safe` on -- from there every hit
+// that could overlap is among the alignments (left of it, windows outside the range may have held more); a cluster that starts earlier
+// and reaches an owned hit raises HITS_FLAG_HALO (a chain of overlapping hits longer than the context: the caller searches whole contigs).
+struct HitsOwn { unsigned long long lo = 0, hi = ~0ull, safe = 0; };
+
 // Where a per-contig pass gets its HitsExt from: get(contig, &ext) is called right before the contig's row stage and may block until the
 // caller has finished the contig's entries (*ext = nullptr: none).  A return value != 0 means the caller gave up: the search stops.
 struct HitsExtSource { std::function<int(int contig, const HitsExt** ext)> get; };
@@ -81,7 +89,8 @@ struct HitsExtSource { std::function<int(int contig, const HitsExt** ext)> get; 
 // final order.
 hipError_t hits_run(HitsWork** work, const HitsRef& ref, const RawAln* d_final, uint32_t n, const GuideDev* d_guides,
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& strings, int max_overlap, int score_hi,
-                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res, const HitsExt* ext = nullptr);
+                    int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res, const HitsExt* ext = nullptr,
+                    const HitsOwn* own = nullptr);
 void hits_destroy(HitsWork* work);
 
 }  // namespace calitas

@@ -135,6 +135,7 @@ struct MidArgs {
   uint32_t n_dev;            // order[k] >= n_dev: a hit the caller built (HitsExt) -- no row to build, its length comes from ext_off
   const uint64_t* ext_off;
   uint32_t* ext_kept;        // out: how many of those were kept
+  unsigned long long own_lo, own_hi;   // HitsOwn: rows only for hits with own_lo <= (contig << 32 | coordinate_start) < own_hi (0 / ~0: all)
 };
 
 static_assert(offsetof(RawAln, ops) % 4 == 0 && sizeof(RawAln) % 4 == 0, "RawAln::ops must be word aligned");

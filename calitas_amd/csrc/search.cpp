@@ -818,7 +818,15 @@ static uint64_t guide_hash(const GuideDev& g) {
   return h;
 }
 
-static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
+// binned_possible: the search is one the per-bin kernels take at all.  binned_remembered: ... but this very guide met a crowded bin on this
+// context before (a property of guide x reference: it would again).  binned_wanted: both considered -- what decides a lane's tail.
+static bool binned_remembered(calitas_ctx* lane, const SearchPlan& pl) {
+  const calitas_ctx* own = ref_owner(lane);
+  const GuideDev& g = pl.gd[0];
+  return own->bin_decl_pams == g.n_pams && own->bin_decl_L == g.L && g.min_guide_score <= own->bin_decl_min_score && own->bin_decl_guide == guide_hash(g);
+}
+
+static bool binned_possible(calitas_ctx* lane, const SearchPlan& pl) {
   const calitas_ctx* own = ref_owner(lane);
   if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0 || pl.general_tail) return false;
   if (!pl.owned && (pl.gw_lo != 0 || pl.gw_hi != ~0ull)) return false;   // (a window range of calitas_search: alignment records, no rows)
@@ -835,10 +843,10 @@ static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) {
   }
   if (!want) return false;
   if (pl.p.max_overlap < 1 || own->ref.contigs.size() >= (1u << 18) - 1) return false;
-  const GuideDev& g = pl.gd[0];
-  if (own->bin_decl_pams == g.n_pams && own->bin_decl_L == g.L && g.min_guide_score <= own->bin_decl_min_score && own->bin_decl_guide == guide_hash(g)) return false;
   return true;
 }
+
+static bool binned_wanted(calitas_ctx* lane, const SearchPlan& pl) { return binned_possible(lane, pl) && !binned_remembered(lane, pl); }
 
 // The per-call constants of a lane's row stage -- and the cleared scratch of the bins when the lane takes the binned tail --, queued on
 // its stream ahead of its kernels (callers that queue a wait for a scan on that stream do this first).
@@ -890,7 +898,7 @@ constexpr int kExtDeclined = -1001;     // (internal) a pass that brings hits of
 
 struct LaneText;
 static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, LaneText& lt, bool prepared,
-                            bool* declined, const LaneDest* dest = nullptr);
+                            bool* declined, const LaneDest* dest = nullptr, uint32_t* decline_flags = nullptr);
 
 // One lane from the scan stage (queued here, or already queued by the caller) to its finished rows.
 // hits_prepared: the caller queued hits_prepare on the lane's stream already -- *before* the stream's wait for the scan, so that
@@ -907,12 +915,24 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   uint64_t n_alns = 0;
   bool resume = false;
   lane->binned_late_check = false;
-  if (pl.owned && !binned_wanted(lane, pl)) return kOwnedDeclined;   // (the general kernels return whole windows, not a stretch's rows)
-  if (binned_wanted(lane, pl)) {
+  // A stretch (SearchPlan::owned) is the bins' to decide.  Where one of its bins is crowded -- the guide meets a repeat: more alignments
+  // than a wave holds -- the general kernels finish it from the same alignments and keep the rows the stretch owns (HitsOwn): exact
+  // unless a chain of overlapping hits reaches from the edge of the aligned context into the stretch, which they detect (HITS_FLAG_HALO)
+  // and which the bins' own halo flag says as well; then, and for anything else, the caller searches the touched contigs whole.
+  bool own_general = false;
+  if (pl.owned && !binned_possible(lane, pl)) return kOwnedDeclined;   // (no bins for this window size / forced off: the caller's whole-contig path)
+  if (pl.owned && binned_remembered(lane, pl)) {                        // this guide crowded a bin here before: the general kernels at once
+    if (std::getenv("CALITAS_OWN_GENERAL_OFF")) return kOwnedDeclined;
+    own_general = true;
+  } else if (binned_wanted(lane, pl)) {
     bool declined = false;
-    int rc = lane_rows_binned(lane, pl, prelaunched, rs, lt, hits_prepared, &declined, dest);
+    uint32_t why = 0;
+    int rc = lane_rows_binned(lane, pl, prelaunched, rs, lt, hits_prepared, &declined, dest, &why);
     if (rc || !declined) return rc;
-    if (pl.owned) return kOwnedDeclined;
+    if (pl.owned) {
+      if (why != BIN_FLAG_CROWDED || std::getenv("CALITAS_OWN_GENERAL_OFF")) return kOwnedDeclined;
+      own_general = true;
+    }
     // the bins declined: the raw alignments are where the general kernels expect them, the lane's counters in h_counters
     resume = true;
     hits_prepared = false;                                   // binned_run consumed the row constants
@@ -921,6 +941,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched, resume);
   if (rc) return rc;
   lt.tm = lane->timing;
+  if (own_general && !dev.valid) { calitas_free(alns); return kOwnedDeclined; }
   const HitsExt* ext = nullptr;             // the caller's own hits of this contig: asked for now, the search kernels of the pass are behind us
   if (ext_source && ext_source->get(ext_contig, &ext) != 0) { calitas_free(alns); return kExtDeclined; }
   if (ext && !dev.valid && n_alns == 0) {   // nothing of the reference's own on this contig: the row stage still places the caller's hits
@@ -941,18 +962,36 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       }
       HitsRef hr{own->d_codes, own->d_mask, own->d_runs, (int64_t)ref.runs.size(), own->d_contigs, (int)ref.contigs.size()};
       HitsResult res{};
+      HitsOwn ho;
+      if (own_general) {
+        // from where on every hit that could overlap is known: the first aligned window's start + a window (hits of the windows left of it
+        // end before that) + the longest hit; a context that starts with its contig knows everything
+        ho.lo = pl.own_lo; ho.hi = pl.own_hi;
+        uint64_t w0 = 0;
+        for (size_t c = 0; c < ref.contigs.size(); c++) {
+          const uint64_t nw = window_count(ref.contigs[c].len, pl.step);
+          if (pl.gw_lo < w0 + nw || c + 1 == ref.contigs.size()) {
+            const uint64_t pos = (pl.gw_lo - w0) * (uint64_t)pl.step;
+            ho.safe = pos == 0 ? ((uint64_t)c << 32) : (((uint64_t)c << 32) | (pos + (uint64_t)p.window_size + CALITAS_MAX_OPS));
+            break;
+          }
+          w0 += nw;
+        }
+      }
       HIP_TRY(lane, hipEventRecord(lane->ev[4], lane->stream));
       lane->rows_ev0 = 4;
       HIP_TRY(lane, hits_run(&lane->hits, hr, dev.d_final, dev.n_sel, lane->d_guides, own->d_win_base, own->d_win, rs, p.max_overlap, score_hi,
                              pl.gd[0].span + 1 + p.max_gaps_between_guide_and_pam + max_pam, dev.crowded ? 0u : (uint32_t)((p.window_size + pl.step - 1) / pl.step),
-                             lane->stream, &res, ext));
+                             lane->stream, &res, ext, own_general ? &ho : nullptr));
       HIP_TRY(lane, hipEventRecord(lane->ev[5], lane->stream));
       g_marks.mark("rows-queued");
       kernel_times(lane, lt.tm);          // while out_kernel runs
       if (res.flags == 0) {
         lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows;
+        if (own_general) lt.tm.owned_general_lanes = 1;
         return CALITAS_OK;
       }
+      if (own_general) return kOwnedDeclined;
       if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
     }
     if (ext) return kExtDeclined;       // (a contig without hits of the caller's needs no merge: any tail writes its text)
@@ -981,7 +1020,8 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
 // prepared: the caller queued hits_prepare and binned_prepare on the lane's stream already, ahead of its wait for the scan.
 // *declined: a bin was crowded / a repeat outran the halo / a lane buffer overflowed: nothing is lost, the general kernels take over.
 static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, const RowStrings& rs, LaneText& lt, bool prepared,
-                            bool* declined, const LaneDest* dest) {
+                            bool* declined, const LaneDest* dest, uint32_t* decline_flags) {
+  if (decline_flags) *decline_flags = 0;
   calitas_ctx* own = ref_owner(lane);
   const PackedRef& ref = own->ref;
   const calitas_params_t& p = pl.p;
@@ -1050,6 +1090,7 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
     }
     HIP_TRY(lane, calitas_spin_sync(lane->stream));          // the rows kernel returns at once; nothing of it may linger over the retry
     *declined = true;
+    if (decline_flags) *decline_flags = overflow ? ~0u : (flags & ~BIN_FLAG_TEXT);
     return CALITAS_OK;
   }
   uint64_t bytes = (uint64_t)lane->mbox.host[BIN_BOX_BYTES] | ((uint64_t)lane->mbox.host[BIN_BOX_BYTES + 1] << 32);
@@ -1421,7 +1462,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
     tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
     tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries; tm.hits_copy_ms += lt.tm.hits_copy_ms;
-    tm.binned_lanes += lt.tm.binned_lanes;
+    tm.binned_lanes += lt.tm.binned_lanes; tm.owned_general_lanes += lt.tm.owned_general_lanes;
     {
       std::lock_guard<std::mutex> lk(mu);
       sl.state = 0;
@@ -1774,7 +1815,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   if (rc) return rc;
   const PackedRef& ref = ctx->ref;
   const SearchPlan whole = pl;
-  if (owned && (!plan_owned_range(ctx, pl, owned[0], owned[1]) || !binned_wanted(ctx, pl))) { if (owned_declined) *owned_declined = true; return CALITAS_OK; }
+  if (owned && (!plan_owned_range(ctx, pl, owned[0], owned[1]) || !binned_possible(ctx, pl))) { if (owned_declined) *owned_declined = true; return CALITAS_OK; }
   // The constant pieces of a row.  A chunked search builds them after its scans are queued: nothing on the device needs them before
   // the first range's rows, and the first scan should not wait for string formatting on the host.
   std::string version, stamp;
@@ -1823,7 +1864,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       const uint64_t end = c + 1 == weights.size() ? owned[0] + owned[1] : owned[0] + (uint64_t)((double)owned[1] * acc / wsum);
       if (end <= first) continue;
       SearchPlan q = whole;
-      if (!plan_owned_range(ctx, q, first, end - first) || !binned_wanted(ctx, q)) { if (owned_declined) *owned_declined = true; return CALITAS_OK; }
+      if (!plan_owned_range(ctx, q, first, end - first) || !binned_possible(ctx, q)) { if (owned_declined) *owned_declined = true; return CALITAS_OK; }
       owned_plans.push_back(q);
       first = end;
     }
@@ -2101,7 +2142,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
     tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
     tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries;
-    tm.hits_kernel_ms += lt.tm.hits_kernel_ms; tm.hits_copy_ms += lt.tm.hits_copy_ms; tm.binned_lanes += lt.tm.binned_lanes;
+    tm.hits_kernel_ms += lt.tm.hits_kernel_ms; tm.hits_copy_ms += lt.tm.hits_copy_ms; tm.binned_lanes += lt.tm.binned_lanes; tm.owned_general_lanes += lt.tm.owned_general_lanes;
   }
   text[total] = 0;
   tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = (uint32_t)parts.size();
@@ -2181,7 +2222,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
     if (params->first_window < 0 || params->n_windows <= 0 || (uint64_t)params->first_window + (uint64_t)params->n_windows > plans[0].win_n)
       return fail(ctx, CALITAS_EINVAL, "first_window / n_windows outside the window table (" + std::to_string(plans[0].win_n) + " windows)");
     for (int i = 0; i < n_guides; i++)
-      owned_ok[(size_t)i] = plan_owned_range(ctx, plans[i], (uint64_t)params->first_window, (uint64_t)params->n_windows) && binned_wanted(ctx, plans[i]);
+      owned_ok[(size_t)i] = plan_owned_range(ctx, plans[i], (uint64_t)params->first_window, (uint64_t)params->n_windows) && binned_possible(ctx, plans[i]);
   }
   int rc = ensure_lanes(ctx, (size_t)n_lanes);
   if (rc) return rc;
@@ -2270,7 +2311,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
     tm.scan_kernel_ms += t.scan_kernel_ms; tm.align_kernel_ms += t.align_kernel_ms; tm.gpu_total_ms += t.gpu_total_ms;
     tm.bases_scanned += t.bases_scanned; tm.packed_bytes += t.packed_bytes; tm.scan_records += t.scan_records;
     tm.candidate_columns += t.candidate_columns; tm.raw_alignments += t.raw_alignments; tm.accepted_alignments += t.accepted_alignments;
-    tm.retries += t.retries; tm.hit_rows += t.hit_rows; tm.hits_bytes += t.hits_bytes; tm.binned_lanes += t.binned_lanes;
+    tm.retries += t.retries; tm.hit_rows += t.hit_rows; tm.hits_bytes += t.hits_bytes; tm.binned_lanes += t.binned_lanes; tm.owned_general_lanes += t.owned_general_lanes;
   }
   tm.lanes = (uint32_t)n_lanes;
   ctx->timing = tm;

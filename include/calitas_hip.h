@@ -131,6 +131,9 @@ typedef struct {
   uint32_t contig_passes;        /* calitas_search_hits in one-pass-per-contig mode: passes run (0 otherwise) */
   uint32_t binned_lanes;         /* calitas_search_hits*: contig ranges / passes / guides whose tail (per-window filter ... rows) ran on the
                                   * per-bin kernels (binned.hpp); the others ran on the general kernels (same text) */
+  uint32_t owned_general_lanes;  /* a window range (first_window / n_windows): pieces whose bins were crowded and whose owned rows the general
+                                  * kernels decided from the same alignments (round 4; before, such a range searched its contigs whole) */
+  uint32_t reserved;
 } calitas_timing_t;
 
 /* Context ------------------------------------------------------------------------------------------------------- */

@@ -228,7 +228,10 @@ def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts
     unit = b"CTTGCCCCACAGGGCAGTAATGG"
     for k in range(12):
         cb[22 * step - 70 + 9 * k: 22 * step - 70 + 9 * k + len(unit)] = unit
-    cc = planted(rng, lc, [(int(p), 1, False) for p in rng.integers(200, lc - 200, size=10)])
+    cc = bytearray(planted(rng, lc, [(int(p), 1, False) for p in rng.integers(200, lc - 200, size=10)]).encode())
+    for k in range(110):                                       # a crowded bin without a chain: 110 separate copies of the site, 30 bases apart
+        cc[12000 + 30 * k: 12000 + 30 * k + len(unit)] = unit
+    cc = cc.decode()
     fa = write_fasta(str(tmp_path / "ranges.fa"), [("a", ca), ("b", cb.decode()), ("c", cc), ("d", "ACGT" * 20)])
     lengths = [la, lb, lc, 80]
     n_win = sum(shard.window_counts(lengths, step))
@@ -241,7 +244,10 @@ def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts
         # cut points: equal parts, one moved onto the chain of contig b, one onto a contig boundary
         wa = shard.window_counts(lengths, step)[0]
         bounds = sorted(set([0, n_win] + [n_win * i // cuts for i in range(1, cuts)] + ([wa + 22] if cuts > 2 else []) + ([wa] if cuts > 3 else [])))
-        for mode in ("default", "general", "two lanes", "three lanes"):
+        seen_own_general = 0
+        for mode in ("default", "general", "two lanes", "three lanes", "whole contigs"):
+            if mode == "whole contigs":                          # round 3's answer to a crowded bin of a stretch: the touched contigs searched whole
+                monkeypatch.setenv("CALITAS_OWN_GENERAL_OFF", "1")
             if mode == "general":
                 monkeypatch.setenv("CALITAS_BINNED", "0")        # the fallback: whole contigs on the general kernels, rows filtered by position
             if mode.endswith("lanes"):                           # the range cut once more into pipelined pieces, as a rank's share of a large genome is
@@ -252,9 +258,17 @@ def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts
                 head, _, body = text.partition("\n")
                 assert head + "\n" == whole[:len(head) + 1]
                 pieces.append(body); rows += n
+                tm = ctx.timing()
+                if mode == "default":
+                    seen_own_general += tm["owned_general_lanes"]
+                if mode == "whole contigs":
+                    assert tm["owned_general_lanes"] == 0
+            monkeypatch.delenv("CALITAS_OWN_GENERAL_OFF", raising=False)
             monkeypatch.delenv("CALITAS_BINNED", raising=False)
             monkeypatch.delenv("CALITAS_CHUNKS", raising=False)
             assert rows == n_whole and whole == whole[:whole.index("\n") + 1] + "".join(pieces), (mode, bounds)
+        # the stretch that holds the crowded bin of contig c was finished by the general kernels from the bins' alignments, owned rows only
+        assert seen_own_general >= 1
         # calitas_search_hits_batch on a window range (BASELINE config 4 on several GPUs: every process runs all guides on its stretch):
         # per guide the text of calitas_search_hits on the same range -- on the per-bin kernels and, where the bins decline a stretch (the
         # chain of tandem copies of contig b lies on a cut), through the per-guide fallback
