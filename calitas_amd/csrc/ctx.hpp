@@ -141,12 +141,12 @@ int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_
 // Host waits on the critical path poll instead of blocking: a call has four of them per lane and a blocking wait adds tens of
 // microseconds of wake-up latency each.
 // (After a few thousand polls the thread yields between polls, so an oversubscribed host is not starved by waiting lanes.)
+// (Spinning for ~50 us, then yielding the core, then sleeping between polls: mailbox.hpp, Backoff.)
 template <typename Q>
 inline hipError_t calitas_poll(Q query) {
   hipError_t e;
-  for (unsigned spins = 0; (e = query()) == hipErrorNotReady; spins++) {
-    if (spins < 4096) __builtin_ia32_pause(); else sched_yield();
-  }
+  Backoff wait;
+  while ((e = query()) == hipErrorNotReady) wait.pause();
   return e;
 }
 inline hipError_t calitas_spin_sync(hipStream_t s) { return calitas_poll([s] { return hipStreamQuery(s); }); }

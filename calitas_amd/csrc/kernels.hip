@@ -803,19 +803,19 @@ hipError_t mailbox_wait(Mailbox& mb, hipStream_t stream) {
   // Bounded: a kernel that never finishes would otherwise leave the caller (and every lane thread) spinning for good.  The limit is far
   // beyond any legitimate wait (the longest device stage of a PAM-less whole-genome pass is under a second).
   constexpr double kDeadlineSeconds = 120.0;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 0; mb.host[0] != mb.seq; spins++) {
-    if ((spins & 0x3FF) == 0x3FF) {            // now and then: is the stream still alive?
+  Backoff wait;
+  long long next_check_us = 200;               // now and then: is the stream still alive?
+  while (mb.host[0] != mb.seq) {
+    wait.pause();
+    if (wait.spins >= 256 && wait.waited_us() >= next_check_us) {
+      next_check_us = wait.waited_us() + 200;
       const hipError_t e = hipStreamQuery(stream);
       if (e != hipSuccess && e != hipErrorNotReady) return e;
       if (e == hipSuccess && mb.host[0] != mb.seq) {      // everything queued has run, yet nothing arrived
         if (mb.host[0] == mb.seq) break;
         return hipErrorUnknown;
       }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kDeadlineSeconds) return hipErrorLaunchTimeOut;
-      if (spins > (1u << 16)) sched_yield();
-    } else {
-      __builtin_ia32_pause();
+      if ((double)wait.waited_us() * 1e-6 > kDeadlineSeconds) return hipErrorLaunchTimeOut;
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);

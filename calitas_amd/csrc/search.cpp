@@ -1171,7 +1171,10 @@ struct LaneThreads {
             if (i >= k) continue;
           }
           guarded([&] { job(i); });
-          remaining.fetch_sub(1, std::memory_order_release);
+          if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {   // the last lane: wake a caller that has stopped spinning
+            { std::lock_guard<std::mutex> lk(m); }
+            done_cv.notify_all();
+          }
         }
       });
     }
@@ -1180,9 +1183,13 @@ struct LaneThreads {
     { std::lock_guard<std::mutex> lk(m); job = std::move(fn); k = lanes; remaining.store(lanes - 1, std::memory_order_relaxed); threw.store(false, std::memory_order_relaxed); gen++; }
     cv.notify_all();
   }
-  void wait() {                                    // polls: the last lane to finish is the end of the call
-    for (unsigned spins = 0; remaining.load(std::memory_order_acquire) != 0; spins++) {
-      if (spins < (1u << 16)) __builtin_ia32_pause(); else sched_yield();
+  std::condition_variable done_cv;
+  void wait() {                                    // the last lane to finish is the end of the call: spin for it ~50 us, then sleep until it says so
+    Backoff spin;
+    while (remaining.load(std::memory_order_acquire) != 0) {
+      if (spin.spins < 256 || spin.waited_us() < 50) { spin.pause(); continue; }
+      std::unique_lock<std::mutex> lk(m);
+      done_cv.wait(lk, [&] { return remaining.load(std::memory_order_acquire) == 0; });
     }
   }
 };
