@@ -162,7 +162,7 @@ def main():
     def ns_of(c):
         return sum(n * rate_of(op, rates) for op, n in c.items())
     strands = []
-    for hb in d2[:2]:
+    for hb in d2:
         h2 = hb["label"]
         inner = {b["label"]: b for b in blocks if b["depth"] == 2 and b["header"] == h2}
         # one iteration = the cheapest way around the loop: the row's base selects one of the alternatives (A / C / G / T, or a set of
@@ -198,6 +198,11 @@ def main():
             add(rest, census(outer[lb]["ops"]))
         strands.append({"row_loop_header": h2, "guide_loop_header": h1, "row_iteration_path": path, "row_iteration": row, "row_iteration_alternatives": alternatives,
                         "guide_strand_path": opath, "guide_strand_rest": rest, "row_loop_blocks": first_inner})
+    # the kernel holds the row loops twice per strand: for plain tiles and for tiles with exception bases in the text (N runs' edges,
+    # contig ends, IUPAC codes: 392 of 23 616 tiles of the hg38-sized genome), whose Eq needs a third plane.  Priced: the plain pair.
+    strands.sort(key=lambda s_: ns_of(s_["row_iteration"]))
+    masked = strands[2:]
+    strands = strands[:2]
     words = a.nw + a.nwarm
     once = {}
     for b in blocks:                                          # outside every loop: staging, the reverse strand's planes, the flush of the records
@@ -211,6 +216,8 @@ def main():
            "ns_per_word_row": [round(ns(s["row_iteration"]) / words, 3) for s in strands],
            "guide_strand_rest_ns": [round(ns(s["guide_strand_rest"]), 2) for s in strands],
            "once_per_wave": once, "once_per_wave_ns": round(ns(once), 2),
+           "tiles_with_exception_bases": {"row_iteration_ns": [round(ns(s["row_iteration"]), 2) for s in masked],
+                                          "valu_per_row_iteration": [sum(s["row_iteration"].values()) for s in masked]},
            "valu_per_row_iteration": [sum(s["row_iteration"].values()) for s in strands]}
     with open(a.output, "w") as f:
         json.dump(out, f, indent=1)
