@@ -58,7 +58,7 @@ class TimingT(ctypes.Structure):
 
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
-           "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases",
+           "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases", "calitas_expand_rows",
            "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_into", "calitas_pin_host", "calitas_unpin_host", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_scan_candidates_columnwise", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version"]
 
@@ -84,6 +84,9 @@ lib.calitas_reference_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_
                                        ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_contig_name.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_fetch_bases.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
+if hasattr(lib, "calitas_expand_rows"):   # (an older build behind CALITAS_LIB_PATH, for A/B runs, does not have it)
+    lib.calitas_expand_rows.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p,
+                                        ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_window_table.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.POINTER(ctypes.c_uint64)]
 lib.calitas_search.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(GuideT), ctypes.POINTER(ParamsT),

@@ -462,6 +462,19 @@ int calitas_contig_name(const calitas_ctx* ctx, int32_t i, const char** name, ui
   return CALITAS_OK;
 }
 
+int calitas_expand_rows(calitas_ctx* ctx, const char* compact, uint64_t n, uint64_t rows, const char* head, const char* tail, char* out,
+                        uint64_t out_capacity, uint64_t* written) {
+  if (!ctx) return CALITAS_EINVAL;
+  if ((!compact && n) || !head || !tail || !out || !written) return fail(ctx, CALITAS_EINVAL, "NULL argument");
+  const std::string h(head), t(tail);
+  if (t.empty() || t.back() != '\n') return fail(ctx, CALITAS_EINVAL, "the tail of a row ends with a newline");
+  if (out_capacity < n + rows * (uint64_t)(h.size() + t.size() - 1)) return fail(ctx, CALITAS_EINVAL, "out is too small");
+  const size_t w = expand_rows(compact, (size_t)n, rows, h, t, out, ctx->pool);
+  if (w == (size_t)-1) return fail(ctx, CALITAS_EINVAL, "the compact text does not hold exactly the given number of newline-terminated rows");
+  *written = w;
+  return CALITAS_OK;
+}
+
 int calitas_fetch_bases(const calitas_ctx* ctx, int32_t i, uint64_t start, uint32_t len, char* out) {
   if (!ctx || !ctx->has_ref || i < 0 || i >= (int32_t)ctx->ref.contigs.size() || !out) return CALITAS_EINVAL;
   const ContigInfo& c = ctx->ref.contigs[i];

@@ -48,6 +48,15 @@ struct RowStrings {
 RowStrings make_row_strings(const PackedRef& ref, const GuideHost& g, const std::string& guide_id, const calitas_params_t& p,
                             const std::string& version, const std::string& time_stamp);
 
+// Compact rows.  270 of a row's ~520 bytes are the same in every row of a call: head (guide_id, protospacer, genome_build) and tail
+// (aligner ... time_stamp, ReferenceHit.scala:99-132).  Given row constants with an empty head and "\n" for a tail, the device's row
+// kernels write `chromosome \t middle \n` per row -- the same kernels, half the bytes over PCIe -- and the library puts head and tail
+// back on the host's worker pool while the next text is on the bus.
+RowStrings compact_row_strings(const RowStrings& full);
+// n bytes of compact rows (`rows` of them) -> full rows at out, which has room for n + rows * (head.size() + tail.size() - 1) bytes.
+// Returns the bytes written, or (size_t)-1 when the text does not hold exactly `rows` newline-terminated rows.
+size_t expand_rows(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail, char* out, WorkerPool* pool);
+
 // Text of the row of ext[e] (without the newline), for hits whose calitas_ext_hit_t::row is NULL: called from the worker pool, only for
 // the hits removeOverlaps kept -- a caller with millions of hits of its own (the variant branch) builds no text for the ones that go.
 typedef void (*ExtRowFn)(void* user, uint64_t e, std::string& row);

@@ -2224,6 +2224,11 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < n_guides; i++) { int rc = ensure_bin_base(ctx, plans[i], ctx->stream); if (rc) return rc; }
+  // Which tail: every guide's tail runs beside the scans of the guides behind it, where the per-bin kernels cost the scans more than
+  // they save the tail (binned_possible: the three-range call's finding) -- the general kernels, then, unless the batch
+  // runs on a stretch, which only the bins can own.  (Round 3 got there by accident: the first guide that crowded a bin switched the
+  // bins off for every guide behind it; with the decline remembered per guide the batch took 328 instead of 295 ms per 96 guides.)
+  if (!ranged && !std::getenv("CALITAS_BATCH_BINNED")) for (auto& q : plans) q.three_ranges = true;
   std::vector<char> owned_ok((size_t)n_guides, 1);
   if (ranged) {
     if (params->first_window < 0 || params->n_windows <= 0 || (uint64_t)params->first_window + (uint64_t)params->n_windows > plans[0].win_n)
@@ -2240,6 +2245,9 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   const PackedRef& ref = ctx->ref;
   std::mutex scan_mu, copy_mu;
   const bool device_rows = !std::getenv("CALITAS_HOST_HITS");
+  std::atomic<uint64_t> expand_us{0};                           // lane threads' time in expand_rows (their turn on the pool included)
+  bool compact_rows = device_rows;
+  if (const char* e = std::getenv("CALITAS_COMPACT_ROWS")) compact_rows = compact_rows && std::atoi(e) != 0;
   std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
   std::vector<std::string> errs((size_t)n_guides);   // a failed guide's message, kept apart from its lane (a retry below destroys the lanes)
   std::vector<calitas_timing_t> tms((size_t)n_guides);
@@ -2254,7 +2262,10 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
         const SearchPlan& pl = plans[g];
         if (!owned_ok[(size_t)g]) { rcs[g] = kOwnedDeclined; continue; }   // (the stretch is not one for the bins: below, one guide at a time)
         const std::string gid = guide_ids && guide_ids[g] ? guide_ids[g] : "";
-        const RowStrings rs = make_row_strings(ref, pl.gh[0], gid, pl.p, version, stamp);
+        const RowStrings rs_full = make_row_strings(ref, pl.gh[0], gid, pl.p, version, stamp);
+        // the device writes compact rows (post.hpp): a batch is bound by its texts on the bus (15.3 GB per 96 guides on an hg38-sized
+        // genome), and 270 of a row's ~520 bytes are the call's constants
+        const RowStrings rs = compact_rows ? compact_row_strings(rs_full) : rs_full;
         auto step = [&]() -> int {
           {
             // the previous guide of this lane is completely done (its text was copied before the loop went on), so the
@@ -2268,12 +2279,25 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
           LaneText lt;
           int r = lane_rows(lane, pl, true, rs, gid, version, stamp, lt, device_rows);
           if (r) return r;
-          const size_t hlen = rs.header.size(), total = hlen + (size_t)lt.bytes;
-          char* text = (char*)calitas_out_alloc_pinned(total + 1);
+          const bool expand = compact_rows && !lt.on_host;       // (rows the host stages built are whole already)
+          const size_t add = rs_full.head.size() + rs_full.tail.size() - 1;
+          const size_t hlen = rs.header.size(), total = hlen + (size_t)lt.bytes + (expand ? (size_t)lt.rows * add : 0);
+          char* text = (char*)(expand ? calitas_out_alloc(total + 1) : calitas_out_alloc_pinned(total + 1));
           if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
           std::memcpy(text, rs.header.data(), hlen);
           if (lt.bytes && lt.on_host) std::memcpy(text + hlen, lt.host_rows.data(), (size_t)lt.bytes);
-          else if (lt.bytes) {
+          else if (lt.bytes && expand) {
+            char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.bytes);
+            if (!staging) { calitas_free(text); return fail(lane, CALITAS_EINVAL, "out of memory"); }
+            int cr = text_to_host(ctx, lane, staging, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+            size_t wrote = 0;
+            const auto t_exp = std::chrono::steady_clock::now();
+            if (!cr) wrote = expand_rows(staging, (size_t)lt.bytes, lt.rows, rs_full.head, rs_full.tail, text + hlen, ctx->pool);
+            expand_us.fetch_add((uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_exp).count());
+            calitas_free(staging);
+            if (cr) { calitas_free(text); return cr; }
+            if (wrote != total - hlen) { calitas_free(text); return fail(lane, CALITAS_EHIP, "the compact rows of a guide do not expand to the row count the device reported (internal error)"); }
+          } else if (lt.bytes) {
             int cr = text_to_host(ctx, lane, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
             if (cr) { calitas_free(text); return cr; }
           }
@@ -2323,8 +2347,8 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   tm.lanes = (uint32_t)n_lanes;
   ctx->timing = tm;
   if (std::getenv("CALITAS_TRACE"))
-    std::fprintf(stderr, "[calitas] search_hits_batch: %d guides on %d lanes, scan %.3f ms, align %.3f ms (sums), call %.3f ms (%llu rows, %llu bytes)\n",
-                 n_guides, n_lanes, tm.scan_kernel_ms, tm.align_kernel_ms,
+    std::fprintf(stderr, "[calitas] search_hits_batch: %d guides on %d lanes, scan %.3f ms, align %.3f ms, rows expanded on the host %.3f ms (sums), call %.3f ms (%llu rows, %llu bytes)\n",
+                 n_guides, n_lanes, tm.scan_kernel_ms, tm.align_kernel_ms, (double)expand_us.load() * 1e-3,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),
                  (unsigned long long)tm.hit_rows, (unsigned long long)tm.hits_bytes);
   return CALITAS_OK;

@@ -166,6 +166,15 @@ const char* calitas_genome_build(const calitas_ctx* ctx);
  * toUpperCase, ReferenceHit.scala:261-266); out must hold len bytes. */
 int calitas_fetch_bases(const calitas_ctx* ctx, int32_t contig_index, uint64_t start, uint32_t len, char* out);
 
+/* Test hook without a reference counterpart: the host half of the compact rows calitas_search_hits_batch moves over PCIe (round 4).  A
+ * row of hits.txt is head | chromosome \t middle | tail with head (guide_id, unpadded_guide_sequence, genome_build) and tail (aligner ..
+ * time_stamp, ReferenceHit.scala:99-132) the same for every row of a call; the device writes `chromosome \t middle \n` per row and
+ * the library puts head and tail back on its worker pool.  compact[0..n): `rows` such rows; out: room for n + rows * (strlen(head) +
+ * strlen(tail) - 1) bytes (out_capacity is checked).  *written receives the bytes written.  CALITAS_EINVAL when the text does not hold
+ * exactly `rows` newline-terminated rows or out is too small.  ctx may be a host-only context (its worker pool is used). */
+int calitas_expand_rows(calitas_ctx* ctx, const char* compact, uint64_t n, uint64_t rows, const char* head, const char* tail, char* out,
+                        uint64_t out_capacity, uint64_t* written);
+
 /* Window table of windowIterator (SearchReference.scala:39-71) after the length filter (SearchReference.scala:536):
  * rows of (contig_index, start0, end0) with N-trimmed 0-based half-open bounds.  Caller frees *out. */
 int calitas_window_table(const calitas_ctx* ctx, int32_t window_size, int32_t step, int32_t min_length, int32_t chrom_index,

@@ -287,3 +287,31 @@ def test_rank_cpus_from_a_sysfs_tree(tmp_path):
     assert set(shard.rank_cpus(0, 2, allowed, str(root), visible=[4, 5])) <= set(range(16, 32)) | set(range(80, 96))
     # no KFD topology (this container): nothing to do
     assert shard.gpu_numa_nodes(str(tmp_path / "nowhere")) == [] and shard.rank_cpus(0, 2, allowed, str(tmp_path / "nowhere")) is None
+
+
+def test_expand_rows_puts_head_and_tail_back():
+    """calitas_expand_rows (the host half of the compact rows a guide batch moves over PCIe): `chromosome \\t middle \\n` per row becomes
+    head | chromosome \\t middle | tail, on one thread (small texts) and on the worker pool (rows cut at arbitrary byte boundaries between
+    the workers); a text that does not hold the stated number of rows is refused."""
+    import ctypes
+    import numpy as np
+    import calitas_amd as C
+    from calitas_amd import _lib
+    ctx = C.Context(-1)
+    try:
+        rng = np.random.default_rng(3)
+        head, tail = b"guide-7\tACGTACGTACGTACGTACGT\tbuild-x\t", b"CALITAS:SearchReference\tv\tnrg\tmax-guide-diffs=5;window-size=1000\tstamp\n"
+        for n_rows in (0, 1, 7, 40000):
+            rows = [b"chr%d\t%d\t%s" % (int(rng.integers(1, 23)), int(rng.integers(0, 10 ** 8)), b"x" * int(rng.integers(1, 240))) for _ in range(n_rows)]
+            compact = b"".join(r + b"\n" for r in rows)
+            want = b"".join(head + r + tail for r in rows)
+            out = ctypes.create_string_buffer(len(want) + 1)
+            written = ctypes.c_uint64()
+            rc = _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows, head, tail, out, len(want), ctypes.byref(written))
+            assert rc == 0 and written.value == len(want) and out.raw[:len(want)] == want, n_rows
+            if n_rows:
+                assert _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows + 1, head, tail, out, len(want) + 200, ctypes.byref(written)) != 0
+                assert _lib.lib.calitas_expand_rows(ctx._h, compact[:-1], len(compact) - 1, n_rows, head, tail, out, len(want), ctypes.byref(written)) != 0
+                assert _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows, head, tail, out, len(want) - 1, ctypes.byref(written)) != 0
+    finally:
+        ctx.close()
