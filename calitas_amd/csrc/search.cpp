@@ -790,6 +790,7 @@ struct LaneText {
   int rc = CALITAS_OK;
   const char* d_text = nullptr;
   uint64_t bytes = 0, rows = 0;
+  uint64_t compact_bytes = 0;          // != 0: the device holds compact rows (post.hpp) of that many bytes; `bytes` is what they expand to
   bool on_host = false;
   bool in_place = false;               // the rows kernel wrote the text to its final place in the caller's page-locked buffer (LaneDest)
   std::string host_rows;
@@ -1826,13 +1827,19 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   // The constant pieces of a row.  A chunked search builds them after its scans are queued: nothing on the device needs them before
   // the first range's rows, and the first scan should not wait for string formatting on the host.
   std::string version, stamp;
-  RowStrings rs;
+  RowStrings rs, rs_compact;
   size_t hlen = 0;
   auto make_rows = [&] {
     calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
     rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+    rs_compact = compact_row_strings(rs);
     hlen = rs.header.size();
   };
+  // Compact rows (post.hpp) for the ranges of a chunked call whose text is copied while later ranges are still at work: half the bytes
+  // on the bus, head and tail put back by the worker pool.  Not the last range: nothing hides its expansion, and where the per-bin
+  // kernels run its rows kernel writes the text straight to its final place.
+  std::vector<char> lane_compact;
+  auto rs_lane = [&](size_t c) -> const RowStrings& { return c < lane_compact.size() && lane_compact[c] ? rs_compact : rs; };
   const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -1920,6 +1927,18 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       lt.tm.hits_kernel_ms = rows_stage_ms(lane, lt.tm);
       return CALITAS_OK;
     }
+    if (lt.compact_bytes) {                                    // compact rows: over the bus into a staging block, head and tail put back on the pool
+      char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.compact_bytes);
+      if (!staging) return fail(lane, CALITAS_EINVAL, "out of memory");
+      int r = text_to_host(ctx, lane, staging, lt.d_text, (size_t)lt.compact_bytes, &copy_mu, &lt.tm.hits_copy_ms);
+      size_t wrote = 0;
+      if (!r) wrote = expand_rows(staging, (size_t)lt.compact_bytes, lt.rows, rs.head, rs.tail, text + hlen + offset, ctx->pool);
+      calitas_free(staging);
+      if (r) return r;
+      if (wrote != (size_t)lt.bytes) return fail(lane, CALITAS_EHIP, "a lane's compact rows do not expand to the row count the device reported (internal error)");
+      lt.tm.hits_kernel_ms = rows_stage_ms(lane, lt.tm);
+      return CALITAS_OK;
+    }
     int r = text_to_host(ctx, lane, text + hlen + offset, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
     if (r) return r;
     lt.tm.hits_kernel_ms = rows_stage_ms(lane, lt.tm);   // recorded around hits_run by lane_rows
@@ -1955,6 +1974,12 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     rc = ensure_window_table(ctx, pl, ctx->scan_stream);
     if (rc) return rc;
     const bool device_rows = !std::getenv("CALITAS_HOST_HITS");
+    {
+      bool compact_on = device_rows;
+      if (const char* e = std::getenv("CALITAS_COMPACT_ROWS")) compact_on = compact_on && std::atoi(e) != 0;
+      lane_compact.assign(K, 0);
+      for (size_t c = 0; c + 1 < K; c++) lane_compact[c] = compact_on ? 1 : 0;
+    }
     // (no early return inside this loop: the scans of the earlier lanes are already in flight and every exit waits for them)
     auto hip_rc = [&](hipError_t e, const char* what) {
       if (e == hipSuccess) return (int)CALITAS_OK;
@@ -1991,7 +2016,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       // the later ranges: scan inputs and row constants in one launch on the range's own stream, then its scan behind the event
       for (size_t c = 1; c < K && !rc; c++) {
         one = false;
-        if (device_rows_early) rc = queue_lane_setup(lanes[c], plans[c], &rs, lanes[c]->stream, &one);
+        if (device_rows_early) rc = queue_lane_setup(lanes[c], plans[c], &rs_lane(c), lanes[c]->stream, &one);
         if (!rc && one) rows_queued[c] = 1;
         if (!rc && !one) rc = queue_scan_inputs(lanes[c], plans[c], lanes[c]->stream);
         if (!rc) rc = hip_rc(hipEventRecord(lanes[c]->inputs_ready, lanes[c]->stream), "hipEventRecord");
@@ -2003,7 +2028,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       // ... and the first range's row constants (its tail starts when its scan ends)
       if (!rc && device_rows_early) {
         one = false;
-        rc = queue_lane_setup(lanes[0], plans[0], &rs, lanes[0]->stream, &one, false);
+        rc = queue_lane_setup(lanes[0], plans[0], &rs_lane(0), lanes[0]->stream, &one, false);
         if (!rc && one) rows_queued[0] = 1;
         if (rc) ctx->err = lanes[0]->err;
       }
@@ -2020,7 +2045,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     }
     for (size_t c = 0; c < K && !rc; c++) {
       // the row constants of a range go onto its stream before the wait for its scan: in place while the scan runs
-      if (device_rows && !rows_queued[c]) rc = hip_rc(queue_row_constants(lanes[c], plans[c], rs), "hits_prepare");
+      if (device_rows && !rows_queued[c]) rc = hip_rc(queue_row_constants(lanes[c], plans[c], rs_lane(c)), "hits_prepare");
       if (!rc) rc = hip_rc(hipStreamWaitEvent(lanes[c]->stream, lanes[c]->scan_done, 0), "hipStreamWaitEvent");
     }
     g_marks.mark("rows-prepared");
@@ -2058,7 +2083,11 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
           *dst = text_dev + hlen + before; *cap = capacity - before;
           return true;
         };
-        lt.rc = lane_rows(lanes[c], plans[c], true, rs, guide_id, version, stamp, lt, device_rows, c + 1 == K && device_rows ? &dest : nullptr);
+        lt.rc = lane_rows(lanes[c], plans[c], true, rs_lane(c), guide_id, version, stamp, lt, device_rows, c + 1 == K && device_rows ? &dest : nullptr);
+        if (lt.rc == CALITAS_OK && lane_compact[c] && !lt.on_host && !lt.in_place && lt.bytes) {   // what the lanes behind it place their text by: the expanded size
+          lt.compact_bytes = lt.bytes;
+          lt.bytes += lt.rows * (uint64_t)(rs.head.size() + rs.tail.size() - 1);
+        }
         size_t offset = 0;
         bool ok = lt.rc == CALITAS_OK;
         {
@@ -2228,7 +2257,8 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   // they save the tail (binned_possible: the three-range call's finding) -- the general kernels, then, unless the batch
   // runs on a stretch, which only the bins can own.  (Round 3 got there by accident: the first guide that crowded a bin switched the
   // bins off for every guide behind it; with the decline remembered per guide the batch took 328 instead of 295 ms per 96 guides.)
-  if (!ranged && !std::getenv("CALITAS_BATCH_BINNED")) for (auto& q : plans) q.three_ranges = true;
+  // (A reference below 2 Gb keeps the bins, as a single call on it does: fewer launches, and its scans are short.)
+  if (!ranged && ctx->ref.total_bases >= (2048ull << 20) && !std::getenv("CALITAS_BATCH_BINNED")) for (auto& q : plans) q.three_ranges = true;
   std::vector<char> owned_ok((size_t)n_guides, 1);
   if (ranged) {
     if (params->first_window < 0 || params->n_windows <= 0 || (uint64_t)params->first_window + (uint64_t)params->n_windows > plans[0].win_n)

@@ -253,8 +253,13 @@ def test_window_ranges_of_calitas_search_concatenate_to_the_whole_call(C, tmp_pa
                 body += text.split("\n", 1)[1]
                 rows += nr
             assert want_text[0].split("\n", 1)[0] + "\n" + body == want_text[0] and rows == want_text[1], cuts
-        with pytest.raises(C.CalitasError, match="window range"):          # the stream and batch calls refuse a range
-            ctx.search_hits_batch([G, G], ["a", "b"], C.make_params(first_window=0, n_windows=10, **kw), "v0", "stamp")
+        # the batch call takes a range since round 4 (every guide's rows of the stretch); the stream call refuses one
+        pr = C.make_params(first_window=0, n_windows=10, **kw)
+        assert ctx.search_hits_batch([G, G], ["a", "b"], pr, "v0", "stamp")[0] == ctx.search_hits(G, "a", pr, "v0", "stamp")
+        with pytest.raises(C.CalitasError, match="window range"):
+            ctx.search_hits_stream(G, "a", pr, lambda piece: None, "v0", "stamp")
+        with pytest.raises(C.CalitasError, match="outside the window table"):
+            ctx.search_hits_batch([G, G], ["a", "b"], C.make_params(first_window=total - 5, n_windows=10, **kw), "v0", "stamp")
         with pytest.raises(C.CalitasError, match="outside the window table"):
             ctx.search([G], C.make_params(first_window=total - 5, n_windows=10, **kw))
     finally:
