@@ -1857,7 +1857,11 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     if (weights.size() == 1) { int k = std::max(1, std::min(16, (int)weights[0])); weights.assign((size_t)k, 1.0); }
     for (double w : weights) if (!(w > 0)) { weights.clear(); break; }
   } else if ((owned ? owned[1] * (uint64_t)pl.step : ref.total_bases) >= (2048ull << 20)) {
-    weights = {5, 3, 2};   // measured on hg38-sized input: the last range small, its tail is what nothing hides
+    // measured on hg38-sized input: the last range small, its tail is what nothing hides.  5:3:2 while all of the text
+    // crossed the bus behind the first range's rows; with compact rows for the first two ranges (round 4) the copies are half as long
+    // and the first range can be larger, the last smaller: 5.5:3:1.5 2.196 ms against 2.268 (tools/sweep_env.py, interleaved;
+    // 6:3:1 2.253, 5:3.5:1.5 2.207, four ranges 2.28)
+    weights = {5.5, 3, 1.5};
   } else if ((owned ? owned[1] * (uint64_t)pl.step : ref.total_bases) >= (256ull << 20)) {
     // a half, a quarter or an eighth of it (a rank's share on 2, 4 or 8 GPUs).  Round 3, with the per-bin tail: 1.41 / 0.86 / 0.58 ms
     // for two equal ranges against 1.46 / 0.89 / 0.62 for 3:2 and 1.53 / 0.96 / 0.72 for three; one pass: - / 0.90 / 0.60
