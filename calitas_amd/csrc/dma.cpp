@@ -19,41 +19,53 @@ thread_local const char* g_dma_reason = "";
 const char* DmaCopier::last_reason() { return g_dma_reason; }
 
 bool DmaCopier::copy_to_host(void* dst_host, const void* src_dev, size_t n) const {
+  if (n == 0) { g_dma_reason = ""; return ok_; }
+  const unsigned long long t = start(dst_host, src_dev, n);
+  return t != 0 && finish(t);
+}
+
+bool DmaCopier::finish(unsigned long long ticket) const {
+  hsa_signal_t sig;
+  sig.handle = ticket;
+  hsa_signal_value_t v;
+  do { v = hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE); } while (v >= 1);
+  hsa_signal_destroy(sig);
+  return v == 0;                                            // negative: the runtime reports a failed copy
+}
+
+unsigned long long DmaCopier::start(void* dst_host, const void* src_dev, size_t n) const {
   g_dma_reason = "";
-  if (!ok_) return false;
-  if (n == 0) return true;
+  if (!ok_ || n == 0) return 0;
   hsa_amd_pointer_info_t si{}, di{};
   si.size = sizeof(si); di.size = sizeof(di);
   if (hsa_amd_pointer_info(const_cast<void*>(src_dev), &si, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS ||
       hsa_amd_pointer_info(dst_host, &di, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS)
-    { g_dma_reason = "pointer info unavailable"; return false; }
+    { g_dma_reason = "pointer info unavailable"; return 0; }
   // both ends must be allocations of the runtime itself (hipMalloc / hipHostMalloc).  A host range that is merely *locked* -- which
   // is what the runtime's own pageable copies leave behind, possibly mapped read-only -- is left to hipMemcpyAsync.
   if (si.type != HSA_EXT_POINTER_TYPE_HSA || di.type != HSA_EXT_POINTER_TYPE_HSA) {
     g_dma_reason = di.type == HSA_EXT_POINTER_TYPE_LOCKED ? "destination is a locked pageable range" : "an end is not a runtime allocation";
-    return false;
+    return 0;
   }
   {
     const char* base = (const char*)(di.hostBaseAddress ? di.hostBaseAddress : di.agentBaseAddress);
-    if ((const char*)dst_host < base || (const char*)dst_host + n > base + di.sizeInBytes) { g_dma_reason = "destination range leaves its allocation"; return false; }
+    if ((const char*)dst_host < base || (const char*)dst_host + n > base + di.sizeInBytes) { g_dma_reason = "destination range leaves its allocation"; return 0; }
   }
   if ((const char*)src_dev < (const char*)si.agentBaseAddress || (const char*)src_dev + n > (const char*)si.agentBaseAddress + si.sizeInBytes) {
     g_dma_reason = "source range leaves its allocation";
-    return false;
+    return 0;
   }
   hsa_device_type_t st, dt;
-  if (hsa_agent_get_info(si.agentOwner, HSA_AGENT_INFO_DEVICE, &st) != HSA_STATUS_SUCCESS || st != HSA_DEVICE_TYPE_GPU) return false;
-  if (hsa_agent_get_info(di.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS || dt != HSA_DEVICE_TYPE_CPU) return false;
+  if (hsa_agent_get_info(si.agentOwner, HSA_AGENT_INFO_DEVICE, &st) != HSA_STATUS_SUCCESS || st != HSA_DEVICE_TYPE_GPU) return 0;
+  if (hsa_agent_get_info(di.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS || dt != HSA_DEVICE_TYPE_CPU) return 0;
   hsa_signal_t sig;
-  if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
-  bool good = hsa_amd_memory_async_copy(dst_host, di.agentOwner, src_dev, si.agentOwner, n, 0, nullptr, sig) == HSA_STATUS_SUCCESS;
-  if (good) {
-    hsa_signal_value_t v;
-    do { v = hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE); } while (v >= 1);
-    good = v == 0;                                          // negative: the runtime reports a failed copy
+  if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return 0;
+  if (hsa_amd_memory_async_copy(dst_host, di.agentOwner, src_dev, si.agentOwner, n, 0, nullptr, sig) != HSA_STATUS_SUCCESS || sig.handle == 0) {
+    hsa_signal_destroy(sig);
+    g_dma_reason = "hsa_amd_memory_async_copy failed";
+    return 0;
   }
-  hsa_signal_destroy(sig);
-  return good;
+  return sig.handle;
 }
 
 }  // namespace calitas

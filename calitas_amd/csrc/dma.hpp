@@ -18,6 +18,10 @@ class DmaCopier {
   // Blocking copy of n bytes from device memory to page-locked host memory; the source must be complete (the caller waited for the
   // producing kernels).  Thread-safe: every call uses its own completion signal.  Returns false on failure.
   bool copy_to_host(void* dst_host, const void* src_dev, size_t n) const;
+  // The same in two halves, so that the caller can work on what has arrived while the next piece is on the bus: start() queues the
+  // copy and returns a ticket (0: declined, see last_reason), finish() waits for it (false: the runtime reports a failed copy).
+  unsigned long long start(void* dst_host, const void* src_dev, size_t n) const;
+  bool finish(unsigned long long ticket) const;
   static const char* last_reason();   // why the last copy_to_host of this thread declined ("" otherwise)
 
  private:

@@ -56,6 +56,10 @@ RowStrings compact_row_strings(const RowStrings& full);
 // n bytes of compact rows (`rows` of them) -> full rows at out, which has room for n + rows * (head.size() + tail.size() - 1) bytes.
 // Returns the bytes written, or (size_t)-1 when the text does not hold exactly `rows` newline-terminated rows.
 size_t expand_rows(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail, char* out, WorkerPool* pool);
+// The rows that END inside compact[0..n) (a piece of a text that is still arriving): consumed = the byte behind the last newline.
+struct ExpandedPiece { size_t consumed = 0, written = 0; uint64_t rows = 0; };
+ExpandedPiece expand_rows_piece(const char* compact, size_t n, const std::string& head, const std::string& tail, char* out, WorkerPool* pool,
+                                uint64_t max_rows = ~0ull);   // more rows than max_rows: nothing is written, .rows says how many
 
 // Text of the row of ext[e] (without the newline), for hits whose calitas_ext_hit_t::row is NULL: called from the worker pool, only for
 // the hits removeOverlaps kept -- a caller with millions of hits of its own (the variant branch) builds no text for the ones that go.

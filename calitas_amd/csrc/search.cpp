@@ -40,6 +40,7 @@ thread_local HostMarks g_marks;
 
 static int fail(calitas_ctx* ctx, int code, const std::string& msg) { return calitas_fail(ctx, code, msg); }
 static void* out_alloc(size_t size) { return calitas_out_alloc(size); }
+static int hip_ok(calitas_ctx* ctx, hipError_t e) { return e == hipSuccess ? CALITAS_OK : calitas_fail(ctx, CALITAS_EHIP, std::string("HIP: ") + hipGetErrorString(e)); }
 
 std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, int max_guide_diffs, int max_pam_mismatches,
                             GuideDev& gd) {
@@ -1934,9 +1935,46 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     if (lt.compact_bytes) {                                    // compact rows: over the bus into a staging block, head and tail put back on the pool
       char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.compact_bytes);
       if (!staging) return fail(lane, CALITAS_EINVAL, "out of memory");
-      int r = text_to_host(ctx, lane, staging, lt.d_text, (size_t)lt.compact_bytes, &copy_mu, &lt.tm.hits_copy_ms);
+      int r = CALITAS_OK;
       size_t wrote = 0;
-      if (!r) wrote = expand_rows(staging, (size_t)lt.compact_bytes, lt.rows, rs.head, rs.tail, text + hlen + offset, ctx->pool);
+      const size_t nbytes = (size_t)lt.compact_bytes;
+      // (In pieces -- the workers expand what has arrived while the next piece is on the bus -- it is no faster: 2.164 against 2.170 ms per
+      // hg38-sized call with 4 MB pieces, 2.24 with 2 MB, 3.4 with 1 MB: a piece costs ~100 us of fixed latency.  CALITAS_COMPACT_PIECE_KB.)
+      size_t piece = ~(size_t)0 >> 2;
+      if (const char* e = std::getenv("CALITAS_COMPACT_PIECE_KB")) piece = (size_t)std::max(64, std::atoi(e)) << 10;
+      const bool in_host_text = lane->binned_late_check && lt.d_text == binned_host_text(lane->binned);
+      if (ctx->dma_tried && ctx->dma.usable() && nbytes > piece + piece / 2 && !in_host_text) {
+        r = hip_ok(lane, calitas_spin_sync(lane->stream));
+        g_marks.mark("rows-done");
+        if (!r && lane->binned_late_check && lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)
+          r = fail(lane, CALITAS_EHIP, "binned rows kernel: a row's length differs between the two kernels (internal error)");
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t sent = 0, consumed = 0;
+        uint64_t rows_done = 0;
+        unsigned long long ticket = 0;
+        auto send = [&](size_t from) -> size_t {               // queues the next piece, returns its end (0: declined)
+          const size_t to = std::min(nbytes, from + piece);
+          ticket = ctx->dma.start(staging + from, lt.d_text + from, to - from);
+          return ticket ? to : 0;
+        };
+        if (!r) { sent = send(0); if (!sent) r = fail(lane, CALITAS_EHIP, std::string("SDMA copy declined: ") + DmaCopier::last_reason()); }
+        while (!r && consumed < nbytes) {
+          if (!ctx->dma.finish(ticket)) { r = fail(lane, CALITAS_EHIP, "SDMA copy failed"); break; }
+          const size_t have = sent;
+          if (have < nbytes) { sent = send(have); if (!sent) { r = fail(lane, CALITAS_EHIP, std::string("SDMA copy declined: ") + DmaCopier::last_reason()); break; } }
+          const ExpandedPiece ep = expand_rows_piece(staging + consumed, have - consumed, rs.head, rs.tail, text + hlen + offset + wrote, ctx->pool, lt.rows - rows_done);
+          if (ep.rows > lt.rows - rows_done) { r = fail(lane, CALITAS_EHIP, "a lane's compact rows hold more rows than the device reported (internal error)"); break; }
+          consumed += ep.consumed; wrote += ep.written; rows_done += ep.rows;
+          if (have == nbytes && ep.consumed != have - (consumed - ep.consumed)) { r = fail(lane, CALITAS_EHIP, "a lane's compact rows do not end with a newline (internal error)"); break; }
+        }
+        if (r && ticket && sent > consumed) (void)ctx->dma.finish(ticket);   // (nothing of the staging block may still be written when it is freed)
+        g_marks.mark("copied");
+        lt.tm.hits_copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (!r && rows_done != lt.rows) wrote = 0;
+      } else {
+        r = text_to_host(ctx, lane, staging, lt.d_text, nbytes, &copy_mu, &lt.tm.hits_copy_ms);
+        if (!r) wrote = expand_rows(staging, nbytes, lt.rows, rs.head, rs.tail, text + hlen + offset, ctx->pool);
+      }
       calitas_free(staging);
       if (r) return r;
       if (wrote != (size_t)lt.bytes) return fail(lane, CALITAS_EHIP, "a lane's compact rows do not expand to the row count the device reported (internal error)");
@@ -1982,7 +2020,9 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       bool compact_on = device_rows;
       if (const char* e = std::getenv("CALITAS_COMPACT_ROWS")) compact_on = compact_on && std::atoi(e) != 0;
       lane_compact.assign(K, 0);
-      for (size_t c = 0; c + 1 < K; c++) lane_compact[c] = compact_on ? 1 : 0;
+      size_t n_compact = K - 1;
+      if (const char* e = std::getenv("CALITAS_COMPACT_LANES")) n_compact = std::min<size_t>(K - 1, (size_t)std::max(0, std::atoi(e)));
+      for (size_t c = 0; c < n_compact; c++) lane_compact[c] = compact_on ? 1 : 0;
     }
     // (no early return inside this loop: the scans of the earlier lanes are already in flight and every exit waits for them)
     auto hip_rc = [&](hipError_t e, const char* what) {
