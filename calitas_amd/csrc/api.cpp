@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/calitas_hip.h"
+#include "tuning.hpp"
 #include "common.hpp"
 #include "fasta.hpp"
 #include "kernels.hpp"
@@ -69,7 +70,7 @@ void* out_alloc_impl(size_t size, bool pinned = false) {
     if (best >= 0) { BlockHeader* h = g_pool[best]; g_pool.erase(g_pool.begin() + best); return h + 1; }
   }
   size_t cap = size + size / 8;
-  if (size >= (1u << 20) && std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] out_alloc: fresh %s block of %zu bytes\n", pinned ? "pinned" : "pageable", cap);
+  if (size >= (1u << 20) && tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] out_alloc: fresh %s block of %zu bytes\n", pinned ? "pinned" : "pageable", cap);
   BlockHeader* h = nullptr;
   if (pinned) {
     if (hipHostMalloc((void**)&h, sizeof(BlockHeader) + cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; pinned = false; }
@@ -142,6 +143,15 @@ static void free_reference_device(calitas_ctx* c) {
 extern "C" {
 
 const char* calitas_version(void) { return "calitas-hip 0.1 (gfx950)"; }
+
+const char* calitas_switches(void) {
+  static const std::string text = [] {
+    std::string t;
+    for (const tune::Switch& s : tune::kSwitches) { t += s.name; t += " <"; t += s.values; t += "> "; t += s.what; t += "\n"; }
+    return t;
+  }();
+  return text.c_str();
+}
 
 const char* calitas_last_error(const calitas_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -231,7 +241,7 @@ static int upload_reference_device(calitas_ctx* ctx) {
   free_reference_device(ctx);
   const PackedRef& r = ctx->ref;
   size_t nruns = std::max<size_t>(1, r.runs.size());
-  if (const char* e = std::getenv("CALITAS_DEVICE_BUDGET_MB")) {   // the budget a caller sharing the card sets covers the reference too
+  if (const char* e = tune::get("CALITAS_DEVICE_BUDGET_MB")) {   // the budget a caller sharing the card sets covers the reference too
     const uint64_t want = (uint64_t)r.codes.size() * 8 + (uint64_t)r.mask.size() * 4 + nruns * sizeof(Run) + r.tiles.size() * sizeof(TileInfo);
     if (want > (uint64_t)std::atoll(e) << 20)
       return fail(ctx, CALITAS_ENOMEM, "the packed reference (" + std::to_string(want >> 20) + " MB on the device) exceeds CALITAS_DEVICE_BUDGET_MB");

@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+#include "tuning.hpp"
+
 namespace calitas {
 
 class WorkerPool {
@@ -58,7 +60,7 @@ class WorkerPool {
   }
 
   static int default_threads() {
-    if (const char* e = std::getenv("CALITAS_THREADS")) { int v = std::atoi(e); if (v > 0) return std::min(v, 256); }
+    if (const char* e = tune::get("CALITAS_THREADS")) { int v = std::atoi(e); if (v > 0) return std::min(v, 256); }
     unsigned hc = std::thread::hardware_concurrency();
     return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));  // the GPU boxes give one GPU a 16-core share
   }

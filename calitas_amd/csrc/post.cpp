@@ -1,6 +1,7 @@
 // post.cpp -- host-side stages of the product path (see post.hpp).  Reference citations: SGA = SequentialGuideAligner.scala,
 // GA = GuideAlignment.scala, RH = ReferenceHit.scala, SR = SearchReference.scala.
 #include "post.hpp"
+#include "tuning.hpp"
 
 #include <emmintrin.h>
 
@@ -304,7 +305,7 @@ ExpandedPiece expand_rows_piece(const char* compact, size_t n, const std::string
   // All workers (CALITAS_EXPAND_THREADS for experiments): the middle range's expansion of a chunked call is on its critical path --
   // hg38-sized call 2.34 ms with 16 workers, 2.35 with 8 (and a wider spread), 2.76 with 4, 3.7 with 2 (tools/sweep_env.py).
   size_t T = (size_t)pool->size();
-  if (const char* e = std::getenv("CALITAS_EXPAND_THREADS")) T = std::max<size_t>(1, std::min<size_t>((size_t)pool->size(), (size_t)std::atoi(e)));
+  if (const char* e = tune::get("CALITAS_EXPAND_THREADS")) T = std::max<size_t>(1, std::min<size_t>((size_t)pool->size(), (size_t)std::atoi(e)));
   const size_t H = head.size(), TL = tail.size();
   // every worker takes the rows that START in its byte range: (1) count them, (2) place them -- a row's place is its compact offset plus
   // (head + tail - 1) bytes for every row before it
@@ -475,7 +476,7 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
                void* ext_user) {
   WorkerPool serial(1);
   if (!pool) pool = &serial;
-  const bool trace = std::getenv("CALITAS_TRACE") != nullptr;
+  const bool trace = tune::get("CALITAS_TRACE") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_start = tnow();
   auto by_hit_order = [](const Lite& x, const Lite& y) {   // RH:284

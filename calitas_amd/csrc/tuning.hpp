@@ -1,0 +1,68 @@
+// tuning.hpp -- every environment switch of the library, in one place.
+//
+// The product has one behaviour; these switches exist for measurements (A/B runs, tools/ab_env.py, tools/sweep_env.py), for tests that
+// force a fallback path, and for a caller that shares the card.  They are read when a call starts a stage (tests change them between
+// calls of one process), always through tune::get(), which refuses a name that is not in the table below -- so the table is complete,
+// and `calitas_switches()` (include/calitas_hip.h) prints it.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+
+namespace calitas {
+namespace tune {
+
+struct Switch { const char* name; const char* values; const char* what; };
+
+// kind: D = diagnostics, F = forces a fallback / alternative path that returns the same bytes (tests), T = tuning (measured defaults,
+// DESIGN.md says where), R = resources
+constexpr Switch kSwitches[] = {
+  {"CALITAS_TRACE", "1 | 2", "D: one line per call / stage on stderr; 2: the host-side time line of calitas_search_hits (microsecond marks)"},
+  {"CALITAS_TWIN_STATS", "1", "D: variant branch: how many description-less hits of variant windows repeat a reference hit (host merge only)"},
+  {"CALITAS_THREADS", "n", "R: worker pool size (default: the CPUs of the process, at most 16)"},
+  {"CALITAS_DEVICE_BUDGET_MB", "n", "R: device memory the library may plan with (reference + search scratch); a search beyond it runs one pass per contig or is refused"},
+  {"CALITAS_HOST_FILTER", "1", "F: per-window filter (SGA:315-320) on the host instead of select.hip"},
+  {"CALITAS_HOST_HITS", "1", "F: removeOverlaps / sort / rows on the host (post.cpp) instead of hits.hip / binned.hip"},
+  {"CALITAS_VARIANTS_HOST", "1", "F: variant branch: merge alignment records on the host (round 3) instead of bringing the variant windows' hits into the device's row stage"},
+  {"CALITAS_SEQUENTIAL", "1", "F: calitas_search_hits as one pass per contig whatever the size"},
+  {"CALITAS_SDMA", "0", "F: text copies with hipMemcpyAsync instead of the SDMA engine (dma.cpp)"},
+  {"CALITAS_BINNED", "1 | 0 | last", "T/F: the per-bin tail for every range / none / the last range only (default: calls of one or two ranges and every window range)"},
+  {"CALITAS_BATCH_BINNED", "1", "T: guide batches on large references keep the per-bin tail (default: general kernels from 2 Gb on)"},
+  {"CALITAS_OWN_GENERAL_OFF", "1", "F: a window range with a crowded bin searches its contigs whole (round 3) instead of finishing on the general kernels with HitsOwn"},
+  {"CALITAS_BINNED_COMPLEX", "1", "F: every bin through the wave-per-bin kernel"},
+  {"CALITAS_BINNED_TEXT_KB", "n", "F: first guess of the per-bin text buffer (forces the regrow path)"},
+  {"CALITAS_BINNED_HOST_TEXT", "0 | 1", "F/T: short texts written into page-locked host memory by the rows kernel (default 1)"},
+  {"CALITAS_BINNED_HOST_TEXT_KB", "n", "T: ... up to this size (default 128)"},
+  {"CALITAS_BINNED_SKIP", "1 | 2 | 3", "D: timing experiments only (the text is wrong): skip the wave-per-bin kernel / the rows"},
+  {"CALITAS_TEXT_IN_PLACE_OFF", "1", "F: the last range's text takes the copy instead of being written to its final place by the rows kernel"},
+  {"CALITAS_CHUNKS", "k | a:b:c", "T: contig ranges of a chunked calitas_search_hits (default 5.5:3:1.5 from 2 Gb, 1:1 from 256 Mb)"},
+  {"CALITAS_CHUNK", "64..512", "T: bases per scan lane chunk (set_reference; default by genome size)"},
+  {"CALITAS_INPUTS_FIRST", "0 | 1 | 2", "T: where the ranges' small inputs are queued (default 2)"},
+  {"CALITAS_LANE_SETUP", "0", "F: separate stream commands instead of the one-launch lane setup"},
+  {"CALITAS_LANE_PRIO", "low", "T: lanes' streams at low priority (experiment)"},
+  {"CALITAS_ALIGN_LPJ", "32", "F: two jobs of 32 lanes per aligner wave even for guides of up to 20 rows"},
+  {"CALITAS_ALIGN_BLOCKS", "n", "T: align_kernel grid, units of four one-wave workgroups (default 512)"},
+  {"CALITAS_ALIGN_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
+  {"CALITAS_TRACE_BLOCKS", "n", "T: trace_kernel grid (default 2048)"},
+  {"CALITAS_TRACE_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
+  {"CALITAS_BATCH_LANES", "1..8", "T: guides in flight in calitas_search_hits_batch (default 5)"},
+  {"CALITAS_COMPACT_ROWS", "0", "F/T: full rows over PCIe instead of compact rows + host expansion (batches, the leading ranges of a chunked call)"},
+  {"CALITAS_COMPACT_LANES", "n", "T: how many leading ranges of a chunked call move compact rows (default all but the last)"},
+  {"CALITAS_COMPACT_PIECE_KB", "n", "T: compact text copied and expanded in pieces of this size (default: one piece)"},
+  {"CALITAS_EXPAND_THREADS", "n", "T: workers that expand compact rows (default: the whole pool)"},
+};
+
+inline bool known(const char* name) {
+  for (const Switch& s : kSwitches) if (std::strcmp(s.name, name) == 0) return true;
+  return false;
+}
+
+// getenv for a switch of the table; a name that is not in it is a bug in the library (the process stops: tests would catch it).
+inline const char* get(const char* name) {
+  if (!known(name)) std::abort();
+  return std::getenv(name);
+}
+inline bool on(const char* name) { const char* e = get(name); return e && std::atoi(e) != 0; }
+inline bool is_set(const char* name) { return get(name) != nullptr; }
+
+}  // namespace tune
+}  // namespace calitas

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "tuning.hpp"
 
 namespace {
 
@@ -641,7 +642,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // The two halves run side by side: this thread produces, aligns (on a side context: a stream and buffers of its own) and keys the
   // variant windows contig by contig -- host work, mostly -- while a helper thread drives the reference's per-contig passes (device work
   // and the text over PCIe); the row stage of contig c waits until this thread has published the contig's entries.
-  const char* force_host = std::getenv("CALITAS_VARIANTS_HOST");
+  const char* force_host = tune::get("CALITAS_VARIANTS_HOST");
   const bool device_merge = !(force_host && std::atoi(force_host) != 0) && p.max_overlap >= 1;
   if (device_merge) { rc = calitas_side_context(ctx, &actx); if (rc) return rc; }
   const size_t nc = ref.contigs.size();
@@ -845,7 +846,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     });
     ctx->pool->for_blocks(kept_windows.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) kept_windows[k] = Batch(); });
     ctx->pool->for_blocks(kept_out.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) { calitas_free(kept_out[k]); kept_out[k] = nullptr; } });
-    if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: teardown %.1f ms\n", ms_since(t0));
+    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: teardown %.1f ms\n", ms_since(t0));
   };
   if (device_merge) {
     helper.join();
@@ -855,7 +856,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       if (tsv_bytes) *tsv_bytes = hr.bytes;
       if (n_rows) *n_rows = hr.rows;
       if (n_windows) *n_windows = windows_total;
-      if (std::getenv("CALITAS_TRACE"))
+      if (tune::get("CALITAS_TRACE"))
         std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: align %.1f ms, keys %.1f ms, groups %.1f + rows %.1f + blobs %.1f ms of %zu hits, "
                              "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms\n",
                      ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_groups, ms_make, ms_blob, hits.size(), ms_variant_half, hr.ms, ms_since(t_call));
@@ -863,7 +864,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     }
     calitas_free(hr.tsv);
     if (!hr.declined) { teardown(); return hr.rc; }
-    if (std::getenv("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
+    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
   }
   // On the host (a stage the device declines: -O 0, a window beyond the device filter, an overlap cluster beyond one lane's walk):
   // reference windows on the GPU, their alignment records back, removeOverlaps + sort over everything.
@@ -880,7 +881,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     ext[k].contig_index = h.w->contig; ext[k].coordinate_start = h.gstart; ext[k].end = h.gstart + h.tlen - 1; ext[k].score = h.a->score;
     ext[k].strand = (int8_t)h.a->strand; ext[k].variant_description = h.desc.empty() ? nullptr : h.desc.c_str(); ext[k].row = nullptr;
   }
-  if (std::getenv("CALITAS_TWIN_STATS")) {   // how many hits of variant windows that touch no variant repeat a reference hit exactly
+  if (tune::get("CALITAS_TWIN_STATS")) {   // how many hits of variant windows that touch no variant repeat a reference hit exactly
     std::vector<std::array<int64_t, 3>> keys(n_ref);
     for (uint64_t i = 0; i < n_ref; i++) {
       const calitas_aln_t& a = ref_alns[i];
@@ -914,7 +915,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   if (n_rows) *n_rows = nr;
   if (n_windows) *n_windows = windows_total;
   ms_merge = ms_since(t_merge);
-  if (std::getenv("CALITAS_TRACE"))
+  if (tune::get("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search_variants: reference search %.1f ms, VCF %.1f ms (%zu records), %llu windows: align %.1f ms, rows %.1f ms, merge %.1f ms, call %.1f ms\n",
                  ms_ref, ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_merge, ms_since(t_call));
   return CALITAS_OK;

@@ -166,6 +166,11 @@ const char* calitas_genome_build(const calitas_ctx* ctx);
  * toUpperCase, ReferenceHit.scala:261-266); out must hold len bytes. */
 int calitas_fetch_bases(const calitas_ctx* ctx, int32_t contig_index, uint64_t start, uint32_t len, char* out);
 
+/* Every environment switch the library reads (calitas_amd/csrc/tuning.hpp): "NAME <values> what it does" per line; the product has one
+ * behaviour, the switches are for measurements, for tests that force a fallback path and for a caller that shares the card.  The string
+ * lives as long as the library. */
+const char* calitas_switches(void);
+
 /* Test hook without a reference counterpart: the host half of the compact rows calitas_search_hits_batch moves over PCIe (round 4).  A
  * row of hits.txt is head | chromosome \t middle | tail with head (guide_id, unpadded_guide_sequence, genome_build) and tail (aligner ..
  * time_stamp, ReferenceHit.scala:99-132) the same for every row of a call; the device writes `chromosome \t middle \n` per row and

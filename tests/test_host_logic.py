@@ -315,3 +315,25 @@ def test_expand_rows_puts_head_and_tail_back():
                 assert _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows, head, tail, out, len(want) - 1, ctypes.byref(written)) != 0
     finally:
         ctx.close()
+
+
+def test_every_environment_switch_is_in_the_table():
+    """calitas_switches() (calitas_amd/csrc/tuning.hpp) lists every CALITAS_* switch the library reads, and nothing else: the sources
+    read them through tune::get() only (a name missing from the table stops the process), and no std::getenv of a CALITAS_ name is left."""
+    import glob
+    import re
+    import calitas_amd  # noqa: F401
+    from calitas_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    listed = {ln.split(" ", 1)[0] for ln in _lib.lib.calitas_switches().decode().splitlines() if ln}
+    used, raw = set(), []
+    for f in glob.glob(os.path.join(root, "calitas_amd", "csrc", "*.[ch]*")):
+        if f.endswith("tuning.hpp") or f.endswith(".o"):
+            continue
+        text = open(f, errors="replace").read()
+        used |= set(re.findall(r'tune::(?:get|on|is_set)\("(CALITAS_[A-Z0-9_]+)"\)', text))
+        used |= set(re.findall(r'narrow_blocks\([^"]*"(CALITAS_[A-Z0-9_]+)" : "(CALITAS_[A-Z0-9_]+)"', text) and
+                    [x for pair in re.findall(r'"(CALITAS_[A-Z0-9_]+)" : "(CALITAS_[A-Z0-9_]+)"', text) for x in pair])
+        raw += re.findall(r'[^:]getenv\("(CALITAS_[A-Z0-9_]+)"\)', text)
+    assert not raw, raw
+    assert used == listed, (sorted(used - listed), sorted(listed - used))
