@@ -369,22 +369,44 @@ def main():
                          % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    def pin_this_rank():
+        """N > 1: every rank on the CPUs of its GPU's NUMA node (a rank's slice is bound by host round trips, and one from the far socket
+        costs a quarter more: DESIGN.md 4.7), its share of them when several GPUs hang off one node -- before anything starts a thread.
+        (calitas_amd/shard.py loaded by path: the package itself loads the HIP library, which has to come after torch.)"""
+        if world <= 1 or args.rehearse_on_one_gpu or os.environ.get("CALITAS_BENCH_PIN", "1") == "0":
+            return None
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_calitas_shard", os.path.join(ROOT, "calitas_amd", "shard.py"))
+        shard_mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(shard_mod)
+        cpus = shard_mod.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        if cpus and "CALITAS_THREADS" not in os.environ:
+            os.environ["CALITAS_THREADS"] = str(min(16, len(cpus)))       # the library's worker pool: one thread per CPU it may use
+        return cpus
+
     if args.dry_run:
         if rank == args.dry_run_fail_rank:
             sys.stderr.write("bench.py: rank %d fails on request (--dry-run-fail-rank)\n" % rank)
             raise SystemExit(3)
+        pinned = pin_this_rank()
         import torch
         import torch.distributed as dist
         total = rank + 1
+        cpus = [sorted(os.sched_getaffinity(0))]
         if world > 1:
             dist.init_process_group("gloo")
             t = torch.tensor([rank + 1], dtype=torch.int64)
             dist.all_reduce(t)
             total = int(t.item())
+            cpus = [None] * world
+            dist.all_gather_object(cpus, sorted(os.sched_getaffinity(0)))
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": total, "local_rank": local_rank}), flush=True)
+            line = {"dry_run": True, "n_gpus": world, "rank_sum": total, "local_rank": local_rank}
+            if pinned:
+                line["rank_cpus"] = cpus                          # (only when a topology was found: the affinity every rank ended up with)
+            print(json.dumps(line), flush=True)
         return
     if args.steps is None:
         args.steps = {3: 20, 4: 2, 5: 2}[args.config]
@@ -395,18 +417,7 @@ def main():
     if args.scale is None:
         args.scale = 0.05 if args.config == 5 else 1.0
 
-    # N > 1: every rank on the CPUs of its GPU's NUMA node (a rank's slice is bound by host round trips, and one from the far socket
-    # costs a quarter more: DESIGN.md 4.7), its share of them when several GPUs hang off one node -- before anything starts a thread.
-    # (calitas_amd/shard.py loaded by path: the package itself loads the HIP library, which has to come after torch.)
-    pinned = None
-    if world > 1 and not args.rehearse_on_one_gpu and os.environ.get("CALITAS_BENCH_PIN", "1") != "0":
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("_calitas_shard", os.path.join(ROOT, "calitas_amd", "shard.py"))
-        shard_mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(shard_mod)
-        pinned = shard_mod.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-        if pinned and "CALITAS_THREADS" not in os.environ:
-            os.environ["CALITAS_THREADS"] = str(min(16, len(pinned)))       # the library's worker pool: one thread per CPU it may use
+    pinned = pin_this_rank()
 
     import torch
     if not torch.cuda.is_available():
@@ -523,15 +534,8 @@ def main():
         check = {"guides": sample, "identical": True, "rows": 0}
         for k, gi in enumerate(sample):
             whole, n_whole = ctx.search_hits(G96[gi], ids96[gi], params, "bench", "bench", decode="bytes")
-            head = whole[:whole.index(b"\n") + 1]
-            off = len(head)
-            for r in range(world):
-                crc, nb, rows = (int(allst[r][3 + 3 * k + j]) for j in range(3))
-                piece = whole[off: off + nb - len(head)]
-                off += nb - len(head)
-                if zlib.crc32(head + piece) != crc:
-                    check["identical"] = False
-            if off != len(whole) or sum(int(allst[r][3 + 3 * k + 2]) for r in range(world)) != n_whole:
+            pieces = [tuple(int(allst[r][3 + 3 * k + j]) for j in range(3)) for r in range(world)]
+            if not shard.pieces_match(whole, pieces, n_whole):
                 check["identical"] = False
             check["rows"] += n_whole
         total_bases = sum(lengths)

@@ -234,9 +234,28 @@ def rank_cpus(local_rank, n_local, allowed, root="/", visible=None, min_cpus=2):
     return cpus[k * per:(k + 1) * per]
 
 
-def pin_rank(local_rank, n_local):
-    """sched_setaffinity for this process (before any thread pool exists) per rank_cpus; returns the CPU list or None."""
+def pieces_match(whole, pieces, rows_whole=None):
+    """Whether the ranks' texts of one guide are the whole job's text cut into consecutive pieces: `whole` = the bytes of a
+    single-process hits.txt, pieces = [(crc32, n_bytes, n_rows) of rank r's text, header line included] in rank order.  A rank's text
+    must be the header plus its consecutive piece of the body -- the ranks own consecutive stretches of the genome and coordinate_start
+    is the first sort key (ReferenceHit.scala:284).  What bench.py's batch_sharded block checks for a sample of guides."""
+    import zlib
+    head = whole[:whole.index(b"\n") + 1]
+    off, rows = len(head), 0
+    for crc, nbytes, nrows in pieces:
+        body = int(nbytes) - len(head)
+        if body < 0 or zlib.crc32(head + whole[off:off + body]) != int(crc):
+            return False
+        off += body
+        rows += int(nrows)
+    return off == len(whole) and (rows_whole is None or rows == rows_whole)
+
+
+def pin_rank(local_rank, n_local, root=None):
+    """sched_setaffinity for this process (before any thread pool exists) per rank_cpus; returns the CPU list or None.
+    root (or CALITAS_BENCH_SYSFS_ROOT): another tree than / to read the topology from (tests)."""
     import os
+    root = root or os.environ.get("CALITAS_BENCH_SYSFS_ROOT") or "/"
     vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
     try:
         visible = [int(x) for x in vis.split(",")] if vis else None
@@ -245,7 +264,7 @@ def pin_rank(local_rank, n_local):
         if vis:
             return None
     try:
-        cpus = rank_cpus(local_rank, n_local, os.sched_getaffinity(0), visible=visible)
+        cpus = rank_cpus(local_rank, n_local, os.sched_getaffinity(0), root=root, visible=visible)
         if cpus:
             os.sched_setaffinity(0, cpus)
         return cpus

@@ -316,3 +316,101 @@ def test_owned_stretches_concatenate_to_the_whole_job():
         assert a[1] == b[0] and a[1][1] % hstep == 0
     loads = [shard.range_bases(synth.HG38_LENGTHS, hstep, 1000, f, n) for f, n in parts]
     assert max(loads) / (sum(loads) / 8) < 1.001
+
+
+GUIDES3 = [GUIDE, "GTGACTTGAAGTCTCAGTATnrg", "ACGTTGCATGCATGCCATGAnrg"]
+
+
+def _worker_batch_sharded(rank, world, port, outdir):
+    """bench.py's batch_sharded block with the oracle as compute: every rank runs ALL guides on its stretch (the rows it owns per guide),
+    reports (crc32, bytes, rows) of each text over a gloo all_gather, and rank 0 -- which has the whole genome -- holds every rank's text
+    against its consecutive piece of the single-process text (shard.pieces_match, the function bench.py calls)."""
+    import zlib
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    import calitas_amd as C
+    from calitas_amd import shard
+    from fasta_util import write_fasta
+    names, seqs = _genome()
+    lengths = [len(s) for s in seqs]
+    step = 1000 - (C.Guide(GUIDE).cli_length + 4 + 2 - 1)
+    first, n = shard.window_partition(lengths, world, step)[rank]
+    stretch = shard.owned_stretch(lengths, step, first, n)
+    touched = sorted({ci for ci, _, _, _ in shard.range_contigs(lengths, step, first, n)})
+    fa = write_fasta(os.path.join(outdir, "bs_%d.fa" % rank), [(names[ci], seqs[ci].decode()) for ci in touched])
+    fa_all = write_fasta(os.path.join(outdir, "bs_all_%d.fa" % rank), [(nm, s.decode()) for nm, s in zip(names, seqs)])
+
+    def text_of(header, rows):
+        return ("\t".join(header) + "\n" + "".join("\t".join(r[h] for h in header) + "\n" for r in rows)).encode()
+    stats = []
+    for gi, g in enumerate(GUIDES3):
+        header, rows, _ = O.search_reference(fa, g, "g%d" % gi, d=4, p=1, g=2, D=7, threads=2)
+        mine = [r for r in rows if shard.owns(stretch, names.index(r["chromosome"]), int(r["coordinate_start"]))]
+        for r in mine + rows:
+            r["time_stamp"] = "t"; r["aligner_version"] = "v"            # (run-dependent columns: fixed, as the bench passes them)
+        t = text_of(header, mine)
+        stats += [float(zlib.crc32(t)), float(len(t)), float(len(mine))]
+    mine_t = torch.tensor(stats, dtype=torch.float64)
+    gathered = [torch.zeros_like(mine_t) for _ in range(world)]
+    dist.all_gather(gathered, mine_t)
+    if rank == 0:
+        ok, tampered = [], []
+        for gi, g in enumerate(GUIDES3):
+            header, rows, _ = O.search_reference(fa_all, g, "g%d" % gi, d=4, p=1, g=2, D=7, threads=2)
+            for r in rows:
+                r["time_stamp"] = "t"; r["aligner_version"] = "v"
+            whole = text_of(header, rows)
+            pieces = [tuple(int(x) for x in gathered[r][3 * gi:3 * gi + 3].tolist()) for r in range(world)]
+            ok.append(shard.pieces_match(whole, pieces, len(rows)))
+            bad = [pieces[0]] + [(c ^ 1, nb, nr) for c, nb, nr in pieces[1:]]
+            tampered.append(shard.pieces_match(whole, bad, len(rows)) or shard.pieces_match(whole, pieces, len(rows) + 1)
+                            or shard.pieces_match(whole + b"x\n", pieces, len(rows)))
+        import json
+        json.dump({"ok": ok, "tampered": tampered, "rows": [int(gathered[r][2]) for r in range(world)]}, open(os.path.join(outdir, "bs.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_sharded_check_over_gloo():
+    """world_size 2: the check of bench.py's batch_sharded block -- every rank all guides on its stretch, (crc, bytes, rows) gathered,
+    rank 0 compares with single-process texts -- accepts the true partition and refuses a wrong CRC, a wrong row count and a longer text."""
+    import json
+    with tempfile.TemporaryDirectory() as d:
+        port = 35600 + os.getpid() % 2000
+        mp.start_processes(_worker_batch_sharded, args=(2, port, d), nprocs=2, join=True, start_method="spawn")
+        res = json.load(open(os.path.join(d, "bs.json")))
+    assert res["ok"] == [True, True, True] and res["tampered"] == [False, False, False] and all(r >= 0 for r in res["rows"])
+
+
+def test_bench_ranks_pin_themselves_to_their_gpus_numa_node(tmp_path):
+    """`python bench.py --gpus 2 --dry-run` with a KFD topology to read (a fake /sys: two GPUs on one NUMA node whose CPUs are the ones this
+    process may use): every rank ends up on its half of the node's CPUs before it starts a thread; without a topology nothing is touched."""
+    import json
+    import subprocess
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("fewer than 4 CPUs")
+    def put(rel, text):
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(text)
+    put("sys/class/kfd/kfd/topology/nodes/0/properties", "cpu_cores_count %d\nsimd_count 0\ndrm_render_minor -1\n" % len(allowed))
+    for g in range(2):
+        put("sys/class/kfd/kfd/topology/nodes/%d/properties" % (1 + g), "cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % (128 + g))
+        put("sys/class/drm/renderD%d/device/numa_node" % (128 + g), "0\n")
+    put("sys/devices/system/node/node0/cpulist", ",".join(str(c) for c in allowed) + "\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "CALITAS_THREADS")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, CALITAS_BENCH_SYSFS_ROOT=str(tmp_path)),
+                         capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    half = len(allowed) // 2
+    assert line["rank_cpus"] == [allowed[:half], allowed[half:2 * half]]
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, CALITAS_BENCH_SYSFS_ROOT=str(tmp_path / "nowhere")),
+                           capture_output=True, timeout=300)
+    assert plain.returncode == 0 and "rank_cpus" not in json.loads(plain.stdout.decode().strip().splitlines()[-1])
