@@ -111,41 +111,6 @@ __device__ __forceinline__ Derived derive_in_contig(const RawAln* rp, const Guid
   return d;
 }
 
-// Length of the middle part of a row = what build_middle computes with ballots, for one lane: the field lengths of RH:210-254 from
-// the alignment's op counts (GA:99-115, 139-183) and the run-length encoding of its cigar.  -1: the row builder does not lay it out.
-__device__ __forceinline__ int middle_length(const RawAln* rp, const HitRec& h, int L, int pam_len, int pu_len, int n_max, int mid_bound) {
-  const int ng = rp->n_ops, pam = rp->pam;
-  const int gap = pam >= 0 ? rp->offset : 0;
-  const uint32_t pam_x = rp->pam_x;
-  const int n = ng + gap + pam_len;
-  const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
-  if (n > n_max || n > MID_COLS || hi - lo > MID_FWD) return -1;
-  const OpsWords ow = load_ops_words(rp->ops);
-  const OpCounts oc = count_ops(ow, ng);
-  const int utn = oc.not_ins - oc.lead_d - oc.trail_d;                 // target bases under the first .. last protospacer column (GA:111-115)
-  const int gmm = oc.non_eq - oc.gaps, pam_mm = pam >= 0 ? __popc(pam_x) : 0;   // 'X' columns by the case of the query base (GA:103, 106)
-  const int ggp = oc.gaps + gap;                                       // every gap column has a protospacer base on one side (GA:104, 168-182)
-  const int edits = oc.non_eq + gap + pam_mm;                          // GA:101
-  // Cigar.coalesce + toString over the columns: guide part (aligner order = traceback order reversed), the gap, the PAM; the number of
-  // runs and of two-digit run lengths does not depend on the direction the columns are read in (5' PAM)
-  int runs = 0, long_runs = 0, prev = -1, len = 0;
-  for (int k = 0; k < n; k++) {
-    const int op = k < ng ? ow.op(ng - 1 - k) : k < ng + gap ? 3 : (int)((pam_x >> ((k - ng - gap) & 15)) & 1u);
-    if (op != prev) { if (len >= 10) long_runs++; runs++; len = 0; prev = op; }
-    len++;
-  }
-  if (len >= 10) long_runs++;
-  const int cigar_len = 2 * runs + long_runs;
-  auto digits = [](int v) {
-    const unsigned u = (unsigned)(v < 0 ? -v : v);
-    return (v < 0 ? 1 : 0) + 1 + (u >= 10u) + (u >= 100u) + (u >= 1000u) + (u >= 10000u) + (u >= 100000u) + (u >= 1000000u) + (u >= 10000000u) +
-           (u >= 100000000u) + (u >= 1000000000u);
-  };
-  const int total = MID_FIELDS + digits(h.gstart) + digits(h.gend) + 1 + utn + 10 + 10 + pu_len + digits(h.score) + digits(gmm) + digits(ggp) +
-                    digits(gmm + ggp) + digits(pam_mm) + digits(edits) + 3 * n + 8 + 8 + cigar_len + digits(L) + digits(utn);
-  return total > mid_bound ? -1 : total;
-}
-
 // One bin by a whole wave: the bins whose context holds more than SMALL_MAX alignments (bin_hits_kernel's waves stride over the
 // list bin_hits_small_kernel made of them).
 __device__ __forceinline__ void bin_hits_wave(const BinArgs& a, const MidArgs& m, const uint32_t rel, const int lane) {

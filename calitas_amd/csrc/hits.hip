@@ -15,7 +15,8 @@
 //                      far" only needs a look back over the hits that start within that distance.
 //   3. cluster_kernel  the restart points cut every group into clusters (usually 1-3 hits) that are independent of each other;
 //                      one lane walks one cluster with the reference's loop (SR:661-671), stepping over the other strand's hits.
-//   4. mid_kernel / out_kernel: rows of the kept hits, already in final order (dropped hits have length 0).
+//   4. len_kernel / rows_kernel: rows of the kept hits, already in final order (dropped hits have length 0): lengths, offsets, then
+//                      every row built at its final place.
 #include <hip/hip_runtime.h>
 #include <sched.h>
 
@@ -198,124 +199,120 @@ __global__ __launch_bounds__(HITS_SMALL) void hits_small_kernel(HitsSmallArgs a)
   if (mine) cluster_body(i, a.s_start, a.s_end, a.s_score, a.s_cs, a.head, a.n, a.max_overlap, a.keep, a.flags);
 }
 
-__global__ __launch_bounds__(256) void mid_kernel(MidArgs a, uint8_t* stage, uint32_t* midlen, uint64_t* lens, uint32_t* flags) {
+// Rows in two kernels (round 4; round 2 built every middle part into a staging buffer -- mid_kernel -- and assembled the rows from it
+// once their offsets were known -- out_kernel: 350 bytes per row written and read again, 20 GB of staging for the 4.1e7 rows of a PAM-less
+// whole-genome search):
+//   len_kernel   one lane per sorted position: the row's length from the alignment's op counts (middle_length: the arithmetic
+//                build_middle does with ballots, without fetching or writing anything) -- what the offsets' scan needs;
+//   rows_kernel  after the scan and the host's look at the totals: a wave per row builds the middle part in its LDS line and writes
+//                head | chromosome \t | middle | tail at the row's final place.  The two lengths are held against each other for every
+//                row (a mismatch raises HITS_FLAG_INTERNAL in the work's late word: two implementations of one arithmetic).
+__global__ __launch_bounds__(256) void len_kernel(MidArgs a, uint32_t* midlen, uint64_t* lens, uint32_t* flags) {
   CALITAS_TAIL_PRIO();
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // per wave: line | fwd; then the constant strings (queries, PAMs)
-  __shared__ uint32_t s_live;
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  bool live = false, is_ext = false;
+  if (k < a.n) {
+    live = a.keep[k] != 0;
+    const uint32_t v = a.order[k];
+    is_ext = v >= a.n_dev;
+    if (is_ext) {                                          // the caller's own hit: its row comes finished (HitsExt), rows_kernel copies it
+      midlen[k] = live ? 0xFFFFFFFFu : 0u;
+      lens[k] = live ? a.ext_off[v - a.n_dev + 1] - a.ext_off[v - a.n_dev] : 0;
+    } else {
+      const HitRec h = a.hits[v];
+      if (live && (a.own_lo != 0 || a.own_hi != ~0ull)) {   // HitsOwn: rows of the stretch only
+        const unsigned long long key = ((unsigned long long)(uint32_t)h.contig << 32) | (uint32_t)h.gstart;
+        live = key >= a.own_lo && key < a.own_hi;
+      }
+      int len = 0;
+      if (live) {
+        const RawAln* rp = a.fin + v;
+        const GuideDev* gp = a.guides + rp->guide;
+        const int pam = rp->pam;
+        len = middle_length(rp, h, gp->L, pam >= 0 ? gp->pam_len[pam] : 0, (int)a.rc.pu_len[pam + 1], (int)a.n_max, (int)a.mid_bound);
+        if (len < 0) { atomicOr(flags, HITS_FLAG_ROW); len = 0; }
+      }
+      midlen[k] = (uint32_t)len;
+      lens[k] = live ? (uint64_t)(a.rc.head_len + (a.name_off[h.contig + 1] - a.name_off[h.contig]) + 1 + (uint32_t)len + a.rc.tail_len) : 0;
+    }
+  }
+  // rows (and kept hits of the caller's own) of the call: one atomic per wave
+  const unsigned long long lv = __ballot(live), ev = __ballot(live && is_ext);
+  if ((threadIdx.x & 63) == 0) {
+    if (lv) atomicAdd(a.n_rows, (uint32_t)__popcll(lv));
+    if (ev) atomicAdd(a.ext_kept, (uint32_t)__popcll(ev));
+  }
+}
+
+struct OutArgs {
+  const char* names;
+  const uint64_t* offs;
+  const uint32_t* midlen;      // per sorted position: 0 dropped, 0xFFFFFFFF a kept hit of the caller's own (copy its finished row)
+  const char* ext_rows;
+  uint32_t* late;              // the work's mailbox word for flags raised while rows are written (page-locked host memory)
+  const uint64_t* counts;      // [0] bytes of the text, [2] low word: flags -- final when this kernel starts (total_kernel ran before it)
+  uint64_t text_cap;           // room at `text`: a longer text makes the kernel return at once (the host grows the buffer and runs it again)
+};
+
+constexpr int ROWS_PER_WAVE = 4;
+
+__global__ __launch_bounds__(256) void rows_kernel(MidArgs a, OutArgs o, char* text) {
+  CALITAS_TAIL_PRIO();
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // per wave: line | fwd; then the constant strings (head, tail, queries, PAMs)
   const int lane = (int)(threadIdx.x & 63);
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* line = lds + wave * (MID_LINE + MID_FWD);
   uint8_t* fwd = line + MID_LINE;
   uint8_t* blob = lds + 4 * (MID_LINE + MID_FWD);
   for (uint32_t i = threadIdx.x; i < a.blob_bytes; i += 256) blob[i] = (uint8_t)a.blob[i];
-  if (threadIdx.x == 0) s_live = 0;
   __syncthreads();
-  uint32_t live_rows = 0;
-  const uint32_t k0 = (blockIdx.x * 4 + wave) * MID_ROWS_PER_WAVE;
-  for (int rr = 0; rr < MID_ROWS_PER_WAVE; rr++) {
+  // queued right behind the kernels that size the text, before the host has looked at their counts: nothing to do when the stage
+  // declined, and nothing may be written when the text does not fit the buffer it was given
+  if (o.counts[0] > o.text_cap || (uint32_t)o.counts[2] != 0u) return;
+  const uint8_t* head = blob + a.rc.head_off;
+  const uint8_t* tail = blob + a.rc.tail_off;
+  const uint32_t k0 = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
+  for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {
     const uint32_t k = k0 + (uint32_t)rr;
     if (k >= a.n) break;
-    int len = 0;
-    uint32_t name_len = 0;
-    bool live = uniform_ptr(a.keep)[k] != 0;
+    const uint32_t want = uniform_ptr(o.midlen)[k];
+    if (want == 0) continue;                              // dropped by removeOverlaps (or not owned)
     const uint32_t v = uniform_ptr(a.order)[k];
-    if (live && v < a.n_dev && (a.own_lo != 0 || a.own_hi != ~0ull)) {   // HitsOwn: rows of the stretch only
-      const auto* hq = uniform_ptr(a.hits) + v;
-      const unsigned long long key = ((unsigned long long)(uint32_t)hq->contig << 32) | (uint32_t)hq->gstart;
-      live = key >= a.own_lo && key < a.own_hi;
-    }
-    if (v >= a.n_dev) {                                  // the caller's own hit: its row comes finished (HitsExt), out_kernel copies it
-      if (lane == 0) {
-        midlen[k] = live ? 0xFFFFFFFFu : 0u;
-        lens[k] = live ? uniform_ptr(a.ext_off)[v - a.n_dev + 1] - uniform_ptr(a.ext_off)[v - a.n_dev] : 0;
-        if (live) atomicAdd(a.ext_kept, 1u);
-      }
-      live_rows += live ? 1u : 0u;
+    char* dst = text + uniform_ptr(o.offs)[k];
+    if (want == 0xFFFFFFFFu) {
+      const uint32_t e = v - a.n_dev;
+      const uint64_t b0 = uniform_ptr(a.ext_off)[e], nb = uniform_ptr(a.ext_off)[e + 1] - b0;
+      for (uint64_t b = (uint64_t)lane; b < nb; b += 64) dst[b] = o.ext_rows[b0 + b];
       continue;
     }
-    if (live) {
-      const auto* rp = uniform_ptr(a.fin) + v;
-      RowIn r;
-      const auto* ow = (const __attribute__((address_space(4))) uint32_t*)rp->ops;   // RawAln::ops sits at a 4-byte aligned offset
-      r.w0 = ow[0]; r.w1 = ow[1]; r.w2 = ow[2]; r.w3 = ow[3]; r.w4 = ow[4];
-      r.n_ops = rp->n_ops; r.pam = rp->pam; r.offset = rp->offset; r.pam_x = rp->pam_x;
-      const auto* hp = uniform_ptr(a.hits) + v;
-      HitRec h;
-      h.contig = hp->contig; h.start = hp->start; h.end = hp->end; h.gstart = hp->gstart; h.gend = hp->gend; h.score = hp->score;
-      h.rh_end = hp->rh_end; h.minus = hp->minus;
-      const auto* gp = uniform_ptr(a.guides) + rp->guide;
-      RowGuide g;
-      g.L = gp->L; g.pam5 = gp->pam5; g.pam_len = r.pam >= 0 ? gp->pam_len[r.pam] : 0;
-      wave_lds_sync();                                    // the copy-out of the previous row is done with line[]
-      len = build_middle(line, fwd, a, blob, r, h, g, lane);
-      if (len < 0) { if (lane == 0) atomicOr(flags, HITS_FLAG_ROW); len = 0; }
-      name_len = uniform_ptr(a.name_off)[h.contig + 1] - uniform_ptr(a.name_off)[h.contig];
-      live_rows++;
-      wave_lds_sync();
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(line);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (size_t)k * a.mid_bound);
-      for (int wd = lane; wd < (len + 3) / 4; wd += 64) dst[wd] = src[wd];
-    }
-    if (lane == 0) {
-      midlen[k] = (uint32_t)len;
-      lens[k] = live ? (uint64_t)(a.rc.head_len + name_len + 1 + (uint32_t)len + a.rc.tail_len) : 0;
-    }
-  }
-  if (lane == 0 && live_rows) atomicAdd(&s_live, live_rows);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_live) atomicAdd(a.n_rows, s_live);
-}
-
-struct OutArgs {
-  RowConstDev rc;
-  const char* blob;
-  const char* names;
-  const uint32_t* name_off;
-  const HitRec* hits;
-  const uint32_t* order;
-  const uint32_t* midlen;
-  const uint64_t* offs;
-  const uint8_t* stage;
-  uint32_t n, mid_bound;       // n sorted positions; dropped hits have midlen 0
-  uint32_t n_dev;              // order[k] >= n_dev: the caller's own hit (HitsExt), midlen 0xFFFFFFFF when kept: copy its finished row
-  const uint64_t* ext_off;
-  const char* ext_rows;
-};
-
-constexpr int OUT_ROWS_PER_WAVE = 8;
-
-__global__ __launch_bounds__(256) void out_kernel(OutArgs a, char* text) {
-  CALITAS_TAIL_PRIO();
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // head | tail
-  for (uint32_t i = threadIdx.x; i < a.rc.head_len; i += 256) lds[i] = (uint8_t)a.blob[a.rc.head_off + i];
-  for (uint32_t i = threadIdx.x; i < a.rc.tail_len; i += 256) lds[a.rc.head_len + i] = (uint8_t)a.blob[a.rc.tail_off + i];
-  __syncthreads();
-  const uint32_t lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint8_t* head = lds;
-  const uint8_t* tail = lds + a.rc.head_len;
-  for (int rr = 0; rr < OUT_ROWS_PER_WAVE; rr++) {
-    const uint32_t k = wave * OUT_ROWS_PER_WAVE + rr;
-    if (k >= a.n) return;
-    if (a.midlen[k] == 0) continue;                     // dropped by removeOverlaps
-    if (a.midlen[k] == 0xFFFFFFFFu) {
-      const uint32_t e = a.order[k] - a.n_dev;
-      const uint64_t b0 = a.ext_off[e], nb = a.ext_off[e + 1] - b0;
-      char* dst = text + a.offs[k];
-      for (uint64_t b = lane; b < nb; b += 64) dst[b] = a.ext_rows[b0 + b];
+    const auto* rp = uniform_ptr(a.fin) + v;
+    RowIn r;
+    const auto* ow = (const __attribute__((address_space(4))) uint32_t*)rp->ops;   // RawAln::ops sits at a 4-byte aligned offset
+    r.w0 = ow[0]; r.w1 = ow[1]; r.w2 = ow[2]; r.w3 = ow[3]; r.w4 = ow[4];
+    r.n_ops = rp->n_ops; r.pam = rp->pam; r.offset = rp->offset; r.pam_x = rp->pam_x;
+    const auto* hp = uniform_ptr(a.hits) + v;
+    HitRec h;
+    h.contig = hp->contig; h.start = hp->start; h.end = hp->end; h.gstart = hp->gstart; h.gend = hp->gend; h.score = hp->score;
+    h.rh_end = hp->rh_end; h.minus = hp->minus;
+    const auto* gp = uniform_ptr(a.guides) + rp->guide;
+    RowGuide g;
+    g.L = gp->L; g.pam5 = gp->pam5; g.pam_len = r.pam >= 0 ? gp->pam_len[r.pam] : 0;
+    wave_lds_sync();                                      // the copy-out of the previous row is done with line[]
+    const int len = build_middle(line, fwd, a, blob, r, h, g, lane);
+    if (len < 0 || (uint32_t)len != want) {               // cannot happen: both kernels run the same arithmetic
+      if (lane == 0) __hip_atomic_fetch_or(o.late, HITS_FLAG_INTERNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       continue;
     }
-    const uint32_t contig = (uint32_t)a.hits[a.order[k]].contig;
-    const uint32_t nb = a.name_off[contig], nl = a.name_off[contig + 1] - nb;
-    const uint32_t s0 = a.rc.head_len, s1 = s0 + nl + 1, s2 = s1 + a.midlen[k], total = s2 + a.rc.tail_len;
-    const uint8_t* mid = a.stage + (size_t)k * a.mid_bound;
-    char* dst = text + a.offs[k];
-    for (uint32_t b = lane; b < total; b += 64) {
-      uint8_t c;
-      if (b < s0) c = head[b];
-      else if (b < s1) c = (b - s0 < nl) ? (uint8_t)a.names[nb + b - s0] : (uint8_t)'\t';
-      else if (b < s2) c = mid[b - s1];
-      else c = tail[b - s2];
-      dst[b] = (char)c;
+    wave_lds_sync();
+    const uint32_t nb = uniform_ptr(a.name_off)[h.contig], nl = uniform_ptr(a.name_off)[h.contig + 1] - nb;
+    const uint32_t s0 = a.rc.head_len, s1 = s0 + nl + 1, s2 = s1 + (uint32_t)len, total = s2 + a.rc.tail_len;
+    for (uint32_t x = (uint32_t)lane; x < total; x += 64) {
+      uint8_t ch;
+      if (x < s0) ch = head[x];
+      else if (x < s1) ch = (x - s0 < nl) ? (uint8_t)o.names[nb + x - s0] : (uint8_t)'\t';
+      else if (x < s2) ch = line[x - s1];
+      else ch = tail[x - s2];
+      dst[x] = (char)ch;
     }
   }
 }
@@ -361,12 +358,14 @@ __global__ __launch_bounds__(HITS_SMALL) void offs_small_kernel(const uint64_t* 
 
 }  // namespace
 
+uint32_t hits_late(const HitsWork* w) { return w && w->mbox.host ? w->mbox.host[HITS_BOX_LATE] : 0u; }
+
 void hits_destroy(HitsWork* w) {
   if (!w) return;
   (void)hipFree(w->hits); (void)hipFree(w->keys); (void)hipFree(w->keys2); (void)hipFree(w->lens); (void)hipFree(w->offs);
   (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_cs); (void)hipFree(w->wks); (void)hipFree(w->s_start); (void)hipFree(w->s_end);
   (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->head); (void)hipFree(w->temp); (void)hipFree(w->text);
-  (void)hipFree(w->stage); (void)hipFree(w->midlen); (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off);
+  (void)hipFree(w->midlen); (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off);
   (void)hipFree(w->d_counts); (void)hipFree(w->ext_keys); (void)hipFree(w->ext_off); (void)hipFree(w->ext_rows);
   if (w->h_counts) (void)hipHostFree(w->h_counts);
   mailbox_close(w->mbox);
@@ -503,16 +502,15 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
     return hipSuccess;
   }
   const size_t n_pad = (n + 63) / 64 * 64;
-  TRY(grow(&w.stage, w.stage_cap, n_pad * mid_bound));
   TRY(grow(&w.midlen, w.midlen_cap, n_pad));
+  if (!w.text) TRY(grow(&w.text, w.text_cap, std::min<size_t>((size_t)32 << 20, n * (size_t)(mid_bound + rc.head_len + rc.tail_len + 64))));   // (first call: a guess)
   MidArgs ma{};
   ma.ref = ref; ma.rc = rc; ma.blob = w.blob; ma.name_off = w.name_off; ma.fin = d_final; ma.hits = w.hits; ma.guides = d_guides;
   ma.keep = w.keep; ma.order = w.vals2; ma.n = n_in; ma.n_rows = d_kept; ma.n_dev = n_dev; ma.ext_off = w.ext_off; ma.ext_kept = d_kept + 1; ma.own_lo = ho.lo; ma.own_hi = ho.hi; ma.mid_bound = mid_bound; ma.n_max = n_max; ma.blob_bytes = (uint32_t)blob_bytes;
-  const unsigned rows_per_mid_block = 4 * MID_ROWS_PER_WAVE;
-  hipLaunchKernelGGL(mid_kernel, dim3((unsigned)((n + rows_per_mid_block - 1) / rows_per_mid_block)), dim3(256), mid_lds, stream, ma, w.stage, w.midlen,
-                     w.lens, d_flags);
+  hipLaunchKernelGGL(len_kernel, grid, block, 0, stream, ma, w.midlen, w.lens, d_flags);
   TRY(mailbox_open(w.mbox));
   w.mbox.seq++;
+  w.mbox.host[HITS_BOX_LATE] = 0;                          // raised by rows_kernel while rows are written; read when the stream is done (hits_late)
   if (small) {
     hipLaunchKernelGGL(offs_small_kernel, dim3(1), dim3(HITS_SMALL), 0, stream, (const uint64_t*)w.lens, n_in, w.offs, w.d_counts, w.mbox.dev, w.mbox.seq);
   } else {
@@ -520,6 +518,17 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
     TRY(rocprim::exclusive_scan(w.temp, ts, w.lens, w.offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream));
     hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1), 0, stream, (const uint64_t*)w.offs, (const uint64_t*)w.lens, n_in, w.d_counts, w.mbox.dev, w.mbox.seq);
   }
+  TRY(hipGetLastError());
+  // The rows kernel goes out at once, into the buffer as it is (sized by the last call's text: a search is usually followed by one like
+  // it): the host's look at the counts -- a round trip of 20-30 us -- is then off the lane's critical path, as in the binned tail.  A
+  // text that does not fit makes the kernel return untouched; the buffer grows and the kernel runs again.
+  OutArgs oa{};
+  oa.names = w.names; oa.offs = w.offs; oa.midlen = w.midlen; oa.ext_rows = w.ext_rows; oa.late = w.mbox.dev + HITS_BOX_LATE;
+  oa.counts = w.d_counts;
+  const unsigned rows_per_block = 4 * ROWS_PER_WAVE;
+  const dim3 rows_grid((n_in + rows_per_block - 1) / rows_per_block);
+  oa.text_cap = w.text_cap;
+  hipLaunchKernelGGL(rows_kernel, rows_grid, dim3(256), mid_lds, stream, ma, oa, w.text);
   TRY(hipGetLastError());
   TRY(mailbox_wait(w.mbox, stream));
   for (int k = 0; k < 3; k++) w.h_counts[k] = (uint64_t)w.mbox.host[1 + 2 * k] | ((uint64_t)w.mbox.host[2 + 2 * k] << 32);
@@ -529,15 +538,13 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   res->n_rows = (uint32_t)w.h_counts[1];
   if (ext && ext->kept) *ext->kept = (uint32_t)(w.h_counts[1] >> 32);
   res->text_bytes = w.h_counts[0];
-  TRY(grow(&w.text, w.text_cap, std::max<size_t>(1, (size_t)res->text_bytes)));
-  if (res->n_rows) {
-    OutArgs oa{};
-    oa.rc = rc; oa.blob = w.blob; oa.names = w.names; oa.name_off = w.name_off; oa.hits = w.hits; oa.order = w.vals2; oa.midlen = w.midlen;
-    oa.offs = w.offs; oa.stage = w.stage; oa.n = n_in; oa.mid_bound = mid_bound; oa.n_dev = n_dev; oa.ext_off = w.ext_off; oa.ext_rows = w.ext_rows;
-    const unsigned rows_per_block = 4 * OUT_ROWS_PER_WAVE;
-    hipLaunchKernelGGL(out_kernel, dim3((n_in + rows_per_block - 1) / rows_per_block), dim3(256), rc.head_len + rc.tail_len, stream, oa, w.text);
+  if (res->text_bytes > oa.text_cap) {                       // the kernel returned at once: a buffer of the right size (and some more), again
+    TRY(hipStreamSynchronize(stream));
+    TRY(grow(&w.text, w.text_cap, (size_t)res->text_bytes + (size_t)(res->text_bytes / 8) + 4096));
+    oa.text_cap = w.text_cap;
+    hipLaunchKernelGGL(rows_kernel, rows_grid, dim3(256), mid_lds, stream, ma, oa, w.text);
+    TRY(hipGetLastError());
   }
-  TRY(hipGetLastError());
   res->d_text = w.text;
   return hipSuccess;
 }

@@ -36,6 +36,7 @@ constexpr uint32_t HITS_FLAG_SCORE_RANGE = 1;   // a score fell outside the sort
 constexpr uint32_t HITS_FLAG_CLUSTER = 2;       // an overlap cluster is longer than one lane should walk
 
 constexpr uint32_t HITS_FLAG_ROW = 4;           // a row has more padded columns than max_ops allows
+constexpr uint32_t HITS_FLAG_INTERNAL = 16;     // a row's length differs between len_kernel and rows_kernel (a bug, never a property of the input)
 constexpr uint32_t HITS_FLAG_HALO = 8;          // HitsOwn: an owned hit hangs on a removeOverlaps cluster that starts where not every hit is known
 
 // Whether the sort keys can represent this search at all.
@@ -91,6 +92,9 @@ hipError_t hits_run(HitsWork** work, const HitsRef& ref, const RawAln* d_final, 
                     const uint64_t* d_win_base, const int2* d_win, const RowStrings& strings, int max_overlap, int score_hi,
                     int max_ops, uint32_t window_reach, hipStream_t stream, HitsResult* res, const HitsExt* ext = nullptr,
                     const HitsOwn* own = nullptr);
+// Flags raised while the rows of the last hits_run were being written (HITS_FLAG_INTERNAL); valid once the stream the rows kernel ran
+// on is done.
+uint32_t hits_late(const HitsWork* work);
 void hits_destroy(HitsWork* work);
 
 }  // namespace calitas

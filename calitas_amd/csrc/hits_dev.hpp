@@ -111,7 +111,7 @@ __device__ char base_upper_dev(const HitsRef& ref, uint64_t gpos) {
   return base_letter((ref.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u);
 }
 
-constexpr int MID_ROWS_PER_WAVE = 4;
+constexpr int HITS_BOX_LATE = 8;      // word of the work's mailbox for flags raised while rows are written (the post uses words 0..6)
 constexpr int MID_COLS = 64;          // padded columns a row may have on this path: one per lane
 constexpr int MID_LINE = 6 * MID_COLS + 128;   // bytes of a wave's line buffer = the largest mid_bound
 constexpr int MID_FWD = 128;          // reference bases staged per row: the alignment and its flanks
@@ -335,6 +335,41 @@ hipError_t grow(T** p, size_t& cap, size_t need) {
 
 }  // namespace
 
+// Length of the middle part of a row = what build_middle computes with ballots, for one lane: the field lengths of RH:210-254 from
+// the alignment's op counts (GA:99-115, 139-183) and the run-length encoding of its cigar.  -1: the row builder does not lay it out.
+__device__ __forceinline__ int middle_length(const RawAln* rp, const HitRec& h, int L, int pam_len, int pu_len, int n_max, int mid_bound) {
+  const int ng = rp->n_ops, pam = rp->pam;
+  const int gap = pam >= 0 ? rp->offset : 0;
+  const uint32_t pam_x = rp->pam_x;
+  const int n = ng + gap + pam_len;
+  const int lo = min(h.start - 8, h.gstart - 10), hi = max(h.end + 8, h.gend + 10);
+  if (n > n_max || n > MID_COLS || hi - lo > MID_FWD) return -1;
+  const OpsWords ow = load_ops_words(rp->ops);
+  const OpCounts oc = count_ops(ow, ng);
+  const int utn = oc.not_ins - oc.lead_d - oc.trail_d;                 // target bases under the first .. last protospacer column (GA:111-115)
+  const int gmm = oc.non_eq - oc.gaps, pam_mm = pam >= 0 ? __popc(pam_x) : 0;   // 'X' columns by the case of the query base (GA:103, 106)
+  const int ggp = oc.gaps + gap;                                       // every gap column has a protospacer base on one side (GA:104, 168-182)
+  const int edits = oc.non_eq + gap + pam_mm;                          // GA:101
+  // Cigar.coalesce + toString over the columns: guide part (aligner order = traceback order reversed), the gap, the PAM; the number of
+  // runs and of two-digit run lengths does not depend on the direction the columns are read in (5' PAM)
+  int runs = 0, long_runs = 0, prev = -1, len = 0;
+  for (int k = 0; k < n; k++) {
+    const int op = k < ng ? ow.op(ng - 1 - k) : k < ng + gap ? 3 : (int)((pam_x >> ((k - ng - gap) & 15)) & 1u);
+    if (op != prev) { if (len >= 10) long_runs++; runs++; len = 0; prev = op; }
+    len++;
+  }
+  if (len >= 10) long_runs++;
+  const int cigar_len = 2 * runs + long_runs;
+  auto digits = [](int v) {
+    const unsigned u = (unsigned)(v < 0 ? -v : v);
+    return (v < 0 ? 1 : 0) + 1 + (u >= 10u) + (u >= 100u) + (u >= 1000u) + (u >= 10000u) + (u >= 100000u) + (u >= 1000000u) + (u >= 10000000u) +
+           (u >= 100000000u) + (u >= 1000000000u);
+  };
+  const int total = MID_FIELDS + digits(h.gstart) + digits(h.gend) + 1 + utn + 10 + 10 + pu_len + digits(h.score) + digits(gmm) + digits(ggp) +
+                    digits(gmm + ggp) + digits(pam_mm) + digits(edits) + 3 * n + 8 + 8 + cigar_len + digits(L) + digits(utn);
+  return total > mid_bound ? -1 : total;
+}
+
 struct HitsWork {
   HitRec* hits = nullptr; size_t hits_cap = 0;
   uint64_t *keys = nullptr, *keys2 = nullptr, *lens = nullptr, *offs = nullptr;
@@ -344,7 +379,6 @@ struct HitsWork {
   uint8_t *keep = nullptr, *head = nullptr; size_t keep_cap = 0, head_cap = 0;
   void* temp = nullptr; size_t temp_cap = 0;
   char* text = nullptr; size_t text_cap = 0;
-  uint8_t* stage = nullptr; size_t stage_cap = 0;
   uint32_t* midlen = nullptr; size_t midlen_cap = 0;
   char* blob = nullptr; size_t blob_cap = 0;
   char* names = nullptr; size_t names_cap = 0;

@@ -796,8 +796,16 @@ struct LaneText {
   bool on_host = false;
   bool in_place = false;               // the rows kernel wrote the text to its final place in the caller's page-locked buffer (LaneDest)
   std::string host_rows;
+  const HitsWork* rows_by = nullptr;   // the general row stage that wrote d_text (its late flags are looked at once the text has been copied)
   calitas_timing_t tm{};
 };
+
+// After the text of a lane has been copied (so its rows kernel is done): did the rows kernel of the general stage object to anything?
+static int rows_late_check(calitas_ctx* lane, const LaneText& lt) {
+  if (lt.rows_by && hits_late(lt.rows_by) != 0)
+    return calitas_fail(lane, CALITAS_EHIP, "rows kernel: a row's length differs between the two kernels (internal error)");
+  return CALITAS_OK;
+}
 
 // Kernel time of a lane's row stage once its last kernel is done.  General kernels: ev[4] .. ev[5] around hits_run.  Binned tail: no event
 // sits between its kernels, so: end of the scan .. end of the rows kernel, less align_kernel + trace_kernel (by the stamps) -- the two bin
@@ -990,7 +998,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       g_marks.mark("rows-queued");
       kernel_times(lane, lt.tm);          // while out_kernel runs
       if (res.flags == 0) {
-        lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows;
+        lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows; lt.rows_by = lane->hits;
         if (own_general) lt.tm.owned_general_lanes = 1;
         return CALITAS_OK;
       }
@@ -1464,6 +1472,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
           ctx->pool->for_blocks(n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
         }
         if (rc) break;
+        if ((rc = rows_late_check(ctx, lt)) != CALITAS_OK) break;
       }
       total += (size_t)lt.bytes;
     }
@@ -1978,12 +1987,14 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       }
       calitas_free(staging);
       if (r) return r;
+      if ((r = rows_late_check(lane, lt)) != CALITAS_OK) return r;
       if (wrote != (size_t)lt.bytes) return fail(lane, CALITAS_EHIP, "a lane's compact rows do not expand to the row count the device reported (internal error)");
       lt.tm.hits_kernel_ms = rows_stage_ms(lane, lt.tm);
       return CALITAS_OK;
     }
     int r = text_to_host(ctx, lane, text + hlen + offset, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
     if (r) return r;
+    if ((r = rows_late_check(lane, lt)) != CALITAS_OK) return r;
     lt.tm.hits_kernel_ms = rows_stage_ms(lane, lt.tm);   // recorded around hits_run by lane_rows
     return CALITAS_OK;
   };
@@ -2370,10 +2381,12 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
             if (!cr) wrote = expand_rows(staging, (size_t)lt.bytes, lt.rows, rs_full.head, rs_full.tail, text + hlen, ctx->pool);
             expand_us.fetch_add((uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_exp).count());
             calitas_free(staging);
+            if (!cr) cr = rows_late_check(lane, lt);
             if (cr) { calitas_free(text); return cr; }
             if (wrote != total - hlen) { calitas_free(text); return fail(lane, CALITAS_EHIP, "the compact rows of a guide do not expand to the row count the device reported (internal error)"); }
           } else if (lt.bytes) {
             int cr = text_to_host(ctx, lane, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+            if (!cr) cr = rows_late_check(lane, lt);
             if (cr) { calitas_free(text); return cr; }
           }
           text[total] = 0;
