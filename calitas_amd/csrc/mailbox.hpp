@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include "parallel.hpp"   // Backoff
+
 #include <sched.h>
 #include <time.h>
 
@@ -12,23 +14,6 @@
 #include <cstdint>
 
 namespace calitas {
-
-// One step of a host wait on the critical path: pure spinning for the first ~50 us (a round trip through the mailbox is 10-30 us and a
-// blocking wait would add its wake-up latency to each of them), then the core is offered to whoever else can run on it (eight ranks
-// of a job, each with a caller and a lane thread, may share sixteen cores), and from 5 ms on -- a long kernel, a 20 GB copy -- the
-// thread sleeps between looks.
-struct Backoff {
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  unsigned spins = 0;
-  long long waited_us() const { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
-  void pause() {
-    if (++spins < 256) { __builtin_ia32_pause(); return; }   // (the first ~10 us: not even a look at the clock)
-    const long long us = waited_us();
-    if (us < 50) __builtin_ia32_pause();
-    else if (us < 5000) sched_yield();
-    else { timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
-  }
-};
 
 constexpr int MAILBOX_WORDS = 21;
 

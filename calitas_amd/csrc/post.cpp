@@ -292,6 +292,110 @@ size_t expand_rows(const char* compact, size_t n, uint64_t rows, const std::stri
   return p.written;
 }
 
+namespace {
+
+// The output is written once and not read again by this thread: whole cache lines go out with non-temporal stores (no read for
+// ownership: a 176 MB text is otherwise 352 MB of memory traffic plus the 84 MB read), assembled in a line-sized buffer.
+struct LineWriter {
+  char* w;                                                    // next byte of the output
+  alignas(64) char line[64];
+  size_t fill = 0;                                            // bytes of the current (64-byte aligned) output line held in line[]
+  explicit LineWriter(char* at) : w(at) {}
+  void put(const char* p, size_t len) {
+    if (fill == 0) {                                          // not on a line yet: plain stores up to the next line boundary
+      const size_t to_line = (64 - ((uintptr_t)w & 63)) & 63;
+      const size_t c = std::min(len, to_line);
+      std::memcpy(w, p, c); w += c; p += c; len -= c;
+      if (!len && ((uintptr_t)w & 63)) return;
+    }
+    while (len) {
+      const size_t c = std::min(len, 64 - fill);
+      std::memcpy(line + fill, p, c);
+      fill += c; p += c; len -= c;
+      if (fill == 64) {
+        const __m128i* src = reinterpret_cast<const __m128i*>(line);
+        __m128i* dst = reinterpret_cast<__m128i*>(w);
+        _mm_stream_si128(dst, src[0]); _mm_stream_si128(dst + 1, src[1]); _mm_stream_si128(dst + 2, src[2]); _mm_stream_si128(dst + 3, src[3]);
+        w += 64; fill = 0;
+      }
+    }
+  }
+  void finish() { if (fill) { std::memcpy(w, line, fill); w += fill; fill = 0; } _mm_sfence(); }
+};
+
+// The expansion as a job of pieces (WorkerPool::offer): a piece is the rows that START in one stretch of the compact text.  (1) every
+// piece's rows are counted, (2) every piece is placed -- a row's place is its compact offset plus (head + tail - 1) bytes for every
+// row before it.  Whoever arrives takes the next piece of the phase; the phase ends when the pieces that were taken are finished, so
+// a worker that arrives late (or never) holds nobody up.  (Both phases through WorkerPool::run, a static share per worker, made one
+// hg38-sized call in forty take 6-10 ms: profiles/r04_slow_calls.txt.)
+struct ExpandJob : SharedJob {
+  const char* compact = nullptr;
+  char* out = nullptr;
+  const char* hp = nullptr; const char* tp = nullptr;
+  size_t H = 0, TL = 0, add = 0;
+  uint64_t max_rows = 0;
+  size_t limit = 0;                                           // participants that may take pieces (CALITAS_EXPAND_THREADS)
+  std::vector<size_t> first;                                  // [pieces + 1] piece starts, on row starts
+  std::vector<size_t> count;                                  // [pieces] rows of each piece
+  std::atomic<size_t> joined{0}, next1{0}, done1{0}, next2{0}, done2{0};
+  size_t pieces() const { return first.size() - 1; }
+
+  void work() override {
+    if (joined.fetch_add(1, std::memory_order_relaxed) >= limit) return;
+    const size_t P = pieces();
+    for (;;) {                                                // (1)
+      const size_t k = next1.fetch_add(1, std::memory_order_relaxed);
+      if (k >= P) break;
+      size_t c = 0;
+      for (const char* p = compact + first[k]; p < compact + first[k + 1];) {
+        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(compact + first[k + 1] - p));
+        if (!nl) break;
+        c++; p = nl + 1;
+      }
+      count[k] = c;
+      done1.fetch_add(1, std::memory_order_release);
+    }
+    Backoff wait;
+    while (done1.load(std::memory_order_acquire) < P) wait.pause();
+    size_t k = next2.fetch_add(1, std::memory_order_relaxed);
+    if (k >= P) return;
+    size_t before = 0, at = 0, total = 0;                     // rows before piece `at`
+    for (size_t i = 0; i < P; i++) total += count[i];
+    if (total > max_rows) return;                             // (nothing is written: finish() tells the caller)
+    for (;;) {                                                // (2)
+      for (; at < k; at++) before += count[at];
+      const char* p = compact + first[k];
+      const char* const end = compact + first[k + 1];
+      LineWriter lw(out + first[k] + before * add);
+      while (p < end) {
+        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+        const size_t len = (size_t)(nl - p);                    // (every row of the piece ends inside it: counted above)
+        lw.put(hp, H);
+        lw.put(p, len);
+        lw.put(tp, TL);
+        p = nl + 1;
+      }
+      lw.finish();
+      done2.fetch_add(1, std::memory_order_release);
+      k = next2.fetch_add(1, std::memory_order_relaxed);
+      if (k >= P) return;
+    }
+  }
+  // The caller's side, after its own work(): the rows counted; the pieces others still hold are waited for.
+  uint64_t finish() {
+    const size_t P = pieces();
+    Backoff wait;
+    while (done1.load(std::memory_order_acquire) < P) wait.pause();
+    uint64_t total = 0;
+    for (size_t i = 0; i < P; i++) total += count[i];
+    if (total > max_rows) return total;
+    while (done2.load(std::memory_order_acquire) < P) wait.pause();
+    return total;
+  }
+};
+
+}  // namespace
+
 ExpandedPiece expand_rows_piece(const char* compact, size_t n, const std::string& head, const std::string& tail, char* out, WorkerPool* pool, uint64_t max_rows) {
   ExpandedPiece res;
   // only whole rows: up to the last newline
@@ -300,87 +404,33 @@ ExpandedPiece expand_rows_piece(const char* compact, size_t n, const std::string
     n = nl ? (size_t)((const char*)nl - compact) + 1 : 0;
   }
   if (!n) return res;
-  WorkerPool serial(1);
-  if (!pool || n < (1u << 20)) pool = &serial;
+  if (n < (1u << 20)) pool = nullptr;
   // All workers (CALITAS_EXPAND_THREADS for experiments): the middle range's expansion of a chunked call is on its critical path --
   // hg38-sized call 2.34 ms with 16 workers, 2.35 with 8 (and a wider spread), 2.76 with 4, 3.7 with 2 (tools/sweep_env.py).
-  size_t T = (size_t)pool->size();
-  if (const char* e = tune::get("CALITAS_EXPAND_THREADS")) T = std::max<size_t>(1, std::min<size_t>((size_t)pool->size(), (size_t)std::atoi(e)));
-  const size_t H = head.size(), TL = tail.size();
-  // every worker takes the rows that START in its byte range: (1) count them, (2) place them -- a row's place is its compact offset plus
-  // (head + tail - 1) bytes for every row before it
-  std::vector<size_t> first(T + 1, n), count(T + 1, 0);
-  auto row_start_at_or_after = [&](size_t b) -> size_t {
-    if (b == 0) return 0;
-    if (b >= n) return n;
+  size_t T = pool ? (size_t)pool->size() : 1;
+  if (const char* e = tune::get("CALITAS_EXPAND_THREADS")) T = std::max<size_t>(1, std::min<size_t>(T, (size_t)std::atoi(e)));
+  auto job = std::make_shared<ExpandJob>();
+  job->compact = compact; job->out = out;
+  job->hp = head.data(); job->tp = tail.data();
+  job->H = head.size(); job->TL = tail.size(); job->add = head.size() + tail.size() - 1;
+  job->max_rows = max_rows; job->limit = T;
+  // pieces of 64 KB of compact text (about 180 KB of rows, some 10 us of one core): small enough that the last ones end together
+  const size_t piece = 64u << 10;
+  const size_t P = T == 1 ? 1 : (n + piece - 1) / piece;
+  job->first.assign(P + 1, n);
+  job->count.assign(P, 0);
+  for (size_t k = 0; k < P; k++) {
+    const size_t b = k * piece;
+    if (b == 0) { job->first[k] = 0; continue; }
     const char* nl = (const char*)std::memchr(compact + b - 1, '\n', n - (b - 1));
-    return nl ? (size_t)(nl - compact) + 1 : n;
-  };
-  const size_t per = (n + T - 1) / T;
-  for (size_t t = 0; t < T; t++) first[t] = row_start_at_or_after(std::min(n, per * t));
-  first[T] = n;
-  const size_t add = H + TL - 1;
-  const char* const hp = head.data();
-  const char* const tp = tail.data();
-  // The output is written once and not read again by this thread: whole cache lines go out with non-temporal stores (no read for
-  // ownership: a 176 MB text is otherwise 352 MB of memory traffic plus the 84 MB read), assembled in a line-sized buffer.
-  struct LineWriter {
-    char* w;                                                    // next byte of the output
-    alignas(64) char line[64];
-    size_t fill = 0;                                            // bytes of the current (64-byte aligned) output line held in line[]
-    explicit LineWriter(char* at) : w(at) {}
-    void put(const char* p, size_t len) {
-      if (fill == 0) {                                          // not on a line yet: plain stores up to the next line boundary
-        const size_t to_line = (64 - ((uintptr_t)w & 63)) & 63;
-        const size_t c = std::min(len, to_line);
-        std::memcpy(w, p, c); w += c; p += c; len -= c;
-        if (!len && ((uintptr_t)w & 63)) return;
-      }
-      while (len) {
-        const size_t c = std::min(len, 64 - fill);
-        std::memcpy(line + fill, p, c);
-        fill += c; p += c; len -= c;
-        if (fill == 64) {
-          const __m128i* src = reinterpret_cast<const __m128i*>(line);
-          __m128i* dst = reinterpret_cast<__m128i*>(w);
-          _mm_stream_si128(dst, src[0]); _mm_stream_si128(dst + 1, src[1]); _mm_stream_si128(dst + 2, src[2]); _mm_stream_si128(dst + 3, src[3]);
-          w += 64; fill = 0;
-        }
-      }
-    }
-    void finish() { if (fill) { std::memcpy(w, line, fill); w += fill; fill = 0; } _mm_sfence(); }
-  };
-  pool->run([&](int tid) {                                     // (1) rows that start in each worker's byte range
-    if ((size_t)tid >= T) return;
-    size_t c = 0;
-    for (const char* p = compact + first[(size_t)tid]; p < compact + first[(size_t)tid + 1];) {
-      const char* nl = (const char*)std::memchr(p, '\n', (size_t)(compact + first[(size_t)tid + 1] - p));
-      if (!nl) break;
-      c++; p = nl + 1;
-    }
-    count[(size_t)tid + 1] = c;
-  });
-  for (size_t t = 0; t < T; t++) count[t + 1] += count[t];
-  if (count[T] > max_rows) { res.rows = count[T]; return res; }   // more rows than the caller has room for: nothing is written
-  // (Both phases as one job with a spin barrier between them, and workers that keep looking for the next job for 200 us, saved 0.03 ms of
-  // an hg38-sized call -- and made one call in twenty take 5-8 ms: sixteen workers and three lane threads spinning on sixteen cores
-  // leave a descheduled worker waiting for a whole time slice.)
-  pool->run([&](int tid) {                                     // (2) placed
-    if ((size_t)tid >= T) return;
-    const char* p = compact + first[(size_t)tid];
-    const char* const end = compact + first[(size_t)tid + 1];
-    LineWriter lw(out + first[(size_t)tid] + count[(size_t)tid] * add);
-    while (p < end) {
-      const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
-      const size_t len = (size_t)(nl - p);                      // (every row of the range ends inside it: counted above)
-      lw.put(hp, H);
-      lw.put(p, len);
-      lw.put(tp, TL);
-      p = nl + 1;
-    }
-    lw.finish();
-  });
-  res.consumed = n; res.rows = count[T]; res.written = n + (size_t)count[T] * add;
+    job->first[k] = nl ? (size_t)(nl - compact) + 1 : n;
+  }
+  if (T > 1) pool->offer(job);
+  job->work();
+  const uint64_t rows = job->finish();
+  res.rows = rows;
+  if (rows > max_rows) return res;                            // more rows than the caller has room for: nothing was written
+  res.consumed = n; res.written = n + (size_t)rows * job->add;
   return res;
 }
 

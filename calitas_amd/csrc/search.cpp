@@ -1945,6 +1945,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     if (lt.compact_bytes) {                                    // compact rows: over the bus into a staging block, head and tail put back on the pool
       char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.compact_bytes);
       if (!staging) return fail(lane, CALITAS_EINVAL, "out of memory");
+      g_marks.mark("staging");
       int r = CALITAS_OK;
       size_t wrote = 0;
       const size_t nbytes = (size_t)lt.compact_bytes;
@@ -1984,6 +1985,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       } else {
         r = text_to_host(ctx, lane, staging, lt.d_text, nbytes, &copy_mu, &lt.tm.hits_copy_ms);
         if (!r) wrote = expand_rows(staging, nbytes, lt.rows, rs.head, rs.tail, text + hlen + offset, ctx->pool);
+        g_marks.mark("expanded");
       }
       calitas_free(staging);
       if (r) return r;
