@@ -5,6 +5,7 @@
 // PCIe takes.  hsa_amd_memory_async_copy between the GPU agent and a CPU agent uses a DMA engine instead and leaves the CUs alone.
 #pragma once
 #include <cstddef>
+#include <vector>
 
 namespace calitas {
 
@@ -22,6 +23,9 @@ class DmaCopier {
   // copy and returns a ticket (0: declined, see last_reason), finish() waits for it (false: the runtime reports a failed copy).
   unsigned long long start(void* dst_host, const void* src_dev, size_t n) const;
   bool finish(unsigned long long ticket) const;
+  // One copy as pieces of `piece` bytes queued back to back (a ticket each, in the order of the bytes): the caller hands the pieces on
+  // as they land.  false: declined, nothing is on its way.
+  bool start_pieces(void* dst_host, const void* src_dev, size_t n, size_t piece, std::vector<unsigned long long>& tickets) const;
   static const char* last_reason();   // why the last copy_to_host of this thread declined ("" otherwise)
 
  private:

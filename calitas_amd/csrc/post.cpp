@@ -283,155 +283,168 @@ RowStrings compact_row_strings(const RowStrings& full) {
   return c;
 }
 
-size_t expand_rows(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail, char* out, WorkerPool* pool) {
-  if (n && compact[n - 1] != '\n') return (size_t)-1;
-  // (the row count is checked before anything is written when the text is small enough to count on one thread; a large one is
-  // counted by the workers as part of the expansion, and the caller's buffer has room for the stated number of rows either way)
-  const ExpandedPiece p = expand_rows_piece(compact, n, head, tail, out, pool, rows);
-  if (p.consumed != n || p.rows != rows) return (size_t)-1;
-  return p.written;
-}
-
 namespace {
 
-// The output is written once and not read again by this thread: whole cache lines go out with non-temporal stores (no read for
-// ownership: a 176 MB text is otherwise 352 MB of memory traffic plus the 84 MB read), assembled in a line-sized buffer.
-struct LineWriter {
-  char* w;                                                    // next byte of the output
-  alignas(64) char line[64];
-  size_t fill = 0;                                            // bytes of the current (64-byte aligned) output line held in line[]
-  explicit LineWriter(char* at) : w(at) {}
+// Rows are assembled in a buffer that stays in the first-level cache and leave it as whole 64-byte lines through non-temporal stores:
+// the output is written once and not read again by this thread (no read for ownership: a 176 MB text is otherwise 352 MB of memory
+// traffic plus the 84 MB read).  The bytes before the first line boundary of the destination and behind the last go out as plain stores.
+struct RowWriter {
+  char* w;                                                    // where buf[0] belongs
+  size_t fill = 0;
+  alignas(64) char buf[4096];
+  explicit RowWriter(char* at) : w(at) {}
   void put(const char* p, size_t len) {
-    if (fill == 0) {                                          // not on a line yet: plain stores up to the next line boundary
-      const size_t to_line = (64 - ((uintptr_t)w & 63)) & 63;
-      const size_t c = std::min(len, to_line);
-      std::memcpy(w, p, c); w += c; p += c; len -= c;
-      if (!len && ((uintptr_t)w & 63)) return;
-    }
     while (len) {
-      const size_t c = std::min(len, 64 - fill);
-      std::memcpy(line + fill, p, c);
+      const size_t c = std::min(len, sizeof(buf) - fill);
+      std::memcpy(buf + fill, p, c);
       fill += c; p += c; len -= c;
-      if (fill == 64) {
-        const __m128i* src = reinterpret_cast<const __m128i*>(line);
-        __m128i* dst = reinterpret_cast<__m128i*>(w);
-        _mm_stream_si128(dst, src[0]); _mm_stream_si128(dst + 1, src[1]); _mm_stream_si128(dst + 2, src[2]); _mm_stream_si128(dst + 3, src[3]);
-        w += 64; fill = 0;
-      }
+      if (fill == sizeof(buf)) lines_out();
     }
   }
-  void finish() { if (fill) { std::memcpy(w, line, fill); w += fill; fill = 0; } _mm_sfence(); }
-};
-
-// The expansion as a job of pieces (WorkerPool::offer): a piece is the rows that START in one stretch of the compact text.  (1) every
-// piece's rows are counted, (2) every piece is placed -- a row's place is its compact offset plus (head + tail - 1) bytes for every
-// row before it.  Whoever arrives takes the next piece of the phase; the phase ends when the pieces that were taken are finished, so
-// a worker that arrives late (or never) holds nobody up.  (Both phases through WorkerPool::run, a static share per worker, made one
-// hg38-sized call in forty take 6-10 ms: profiles/r04_slow_calls.txt.)
-struct ExpandJob : SharedJob {
-  const char* compact = nullptr;
-  char* out = nullptr;
-  const char* hp = nullptr; const char* tp = nullptr;
-  size_t H = 0, TL = 0, add = 0;
-  uint64_t max_rows = 0;
-  size_t limit = 0;                                           // participants that may take pieces (CALITAS_EXPAND_THREADS)
-  std::vector<size_t> first;                                  // [pieces + 1] piece starts, on row starts
-  std::vector<size_t> count;                                  // [pieces] rows of each piece
-  std::atomic<size_t> joined{0}, next1{0}, done1{0}, next2{0}, done2{0};
-  size_t pieces() const { return first.size() - 1; }
-
-  void work() override {
-    if (joined.fetch_add(1, std::memory_order_relaxed) >= limit) return;
-    const size_t P = pieces();
-    for (;;) {                                                // (1)
-      const size_t k = next1.fetch_add(1, std::memory_order_relaxed);
-      if (k >= P) break;
-      size_t c = 0;
-      for (const char* p = compact + first[k]; p < compact + first[k + 1];) {
-        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(compact + first[k + 1] - p));
-        if (!nl) break;
-        c++; p = nl + 1;
-      }
-      count[k] = c;
-      done1.fetch_add(1, std::memory_order_release);
+  void lines_out() {
+    size_t off = 0;
+    if ((uintptr_t)w & 63) {                                  // (once per writer: up to the first line boundary)
+      off = std::min(fill, (size_t)(64 - ((uintptr_t)w & 63)));
+      std::memcpy(w, buf, off);
+      w += off;
     }
-    Backoff wait;
-    while (done1.load(std::memory_order_acquire) < P) wait.pause();
-    size_t k = next2.fetch_add(1, std::memory_order_relaxed);
-    if (k >= P) return;
-    size_t before = 0, at = 0, total = 0;                     // rows before piece `at`
-    for (size_t i = 0; i < P; i++) total += count[i];
-    if (total > max_rows) return;                             // (nothing is written: finish() tells the caller)
-    for (;;) {                                                // (2)
-      for (; at < k; at++) before += count[at];
-      const char* p = compact + first[k];
-      const char* const end = compact + first[k + 1];
-      LineWriter lw(out + first[k] + before * add);
-      while (p < end) {
-        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
-        const size_t len = (size_t)(nl - p);                    // (every row of the piece ends inside it: counted above)
-        lw.put(hp, H);
-        lw.put(p, len);
-        lw.put(tp, TL);
-        p = nl + 1;
-      }
-      lw.finish();
-      done2.fetch_add(1, std::memory_order_release);
-      k = next2.fetch_add(1, std::memory_order_relaxed);
-      if (k >= P) return;
+    const size_t lines = (fill - off) / 64;
+    const char* src = buf + off;
+    for (size_t i = 0; i < lines; i++, src += 64, w += 64) {
+      __m128i* dst = reinterpret_cast<__m128i*>(w);
+      _mm_stream_si128(dst, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src)));
+      _mm_stream_si128(dst + 1, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 16)));
+      _mm_stream_si128(dst + 2, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 32)));
+      _mm_stream_si128(dst + 3, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 48)));
     }
+    off += lines * 64;
+    if (off < fill) std::memmove(buf, buf + off, fill - off);
+    fill -= off;
   }
-  // The caller's side, after its own work(): the rows counted; the pieces others still hold are waited for.
-  uint64_t finish() {
-    const size_t P = pieces();
-    Backoff wait;
-    while (done1.load(std::memory_order_acquire) < P) wait.pause();
-    uint64_t total = 0;
-    for (size_t i = 0; i < P; i++) total += count[i];
-    if (total > max_rows) return total;
-    while (done2.load(std::memory_order_acquire) < P) wait.pause();
-    return total;
+  void finish() {
+    lines_out();
+    if (fill) { std::memcpy(w, buf, fill); w += fill; fill = 0; }
+    _mm_sfence();
   }
 };
 
 }  // namespace
 
-ExpandedPiece expand_rows_piece(const char* compact, size_t n, const std::string& head, const std::string& tail, char* out, WorkerPool* pool, uint64_t max_rows) {
-  ExpandedPiece res;
-  // only whole rows: up to the last newline
-  while (n && compact[n - 1] != '\n') {
-    const void* nl = memrchr(compact, '\n', n);
-    n = nl ? (size_t)((const char*)nl - compact) + 1 : 0;
+// The expansion as a job of pieces (WorkerPool::offer) over a text that may still be arriving.  A piece is the rows that START in one
+// 64 KB stretch of the compact text.  Whoever arrives takes the next piece, waits until its bytes are there, counts its rows, learns
+// from the piece before it how many rows precede it (and tells the piece behind it), and places its rows -- a row's place is its
+// compact offset plus (head + tail - 1) bytes for every row before it.  Only the counting is a chain from piece to piece (a few
+// microseconds each); the placing runs on as many workers as have arrived.  Nobody waits for a worker that has not arrived: it
+// finds the pieces gone.  (Two WorkerPool::run passes with a static share per worker made one hg38-sized call in forty take 6-10 ms,
+// profiles/r04_slow_calls.txt.)
+struct RowExpansion : SharedJob {
+  static constexpr size_t PIECE = 64u << 10;
+  const char* compact = nullptr;
+  size_t n = 0;
+  char* out = nullptr;
+  const char* hp = nullptr; const char* tp = nullptr;
+  size_t H = 0, TL = 0, add = 0;
+  uint64_t max_rows = 0;
+  size_t limit = 1, P = 0;
+  std::atomic<size_t> avail{0};                               // bytes of compact[] that are there
+  std::atomic<bool> gave_up{false};                           // the feeder's copy failed: nothing more will arrive
+  std::atomic<bool> too_many{false};                          // more rows than max_rows: the rows beyond are not written
+  std::atomic<size_t> joined{0}, next{0}, done{0};
+  std::unique_ptr<std::atomic<uint64_t>[]> before;            // [P + 1] rows before piece k, plus one (0: not known yet)
+
+  // first byte of the first row that starts at or after b (b > 0); waits for the bytes it has to look at.  n when there is none.
+  size_t row_start(size_t b) {
+    if (b >= n) return n;
+    size_t from = b - 1;
+    Backoff wait;
+    for (;;) {
+      const size_t have = avail.load(std::memory_order_acquire);
+      if (have > from) {
+        const char* nl = (const char*)std::memchr(compact + from, '\n', have - from);
+        if (nl) return (size_t)(nl - compact) + 1;
+        from = have;
+      }
+      if (have >= n || gave_up.load(std::memory_order_relaxed)) return n;
+      wait.pause();
+    }
   }
-  if (!n) return res;
-  if (n < (1u << 20)) pool = nullptr;
-  // All workers (CALITAS_EXPAND_THREADS for experiments): the middle range's expansion of a chunked call is on its critical path --
-  // hg38-sized call 2.34 ms with 16 workers, 2.35 with 8 (and a wider spread), 2.76 with 4, 3.7 with 2 (tools/sweep_env.py).
-  size_t T = pool ? (size_t)pool->size() : 1;
-  if (const char* e = tune::get("CALITAS_EXPAND_THREADS")) T = std::max<size_t>(1, std::min<size_t>(T, (size_t)std::atoi(e)));
-  auto job = std::make_shared<ExpandJob>();
-  job->compact = compact; job->out = out;
+
+  void work() override {
+    if (joined.fetch_add(1, std::memory_order_relaxed) >= limit) return;
+    for (;;) {
+      const size_t k = next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= P) return;
+      const size_t first = k ? row_start(k * PIECE) : 0;
+      const size_t last = row_start((k + 1) * PIECE);          // (every row of the piece ends at or before `last`, which has arrived)
+      uint64_t c = 0;
+      for (const char* p = compact + first; p < compact + last;) {
+        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(compact + last - p));
+        if (!nl) break;                                       // (a text that does not end with a newline: the caller checks)
+        c++; p = nl + 1;
+      }
+      Backoff wait;
+      uint64_t b;
+      while ((b = before[k].load(std::memory_order_acquire)) == 0) wait.pause();
+      before[k + 1].store(b + c, std::memory_order_release);
+      b -= 1;
+      if (b + c > max_rows) too_many.store(true, std::memory_order_relaxed);
+      else if (c && !gave_up.load(std::memory_order_relaxed)) {
+        RowWriter rw(out + first + b * add);
+        const char* p = compact + first;
+        const char* const end = compact + last;
+        while (p < end) {
+          const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+          if (!nl) break;
+          rw.put(hp, H);
+          rw.put(p, (size_t)(nl - p));
+          rw.put(tp, TL);
+          p = nl + 1;
+        }
+        rw.finish();
+      }
+      done.fetch_add(1, std::memory_order_release);
+    }
+  }
+};
+
+std::shared_ptr<RowExpansion> expand_rows_begin(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail,
+                                                char* out, WorkerPool* pool) {
+  auto job = std::make_shared<RowExpansion>();
+  job->compact = compact; job->n = n; job->out = out;
   job->hp = head.data(); job->tp = tail.data();
   job->H = head.size(); job->TL = tail.size(); job->add = head.size() + tail.size() - 1;
-  job->max_rows = max_rows; job->limit = T;
-  // pieces of 64 KB of compact text (about 180 KB of rows, some 10 us of one core): small enough that the last ones end together
-  const size_t piece = 64u << 10;
-  const size_t P = T == 1 ? 1 : (n + piece - 1) / piece;
-  job->first.assign(P + 1, n);
-  job->count.assign(P, 0);
-  for (size_t k = 0; k < P; k++) {
-    const size_t b = k * piece;
-    if (b == 0) { job->first[k] = 0; continue; }
-    const char* nl = (const char*)std::memchr(compact + b - 1, '\n', n - (b - 1));
-    job->first[k] = nl ? (size_t)(nl - compact) + 1 : n;
-  }
-  if (T > 1) pool->offer(job);
-  job->work();
-  const uint64_t rows = job->finish();
-  res.rows = rows;
-  if (rows > max_rows) return res;                            // more rows than the caller has room for: nothing was written
-  res.consumed = n; res.written = n + (size_t)rows * job->add;
-  return res;
+  job->max_rows = rows;
+  // All workers (CALITAS_EXPAND_THREADS for experiments): 34.8 MB of rows in 3.8 / 2.0 / 1.0 / 0.55 / 0.35 ms on 1 / 2 / 4 / 8 / 16
+  // of an MI355X box's cores (tools/expand_speed.py); a text below 1 MB is not worth the wake-ups.
+  size_t T = pool && n >= (1u << 20) ? (size_t)pool->size() : 1;
+  if (const char* e = tune::get("CALITAS_EXPAND_THREADS")) T = std::max<size_t>(1, std::min<size_t>(T, (size_t)std::atoi(e)));
+  job->limit = T;
+  job->P = (n + RowExpansion::PIECE - 1) / RowExpansion::PIECE;
+  job->before.reset(new std::atomic<uint64_t>[job->P + 1]);
+  for (size_t k = 0; k <= job->P; k++) job->before[k].store(k ? 0 : 1, std::memory_order_relaxed);
+  if (T > 1 && job->P > 1) pool->offer(job);
+  return job;
+}
+
+void expand_rows_arrived(RowExpansion& job, size_t bytes) { job.avail.store(std::min(bytes, job.n), std::memory_order_release); }
+
+size_t expand_rows_end(RowExpansion& job, bool complete) {
+  if (!complete) job.gave_up.store(true, std::memory_order_release);
+  else job.avail.store(job.n, std::memory_order_release);
+  job.work();
+  Backoff wait;
+  while (job.done.load(std::memory_order_acquire) < job.P) wait.pause();   // (pieces that were taken: their holders are running)
+  if (!complete || job.too_many.load()) return (size_t)-1;
+  if (job.n && job.compact[job.n - 1] != '\n') return (size_t)-1;
+  const uint64_t rows = job.before[job.P].load(std::memory_order_acquire) - 1;
+  if (rows != job.max_rows) return (size_t)-1;
+  return job.n + (size_t)rows * job.add;
+}
+
+size_t expand_rows(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail, char* out, WorkerPool* pool) {
+  if (n && compact[n - 1] != '\n') return (size_t)-1;
+  auto job = expand_rows_begin(compact, n, rows, head, tail, out, pool);
+  return expand_rows_end(*job, true);
 }
 
 static inline char* put_int_p(char* w, long v) {

@@ -1,6 +1,7 @@
 // post.hpp -- host-side stages above the kernels: raw alignment -> GuideAlignment record, the per-window filter,
 // removeOverlaps / sort / hits.txt rows.
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -56,10 +57,15 @@ RowStrings compact_row_strings(const RowStrings& full);
 // n bytes of compact rows (`rows` of them) -> full rows at out, which has room for n + rows * (head.size() + tail.size() - 1) bytes.
 // Returns the bytes written, or (size_t)-1 when the text does not hold exactly `rows` newline-terminated rows.
 size_t expand_rows(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail, char* out, WorkerPool* pool);
-// The rows that END inside compact[0..n) (a piece of a text that is still arriving): consumed = the byte behind the last newline.
-struct ExpandedPiece { size_t consumed = 0, written = 0; uint64_t rows = 0; };
-ExpandedPiece expand_rows_piece(const char* compact, size_t n, const std::string& head, const std::string& tail, char* out, WorkerPool* pool,
-                                uint64_t max_rows = ~0ull);   // more rows than max_rows: nothing is written, .rows says how many
+// The same over a text that is still arriving (the pieces of a copy from the device): begin() wakes the workers, which expand what
+// arrived() has announced -- the first `bytes` bytes of compact[] are there -- and end() has the caller join in and wait for the
+// pieces in hand (complete = false: the copy failed, nothing more will arrive; the result is then (size_t)-1).  head, tail, compact
+// and out stay valid until end() has returned.
+struct RowExpansion;
+std::shared_ptr<RowExpansion> expand_rows_begin(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail,
+                                                char* out, WorkerPool* pool);
+void expand_rows_arrived(RowExpansion& job, size_t bytes);
+size_t expand_rows_end(RowExpansion& job, bool complete);
 
 // Text of the row of ext[e] (without the newline), for hits whose calitas_ext_hit_t::row is NULL: called from the worker pool, only for
 // the hits removeOverlaps kept -- a caller with millions of hits of its own (the variant branch) builds no text for the ones that go.

@@ -41,7 +41,6 @@ thread_local HostMarks g_marks;
 
 static int fail(calitas_ctx* ctx, int code, const std::string& msg) { return calitas_fail(ctx, code, msg); }
 static void* out_alloc(size_t size) { return calitas_out_alloc(size); }
-static int hip_ok(calitas_ctx* ctx, hipError_t e) { return e == hipSuccess ? CALITAS_OK : calitas_fail(ctx, CALITAS_EHIP, std::string("HIP: ") + hipGetErrorString(e)); }
 
 std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, const Scores& sc, int max_guide_diffs, int max_pam_mismatches,
                             GuideDev& gd) {
@@ -144,6 +143,7 @@ struct SearchPlan {
   uint64_t own_lo = 0, own_hi = ~0ull;
   bool narrow_tail = false;           // a range of a chunked call that is not the last: its tail shares the chip with the next scan
   bool three_ranges = false;          // a range of a call cut into three or more
+  bool last_range = false;            // ... and the last of them: no scan runs beside its tail
   bool general_tail = false;          // the caller brings hits of its own into the row stage (HitsExt): the general kernels take them, the bins do not
 };
 
@@ -727,16 +727,19 @@ void calitas_default_version_and_stamp(const char* aligner_version, const char* 
 // The finished text of a lane, device -> page-locked host.  Preferred: an SDMA engine through the HSA runtime (dma.hpp), after
 // waiting for the lane's row kernels -- the CUs stay with the search kernels.  Otherwise the runtime's copy (a blit kernel) on the
 // owner's low-priority copy stream (chunked / batch calls: one stream for all lanes) or on the lane's own stream.
+static void dma_open_once(calitas_ctx* owner) {
+  if (owner->dma_tried) return;
+  std::lock_guard<std::mutex> lk(owner->host_mu);
+  if (!owner->dma_tried) {
+    const char* e = tune::get("CALITAS_SDMA");
+    if (!(e && std::atoi(e) == 0)) owner->dma.open(owner->device);
+    owner->dma_tried = true;
+  }
+}
+
 static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const char* src, size_t n, std::mutex* copy_mu, double* ms_out,
                         hipEvent_t rows_done = nullptr) {
-  if (!owner->dma_tried) {
-    std::lock_guard<std::mutex> lk(owner->host_mu);
-    if (!owner->dma_tried) {
-      const char* e = tune::get("CALITAS_SDMA");
-      if (!(e && std::atoi(e) == 0)) owner->dma.open(owner->device);
-      owner->dma_tried = true;
-    }
-  }
+  dma_open_once(owner);
   if (lane->binned_late_check && src && src == binned_host_text(lane->binned)) {   // the rows kernel wrote the text into host memory itself
     if (rows_done) HIP_TRY(lane, calitas_spin_sync(rows_done)); else HIP_TRY(lane, calitas_spin_sync(lane->stream));
     g_marks.mark("rows-done");
@@ -807,6 +810,49 @@ static int rows_late_check(calitas_ctx* lane, const LaneText& lt) {
   return CALITAS_OK;
 }
 
+// The compact rows of a lane (nbytes of `chromosome \t middle \n` in lt.d_text) become full rows at dst: the text crosses PCIe in
+// pieces queued back to back on the DMA engine, and the worker pool expands what has landed while the rest is on the bus
+// (post.cpp RowExpansion) -- the call's last expansion ends ~one piece after its copy instead of a whole expansion after it.
+// *wrote: bytes written at dst, (size_t)-1 when the text does not hold lt.rows rows.
+static int compact_rows_to_host(calitas_ctx* owner, calitas_ctx* lane, LaneText& lt, size_t nbytes, char* staging, const std::string& head,
+                                const std::string& tail, char* dst, std::mutex* copy_mu, size_t* wrote) {
+  *wrote = 0;
+  dma_open_once(owner);
+  size_t piece = 2u << 20;
+  if (const char* e = tune::get("CALITAS_COMPACT_PIECE_KB")) piece = (size_t)std::max(64, std::atoi(e)) << 10;
+  const bool in_host_text = lane->binned_late_check && lt.d_text == binned_host_text(lane->binned);
+  auto whole = [&]() -> int {
+    int r = text_to_host(owner, lane, staging, lt.d_text, nbytes, copy_mu, &lt.tm.hits_copy_ms);
+    if (r) return r;
+    *wrote = expand_rows(staging, nbytes, lt.rows, head, tail, dst, owner->pool);
+    g_marks.mark("expanded");
+    return CALITAS_OK;
+  };
+  if (!owner->dma.usable() || in_host_text || nbytes < (1u << 20)) return whole();
+  HIP_TRY(lane, calitas_spin_sync(lane->stream));
+  g_marks.mark("rows-done");
+  if (lane->binned_late_check && lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)
+    return fail(lane, CALITAS_EHIP, "binned rows kernel: a row's length differs between the two kernels (internal error)");
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<unsigned long long> tickets;
+  if (!owner->dma.start_pieces(staging, lt.d_text, nbytes, piece, tickets)) {
+    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using hipMemcpyAsync\n", DmaCopier::last_reason());
+    return whole();
+  }
+  auto job = expand_rows_begin(staging, nbytes, lt.rows, head, tail, dst, owner->pool);   // the workers wake while the first piece is on the bus
+  bool ok = true;
+  for (size_t i = 0; i < tickets.size(); i++) {
+    if (!owner->dma.finish(tickets[i])) ok = false;           // (every ticket is waited for: nothing may land in a freed block)
+    if (ok) expand_rows_arrived(*job, std::min(nbytes, (i + 1) * piece));
+  }
+  g_marks.mark("copied");
+  lt.tm.hits_copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *wrote = expand_rows_end(*job, ok);
+  g_marks.mark("expanded");
+  if (!ok) return fail(lane, CALITAS_EHIP, "SDMA copy failed");
+  return CALITAS_OK;
+}
+
 // Kernel time of a lane's row stage once its last kernel is done.  General kernels: ev[4] .. ev[5] around hits_run.  Binned tail: no event
 // sits between its kernels, so: end of the scan .. end of the rows kernel, less align_kernel + trace_kernel (by the stamps) -- the two bin
 // kernels, the rows kernel and the kernel boundaries of the chain.
@@ -846,8 +892,10 @@ static bool binned_possible(calitas_ctx* lane, const SearchPlan& pl) {
   // genome on 2-8 GPUs, a bacterial genome) -- 0.58 against 0.62 ms for an eighth of the hg38-sized genome, 0.164 against 0.190 ms for
   // an E. coli-sized one.  A call cut into three ranges (the whole hg38-sized genome on one GPU) is bound by its scans, and those
   // lose more to the per-bin kernels running beside them (many short waves) than the last range's tail gains: 2.39 ms per pass on
-  // the general kernels against 2.45-2.53 (tools/sweep_lanes.py, profiles/r03_*).  CALITAS_BINNED=1 / 0 / last force a choice.
-  bool want = !pl.three_ranges || pl.owned;                    // (a stretch that cuts a contig: only the bins can own it)
+  // the general kernels against 2.45-2.53 (tools/sweep_lanes.py, profiles/r03_*).  The last range's tail has the chip to itself, and
+  // since the leading ranges' rows cross PCIe compact (round 4) it ends the call: per-bin there, 2.15 / 2.23 / 2.17 against
+  // 2.18 / 2.26 / 2.29 ms (three boxes, tools/sweep_env.py CALITAS_BINNED - last).  CALITAS_BINNED=1 / 0 / last force a choice.
+  bool want = !pl.three_ranges || pl.owned || pl.last_range;   // (a stretch that cuts a contig: only the bins can own it)
   if (const char* e = tune::get("CALITAS_BINNED")) {
     if (std::strcmp(e, "last") == 0) want = !pl.narrow_tail;
     else want = std::atoi(e) != 0;
@@ -1946,47 +1994,10 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.compact_bytes);
       if (!staging) return fail(lane, CALITAS_EINVAL, "out of memory");
       g_marks.mark("staging");
-      int r = CALITAS_OK;
       size_t wrote = 0;
-      const size_t nbytes = (size_t)lt.compact_bytes;
-      // (In pieces -- the workers expand what has arrived while the next piece is on the bus -- it is no faster: 2.164 against 2.170 ms per
-      // hg38-sized call with 4 MB pieces, 2.24 with 2 MB, 3.4 with 1 MB: a piece costs ~100 us of fixed latency.  CALITAS_COMPACT_PIECE_KB.)
-      size_t piece = ~(size_t)0 >> 2;
-      if (const char* e = tune::get("CALITAS_COMPACT_PIECE_KB")) piece = (size_t)std::max(64, std::atoi(e)) << 10;
-      const bool in_host_text = lane->binned_late_check && lt.d_text == binned_host_text(lane->binned);
-      if (ctx->dma_tried && ctx->dma.usable() && nbytes > piece + piece / 2 && !in_host_text) {
-        r = hip_ok(lane, calitas_spin_sync(lane->stream));
-        g_marks.mark("rows-done");
-        if (!r && lane->binned_late_check && lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)
-          r = fail(lane, CALITAS_EHIP, "binned rows kernel: a row's length differs between the two kernels (internal error)");
-        const auto t0 = std::chrono::steady_clock::now();
-        size_t sent = 0, consumed = 0;
-        uint64_t rows_done = 0;
-        unsigned long long ticket = 0;
-        auto send = [&](size_t from) -> size_t {               // queues the next piece, returns its end (0: declined)
-          const size_t to = std::min(nbytes, from + piece);
-          ticket = ctx->dma.start(staging + from, lt.d_text + from, to - from);
-          return ticket ? to : 0;
-        };
-        if (!r) { sent = send(0); if (!sent) r = fail(lane, CALITAS_EHIP, std::string("SDMA copy declined: ") + DmaCopier::last_reason()); }
-        while (!r && consumed < nbytes) {
-          if (!ctx->dma.finish(ticket)) { r = fail(lane, CALITAS_EHIP, "SDMA copy failed"); break; }
-          const size_t have = sent;
-          if (have < nbytes) { sent = send(have); if (!sent) { r = fail(lane, CALITAS_EHIP, std::string("SDMA copy declined: ") + DmaCopier::last_reason()); break; } }
-          const ExpandedPiece ep = expand_rows_piece(staging + consumed, have - consumed, rs.head, rs.tail, text + hlen + offset + wrote, ctx->pool, lt.rows - rows_done);
-          if (ep.rows > lt.rows - rows_done) { r = fail(lane, CALITAS_EHIP, "a lane's compact rows hold more rows than the device reported (internal error)"); break; }
-          consumed += ep.consumed; wrote += ep.written; rows_done += ep.rows;
-          if (have == nbytes && ep.consumed != have - (consumed - ep.consumed)) { r = fail(lane, CALITAS_EHIP, "a lane's compact rows do not end with a newline (internal error)"); break; }
-        }
-        if (r && ticket && sent > consumed) (void)ctx->dma.finish(ticket);   // (nothing of the staging block may still be written when it is freed)
-        g_marks.mark("copied");
-        lt.tm.hits_copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (!r && rows_done != lt.rows) wrote = 0;
-      } else {
-        r = text_to_host(ctx, lane, staging, lt.d_text, nbytes, &copy_mu, &lt.tm.hits_copy_ms);
-        if (!r) wrote = expand_rows(staging, nbytes, lt.rows, rs.head, rs.tail, text + hlen + offset, ctx->pool);
-        g_marks.mark("expanded");
-      }
+      // (Copy and expansion in pieces were no faster while every piece cost two passes of the whole pool -- ~100 us of fixed latency, 2.164
+      // against 2.170 ms per hg38-sized call with 4 MB pieces, 3.4 ms with 1 MB; as one job fed by the copy's pieces: see DESIGN.md 4.5.)
+      int r = compact_rows_to_host(ctx, lane, lt, (size_t)lt.compact_bytes, staging, rs.head, rs.tail, text + hlen + offset, &copy_mu, &wrote);
       calitas_free(staging);
       if (r) return r;
       if ((r = rows_late_check(lane, lt)) != CALITAS_OK) return r;
@@ -2020,7 +2031,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       for (int k = ranges[c].first; k < ranges[c].second; k++) { q.bases += ref.contigs[k].len; q.win_n += window_count(ref.contigs[k].len, q.step); }
       plan_bins(ctx, q, ranges[c].first, ranges[c].second);
       }
-      q.narrow_tail = c + 1 < K; q.three_ranges = K >= 3;
+      q.narrow_tail = c + 1 < K; q.three_ranges = K >= 3; q.last_range = K >= 3 && c + 1 == K;
       rc = lane_prepare(lanes[c], q);
       if (rc) ctx->err = lanes[c]->err;
     }
@@ -2168,6 +2179,15 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     ctx->lane_threads->guarded([&] { lane_body(0); });         // the calling thread drives the first lane itself
     ctx->lane_threads->wait();
     g_marks.mark("joined");
+    if (g_marks.on && !ctx->lane_threads->threw.load()) {       // the scan stream's idle time between the ranges' scans
+      std::string gaps;
+      for (size_t c = 0; c + 1 < K; c++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, lanes[c]->t_scan1, lanes[c + 1]->t_scan0) == hipSuccess) gaps += " " + std::to_string((int)(ms * 1e3f));
+        if (hipEventElapsedTime(&ms, lanes[c]->t_scan0, lanes[c]->t_scan1) == hipSuccess) gaps += " (scan " + std::to_string((int)(ms * 1e3f)) + ")";
+      }
+      std::fprintf(stderr, "[calitas] scan stream idle between ranges (us):%s\n", gaps.c_str());
+    }
     if (ctx->lane_threads->threw.load()) {
       (void)hipDeviceSynchronize();
       free_text();
@@ -2339,71 +2359,91 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
   std::vector<std::string> errs((size_t)n_guides);   // a failed guide's message, kept apart from its lane (a retry below destroys the lanes)
   std::vector<calitas_timing_t> tms((size_t)n_guides);
+  // A guide on a lane, in three parts: its scan queued on the scan stream; its tail (aligner, filter, rows) on the lane's stream with
+  // the host answering the tail's counters; its text brought to the host (copy + expansion) and handed over.
+  struct InFlight {
+    int g = -1;
+    LaneText lt;
+    RowStrings rs_full, rs;
+  };
+  auto queue_scan = [&](calitas_ctx* lane, int g, InFlight& f) -> int {
+    const SearchPlan& pl = plans[g];
+    const std::string gid = guide_ids && guide_ids[g] ? guide_ids[g] : "";
+    f.g = g;
+    f.lt = LaneText();
+    f.rs_full = make_row_strings(ref, pl.gh[0], gid, pl.p, version, stamp);
+    // the device writes compact rows (post.hpp): a batch is bound by its texts on the bus (15.3 GB per 96 guides on an hg38-sized
+    // genome), and 270 of a row's ~520 bytes are the call's constants
+    f.rs = compact_rows ? compact_row_strings(f.rs_full) : f.rs_full;
+    // the previous guide of this lane is done on the device (its tail ended before this is queued), so the lane's buffers are free
+    // for this scan
+    if (device_rows) HIP_TRY(lane, queue_row_constants(lane, pl, f.rs));   // before the wait for the scan is queued
+    std::lock_guard<std::mutex> lk(scan_mu);
+    return launch_scan_stage(lane, pl, ctx->scan_stream);       // records lane->scan_done
+  };
+  auto run_tail = [&](calitas_ctx* lane, InFlight& f, hipEvent_t scans_done) -> int {
+    HIP_TRY(lane, hipStreamWaitEvent(lane->stream, scans_done, 0));
+    const std::string gid = guide_ids && guide_ids[f.g] ? guide_ids[f.g] : "";
+    return lane_rows(lane, plans[f.g], true, f.rs, gid, version, stamp, f.lt, device_rows);
+  };
+  auto finish = [&](calitas_ctx* lane, InFlight& f) -> int {
+    const int g = f.g;
+    LaneText& lt = f.lt;
+    const RowStrings& rs = f.rs;
+    const RowStrings& rs_full = f.rs_full;
+    const bool expand = compact_rows && !lt.on_host;           // (rows the host stages built are whole already)
+    const size_t add = rs_full.head.size() + rs_full.tail.size() - 1;
+    const size_t hlen = rs.header.size(), total = hlen + (size_t)lt.bytes + (expand ? (size_t)lt.rows * add : 0);
+    char* text = (char*)(expand ? calitas_out_alloc(total + 1) : calitas_out_alloc_pinned(total + 1));
+    if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
+    std::memcpy(text, rs.header.data(), hlen);
+    if (lt.bytes && lt.on_host) std::memcpy(text + hlen, lt.host_rows.data(), (size_t)lt.bytes);
+    else if (lt.bytes && expand) {
+      char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.bytes);
+      if (!staging) { calitas_free(text); return fail(lane, CALITAS_EINVAL, "out of memory"); }
+      size_t wrote = 0;
+      const auto t_exp = std::chrono::steady_clock::now();
+      int cr = compact_rows_to_host(ctx, lane, lt, (size_t)lt.bytes, staging, rs_full.head, rs_full.tail, text + hlen, &copy_mu, &wrote);
+      expand_us.fetch_add((uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_exp).count());
+      calitas_free(staging);
+      if (!cr) cr = rows_late_check(lane, lt);
+      if (cr) { calitas_free(text); return cr; }
+      if (wrote != total - hlen) { calitas_free(text); return fail(lane, CALITAS_EHIP, "the compact rows of a guide do not expand to the row count the device reported (internal error)"); }
+    } else if (lt.bytes) {
+      int cr = text_to_host(ctx, lane, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+      if (!cr) cr = rows_late_check(lane, lt);
+      if (cr) { calitas_free(text); return cr; }
+    }
+    text[total] = 0;
+    tsv[g] = text;
+    if (tsv_bytes) tsv_bytes[g] = total;
+    if (n_rows) n_rows[g] = lt.rows;
+    tms[g] = lt.tm; tms[g].hit_rows = lt.rows; tms[g].hits_bytes = total;
+    return CALITAS_OK;
+  };
+  auto failed = [&](calitas_ctx* lane, int g, int r) {
+    rcs[g] = r;
+    errs[g] = lane->err;
+    (void)hipStreamSynchronize(lane->stream);                   // leave the lane quiet before its next guide
+  };
+  // (Phases -- the guides in groups of one per lane, the group's scans back to back with nothing beside them, then the group's tails side
+  // by side with no scan beside them, the texts of the group before brought in meanwhile -- were tried in round 4: the scans then take
+  // 1.27 instead of 2.05 ms per guide, and the 96 guides take as long as before, 249 ms.  A guide's tail is 1.3 ms of the whole chip
+  // whatever runs beside it (five tails side by side: 6.6 ms); it is the tail's own kernels that have to get cheaper, not their place.
+  // tools/batch_probe.py)
   // one host thread per lane: the caller drives lane 0, the context's lane threads (they live as long as the lanes: starting a thread
   // per lane and call cost ~100 us) the others
   auto lane_job = [&](size_t l_) {
-    {
-      const int l = (int)l_;
-      (void)hipSetDevice(ctx->device);
-      calitas_ctx* lane = ctx->lanes[l];
-      for (int g = l; g < n_guides; g += n_lanes) {
-        const SearchPlan& pl = plans[g];
-        if (!owned_ok[(size_t)g]) { rcs[g] = kOwnedDeclined; continue; }   // (the stretch is not one for the bins: below, one guide at a time)
-        const std::string gid = guide_ids && guide_ids[g] ? guide_ids[g] : "";
-        const RowStrings rs_full = make_row_strings(ref, pl.gh[0], gid, pl.p, version, stamp);
-        // the device writes compact rows (post.hpp): a batch is bound by its texts on the bus (15.3 GB per 96 guides on an hg38-sized
-        // genome), and 270 of a row's ~520 bytes are the call's constants
-        const RowStrings rs = compact_rows ? compact_row_strings(rs_full) : rs_full;
-        auto step = [&]() -> int {
-          {
-            // the previous guide of this lane is completely done (its text was copied before the loop went on), so the
-            // lane's buffers are free for this scan
-            if (device_rows) HIP_TRY(lane, queue_row_constants(lane, pl, rs));   // before the wait below is queued
-            std::lock_guard<std::mutex> lk(scan_mu);
-            int r = launch_scan_stage(lane, pl, ctx->scan_stream);   // records lane->scan_done
-            if (r) return r;
-            HIP_TRY(lane, hipStreamWaitEvent(lane->stream, lane->scan_done, 0));
-          }
-          LaneText lt;
-          int r = lane_rows(lane, pl, true, rs, gid, version, stamp, lt, device_rows);
-          if (r) return r;
-          const bool expand = compact_rows && !lt.on_host;       // (rows the host stages built are whole already)
-          const size_t add = rs_full.head.size() + rs_full.tail.size() - 1;
-          const size_t hlen = rs.header.size(), total = hlen + (size_t)lt.bytes + (expand ? (size_t)lt.rows * add : 0);
-          char* text = (char*)(expand ? calitas_out_alloc(total + 1) : calitas_out_alloc_pinned(total + 1));
-          if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
-          std::memcpy(text, rs.header.data(), hlen);
-          if (lt.bytes && lt.on_host) std::memcpy(text + hlen, lt.host_rows.data(), (size_t)lt.bytes);
-          else if (lt.bytes && expand) {
-            char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.bytes);
-            if (!staging) { calitas_free(text); return fail(lane, CALITAS_EINVAL, "out of memory"); }
-            int cr = text_to_host(ctx, lane, staging, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
-            size_t wrote = 0;
-            const auto t_exp = std::chrono::steady_clock::now();
-            if (!cr) wrote = expand_rows(staging, (size_t)lt.bytes, lt.rows, rs_full.head, rs_full.tail, text + hlen, ctx->pool);
-            expand_us.fetch_add((uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_exp).count());
-            calitas_free(staging);
-            if (!cr) cr = rows_late_check(lane, lt);
-            if (cr) { calitas_free(text); return cr; }
-            if (wrote != total - hlen) { calitas_free(text); return fail(lane, CALITAS_EHIP, "the compact rows of a guide do not expand to the row count the device reported (internal error)"); }
-          } else if (lt.bytes) {
-            int cr = text_to_host(ctx, lane, text + hlen, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
-            if (!cr) cr = rows_late_check(lane, lt);
-            if (cr) { calitas_free(text); return cr; }
-          }
-          text[total] = 0;
-          tsv[g] = text;
-          if (tsv_bytes) tsv_bytes[g] = total;
-          if (n_rows) n_rows[g] = lt.rows;
-          tms[g] = lt.tm; tms[g].hit_rows = lt.rows; tms[g].hits_bytes = total;
-          return CALITAS_OK;
-        };
-        rcs[g] = step();
-        if (rcs[g] != CALITAS_OK) {
-          errs[g] = lane->err;
-          (void)hipStreamSynchronize(lane->stream);   // leave the lane quiet before its next guide
-        }
-      }
+    const int l = (int)l_;
+    (void)hipSetDevice(ctx->device);
+    calitas_ctx* lane = ctx->lanes[l];
+    InFlight f;
+    for (int g = l; g < n_guides; g += n_lanes) {
+      if (!owned_ok[(size_t)g]) { rcs[g] = kOwnedDeclined; continue; }   // (the stretch is not one for the bins: below, one guide at a time)
+      int r = queue_scan(lane, g, f);
+      if (!r) r = run_tail(lane, f, lane->scan_done);
+      if (!r) r = finish(lane, f);
+      if (r) failed(lane, g, r);
     }
   };
   ctx->lane_threads->start((size_t)n_lanes, lane_job);

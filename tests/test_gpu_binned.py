@@ -193,7 +193,10 @@ def test_lanes_and_batch_take_the_binned_tail(C, tmp_path, monkeypatch):
                 assert bytes(buf[:nb]).decode() == one
         finally:
             ctx.unpin_host(buf.ctypes.data)
-        monkeypatch.setenv("CALITAS_CHUNKS", "3")                 # three ranges: the general kernels by default ...
+        monkeypatch.setenv("CALITAS_CHUNKS", "3")                 # three ranges: the general kernels beside the scans, the per-bin ones
+        three, _ = sr.run("v0", "stamp")                           # for the last range ...
+        assert ctx.timing()["binned_lanes"] == 1 and three == one
+        monkeypatch.setenv("CALITAS_BINNED", "0")                 # ... none on request
         three, _ = sr.run("v0", "stamp")
         assert ctx.timing()["binned_lanes"] == 0 and three == one
         monkeypatch.setenv("CALITAS_BINNED", "1")                 # ... the per-bin ones on request
