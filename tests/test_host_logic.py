@@ -313,6 +313,23 @@ def test_expand_rows_puts_head_and_tail_back():
                 assert _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows + 1, head, tail, out, len(want) + 200, ctypes.byref(written)) != 0
                 assert _lib.lib.calitas_expand_rows(ctx._h, compact[:-1], len(compact) - 1, n_rows, head, tail, out, len(want), ctypes.byref(written)) != 0
                 assert _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows, head, tail, out, len(want) - 1, ctypes.byref(written)) != 0
+        # pieces of the expansion job (64 KB of compact text each, post.cpp RowExpansion): rows longer than a piece, rows that end on a
+        # piece boundary, and every number of workers
+        for trial, (n_rows, longest) in enumerate(((30000, 90), (2000, 3000), (300, 70000), (65536 // 8, 8), (9000, 300))):
+            lens = rng.integers(1, longest, size=n_rows) if longest != 8 else np.full(n_rows, 5)   # (5 x's + "c\t" + newline = 8 bytes)
+            rows = [b"c\t" + b"x" * int(l) for l in lens]
+            compact = b"".join(r + b"\n" for r in rows)
+            want = b"".join(head + r + tail for r in rows)
+            out = ctypes.create_string_buffer(len(want) + 1)
+            for threads in ("1", "2", "3", "16"):
+                os.environ["CALITAS_EXPAND_THREADS"] = threads
+                try:
+                    ctypes.memset(out, 0, len(want) + 1)
+                    rc = _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows, head, tail, out, len(want), ctypes.byref(written))
+                    assert rc == 0 and written.value == len(want) and out.raw[:len(want)] == want, (trial, threads)
+                    assert _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), n_rows - 1, head, tail, out, len(want), ctypes.byref(written)) != 0
+                finally:
+                    del os.environ["CALITAS_EXPAND_THREADS"]
     finally:
         ctx.close()
 
