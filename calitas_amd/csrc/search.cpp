@@ -1919,8 +1919,10 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     // measured on hg38-sized input: the last range small, its tail is what nothing hides.  5:3:2 while all of the text
     // crossed the bus behind the first range's rows; with compact rows for the first two ranges (round 4) the copies are half as long
     // and the first range can be larger, the last smaller: 5.5:3:1.5 2.196 ms against 2.268 (tools/sweep_env.py, interleaved;
-    // 6:3:1 2.253, 5:3.5:1.5 2.207, four ranges 2.28)
-    weights = {5.5, 3, 1.5};
+    // 6:3:1 2.253, 5:3.5:1.5 2.207, four ranges 2.28).  With the last range on the per-bin kernels, its rows compact too and every
+    // expansion fed by its copy, the last range shrinks again: 5.8:2.9:1.3 2.016 / 2.025 ms against 2.073 for 5.5:3:1.5 (6:2.8:1.2
+    // 2.021, 6.2:2.8:1 2.013, 6.4:2.6:1 2.022, 5.6:3.2:1.2 2.083, 5:3:2 2.104; the cuts fall on contig boundaries)
+    weights = {5.8, 2.9, 1.3};
   } else if ((owned ? owned[1] * (uint64_t)pl.step : ref.total_bases) >= (256ull << 20)) {
     // a half, a quarter or an eighth of it (a rank's share on 2, 4 or 8 GPUs).  Round 3, with the per-bin tail: 1.41 / 0.86 / 0.58 ms
     // for two equal ranges against 1.46 / 0.89 / 0.62 for 3:2 and 1.53 / 0.96 / 0.72 for three; one pass: - / 0.90 / 0.60
@@ -2045,8 +2047,12 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       bool compact_on = device_rows;
       if (const char* e = tune::get("CALITAS_COMPACT_ROWS")) compact_on = compact_on && std::atoi(e) != 0;
       lane_compact.assign(K, 0);
-      size_t n_compact = K - 1;
-      if (const char* e = tune::get("CALITAS_COMPACT_LANES")) n_compact = std::min<size_t>(K - 1, (size_t)std::max(0, std::atoi(e)));
+      // Which ranges move compact rows: the leading ones always (their expansion hides behind the later ranges' scans); the last one
+      // where the text is long -- a call cut into three: its rows kernel then writes 3 MB into device memory and the text's pieces are
+      // expanded as they land, instead of 9 MB written across PCIe by the kernel itself, 2.072 against 2.098 ms per hg38-sized call;
+      // the last of two ranges keeps its rows kernel writing in place (a rank of eight: 0.48 against 0.50 ms).
+      size_t n_compact = K >= 3 ? K : K - 1;
+      if (const char* e = tune::get("CALITAS_COMPACT_LANES")) n_compact = std::min<size_t>(K, (size_t)std::max(0, std::atoi(e)));
       for (size_t c = 0; c < n_compact; c++) lane_compact[c] = compact_on ? 1 : 0;
     }
     // (no early return inside this loop: the scans of the earlier lanes are already in flight and every exit waits for them)
@@ -2152,7 +2158,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
           *dst = text_dev + hlen + before; *cap = capacity - before;
           return true;
         };
-        lt.rc = lane_rows(lanes[c], plans[c], true, rs_lane(c), guide_id, version, stamp, lt, device_rows, c + 1 == K && device_rows ? &dest : nullptr);
+        lt.rc = lane_rows(lanes[c], plans[c], true, rs_lane(c), guide_id, version, stamp, lt, device_rows, c + 1 == K && device_rows && !lane_compact[c] ? &dest : nullptr);
         if (lt.rc == CALITAS_OK && lane_compact[c] && !lt.on_host && !lt.in_place && lt.bytes) {   // what the lanes behind it place their text by: the expanded size
           lt.compact_bytes = lt.bytes;
           lt.bytes += lt.rows * (uint64_t)(rs.head.size() + rs.tail.size() - 1);

@@ -34,7 +34,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_BINNED_HOST_TEXT_KB", "n", "T: ... up to this size (default 128)"},
   {"CALITAS_BINNED_SKIP", "1 | 2 | 3", "D: timing experiments only (the text is wrong): skip the wave-per-bin kernel / the rows"},
   {"CALITAS_TEXT_IN_PLACE_OFF", "1", "F: the last range's text takes the copy instead of being written to its final place by the rows kernel"},
-  {"CALITAS_CHUNKS", "k | a:b:c", "T: contig ranges of a chunked calitas_search_hits (default 5.5:3:1.5 from 2 Gb, 1:1 from 256 Mb)"},
+  {"CALITAS_CHUNKS", "k | a:b:c", "T: contig ranges of a chunked calitas_search_hits (default 5.8:2.9:1.3 from 2 Gb, 1:1 from 256 Mb)"},
   {"CALITAS_CHUNK", "64..512", "T: bases per scan lane chunk (set_reference; default by genome size)"},
   {"CALITAS_INPUTS_FIRST", "0 | 1 | 2", "T: where the ranges' small inputs are queued (default 2)"},
   {"CALITAS_LANE_SETUP", "0", "F: separate stream commands instead of the one-launch lane setup"},
@@ -46,7 +46,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_TRACE_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
   {"CALITAS_BATCH_LANES", "1..8", "T: guides in flight in calitas_search_hits_batch (default 5)"},
   {"CALITAS_COMPACT_ROWS", "0", "F/T: full rows over PCIe instead of compact rows + host expansion (batches, the leading ranges of a chunked call)"},
-  {"CALITAS_COMPACT_LANES", "n", "T: how many leading ranges of a chunked call move compact rows (default all but the last)"},
+  {"CALITAS_COMPACT_LANES", "n", "T: how many leading ranges of a chunked call move compact rows (default: all of three or more, all but the last of two)"},
   {"CALITAS_COMPACT_PIECE_KB", "n", "T: compact text copied and expanded in pieces of this size (default: one piece)"},
   {"CALITAS_EXPAND_THREADS", "n", "T: workers that expand compact rows (default: the whole pool)"},
 };

@@ -12,3 +12,7 @@ python3 bench.py --config 4 --steps 3 > $OUT/r04_bench_config4.json 2> $OUT/benc
 bash tools/pmc_pass.sh fetch "FETCH_SIZE" 1.0 3 > $OUT/pmc_fetch.txt 2>&1; cp gpurun_out/pmc_fetch.csv $OUT/r04_pmc_fetch_size.csv; echo "pmc fetch $?"
 bash tools/pmc_pass.sh write "WRITE_SIZE" 1.0 3 > $OUT/pmc_write.txt 2>&1; cp gpurun_out/pmc_write.csv $OUT/r04_pmc_write_size.csv; echo "pmc write $?"
 bash tools/pmc_pass.sh insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" 1.0 3 > $OUT/pmc_insts.txt 2>&1; cp gpurun_out/pmc_insts.csv $OUT/r04_pmc_insts.csv; echo "pmc insts $?"
+python3 tools/slow_calls.py 600 > $OUT/slow_calls_now.txt 2>&1; echo "slow calls $?"
+python3 tools/batch_probe.py 96 2 > $OUT/r04_batch_probe.txt 2>&1; echo "batch probe $?"
+python3 tools/expand_speed.py 118000 30 > $OUT/r04_expand_speed.txt 2>&1; echo "expand speed $?"
+bash tools/cgroup_stat.sh > $OUT/r04_cgroup.txt 2>&1
