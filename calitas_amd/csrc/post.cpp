@@ -417,7 +417,8 @@ std::shared_ptr<RowExpansion> expand_rows_begin(const char* compact, size_t n, u
   // All workers (CALITAS_EXPAND_THREADS for experiments): 34.8 MB of rows in 3.8 / 2.0 / 1.0 / 0.55 / 0.35 ms on 1 / 2 / 4 / 8 / 16
   // of an MI355X box's cores (tools/expand_speed.py); a text below 1 MB is not worth the wake-ups.
   size_t T = pool && n >= (1u << 20) ? (size_t)pool->size() : 1;
-  if (const char* e = tune::get("CALITAS_EXPAND_THREADS")) T = std::max<size_t>(1, std::min<size_t>(T, (size_t)std::atoi(e)));
+  if (const char* e = tune::get("CALITAS_EXPAND_THREADS"))    // (also for short texts: the tests run the job's hand-overs on small genomes)
+    T = std::max<size_t>(1, std::min<size_t>(pool ? (size_t)pool->size() : 1, (size_t)std::atoi(e)));
   job->limit = T;
   job->P = (n + RowExpansion::PIECE - 1) / RowExpansion::PIECE;
   job->before.reset(new std::atomic<uint64_t>[job->P + 1]);

@@ -828,7 +828,7 @@ static int compact_rows_to_host(calitas_ctx* owner, calitas_ctx* lane, LaneText&
     g_marks.mark("expanded");
     return CALITAS_OK;
   };
-  if (!owner->dma.usable() || in_host_text || nbytes < (1u << 20)) return whole();
+  if (!owner->dma.usable() || in_host_text || nbytes < std::min<size_t>(1u << 20, 2 * piece)) return whole();   // (a short text: one copy, then the rows)
   HIP_TRY(lane, calitas_spin_sync(lane->stream));
   g_marks.mark("rows-done");
   if (lane->binned_late_check && lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)

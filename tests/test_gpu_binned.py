@@ -214,6 +214,41 @@ def test_lanes_and_batch_take_the_binned_tail(C, tmp_path, monkeypatch):
     assert strip(C.read_hits(one)) == strip(want)
 
 
+def test_compact_rows_arrive_in_pieces(C, tmp_path, monkeypatch):
+    """The ranges of a chunked call move compact rows over PCIe in pieces and the worker pool expands what has landed (search.cpp
+    compact_rows_to_host, post.cpp RowExpansion).  On a dense genome with 64 KB pieces and the job's hand-overs forced onto several
+    workers: the same text as full rows over the bus, as one copy per range, and as the call in one pass."""
+    rng = np.random.default_rng(77)
+    contigs = []
+    for ci, length in enumerate((400000, 300000, 350000, 250000)):
+        pos = np.sort(rng.choice(np.arange(100, length - 100, 60), size=length // 90, replace=False))
+        sites = [(int(p), int(rng.integers(0, 4)), bool(rng.integers(0, 2))) for p in pos]
+        contigs.append(("d%d" % ci, planted(rng, length, sites)))
+    fa = write_fasta(str(tmp_path / "dense.fa"), contigs)
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    try:
+        sr = C.SearchReference(guide=GUIDE, guide_id="a", context=ctx, max_gaps_between_guide_and_pam=2)
+        one, n_one = sr.run("v0", "stamp")
+        assert n_one > 10000 and len(one) > 3 * (1 << 20)     # (every range's compact text: several pieces)
+        monkeypatch.setenv("CALITAS_CHUNKS", "3")
+        monkeypatch.setenv("CALITAS_COMPACT_ROWS", "0")
+        full, _ = sr.run("v0", "stamp")
+        assert full == one
+        monkeypatch.delenv("CALITAS_COMPACT_ROWS")
+        for piece, threads in (("64", "4"), ("64", "1"), ("128", "16"), ("65536", "3")):
+            monkeypatch.setenv("CALITAS_COMPACT_PIECE_KB", piece)
+            monkeypatch.setenv("CALITAS_EXPAND_THREADS", threads)
+            for _ in range(3):
+                again, n_again = sr.run("v0", "stamp")
+                assert n_again == n_one and again == one, (piece, threads)
+        # the same through the batch entry point (every guide's text is compact there)
+        res = ctx.search_hits_batch([C.Guide(GUIDE)] * 3, ["a", "a", "a"], C.make_params(max_gaps_between_guide_and_pam=2), "v0", "stamp")
+        assert all(t == one for t, _ in res)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("cuts", [2, 3, 8])
 def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts):
     """calitas_search_hits on a window range returns the rows whose coordinate_start lies in the range's stretch of the genome: the
