@@ -1925,8 +1925,12 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     weights = {5.8, 2.9, 1.3};
   } else if ((owned ? owned[1] * (uint64_t)pl.step : ref.total_bases) >= (256ull << 20)) {
     // a half, a quarter or an eighth of it (a rank's share on 2, 4 or 8 GPUs).  Round 3, with the per-bin tail: 1.41 / 0.86 / 0.58 ms
-    // for two equal ranges against 1.46 / 0.89 / 0.62 for 3:2 and 1.53 / 0.96 / 0.72 for three; one pass: - / 0.90 / 0.60
-    weights = {1, 1};
+    // for two equal ranges against 1.46 / 0.89 / 0.62 for 3:2 and 1.53 / 0.96 / 0.72 for three; one pass: - / 0.90 / 0.60.
+    // Round 4, with the last range's text written in place by its rows kernel (nothing of it is left to copy when its tail ends) the
+    // second range shrinks: interleaved on one box (tools/owned_cut_sweep.py) a half 1.315 -> 1.23 ms at 5:3 (3:2 1.25, 2:1 1.31), a
+    // quarter 0.75 -> 0.72 at 5:3 (3:2 0.73), an eighth 0.48 -> 0.46 at 3:2 (5:3 0.46-0.49, 2:1 0.53)
+    if ((owned ? owned[1] * (uint64_t)pl.step : ref.total_bases) >= (600ull << 20)) weights = {5, 3};
+    else weights = {3, 2};
   }
   std::vector<std::pair<int, int>> ranges;
   if (!owned && weights.size() > 1 && pl.p.chrom_index < 0 && ref.contigs.size() > 1) ranges = chunk_ranges(ref, weights);

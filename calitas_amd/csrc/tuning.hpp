@@ -34,7 +34,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_BINNED_HOST_TEXT_KB", "n", "T: ... up to this size (default 128)"},
   {"CALITAS_BINNED_SKIP", "1 | 2 | 3", "D: timing experiments only (the text is wrong): skip the wave-per-bin kernel / the rows"},
   {"CALITAS_TEXT_IN_PLACE_OFF", "1", "F: the last range's text takes the copy instead of being written to its final place by the rows kernel"},
-  {"CALITAS_CHUNKS", "k | a:b:c", "T: contig ranges of a chunked calitas_search_hits (default 5.8:2.9:1.3 from 2 Gb, 1:1 from 256 Mb)"},
+  {"CALITAS_CHUNKS", "k | a:b:c", "T: contig ranges of a chunked calitas_search_hits (default 5.8:2.9:1.3 from 2 Gb, 5:3 from 600 Mb, 3:2 from 256 Mb)"},
   {"CALITAS_CHUNK", "64..512", "T: bases per scan lane chunk (set_reference; default by genome size)"},
   {"CALITAS_INPUTS_FIRST", "0 | 1 | 2", "T: where the ranges' small inputs are queued (default 2)"},
   {"CALITAS_LANE_SETUP", "0", "F: separate stream commands instead of the one-launch lane setup"},
