@@ -3,7 +3,7 @@
 #include "post.hpp"
 #include "tuning.hpp"
 
-#include <emmintrin.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <cctype>
@@ -288,6 +288,24 @@ namespace {
 // Rows are assembled in a buffer that stays in the first-level cache and leave it as whole 64-byte lines through non-temporal stores:
 // the output is written once and not read again by this thread (no read for ownership: a 176 MB text is otherwise 352 MB of memory
 // traffic plus the 84 MB read).  The bytes before the first line boundary of the destination and behind the last go out as plain stores.
+static void stream_lines_sse2(char* w, const char* src, size_t lines) {
+  for (size_t i = 0; i < lines; i++, src += 64, w += 64) {
+    __m128i* dst = reinterpret_cast<__m128i*>(w);
+    _mm_stream_si128(dst, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src)));
+    _mm_stream_si128(dst + 1, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 16)));
+    _mm_stream_si128(dst + 2, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 32)));
+    _mm_stream_si128(dst + 3, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 48)));
+  }
+}
+__attribute__((target("avx2"))) static void stream_lines_avx2(char* w, const char* src, size_t lines) {
+  for (size_t i = 0; i < lines; i++, src += 64, w += 64) {
+    __m256i* dst = reinterpret_cast<__m256i*>(w);
+    _mm256_stream_si256(dst, _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src)));
+    _mm256_stream_si256(dst + 1, _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 32)));
+  }
+}
+static const bool wide_stores = __builtin_cpu_supports("avx2");
+
 struct RowWriter {
   char* w;                                                    // where buf[0] belongs
   size_t fill = 0;
@@ -309,14 +327,8 @@ struct RowWriter {
       w += off;
     }
     const size_t lines = (fill - off) / 64;
-    const char* src = buf + off;
-    for (size_t i = 0; i < lines; i++, src += 64, w += 64) {
-      __m128i* dst = reinterpret_cast<__m128i*>(w);
-      _mm_stream_si128(dst, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src)));
-      _mm_stream_si128(dst + 1, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 16)));
-      _mm_stream_si128(dst + 2, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 32)));
-      _mm_stream_si128(dst + 3, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 48)));
-    }
+    if (wide_stores) stream_lines_avx2(w, buf + off, lines); else stream_lines_sse2(w, buf + off, lines);
+    w += lines * 64;
     off += lines * 64;
     if (off < fill) std::memmove(buf, buf + off, fill - off);
     fill -= off;
@@ -344,6 +356,7 @@ struct RowExpansion : SharedJob {
   char* out = nullptr;
   const char* hp = nullptr; const char* tp = nullptr;
   size_t H = 0, TL = 0, add = 0;
+  std::string tail_head;                                      // what stands between the middles of two consecutive rows
   uint64_t max_rows = 0;
   size_t limit = 1, P = 0;
   std::atomic<size_t> avail{0};                               // bytes of compact[] that are there
@@ -392,13 +405,13 @@ struct RowExpansion : SharedJob {
         RowWriter rw(out + first + b * add);
         const char* p = compact + first;
         const char* const end = compact + last;
+        rw.put(hp, H);
         while (p < end) {
           const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
           if (!nl) break;
-          rw.put(hp, H);
           rw.put(p, (size_t)(nl - p));
-          rw.put(tp, TL);
           p = nl + 1;
+          if (p < end) rw.put(tail_head.data(), tail_head.size()); else rw.put(tp, TL);
         }
         rw.finish();
       }
@@ -413,6 +426,7 @@ std::shared_ptr<RowExpansion> expand_rows_begin(const char* compact, size_t n, u
   job->compact = compact; job->n = n; job->out = out;
   job->hp = head.data(); job->tp = tail.data();
   job->H = head.size(); job->TL = tail.size(); job->add = head.size() + tail.size() - 1;
+  job->tail_head = tail + head;
   job->max_rows = rows;
   // All workers (CALITAS_EXPAND_THREADS for experiments): 34.8 MB of rows in 3.8 / 2.0 / 1.0 / 0.55 / 0.35 ms on 1 / 2 / 4 / 8 / 16
   // of an MI355X box's cores (tools/expand_speed.py); a text below 1 MB is not worth the wake-ups.
