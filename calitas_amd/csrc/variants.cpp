@@ -20,6 +20,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -538,9 +539,10 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         if (!row.empty() && row.back() == '\n') row.pop_back();
   };
 
-  auto flush = [&]() -> int {
-    if (nb == 0) return CALITAS_OK;
-    const size_t n = nb;
+  // A built batch of windows through the aligner (device) and its alignments lifted back and listed as hits (worker pool).  Runs on the
+  // aligner thread (below) while this thread builds the next batch; `err_out` is that thread's own.
+  auto align_stage = [&](Batch& batch, const size_t n, std::string& err) -> int {
+    if (n == 0) return CALITAS_OK;
     std::vector<calitas_guide_t> guides(n, *guide);
     std::vector<const uint8_t*> targets(n);
     std::vector<uint32_t> lens(n);
@@ -554,11 +556,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     if (r) { if (actx != ctx) calitas_fail(ctx, r, calitas_last_error(actx)); return r; }
     ms_align += ms_since(t0);
     const auto t1 = std::chrono::steady_clock::now();
-    // the batch's windows and records stay until the rows are written; a fresh batch for the producer
+    // the batch's windows and records stay until the rows are written
     kept_windows.emplace_back(std::move(batch));                  // (vectors move: the views keep pointing into the arenas)
-    batch = Batch();
-    batch.wins.resize(kBatch + 1);
-    batch.arenas.resize((size_t)ctx->pool->size());
     const std::vector<Window>& wins = kept_windows.back().wins;
     kept_out.push_back(out);
     std::vector<uint64_t> first(n + 1, 0);
@@ -585,9 +584,21 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     });
     for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
     calitas_free(counts);
-    nb = 0;
     ms_rows += ms_since(t1);
     return CALITAS_OK;
+  };
+  // where a built batch goes: to the aligner thread once it runs (hand_over), through align_stage on this thread before that
+  std::function<int(Batch&&, size_t)> hand_over;
+  auto flush = [&]() -> int {
+    if (nb == 0) return CALITAS_OK;
+    Batch full = std::move(batch);
+    const size_t n = nb;
+    batch = Batch();                                              // a fresh batch for the producer
+    batch.wins.resize(kBatch + 1);
+    batch.arenas.resize((size_t)ctx->pool->size());
+    nb = 0;
+    if (hand_over) return hand_over(std::move(full), n);
+    return align_stage(full, n, err);
   };
 
   // variantWindowIterator SR:217-256 with nextChunk / reChunk SR:326-347.  The iterator itself only lists what each window is made
@@ -773,9 +784,64 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   };
   // The contigs before `upto` have all their windows emitted: align what is pending, finish and publish them.
   size_t contigs_done = 0, hits_done = 0;
+  // The aligner thread: batch k is on the device (and its alignments are lifted back) while this thread walks the VCF and builds
+  // batch k + 1 -- 48 batches of 65 536 windows at full size, 13 ms each in the aligner, 8 ms each to build.  One batch waits at most.
+  struct AlignerState {
+    std::mutex mu;
+    std::condition_variable cv;
+    Batch waiting; size_t n_waiting = 0; bool have = false, busy = false, quit = false;
+    int rc = CALITAS_OK;
+    std::string err;
+  } al;
+  std::thread aligner;
+  struct JoinAligner {
+    std::thread& t; AlignerState& al;
+    ~JoinAligner() { if (t.joinable()) { { std::lock_guard<std::mutex> lk(al.mu); al.quit = true; } al.cv.notify_all(); t.join(); } }
+  } join_aligner{aligner, al};
+  aligner = std::thread([&] {
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    for (;;) {
+      Batch b; size_t n = 0;
+      {
+        std::unique_lock<std::mutex> lk(al.mu);
+        al.cv.wait(lk, [&] { return al.have || al.quit; });
+        if (!al.have) return;
+        b = std::move(al.waiting); n = al.n_waiting; al.have = false; al.busy = true;
+      }
+      al.cv.notify_all();
+      int r = CALITAS_OK;
+      std::string e;
+      try { r = align_stage(b, n, e); }
+      catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("the aligner thread ended with an exception: ") + x.what(); }
+      {
+        std::lock_guard<std::mutex> lk(al.mu);
+        al.busy = false;
+        if (r && al.rc == CALITAS_OK) al.rc = r;
+        if (!e.empty() && al.err.empty()) al.err = e;
+      }
+      al.cv.notify_all();
+    }
+  });
+  hand_over = [&](Batch&& b, size_t n) -> int {
+    std::unique_lock<std::mutex> lk(al.mu);
+    al.cv.wait(lk, [&] { return !al.have; });
+    if (al.rc != CALITAS_OK || !al.err.empty()) return al.rc;     // (the caller learns the reason from drain())
+    al.waiting = std::move(b); al.n_waiting = n; al.have = true;
+    lk.unlock();
+    al.cv.notify_all();
+    return CALITAS_OK;
+  };
+  auto drain = [&]() -> int {                                     // everything handed over is in hits[]
+    std::unique_lock<std::mutex> lk(al.mu);
+    al.cv.wait(lk, [&] { return !al.have && !al.busy; });
+    if (!al.err.empty() && err.empty()) err = al.err;
+    return al.rc;
+  };
   auto finish_contigs = [&](size_t upto) -> int {
     if (upto <= contigs_done) return CALITAS_OK;
     int r = build_and_flush();
+    if (r || !err.empty()) return r;
+    r = drain();
     if (r || !err.empty()) return r;
     if (device_merge) {
       // hits[hits_done, ...) lie on contigs [contigs_done, upto), in contig order
