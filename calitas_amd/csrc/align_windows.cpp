@@ -59,7 +59,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
   auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
   double ms_prep = 0, ms_pack = 0, ms_recs = 0, ms_upload = 0, ms_gpu = 0, ms_post = 0;
   auto t_sec = clk::now();
-  std::vector<calitas_aln_t> result;
+  std::vector<std::vector<calitas_aln_t>> pieces;             // the kept alignments, block by block in task order (assembled once, at the end)
   std::vector<uint32_t> per_task((size_t)std::max(n_tasks, 0), 0u);
   // guides: consecutive tasks that pass the same guide (the variant branch: one guide, a million windows) share one GuideHost
   std::vector<GuideHost> uniq;
@@ -138,21 +138,29 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       W = std::max<uint32_t>(W, target_lengths[t0 + i]);
     }
     PackedRef ref;
-    try { pack_targets_dense(ref, nt, lens.data(), bases.data()); }
+    WorkerPool* const owners_pool = (ctx->parent ? ctx->parent : ctx)->pool;   // (a child context works on its parent's pool)
+    try { pack_targets_dense(ref, nt, lens.data(), bases.data(), owners_pool); }
     catch (std::exception& e) { return calitas_fail(ctx, CALITAS_EINVAL, e.what()); }
 
     ms_pack += ms_since(t_sec); t_sec = clk::now();
     // every column of every task, both directions
-    std::vector<ScanRecord> recs;
-    for (int i = 0; i < nt; i++) {
-      const uint32_t g0 = (uint32_t)(ref.contigs[i].gbase / 16);
-      for (uint32_t w = 0; w * 16 < lens[i]; w++) {
-        const uint32_t nb = (uint32_t)std::min<uint64_t>(16, lens[i] - (uint64_t)w * 16);
-        const uint32_t m = nb == 16 ? 0xFFFFu : ((1u << nb) - 1u);
-        recs.push_back(ScanRecord{g0 + w, m | ((uint32_t)task_slot[i] << 17)});
-        recs.push_back(ScanRecord{g0 + w, m | (1u << 16) | ((uint32_t)task_slot[i] << 17)});
+    std::vector<uint64_t> rec_at((size_t)nt + 1, 0);
+    for (int i = 0; i < nt; i++) rec_at[(size_t)i + 1] = rec_at[(size_t)i] + 2 * ((lens[i] + 15) / 16);
+    if (rec_at[(size_t)nt] > 0xFFFFFFF0ull) return calitas_fail(ctx, CALITAS_EINVAL, "too many target columns for one batch");
+    std::vector<ScanRecord> recs((size_t)rec_at[(size_t)nt]);
+    WorkerPool one_thread(1);
+    (owners_pool && nt >= 4096 ? owners_pool : &one_thread)->for_blocks((size_t)nt, [&](size_t tb, size_t te, int) {
+      for (size_t i = tb; i < te; i++) {
+        const uint32_t g0 = (uint32_t)(ref.contigs[i].gbase / 16);
+        ScanRecord* r = recs.data() + rec_at[i];
+        for (uint32_t w = 0; w * 16 < lens[i]; w++) {
+          const uint32_t nb = (uint32_t)std::min<uint64_t>(16, lens[i] - (uint64_t)w * 16);
+          const uint32_t m = nb == 16 ? 0xFFFFu : ((1u << nb) - 1u);
+          *r++ = ScanRecord{g0 + w, m | ((uint32_t)task_slot[i] << 17)};
+          *r++ = ScanRecord{g0 + w, m | (1u << 16) | ((uint32_t)task_slot[i] << 17)};
+        }
       }
-    }
+    });
     const uint32_t n_rec = (uint32_t)recs.size();
     const uint32_t slots_per_rec = (W + 14) / W + 1;
     const uint64_t slab_per_rec = (uint64_t)slab_bytes * slots_per_rec;
@@ -266,7 +274,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
         per_task[t] = (uint32_t)kept.size();
       }
     });
-    for (auto& v : part) result.insert(result.end(), v.begin(), v.end());
+    for (auto& v : part) if (!v.empty()) pieces.emplace_back(std::move(v));
     t0 = t1;
     ms_post += ms_since(t_sec);
   }
@@ -274,10 +282,22 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
     std::fprintf(stderr, "[calitas] align_windows: %d tasks: guides %.1f ms, pack %.1f ms, records %.1f ms, alloc+upload %.1f ms, kernels+copy %.1f ms, filter %.1f ms\n",
                  n_tasks, ms_prep, ms_pack, ms_recs, ms_upload, ms_gpu, ms_post);
 
-  *n_out = result.size();
-  *out = (calitas_aln_t*)calitas_out_alloc(std::max<size_t>(1, result.size()) * sizeof(calitas_aln_t));
+  std::vector<size_t> piece_at(pieces.size() + 1, 0);
+  for (size_t k = 0; k < pieces.size(); k++) piece_at[k + 1] = piece_at[k] + pieces[k].size();
+  const size_t n_result = piece_at[pieces.size()];
+  *n_out = n_result;
+  *out = (calitas_aln_t*)calitas_out_alloc(std::max<size_t>(1, n_result) * sizeof(calitas_aln_t));
   if (!*out) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
-  if (!result.empty()) std::memcpy(*out, result.data(), result.size() * sizeof(calitas_aln_t));
+  {
+    // (one copy, by the pool: a batch of the variant branch returns 7 MB of records, and three single-threaded copies of them were
+    // 4 of the call's 14 ms)
+    WorkerPool one_thread(1);
+    WorkerPool* const owners_pool = (ctx->parent ? ctx->parent : ctx)->pool;
+    calitas_aln_t* const dst = *out;
+    (owners_pool && n_result >= 4096 ? owners_pool : &one_thread)->for_blocks(pieces.size(), [&](size_t b, size_t e, int) {
+      for (size_t k = b; k < e; k++) std::memcpy(dst + piece_at[k], pieces[k].data(), pieces[k].size() * sizeof(calitas_aln_t));
+    });
+  }
   if (counts) {
     *counts = (uint32_t*)calitas_out_alloc(std::max<size_t>(1, per_task.size()) * sizeof(uint32_t));
     if (!*counts) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");

@@ -1,6 +1,7 @@
 // refpack.cpp -- ASCII contigs -> 2-bit codes + exception mask + run table + scan-tile table (layout: common.hpp).
 #include "refpack.hpp"
 #include "tuning.hpp"
+#include "parallel.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -87,7 +88,7 @@ static void pack_span(const uint8_t* src, uint64_t n, uint64_t g0, uint32_t* cw,
 
 // Explicit targets (calitas_align_windows) packed back to back, each starting on a 32-base boundary: the align / trace kernels read
 // inside a target only, so none of the tile padding and halos the scan kernel needs.  "Tiles" are 32 bases (tile -> target lookup).
-void pack_targets_dense(PackedRef& out, int n, const uint64_t* lengths, const uint8_t* const* bases) {
+void pack_targets_dense(PackedRef& out, int n, const uint64_t* lengths, const uint8_t* const* bases, WorkerPool* pool) {
   out = PackedRef();
   out.genome_build = "windows";
   out.chunk = 32; out.tile = 32;
@@ -104,11 +105,19 @@ void pack_targets_dense(PackedRef& out, int n, const uint64_t* lengths, const ui
   out.codes.assign(g / 16, 0u);
   out.mask.assign(g / 32, 0xFFFFFFFFu);
   out.tiles.assign(g / 32, TileInfo{0xFFFFFFFFu, 1u});
-  for (int i = 0; i < n; i++) {
-    const uint64_t g0 = out.contigs[i].gbase;
-    pack_span(bases[i], lengths[i], g0, out.codes.data() + g0 / 16, out.mask.data() + g0 / 32, out.runs);
-    for (uint64_t t = g0 / 32; t < (g0 + lengths[i] + 31) / 32; t++) out.tiles[t].contig = (uint32_t)i;
-  }
+  // every target starts on a 32-base boundary: no code or mask word is shared, blocks of targets can be packed side by side; the runs
+  // of exception bases of a block are in position order, and so are the blocks
+  auto pack_block = [&](size_t b, size_t e, std::vector<Run>& runs) {
+    for (size_t i = b; i < e; i++) {
+      const uint64_t g0 = out.contigs[i].gbase;
+      pack_span(bases[i], lengths[i], g0, out.codes.data() + g0 / 16, out.mask.data() + g0 / 32, runs);
+      for (uint64_t t = g0 / 32; t < (g0 + lengths[i] + 31) / 32; t++) out.tiles[t].contig = (uint32_t)i;
+    }
+  };
+  if (!pool || pool->size() < 2 || n < 4096) { pack_block(0, (size_t)n, out.runs); return; }
+  std::vector<std::vector<Run>> runs((size_t)pool->size());
+  pool->for_blocks((size_t)n, [&](size_t b, size_t e, int tid) { pack_block(b, e, runs[(size_t)tid]); });
+  for (auto& r : runs) out.runs.insert(out.runs.end(), r.begin(), r.end());
 }
 
 void pack_reference(PackedRef& out, int n_contigs, const char* const* names, const uint64_t* lengths,

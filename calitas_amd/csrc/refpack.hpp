@@ -25,7 +25,9 @@ struct PackedRef {
 };
 
 // Packs ASCII contigs.  `threads` <= 0 picks the hardware concurrency.
-void pack_targets_dense(PackedRef& out, int n, const uint64_t* lengths, const uint8_t* const* bases);
+class WorkerPool;
+// (pool: the targets are packed in blocks by its workers -- the variant branch packs 65 536 windows per batch)
+void pack_targets_dense(PackedRef& out, int n, const uint64_t* lengths, const uint8_t* const* bases, WorkerPool* pool = nullptr);
 void pack_reference(PackedRef& out, int n_contigs, const char* const* names, const uint64_t* lengths,
                     const uint8_t* const* bases, const char* genome_build, int threads);
 

@@ -413,7 +413,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
 
   const auto t_call = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-  double ms_ref = 0, ms_parse = 0, ms_align = 0, ms_rows = 0, ms_merge = 0;
+  double ms_ref = 0, ms_parse = 0, ms_align = 0, ms_rows = 0, ms_merge = 0, ms_build = 0, ms_wait = 0, ms_finish = 0;
   calitas_aln_t* ref_alns = nullptr;                                                               // (host merge only, below)
   uint64_t n_ref = 0;
   int rc = CALITAS_OK;
@@ -611,6 +611,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   auto build_and_flush = [&]() -> int {
     nb = spec_contig.size();
     if (nb == 0) return CALITAS_OK;
+    const auto t_build = std::chrono::steady_clock::now();
     std::vector<std::string> errs((size_t)ctx->pool->size());
     ctx->pool->for_blocks(nb, [&](size_t b, size_t e, int tid) {
       Arena& A = batch.arenas[(size_t)tid];
@@ -629,6 +630,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     });
     for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
     spec_off.assign(1, 0u); spec_v.clear(); spec_a.clear(); spec_contig.clear(); spec_chunk.clear();
+    ms_build += ms_since(t_build);
     if (!err.empty()) { nb = 0; return CALITAS_OK; }
     return flush();
   };
@@ -785,11 +787,13 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // The contigs before `upto` have all their windows emitted: align what is pending, finish and publish them.
   size_t contigs_done = 0, hits_done = 0;
   // The aligner thread: batch k is on the device (and its alignments are lifted back) while this thread walks the VCF and builds
-  // batch k + 1 -- 48 batches of 65 536 windows at full size, 13 ms each in the aligner, 8 ms each to build.  One batch waits at most.
+  // batch k + 1 -- 48 batches of 65 536 windows at full size, 10 ms each in the aligner, 5 ms each to walk and build.  Jobs run in the
+  // order they were handed over; two wait at most.
   struct AlignerState {
     std::mutex mu;
     std::condition_variable cv;
-    Batch waiting; size_t n_waiting = 0; bool have = false, busy = false, quit = false;
+    std::deque<std::function<int(std::string&)>> jobs;
+    bool busy = false, quit = false;
     int rc = CALITAS_OK;
     std::string err;
   } al;
@@ -801,18 +805,25 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   aligner = std::thread([&] {
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     for (;;) {
-      Batch b; size_t n = 0;
+      std::function<int(std::string&)> job;
+      bool skip = false;
       {
         std::unique_lock<std::mutex> lk(al.mu);
-        al.cv.wait(lk, [&] { return al.have || al.quit; });
-        if (!al.have) return;
-        b = std::move(al.waiting); n = al.n_waiting; al.have = false; al.busy = true;
+        al.cv.wait(lk, [&] { return !al.jobs.empty() || al.quit; });
+        if (al.jobs.empty()) return;
+        job = std::move(al.jobs.front());
+        al.jobs.pop_front();
+        al.busy = true;
+        skip = al.rc != CALITAS_OK || !al.err.empty();            // (after a failure the rest is dropped)
       }
       al.cv.notify_all();
       int r = CALITAS_OK;
       std::string e;
-      try { r = align_stage(b, n, e); }
-      catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("the aligner thread ended with an exception: ") + x.what(); }
+      if (!skip) {
+        try { r = job(e); }
+        catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("the aligner thread ended with an exception: ") + x.what(); }
+      }
+      job = nullptr;
       {
         std::lock_guard<std::mutex> lk(al.mu);
         al.busy = false;
@@ -822,34 +833,41 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       al.cv.notify_all();
     }
   });
-  hand_over = [&](Batch&& b, size_t n) -> int {
+  auto enqueue = [&](std::function<int(std::string&)> job) -> int {
+    const auto t_wait = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(al.mu);
-    al.cv.wait(lk, [&] { return !al.have; });
+    al.cv.wait(lk, [&] { return al.jobs.size() < 2; });
+    ms_wait += ms_since(t_wait);
     if (al.rc != CALITAS_OK || !al.err.empty()) return al.rc;     // (the caller learns the reason from drain())
-    al.waiting = std::move(b); al.n_waiting = n; al.have = true;
+    al.jobs.push_back(std::move(job));
     lk.unlock();
     al.cv.notify_all();
     return CALITAS_OK;
   };
-  auto drain = [&]() -> int {                                     // everything handed over is in hits[]
+  hand_over = [&](Batch&& b, size_t n) -> int {
+    auto held = std::make_shared<Batch>(std::move(b));
+    return enqueue([&, held, n](std::string& e) { return align_stage(*held, n, e); });
+  };
+  auto drain = [&]() -> int {                                     // everything handed over has been done
+    const auto t_wait = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(al.mu);
-    al.cv.wait(lk, [&] { return !al.have && !al.busy; });
+    al.cv.wait(lk, [&] { return al.jobs.empty() && !al.busy; });
+    ms_wait += ms_since(t_wait);
     if (!al.err.empty() && err.empty()) err = al.err;
     return al.rc;
   };
-  auto finish_contigs = [&](size_t upto) -> int {
+  // (every batch handed over before it has been through the aligner: finish_contigs drains first)
+  auto finish_upto = [&](size_t upto) -> int {
     if (upto <= contigs_done) return CALITAS_OK;
-    int r = build_and_flush();
-    if (r || !err.empty()) return r;
-    r = drain();
-    if (r || !err.empty()) return r;
+    const auto t_fin = std::chrono::steady_clock::now();
+    struct Fin { double& ms; std::chrono::steady_clock::time_point t0; ~Fin() { ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } fin{ms_finish, t_fin};
     if (device_merge) {
       // hits[hits_done, ...) lie on contigs [contigs_done, upto), in contig order
       size_t h = hits_done;
       for (size_t c = contigs_done; c < upto; c++) {
         size_t e = h;
         while (e < hits.size() && (size_t)hits[e].w->contig == c) e++;
-        r = finish_contig(c, h, e);
+        const int r = finish_contig(c, h, e);
         if (r) return r;
         h = e;
         publish(c + 1, false);
@@ -858,6 +876,19 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     hits_done = hits.size();
     contigs_done = upto;
     return CALITAS_OK;
+  };
+  size_t contigs_asked = 0;                                       // (this thread's side of contigs_done)
+  auto finish_contigs = [&](size_t upto) -> int {
+    if (upto <= contigs_asked) return CALITAS_OK;
+    int r = build_and_flush();
+    if (r || !err.empty()) return r;
+    contigs_asked = upto;
+    // (The contig's entries made on the aligner thread too, behind its last batch, while this thread goes on with the next contig:
+    // measured slower -- that thread then carries 1.26 s of the call's host work one after the other and every pool section waits
+    // for its turn: variant half 1.54 against 1.38 s.)
+    r = drain();
+    if (r || !err.empty()) return r;
+    return finish_upto(upto);
   };
 
   const int max_variants = p.max_variants;
@@ -872,7 +903,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     int contig = -1;
     for (size_t k = 0; k < ref.names.size(); k++) if (ref.names[k] == order[ci]) { contig = (int)k; break; }
     chunk_serial++;
-    if ((size_t)contig > contigs_done) { rc = finish_contigs((size_t)contig); if (rc || !err.empty()) break; }   // the contigs before this one are complete
+    if ((size_t)contig > contigs_asked) { rc = finish_contigs((size_t)contig); if (rc || !err.empty()) break; }   // the contigs before this one are complete: their entries are made behind their last batch
     for (size_t s = 0; s < chunk.size() && err.empty() && rc == CALITAS_OK; s++) {
       std::vector<const Var*> sub;
       for (size_t k = s; k < chunk.size(); k++) { if (chunk[k]->pos - chunk[s]->end > padding) break; sub.push_back(chunk[k]); }
@@ -894,6 +925,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     }
   }
   if (rc == CALITAS_OK && err.empty()) rc = finish_contigs(nc);
+  { const int dr = drain(); if (rc == CALITAS_OK) rc = dr; }
   if (rc != CALITAS_OK || !err.empty()) {
     publish(nc, true);
     if (helper.joinable()) helper.join();
@@ -923,9 +955,10 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       if (n_rows) *n_rows = hr.rows;
       if (n_windows) *n_windows = windows_total;
       if (tune::get("CALITAS_TRACE"))
-        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: align %.1f ms, keys %.1f ms, groups %.1f + rows %.1f + blobs %.1f ms of %zu hits, "
+        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: built in %.1f ms, waiting for the aligner thread %.1f ms (align %.1f ms, keys %.1f ms there), "
+                             "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits, "
                              "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms\n",
-                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_groups, ms_make, ms_blob, hits.size(), ms_variant_half, hr.ms, ms_since(t_call));
+                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_build, ms_wait, ms_align, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, hits.size(), ms_variant_half, hr.ms, ms_since(t_call));
       return CALITAS_OK;
     }
     calitas_free(hr.tsv);
