@@ -371,6 +371,78 @@ std::string md5_file(const char* path, std::string& hex) {
   return "";
 }
 
+// A thread that runs jobs in the order they are handed over (a stage of the variant branch's pipeline).  After a job has failed the
+// ones behind it are dropped; drain() reports the failure.
+struct StageThread {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<int(std::string&)>> jobs;
+  bool busy = false, quit = false;
+  int rc = CALITAS_OK;
+  std::string err;
+  std::thread t;
+  void start(int device) {
+    t = std::thread([this, device] {
+      if (device >= 0) (void)hipSetDevice(device);
+      for (;;) {
+        std::function<int(std::string&)> job;
+        bool skip = false;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return !jobs.empty() || quit; });
+          if (jobs.empty()) return;
+          job = std::move(jobs.front());
+          jobs.pop_front();
+          busy = true;
+          skip = rc != CALITAS_OK || !err.empty();
+        }
+        cv.notify_all();
+        int r = CALITAS_OK;
+        std::string e;
+        if (!skip) {
+          try { r = job(e); }
+          catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("a stage of the variant branch ended with an exception: ") + x.what(); }
+        }
+        job = nullptr;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          busy = false;
+          if (r && rc == CALITAS_OK) rc = r;
+          if (!e.empty() && err.empty()) err = e;
+        }
+        cv.notify_all();
+      }
+    });
+  }
+  // hands a job over; waits while max_waiting jobs are waiting (ms_wait: that time is added to it)
+  int enqueue(std::function<int(std::string&)> job, size_t max_waiting, double* ms_wait) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return jobs.size() < max_waiting; });
+    if (ms_wait) *ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != CALITAS_OK || !err.empty()) return rc;             // (the caller learns the reason from drain())
+    jobs.push_back(std::move(job));
+    lk.unlock();
+    cv.notify_all();
+    return CALITAS_OK;
+  }
+  // every job handed over has run
+  int drain(double* ms_wait, std::string* err_out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return jobs.empty() && !busy; });
+    if (ms_wait) *ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (err_out && !err.empty() && err_out->empty()) *err_out = err;
+    return rc;
+  }
+  ~StageThread() {
+    if (!t.joinable()) return;
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    t.join();
+  }
+};
+
 }  // namespace
 
 extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
@@ -541,20 +613,23 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
 
   // A built batch of windows through the aligner (device) and its alignments lifted back and listed as hits (worker pool).  Runs on the
   // aligner thread (below) while this thread builds the next batch; `err_out` is that thread's own.
-  auto align_stage = [&](Batch& batch, const size_t n, std::string& err) -> int {
-    if (n == 0) return CALITAS_OK;
+  struct Aligned { calitas_aln_t* out = nullptr; uint64_t n_out = 0; uint32_t* counts = nullptr; };
+  auto align_part = [&](Batch& batch, const size_t n, Aligned& res) -> int {
     std::vector<calitas_guide_t> guides(n, *guide);
     std::vector<const uint8_t*> targets(n);
     std::vector<uint32_t> lens(n);
     std::vector<int32_t> offs(n, 0);
     for (size_t i = 0; i < n; i++) { targets[i] = reinterpret_cast<const uint8_t*>(batch.wins[i].bases); lens[i] = (uint32_t)batch.wins[i].len; }
-    calitas_aln_t* out = nullptr;
-    uint64_t n_out = 0;
-    uint32_t* counts = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    int r = calitas_align_windows(actx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &out, &n_out, &counts);
+    int r = calitas_align_windows(actx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &res.out, &res.n_out, &res.counts);
     if (r) { if (actx != ctx) calitas_fail(ctx, r, calitas_last_error(actx)); return r; }
     ms_align += ms_since(t0);
+    return CALITAS_OK;
+  };
+  auto lift_part = [&](Batch& batch, const size_t n, const Aligned& res, std::string& err) -> int {
+    calitas_aln_t* const out = res.out;
+    const uint64_t n_out = res.n_out;
+    uint32_t* const counts = res.counts;
     const auto t1 = std::chrono::steady_clock::now();
     // the batch's windows and records stay until the rows are written
     kept_windows.emplace_back(std::move(batch));                  // (vectors move: the views keep pointing into the arenas)
@@ -586,6 +661,12 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     calitas_free(counts);
     ms_rows += ms_since(t1);
     return CALITAS_OK;
+  };
+  auto align_stage = [&](Batch& batch, const size_t n, std::string& err) -> int {
+    if (n == 0) return CALITAS_OK;
+    Aligned res;
+    const int r = align_part(batch, n, res);
+    return r ? r : lift_part(batch, n, res, err);
   };
   // where a built batch goes: to the aligner thread once it runs (hand_over), through align_stage on this thread before that
   std::function<int(Batch&&, size_t)> hand_over;
@@ -786,75 +867,26 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   };
   // The contigs before `upto` have all their windows emitted: align what is pending, finish and publish them.
   size_t contigs_done = 0, hits_done = 0;
-  // The aligner thread: batch k is on the device (and its alignments are lifted back) while this thread walks the VCF and builds
-  // batch k + 1 -- 48 batches of 65 536 windows at full size, 10 ms each in the aligner, 5 ms each to walk and build.  Jobs run in the
-  // order they were handed over; two wait at most.
-  struct AlignerState {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::function<int(std::string&)>> jobs;
-    bool busy = false, quit = false;
-    int rc = CALITAS_OK;
-    std::string err;
-  } al;
-  std::thread aligner;
-  struct JoinAligner {
-    std::thread& t; AlignerState& al;
-    ~JoinAligner() { if (t.joinable()) { { std::lock_guard<std::mutex> lk(al.mu); al.quit = true; } al.cv.notify_all(); t.join(); } }
-  } join_aligner{aligner, al};
-  aligner = std::thread([&] {
-    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-    for (;;) {
-      std::function<int(std::string&)> job;
-      bool skip = false;
-      {
-        std::unique_lock<std::mutex> lk(al.mu);
-        al.cv.wait(lk, [&] { return !al.jobs.empty() || al.quit; });
-        if (al.jobs.empty()) return;
-        job = std::move(al.jobs.front());
-        al.jobs.pop_front();
-        al.busy = true;
-        skip = al.rc != CALITAS_OK || !al.err.empty();            // (after a failure the rest is dropped)
-      }
-      al.cv.notify_all();
-      int r = CALITAS_OK;
-      std::string e;
-      if (!skip) {
-        try { r = job(e); }
-        catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("the aligner thread ended with an exception: ") + x.what(); }
-      }
-      job = nullptr;
-      {
-        std::lock_guard<std::mutex> lk(al.mu);
-        al.busy = false;
-        if (r && al.rc == CALITAS_OK) al.rc = r;
-        if (!e.empty() && al.err.empty()) al.err = e;
-      }
-      al.cv.notify_all();
-    }
-  });
-  auto enqueue = [&](std::function<int(std::string&)> job) -> int {
-    const auto t_wait = std::chrono::steady_clock::now();
-    std::unique_lock<std::mutex> lk(al.mu);
-    al.cv.wait(lk, [&] { return al.jobs.size() < 2; });
-    ms_wait += ms_since(t_wait);
-    if (al.rc != CALITAS_OK || !al.err.empty()) return al.rc;     // (the caller learns the reason from drain())
-    al.jobs.push_back(std::move(job));
-    lk.unlock();
-    al.cv.notify_all();
-    return CALITAS_OK;
-  };
+  // Two stage threads: batch k is on the device (aligner), the alignments of batch k - 1 are lifted back and listed as hits (lifter),
+  // while this thread walks the VCF and builds batch k + 1 -- 48 batches of 65 536 windows at full size: 8-10 ms each in the aligner, 3 to
+  // lift, 5 to walk and build.  Jobs run in the order they were handed over; two wait per stage at most.
+  StageThread aligner, lifter;
+  aligner.start(ctx->device);
+  lifter.start(-1);
   hand_over = [&](Batch&& b, size_t n) -> int {
     auto held = std::make_shared<Batch>(std::move(b));
-    return enqueue([&, held, n](std::string& e) { return align_stage(*held, n, e); });
+    return aligner.enqueue([&, held, n](std::string&) -> int {
+      if (n == 0) return CALITAS_OK;
+      auto res = std::make_shared<Aligned>();
+      const int r = align_part(*held, n, *res);
+      if (r) return r;
+      return lifter.enqueue([&, held, n, res](std::string& e) { return lift_part(*held, n, *res, e); }, 2, nullptr);
+    }, 2, &ms_wait);
   };
-  auto drain = [&]() -> int {                                     // everything handed over has been done
-    const auto t_wait = std::chrono::steady_clock::now();
-    std::unique_lock<std::mutex> lk(al.mu);
-    al.cv.wait(lk, [&] { return al.jobs.empty() && !al.busy; });
-    ms_wait += ms_since(t_wait);
-    if (!al.err.empty() && err.empty()) err = al.err;
-    return al.rc;
+  auto drain = [&]() -> int {                                     // everything handed over is in hits[]
+    const int ra = aligner.drain(&ms_wait, &err);
+    const int rl = lifter.drain(&ms_wait, &err);
+    return ra ? ra : rl;
   };
   // (every batch handed over before it has been through the aligner: finish_contigs drains first)
   auto finish_upto = [&](size_t upto) -> int {
@@ -944,11 +976,27 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     });
     ctx->pool->for_blocks(kept_windows.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) kept_windows[k] = Batch(); });
     ctx->pool->for_blocks(kept_out.size(), [&](size_t b, size_t e, int) { for (size_t k = b; k < e; k++) { calitas_free(kept_out[k]); kept_out[k] = nullptr; } });
+    // the contigs' row blobs (1.1 GB at full size) and entry tables, and the big tables themselves: the kernel clears pages as they are
+    // handed back, on the thread that hands them back -- one thread per block instead of this one for all of them on the way out
+    ctx->pool->for_blocks(cx.size() + 2, [&](size_t b, size_t e, int) {
+      for (size_t k = b; k < e; k++) {
+        if (k < cx.size()) {
+          std::free(cx[k].blob.p); cx[k].blob.p = nullptr;
+          std::vector<HitsExtKey>().swap(cx[k].keys);
+          std::vector<uint64_t>().swap(cx[k].row_off);
+        } else if (k == cx.size()) {
+          std::vector<ExtHit>().swap(hits);
+        } else {
+          std::vector<Var>().swap(vcf);
+        }
+      }
+    });
     if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: teardown %.1f ms\n", ms_since(t0));
   };
   if (device_merge) {
     helper.join();
     if (hr.rc == CALITAS_OK) {
+      const size_t n_hits = hits.size(), n_vcf = vcf.size();
       teardown();
       *tsv = hr.tsv;
       if (tsv_bytes) *tsv_bytes = hr.bytes;
@@ -958,7 +1006,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: built in %.1f ms, waiting for the aligner thread %.1f ms (align %.1f ms, keys %.1f ms there), "
                              "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits, "
                              "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms\n",
-                     ms_parse, vcf.size(), (unsigned long long)windows_total, ms_build, ms_wait, ms_align, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, hits.size(), ms_variant_half, hr.ms, ms_since(t_call));
+                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_build, ms_wait, ms_align, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, ms_variant_half, hr.ms, ms_since(t_call));
       return CALITAS_OK;
     }
     calitas_free(hr.tsv);
@@ -1008,6 +1056,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   *tsv = hits_tsv(ref, gh, gid, p, ref_alns, n_ref, version, stamp, &nr, ctx->pool, calitas_out_alloc, ext.data(), (uint64_t)ext.size(),
                   [](void* user, uint64_t e, std::string& row) { auto* m = static_cast<RowMaker*>(user); (*m->fn)((*m->hits)[(size_t)e], row); }, &maker);
   calitas_free(ref_alns);
+  const size_t n_vcf_records = vcf.size();
   teardown();
   if (!*tsv) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
   if (tsv_bytes) *tsv_bytes = std::strlen(*tsv);
@@ -1016,6 +1065,6 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   ms_merge = ms_since(t_merge);
   if (tune::get("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search_variants: reference search %.1f ms, VCF %.1f ms (%zu records), %llu windows: align %.1f ms, rows %.1f ms, merge %.1f ms, call %.1f ms\n",
-                 ms_ref, ms_parse, vcf.size(), (unsigned long long)windows_total, ms_align, ms_rows, ms_merge, ms_since(t_call));
+                 ms_ref, ms_parse, n_vcf_records, (unsigned long long)windows_total, ms_align, ms_rows, ms_merge, ms_since(t_call));
   return CALITAS_OK;
 }
