@@ -465,7 +465,14 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
     TRY(grow(&w.ext_rows, w.ext_rows_cap, std::max<size_t>(1, row_bytes)));
     TRY(hipMemcpyAsync(w.ext_keys, ext->keys, (size_t)n_ext * sizeof(HitsExtKey), hipMemcpyHostToDevice, stream));
     TRY(hipMemcpyAsync(w.ext_off, ext->row_off, ((size_t)n_ext + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    if (row_bytes) TRY(hipMemcpyAsync(w.ext_rows, ext->rows, row_bytes, hipMemcpyHostToDevice, stream));
+    if (row_bytes && ext->rows) TRY(hipMemcpyAsync(w.ext_rows, ext->rows, row_bytes, hipMemcpyHostToDevice, stream));
+    else if (row_bytes) {
+      if (!ext->n_seg || !ext->seg || !ext->seg_off || ext->seg_off[0] != 0 || ext->seg_off[ext->n_seg] != row_bytes) return hipErrorInvalidValue;
+      for (uint32_t sg = 0; sg < ext->n_seg; sg++) {
+        const uint64_t nb = ext->seg_off[sg + 1] - ext->seg_off[sg];
+        if (nb) TRY(hipMemcpyAsync(w.ext_rows + ext->seg_off[sg], ext->seg[sg], (size_t)nb, hipMemcpyHostToDevice, stream));
+      }
+    }
   }
   const bool small = n_in <= HITS_SMALL && window_reach != 0 && !own;
   const HitsOwn ho = own ? *own : HitsOwn();

@@ -69,6 +69,11 @@ struct HitsExt {
   const HitsExtKey* keys = nullptr;
   const uint64_t* row_off = nullptr;   // n + 1 offsets into rows
   const char* rows = nullptr;
+  // ... or the rows in n_seg consecutive pieces (rows null): piece s holds bytes [seg_off[s], seg_off[s + 1]) of the rows' text -- the
+  // caller's workers each wrote a block of rows into a buffer of their own, and joining 1.1 GB of them only to upload them is a copy
+  uint32_t n_seg = 0;
+  const char* const* seg = nullptr;
+  const uint64_t* seg_off = nullptr;   // n_seg + 1
   uint32_t* kept = nullptr;            // out (optional): how many of the entries were kept
 };
 

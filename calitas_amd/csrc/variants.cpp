@@ -597,8 +597,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         const int gmm = ga_count(pg, pa, n_ops, false, false, true, false), ggp = ga_count(pg, pa, n_ops, false, false, false, true);
         std::string cigar;
         for (int i = 0; i < n_ops;) { int j = i; while (j < n_ops && a.ops[j] == a.ops[i]) j++; cigar += std::to_string(j - i); cigar += (char)a.ops[i]; i = j; }
-        row.clear();
-        row.reserve(640);
+        const size_t row_at = row.size();                                                           // (appends to what is there)
         auto add = [&](const std::string& s) { row += s; row += '\t'; };
         add(gid); add(gh.protospacer); add(ref.genome_build + (vs.empty() ? "" : "+variants")); add(ref.names[w.contig]);
         add(std::to_string(gstart)); add(std::to_string(gend)); add(std::string(1, (char)a.strand)); add(unpadded_target);
@@ -608,7 +607,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         add(std::string(pg, (size_t)n_ops)); add(std::string(pa, (size_t)n_ops)); add(std::string(pt, (size_t)n_ops));
         add(c5_8); add(c3_8); add(cigar); add(rs.proto_len); add(std::to_string(unpadded_target.size()));
         row += rs.tail;                                                                             // aligner .. time_stamp + '\n'
-        if (!row.empty() && row.back() == '\n') row.pop_back();
+        if (row.size() > row_at && row.back() == '\n') row.pop_back();
   };
 
   // A built batch of windows through the aligner (device) and its alignments lifted back and listed as hits (worker pool).  Runs on the
@@ -740,8 +739,12 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   const bool device_merge = !(force_host && std::atoi(force_host) != 0) && p.max_overlap >= 1;
   if (device_merge) { rc = calitas_side_context(ctx, &actx); if (rc) return rc; }
   const size_t nc = ref.contigs.size();
-  struct Blob { char* p = nullptr; ~Blob() { std::free(p); } };
-  struct ContigExt { std::vector<HitsExtKey> keys; std::vector<uint64_t> row_off; Blob blob; HitsExt ext; };
+  struct ContigExt {
+    std::vector<HitsExtKey> keys; std::vector<uint64_t> row_off;
+    std::vector<std::string> segs;                                // the rows' text as the workers wrote it: a block of rows each
+    std::vector<const char*> seg_ptr; std::vector<uint64_t> seg_off;
+    HitsExt ext;
+  };
   std::vector<ContigExt> cx(nc);
   std::mutex pub_mu;
   std::condition_variable pub_cv;
@@ -828,21 +831,21 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     ms_groups += ms_since(t0);
     const auto t1 = std::chrono::steady_clock::now();
     if (!need_vid()) return calitas_fail(ctx, CALITAS_EIO, md5_err);
-    // rows: every worker writes the rows of a consecutive block of entries into one buffer of its own; the blob is filled from those
+    // rows: every worker writes the rows of a consecutive block of entries into one buffer of its own; the device takes them piece by piece
     ContigExt& x = cx[c];
     std::vector<uint32_t> row_len(n);
-    std::vector<std::string> local(T);
+    std::vector<std::string>& local = x.segs;
+    local.assign(T, std::string());
     std::vector<std::pair<size_t, size_t>> local_range(T, {0, 0});
     ctx->pool->for_blocks(n, [&](size_t b, size_t e, int tid) {
       std::string& buf = local[(size_t)tid];
-      buf.reserve((e - b) * 640);
-      std::string row;
+      buf.reserve((e - b) * 600);
       local_range[(size_t)tid] = {b, e};
       for (size_t i = b; i < e; i++) {
-        make_row(hits[h0 + order[i]], row);
-        row += '\n';
-        row_len[i] = (uint32_t)row.size();
-        buf += row;
+        const size_t at = buf.size();
+        make_row(hits[h0 + order[i]], buf);                       // (appends)
+        buf += '\n';
+        row_len[i] = (uint32_t)(buf.size() - at);
       }
     });
     ms_make += ms_since(t1);
@@ -854,14 +857,17 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       x.keys[i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (i >= n_plain ? HITS_EXT_PLACED : 0u)};
       x.row_off[i + 1] = x.row_off[i] + row_len[i];
     }
-    x.blob.p = (char*)std::malloc(std::max<size_t>(1, (size_t)x.row_off[n]));
-    if (!x.blob.p) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
-    ctx->pool->run([&](int tid) {
-      const size_t b = local_range[(size_t)tid].first, e = local_range[(size_t)tid].second;
-      if (b < e) std::memcpy(x.blob.p + x.row_off[b], local[(size_t)tid].data(), (size_t)(x.row_off[e] - x.row_off[b]));
-      std::string().swap(local[(size_t)tid]);
-    });
-    x.ext.contig = (int32_t)c; x.ext.n = (uint32_t)n; x.ext.keys = x.keys.data(); x.ext.row_off = x.row_off.data(); x.ext.rows = x.blob.p;
+    // the workers' buffers in the order of their blocks (for_blocks hands block t to worker t) are the rows' text
+    x.seg_ptr.assign(T, nullptr); x.seg_off.assign(T + 1, 0);
+    for (size_t t = 0; t < T; t++) {
+      const size_t b = local_range[t].first, e = local_range[t].second;
+      x.seg_ptr[t] = local[t].data();
+      x.seg_off[t + 1] = x.seg_off[t] + (b < e ? x.row_off[e] - x.row_off[b] : 0);
+      if (b < e && (x.seg_off[t] != x.row_off[b] || local[t].size() != x.row_off[e] - x.row_off[b]))
+        return calitas_fail(ctx, CALITAS_EINVAL, "the rows of a contig's entries are not where their offsets say (internal error)");
+    }
+    x.ext.contig = (int32_t)c; x.ext.n = (uint32_t)n; x.ext.keys = x.keys.data(); x.ext.row_off = x.row_off.data(); x.ext.rows = nullptr;
+    x.ext.n_seg = (uint32_t)T; x.ext.seg = x.seg_ptr.data(); x.ext.seg_off = x.seg_off.data();
     ms_blob += ms_since(t2);
     return CALITAS_OK;
   };
@@ -981,7 +987,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     ctx->pool->for_blocks(cx.size() + 2, [&](size_t b, size_t e, int) {
       for (size_t k = b; k < e; k++) {
         if (k < cx.size()) {
-          std::free(cx[k].blob.p); cx[k].blob.p = nullptr;
+          std::vector<std::string>().swap(cx[k].segs);
           std::vector<HitsExtKey>().swap(cx[k].keys);
           std::vector<uint64_t>().swap(cx[k].row_off);
         } else if (k == cx.size()) {
@@ -1054,7 +1060,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   uint64_t nr = 0;
   const auto t_merge = std::chrono::steady_clock::now();
   *tsv = hits_tsv(ref, gh, gid, p, ref_alns, n_ref, version, stamp, &nr, ctx->pool, calitas_out_alloc, ext.data(), (uint64_t)ext.size(),
-                  [](void* user, uint64_t e, std::string& row) { auto* m = static_cast<RowMaker*>(user); (*m->fn)((*m->hits)[(size_t)e], row); }, &maker);
+                  [](void* user, uint64_t e, std::string& row) { auto* m = static_cast<RowMaker*>(user); row.clear(); (*m->fn)((*m->hits)[(size_t)e], row); }, &maker);
   calitas_free(ref_alns);
   const size_t n_vcf_records = vcf.size();
   teardown();
