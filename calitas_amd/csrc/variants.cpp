@@ -538,6 +538,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   };
 
   // the row of a kept hit (RH:210-254 with the window's own bases, SR:598-613)
+  const std::string build_with_variants = ref.genome_build + "+variants";
   auto make_row = [&](const ExtHit& h, std::string& row) {
         const Window& w = *h.w;
         const calitas_aln_t& a = *h.a;
@@ -566,8 +567,13 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         const std::string c3_8 = v_r8 ? r8 : (!minus ? eight_right() : eight_left());
         // padded strings from the window's own bases (SGA:511; '-' strand: revcomp of the window span)
         const std::string& q = rs.query[a.pam_index + 1];
-        std::string t(w.bases + as, (size_t)(ae - as));
-        if (minus) t = revcomp(t);
+        // (two million rows per call at full size: the pieces of a row are put together in buffers on the stack, not in strings of their own)
+        char t[CALITAS_MAX_OPS + 8];
+        {
+          const int tl = std::min(ae - as, (int)CALITAS_MAX_OPS);
+          if (!minus) std::memcpy(t, w.bases + as, (size_t)tl);
+          else for (int i = 0; i < tl; i++) t[i] = complement_base(w.bases[ae - 1 - i]);
+        }
         const int n_ops = a.n_ops;
         char pg[CALITAS_MAX_OPS + 1], pa[CALITAS_MAX_OPS + 1], pt[CALITAS_MAX_OPS + 1];
         size_t qi = 0, ti = 0;
@@ -582,11 +588,24 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         }
         int ps = -1, pe = -1;                                                                       // GA:111-115
         for (int i = 0; i < n_ops; i++) if (pg[i] >= 'A' && pg[i] <= 'Z') { if (ps < 0) ps = i; pe = i; }
-        std::string unpadded_target;
-        for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target += pt[i];
+        char unpadded_target[CALITAS_MAX_OPS + 1];
+        size_t n_unpadded = 0;
+        for (int i = ps; i >= 0 && i <= pe; i++) if (pt[i] != '-') unpadded_target[n_unpadded++] = pt[i];
         // variants under the hit (RH:211) and their columns (RH:211-233)
-        std::vector<const Allele*> vs;
-        for (int k = 0; k < w.nv; k++) { const Allele& al = w.variants[k]; if (start <= al.v->pos - 1 && al.v->pos - 1 <= end) vs.push_back(&al); }
+        const Allele* vs_few[8];
+        std::vector<const Allele*> vs_many;
+        size_t n_vs = 0;
+        for (int k = 0; k < w.nv; k++) {
+          const Allele& al = w.variants[k];
+          if (!(start <= al.v->pos - 1 && al.v->pos - 1 <= end)) continue;
+          if (n_vs < 8) vs_few[n_vs] = &al;
+          else { if (n_vs == 8) vs_many.assign(vs_few, vs_few + 8); vs_many.push_back(&al); }
+          n_vs++;
+        }
+        const Allele* const* vs_p = n_vs <= 8 ? vs_few : vs_many.data();
+        struct VsView { const Allele* const* p; size_t n; bool empty() const { return n == 0; } size_t size() const { return n; }
+                        const Allele* operator[](size_t i) const { return p[i]; } const Allele* const* begin() const { return p; } const Allele* const* end() const { return p + n; } };
+        const VsView vs{vs_p, n_vs};
         std::string ids, descs, af;
         if (!vs.empty()) {
           const Allele* mn = vs[0];
@@ -595,17 +614,28 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
           for (size_t i = 0; i < vs.size(); i++) { if (i) { ids += ';'; descs += ';'; } ids += vs[i]->v->id; descs += display_string(*vs[i]); }
         }
         const int gmm = ga_count(pg, pa, n_ops, false, false, true, false), ggp = ga_count(pg, pa, n_ops, false, false, false, true);
-        std::string cigar;
-        for (int i = 0; i < n_ops;) { int j = i; while (j < n_ops && a.ops[j] == a.ops[i]) j++; cigar += std::to_string(j - i); cigar += (char)a.ops[i]; i = j; }
+        char cigar[4 * CALITAS_MAX_OPS + 8];
+        size_t n_cigar = 0;
+        auto put_int = [](char* at, long v) -> size_t {            // decimal digits of v at `at`; returns how many
+          char d[24]; int nd = 0; const bool neg = v < 0; unsigned long u = neg ? (unsigned long)(-v) : (unsigned long)v;
+          do { d[nd++] = (char)('0' + u % 10); u /= 10; } while (u);
+          size_t k = 0;
+          if (neg) at[k++] = '-';
+          while (nd) at[k++] = d[--nd];
+          return k;
+        };
+        for (int i = 0; i < n_ops;) { int j = i; while (j < n_ops && a.ops[j] == a.ops[i]) j++; n_cigar += put_int(cigar + n_cigar, j - i); cigar[n_cigar++] = (char)a.ops[i]; i = j; }
         const size_t row_at = row.size();                                                           // (appends to what is there)
         auto add = [&](const std::string& s) { row += s; row += '\t'; };
-        add(gid); add(gh.protospacer); add(ref.genome_build + (vs.empty() ? "" : "+variants")); add(ref.names[w.contig]);
-        add(std::to_string(gstart)); add(std::to_string(gend)); add(std::string(1, (char)a.strand)); add(unpadded_target);
-        add(c5_10); add(c3_10); add(rs.pam_used[a.pam_index + 1]); add(ids); add(descs); add(vs.empty() ? std::string() : vid); add(af);
-        add(std::to_string(a.score)); add(std::to_string(gmm)); add(std::to_string(ggp)); add(std::to_string(gmm + ggp));
-        add(std::to_string(ga_count(pg, pa, n_ops, true, true, true, false))); add(std::to_string(mm + gp));
-        add(std::string(pg, (size_t)n_ops)); add(std::string(pa, (size_t)n_ops)); add(std::string(pt, (size_t)n_ops));
-        add(c5_8); add(c3_8); add(cigar); add(rs.proto_len); add(std::to_string(unpadded_target.size()));
+        auto add_mem = [&](const char* m, size_t len) { row.append(m, len); row += '\t'; };
+        auto add_int = [&](long v) { char d[24]; const size_t k = put_int(d, v); row.append(d, k); row += '\t'; };
+        add(gid); add(gh.protospacer); add(vs.empty() ? ref.genome_build : build_with_variants); add(ref.names[w.contig]);
+        add_int(gstart); add_int(gend); row += (char)a.strand; row += '\t'; add_mem(unpadded_target, n_unpadded);
+        add(c5_10); add(c3_10); add(rs.pam_used[a.pam_index + 1]); add(ids); add(descs); if (vs.empty()) row += '\t'; else add(vid); add(af);
+        add_int(a.score); add_int(gmm); add_int(ggp); add_int(gmm + ggp);
+        add_int(ga_count(pg, pa, n_ops, true, true, true, false)); add_int(mm + gp);
+        add_mem(pg, (size_t)n_ops); add_mem(pa, (size_t)n_ops); add_mem(pt, (size_t)n_ops);
+        add(c5_8); add(c3_8); add_mem(cigar, n_cigar); add(rs.proto_len); add_int((long)n_unpadded);
         row += rs.tail;                                                                             // aligner .. time_stamp + '\n'
         if (row.size() > row_at && row.back() == '\n') row.pop_back();
   };
