@@ -216,6 +216,7 @@ void calitas_destroy(calitas_ctx* c) {
     (void)hipFree(c->d_slab); (void)hipFree(c->d_items);
     calitas_destroy_lanes(c);
     if (c->side) { calitas_destroy(c->side); c->side = nullptr; }
+    if (c->side2) { calitas_destroy(c->side2); c->side2 = nullptr; }
     for (void* q : c->aw.p) (void)hipFree(q);
     select_destroy(c->select);
     hits_destroy(c->hits);

@@ -81,6 +81,7 @@ struct calitas_ctx {
   // calitas_align_windows: the temporary packed reference of a call's tasks on the device, kept between calls (freeing device memory
   // waits for the whole device, and the variant branch aligns its windows beside the reference passes of the same call)
   struct AlignScratch { void* p[8] = {}; size_t cap[8] = {}; } aw;
+  calitas_ctx* side2 = nullptr;     // ... and a second one: two batches of variant windows are aligned side by side
   calitas_ctx* side = nullptr;      // a child context of its own (stream, buffers) for work that runs beside a search of this context: the
                                     // variant windows' alignment while the reference passes of the same call are under way (calitas_side_context)
   struct LaneThreads* lane_threads = nullptr;   // parent: the host threads that drive lanes 1.. (search.cpp)
@@ -125,7 +126,7 @@ int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* gui
 int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                  const char* aligner_version, const char* time_stamp, const HitsExtSource& source, char** tsv,
                                  uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined);
-int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side);
+int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side, int which = 0);
 int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
                                    const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
                                    uint64_t* tsv_bytes, uint64_t* n_rows);

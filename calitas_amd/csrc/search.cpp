@@ -1292,10 +1292,11 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
 }
 
 // ctx->side: a child context with a stream and buffers of its own, the parent's reference and worker pool (see ctx.hpp).
-int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side) {
+int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side, int which) {
   *side = nullptr;
   if (ctx->device < 0) return fail(ctx, CALITAS_ENODEV, "host-only context");
-  if (!ctx->side) {
+  calitas_ctx*& slot = which ? ctx->side2 : ctx->side;
+  if (!slot) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     calitas_ctx* c = new calitas_ctx();
     c->device = ctx->device; c->parent = ctx;
@@ -1306,9 +1307,9 @@ int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side) {
     ok = ok && hipMalloc((void**)&c->d_guides, sizeof(GuideDev) * MAX_GUIDES) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_guides, sizeof(GuideDev) * MAX_GUIDES, hipHostMallocDefault) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); calitas_destroy(c); return fail(ctx, CALITAS_EHIP, "could not create the side context"); }
-    ctx->side = c;
+    slot = c;
   }
-  *side = ctx->side;
+  *side = slot;
   return CALITAS_OK;
 }
 

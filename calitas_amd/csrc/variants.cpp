@@ -643,7 +643,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // A built batch of windows through the aligner (device) and its alignments lifted back and listed as hits (worker pool).  Runs on the
   // aligner thread (below) while this thread builds the next batch; `err_out` is that thread's own.
   struct Aligned { calitas_aln_t* out = nullptr; uint64_t n_out = 0; uint32_t* counts = nullptr; };
-  auto align_part = [&](Batch& batch, const size_t n, Aligned& res) -> int {
+  auto align_part = [&](calitas_ctx* actx, Batch& batch, const size_t n, Aligned& res) -> int {
     std::vector<calitas_guide_t> guides(n, *guide);
     std::vector<const uint8_t*> targets(n);
     std::vector<uint32_t> lens(n);
@@ -694,7 +694,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   auto align_stage = [&](Batch& batch, const size_t n, std::string& err) -> int {
     if (n == 0) return CALITAS_OK;
     Aligned res;
-    const int r = align_part(batch, n, res);
+    const int r = align_part(actx, batch, n, res);
     return r ? r : lift_part(batch, n, res, err);
   };
   // where a built batch goes: to the aligner thread once it runs (hand_over), through align_stage on this thread before that
@@ -767,7 +767,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // and the text over PCIe); the row stage of contig c waits until this thread has published the contig's entries.
   const char* force_host = tune::get("CALITAS_VARIANTS_HOST");
   const bool device_merge = !(force_host && std::atoi(force_host) != 0) && p.max_overlap >= 1;
-  if (device_merge) { rc = calitas_side_context(ctx, &actx); if (rc) return rc; }
+  calitas_ctx* actx2 = nullptr;                                                                    // (a second aligner, below)
+  if (device_merge) { rc = calitas_side_context(ctx, &actx); if (rc) return rc; rc = calitas_side_context(ctx, &actx2, 1); if (rc) return rc; }
   const size_t nc = ref.contigs.size();
   struct ContigExt {
     std::vector<HitsExtKey> keys; std::vector<uint64_t> row_off;
@@ -915,23 +916,40 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // Two stage threads: batch k is on the device (aligner), the alignments of batch k - 1 are lifted back and listed as hits (lifter),
   // while this thread walks the VCF and builds batch k + 1 -- 48 batches of 65 536 windows at full size: 8-10 ms each in the aligner, 3 to
   // lift, 5 to walk and build.  Jobs run in the order they were handed over; two wait per stage at most.
-  StageThread aligner, lifter;
+  // (Two aligners when the call has side contexts: a batch is 8-10 ms in calitas_align_windows and 5 ms to walk and build, so one
+  // aligner was the pipeline's slowest stage; the batches alternate between them and reach the lifter in their own order.)
+  StageThread aligner, aligner2, lifter;
+  const bool two_aligners = actx2 != nullptr;
   aligner.start(ctx->device);
+  if (two_aligners) aligner2.start(ctx->device);
   lifter.start(-1);
+  std::mutex order_mu;
+  std::condition_variable order_cv;
+  uint64_t batches_handed = 0, batches_lifting = 0;               // (batches_lifting: under order_mu)
   hand_over = [&](Batch&& b, size_t n) -> int {
     auto held = std::make_shared<Batch>(std::move(b));
-    return aligner.enqueue([&, held, n](std::string&) -> int {
-      if (n == 0) return CALITAS_OK;
+    const uint64_t k = batches_handed++;
+    const bool second = two_aligners && (k & 1);
+    calitas_ctx* const where = second ? actx2 : actx;
+    return (second ? aligner2 : aligner).enqueue([&, held, n, k, where](std::string&) -> int {
       auto res = std::make_shared<Aligned>();
-      const int r = align_part(*held, n, *res);
-      if (r) return r;
-      return lifter.enqueue([&, held, n, res](std::string& e) { return lift_part(*held, n, *res, e); }, 2, nullptr);
+      const int r = n ? align_part(where, *held, n, *res) : CALITAS_OK;
+      // the lifter takes the batches in the order they were built, whichever aligner is done first
+      std::unique_lock<std::mutex> lk(order_mu);
+      order_cv.wait(lk, [&] { return batches_lifting == k; });
+      int lr = r;
+      if (!r && n) lr = lifter.enqueue([&, held, n, res](std::string& e) { return lift_part(*held, n, *res, e); }, 2, nullptr);
+      batches_lifting = k + 1;
+      lk.unlock();
+      order_cv.notify_all();
+      return lr;
     }, 2, &ms_wait);
   };
   auto drain = [&]() -> int {                                     // everything handed over is in hits[]
     const int ra = aligner.drain(&ms_wait, &err);
+    const int rb = two_aligners ? aligner2.drain(&ms_wait, &err) : CALITAS_OK;
     const int rl = lifter.drain(&ms_wait, &err);
-    return ra ? ra : rl;
+    return ra ? ra : rb ? rb : rl;
   };
   // (every batch handed over before it has been through the aligner: finish_contigs drains first)
   auto finish_upto = [&](size_t upto) -> int {
