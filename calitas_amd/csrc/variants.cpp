@@ -978,9 +978,11 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     int r = build_and_flush();
     if (r || !err.empty()) return r;
     contigs_asked = upto;
-    // (The contig's entries made on the aligner thread too, behind its last batch, while this thread goes on with the next contig:
-    // measured slower -- that thread then carries 1.26 s of the call's host work one after the other and every pool section waits
-    // for its turn: variant half 1.54 against 1.38 s.)
+    // (The contig's entries made on a stage thread, behind the contig's last batch, while this thread goes on with the next contig --
+    // no waiting for the stages to run dry at each of the 25 contig ends --: measured twice.  On the one aligner thread there was at
+    // first that thread carried 1.26 s of host work one after the other (variant half 1.54 against 1.38 s); on the lifter thread, with
+    // two aligners, every section on the worker pool waits for its turn behind the others' (windows built in 0.47 instead of 0.17 s)
+    // and the variant half takes the same 1.35-1.41 s.)
     r = drain();
     if (r || !err.empty()) return r;
     return finish_upto(upto);
