@@ -3,6 +3,7 @@
 // alignment work and the pool only covers the residual host stages, which are independent per window / per contig.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <functional>
@@ -47,54 +48,57 @@ class WorkerPool {
  public:
   explicit WorkerPool(int n_threads) {
     n_ = std::max(1, n_threads);
-    for (int i = 1; i < n_; i++) threads_.emplace_back([this, i] { loop(i); });
+    for (int i = 1; i < n_; i++) threads_.emplace_back([this] { loop(); });
   }
   ~WorkerPool() {
     {
       std::lock_guard<std::mutex> lk(m_);
       stop_ = true;
-      gen_++;
+      wake_seq_++;
     }
     cv_.notify_all();
     for (auto& t : threads_) t.join();
   }
   int size() const { return n_; }
 
-  // Runs fn(tid) on every worker (tid 0 is the calling thread) and waits for all of them.
-  // (Callers on different threads take turns: the variant branch builds windows and rows while the reference passes of the same
-  // call copy their text, variants.cpp.)
+  // Runs fn(0) ... fn(size() - 1), each once, on whichever threads are free -- the caller among them -- and returns when all have run.
+  // The argument is the share's number, not a thread's: what fn(t) writes is share t's, and two shares may run on one thread one
+  // after the other.  Callers on different threads run side by side (the variant branch builds windows, lifts alignments and makes
+  // rows on three threads while the reference passes of the same call expand their text): their shares are taken in the order the
+  // calls came.  Nobody waits for a worker that has not arrived (a GPU box bounds this process by a CPU quota on a host shared with
+  // other tenants: one woken thread in a few hundred starts 4-8 ms late, profiles/r04_slow_calls.txt) -- only for shares in hand.
   void run(const std::function<void(int)>& fn) {
     if (n_ == 1) { fn(0); return; }
-    std::lock_guard<std::mutex> turn(run_mu_);
+    auto job = std::make_shared<Shares>();
+    job->fn = &fn; job->total = n_;
     {
       std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn;
-      pending_ = n_ - 1;
-      gen_++;
+      active_.push_back(job);
+      wake_seq_++;
     }
     cv_.notify_all();
-    fn(0);
-    std::unique_lock<std::mutex> lk(m_);
-    done_cv_.wait(lk, [this] { return pending_ == 0; });
-    fn_ = nullptr;
+    take_shares(*job);
+    Backoff wait;
+    while (job->done.load(std::memory_order_acquire) < job->total) wait.pause();   // (shares in hand: their holders are running)
+    std::lock_guard<std::mutex> lk(m_);
+    active_.erase(std::find(active_.begin(), active_.end(), job));
   }
 
   // Offers a job to the workers that are free and returns at once: each of them calls job->work() once, when it gets to it.  The
-  // caller works on the job itself and decides when it is complete -- it does not wait for workers that have not arrived.  (A GPU
-  // box shares its host with other tenants and bounds this process by a CPU quota, not a CPU set: one woken thread in a few hundred
-  // lands behind somebody else's time slice and starts 4-8 ms late, profiles/r04_slow_calls.txt.  With run() the whole job waits
-  // for it; here it finds the pieces gone.)  The job is kept alive by the shared_ptr until the last late worker has looked at it.
+  // caller works on the job itself and decides when it is complete.  The job is kept alive by the shared_ptr until the last late
+  // worker has looked at it.
   void offer(const std::shared_ptr<SharedJob>& job) {
     if (n_ == 1) return;
     {
       std::lock_guard<std::mutex> lk(m_);
       offer_ = job;
       offer_seq_++;
+      wake_seq_++;
     }
     cv_.notify_all();
   }
 
-  // Static block partition of [0, n) over the workers.
+  // Static block partition of [0, n) into size() consecutive blocks: body(begin, end, block number).
   void for_blocks(size_t n, const std::function<void(size_t, size_t, int)>& body) {
     run([&](int tid) {
       size_t per = (n + n_ - 1) / n_;
@@ -110,40 +114,47 @@ class WorkerPool {
   }
 
  private:
-  void loop(int tid) {
+  struct Shares {                                               // one run(): its shares are numbered 0 .. total - 1
+    const std::function<void(int)>* fn = nullptr;               // (the caller's: alive until every share has run)
+    int total = 0;
+    std::atomic<int> next{0}, done{0};
+  };
+  static void take_shares(Shares& j) {
+    for (;;) {
+      const int t = j.next.fetch_add(1, std::memory_order_relaxed);
+      if (t >= j.total) return;
+      (*j.fn)(t);
+      j.done.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void loop() {
     unsigned long seen = 0, seen_offer = 0;
     for (;;) {
-      const std::function<void(int)>* fn = nullptr;
+      std::shared_ptr<Shares> shares;
       std::shared_ptr<SharedJob> job;
       {
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return gen_ != seen || offer_seq_ != seen_offer; });
-        if (stop_) return;
-        if (gen_ == seen) {                                     // an offered job: no one waits for this worker
-          seen_offer = offer_seq_;
-          job = offer_;
-        } else {
-          seen = gen_;
-          fn = fn_;
+        for (;;) {
+          if (stop_) return;
+          for (auto& a : active_) if (a->next.load(std::memory_order_relaxed) < a->total) { shares = a; break; }
+          if (shares) break;
+          if (offer_seq_ != seen_offer) { seen_offer = offer_seq_; job = offer_; break; }
+          seen = wake_seq_;
+          cv_.wait(lk, [&] { return wake_seq_ != seen; });
         }
       }
-      if (job) { job->work(); continue; }
-      if (fn) (*fn)(tid);
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (--pending_ == 0) done_cv_.notify_one();
-      }
+      if (shares) take_shares(*shares);
+      else if (job) job->work();
     }
   }
   int n_ = 1;
   std::vector<std::thread> threads_;
-  std::mutex m_, run_mu_;
-  std::condition_variable cv_, done_cv_;
-  const std::function<void(int)>* fn_ = nullptr;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<std::shared_ptr<Shares>> active_;                 // the calls of run() under way, oldest first
   std::shared_ptr<SharedJob> offer_;
   unsigned long offer_seq_ = 0;
-  unsigned long gen_ = 0;
-  int pending_ = 0;
+  unsigned long wake_seq_ = 0;
   bool stop_ = false;
 };
 
