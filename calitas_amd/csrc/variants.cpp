@@ -926,6 +926,22 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   std::mutex order_mu;
   std::condition_variable order_cv;
   uint64_t batches_handed = 0, batches_lifting = 0;               // (batches_lifting: under order_mu)
+  std::function<int(size_t)> finish_upto_fn;                      // (finish_upto, defined below: the lifter runs it behind a contig's last batch)
+  // a contig's entries for the device are made on the lifter thread, behind the lift of the contig's last batch, while this thread is
+  // already walking the next contig (waiting for the stages to run dry at every one of 25 contig ends was 0.22 s of the variant half)
+  auto hand_over_finish = [&](size_t upto) -> int {
+    const uint64_t k = batches_handed++;
+    const bool second = two_aligners && (k & 1);
+    return (second ? aligner2 : aligner).enqueue([&, k, upto](std::string&) -> int {
+      std::unique_lock<std::mutex> lk(order_mu);
+      order_cv.wait(lk, [&] { return batches_lifting == k; });
+      const int lr = lifter.enqueue([&, upto](std::string&) { return finish_upto_fn(upto); }, 2, nullptr);
+      batches_lifting = k + 1;
+      lk.unlock();
+      order_cv.notify_all();
+      return lr;
+    }, 2, &ms_wait);
+  };
   hand_over = [&](Batch&& b, size_t n) -> int {
     auto held = std::make_shared<Batch>(std::move(b));
     const uint64_t k = batches_handed++;
@@ -978,15 +994,14 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     int r = build_and_flush();
     if (r || !err.empty()) return r;
     contigs_asked = upto;
-    // (The contig's entries made on a stage thread, behind the contig's last batch, while this thread goes on with the next contig --
-    // no waiting for the stages to run dry at each of the 25 contig ends --: measured twice.  On the one aligner thread there was at
-    // first that thread carried 1.26 s of host work one after the other (variant half 1.54 against 1.38 s); on the lifter thread, with
-    // two aligners, every section on the worker pool waits for its turn behind the others' (windows built in 0.47 instead of 0.17 s)
-    // and the variant half takes the same 1.35-1.41 s.)
-    r = drain();
-    if (r || !err.empty()) return r;
-    return finish_upto(upto);
+    // The contig's entries are made on the lifter thread, behind the lift of the contig's last batch, while this thread goes on with
+    // the next contig -- no waiting for the stages to run dry at each of the 25 contig ends.  (Measured three times: on the one aligner
+    // thread there was at first, that thread carried 1.26 s of host work one after the other, variant half 1.54 against 1.38 s; on the
+    // lifter with two aligners but a pool that let one caller in at a time, the same 1.35-1.41 s; with the pool's shares, 0.95-1.04
+    // against 1.25-1.32 s, step 1.36-1.38 against 1.60-1.62 s on one box, alternating.)
+    return hand_over_finish(upto);
   };
+  finish_upto_fn = finish_upto;
 
   const int max_variants = p.max_variants;
   size_t ci = 0, i = 0;
