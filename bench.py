@@ -677,6 +677,10 @@ def main():
             acc["scan"] += tm["scan_kernel_ms"]; acc["align"] += tm["align_kernel_ms"]; acc["post"] += tm["host_post_ms"]
             acc["gpu"] += tm["gpu_total_ms"]; acc["hitsk"] += tm["hits_kernel_ms"]; acc["copy"] += tm["hits_copy_ms"]
             last = (tm, n_alns, rows)
+        # memory the calls handed back on the library's own thread (a 22 GB text per config-5 step, the variant half's tables) is part of
+        # the step: the timed region ends when that thread has nothing left to do
+        if hasattr(C._lib.lib, "calitas_reap_wait"):
+            C._lib.lib.calitas_reap_wait()
         sync()
         dt = time.perf_counter() - t0
         if world > 1:

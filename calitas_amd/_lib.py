@@ -60,7 +60,7 @@ class TimingT(ctypes.Structure):
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
            "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases", "calitas_expand_rows",
            "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_into", "calitas_pin_host", "calitas_unpin_host", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_scan_candidates_columnwise", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants",
-           "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version", "calitas_switches"]
+           "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version", "calitas_switches", "calitas_reap_wait"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError("%s is missing: build it with `make -C calitas_amd/csrc` (hipcc, gfx950). "
@@ -71,6 +71,9 @@ lib.calitas_last_error.restype = ctypes.c_char_p
 lib.calitas_last_error.argtypes = [ctypes.c_void_p]
 lib.calitas_version.restype = ctypes.c_char_p
 lib.calitas_switches.restype = ctypes.c_char_p
+if hasattr(lib, "calitas_reap_wait"):
+    lib.calitas_reap_wait.restype = None
+    lib.calitas_reap_wait.argtypes = []
 lib.calitas_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
 lib.calitas_destroy.argtypes = [ctypes.c_void_p]
 lib.calitas_destroy.restype = None

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <ctime>
 #include <numeric>
 #include <mutex>
@@ -38,9 +40,59 @@ std::vector<BlockHeader*> g_pool;   // parked blocks
 constexpr size_t kPoolBlocks = 128;    // a batch call hands out one text buffer per guide (BASELINE config 4: 96 guides)
 constexpr uint64_t kPoolBytes = 24ull << 30;   // ... of ~180 MB each at hg38 size; page-locking a fresh one costs tens of milliseconds
 
+struct Reaper {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> jobs;
+  bool quit = false, busy = false;
+  std::thread t;
+  void wait_idle() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return jobs.empty() && !busy; });
+  }
+  void give(std::function<void()> job) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!t.joinable()) t = std::thread([this] {
+        for (;;) {
+          std::function<void()> j;
+          {
+            std::unique_lock<std::mutex> lk2(mu);
+            cv.wait(lk2, [&] { return !jobs.empty() || quit; });
+            if (jobs.empty()) return;
+            j = std::move(jobs.front());
+            jobs.pop_front();
+            busy = true;
+          }
+          j();
+          j = nullptr;
+          { std::lock_guard<std::mutex> lk2(mu); busy = false; }
+          cv.notify_all();
+        }
+      });
+      jobs.push_back(std::move(job));
+    }
+    cv.notify_all();
+  }
+  ~Reaper() {
+    if (!t.joinable()) return;
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    t.join();
+  }
+};
+Reaper g_reaper;
+
+void release_block_now(BlockHeader* h);
 void release_block(BlockHeader* h) {
   h->magic = 0;
   if (h->pinned) { (void)hipHostFree(h); return; }
+  // (a text of gigabytes: the caller's free() returns at once, the pages go back on the library's own thread -- 0.13 s per 22 GB even
+  // with sixteen threads handing them back)
+  if (h->capacity >= (1ull << 30) && !tune::get("CALITAS_FREE_NOW")) { g_reaper.give([h] { release_block_now(h); }); return; }
+  release_block_now(h);
+}
+void release_block_now(BlockHeader* h) {
   // A text of tens of gigabytes: the kernel clears pages as it takes them back (16 GB: 0.77 s inside free() on the GPU boxes, huge
   // pages or not).  MADV_DONTNEED takes the address-space lock shared, so the workers hand the pages back side by side first
   // (0.135 s, tools/thp_bench.cpp) and free() then unmaps an empty range.
@@ -119,6 +171,8 @@ void* calitas_out_grow(void* p, size_t keep, size_t size) {
   }
   return n + 1;
 }
+void calitas_reap_later(std::function<void()> job) { g_reaper.give(std::move(job)); }
+extern "C" void calitas_reap_wait(void) { g_reaper.wait_idle(); }
 void* calitas_out_alloc(size_t size) { return out_alloc_impl(size); }
 void* calitas_out_alloc_pinned(size_t size) { return out_alloc_impl(size, true); }
 static void* out_alloc(size_t size) { return out_alloc_impl(size); }

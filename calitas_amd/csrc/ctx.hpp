@@ -4,6 +4,7 @@
 
 #include <sched.h>
 
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -127,6 +128,9 @@ int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide,
                                  const char* aligner_version, const char* time_stamp, const HitsExtSource& source, char** tsv,
                                  uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined);
 int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side, int which = 0);
+// Work nobody waits for -- handing memory back -- on a thread of the library's own, in the order it was given (joined when the library
+// is unloaded).  A call that built millions of small objects, or a caller that frees a text of tens of gigabytes, returns at once.
+void calitas_reap_later(std::function<void()> job);
 int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t* guides, const char* const* guide_ids,
                                    const calitas_params_t* params, const char* aligner_version, const char* time_stamp, char** tsv,
                                    uint64_t* tsv_bytes, uint64_t* n_rows);

@@ -44,6 +44,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_ALIGN_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
   {"CALITAS_TRACE_BLOCKS", "n", "T: trace_kernel grid (default 2048)"},
   {"CALITAS_TRACE_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
+  {"CALITAS_FREE_NOW", "1", "F/T: calitas_free of a block of gigabytes hands its pages back before it returns (default: on the library's own thread)"},
   {"CALITAS_BATCH_LANES", "1..8", "T: guides in flight in calitas_search_hits_batch (default 5)"},
   {"CALITAS_COMPACT_ROWS", "0", "F/T: full rows over PCIe instead of compact rows + host expansion (batches, the leading ranges of a chunked call)"},
   {"CALITAS_COMPACT_LANES", "n", "T: how many leading ranges of a chunked call move compact rows (default: all of three or more, all but the last of two)"},

@@ -1077,7 +1077,15 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     helper.join();
     if (hr.rc == CALITAS_OK) {
       const size_t n_hits = hits.size(), n_vcf = vcf.size();
-      teardown();
+      if (tune::get("CALITAS_FREE_NOW")) teardown();
+      else {
+        // millions of small heap blocks and a few gigabytes of tables: nobody waits for them (0.17 s per call at full size even with
+        // every worker handing them back) -- they go to the library's own thread as they are
+        struct Garbage { decltype(hits) h; decltype(vcf) v; decltype(kept_windows) kw; decltype(kept_out) ko; decltype(cx) c; };
+        auto g = std::make_shared<Garbage>();
+        g->h = std::move(hits); g->v = std::move(vcf); g->kw = std::move(kept_windows); g->ko = std::move(kept_out); g->c = std::move(cx);
+        calitas_reap_later([g]() mutable { for (auto* o : g->ko) calitas_free(o); g.reset(); });
+      }
       *tsv = hr.tsv;
       if (tsv_bytes) *tsv_bytes = hr.bytes;
       if (n_rows) *n_rows = hr.rows;

@@ -171,6 +171,12 @@ int calitas_fetch_bases(const calitas_ctx* ctx, int32_t contig_index, uint64_t s
  * lives as long as the library. */
 const char* calitas_switches(void);
 
+/* calitas_free of a text of gigabytes, and the tables calitas_search_variants builds on the way (millions of small heap blocks), are
+ * handed back on a thread of the library's own: the calls return at once (CALITAS_FREE_NOW=1: before they return).  This waits until
+ * that thread has nothing left to do -- for a caller who measures, or who wants the memory back before going on.  No reference
+ * counterpart (the JVM's collector plays this part there). */
+void calitas_reap_wait(void);
+
 /* Test hook without a reference counterpart: the host half of the compact rows calitas_search_hits_batch moves over PCIe (round 4).  A
  * row of hits.txt is head | chromosome \t middle | tail with head (guide_id, unpadded_guide_sequence, genome_build) and tail (aligner ..
  * time_stamp, ReferenceHit.scala:99-132) the same for every row of a call; the device writes `chromosome \t middle \n` per row and
