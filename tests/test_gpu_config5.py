@@ -93,6 +93,12 @@ def test_config5_twentieth_both_merge_paths_same_bytes(bench_mod, tmp_path, monk
         ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized")
         dev, rows, nwin = _search_variants(C, ctx, bench_mod.GUIDE0[:20], vcf)
         assert ctx.timing()["contig_passes"] == 25
+        # the same call with its tables handed back before it returns (default: on the library's own thread, calitas_reap_wait waits)
+        monkeypatch.setenv("CALITAS_FREE_NOW", "1")
+        again, rows_a, nwin_a = _search_variants(C, ctx, bench_mod.GUIDE0[:20], vcf)
+        monkeypatch.delenv("CALITAS_FREE_NOW")
+        C._lib.lib.calitas_reap_wait()
+        assert (zlib.crc32(again), len(again), rows_a, nwin_a) == (zlib.crc32(dev), len(dev), rows, nwin)
         monkeypatch.setenv("CALITAS_VARIANTS_HOST", "1")
         host, rows_h, nwin_h = _search_variants(C, ctx, bench_mod.GUIDE0[:20], vcf)
         assert ctx.timing()["contig_passes"] == 0

@@ -334,6 +334,65 @@ def test_expand_rows_puts_head_and_tail_back():
         ctx.close()
 
 
+def test_callers_on_several_threads_share_the_worker_pool(C, tmp_path):
+    """WorkerPool::run hands numbered shares to whichever threads are free and offer() hands out a job's pieces: callers on different
+    threads run side by side on one context's pool (the variant branch does, four threads at a time).  Several threads at once: the
+    rows stage (calitas_hits_tsv: pool sections) and the row expansion (an offered job), every result as from one thread alone."""
+    import ctypes
+    import threading
+    from calitas_amd import synth, _lib
+    guide = "CTTGCCCCACAGGGCAGTAAnrg"
+    G = C.Guide(guide)
+    names, seqs = synth.make_genome([("chrA", 40000), ("chrB", 15000)], seed=8, guides=[(G.guide, G.pams[0], G.pam_is_five_prime)],
+                                    sites_per_guide=60, n_run_ends=100, n_block=1200, tandem_frac=0.05)
+    contigs = [(n, s.tobytes().decode()) for n, s in zip(names, seqs)]
+    fa = write_fasta(str(tmp_path / "p.fa"), contigs)
+    kw = dict(d=4, p=1, g=2, D=7, O=10)
+    alns = []
+    for ci, (n, sq) in enumerate(contigs):
+        alns += _oracle_alignments(C, guide, n, ci, sq, kw)
+    ctx = C.Context(-1)
+    ctx.set_reference_fasta(fa)
+    params = C.make_params(max_guide_diffs=4, max_pam_mismatches=1, max_gaps_between_guide_and_pam=2, max_total_diffs=7)
+    rng = np.random.default_rng(12)
+    head, tail = b"g\tACGT\tb\t", b"CALITAS\tv\tnrg\tparams\tstamp\n"
+    rows = [b"c\t" + b"x" * int(l) for l in rng.integers(1, 200, size=30000)]
+    compact = b"".join(r + b"\n" for r in rows)
+    want_rows = b"".join(head + r + tail for r in rows)
+    want_text, want_n = ctx.hits_tsv(G, "a", params, alns)
+    os.environ["CALITAS_EXPAND_THREADS"] = "16"
+    errors = []
+
+    def tsv_worker():
+        try:
+            for _ in range(6):
+                text, n = ctx.hits_tsv(G, "a", params, alns)
+                assert n == want_n and text == want_text
+        except Exception as e:       # noqa: BLE001  (reported by the main thread)
+            errors.append(repr(e))
+
+    def expand_worker():
+        try:
+            out = ctypes.create_string_buffer(len(want_rows) + 1)
+            written = ctypes.c_uint64()
+            for _ in range(12):
+                rc = _lib.lib.calitas_expand_rows(ctx._h, compact, len(compact), len(rows), head, tail, out, len(want_rows), ctypes.byref(written))
+                assert rc == 0 and written.value == len(want_rows) and out.raw[:len(want_rows)] == want_rows
+        except Exception as e:       # noqa: BLE001
+            errors.append(repr(e))
+
+    try:
+        threads = [threading.Thread(target=tsv_worker) for _ in range(2)] + [threading.Thread(target=expand_worker) for _ in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        del os.environ["CALITAS_EXPAND_THREADS"]
+        ctx.close()
+    assert not errors, errors
+
+
 def test_every_environment_switch_is_in_the_table():
     """calitas_switches() (calitas_amd/csrc/tuning.hpp) lists every CALITAS_* switch the library reads, and nothing else: the sources
     read them through tune::get() only (a name missing from the table stops the process), and no std::getenv of a CALITAS_ name is left."""
