@@ -625,19 +625,29 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
           return k;
         };
         for (int i = 0; i < n_ops;) { int j = i; while (j < n_ops && a.ops[j] == a.ops[i]) j++; n_cigar += put_int(cigar + n_cigar, j - i); cigar[n_cigar++] = (char)a.ops[i]; i = j; }
+        // the row is put together in place: room for the longest it can be, one pointer walking through it (sixty appends to a string,
+        // each with its capacity check, were a microsecond per row -- two seconds of the workers' time per call at full size)
         const size_t row_at = row.size();                                                           // (appends to what is there)
-        auto add = [&](const std::string& s) { row += s; row += '\t'; };
-        auto add_mem = [&](const char* m, size_t len) { row.append(m, len); row += '\t'; };
-        auto add_int = [&](long v) { char d[24]; const size_t k = put_int(d, v); row.append(d, k); row += '\t'; };
-        add(gid); add(gh.protospacer); add(vs.empty() ? ref.genome_build : build_with_variants); add(ref.names[w.contig]);
-        add_int(gstart); add_int(gend); row += (char)a.strand; row += '\t'; add_mem(unpadded_target, n_unpadded);
-        add(c5_10); add(c3_10); add(rs.pam_used[a.pam_index + 1]); add(ids); add(descs); if (vs.empty()) row += '\t'; else add(vid); add(af);
+        const std::string& build = vs.empty() ? ref.genome_build : build_with_variants;
+        const std::string& pam_used = rs.pam_used[a.pam_index + 1];
+        const size_t room = gid.size() + gh.protospacer.size() + build.size() + ref.names[w.contig].size() + n_unpadded + c5_10.size() + c3_10.size() +
+                            pam_used.size() + ids.size() + descs.size() + vid.size() + af.size() + 3 * (size_t)n_ops + c5_8.size() + c3_8.size() + n_cigar +
+                            rs.proto_len.size() + rs.tail.size() + 9 * 24 + 40;
+        row.resize(row_at + room);
+        char* wp = &row[row_at];
+        auto add = [&](const std::string& s) { std::memcpy(wp, s.data(), s.size()); wp += s.size(); *wp++ = '\t'; };
+        auto add_mem = [&](const char* m, size_t len) { std::memcpy(wp, m, len); wp += len; *wp++ = '\t'; };
+        auto add_int = [&](long v) { wp += put_int(wp, v); *wp++ = '\t'; };
+        add(gid); add(gh.protospacer); add(build); add(ref.names[w.contig]);
+        add_int(gstart); add_int(gend); *wp++ = (char)a.strand; *wp++ = '\t'; add_mem(unpadded_target, n_unpadded);
+        add(c5_10); add(c3_10); add(pam_used); add(ids); add(descs); if (vs.empty()) *wp++ = '\t'; else add(vid); add(af);
         add_int(a.score); add_int(gmm); add_int(ggp); add_int(gmm + ggp);
         add_int(ga_count(pg, pa, n_ops, true, true, true, false)); add_int(mm + gp);
         add_mem(pg, (size_t)n_ops); add_mem(pa, (size_t)n_ops); add_mem(pt, (size_t)n_ops);
         add(c5_8); add(c3_8); add_mem(cigar, n_cigar); add(rs.proto_len); add_int((long)n_unpadded);
-        row += rs.tail;                                                                             // aligner .. time_stamp + '\n'
-        if (row.size() > row_at && row.back() == '\n') row.pop_back();
+        std::memcpy(wp, rs.tail.data(), rs.tail.size()); wp += rs.tail.size();                      // aligner .. time_stamp + '\n'
+        if (wp > &row[row_at] && wp[-1] == '\n') wp--;
+        row.resize((size_t)(wp - row.data()));
   };
 
   // A built batch of windows through the aligner (device) and its alignments lifted back and listed as hits (worker pool).  Runs on the
@@ -879,7 +889,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         if (sg >= S) return;
         const size_t b = local_range[sg].first, e = local_range[sg].second;
         std::string& buf = local[sg];
-        buf.reserve((e - b) * 700);
+        buf.reserve((e - b) * 700 + 2048);                       // (+ the room make_row asks for before it knows the last row's length)
         for (size_t i = b; i < e; i++) {
           const size_t at = buf.size();
           make_row(hits[h0 + order[i]], buf);                     // (appends)
