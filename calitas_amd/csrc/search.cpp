@@ -1275,7 +1275,10 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
     calitas_ctx* c = new calitas_ctx();
     c->device = ctx->device; c->parent = ctx;
     int lane_prio = greatest;
-    if (const char* e = tune::get("CALITAS_LANE_PRIO")) if (std::strcmp(e, "low") == 0) lane_prio = least;   // experiment: the tails do not outrank the scan
+    if (const char* e = tune::get("CALITAS_LANE_PRIO")) {       // experiment: the tails do not outrank the scan ("low": none does; "low0" / "low01": the first / the first two lanes)
+      const size_t idx = ctx->lanes.size();
+      if (std::strcmp(e, "low") == 0 || (std::strcmp(e, "low0") == 0 && idx == 0) || (std::strcmp(e, "low01") == 0 && idx <= 1)) lane_prio = least;
+    }
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, lane_prio) == hipSuccess;
     for (int i = 0; i < 8; i++) ok = ok && hipEventCreateWithFlags(&c->ev[i], i < 6 ? hipEventReleaseToDevice : hipEventDefault) == hipSuccess;   // as in calitas_create
     ok = ok && hipEventCreateWithFlags(&c->scan_done, hipEventReleaseToDevice) == hipSuccess;   // timed: it also brackets the scan

@@ -38,7 +38,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_CHUNK", "64..512", "T: bases per scan lane chunk (set_reference; default by genome size)"},
   {"CALITAS_INPUTS_FIRST", "0 | 1 | 2", "T: where the ranges' small inputs are queued (default 2)"},
   {"CALITAS_LANE_SETUP", "0", "F: separate stream commands instead of the one-launch lane setup"},
-  {"CALITAS_LANE_PRIO", "low", "T: lanes' streams at low priority (experiment)"},
+  {"CALITAS_LANE_PRIO", "low | low0 | low01", "T: lanes' streams at low priority (experiment)"},
   {"CALITAS_ALIGN_LPJ", "32", "F: two jobs of 32 lanes per aligner wave even for guides of up to 20 rows"},
   {"CALITAS_ALIGN_BLOCKS", "n", "T: align_kernel grid, units of four one-wave workgroups (default 512)"},
   {"CALITAS_ALIGN_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
