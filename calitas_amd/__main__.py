@@ -62,6 +62,7 @@ def main(argv=None):
     pv.add_argument("-i", "--input", nargs="+", required=True)
     pv.add_argument("-o", "--output", required=True)
     pv.add_argument("-f", "--min-af", type=float, default=0.01)
+    pv.add_argument("-d", "--dict", help="sequence dictionary (.dict, .fai, or a FASTA with its .dict) that overrides the contig lines")
     pv.add_argument("-c", "--add-chr-prefix", type=lambda s: s.lower() in ("1", "true", "yes"), default=True)
 
     a = top.parse_args(argv)
@@ -86,7 +87,7 @@ def main(argv=None):
                                  mismatch_net_cost=a.guide_mismatch_net_cost, pam_mismatch_net_cost=a.pam_mismatch_net_cost,
                                  genome_gap_net_cost=a.genome_gap_net_cost, guide_gap_net_cost=a.guide_gap_net_cost, device=a.device)
     else:
-        prepare_vcf(a.input, a.output, min_af=a.min_af, add_chr_prefix=a.add_chr_prefix)
+        prepare_vcf(a.input, a.output, min_af=a.min_af, add_chr_prefix=a.add_chr_prefix, dict_path=a.dict)
     return 0
 
 

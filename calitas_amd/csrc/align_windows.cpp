@@ -278,7 +278,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
     t0 = t1;
     ms_post += ms_since(t_sec);
   }
-  if (tune::get("CALITAS_TRACE") && n_tasks >= 1024)
+  if (TUNE_GET("CALITAS_TRACE") && n_tasks >= 1024)
     std::fprintf(stderr, "[calitas] align_windows: %d tasks: guides %.1f ms, pack %.1f ms, records %.1f ms, alloc+upload %.1f ms, kernels+copy %.1f ms, filter %.1f ms\n",
                  n_tasks, ms_prep, ms_pack, ms_recs, ms_upload, ms_gpu, ms_post);
 

@@ -82,6 +82,10 @@ struct Reaper {
   }
 };
 Reaper g_reaper;
+// Bytes of pageable blocks whose pages are still on their way back (release_block): a caller that frees a text of tens of gigabytes
+// and asks for the next one at once would hold both for a moment -- on a box with a memory limit that is the OOM killer's cue --,
+// so a fresh block of a gigabyte or more waits for them first (out_alloc_impl).
+std::atomic<uint64_t> g_deferred_bytes{0};
 
 void release_block_now(BlockHeader* h);
 void release_block(BlockHeader* h) {
@@ -89,7 +93,12 @@ void release_block(BlockHeader* h) {
   if (h->pinned) { (void)hipHostFree(h); return; }
   // (a text of gigabytes: the caller's free() returns at once, the pages go back on the library's own thread -- 0.13 s per 22 GB even
   // with sixteen threads handing them back)
-  if (h->capacity >= (1ull << 30) && !tune::get("CALITAS_FREE_NOW")) { g_reaper.give([h] { release_block_now(h); }); return; }
+  if (h->capacity >= (1ull << 30) && !TUNE_GET("CALITAS_FREE_NOW")) {
+    const uint64_t cap = h->capacity;
+    g_deferred_bytes += cap;
+    g_reaper.give([h, cap] { release_block_now(h); g_deferred_bytes -= cap; });
+    return;
+  }
   release_block_now(h);
 }
 void release_block_now(BlockHeader* h) {
@@ -122,7 +131,8 @@ void* out_alloc_impl(size_t size, bool pinned = false) {
     if (best >= 0) { BlockHeader* h = g_pool[best]; g_pool.erase(g_pool.begin() + best); return h + 1; }
   }
   size_t cap = size + size / 8;
-  if (size >= (1u << 20) && tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] out_alloc: fresh %s block of %zu bytes\n", pinned ? "pinned" : "pageable", cap);
+  if (!pinned && size >= (1ull << 30) && g_deferred_bytes.load() != 0) g_reaper.wait_idle();   // (see g_deferred_bytes)
+  if (size >= (1u << 20) && TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] out_alloc: fresh %s block of %zu bytes\n", pinned ? "pinned" : "pageable", cap);
   BlockHeader* h = nullptr;
   if (pinned) {
     if (hipHostMalloc((void**)&h, sizeof(BlockHeader) + cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; pinned = false; }
@@ -296,7 +306,7 @@ static int upload_reference_device(calitas_ctx* ctx) {
   free_reference_device(ctx);
   const PackedRef& r = ctx->ref;
   size_t nruns = std::max<size_t>(1, r.runs.size());
-  if (const char* e = tune::get("CALITAS_DEVICE_BUDGET_MB")) {   // the budget a caller sharing the card sets covers the reference too
+  if (const char* e = TUNE_GET("CALITAS_DEVICE_BUDGET_MB")) {   // the budget a caller sharing the card sets covers the reference too
     const uint64_t want = (uint64_t)r.codes.size() * 8 + (uint64_t)r.mask.size() * 4 + nruns * sizeof(Run) + r.tiles.size() * sizeof(TileInfo);
     if (want > (uint64_t)std::atoll(e) << 20)
       return fail(ctx, CALITAS_ENOMEM, "the packed reference (" + std::to_string(want >> 20) + " MB on the device) exceeds CALITAS_DEVICE_BUDGET_MB");

@@ -71,7 +71,7 @@ struct BinArgs {
   uint32_t* rows_list;               // bins with rows, in no particular order (one append per wave)
   uint32_t* rows_count;              // (zero at launch)
   unsigned long long* stamps;        // [0] align_kernel's start (written there), [1] bin_hits_small_kernel's: the device's wall clock
-  uint32_t dbg;                      // timing experiments (CALITAS_BINNED_SKIP)
+  uint32_t dbg;                      // timing experiments (CALITAS_BINNED_SKIP; always 0 unless built with -DCALITAS_EXPERIMENTS)
 };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -781,7 +781,7 @@ hipError_t binned_prepare_host(BinnedWork** pw, uint32_t n_bins, void** clear, s
   w.bin_count = w.flags + 3;
   w.n_bins = n_bins; w.n_chunks = n_chunks; w.n_supers = n_supers;
   unsigned long long host_want = BIN_HOST_TEXT;
-  if (const char* env = tune::get("CALITAS_BINNED_HOST_TEXT_KB")) host_want = (unsigned long long)std::max(0, std::atoi(env)) << 10;   // (experiments)
+  if (const char* env = TUNE_GET("CALITAS_BINNED_HOST_TEXT_KB")) host_want = (unsigned long long)std::max(0, std::atoi(env)) << 10;   // (experiments)
   if (w.host_text && w.host_alloc < host_want) { (void)hipHostFree(w.host_text); w.host_text = nullptr; }
   if (!w.host_text && host_want) {
     if (hipHostMalloc((void**)&w.host_text, host_want, hipHostMallocDefault) != hipSuccess) {   // (coherent: the device writes through)
@@ -798,8 +798,8 @@ hipError_t binned_prepare_host(BinnedWork** pw, uint32_t n_bins, void** clear, s
     w.stamp_khz = khz;
   }
   // (tests: CALITAS_BINNED_TEXT_KB forces the regrow path of the device buffer, CALITAS_BINNED_HOST_TEXT=0 the copy for every text)
-  if (tune::get("CALITAS_BINNED_TEXT_KB")) w.host_cap = 0;
-  if (const char* env = tune::get("CALITAS_BINNED_HOST_TEXT")) w.host_cap = std::atoi(env) != 0 ? host_want : 0;
+  if (TUNE_GET("CALITAS_BINNED_TEXT_KB")) w.host_cap = 0;
+  if (const char* env = TUNE_GET("CALITAS_BINNED_HOST_TEXT")) w.host_cap = std::atoi(env) != 0 ? host_want : 0;
   *clear = w.clear; *clear_bytes = bytes;
   return hipSuccess;
 }
@@ -853,7 +853,7 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
   hipError_t e;
   {
     size_t first_guess = (size_t)32 << 20;                     // BIN_FLAG_TEXT asks for more
-    if (const char* env = tune::get("CALITAS_BINNED_TEXT_KB")) first_guess = (size_t)std::max(1, std::atoi(env)) << 10;   // tests: force the regrow path
+    if (const char* env = TUNE_GET("CALITAS_BINNED_TEXT_KB")) first_guess = (size_t)std::max(1, std::atoi(env)) << 10;   // tests: force the regrow path
     if (hw.text_cap < first_guess) TRY(grow(&hw.text, hw.text_cap, first_guess));
   }
   BinArgs ba; MidArgs ma;
@@ -864,7 +864,7 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
       !hw.text || w.n_bins < geo.n_bins)
     return hipErrorInvalidValue;
   SmallArgs sa{w.complex_list, w.complex_count, 0u};
-  if (const char* env = tune::get("CALITAS_BINNED_COMPLEX")) sa.force_complex = std::atoi(env) != 0;   // tests: the wave-per-bin kernel for every bin
+  if (const char* env = TUNE_GET("CALITAS_BINNED_COMPLEX")) sa.force_complex = std::atoi(env) != 0;   // tests: the wave-per-bin kernel for every bin
   if (!sa.complex_list || !sa.complex_count) return hipErrorInvalidValue;
   // (the listed bins inside the lane kernel -- its waves doing the bins their lanes left over, one launch less -- measured slower at
   // every size: 0.176 against 0.165 ms for an E. coli-sized call, 0.685 against 0.588 ms for an eighth of the hg38-sized genome: the
@@ -875,7 +875,9 @@ hipError_t binned_run(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo,
   // the listed bins: a fixed grid that strides over the list (its length is on the device)
   const unsigned grid = std::min<uint32_t>(std::max<uint32_t>(geo.n_bins, 1u), 1024u);
   int skip = 0;                                            // timing experiments only (the text is wrong): 1 = no wave-per-bin kernel, 2 = rows kernel posts and returns
-  if (const char* env = tune::get("CALITAS_BINNED_SKIP")) skip = std::atoi(env);
+#ifdef CALITAS_EXPERIMENTS
+  if (const char* env = TUNE_GET("CALITAS_BINNED_SKIP")) skip = std::atoi(env);
+#endif
   ba.dbg = (skip & 2) ? 2u : 0u;
   if (!(skip & 1))
     hipExtLaunchKernelGGL(bin_hits_kernel, dim3(grid), dim3(64), 0, stream, nullptr, ev_hits_done, 0, ba, ma, (const uint32_t*)w.complex_list,
@@ -892,7 +894,9 @@ hipError_t binned_rows(BinnedWork* pw, HitsWork** phw, const BinnedGeometry& geo
   BinArgs ba; MidArgs ma;
   fill_args(*pw, **phw, geo, ref, d_raw, d_guides, d_win_base, d_win, p, ba, ma);
   int skip = 0;
-  if (const char* env = tune::get("CALITAS_BINNED_SKIP")) skip = std::atoi(env);
+#ifdef CALITAS_EXPERIMENTS
+  if (const char* env = TUNE_GET("CALITAS_BINNED_SKIP")) skip = std::atoi(env);
+#endif
   ba.dbg = (skip & 2) ? 2u : 0u;
   return launch_rows(*pw, **phw, ba, ma, d_counters, stream, post, nullptr, ev_rows_done, host_dst, host_dst_cap);
 }

@@ -882,7 +882,7 @@ hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t strea
   const dim3 grid(n_blocks * 4), block(64);                  // one wave per workgroup
   // three jobs per wave when no guide has more than 20 rows (max_guide_len 0: unknown)
   bool three = a.max_guide_len > 0 && a.max_guide_len <= 20;
-  if (const char* env = tune::get("CALITAS_ALIGN_LPJ")) three = three && std::atoi(env) == 21;   // (tests / measurements: 32 forces two jobs)
+  if (const char* env = TUNE_GET("CALITAS_ALIGN_LPJ")) three = three && std::atoi(env) == 21;   // (tests / measurements: 32 forces two jobs)
   if (a.sp.per_matrix) {
     if (three) hipLaunchKernelGGL((align_kernel<true, 21>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((align_kernel<true, 32>), grid, block, 0, stream, a);

@@ -42,6 +42,7 @@ struct Backoff {
 struct SharedJob {
   virtual ~SharedJob() {}
   virtual void work() = 0;
+  virtual bool exhausted() const { return false; }              // nothing left to take: the pool forgets the job
 };
 
 class WorkerPool {
@@ -86,13 +87,16 @@ class WorkerPool {
 
   // Offers a job to the workers that are free and returns at once: each of them calls job->work() once, when it gets to it.  The
   // caller works on the job itself and decides when it is complete.  The job is kept alive by the shared_ptr until the last late
-  // worker has looked at it.
+  // worker has looked at it.  Several offers can be live at once (the lanes of a chunked or batch call expand their texts side by
+  // side): every worker visits each of them once, oldest first; an offer is forgotten when it says it is exhausted, and the oldest
+  // one when more than kMaxOffers are live (its caller finishes it alone, as it would with no worker free).
   void offer(const std::shared_ptr<SharedJob>& job) {
     if (n_ == 1) return;
     {
       std::lock_guard<std::mutex> lk(m_);
-      offer_ = job;
-      offer_seq_++;
+      offers_.erase(std::remove_if(offers_.begin(), offers_.end(), [](const Offer& o) { return o.job->exhausted(); }), offers_.end());
+      if (offers_.size() >= kMaxOffers) offers_.erase(offers_.begin());
+      offers_.push_back(Offer{++offer_seq_, job});
       wake_seq_++;
     }
     cv_.notify_all();
@@ -108,7 +112,7 @@ class WorkerPool {
   }
 
   static int default_threads() {
-    if (const char* e = tune::get("CALITAS_THREADS")) { int v = std::atoi(e); if (v > 0) return std::min(v, 256); }
+    if (const char* e = TUNE_GET("CALITAS_THREADS")) { int v = std::atoi(e); if (v > 0) return std::min(v, 256); }
     unsigned hc = std::thread::hardware_concurrency();
     return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));  // the GPU boxes give one GPU a 16-core share
   }
@@ -138,7 +142,12 @@ class WorkerPool {
           if (stop_) return;
           for (auto& a : active_) if (a->next.load(std::memory_order_relaxed) < a->total) { shares = a; break; }
           if (shares) break;
-          if (offer_seq_ != seen_offer) { seen_offer = offer_seq_; job = offer_; break; }
+          for (auto it = offers_.begin(); it != offers_.end();) {
+            if (it->job->exhausted()) { it = offers_.erase(it); continue; }
+            if (it->seq > seen_offer) { seen_offer = it->seq; job = it->job; break; }
+            ++it;
+          }
+          if (job) break;
           seen = wake_seq_;
           cv_.wait(lk, [&] { return wake_seq_ != seen; });
         }
@@ -152,7 +161,9 @@ class WorkerPool {
   std::mutex m_;
   std::condition_variable cv_;
   std::vector<std::shared_ptr<Shares>> active_;                 // the calls of run() under way, oldest first
-  std::shared_ptr<SharedJob> offer_;
+  struct Offer { unsigned long seq; std::shared_ptr<SharedJob> job; };
+  static constexpr size_t kMaxOffers = 16;
+  std::vector<Offer> offers_;                                   // the live offers, oldest first
   unsigned long offer_seq_ = 0;
   unsigned long wake_seq_ = 0;
   bool stop_ = false;

@@ -382,6 +382,7 @@ struct RowExpansion : SharedJob {
     }
   }
 
+  bool exhausted() const override { return next.load(std::memory_order_relaxed) >= P || joined.load(std::memory_order_relaxed) >= limit; }
   void work() override {
     if (joined.fetch_add(1, std::memory_order_relaxed) >= limit) return;
     for (;;) {
@@ -431,7 +432,7 @@ std::shared_ptr<RowExpansion> expand_rows_begin(const char* compact, size_t n, u
   // All workers (CALITAS_EXPAND_THREADS for experiments): 34.8 MB of rows in 3.8 / 2.0 / 1.0 / 0.55 / 0.35 ms on 1 / 2 / 4 / 8 / 16
   // of an MI355X box's cores (tools/expand_speed.py); a text below 1 MB is not worth the wake-ups.
   size_t T = pool && n >= (1u << 20) ? (size_t)pool->size() : 1;
-  if (const char* e = tune::get("CALITAS_EXPAND_THREADS"))    // (also for short texts: the tests run the job's hand-overs on small genomes)
+  if (const char* e = TUNE_GET("CALITAS_EXPAND_THREADS"))    // (also for short texts: the tests run the job's hand-overs on small genomes)
     T = std::max<size_t>(1, std::min<size_t>(pool ? (size_t)pool->size() : 1, (size_t)std::atoi(e)));
   job->limit = T;
   job->P = (n + RowExpansion::PIECE - 1) / RowExpansion::PIECE;
@@ -554,7 +555,7 @@ char* hits_tsv(const PackedRef& ref, const GuideHost& g, const std::string& guid
                void* ext_user) {
   WorkerPool serial(1);
   if (!pool) pool = &serial;
-  const bool trace = tune::get("CALITAS_TRACE") != nullptr;
+  const bool trace = TUNE_GET("CALITAS_TRACE") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_start = tnow();
   auto by_hit_order = [](const Lite& x, const Lite& y) {   // RH:284

@@ -36,7 +36,7 @@ int pick_chunk(uint64_t total_bases) {
   // (17-word chains) scan_rows_kernel holds three waves per SIMD, at 256 (9 words, 89 VGPRs) five, which more than pays for the
   // 6 % of extra warm-up (1.286 against 1.314 ms per hg38 pass; CALITAS_CHUNK=512 still selects the longer lane).
   int chunk = 256;
-  if (const char* e = tune::get("CALITAS_CHUNK")) { int v = std::atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) return v; }
+  if (const char* e = TUNE_GET("CALITAS_CHUNK")) { int v = std::atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) return v; }
   while (chunk > 64 && total_bases / ((uint64_t)chunk * LANES_PER_TILE) < 2048) chunk >>= 1;
   return chunk;
 }

@@ -27,7 +27,7 @@ struct HostMarks {
   std::chrono::steady_clock::time_point t0;
   std::string line;
   void start() { start_at(std::chrono::steady_clock::now()); }
-  void start_at(std::chrono::steady_clock::time_point t) { const char* e = tune::get("CALITAS_TRACE"); on = e && std::atoi(e) >= 2; line.clear(); t0 = t; }
+  void start_at(std::chrono::steady_clock::time_point t) { const char* e = TUNE_GET("CALITAS_TRACE"); on = e && std::atoi(e) >= 2; line.clear(); t0 = t; }
   void mark(const char* what) {
     if (!on) return;
     char b[64];
@@ -86,7 +86,7 @@ std::string build_guide_dev(const GuideHost& gh, const calitas_params_t& p, cons
 
 int ensure_buffers(calitas_ctx* ctx, uint32_t rec_cap, uint32_t raw_cap, uint64_t slab_per_rec, uint32_t item_cap) {
   rec_cap = std::max(rec_cap, ctx->rec_cap);
-  if (const char* e = tune::get("CALITAS_DEVICE_BUDGET_MB")) {   // refuse instead of trying: what a caller sharing the card can set
+  if (const char* e = TUNE_GET("CALITAS_DEVICE_BUDGET_MB")) {   // refuse instead of trying: what a caller sharing the card can set
     const uint64_t want = (uint64_t)rec_cap * slab_per_rec + (uint64_t)rec_cap * sizeof(ScanRecord) +
                           (uint64_t)std::max(raw_cap, ctx->raw_cap) * sizeof(RawAln) + (uint64_t)std::max(item_cap, ctx->item_cap) * sizeof(uint64_t);
     if (want > (uint64_t)std::atoll(e) << 20)
@@ -400,9 +400,9 @@ static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
 // trace_kernel's grid makes no difference between 512 and 2048 (256 costs 0.3 ms at full size).
 // CALITAS_ALIGN_BLOCKS / CALITAS_TRACE_BLOCKS (and ..._NARROW for the ranges whose tail runs beside the next range's scan) override.
 constexpr int kAlignBlocks = 512, kTraceBlocks = 2048;
-static int narrow_blocks(const char* env, int wide, int narrow) {
-  if (const char* e = tune::get(env)) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) return v; }
-  return narrow;
+static int narrow_blocks(const char* e, int fallback) {   // e = the switch's value (TUNE_GET), or null
+  if (e) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) return v; }
+  return fallback;
 }
 
 // calitas_search; with dev != nullptr the accepted alignments stay on the device when the device filter handled them
@@ -431,7 +431,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
   tm.packed_bytes = (tm.bases_scanned + 3) / 4;
   uint32_t n_rec = 0, n_raw = 0;
   const calitas_ctx* own = ref_owner(ctx);
-  const bool device_filter = !tune::get("CALITAS_HOST_FILTER") && select_supported(pl.win_n, p.window_size, n_guides);
+  const bool device_filter = !TUNE_GET("CALITAS_HOST_FILTER") && select_supported(pl.win_n, p.window_size, n_guides);
   // A small reference usually yields few alignments: the one-workgroup filter is queued right behind trace_kernel and reads the counts
   // on the device, so the host hears about the counters and the filter's result in one round trip (select_run_speculative).
   const bool speculate = !prelaunched && !resume && device_filter && pl.bases <= (64ull << 20);
@@ -447,10 +447,10 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     ScanArgs sa; AlignArgs aa;
     fill_kernel_args(ctx, pl, sa, aa);
-    HIP_TRY(ctx, launch_align(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_ALIGN_BLOCKS_NARROW" : "CALITAS_ALIGN_BLOCKS", kAlignBlocks, kAlignBlocks), ctx->stream));
+    HIP_TRY(ctx, launch_align(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_ALIGN_BLOCKS_NARROW") : TUNE_GET("CALITAS_ALIGN_BLOCKS"), kAlignBlocks), ctx->stream));
     // (trace_kernel can post the counters itself from its last workgroup -- launch_trace's `post` -- but finding the last of 2048
     // workgroups is 2048 atomics on one word, ~8 ns each: 20-30 us against the ~10 us of this launch)
-    HIP_TRY(ctx, launch_trace(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_TRACE_BLOCKS_NARROW" : "CALITAS_TRACE_BLOCKS", kTraceBlocks, kTraceBlocks), ctx->stream, ctx->ev[2]));
+    HIP_TRY(ctx, launch_trace(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_TRACE_BLOCKS_NARROW") : TUNE_GET("CALITAS_TRACE_BLOCKS"), kTraceBlocks), ctx->stream, ctx->ev[2]));
     if (speculate) {
       HIP_TRY(ctx, select_run_speculative(&ctx->select, ctx->d_raw, ctx->d_counters, ctx->rec_cap, ctx->raw_cap, ctx->item_cap, ctx->d_guides,
                                           own->d_win_base, own->d_win, pl.win_lo, pl.win_n, max_total, p.max_overlap, ctx->stream, &d_spec, &ctx->mbox));
@@ -549,7 +549,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     if (rc) return rc;
     tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing = tm;
-    if (tune::get("CALITAS_TRACE"))
+    if (TUNE_GET("CALITAS_TRACE"))
       std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms (incl. sort+filter on the GPU), copy+convert %.3f ms, call %.3f ms (%u records, %u raw, %u accepted)\n",
                    tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_sel);
@@ -639,12 +639,12 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     });
   }
   tm.host_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (tune::get("CALITAS_TRACE")) {
+  if (TUNE_GET("CALITAS_TRACE")) {
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::fprintf(stderr, "[calitas] host filter: bucket %.2f ms, sort+convert+filter %.2f ms, concat %.2f ms (%zu buckets)\n",
                  ms(t0, t_bucketed), ms(t_bucketed, t_filtered), ms(t_filtered, std::chrono::steady_clock::now()), n_buckets);
   }
-  if (tune::get("CALITAS_TRACE"))
+  if (TUNE_GET("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search: scan %.3f ms, align %.3f ms, gpu total %.3f ms, host filter %.3f ms, call %.3f ms (%u records, %u raw, %zu accepted)\n",
                  tm.scan_kernel_ms, tm.align_kernel_ms, tm.gpu_total_ms, tm.host_post_ms,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), n_rec, n_raw, n_result);
@@ -731,7 +731,7 @@ static void dma_open_once(calitas_ctx* owner) {
   if (owner->dma_tried) return;
   std::lock_guard<std::mutex> lk(owner->host_mu);
   if (!owner->dma_tried) {
-    const char* e = tune::get("CALITAS_SDMA");
+    const char* e = TUNE_GET("CALITAS_SDMA");
     if (!(e && std::atoi(e) == 0)) owner->dma.open(owner->device);
     owner->dma_tried = true;
   }
@@ -761,7 +761,7 @@ static int text_to_host(calitas_ctx* owner, calitas_ctx* lane, char* dst, const 
       if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       return CALITAS_OK;
     }
-    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using hipMemcpyAsync\n", DmaCopier::last_reason());
+    if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using hipMemcpyAsync\n", DmaCopier::last_reason());
   }
   // a stream of its own for the copy whenever other work may be queued behind the rows on the lane's stream: the lanes of a chunked /
   // batch call, and the per-contig passes (rows_done given: the helper thread queues the next contig's kernels on ctx->stream)
@@ -820,7 +820,7 @@ static int compact_rows_to_host(calitas_ctx* owner, calitas_ctx* lane, LaneText&
   dma_open_once(owner);
   // (pieces of a sixth of the text, 256 KB to 2 MB -- less left to do behind the last piece of a short text: 2.028 against 2.001 ms)
   size_t piece = 2u << 20;
-  if (const char* e = tune::get("CALITAS_COMPACT_PIECE_KB")) piece = (size_t)std::max(64, std::atoi(e)) << 10;
+  if (const char* e = TUNE_GET("CALITAS_COMPACT_PIECE_KB")) piece = (size_t)std::max(64, std::atoi(e)) << 10;
   const bool in_host_text = lane->binned_late_check && lt.d_text == binned_host_text(lane->binned);
   auto whole = [&]() -> int {
     int r = text_to_host(owner, lane, staging, lt.d_text, nbytes, copy_mu, &lt.tm.hits_copy_ms);
@@ -837,7 +837,7 @@ static int compact_rows_to_host(calitas_ctx* owner, calitas_ctx* lane, LaneText&
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<unsigned long long> tickets;
   if (!owner->dma.start_pieces(staging, lt.d_text, nbytes, piece, tickets)) {
-    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using hipMemcpyAsync\n", DmaCopier::last_reason());
+    if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using hipMemcpyAsync\n", DmaCopier::last_reason());
     return whole();
   }
   auto job = expand_rows_begin(staging, nbytes, lt.rows, head, tail, dst, owner->pool);   // the workers wake while the first piece is on the bus
@@ -888,7 +888,7 @@ static bool binned_possible(calitas_ctx* lane, const SearchPlan& pl) {
   const calitas_ctx* own = ref_owner(lane);
   if (!pl.bin_shift || pl.n_bins == 0 || pl.n_guides != 1 || pl.rec_hint != 0 || pl.general_tail) return false;
   if (!pl.owned && (pl.gw_lo != 0 || pl.gw_hi != ~0ull)) return false;   // (a window range of calitas_search: alignment records, no rows)
-  if (tune::get("CALITAS_HOST_FILTER") || tune::get("CALITAS_HOST_HITS")) return false;
+  if (TUNE_GET("CALITAS_HOST_FILTER") || TUNE_GET("CALITAS_HOST_HITS")) return false;
   // Which tail by default: the per-bin kernels wherever a call is one pass or two ranges (references up to 2 Gb: a rank's share of a
   // genome on 2-8 GPUs, a bacterial genome) -- 0.58 against 0.62 ms for an eighth of the hg38-sized genome, 0.164 against 0.190 ms for
   // an E. coli-sized one.  A call cut into three ranges (the whole hg38-sized genome on one GPU) is bound by its scans, and those
@@ -897,7 +897,7 @@ static bool binned_possible(calitas_ctx* lane, const SearchPlan& pl) {
   // since the leading ranges' rows cross PCIe compact (round 4) it ends the call: per-bin there, 2.15 / 2.23 / 2.17 against
   // 2.18 / 2.26 / 2.29 ms (three boxes, tools/sweep_env.py CALITAS_BINNED - last).  CALITAS_BINNED=1 / 0 / last force a choice.
   bool want = !pl.three_ranges || pl.owned || pl.last_range;   // (a stretch that cuts a contig: only the bins can own it)
-  if (const char* e = tune::get("CALITAS_BINNED")) {
+  if (const char* e = TUNE_GET("CALITAS_BINNED")) {
     if (std::strcmp(e, "last") == 0) want = !pl.narrow_tail;
     else want = std::atoi(e) != 0;
   }
@@ -923,7 +923,7 @@ static hipError_t queue_row_constants(calitas_ctx* lane, const SearchPlan& pl, c
 static int queue_lane_setup(calitas_ctx* lane, const SearchPlan& pl, const RowStrings* rs, hipStream_t stream, bool* done, bool with_scan_inputs = true) {
   *done = false;
   if (pl.n_guides != 1) return CALITAS_OK;
-  if (const char* e = tune::get("CALITAS_LANE_SETUP")) if (std::atoi(e) == 0) return CALITAS_OK;
+  if (const char* e = TUNE_GET("CALITAS_LANE_SETUP")) if (std::atoi(e) == 0) return CALITAS_OK;
   LaneSetupArgs a{};
   if (rs) {
     HitsSetup hs{};
@@ -982,7 +982,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   bool own_general = false;
   if (pl.owned && !binned_possible(lane, pl)) return kOwnedDeclined;   // (no bins for this window size / forced off: the caller's whole-contig path)
   if (pl.owned && binned_remembered(lane, pl)) {                        // this guide crowded a bin here before: the general kernels at once
-    if (tune::get("CALITAS_OWN_GENERAL_OFF")) return kOwnedDeclined;
+    if (TUNE_GET("CALITAS_OWN_GENERAL_OFF")) return kOwnedDeclined;
     own_general = true;
   } else if (binned_wanted(lane, pl)) {
     bool declined = false;
@@ -990,14 +990,14 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
     int rc = lane_rows_binned(lane, pl, prelaunched, rs, lt, hits_prepared, &declined, dest, &why);
     if (rc || !declined) return rc;
     if (pl.owned) {
-      if (why != BIN_FLAG_CROWDED || tune::get("CALITAS_OWN_GENERAL_OFF")) return kOwnedDeclined;
+      if (why != BIN_FLAG_CROWDED || TUNE_GET("CALITAS_OWN_GENERAL_OFF")) return kOwnedDeclined;
       own_general = true;
     }
     // the bins declined: the raw alignments are where the general kernels expect them, the lane's counters in h_counters
     resume = true;
     hits_prepared = false;                                   // binned_run consumed the row constants
   }
-  if (!hits_prepared && !tune::get("CALITAS_HOST_HITS")) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // ahead of the lane's kernels
+  if (!hits_prepared && !TUNE_GET("CALITAS_HOST_HITS")) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // ahead of the lane's kernels
   int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched, resume);
   if (rc) return rc;
   lt.tm = lane->timing;
@@ -1007,8 +1007,8 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   if (ext && !dev.valid && n_alns == 0) {   // nothing of the reference's own on this contig: the row stage still places the caller's hits
     dev.valid = true; dev.d_final = nullptr; dev.n_sel = 0; dev.crowded = true;
   }
-  if (ext && (!dev.valid || tune::get("CALITAS_HOST_HITS"))) { calitas_free(alns); return kExtDeclined; }
-  if (dev.valid && !tune::get("CALITAS_HOST_HITS")) {
+  if (ext && (!dev.valid || TUNE_GET("CALITAS_HOST_HITS"))) { calitas_free(alns); return kExtDeclined; }
+  if (dev.valid && !TUNE_GET("CALITAS_HOST_HITS")) {
     // removeOverlaps, ReferenceHit.sort and the rows on the device (hits.hip); only text crosses PCIe
     int max_pam = 0;
     for (auto& q : gh.pams) max_pam = std::max<int>(max_pam, (int)q.size());
@@ -1052,7 +1052,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
         return CALITAS_OK;
       }
       if (own_general) return kOwnedDeclined;
-      if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
+      if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: device rows declined (flags %u), finishing on the host\n", res.flags);
     }
     if (ext) return kExtDeclined;       // (a contig without hits of the caller's needs no merge: any tail writes its text)
   }
@@ -1118,9 +1118,9 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(lane, pl, sa, aa);
   binned_fill_align_args(lane->binned, geo, aa);
-  HIP_TRY(lane, launch_align(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_ALIGN_BLOCKS_NARROW" : "CALITAS_ALIGN_BLOCKS", kAlignBlocks, kAlignBlocks), lane->stream));
+  HIP_TRY(lane, launch_align(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_ALIGN_BLOCKS_NARROW") : TUNE_GET("CALITAS_ALIGN_BLOCKS"), kAlignBlocks), lane->stream));
   // (no events on these dispatches: each would hold back the kernel behind it by ~5 us; the kernels stamp the device's wall clock instead)
-  HIP_TRY(lane, launch_trace(aa, narrow_blocks(pl.narrow_tail ? "CALITAS_TRACE_BLOCKS_NARROW" : "CALITAS_TRACE_BLOCKS", kTraceBlocks, kTraceBlocks), lane->stream, nullptr));
+  HIP_TRY(lane, launch_trace(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_TRACE_BLOCKS_NARROW") : TUNE_GET("CALITAS_TRACE_BLOCKS"), kTraceBlocks), lane->stream, nullptr));
   HIP_TRY(lane, binned_run(lane->binned, &lane->hits, geo, hr, lane->d_raw, lane->d_guides, own->d_win_base, own->d_win, bp, lane->d_counters, lane->stream,
                            &lane->mbox, nullptr, nullptr, lane->ev[5], dest == nullptr));
   char* host_dst = nullptr;
@@ -1146,7 +1146,7 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
     if (!overflow) {   // a property of this search on this reference: remember it
       own->bin_decl_L = pl.gd[0].L; own->bin_decl_pams = pl.gd[0].n_pams; own->bin_decl_min_score = pl.gd[0].min_guide_score;
       own->bin_decl_guide = guide_hash(pl.gd[0]);
-      if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] binned tail declined (flags %u): finishing on the general kernels\n", flags);
+      if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] binned tail declined (flags %u): finishing on the general kernels\n", flags);
     }
     HIP_TRY(lane, calitas_spin_sync(lane->stream));          // the rows kernel returns at once; nothing of it may linger over the retry
     *declined = true;
@@ -1165,7 +1165,7 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   tm.bases_scanned = pl.bases; tm.packed_bytes = (pl.bases + 3) / 4;
   tm.scan_records = n_rec; tm.raw_alignments = n_raw; tm.candidate_columns = lane->h_counters[4];
   tm.accepted_alignments = lane->mbox.host[BIN_BOX_ACCEPTED];
-  if (tune::get("CALITAS_TRACE"))
+  if (TUNE_GET("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] binned tail: %u bins, %u of them by a whole wave, %u rows, %llu bytes\n", pl.n_bins, (unsigned)lane->mbox.host[BIN_BOX_COMPLEX],
                  (unsigned)lane->mbox.host[BIN_BOX_ROWS], (unsigned long long)bytes);
   {                                                          // scan: its events; the kernels behind it: their stamps
@@ -1275,7 +1275,7 @@ static int ensure_lanes(calitas_ctx* ctx, size_t k) {
     calitas_ctx* c = new calitas_ctx();
     c->device = ctx->device; c->parent = ctx;
     int lane_prio = greatest;
-    if (const char* e = tune::get("CALITAS_LANE_PRIO")) {       // experiment: the tails do not outrank the scan ("low": none does; "low0" / "low01": the first / the first two lanes)
+    if (const char* e = TUNE_GET("CALITAS_LANE_PRIO")) {       // experiment: the tails do not outrank the scan ("low": none does; "low0" / "low01": the first / the first two lanes)
       const size_t idx = ctx->lanes.size();
       if (std::strcmp(e, "low") == 0 || (std::strcmp(e, "low0") == 0 && idx == 0) || (std::strcmp(e, "low01") == 0 && idx <= 1)) lane_prio = least;
     }
@@ -1555,7 +1555,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1; tm.contig_passes = n_passes;
   ctx->timing = tm;
   ctx->last_text_bytes = total;
-  if (tune::get("CALITAS_TRACE"))
+  if (TUNE_GET("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search_hits: one pass per contig (%d), scan %.3f ms, align %.3f ms, all device stages incl. allocation %.3f ms, text copy %.3f ms (sums), call %.3f ms (%llu rows, %zu bytes)\n",
                  n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, ms_rows, tm.hits_copy_ms,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), (unsigned long long)rows, total);
@@ -1574,7 +1574,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
 // Whether this search is known not to fit one pass: forced (CALITAS_SEQUENTIAL, tests), or at least as permissive as the last one on
 // this context that did not.  remember = true records the search as such.
 static bool known_not_to_fit(calitas_ctx* ctx, const calitas_guide_t* guide, const calitas_params_t* params, bool remember) {
-  if (!remember && tune::get("CALITAS_SEQUENTIAL")) return true;
+  if (!remember && TUNE_GET("CALITAS_SEQUENTIAL")) return true;
   SearchPlan pl;
   if (!guide || !params || plan_search(ctx, 1, guide, params, pl) != CALITAS_OK) return false;
   const GuideDev& g = pl.gd[0];
@@ -1619,7 +1619,7 @@ static bool predicted_not_to_fit(calitas_ctx* ctx, const calitas_guide_t* guide,
   const GuideDev& g = pl.gd[0];
   if (ctx->fit_pams == g.n_pams && ctx->fit_L == g.L && g.min_guide_score >= ctx->fit_min_score) return false;
   uint64_t limit = 0;
-  if (const char* e = tune::get("CALITAS_DEVICE_BUDGET_MB")) limit = (uint64_t)std::atoll(e) << 20;
+  if (const char* e = TUNE_GET("CALITAS_DEVICE_BUDGET_MB")) limit = (uint64_t)std::atoll(e) << 20;
   else {
     size_t mem_free = 0, mem_total = 0;
     if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return false;
@@ -1634,7 +1634,7 @@ static bool predicted_not_to_fit(calitas_ctx* ctx, const calitas_guide_t* guide,
   uint64_t live = 0;
   if (estimate_scan_records(ctx, pl, &per_tile, &live) != CALITAS_OK) return false;
   const double n_rec = per_tile * (double)live;
-  if (tune::get("CALITAS_TRACE"))
+  if (TUNE_GET("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search_hits: about %.3g scan records expected (%.1f per tile), %.1f GB of scratch for one pass, limit %.1f GB\n",
                  n_rec, per_tile, n_rec * (double)per_rec / 1e9, (double)limit / 1e9);
   if (n_rec * (double)per_rec <= (double)limit) return false;
@@ -1652,7 +1652,7 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
   if (!known_not_to_fit(ctx, guide, params, false) && !predicted_not_to_fit(ctx, guide, params)) {
     rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows);
     if (rc != CALITAS_ENOMEM) return rc;
-    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
+    if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
     release_scratch(ctx);
     (void)known_not_to_fit(ctx, guide, params, true);
   }
@@ -1706,7 +1706,7 @@ int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* gui
       return CALITAS_OK;
     }
     if (rc != CALITAS_ENOMEM) return rc;
-    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
+    if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits: %s -- retrying with one pass per contig\n", ctx->err.c_str());
     release_scratch(ctx);
     (void)known_not_to_fit(ctx, guide, params, true);
   }
@@ -1815,7 +1815,7 @@ static int search_hits_owned(calitas_ctx* ctx, const calitas_guide_t* guide, con
     HIP_TRY(ctx, calitas_spin_sync(ctx->stream));
   }
   // ---- the contigs the stretch touches, whole, on the general kernels; their rows filtered by position ----
-  if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits on a window range: the bins declined, searching the touched contigs whole\n");
+  if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits on a window range: the bins declined, searching the touched contigs whole\n");
   std::vector<uint64_t> wb(ref.contigs.size() + 1, 0);
   for (size_t c = 0; c < ref.contigs.size(); c++) wb[c + 1] = wb[c] + window_count(ref.contigs[c].len, pl.step);
   const uint64_t first = (uint64_t)params->first_window, last = first + (uint64_t)params->n_windows;
@@ -1906,12 +1906,12 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
   // kernels run its rows kernel writes the text straight to its final place.
   std::vector<char> lane_compact;
   auto rs_lane = [&](size_t c) -> const RowStrings& { return c < lane_compact.size() && lane_compact[c] ? rs_compact : rs; };
-  const bool trace = tune::get("CALITAS_TRACE") != nullptr;
+  const bool trace = TUNE_GET("CALITAS_TRACE") != nullptr;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 
   // ---- how many lanes: one pass over the whole reference, or contig ranges pipelined against each other ----
   std::vector<double> weights;
-  if (const char* e = tune::get("CALITAS_CHUNKS")) {
+  if (const char* e = TUNE_GET("CALITAS_CHUNKS")) {
     // "3" = three equal chunks, "5:3:2" = relative sizes
     for (const char* q = e; *q;) {
       char* end = nullptr;
@@ -1979,7 +1979,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       text = (char*)calitas_out_alloc_pinned(hlen + body + 1);
     }
     if (text) std::memcpy(text, rs.header.data(), hlen);
-    if (text && !tune::get("CALITAS_TEXT_IN_PLACE_OFF")) {
+    if (text && !TUNE_GET("CALITAS_TEXT_IN_PLACE_OFF")) {
       void* dp = nullptr;
       if (hipHostGetDevicePointer(&dp, text, 0) == hipSuccess) text_dev = static_cast<char*>(dp); else (void)hipGetLastError();
     }
@@ -2053,17 +2053,17 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     // when its scan is done, so the tail of chunk c runs while chunk c+1 is still being scanned
     rc = ensure_window_table(ctx, pl, ctx->scan_stream);
     if (rc) return rc;
-    const bool device_rows = !tune::get("CALITAS_HOST_HITS");
+    const bool device_rows = !TUNE_GET("CALITAS_HOST_HITS");
     {
       bool compact_on = device_rows;
-      if (const char* e = tune::get("CALITAS_COMPACT_ROWS")) compact_on = compact_on && std::atoi(e) != 0;
+      if (const char* e = TUNE_GET("CALITAS_COMPACT_ROWS")) compact_on = compact_on && std::atoi(e) != 0;
       lane_compact.assign(K, 0);
       // Which ranges move compact rows: the leading ones always (their expansion hides behind the later ranges' scans); the last one
       // where the text is long -- a call cut into three: its rows kernel then writes 3 MB into device memory and the text's pieces are
       // expanded as they land, instead of 9 MB written across PCIe by the kernel itself, 2.072 against 2.098 ms per hg38-sized call;
       // the last of two ranges keeps its rows kernel writing in place (a rank of eight: 0.48 against 0.50 ms).
       size_t n_compact = K >= 3 ? K : K - 1;
-      if (const char* e = tune::get("CALITAS_COMPACT_LANES")) n_compact = std::min<size_t>(K, (size_t)std::max(0, std::atoi(e)));
+      if (const char* e = TUNE_GET("CALITAS_COMPACT_LANES")) n_compact = std::min<size_t>(K, (size_t)std::max(0, std::atoi(e)));
       for (size_t c = 0; c < n_compact; c++) lane_compact[c] = compact_on ? 1 : 0;
     }
     // (no early return inside this loop: the scans of the earlier lanes are already in flight and every exit waits for them)
@@ -2083,12 +2083,12 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
     // against 0.517 for an eighth, interleaved):
     bool inputs_first = true;
     int inputs_mode = 2;
-    if (const char* e = tune::get("CALITAS_INPUTS_FIRST")) { inputs_mode = std::atoi(e); inputs_first = inputs_mode != 0; }
+    if (const char* e = TUNE_GET("CALITAS_INPUTS_FIRST")) { inputs_mode = std::atoi(e); inputs_first = inputs_mode != 0; }
     // mode 2: the first range's inputs ahead of its scan on the scan stream, the later ranges' on their own streams (which have nothing
     // else to do yet); the scan stream waits for each with an event that has long fired when its turn comes.  A range's small inputs
     // are ONE launch (queue_lane_setup) where they used to be two stream commands for the scan and three or four for the row stage.
     std::vector<char> rows_queued(K, 0);                      // the lane's row constants went out with its scan inputs (one launch for both)
-    const bool device_rows_early = !tune::get("CALITAS_HOST_HITS");
+    const bool device_rows_early = !TUNE_GET("CALITAS_HOST_HITS");
     if (inputs_mode == 2) {
       // the first range: its scan inputs (one launch: queue_lane_setup) and its scan, before anything else is prepared
       bool one = false;
@@ -2322,7 +2322,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   // Five guides in flight: with three the bus idled a sixth of the time between the texts of a 96-guide batch on an hg38-sized genome
   // (15.3 GB per batch: 328.6 ms; four lanes 298.0, five 292.1 = 52 GB/s, six 300.6, eight 295.5).
   int n_lanes = 5;
-  if (const char* e = tune::get("CALITAS_BATCH_LANES")) n_lanes = std::max(1, std::min(8, std::atoi(e)));
+  if (const char* e = TUNE_GET("CALITAS_BATCH_LANES")) n_lanes = std::max(1, std::min(8, std::atoi(e)));
   n_lanes = std::min(n_lanes, (int)n_guides);
   if (n_lanes < 2) {   // nothing to pipeline
     for (int i = 0; i < n_guides; i++) {
@@ -2353,7 +2353,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   // runs on a stretch, which only the bins can own.  (Round 3 got there by accident: the first guide that crowded a bin switched the
   // bins off for every guide behind it; with the decline remembered per guide the batch took 328 instead of 295 ms per 96 guides.)
   // (A reference below 2 Gb keeps the bins, as a single call on it does: fewer launches, and its scans are short.)
-  if (!ranged && ctx->ref.total_bases >= (2048ull << 20) && !tune::get("CALITAS_BATCH_BINNED")) for (auto& q : plans) q.three_ranges = true;
+  if (!ranged && ctx->ref.total_bases >= (2048ull << 20) && !TUNE_GET("CALITAS_BATCH_BINNED")) for (auto& q : plans) q.three_ranges = true;
   std::vector<char> owned_ok((size_t)n_guides, 1);
   if (ranged) {
     if (params->first_window < 0 || params->n_windows <= 0 || (uint64_t)params->first_window + (uint64_t)params->n_windows > plans[0].win_n)
@@ -2369,10 +2369,10 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   if (rc) return rc;
   const PackedRef& ref = ctx->ref;
   std::mutex scan_mu, copy_mu;
-  const bool device_rows = !tune::get("CALITAS_HOST_HITS");
+  const bool device_rows = !TUNE_GET("CALITAS_HOST_HITS");
   std::atomic<uint64_t> expand_us{0};                           // lane threads' time in expand_rows (their turn on the pool included)
   bool compact_rows = device_rows;
-  if (const char* e = tune::get("CALITAS_COMPACT_ROWS")) compact_rows = compact_rows && std::atoi(e) != 0;
+  if (const char* e = TUNE_GET("CALITAS_COMPACT_ROWS")) compact_rows = compact_rows && std::atoi(e) != 0;
   std::vector<int> rcs((size_t)n_guides, CALITAS_OK);
   std::vector<std::string> errs((size_t)n_guides);   // a failed guide's message, kept apart from its lane (a retry below destroys the lanes)
   std::vector<calitas_timing_t> tms((size_t)n_guides);
@@ -2493,7 +2493,7 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   }
   tm.lanes = (uint32_t)n_lanes;
   ctx->timing = tm;
-  if (tune::get("CALITAS_TRACE"))
+  if (TUNE_GET("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search_hits_batch: %d guides on %d lanes, scan %.3f ms, align %.3f ms, rows expanded on the host %.3f ms (sums), call %.3f ms (%llu rows, %llu bytes)\n",
                  n_guides, n_lanes, tm.scan_kernel_ms, tm.align_kernel_ms, (double)expand_us.load() * 1e-3,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(),

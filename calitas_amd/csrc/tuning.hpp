@@ -2,8 +2,10 @@
 //
 // The product has one behaviour; these switches exist for measurements (A/B runs, tools/ab_env.py, tools/sweep_env.py), for tests that
 // force a fallback path, and for a caller that shares the card.  They are read when a call starts a stage (tests change them between
-// calls of one process), always through tune::get(), which refuses a name that is not in the table below -- so the table is complete,
-// and `calitas_switches()` (include/calitas_hip.h) prints it.
+// calls of one process), always through TUNE_GET / TUNE_ON / TUNE_SET, which refuse a name that is not in the table below AT COMPILE TIME
+// (a static_assert on the literal) -- so the table is complete, `calitas_switches()` (include/calitas_hip.h) prints it, and nothing in
+// the library stops the process over a switch.  Switches that make the library return WRONG bytes for the sake of a timing experiment
+// exist only in builds made with `make EXPERIMENTS=1` (-DCALITAS_EXPERIMENTS); the shipped library does not know their names.
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +25,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_HOST_FILTER", "1", "F: per-window filter (SGA:315-320) on the host instead of select.hip"},
   {"CALITAS_HOST_HITS", "1", "F: removeOverlaps / sort / rows on the host (post.cpp) instead of hits.hip / binned.hip"},
   {"CALITAS_VARIANTS_HOST", "1", "F: variant branch: merge alignment records on the host (round 3) instead of bringing the variant windows' hits into the device's row stage"},
+  {"CALITAS_FAIL_ALIGN_BATCH", "k", "F: variant branch: the k-th batch of variant windows (0-based) fails in the aligner stage (tests of the stages' error path)"},
   {"CALITAS_SEQUENTIAL", "1", "F: calitas_search_hits as one pass per contig whatever the size"},
   {"CALITAS_SDMA", "0", "F: text copies with hipMemcpyAsync instead of the SDMA engine (dma.cpp)"},
   {"CALITAS_BINNED", "1 | 0 | last", "T/F: the per-bin tail for every range / none / the last range only (default: calls of one or two ranges, the last range of three, every window range)"},
@@ -32,7 +35,9 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_BINNED_TEXT_KB", "n", "F: first guess of the per-bin text buffer (forces the regrow path)"},
   {"CALITAS_BINNED_HOST_TEXT", "0 | 1", "F/T: short texts written into page-locked host memory by the rows kernel (default 1)"},
   {"CALITAS_BINNED_HOST_TEXT_KB", "n", "T: ... up to this size (default 128)"},
+#ifdef CALITAS_EXPERIMENTS
   {"CALITAS_BINNED_SKIP", "1 | 2 | 3", "D: timing experiments only (the text is wrong): skip the wave-per-bin kernel / the rows"},
+#endif
   {"CALITAS_TEXT_IN_PLACE_OFF", "1", "F: the last range's text takes the copy instead of being written to its final place by the rows kernel"},
   {"CALITAS_CHUNKS", "k | a:b:c", "T: contig ranges of a chunked calitas_search_hits (default 5.8:2.9:1.3 from 2 Gb, 5:3 from 600 Mb, 3:2 from 256 Mb)"},
   {"CALITAS_CHUNK", "64..512", "T: bases per scan lane chunk (set_reference; default by genome size)"},
@@ -52,18 +57,19 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_EXPAND_THREADS", "n", "T: workers that expand compact rows (default: the whole pool)"},
 };
 
-inline bool known(const char* name) {
-  for (const Switch& s : kSwitches) if (std::strcmp(s.name, name) == 0) return true;
+constexpr bool same(const char* a, const char* b) {
+  while (*a && *a == *b) { ++a; ++b; }
+  return *a == *b;
+}
+constexpr bool known(const char* name) {
+  for (const Switch& s : kSwitches) if (same(s.name, name)) return true;
   return false;
 }
 
-// getenv for a switch of the table; a name that is not in it is a bug in the library (the process stops: tests would catch it).
-inline const char* get(const char* name) {
-  if (!known(name)) std::abort();
-  return std::getenv(name);
-}
-inline bool on(const char* name) { const char* e = get(name); return e && std::atoi(e) != 0; }
-inline bool is_set(const char* name) { return get(name) != nullptr; }
-
 }  // namespace tune
 }  // namespace calitas
+
+// getenv for a switch of the table.  NAME is a string literal; one that is not in the table does not compile.
+#define TUNE_GET(NAME) ([]() -> const char* { static_assert(::calitas::tune::known(NAME), "switch missing from tuning.hpp's table"); return std::getenv(NAME); }())
+#define TUNE_ON(NAME) ([]() -> bool { const char* e_ = TUNE_GET(NAME); return e_ && std::atoi(e_) != 0; }())
+#define TUNE_SET(NAME) (TUNE_GET(NAME) != nullptr)

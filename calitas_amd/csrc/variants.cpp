@@ -7,6 +7,18 @@
 // flanks (SR:598-613) and the variant columns (RH:211-233).  calitas_amd/variants.py holds the same logic in Python (the parity
 // tests run both); this file exists because BASELINE config 5 has three million variants.
 //
+// RESTATEMENT, NOT DESIGN: four host functions below follow the reference statement by statement, because what they compute IS the
+// contract -- the order in which allele combinations are enumerated decides the order of the variant windows (and so SR:622's arrival
+// order of their hits), and the shape of a window's CIGAR decides every lifted coordinate:
+//   ref_offset_at          = VariantWindow.refOffsetAtBaseOffset   SearchReference.scala:133-156
+//   is_valid               = VariantSet.isValid                     SearchReference.scala:182-193
+//   build_window           = buildVariantWindow                     SearchReference.scala:263-323  (windowStart / windowEnd, the right-to-left
+//                            patch, refPos / baseOffset / precedingMatch, the M / I / D case split, the same `require`)
+//   allele_combos_counts   = alleleCombos(Seq[Int])                 SearchReference.scala:377-399  (denominators, group size, (allele + 1) % n)
+// They are pinned by the reference's own vectors V1-V9 (SearchReferenceTest.scala:150-295) through tests/test_variants_host.py.
+// Everything around them -- arenas, the VCF reader, the three-stage pipeline, keys and rows, the merge on the device -- has no
+// counterpart in the reference.
+//
 // VCF support is the subset the reference's path needs (fgbio vcf.api): CHROM POS ID REF ALT FILTER INFO(AF, END); plain or gzip.
 #include <zlib.h>
 
@@ -205,7 +217,7 @@ std::string read_vcf(const char* path, const char* chrom, calitas::WorkerPool* p
     Var** dst = out.at.data() + part_at[(size_t)tid];
     for (size_t k = 0; k < mine.size(); k++) dst[k] = &mine[k];
   });
-  if (calitas::tune::get("CALITAS_TRACE") && total >= 100000)
+  if (TUNE_GET("CALITAS_TRACE") && total >= 100000)
     std::fprintf(stderr, "[calitas] read_vcf: %zu bytes read in %.1f ms, %zu records parsed in %.1f ms, joined in %.1f ms\n", n, ms_read, total, ms_parse, ms_since(t_join));
   return "";
 }
@@ -422,11 +434,15 @@ std::string md5_file(const char* path, std::string& hex) {
 }
 
 // A thread that runs jobs in the order they are handed over (a stage of the variant branch's pipeline).  After a job has failed the
-// ones behind it are dropped; drain() reports the failure.
+// ones behind it are dropped -- but a dropped job's `skipped` handler still runs, in the job's place: whatever a job owes OTHER threads
+// (its turn in the order in which batches reach the lifter) is paid there, so nobody waits for a job that will never run.  drain()
+// reports the failure.  A stage that is destroyed with jobs still queued (the calling thread left through an exception) drops them
+// the same way before it joins its thread.
 struct StageThread {
+  struct Job { std::function<int(std::string&)> run; std::function<void()> skipped; };
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::function<int(std::string&)>> jobs;
+  std::deque<Job> jobs;
   bool busy = false, quit = false;
   int rc = CALITAS_OK;
   std::string err;
@@ -435,7 +451,7 @@ struct StageThread {
     t = std::thread([this, device] {
       if (device >= 0) (void)hipSetDevice(device);
       for (;;) {
-        std::function<int(std::string&)> job;
+        Job job;
         bool skip = false;
         {
           std::unique_lock<std::mutex> lk(mu);
@@ -444,16 +460,17 @@ struct StageThread {
           job = std::move(jobs.front());
           jobs.pop_front();
           busy = true;
-          skip = rc != CALITAS_OK || !err.empty();
+          skip = quit || rc != CALITAS_OK || !err.empty();
         }
         cv.notify_all();
         int r = CALITAS_OK;
         std::string e;
-        if (!skip) {
-          try { r = job(e); }
-          catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("a stage of the variant branch ended with an exception: ") + x.what(); }
-        }
-        job = nullptr;
+        try {
+          if (!skip) r = job.run(e);
+          else if (job.skipped) job.skipped();
+        } catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("a stage of the variant branch ended with an exception: ") + x.what(); }
+        catch (...) { r = CALITAS_EHIP; e = "a stage of the variant branch ended with an exception"; }
+        job = Job();
         {
           std::lock_guard<std::mutex> lk(mu);
           busy = false;
@@ -465,13 +482,19 @@ struct StageThread {
     });
   }
   // hands a job over; waits while max_waiting jobs are waiting (ms_wait: that time is added to it)
-  int enqueue(std::function<int(std::string&)> job, size_t max_waiting, double* ms_wait) {
+  // (a job refused here -- the stage has failed -- has NOT been queued: its `skipped` handler runs on the calling thread, now)
+  int enqueue(std::function<int(std::string&)> job, size_t max_waiting, double* ms_wait, std::function<void()> skipped = nullptr) {
     const auto t0 = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [&] { return jobs.size() < max_waiting; });
     if (ms_wait) *ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (rc != CALITAS_OK || !err.empty()) return rc;             // (the caller learns the reason from drain())
-    jobs.push_back(std::move(job));
+    if (rc != CALITAS_OK || !err.empty()) {                      // (the caller learns the reason from drain())
+      const int r = rc != CALITAS_OK ? rc : CALITAS_EINVAL;
+      lk.unlock();
+      if (skipped) skipped();
+      return r;
+    }
+    jobs.push_back(Job{std::move(job), std::move(skipped)});
     lk.unlock();
     cv.notify_all();
     return CALITAS_OK;
@@ -535,7 +558,9 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
 
   const auto t_call = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-  double ms_ref = 0, ms_parse = 0, ms_align = 0, ms_rows = 0, ms_merge = 0, ms_build = 0, ms_wait = 0, ms_finish = 0;
+  std::atomic<int> batch_serial{0};                               // (batches through align_part, for CALITAS_FAIL_ALIGN_BATCH)
+  std::atomic<long long> ns_align{0};                             // (two aligner threads add to it)
+  double ms_ref = 0, ms_parse = 0, ms_rows = 0, ms_merge = 0, ms_build = 0, ms_wait = 0, ms_finish = 0;
   calitas_aln_t* ref_alns = nullptr;                                                               // (host merge only, below)
   uint64_t n_ref = 0;
   int rc = CALITAS_OK;
@@ -710,9 +735,11 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     std::vector<int32_t> offs(n, 0);
     for (size_t i = 0; i < n; i++) { targets[i] = reinterpret_cast<const uint8_t*>(batch.wins[i].bases); lens[i] = (uint32_t)batch.wins[i].len; }
     const auto t0 = std::chrono::steady_clock::now();
+    if (const char* inj = TUNE_GET("CALITAS_FAIL_ALIGN_BATCH"))        // tests: the error path of the stages (a failed batch must fail the call, not hang it)
+      if (std::atoi(inj) == batch_serial++) return calitas_fail(ctx, CALITAS_EHIP, "injected failure of an aligner batch (CALITAS_FAIL_ALIGN_BATCH)");
     int r = calitas_align_windows(actx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &res.out, &res.n_out, &res.counts);
     if (r) { if (actx != ctx) calitas_fail(ctx, r, calitas_last_error(actx)); return r; }
-    ms_align += ms_since(t0);
+    ns_align += (long long)(ms_since(t0) * 1e6);
     return CALITAS_OK;
   };
   auto lift_part = [&](Batch& batch, const size_t n, const Aligned& res, std::string& err) -> int {
@@ -825,7 +852,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // The two halves run side by side: this thread produces, aligns (on a side context: a stream and buffers of its own) and keys the
   // variant windows contig by contig -- host work, mostly -- while a helper thread drives the reference's per-contig passes (device work
   // and the text over PCIe); the row stage of contig c waits until this thread has published the contig's entries.
-  const char* force_host = tune::get("CALITAS_VARIANTS_HOST");
+  const char* force_host = TUNE_GET("CALITAS_VARIANTS_HOST");
   const bool device_merge = !(force_host && std::atoi(force_host) != 0) && p.max_overlap >= 1;
   calitas_ctx* actx2 = nullptr;                                                                    // (a second aligner, below)
   if (device_merge) { rc = calitas_side_context(ctx, &actx); if (rc) return rc; rc = calitas_side_context(ctx, &actx2, 1); if (rc) return rc; }
@@ -978,48 +1005,57 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // lift, 5 to walk and build.  Jobs run in the order they were handed over; two wait per stage at most.
   // (Two aligners when the call has side contexts: a batch is 8-10 ms in calitas_align_windows and 5 ms to walk and build, so one
   // aligner was the pipeline's slowest stage; the batches alternate between them and reach the lifter in their own order.)
-  StageThread aligner, aligner2, lifter;
-  const bool two_aligners = actx2 != nullptr;
-  aligner.start(ctx->device);
-  if (two_aligners) aligner2.start(ctx->device);
-  lifter.start(-1);
+  // Declared BEFORE the stages: what the stages' jobs capture must outlive the stage threads, which are joined by the stages'
+  // destructors -- also when this thread leaves through an exception (std::bad_alloc while building a batch) with jobs still queued.
   std::mutex order_mu;
   std::condition_variable order_cv;
   uint64_t batches_handed = 0, batches_lifting = 0;               // (batches_lifting: under order_mu)
   std::function<int(size_t)> finish_upto_fn;                      // (finish_upto, defined below: the lifter runs it behind a contig's last batch)
+  // Batch k's turn at the lifter: every batch takes it exactly once, in the order the batches were built -- whether its job ran, failed,
+  // threw or was dropped because the stage had failed before (StageThread's `skipped` handler) -- so a job of the other aligner that
+  // waits for "batches_lifting == k" is never left waiting for a job that will not run.  at_turn (may be empty) runs inside the turn.
+  auto pass_turn = [&](uint64_t k, const std::function<int()>& at_turn) -> int {
+    std::unique_lock<std::mutex> lk(order_mu);
+    order_cv.wait(lk, [&] { return batches_lifting == k; });
+    int r = CALITAS_OK;
+    try { if (at_turn) r = at_turn(); }
+    catch (...) { batches_lifting = k + 1; lk.unlock(); order_cv.notify_all(); throw; }
+    batches_lifting = k + 1;
+    lk.unlock();
+    order_cv.notify_all();
+    return r;
+  };
+  // (the lifter first: the aligners' jobs hand work to it, so it is destroyed -- joined -- after them)
+  StageThread lifter, aligner, aligner2;
+  const bool two_aligners = actx2 != nullptr;
+  aligner.start(ctx->device);
+  if (two_aligners) aligner2.start(ctx->device);
+  lifter.start(-1);
   // a contig's entries for the device are made on the lifter thread, behind the lift of the contig's last batch, while this thread is
   // already walking the next contig (waiting for the stages to run dry at every one of 25 contig ends was 0.22 s of the variant half)
   auto hand_over_finish = [&](size_t upto) -> int {
     const uint64_t k = batches_handed++;
     const bool second = two_aligners && (k & 1);
     return (second ? aligner2 : aligner).enqueue([&, k, upto](std::string&) -> int {
-      std::unique_lock<std::mutex> lk(order_mu);
-      order_cv.wait(lk, [&] { return batches_lifting == k; });
-      const int lr = lifter.enqueue([&, upto](std::string&) { return finish_upto_fn(upto); }, 2, nullptr);
-      batches_lifting = k + 1;
-      lk.unlock();
-      order_cv.notify_all();
-      return lr;
-    }, 2, &ms_wait);
+      return pass_turn(k, [&]() -> int { return lifter.enqueue([&, upto](std::string&) { return finish_upto_fn(upto); }, 2, nullptr); });
+    }, 2, &ms_wait, [&, k] { (void)pass_turn(k, nullptr); });
   };
   hand_over = [&](Batch&& b, size_t n) -> int {
     auto held = std::make_shared<Batch>(std::move(b));
     const uint64_t k = batches_handed++;
     const bool second = two_aligners && (k & 1);
     calitas_ctx* const where = second ? actx2 : actx;
-    return (second ? aligner2 : aligner).enqueue([&, held, n, k, where](std::string&) -> int {
+    return (second ? aligner2 : aligner).enqueue([&, held, n, k, where](std::string& e) -> int {
       auto res = std::make_shared<Aligned>();
-      const int r = n ? align_part(where, *held, n, *res) : CALITAS_OK;
+      int r = CALITAS_OK;
+      try { if (n) r = align_part(where, *held, n, *res); }
+      catch (const std::exception& x) { r = CALITAS_EHIP; e = std::string("the aligner stage of the variant branch ended with an exception: ") + x.what(); }
       // the lifter takes the batches in the order they were built, whichever aligner is done first
-      std::unique_lock<std::mutex> lk(order_mu);
-      order_cv.wait(lk, [&] { return batches_lifting == k; });
-      int lr = r;
-      if (!r && n) lr = lifter.enqueue([&, held, n, res](std::string& e) { return lift_part(*held, n, *res, e); }, 2, nullptr);
-      batches_lifting = k + 1;
-      lk.unlock();
-      order_cv.notify_all();
-      return lr;
-    }, 2, &ms_wait);
+      return pass_turn(k, [&]() -> int {
+        if (r || !n) return r;
+        return lifter.enqueue([&, held, n, res](std::string& le) { return lift_part(*held, n, *res, le); }, 2, nullptr);
+      });
+    }, 2, &ms_wait, [&, k] { (void)pass_turn(k, nullptr); });
   };
   auto drain = [&]() -> int {                                     // everything handed over is in hits[]
     const int ra = aligner.drain(&ms_wait, &err);
@@ -1102,7 +1138,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     publish(nc, true);
     if (helper.joinable()) helper.join();
     calitas_free(hr.tsv);
-    return rc != CALITAS_OK ? rc : calitas_fail(ctx, CALITAS_EINVAL, err);
+    if (!err.empty()) return calitas_fail(ctx, rc != CALITAS_OK ? rc : CALITAS_EINVAL, err);   // (a stage's own text, or this thread's)
+    return rc;                                                    // (the context's error text was set where the call failed)
   }
   const double ms_variant_half = ms_since(t_call);
 
@@ -1129,13 +1166,13 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         }
       }
     });
-    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: teardown %.1f ms\n", ms_since(t0));
+    if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: teardown %.1f ms\n", ms_since(t0));
   };
   if (device_merge) {
     helper.join();
     if (hr.rc == CALITAS_OK) {
       const size_t n_hits = hits.size(), n_vcf = vcf.size();
-      if (tune::get("CALITAS_FREE_NOW")) teardown();
+      if (TUNE_GET("CALITAS_FREE_NOW")) teardown();
       else {
         // millions of small heap blocks and a few gigabytes of tables: nobody waits for them (0.17 s per call at full size even with
         // every worker handing them back) -- they go to the library's own thread as they are
@@ -1148,16 +1185,16 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       if (tsv_bytes) *tsv_bytes = hr.bytes;
       if (n_rows) *n_rows = hr.rows;
       if (n_windows) *n_windows = windows_total;
-      if (tune::get("CALITAS_TRACE"))
+      if (TUNE_GET("CALITAS_TRACE"))
         std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: built in %.1f ms, waiting for the aligner thread %.1f ms (align %.1f ms, keys %.1f ms there), "
                              "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits, "
                              "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms\n",
-                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_build, ms_wait, ms_align, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, ms_variant_half, hr.ms, ms_since(t_call));
+                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_build, ms_wait, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, ms_variant_half, hr.ms, ms_since(t_call));
       return CALITAS_OK;
     }
     calitas_free(hr.tsv);
     if (!hr.declined) { teardown(); return hr.rc; }
-    if (tune::get("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
+    if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
   }
   // On the host (a stage the device declines: -O 0, a window beyond the device filter, an overlap cluster beyond one lane's walk):
   // reference windows on the GPU, their alignment records back, removeOverlaps + sort over everything.
@@ -1174,7 +1211,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     ext[k].contig_index = h.w->contig; ext[k].coordinate_start = h.gstart; ext[k].end = h.gstart + h.tlen - 1; ext[k].score = h.a->score;
     ext[k].strand = (int8_t)h.a->strand; ext[k].variant_description = h.desc.empty() ? nullptr : h.desc.c_str(); ext[k].row = nullptr;
   }
-  if (tune::get("CALITAS_TWIN_STATS")) {   // how many hits of variant windows that touch no variant repeat a reference hit exactly
+  if (TUNE_GET("CALITAS_TWIN_STATS")) {   // how many hits of variant windows that touch no variant repeat a reference hit exactly
     std::vector<std::array<int64_t, 3>> keys(n_ref);
     for (uint64_t i = 0; i < n_ref; i++) {
       const calitas_aln_t& a = ref_alns[i];
@@ -1209,8 +1246,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   if (n_rows) *n_rows = nr;
   if (n_windows) *n_windows = windows_total;
   ms_merge = ms_since(t_merge);
-  if (tune::get("CALITAS_TRACE"))
+  if (TUNE_GET("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search_variants: reference search %.1f ms, VCF %.1f ms (%zu records), %llu windows: align %.1f ms, rows %.1f ms, merge %.1f ms, call %.1f ms\n",
-                 ms_ref, ms_parse, n_vcf_records, (unsigned long long)windows_total, ms_align, ms_rows, ms_merge, ms_since(t_call));
+                 ms_ref, ms_parse, n_vcf_records, (unsigned long long)windows_total, (double)ns_align.load() / 1e6, ms_rows, ms_merge, ms_since(t_call));
   return CALITAS_OK;
 }

@@ -92,11 +92,76 @@ def search_variants(sr, ctx, vcf_path, chrom_index=-1, version=None, time_stamp=
     return text, rows.value
 
 
-def prepare_vcf(inputs, output, min_af=0.01, add_chr_prefix=True):
-    """PrepareVcf.execute (PrepareVcf.scala:39-88) without the optional --dict contig rewrite: PASS variants with an ALT at or
-    above min_af, alleles below it dropped, INFO reduced to AF, genotypes and samples removed, optional chr prefix."""
+def read_sequence_dictionary(path):
+    """The sequences of a sequence dictionary as [(name, length, assembly or None)], the way SAMSequenceDictionaryExtractor reads them
+    for PrepareVcf.scala:46-49: a `.dict` / SAM header text (`@SQ` lines with SN, LN and an optional AS), a FASTA (its companion
+    `.dict` -- `ref.dict` or `ref.fa.dict` -- as htsjdk looks for it) or a `.fai` index (names and lengths only)."""
+    path = str(path)
+    low = path.lower()
+    if low.endswith((".fa", ".fasta", ".fna", ".fa.gz", ".fasta.gz")):
+        base = path[:-3] if low.endswith(".gz") else path
+        for cand in (os.path.splitext(base)[0] + ".dict", base + ".dict"):
+            if os.path.exists(cand):
+                return read_sequence_dictionary(cand)
+        raise ValueError("no sequence dictionary (.dict) next to %s" % path)
+    seqs = []
+    with _open_text(path) as f:
+        if low.endswith(".fai"):
+            for line in f:
+                fld = line.rstrip("\n").split("\t")
+                if len(fld) >= 2:
+                    seqs.append((fld[0], int(fld[1]), None))
+        else:
+            for line in f:
+                if not line.startswith("@"):
+                    break                                          # (a SAM file: the header is over)
+                if not line.startswith("@SQ"):
+                    continue
+                tags = dict(t.split(":", 1) for t in line.rstrip("\n").split("\t")[1:] if ":" in t)
+                if "SN" not in tags or "LN" not in tags:
+                    raise ValueError("@SQ line without SN / LN in %s" % path)
+                seqs.append((tags["SN"], int(tags["LN"]), tags.get("AS")))
+    if not seqs:
+        raise ValueError("no sequences in the sequence dictionary %s" % path)
+    return seqs
+
+
+def _header_with_dictionary(header, seqs):
+    """PrepareVcf.scala:46-55: the header's contig lines become the dictionary's sequences (index order; length and, when the
+    dictionary has one, assembly), every `##reference=` line goes and one `##reference=<assembly of the first sequence>` is added
+    behind the other general lines.  Where the lines stand in the written header is fgbio's / htsjdk's business and pinned by no
+    reference test: the contig lines take the place of the first old one (or stand in front of `#CHROM`), the reference line stands
+    in front of `#CHROM`."""
+    assembly = seqs[0][2]
+    if assembly is None:
+        raise ValueError("the first sequence of the dictionary has no assembly (AS) -- PrepareVcf --dict writes it as the VCF's `reference`")
+    contigs = ["##contig=<ID=%s,length=%d%s>" % (n, ln, ",assembly=%s" % a if a is not None else "") for n, ln, a in seqs]
+    out, placed = [], False
+    for h in header:
+        if h.startswith("##contig="):
+            if not placed:
+                out.extend(contigs)
+                placed = True
+            continue
+        if h.startswith("##reference="):
+            continue
+        if h.startswith("#CHROM"):
+            if not placed:
+                out.extend(contigs)
+                placed = True
+            out.append("##reference=%s" % assembly)
+        out.append(h)
+    return out
+
+
+def prepare_vcf(inputs, output, min_af=0.01, add_chr_prefix=True, dict_path=None):
+    """PrepareVcf.execute (PrepareVcf.scala:39-88): PASS variants with an ALT at or above min_af, alleles below it dropped, INFO
+    reduced to AF, genotypes and samples removed, optional chr prefix; with dict_path (`-d / --dict`, PrepareVcf.scala:36, 46-56)
+    the header's contig lines and `reference` line are rewritten from that sequence dictionary."""
     fix = set([str(i) for i in range(1, 23)] + ["X", "Y"])
     first_header, _ = read_vcf(inputs[0])
+    if dict_path is not None:
+        first_header = _header_with_dictionary(first_header, read_sequence_dictionary(dict_path))
     opener = gzip.open if str(output).endswith(".gz") else open
     n = 0
     with opener(output, "wt") as out:

@@ -233,6 +233,35 @@ def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_pa
     assert sorted(map(key, _norm(got))) == sorted(map(key, _norm(want)))
 
 
+@pytest.mark.parametrize("which", [0, 1, 2, 4])
+def test_a_failed_aligner_batch_fails_the_call_instead_of_hanging_it(C, which, tmp_path, monkeypatch):
+    """The variant branch's stages (producer -> two aligners -> lifter) hand batches to the lifter in the order they were built.  A
+    batch that fails in one aligner makes that stage drop the jobs behind it; the other aligner's jobs must still get their turn
+    (StageThread's `skipped` handler passes it), so the call comes back with the error -- it used to wait forever.  Six contigs give
+    six batches and six contig-end jobs, alternating between the two aligners; the k-th batch is made to fail (CALITAS_FAIL_ALIGN_BATCH)."""
+    import threading
+    fa, vcf = _dense_case(C, tmp_path, [("c%d" % i, 9000) for i in range(6)], 120, seed=31)
+    kw = dict(guide="CTTGCCCCACAGGGCAGTAA", guide_id="c5", ref=fa, variants=vcf, max_guide_diffs=6, max_pam_mismatches=0,
+              max_gaps_between_guide_and_pam=3)
+    want = C.SearchReference(**kw).run("v0", "stamp")
+    monkeypatch.setenv("CALITAS_FAIL_ALIGN_BATCH", str(which))
+    box = {}
+
+    def call():
+        try:
+            box["out"] = C.SearchReference(**kw).run("v0", "stamp")
+        except Exception as e:                                   # noqa: BLE001 -- the error is what the test is about
+            box["err"] = str(e)
+
+    t = threading.Thread(target=call, daemon=True)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "calitas_search_variants did not return after a failed batch"
+    assert "out" not in box and "injected failure" in box.get("err", ""), box
+    monkeypatch.delenv("CALITAS_FAIL_ALIGN_BATCH")
+    assert C.SearchReference(**kw).run("v0", "stamp") == want    # and the library is fine afterwards
+
+
 def test_device_merge_declines_to_the_host(C, tmp_path):
     """-O 0 is beyond the device's row stage: the call merges on the host, same rows as the oracle."""
     fa, vcf = _dense_case(C, tmp_path, [("chr1", 30000)], 300, seed=77)

@@ -101,3 +101,47 @@ def test_prepare_vcf(VA, tmp_path):
     assert [h for h in hdr if h.startswith("#CHROM")][0].split("\t")[-1] == "INFO"     # no samples
     assert all(v.chrom == "chr1" for v in vs)
     assert vs[10].alts == ["G"] and vs[10].afs == [0.2]
+
+
+def test_prepare_vcf_with_a_sequence_dictionary(VA, tmp_path):
+    """PrepareVcf --dict (PrepareVcf.scala:36, 46-56): contig lines from the dictionary's sequences (length, assembly), every old
+    `reference` line replaced by the first sequence's assembly, records untouched; the same through `python -m calitas_amd
+    PrepareVcf -d`; a dictionary next to a FASTA is found the way htsjdk finds it; a .fai (no assembly) is refused with a reason."""
+    src = tmp_path / "in.vcf"
+    with open(src, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##reference=file:///old/b37.fa\n##contig=<ID=1,length=5>\n##contig=<ID=2,length=7>\n")
+        f.write("##INFO=<ID=AF,Number=A,Type=Float,Description=\"x\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\n")
+        for i in range(10):
+            f.write("1\t%d\trs%d\tA\tC\t.\tPASS\tAF=0.5\tGT\t0/1\n" % (1000 * (i + 1), i))
+    d = tmp_path / "ref.dict"
+    with open(d, "w") as f:
+        f.write("@HD\tVN:1.5\tSO:unsorted\n@SQ\tSN:chr1\tLN:248956422\tM5:abc\tAS:hg38\tUR:file:/x\n@SQ\tSN:chr2\tLN:242193529\tAS:hg38\n@SQ\tSN:chrM\tLN:16569\n")
+    out = tmp_path / "out.vcf"
+    assert PV.prepare_vcf([str(src)], str(out), dict_path=str(d)) == 10
+    hdr, vs = PV.read_vcf(str(out))
+    assert [h for h in hdr if h.startswith("##contig=")] == ["##contig=<ID=chr1,length=248956422,assembly=hg38>",
+                                                             "##contig=<ID=chr2,length=242193529,assembly=hg38>", "##contig=<ID=chrM,length=16569>"]
+    assert [h for h in hdr if h.startswith("##reference=")] == ["##reference=hg38"]
+    assert hdr[0] == "##fileformat=VCFv4.2" and hdr[-1].split("\t")[-1] == "INFO" and any(h.startswith("##INFO=<ID=AF") for h in hdr)
+    assert len(vs) == 10 and all(v.chrom == "chr1" for v in vs) and [v.id for v in vs] == ["rs%d" % i for i in range(10)]
+    # without --dict the header is the input's (PrepareVcf.scala:45)
+    plain = tmp_path / "plain.vcf"
+    PV.prepare_vcf([str(src)], str(plain))
+    assert [h for h in PV.read_vcf(str(plain))[0] if h.startswith(("##contig=", "##reference="))] == [
+        "##reference=file:///old/b37.fa", "##contig=<ID=1,length=5>", "##contig=<ID=2,length=7>"]
+    # the command line tool, and a FASTA whose dictionary lies next to it
+    (tmp_path / "ref.fa").write_text(">chr1\nACGT\n")
+    import calitas_amd.__main__ as M
+    cli = tmp_path / "cli.vcf.gz"
+    assert M.main(["PrepareVcf", "-i", str(src), "-o", str(cli), "-d", str(tmp_path / "ref.fa")]) == 0
+    assert PV.read_vcf(str(cli))[0] == hdr
+    # a header without contig lines gets them in front of #CHROM; a dictionary without an assembly cannot name the reference
+    bare = tmp_path / "bare.vcf"
+    bare.write_text("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n1\t5\t.\tA\tC\t.\tPASS\tAF=0.5\n")
+    PV.prepare_vcf([str(bare)], str(out), dict_path=str(d))
+    h2 = PV.read_vcf(str(out))[0]
+    assert h2[1:4] == hdr[1:4] and h2[4] == "##reference=hg38" and h2[5].startswith("#CHROM")
+    (tmp_path / "x.fai").write_text("chr1\t100\t6\t60\t61\n")
+    with pytest.raises(ValueError, match="assembly"):
+        PV.prepare_vcf([str(bare)], str(out), dict_path=str(tmp_path / "x.fai"))
