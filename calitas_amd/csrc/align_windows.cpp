@@ -203,7 +203,7 @@ extern "C" int calitas_align_windows(calitas_ctx* ctx, int32_t n_tasks, const ca
       AlignArgs aa{};
       aa.codes = td.codes; aa.mask = td.mask; aa.runs = td.runs; aa.n_runs = (int64_t)ref.runs.size();
       aa.contigs = td.contigs; aa.tiles = td.tiles; aa.win_base = td.win_base; aa.win = td.win; aa.guides = td.guides; aa.recs = ctx->d_recs;
-      aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2; aa.trace_done = ctx->d_counters + 5;
+      aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2; aa.trace_done = ctx->d_counters + 5; aa.job_count = ctx->d_counters + 6;
       aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap; aa.tile_words = (uint32_t)(ref.tile / 16);
       aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.slab_bytes = slab_bytes; aa.slots_per_rec = slots_per_rec; aa.gw_lo = 0; aa.gw_hi = ~0ull;
       aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;

@@ -179,11 +179,13 @@ CAL_HD inline OpCounts count_ops(const OpsWords& w, int n_ops) {
   return c;
 }
 
-// A filled strip handed from align_kernel to trace_kernel.  Slabs have a fixed size per search and a fixed address
-// (record index x slots-per-record + window slot), so the hand-over needs no atomics: header, target masks tb[ntb],
-// trace bytes tr[L][stride].
+// One aligner job = one scan record x one window that holds some of its candidate columns; one slab per job.  The slab is the job's
+// whole life: expand_kernel writes its head (the strip's geometry, the guide's row sets, the target masks tb[ntb]) with one lane
+// group per job, align_kernel reads exactly that -- one 16-byte load per lane, issued a job ahead --, fills the strip and adds the
+// trace bytes tr[L][stride] and which candidate columns passed, trace_kernel walks it.  Slabs have a fixed size per search and the
+// job's number as their address, so the hand-overs need no atomics beyond the one that numbers the jobs.
 struct SlabHeader {
-  uint32_t pass_mask;     // bit x: the x-th candidate column of this (record, window) reached min_guide_score
+  uint32_t pass_mask;     // (align_kernel) bit x: the x-th candidate column of this job reached min_guide_score; 0 from expand_kernel
   uint32_t contig;
   uint32_t window_k;
   int32_t n;              // window length
@@ -191,8 +193,13 @@ struct SlabHeader {
   uint16_t ncols, ntb;
   uint8_t dir, guide, true_border, L;
   uint16_t stride, pad;
-  uint16_t j[16];         // strand-space end column (1-based) of candidate x
-  int32_t best[16];       // score*4 + matrix code of the best of the three bottom-row cells of candidate x
+  uint16_t j[16];         // (align_kernel) strand-space end column (1-based) of candidate x, for the candidates that passed
+  // what align_kernel needs besides the geometry above, so that a job is ONE read of its slab's head:
+  uint8_t qmask[MAX_L];   // IUPAC set of each query row (GuideDev::qmask of the job's guide)
+  int32_t min_score;      // GuideDev::min_guide_score
+  uint32_t sel;           // candidate columns of the record's 16-base word that lie inside this window (bit b = base b)
+  int32_t jbase;          // strand-space column of bit 0: j = jbase + b (dir 0) or jbase - b (dir 1)
+  int32_t reserved[5];
 };
 static_assert(sizeof(SlabHeader) == 128, "slab header layout");
 

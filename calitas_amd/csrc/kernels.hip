@@ -268,7 +268,7 @@ constexpr int NEG = -(1 << 20);                      // "minus infinity" that su
 // per wave: flush threshold + the most one record iteration can add (jobs x 8 windows x 16 candidates; x 3 when every matrix
 // of a cell is an alignment of its own)
 constexpr int STAGE_FLUSH = 16;
-template <bool PM, int LPJ> constexpr int ITEM_STAGE = STAGE_FLUSH + (PM ? 3 : 1) * (64 / LPJ) * 8 * 16;
+template <bool PM, int LPJ> constexpr int ITEM_STAGE = STAGE_FLUSH + (PM ? 3 : 1) * (64 / LPJ) * 16;
 constexpr int TB_LEN = STRIP_MAX_COLS + 48;          // strip columns + gap + PAM look-ahead
 constexpr int TRACE_STAGE = 384;                     // RawAln records staged in LDS per trace_kernel workgroup
 constexpr int TR_STRIDE = 100;                       // bytes per trace row (>= STRIP_MAX_COLS + 4, word aligned; lane r writes byte 99r + t)
@@ -282,37 +282,192 @@ __device__ __forceinline__ int comp_mask4(int m) {  // IUPAC set of the compleme
   return ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3);
 }
 
-// target_mask() of the base at contig offset pos (dir 0) or of its complement (dir 1)
-__device__ int fetch_tmask(const AlignArgs& a, uint64_t gpos, int dir) {
-  uint32_t code = (a.codes[gpos >> 4] >> ((gpos & 15) * 2)) & 3u;
-  uint32_t exc = (a.mask[gpos >> 5] >> (gpos & 31)) & 1u;
+// ------------------------------------------------------------------------------------------------------------------
+// expand_kernel: scan records -> aligner jobs.
+//
+// Round 5.  align_kernel used to start every record with a chain of five dependent global loads (record -> tile -> contig -> window
+// table base -> window bounds) and then fetched the strip's bases column by column: its waves stood in s_waitcnt half their time
+// (profiles/r05_pmc_tail_before.txt: SQ_WAIT_ANY 51 % of SQ_WAVE_CYCLES at one or two waves per SIMD) with registers and LDS held
+// all the while.  Here that chain runs ONCE per record with a lane per record -- 64 independent chains per wave, thousands of waves --,
+// every (record, window) that holds candidate columns gets a number (one atomic per wave and round), and sixteen lanes per job write
+// the head of the job's slab: geometry, the guide's row sets, and the strip's target masks decoded from the packed reference (two code
+// words and two mask words per sixteen columns; run lookups for exception bases).  align_kernel then needs one 16-byte load per lane
+// per job, from an address that depends on nothing but the job's number.
+// ------------------------------------------------------------------------------------------------------------------
+struct JobSeed {           // phase A -> phase B, through LDS: the job's header words and where its strip starts in the packed reference
+  uint32_t contig, window_k, n, c0;
+  uint32_t cols;           // ncols | ntb << 16
+  uint32_t what;           // dir | guide << 8 | true_border << 16 | L << 24
+  uint32_t sel;            // the candidate columns inside the window (bits of the record's 16-base word)
+  int32_t jbase;
+  uint64_t gpos0;          // packed position of strip column c0 + 1 (tb[0]); the columns go up from there (dir 0) or down (dir 1)
+};
+
+__device__ __forceinline__ int tmask_at(const Run* runs, int64_t n_runs, uint64_t gpos, uint32_t code, uint32_t exc, int dir) {
   int m;
   if (!exc) {
     m = 1 << code;
   } else {
-    int64_t r = run_floor(a.runs, a.n_runs, gpos);
+    int64_t r = run_floor(runs, n_runs, gpos);
     uint8_t ch = 0;
-    if (r >= 0 && gpos < a.runs[r].start + a.runs[r].len) ch = a.runs[r].ch;
+    if (r >= 0 && gpos < runs[r].start + runs[r].len) ch = runs[r].ch;
     m = target_mask(ch);
   }
   if (dir) m = (m & 16) | comp_mask4(m & 15);
   return m;
 }
 
+__global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
+  CALITAS_TAIL_PRIO();
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[0] = (unsigned long long)wall_clock64();   // (binned.hpp, BIN_BOX_STAMPS)
+  __shared__ JobSeed s_seed[4][64];
+  __shared__ int s_gint[MAX_GUIDES][4];                           // L, span, min_guide_score, cli_length
+  __shared__ __attribute__((aligned(16))) uint8_t s_qmask[MAX_GUIDES][MAX_L];
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  for (int i = (int)threadIdx.x; i < a.sp.n_guides; i += (int)blockDim.x) {
+    s_gint[i][0] = a.guides[i].L; s_gint[i][1] = a.guides[i].span; s_gint[i][2] = a.guides[i].min_guide_score; s_gint[i][3] = a.guides[i].cli_length;
+  }
+  for (int i = (int)threadIdx.x; i < a.sp.n_guides * (MAX_L / 4); i += (int)blockDim.x)
+    reinterpret_cast<uint32_t*>(s_qmask[i / (MAX_L / 4)])[i % (MAX_L / 4)] = reinterpret_cast<const uint32_t*>(a.guides[i / (MAX_L / 4)].qmask)[i % (MAX_L / 4)];
+  __syncthreads();
+  uint32_t n_recs = *a.rec_count;
+  if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
+  const uint64_t job_capacity = (uint64_t)a.rec_capacity * a.slots_per_rec;
+  const SearchDev& sp = a.sp;
+  const int W = sp.window_size, step = sp.step;
+  const uint32_t n_waves = gridDim.x * 4u;
+  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 64u; base < n_recs; base += n_waves * 64u) {   // (wave-uniform)
+    // ---- phase A: a lane per record ----
+    const uint32_t ri = base + (uint32_t)lane;
+    ScanRecord rec{0u, 0u};
+    if (ri < n_recs) rec = a.recs[ri];
+    const uint32_t cmask = rec.info & 0xFFFFu;
+    const int dir = (int)((rec.info >> 16) & 1u), gi = (int)((rec.info >> 17) & 0x7Fu);
+    uint32_t contig = 0;
+    uint64_t gbase = 0, win_lo = 0, win_cnt = 0;
+    int L = 0, span = 0, g_cli = 0;
+    int64_t p0 = 0, knext = 0, khi = -1, klo = 0;
+    int first = 0, last = 0;
+    if (cmask != 0u && gi < sp.n_guides) {
+      L = s_gint[gi][0]; span = s_gint[gi][1]; g_cli = s_gint[gi][3];
+      contig = a.tiles[rec.gword / a.tile_words].contig;
+      gbase = a.contigs[contig].gbase;
+      const uint64_t clen = a.contigs[contig].len;
+      win_lo = a.win_base[contig]; win_cnt = a.win_base[contig + 1] - win_lo;
+      p0 = (int64_t)((uint64_t)rec.gword * 16 - gbase);          // contig offset of bit 0
+      first = __ffs(cmask) - 1; last = 31 - __clz(cmask);
+      const int64_t plo = p0 + first, phi = p0 + last;
+      klo = (plo - W + 1 + step - 1) / step;                      // ceil((plo - W + 1) / step) for a positive numerator
+      if (plo - W + 1 <= 0) klo = 0;
+      khi = phi / step;
+      knext = klo;
+      if ((uint64_t)plo >= clen) khi = -1;                        // only padding columns: they belong to no window
+    }
+    // rounds: in round s every record contributes its s-th window with candidate columns (nearly always one round, sometimes two)
+    for (;;) {
+      bool have = false;
+      JobSeed seed{};
+      while (knext <= khi) {
+        const int64_t k = knext++;
+        if (k - klo >= (int64_t)a.slots_per_rec) { knext = khi + 1; break; }   // cannot happen: the host sizes slots_per_rec from the tiling
+        if ((uint64_t)k >= win_cnt) continue;                     // no such window on this contig (Range(0, len-1, step), SR:52)
+        if (win_lo + (uint64_t)k < a.gw_lo || win_lo + (uint64_t)k >= a.gw_hi) continue;   // outside this call's window range
+        const int2 wab = a.win[win_lo + (uint64_t)k];             // N-trimmed bounds, precomputed by window_table_kernel
+        const int64_t wa = wab.x, wb = wab.y;
+        const int n = (int)(wb - wa);
+        if (n < g_cli) continue;                                  // SearchReference.scala:536
+        // candidate columns of this word that fall inside the window
+        uint32_t sel = 0;
+        for (int b = first; b <= last; b++) if ((cmask >> b) & 1u) { const int64_t p = p0 + b; if (p >= wa && p < wb) sel |= 1u << b; }
+        if (!sel) continue;
+        const int sfirst = __ffs(sel) - 1, slast = 31 - __clz(sel);
+        int jmin, jmax, jb;                                       // strand-space columns (1-based)
+        if (dir == 0) { jmin = (int)(p0 + sfirst - wa) + 1; jmax = (int)(p0 + slast - wa) + 1; jb = (int)(p0 - wa) + 1; }
+        else          { jmin = (int)(wb - (p0 + slast));    jmax = (int)(wb - (p0 + sfirst)); jb = (int)(wb - p0); }
+        int c0 = jmin - span - 1;
+        if (c0 < 0) c0 = 0;
+        const int ncols = jmax - c0;                              // <= 16 + span + 1 <= STRIP_MAX_COLS (host-checked)
+        int look = jmax + sp.max_gaps + MAX_PAM_LEN;              // PAM look-ahead, clipped to the window
+        if (look > n) look = n;
+        const int ntb = look - c0;                                // tb[x] = column c0 + 1 + x
+        seed.contig = contig; seed.window_k = (uint32_t)k; seed.n = (uint32_t)n; seed.c0 = (uint32_t)c0;
+        seed.cols = (uint32_t)ncols | ((uint32_t)ntb << 16);
+        seed.what = (uint32_t)dir | ((uint32_t)gi << 8) | ((c0 == 0 ? 1u : 0u) << 16) | ((uint32_t)L << 24);
+        seed.sel = sel; seed.jbase = jb;
+        seed.gpos0 = gbase + (uint64_t)(dir ? wb - c0 - 1 : wa + c0);
+        have = true;
+        break;
+      }
+      const unsigned long long bal = __ballot(have);
+      if (bal == 0ull) break;
+      const uint32_t nj = (uint32_t)__popcll(bal), rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      const int leader = __ffsll((long long)bal) - 1;
+      uint32_t jbase0 = 0;
+      if (lane == leader) jbase0 = atomicAdd(a.job_count, nj);
+      jbase0 = (uint32_t)__shfl((int)jbase0, leader);
+      if (have) s_seed[wave][rank] = seed;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- phase B: eight lanes per job write the head of its slab.  Lane c of the eight decodes the target masks of columns
+      //      16 c .. 16 c + 15 (a strip has 45-60 of them at d = 5; TB_LEN = 144 at most: lane 0 then takes the ninth piece too) and
+      //      the lanes from the other end write the header's pieces. ----
+      const int s8 = lane & 7;
+      for (uint32_t q0 = 0; q0 < nj; q0 += 8u) {
+        const uint32_t q = q0 + (uint32_t)(lane >> 3);
+        if (q >= nj || (uint64_t)jbase0 + q >= job_capacity) continue;
+        const JobSeed sd = s_seed[wave][q];
+        const int ntb = (int)(sd.cols >> 16), ncols = (int)(sd.cols & 0xFFFFu), d2 = (int)(sd.what & 1u), g2 = (int)((sd.what >> 8) & 0xFFu);
+        uint8_t* slab = a.slab + ((uint64_t)jbase0 + q) * a.slab_bytes;
+        for (int x0 = s8 * 16; x0 < ntb; x0 += 128) {
+          const int nv = min(16, ntb - x0);
+          const uint64_t pfirst = d2 ? sd.gpos0 - (uint64_t)x0 : sd.gpos0 + (uint64_t)x0;
+          const uint64_t plo = d2 ? pfirst - (uint64_t)(nv - 1) : pfirst, phi = plo + (uint64_t)(nv - 1);
+          const uint32_t cw0 = a.codes[plo >> 4], cw1 = a.codes[phi >> 4], mw0 = a.mask[plo >> 5], mw1 = a.mask[phi >> 5];
+          uint32_t w4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            if (i < nv) {
+              const uint64_t gp = d2 ? pfirst - (uint64_t)i : pfirst + (uint64_t)i;
+              const uint32_t cw = (gp >> 4) == (plo >> 4) ? cw0 : cw1, mw = (gp >> 5) == (plo >> 5) ? mw0 : mw1;
+              const int tm = tmask_at(a.runs, a.n_runs, gp, (cw >> ((gp & 15) * 2)) & 3u, (mw >> (gp & 31)) & 1u, d2);
+              w4[i >> 2] |= (uint32_t)tm << ((i & 3) * 8);
+            }
+          }
+          *reinterpret_cast<uint4*>(slab + sizeof(SlabHeader) + x0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        uint4* head = reinterpret_cast<uint4*>(slab);
+        if (s8 == 7) head[0] = make_uint4(0u, sd.contig, sd.window_k, sd.n);
+        else if (s8 == 6) head[1] = make_uint4(sd.c0, sd.cols, sd.what, (uint32_t)((ncols + 4) & ~3));
+        else if (s8 == 5) head[4] = reinterpret_cast<const uint4*>(s_qmask[g2])[0];
+        else if (s8 == 4) head[5] = reinterpret_cast<const uint4*>(s_qmask[g2])[1];
+        else if (s8 == 3) head[6] = make_uint4((uint32_t)s_gint[g2][2], sd.sel, (uint32_t)sd.jbase, 0u);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // PM: the per-matrix reading of fgbio's enumeration.  A template parameter, not a run-time branch: its LDS
-// (s_fin3, the larger item stage) would cost the default reading a workgroup per CU (43 -> 66 KB: 153 -> 243 us per launch).
+// (s_fin3, the larger item stage) would cost the default reading occupancy.
+// A job's inputs are the head of its slab as expand_kernel wrote it: 128 bytes of header + TB_LEN bytes of target masks = 17 x 16
+// bytes, lane x of the job's lanes loading piece x -- for the NEXT job while this one is being filled, so the load's latency hides
+// behind the fill and the wave never waits on a chain of dependent loads.
+constexpr int JOB_HEAD16 = (int)(sizeof(SlabHeader) + TB_LEN) / 16;
+static_assert((sizeof(SlabHeader) + TB_LEN) % 16 == 0 && JOB_HEAD16 <= 21, "one 16-byte piece of a job's head per lane of the job");
+
 template <bool PM, int LPJ>
 __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
   CALITAS_TAIL_PRIO();
-  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[0] = (unsigned long long)wall_clock64();   // (binned.hpp, BIN_BOX_STAMPS)
   static_assert(LPJ == 32 || LPJ == 21, "two or three jobs per wave");
   constexpr int JOBS = 64 / LPJ;            // jobs per wave (= per workgroup)
   constexpr int ROWS = LPJ == 32 ? MAX_L : LPJ - 1;   // rows a job can have
   constexpr int STAGE = ITEM_STAGE<PM, LPJ>;
   // trace rows are 100 bytes apart: lane r writes byte 99r + t at step t, which spreads the lanes of a job over the banks
   __shared__ __attribute__((aligned(16))) uint8_t s_tr[JOBS][ROWS][TR_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint8_t s_tb[JOBS][TB_LEN];
-  __shared__ __attribute__((aligned(16))) uint8_t s_tbm[JOBS][TB_LEN];
+  __shared__ __attribute__((aligned(16))) uint8_t s_hd[JOBS][sizeof(SlabHeader)];   // the job's header as it came
+  __shared__ __attribute__((aligned(16))) uint8_t s_tbm[JOBS][TB_LEN];              // the bases a column matches (none for an N)
   __shared__ int s_fin[JOBS][STRIP_MAX_COLS + 1];
   __shared__ int s_fin3[PM ? JOBS : 1][3][PM ? STRIP_MAX_COLS + 1 : 1];   // per-matrix enumeration only: Diag / Left / Up of the bottom row
   // passing candidates are staged per wave and appended to a.items with one global atomic per flush: trace_kernel then
@@ -324,7 +479,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
   const int wave = 0, wlane = threadIdx.x & 63;
   if (wlane == 0) s_nitems[wave] = 0;
   __syncthreads();
-  // all lanes of the wave that are still in the record loop call this together
+  // all lanes of the wave that are still in the job loop call this together
   auto flush_items = [&](uint32_t threshold) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -347,78 +502,45 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   };
-  uint8_t (*tr)[TR_STRIDE] = s_tr[job];
-  uint8_t* tb = s_tb[job];
-  uint8_t* tbm = s_tbm[job];
-  int* fin = s_fin[job];
-  int (*fin3)[PM ? STRIP_MAX_COLS + 1 : 1] = s_fin3[PM ? job : 0];
+  uint8_t (*tr)[TR_STRIDE] = s_tr[job < JOBS ? job : 0];
+  uint8_t* tbm = s_tbm[job < JOBS ? job : 0];
+  const uint32_t* hd32 = reinterpret_cast<const uint32_t*>(s_hd[job < JOBS ? job : 0]);
+  int* fin = s_fin[job < JOBS ? job : 0];
+  int (*fin3)[PM ? STRIP_MAX_COLS + 1 : 1] = s_fin3[PM ? (job < JOBS ? job : 0) : 0];
 
-  uint32_t n_recs = *a.rec_count;
-  if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
+  uint64_t n_jobs = *a.job_count;
+  { const uint64_t cap = (uint64_t)a.rec_capacity * a.slots_per_rec; if (n_jobs > cap) n_jobs = cap; }
   const SearchDev& sp = a.sp;
-  const int W = sp.window_size, step = sp.step;
 
   const uint32_t total_jobs = gridDim.x * JOBS;
   // (lane 63 of a three-job wave belongs to no job)
-  for (uint32_t ri = job < JOBS ? blockIdx.x * JOBS + (uint32_t)job : n_recs; ri < n_recs; ri += total_jobs) {
-    flush_items(STAGE_FLUSH);                // a record adds at most 2 jobs x 8 windows x 16 candidates per wave
-    const ScanRecord rec = a.recs[ri];
-    const uint32_t cmask = rec.info & 0xFFFFu;
-    const int dir = (rec.info >> 16) & 1;
-    const int gi = (rec.info >> 17) & 0x7F;
-    const GuideDev& g = a.guides[gi];
-    const int L = g.L, span = g.span, g_min_score = g.min_guide_score, g_cli = g.cli_length;
-    const uint32_t tile = rec.gword / a.tile_words;
-    const uint32_t contig = a.tiles[tile].contig;
-    const uint64_t gbase = a.contigs[contig].gbase, clen = a.contigs[contig].len;
-    const uint64_t win_lo = a.win_base[contig], win_cnt = a.win_base[contig + 1] - win_lo;
-    const int64_t p0 = (int64_t)((uint64_t)rec.gword * 16 - gbase);   // contig offset of bit 0
-    const int first = __ffs(cmask) - 1, last = 31 - __clz(cmask);
-    const int64_t plo = p0 + first, phi = p0 + last;
-    int64_t klo = (plo - W + 1 + step - 1) / step;  // ceil((plo - W + 1) / step) for positive numerator
-    if (plo - W + 1 <= 0) klo = 0;
-    int64_t khi = phi / step;
-    const int qm = (r < L) ? g.qmask[r] : 0;
-    // every slot of this record starts empty; a window that yields candidates overwrites its slot's header below
-    if (r < (int)a.slots_per_rec)
-      reinterpret_cast<SlabHeader*>(a.slab + ((uint64_t)ri * a.slots_per_rec + (uint64_t)r) * a.slab_bytes)->pass_mask = 0u;
-
-    if ((uint64_t)plo >= clen) continue;  // only padding columns: they belong to no window
-    for (int64_t k = klo; k <= khi; k++) {
-      if (k - klo >= (int64_t)a.slots_per_rec) break;   // cannot happen: the host sizes slots_per_rec from the tiling
-      if ((uint64_t)k >= win_cnt) continue;            // no such window on this contig (Range(0, len-1, step), SR:52)
-      if (win_lo + (uint64_t)k < a.gw_lo || win_lo + (uint64_t)k >= a.gw_hi) continue;   // outside this call's window range
-      const int2 wab = a.win[win_lo + (uint64_t)k];     // N-trimmed bounds, precomputed by window_table_kernel
-      const int64_t wa = wab.x, wb = wab.y;
-      const int n = (int)(wb - wa);
-      if (n < g_cli) continue;                         // SearchReference.scala:536
-      // candidate columns of this word that fall inside the window, as strand-space columns
-      uint32_t sel = 0;
-      for (int b = first; b <= last; b++) if ((cmask >> b) & 1u) { int64_t p = p0 + b; if (p >= wa && p < wb) sel |= 1u << b; }
-      if (!sel) continue;
-      const int sfirst = __ffs(sel) - 1, slast = 31 - __clz(sel);
-      int jmin, jmax;
-      if (dir == 0) { jmin = (int)(p0 + sfirst - wa) + 1; jmax = (int)(p0 + slast - wa) + 1; }
-      else          { jmin = (int)(wb - (p0 + slast));    jmax = (int)(wb - (p0 + sfirst)); }
-      int c0 = jmin - span - 1;
-      if (c0 < 0) c0 = 0;
-      const bool true_border = (c0 == 0);
-      const int ncols = jmax - c0;                            // <= 16 + span + 1 <= STRIP_MAX_COLS (host-checked)
-      int look = jmax + sp.max_gaps + MAX_PAM_LEN;            // PAM look-ahead, clipped to the window
-      if (look > n) look = n;
-      const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
-
-      // ---- stage target masks: tb[] as trace_kernel reads them, tbm[] = the bases a column matches (none for an N) ----
-      for (int x = r; x < ntb; x += LPJ) {
-        int col = c0 + 1 + x;                                 // 1-based strand-space column
-        int64_t pos = dir ? (wb - col) : (wa + col - 1);
-        const int tm = fetch_tmask(a, gbase + (uint64_t)pos, dir);
-        tb[x] = (uint8_t)tm;
-        tbm[x] = (uint8_t)((tm & 16) ? 0 : (tm & 15));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint64_t ji = job < JOBS ? (uint64_t)blockIdx.x * JOBS + (uint64_t)job : n_jobs;
+  uint4 pf = make_uint4(0u, 0u, 0u, 0u);                       // piece r of the head of the job's slab, loaded a job ahead
+  if (ji < n_jobs && r < JOB_HEAD16) pf = reinterpret_cast<const uint4*>(a.slab + ji * a.slab_bytes)[r];
+  for (; ji < n_jobs; ji += total_jobs) {
+    flush_items(STAGE_FLUSH);                // a job adds at most 16 candidates (x 3 per-matrix) per job of the wave
+    // ---- stage the job's head in LDS: header as it is, target masks as "the bases this column matches" ----
+    if (r < (int)(sizeof(SlabHeader) / 16)) {
+      reinterpret_cast<uint4*>(s_hd[job])[r] = pf;
+    } else if (r < JOB_HEAD16) {
+      // tb byte: bits 0-3 IUPAC set, bit 4 forced mismatch (N) -> tbm byte: the set, or nothing when forced
+      auto conv = [](uint32_t t) { const uint32_t f = (t >> 4) & 0x01010101u; return t & 0x0F0F0F0Fu & ~(f * 0xFFu); };
+      reinterpret_cast<uint4*>(tbm)[r - (int)(sizeof(SlabHeader) / 16)] = make_uint4(conv(pf.x), conv(pf.y), conv(pf.z), conv(pf.w));
+    }
+    if (ji + total_jobs < n_jobs && r < JOB_HEAD16) pf = reinterpret_cast<const uint4*>(a.slab + (ji + total_jobs) * a.slab_bytes)[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int c0 = (int)hd32[4];
+      const int ncols = (int)(hd32[5] & 0xFFFFu), ntb = (int)(hd32[5] >> 16);
+      const int dir = (int)(hd32[6] & 0xFFu), L = (int)(hd32[6] >> 24);
+      const bool true_border = ((hd32[6] >> 16) & 0xFFu) != 0u;
+      const int g_min_score = (int)hd32[24];
+      const uint32_t sel = hd32[25];
+      const int jb = (int)hd32[26];
+      const int qm = (r < L) ? (int)reinterpret_cast<const uint8_t*>(hd32 + 16)[r] : 0;
+      (void)ntb;
 
       // ---- fill: antidiagonal wavefront, lane r = row r+1 ----
       // A cell of a matrix is kept as score * 4 + the matrix's code (TR_DIAG 2 > TR_LEFT 1 > TR_UP 0): the max of two cells breaks
@@ -486,10 +608,11 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
       // ---- hand the strip over to trace_kernel: one candidate descriptor per passing end column, plus the strip's
-      //      trace matrix and target masks copied from LDS into a slab in HBM (one slab per record x window) ----
+      //      trace matrix copied from LDS into the job's slab (its target masks are there already) ----
       // lane x takes the x-th selected bit in ascending strand-space column order
       int myb = -1;
       {
+        const int sfirst = __ffs(sel) - 1, slast = 31 - __clz(sel);
         int cnt = 0;
         if (dir == 0) { for (int b = sfirst; b <= slast; b++) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
         else          { for (int b = slast; b >= sfirst; b--) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
@@ -499,7 +622,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
       uint32_t pm_pass = 0;                                            // per-matrix enumeration: bit k = matrix k (Diag, Left, Up) passes
       bool pass = false;
       if (myb >= 0) {
-        j = dir ? (int)(wb - (p0 + myb)) : (int)(p0 + myb - wa) + 1;   // strand-space end column
+        j = dir ? jb - myb : jb + myb;                                 // strand-space end column
         P = fin[j - c0];
         if (PM) {                                                      // every bottom-row cell >= minScore is an alignment of its own
 #pragma unroll
@@ -512,20 +635,15 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
       const unsigned long long bal = __ballot(pass);
       const uint32_t mine = (uint32_t)(bal >> (job * LPJ)) & 0xFFFFu;  // this job's lanes (only lanes 0..15 can pass)
       if (mine != 0u) {
-        uint8_t* slab = a.slab + ((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) * a.slab_bytes;
+        uint8_t* slab = a.slab + ji * a.slab_bytes;
         SlabHeader* hd = reinterpret_cast<SlabHeader*>(slab);
         const int stride = (ncols + 4) & ~3;                           // bytes per trace row in the slab (columns 0..ncols)
         const uint32_t tb_bytes = (uint32_t)((ntb + 3) & ~3);
-        if (r == 0) {
-          hd->contig = contig; hd->window_k = (uint32_t)k; hd->n = n; hd->c0 = c0; hd->ncols = (uint16_t)ncols; hd->ntb = (uint16_t)ntb;
-          hd->dir = (uint8_t)dir; hd->guide = (uint8_t)gi; hd->true_border = true_border ? 1 : 0; hd->L = (uint8_t)L;
-          hd->stride = (uint16_t)stride; hd->pad = 0;
-          hd->pass_mask = mine;
-        }
+        if (r == 0) hd->pass_mask = mine;
         if (pass) {
-          hd->j[r] = (uint16_t)j; hd->best[r] = P;
+          hd->j[r] = (uint16_t)j;
           // item = candidate slot | slab index << 4 | start matrix << 40 | (score + 2^21) << 42
-          const uint64_t where = ((((uint64_t)ri * a.slots_per_rec + (uint64_t)(k - klo)) & 0xFFFFFFFFFull) << 4) | (uint64_t)r;
+          const uint64_t where = ((ji & 0xFFFFFFFFFull) << 4) | (uint64_t)r;
           if (PM) {
             constexpr int code[3] = {TR_DIAG, TR_LEFT, TR_UP};         // fgbio's order of directions
 #pragma unroll
@@ -539,9 +657,6 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
             if (slot < (uint32_t)STAGE) s_items[wave][slot] = where | ((uint64_t)(P & 3) << 40) | ((uint64_t)(uint32_t)((P >> 2) + (1 << 21)) << 42);
           }
         }
-        uint32_t* dtb = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader));
-        const uint32_t* stb = reinterpret_cast<const uint32_t*>(tb);
-        for (uint32_t x = r; x < tb_bytes / 4; x += LPJ) dtb[x] = stb[x];
         if (r < L) {
           uint32_t* drow = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader) + tb_bytes + (uint32_t)(r * stride));
           const uint32_t* srow = reinterpret_cast<const uint32_t*>(&tr[r][0]);
@@ -880,6 +995,9 @@ hipError_t launch_lane_setup(const LaneSetupArgs& a, hipStream_t stream) {
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream) {
   // n_blocks counts 256-lane units (8 jobs)
   const dim3 grid(n_blocks * 4), block(64);                  // one wave per workgroup
+  // scan records -> jobs: a lane per record, 256-lane workgroups striding over the records (their number is on the device)
+  const uint32_t expand_blocks = std::max<uint32_t>(1u, std::min<uint32_t>(1024u, (a.rec_capacity + 255u) / 256u));
+  hipLaunchKernelGGL(expand_kernel, dim3(expand_blocks), dim3(256), 0, stream, a);
   // three jobs per wave when no guide has more than 20 rows (max_guide_len 0: unknown)
   bool three = a.max_guide_len > 0 && a.max_guide_len <= 20;
   if (const char* env = TUNE_GET("CALITAS_ALIGN_LPJ")) three = three && std::atoi(env) == 21;   // (tests / measurements: 32 forces two jobs)

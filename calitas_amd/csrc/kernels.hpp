@@ -39,7 +39,8 @@ struct AlignArgs {
   uint32_t* out_count;
   uint32_t* anomalies;
   uint32_t* trace_done;     // trace_kernel: workgroups finished (zero at launch); the last one posts the counters to the mailbox
-  uint8_t* slab;            // strips handed from align_kernel to trace_kernel: rec_capacity x slots_per_rec slabs
+  uint8_t* slab;            // one slab per aligner job (SlabHeader): rec_capacity x slots_per_rec of them
+  uint32_t* job_count;      // jobs numbered by expand_kernel (zero at launch)
   uint32_t* cand_count;     // statistics only
   uint64_t* items;          // passing candidates, (slab index << 4 | candidate slot): align_kernel appends, trace_kernel consumes
   uint32_t* item_count;
@@ -86,6 +87,7 @@ hipError_t launch_scan(const ScanArgs& a, int chunk, uint32_t n_tiles, hipStream
 // scan_rows.hip: the row-wise scan (default) and the one-off conversion codes[] -> planes[] at upload time
 hipError_t launch_scan_rows(const ScanArgs& a, int chunk, int warm_words, uint32_t n_tiles, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_planes(const uint32_t* codes, uint2* planes, uint64_t n32, hipStream_t stream);
+// expand_kernel (scan records -> aligner jobs, their slabs' heads written) + align_kernel
 hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream);
 // post: the kernel's last workgroup publishes the eight counters at a.rec_count to that mailbox (mailbox.hpp) -- wait for it with mailbox_wait
 hipError_t launch_trace(const AlignArgs& a, uint32_t n_blocks, hipStream_t stream, hipEvent_t stop = nullptr, Mailbox* post = nullptr);

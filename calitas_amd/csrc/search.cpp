@@ -325,7 +325,7 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.codes = o->d_codes; aa.mask = o->d_mask; aa.runs = o->d_runs; aa.n_runs = (int64_t)ref.runs.size();
   aa.contigs = o->d_contigs; aa.tiles = o->d_tiles; aa.win_base = o->d_win_base; aa.win = o->d_win; aa.guides = ctx->d_guides; aa.recs = ctx->d_recs;
   aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
-  aa.trace_done = ctx->d_counters + 5;
+  aa.trace_done = ctx->d_counters + 5; aa.job_count = ctx->d_counters + 6;
   for (int g = 0; g < pl.n_guides; g++) aa.max_guide_len = std::max<int32_t>(aa.max_guide_len, pl.gd[g].L);
   aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
   aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
