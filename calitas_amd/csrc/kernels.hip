@@ -335,8 +335,8 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
   const uint64_t job_capacity = (uint64_t)a.rec_capacity * a.slots_per_rec;
   const SearchDev& sp = a.sp;
   const int W = sp.window_size, step = sp.step;
-  const uint32_t n_waves = gridDim.x * 4u;
-  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 64u; base < n_recs; base += n_waves * 64u) {   // (wave-uniform)
+  const uint32_t wpb = blockDim.x / 64u, n_waves = gridDim.x * wpb;
+  for (uint32_t base = (blockIdx.x * wpb + (uint32_t)wave) * 64u; base < n_recs; base += n_waves * 64u) {   // (wave-uniform)
     // ---- phase A: a lane per record ----
     const uint32_t ri = base + (uint32_t)lane;
     ScanRecord rec{0u, 0u};
@@ -346,8 +346,7 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
     uint32_t contig = 0;
     uint64_t gbase = 0, win_lo = 0, win_cnt = 0;
     int L = 0, span = 0, g_cli = 0;
-    int64_t p0 = 0, knext = 0, khi = -1, klo = 0;
-    int first = 0, last = 0;
+    int64_t p0 = 0, khi = -1, klo = 0;
     if (cmask != 0u && gi < sp.n_guides) {
       L = s_gint[gi][0]; span = s_gint[gi][1]; g_cli = s_gint[gi][3];
       contig = a.tiles[rec.gword / a.tile_words].contig;
@@ -355,51 +354,52 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
       const uint64_t clen = a.contigs[contig].len;
       win_lo = a.win_base[contig]; win_cnt = a.win_base[contig + 1] - win_lo;
       p0 = (int64_t)((uint64_t)rec.gword * 16 - gbase);          // contig offset of bit 0
-      first = __ffs(cmask) - 1; last = 31 - __clz(cmask);
-      const int64_t plo = p0 + first, phi = p0 + last;
+      const int64_t plo = p0 + (__ffs(cmask) - 1), phi = p0 + (31 - __clz(cmask));
       klo = (plo - W + 1 + step - 1) / step;                      // ceil((plo - W + 1) / step) for a positive numerator
       if (plo - W + 1 <= 0) klo = 0;
       khi = phi / step;
-      knext = klo;
       if ((uint64_t)plo >= clen) khi = -1;                        // only padding columns: they belong to no window
     }
-    // rounds: in round s every record contributes its s-th window with candidate columns (nearly always one round, sometimes two)
-    for (;;) {
+    // Rounds: round s looks at window klo + s of every record -- a record's candidate columns fall into at most slots_per_rec windows
+    // (two with the usual tiling), so this is a loop with a trip count the whole grid shares, and the ballot below is taken in
+    // straight-line code.  (A first version let every lane walk to its next window with candidate columns in a `while` with `break`s
+    // and took the ballot behind it: the compiler kept the lanes that left the loop empty-handed apart from the others, their ballot
+    // came out empty, they left -- and the jobs that phase B hands to THEIR lanes were never written: stale slab heads, at random.)
+    for (int round = 0; round < (int)a.slots_per_rec; round++) {
       bool have = false;
       JobSeed seed{};
-      while (knext <= khi) {
-        const int64_t k = knext++;
-        if (k - klo >= (int64_t)a.slots_per_rec) { knext = khi + 1; break; }   // cannot happen: the host sizes slots_per_rec from the tiling
-        if ((uint64_t)k >= win_cnt) continue;                     // no such window on this contig (Range(0, len-1, step), SR:52)
-        if (win_lo + (uint64_t)k < a.gw_lo || win_lo + (uint64_t)k >= a.gw_hi) continue;   // outside this call's window range
-        const int2 wab = a.win[win_lo + (uint64_t)k];             // N-trimmed bounds, precomputed by window_table_kernel
+      const int64_t k = klo + round;
+      int2 wab = make_int2(0, 0);
+      const bool in_range = k <= khi && (uint64_t)k < win_cnt &&                 // (no such window on this contig: Range(0, len-1, step), SR:52)
+                            win_lo + (uint64_t)k >= a.gw_lo && win_lo + (uint64_t)k < a.gw_hi;   // (outside this call's window range)
+      if (in_range) wab = a.win[win_lo + (uint64_t)k];            // N-trimmed bounds, precomputed by window_table_kernel
+      {
         const int64_t wa = wab.x, wb = wab.y;
         const int n = (int)(wb - wa);
-        if (n < g_cli) continue;                                  // SearchReference.scala:536
         // candidate columns of this word that fall inside the window
         uint32_t sel = 0;
-        for (int b = first; b <= last; b++) if ((cmask >> b) & 1u) { const int64_t p = p0 + b; if (p >= wa && p < wb) sel |= 1u << b; }
-        if (!sel) continue;
-        const int sfirst = __ffs(sel) - 1, slast = 31 - __clz(sel);
-        int jmin, jmax, jb;                                       // strand-space columns (1-based)
-        if (dir == 0) { jmin = (int)(p0 + sfirst - wa) + 1; jmax = (int)(p0 + slast - wa) + 1; jb = (int)(p0 - wa) + 1; }
-        else          { jmin = (int)(wb - (p0 + slast));    jmax = (int)(wb - (p0 + sfirst)); jb = (int)(wb - p0); }
-        int c0 = jmin - span - 1;
-        if (c0 < 0) c0 = 0;
-        const int ncols = jmax - c0;                              // <= 16 + span + 1 <= STRIP_MAX_COLS (host-checked)
-        int look = jmax + sp.max_gaps + MAX_PAM_LEN;              // PAM look-ahead, clipped to the window
-        if (look > n) look = n;
-        const int ntb = look - c0;                                // tb[x] = column c0 + 1 + x
-        seed.contig = contig; seed.window_k = (uint32_t)k; seed.n = (uint32_t)n; seed.c0 = (uint32_t)c0;
-        seed.cols = (uint32_t)ncols | ((uint32_t)ntb << 16);
-        seed.what = (uint32_t)dir | ((uint32_t)gi << 8) | ((c0 == 0 ? 1u : 0u) << 16) | ((uint32_t)L << 24);
-        seed.sel = sel; seed.jbase = jb;
-        seed.gpos0 = gbase + (uint64_t)(dir ? wb - c0 - 1 : wa + c0);
-        have = true;
-        break;
+        for (int b = 0; b < 16; b++) if ((cmask >> b) & 1u) { const int64_t p = p0 + b; if (p >= wa && p < wb) sel |= 1u << b; }
+        if (in_range && n >= g_cli && sel != 0u) {                // (n < g_cli: SearchReference.scala:536)
+          const int sfirst = __ffs(sel) - 1, slast = 31 - __clz(sel);
+          int jmin, jmax, jb;                                     // strand-space columns (1-based)
+          if (dir == 0) { jmin = (int)(p0 + sfirst - wa) + 1; jmax = (int)(p0 + slast - wa) + 1; jb = (int)(p0 - wa) + 1; }
+          else          { jmin = (int)(wb - (p0 + slast));    jmax = (int)(wb - (p0 + sfirst)); jb = (int)(wb - p0); }
+          int c0 = jmin - span - 1;
+          if (c0 < 0) c0 = 0;
+          const int ncols = jmax - c0;                            // <= 16 + span + 1 <= STRIP_MAX_COLS (host-checked)
+          int look = jmax + sp.max_gaps + MAX_PAM_LEN;            // PAM look-ahead, clipped to the window
+          if (look > n) look = n;
+          const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
+          seed.contig = contig; seed.window_k = (uint32_t)k; seed.n = (uint32_t)n; seed.c0 = (uint32_t)c0;
+          seed.cols = (uint32_t)ncols | ((uint32_t)ntb << 16);
+          seed.what = (uint32_t)dir | ((uint32_t)gi << 8) | ((c0 == 0 ? 1u : 0u) << 16) | ((uint32_t)L << 24);
+          seed.sel = sel; seed.jbase = jb;
+          seed.gpos0 = gbase + (uint64_t)(dir ? wb - c0 - 1 : wa + c0);
+          have = true;
+        }
       }
       const unsigned long long bal = __ballot(have);
-      if (bal == 0ull) break;
+      if (bal == 0ull) continue;                                  // (wave-uniform)
       const uint32_t nj = (uint32_t)__popcll(bal), rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
       const int leader = __ffsll((long long)bal) - 1;
       uint32_t jbase0 = 0;
@@ -421,20 +421,30 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
         uint8_t* slab = a.slab + ((uint64_t)jbase0 + q) * a.slab_bytes;
         for (int x0 = s8 * 16; x0 < ntb; x0 += 128) {
           const int nv = min(16, ntb - x0);
-          const uint64_t pfirst = d2 ? sd.gpos0 - (uint64_t)x0 : sd.gpos0 + (uint64_t)x0;
-          const uint64_t plo = d2 ? pfirst - (uint64_t)(nv - 1) : pfirst, phi = plo + (uint64_t)(nv - 1);
-          const uint32_t cw0 = a.codes[plo >> 4], cw1 = a.codes[phi >> 4], mw0 = a.mask[plo >> 5], mw1 = a.mask[phi >> 5];
-          uint32_t w4[4] = {0u, 0u, 0u, 0u};
+          // the piece's positions, ascending: plo .. plo + nv - 1; column x0 + i is position plo + i (dir 0) or plo + nv - 1 - i (dir 1)
+          const uint64_t plo = d2 ? sd.gpos0 - (uint64_t)(x0 + nv - 1) : sd.gpos0 + (uint64_t)x0, phi = plo + (uint64_t)(nv - 1);
+          const uint64_t cw = ((uint64_t)a.codes[phi >> 4] << 32) | (uint64_t)a.codes[plo >> 4];     // (one word twice when the piece does not straddle)
+          const uint64_t mw = ((uint64_t)a.mask[phi >> 5] << 32) | (uint64_t)a.mask[plo >> 5];
+          const uint32_t c32 = (plo >> 4) == (phi >> 4) ? (uint32_t)((uint32_t)cw >> ((plo & 15) * 2)) : (uint32_t)(cw >> ((plo & 15) * 2));
+          const uint32_t m16 = ((plo >> 5) == (phi >> 5) ? (uint32_t)((uint32_t)mw >> (plo & 31)) : (uint32_t)(mw >> (plo & 31))) & ((1u << nv) - 1u);
+          uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
           for (int i = 0; i < 16; i++) {
-            if (i < nv) {
-              const uint64_t gp = d2 ? pfirst - (uint64_t)i : pfirst + (uint64_t)i;
-              const uint32_t cw = (gp >> 4) == (plo >> 4) ? cw0 : cw1, mw = (gp >> 5) == (plo >> 5) ? mw0 : mw1;
-              const int tm = tmask_at(a.runs, a.n_runs, gp, (cw >> ((gp & 15) * 2)) & 3u, (mw >> (gp & 31)) & 1u, d2);
-              w4[i >> 2] |= (uint32_t)tm << ((i & 3) * 8);
-            }
+            const int ia = d2 ? nv - 1 - i : i;                  // ascending index of column x0 + i (negative beyond the piece: masked below)
+            const uint32_t code = (c32 >> ((ia & 15) * 2)) & 3u;
+            uint32_t tm = 1u << (d2 ? 3u - code : code);         // plain base: its set, complemented for the reverse strand
+            if (i >= nv) tm = 0u;
+            if (i < 4) w0 |= tm << (i * 8); else if (i < 8) w1 |= tm << ((i - 4) * 8); else if (i < 12) w2 |= tm << ((i - 8) * 8); else w3 |= tm << ((i - 12) * 8);
           }
-          *reinterpret_cast<uint4*>(slab + sizeof(SlabHeader) + x0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+          // exception bases (N runs, IUPAC codes, padding: rare): their masks come from the run table
+          for (uint32_t m = m16; m != 0u; m &= m - 1u) {
+            const int ia = __ffs(m) - 1;
+            const int tm = tmask_at(a.runs, a.n_runs, plo + (uint64_t)ia, 0u, 1u, d2);
+            const int i = d2 ? nv - 1 - ia : ia;
+            const uint32_t clr = ~(0xFFu << ((i & 3) * 8)), put = (uint32_t)tm << ((i & 3) * 8);
+            if ((i >> 2) == 0) w0 = (w0 & clr) | put; else if ((i >> 2) == 1) w1 = (w1 & clr) | put; else if ((i >> 2) == 2) w2 = (w2 & clr) | put; else w3 = (w3 & clr) | put;
+          }
+          *reinterpret_cast<uint4*>(slab + sizeof(SlabHeader) + x0) = make_uint4(w0, w1, w2, w3);
         }
         uint4* head = reinterpret_cast<uint4*>(slab);
         if (s8 == 7) head[0] = make_uint4(0u, sd.contig, sd.window_k, sd.n);
