@@ -575,42 +575,63 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
       int add_match = match_t, add_mismatch = mismatch_t;
       asm volatile("" : "+v"(add_match), "+v"(add_mismatch));        // in vector registers once, not re-materialised per step
       auto shift_in = [](int& dst, int src) { dst = __builtin_amdgcn_update_dpp(dst, src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); };
-      // the column's target mask comes from LDS two steps ahead of its use (an LDS round trip is longer than a step); lanes that are
-      // not on the strip yet read a few bytes below tbm[] -- the arrays before it -- and ignore them
-      const uint8_t* tbm_r = tbm - r - 1;                     // tbm_r[t] = mask of the column this row is at in step t
-      int m_a = tbm_r[1], m_b = tbm_r[2];
-      auto cell = [&](const int t, int inPp, int& m_cur, auto patch_lane32) {
+      // The column masks travel down the lanes with the wavefront: row r is at column t - r in step t, where row r - 1 was a step
+      // earlier, so a row takes its mask from the lane above with the same lane shift that brings it the cells.  Round 5: before, every
+      // lane read its column's mask from LDS, "two steps ahead" -- but LDS operations complete in order and s_waitcnt counts them in
+      // order, so waiting for this step's mask also waited for the previous step's trace byte to land: an LDS round trip per step,
+      // ~460 cycles per step at two waves per SIMD (profiles/r05_pmc_tail_before.txt: the waves parked 51 % of their time).  Now only
+      // row 1 of each job reads masks, four at a time (one ds_read_b32 per four steps, issued a round ahead); nothing in a step waits.
+      const uint32_t* tbm32 = reinterpret_cast<const uint32_t*>(tbm);
+      const bool row1 = r == 0, bottom = r == L - 1;
+      uint8_t* const trow = &tr[r < ROWS ? r : ROWS - 1][0];  // (a lane that is no row writes to column 0 of the last row)
+      int m = 0;
+      uint32_t w_cur = tbm32[0];
+      asm volatile("" : "+v"(w_cur));                         // arrived before the loop: otherwise the loop's header waits for "all but the newest" every round
+      auto cell = [&](const int t, const int jj, int inPp, auto patch_lane32) {
         shift_in(inD, curD);
         shift_in(inU, curU);
         if (decltype(patch_lane32)::value && threadIdx.x == 32) { inPp = TR_DIAG; inD = TR_DIAG; inU = TR_UP; }
-        const int m = m_cur;
-        m_cur = tbm_r[t + 2];
-        if (t >= t_first && t <= t_last) {
-          const int c = t - r;                                // strip column 1..ncols
+        const int own = (int)((w_cur >> (8 * jj)) & 0xFFu);   // tbm[t - 1]: the column row 1 is at
+        m = __builtin_amdgcn_update_dpp(own, m, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (row1) m = own;
+        // The two LDS stores of a step stand OUTSIDE the branch, for every lane, every step: a lane that has no column of the strip in
+        // this step writes to column 0 of its own trace row and to fin[0], which nothing reads.  With the stores inside the branch the
+        // compiler cannot count the LDS operations between the read of the next round's masks and its use, assumes none, and waits for
+        // the newest of them (s_waitcnt lgkmcnt(1)): an LDS round trip per round.
+        const bool on = t >= t_first && t <= t_last;
+        int c = 0, tbyte = 0;
+        if (on) {
+          c = t - r;                                          // strip column 1..ncols
           const int add_t = (qm & m) ? add_match : add_mismatch;
           const int newD = (inPp & ~3) + add_t;
           const int newU = max(inD, inU) + tgap4;             // code bits: TR_DIAG = from Diag, TR_UP = from Up
           const int newL = max(curD, curL) + qgap4;           // code bits: TR_DIAG = from Diag, TR_LEFT = from Left
           // trace byte: bits 0-1 where Diag came from, bit 2 Up came from Diag (else Up), bit 3 Left came from Left (else Diag)
-          tr[r][c] = (uint8_t)((((newL & 1) << 3) | (inPp & 3)) | ((newU & 2) << 1));
+          tbyte = (((newL & 1) << 3) | (inPp & 3)) | ((newU & 2) << 1);
           curD = newD; curU = newU & ~3; curL = (newL & ~3) | TR_LEFT;
           curP = max(max(curD, curL), curU);
-          if (r == L - 1) {
-            fin[c] = curP;
-            if (PM) { fin3[0][c] = curD >> 2; fin3[1][c] = curL >> 2; fin3[2][c] = curU >> 2; }
-          }
         }
+        trow[c] = (uint8_t)tbyte;
+        const int fc = bottom ? c : 0;
+        fin[fc] = curP;
+        if (PM) { fin3[0][fc] = curD >> 2; fin3[1][fc] = curL >> 2; fin3[2][fc] = curU >> 2; }
       };
       auto fill = [&](auto patch_lane32) {
         shift_in(inPa, curP);
-        int t = 1;
-        for (; t + 1 <= nsteps; t += 2) {                    // two steps per round: the shifted curP of one is the "previous" of the next
+        // four steps per round (steps past the last one find no row on the strip): the shifted curP of one step is the "previous" of
+        // the step after the next, hence the two registers taking turns
+        for (int t = 1; t <= nsteps; t += 4) {
+          const uint32_t w_next = tbm32[(t + 3) >> 2];       // the masks of the next round's columns
           shift_in(inPb, curP);
-          cell(t, inPa, m_a, patch_lane32);
+          cell(t, 0, inPa, patch_lane32);
           shift_in(inPa, curP);
-          cell(t + 1, inPb, m_b, patch_lane32);
+          cell(t + 1, 1, inPb, patch_lane32);
+          shift_in(inPb, curP);
+          cell(t + 2, 2, inPa, patch_lane32);
+          shift_in(inPa, curP);
+          cell(t + 3, 3, inPb, patch_lane32);
+          w_cur = w_next;
         }
-        if (t <= nsteps) cell(t, inPa, m_a, patch_lane32);
       };
       if (LPJ != 32 || row0_in_lane31) fill(std::false_type{}); else fill(std::true_type{});
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
