@@ -295,6 +295,8 @@ __device__ __forceinline__ int comp_mask4(int m) {  // IUPAC set of the compleme
 // per job, from an address that depends on nothing but the job's number.
 // ------------------------------------------------------------------------------------------------------------------
 struct JobSeed {           // phase A -> phase B, through LDS: the job's header words and where its strip starts in the packed reference
+  uint32_t slab;           // the job's slab: record x slots_per_rec + window slot
+  uint32_t pad;
   uint32_t contig, window_k, n, c0;
   uint32_t cols;           // ncols | ntb << 16
   uint32_t what;           // dir | guide << 8 | true_border << 16 | L << 24
@@ -317,6 +319,35 @@ __device__ __forceinline__ int tmask_at(const Run* runs, int64_t n_runs, uint64_
   return m;
 }
 
+// Sixteen target masks (one 16-byte piece of a strip's tb[]): the bases at packed positions plo .. plo + nv - 1, in column order --
+// ascending for the forward strand, descending and complemented for the reverse strand (d2).  cwl / cwh: the code words of plo and of
+// plo + nv - 1 (the same word when the piece does not straddle), mwl / mwh likewise for the exception mask.
+__device__ __forceinline__ uint4 decode_piece(const Run* runs, int64_t n_runs, uint32_t cwl, uint32_t cwh, uint32_t mwl, uint32_t mwh, uint64_t plo,
+                                              int nv, int d2) {
+  const uint64_t phi = plo + (uint64_t)(nv - 1);
+  const uint64_t cw = ((uint64_t)cwh << 32) | (uint64_t)cwl, mw = ((uint64_t)mwh << 32) | (uint64_t)mwl;
+  const uint32_t c32 = (plo >> 4) == (phi >> 4) ? (uint32_t)((uint32_t)cw >> ((plo & 15) * 2)) : (uint32_t)(cw >> ((plo & 15) * 2));
+  const uint32_t m16 = ((plo >> 5) == (phi >> 5) ? (uint32_t)((uint32_t)mw >> (plo & 31)) : (uint32_t)(mw >> (plo & 31))) & ((1u << nv) - 1u);
+  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int ia = d2 ? nv - 1 - i : i;                          // ascending index of column i of the piece (negative beyond it: masked below)
+    const uint32_t code = (c32 >> ((ia & 15) * 2)) & 3u;
+    uint32_t tm = 1u << (d2 ? 3u - code : code);                 // plain base: its set, complemented for the reverse strand
+    if (i >= nv) tm = 0u;
+    if (i < 4) w0 |= tm << (i * 8); else if (i < 8) w1 |= tm << ((i - 4) * 8); else if (i < 12) w2 |= tm << ((i - 8) * 8); else w3 |= tm << ((i - 12) * 8);
+  }
+  // exception bases (N runs, IUPAC codes, padding: rare): their masks come from the run table
+  for (uint32_t m = m16; m != 0u; m &= m - 1u) {
+    const int ia = __ffs(m) - 1;
+    const int tm = tmask_at(runs, n_runs, plo + (uint64_t)ia, 0u, 1u, d2);
+    const int i = d2 ? nv - 1 - ia : ia;
+    const uint32_t clr = ~(0xFFu << ((i & 3) * 8)), put = (uint32_t)tm << ((i & 3) * 8);
+    if ((i >> 2) == 0) w0 = (w0 & clr) | put; else if ((i >> 2) == 1) w1 = (w1 & clr) | put; else if ((i >> 2) == 2) w2 = (w2 & clr) | put; else w3 = (w3 & clr) | put;
+  }
+  return make_uint4(w0, w1, w2, w3);
+}
+
 __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
   CALITAS_TAIL_PRIO();
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[0] = (unsigned long long)wall_clock64();   // (binned.hpp, BIN_BOX_STAMPS)
@@ -332,7 +363,6 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
   __syncthreads();
   uint32_t n_recs = *a.rec_count;
   if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
-  const uint64_t job_capacity = (uint64_t)a.rec_capacity * a.slots_per_rec;
   const SearchDev& sp = a.sp;
   const int W = sp.window_size, step = sp.step;
   const uint32_t wpb = blockDim.x / 64u, n_waves = gridDim.x * wpb;
@@ -390,6 +420,7 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
           int look = jmax + sp.max_gaps + MAX_PAM_LEN;            // PAM look-ahead, clipped to the window
           if (look > n) look = n;
           const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
+          seed.slab = (uint32_t)round * a.rec_capacity + ri;
           seed.contig = contig; seed.window_k = (uint32_t)k; seed.n = (uint32_t)n; seed.c0 = (uint32_t)c0;
           seed.cols = (uint32_t)ncols | ((uint32_t)ntb << 16);
           seed.what = (uint32_t)dir | ((uint32_t)gi << 8) | ((c0 == 0 ? 1u : 0u) << 16) | ((uint32_t)L << 24);
@@ -399,59 +430,77 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
         }
       }
       const unsigned long long bal = __ballot(have);
-      if (bal == 0ull) continue;                                  // (wave-uniform)
+      const bool any_wide = __ballot(have && (seed.cols >> 16) > 64u) != 0ull;   // (both ballots in straight-line code, see above)
+
+      // A record's job of round k lives in slab k x rec_capacity + record -- a fixed place, no numbering: numbering the jobs with one
+      // returning atomic per wave and round was 3 800 atomics on one word per hg38-sized pass, 42 of the kernel's 60 us (DESIGN.md 4.7,
+      // "returning atomics on one word"); numbering only the later rounds' jobs (3 % of the records have a second window that holds
+      // the same columns) still met most waves.  A slab without a job says so in its header (ncols = 0): align_kernel looks there.
+      if (ri < n_recs && !have) reinterpret_cast<uint32_t*>(a.slab + ((uint64_t)round * a.rec_capacity + ri) * a.slab_bytes)[5] = 0u;
       const uint32_t nj = (uint32_t)__popcll(bal), rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      const int leader = __ffsll((long long)bal) - 1;
-      uint32_t jbase0 = 0;
-      if (lane == leader) jbase0 = atomicAdd(a.job_count, nj);
-      jbase0 = (uint32_t)__shfl((int)jbase0, leader);
+      if (bal == 0ull) continue;                                  // (wave-uniform)
       if (have) s_seed[wave][rank] = seed;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // ---- phase B: eight lanes per job write the head of its slab.  Lane c of the eight decodes the target masks of columns
-      //      16 c .. 16 c + 15 (a strip has 45-60 of them at d = 5; TB_LEN = 144 at most: lane 0 then takes the ninth piece too) and
-      //      the lanes from the other end write the header's pieces. ----
-      const int s8 = lane & 7;
-      for (uint32_t q0 = 0; q0 < nj; q0 += 8u) {
-        const uint32_t q = q0 + (uint32_t)(lane >> 3);
-        if (q >= nj || (uint64_t)jbase0 + q >= job_capacity) continue;
-        const JobSeed sd = s_seed[wave][q];
-        const int ntb = (int)(sd.cols >> 16), ncols = (int)(sd.cols & 0xFFFFu), d2 = (int)(sd.what & 1u), g2 = (int)((sd.what >> 8) & 0xFFu);
-        uint8_t* slab = a.slab + ((uint64_t)jbase0 + q) * a.slab_bytes;
-        for (int x0 = s8 * 16; x0 < ntb; x0 += 128) {
-          const int nv = min(16, ntb - x0);
-          // the piece's positions, ascending: plo .. plo + nv - 1; column x0 + i is position plo + i (dir 0) or plo + nv - 1 - i (dir 1)
-          const uint64_t plo = d2 ? sd.gpos0 - (uint64_t)(x0 + nv - 1) : sd.gpos0 + (uint64_t)x0, phi = plo + (uint64_t)(nv - 1);
-          const uint64_t cw = ((uint64_t)a.codes[phi >> 4] << 32) | (uint64_t)a.codes[plo >> 4];     // (one word twice when the piece does not straddle)
-          const uint64_t mw = ((uint64_t)a.mask[phi >> 5] << 32) | (uint64_t)a.mask[plo >> 5];
-          const uint32_t c32 = (plo >> 4) == (phi >> 4) ? (uint32_t)((uint32_t)cw >> ((plo & 15) * 2)) : (uint32_t)(cw >> ((plo & 15) * 2));
-          const uint32_t m16 = ((plo >> 5) == (phi >> 5) ? (uint32_t)((uint32_t)mw >> (plo & 31)) : (uint32_t)(mw >> (plo & 31))) & ((1u << nv) - 1u);
-          uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+      // ---- phase B: four lanes per job write the head of its slab: lane p of the four decodes the target masks of columns 16 p ..
+      //      16 p + 15 (a strip has 45-61 columns at d = 5) and writes its share of the header.  Sixteen jobs per pass, the passes unrolled
+      //      with ALL their loads issued before the first is used: a wave's round is one trip to memory, not one per pass.  (Eight
+      //      lanes per job and a loop of dependent passes took 40-60 us per launch, most of it waiting.)  Strips wider than 64
+      //      columns (other limits, explicit targets) get their remaining pieces in a loop behind. ----
+      {
+        const int p4 = lane & 3;
+        constexpr int PASSES = 4;
+        uint32_t cwl[PASSES], cwh[PASSES], mwl[PASSES], mwh[PASSES];
 #pragma unroll
-          for (int i = 0; i < 16; i++) {
-            const int ia = d2 ? nv - 1 - i : i;                  // ascending index of column x0 + i (negative beyond the piece: masked below)
-            const uint32_t code = (c32 >> ((ia & 15) * 2)) & 3u;
-            uint32_t tm = 1u << (d2 ? 3u - code : code);         // plain base: its set, complemented for the reverse strand
-            if (i >= nv) tm = 0u;
-            if (i < 4) w0 |= tm << (i * 8); else if (i < 8) w1 |= tm << ((i - 4) * 8); else if (i < 12) w2 |= tm << ((i - 8) * 8); else w3 |= tm << ((i - 12) * 8);
+        for (int it = 0; it < PASSES; it++) {
+          const uint32_t q = (uint32_t)(it * 16 + (lane >> 2));
+          cwl[it] = cwh[it] = mwl[it] = mwh[it] = 0u;
+          if (q < nj) {
+            const JobSeed& sd = s_seed[wave][q];
+            const int ntb = (int)(sd.cols >> 16), d2 = (int)(sd.what & 1u), x0 = p4 * 16;
+            if (x0 < ntb) {
+              const int nv = min(16, ntb - x0);
+              const uint64_t plo = d2 ? sd.gpos0 - (uint64_t)(x0 + nv - 1) : sd.gpos0 + (uint64_t)x0, phi = plo + (uint64_t)(nv - 1);
+              cwl[it] = a.codes[plo >> 4]; cwh[it] = a.codes[phi >> 4]; mwl[it] = a.mask[plo >> 5]; mwh[it] = a.mask[phi >> 5];
+            }
           }
-          // exception bases (N runs, IUPAC codes, padding: rare): their masks come from the run table
-          for (uint32_t m = m16; m != 0u; m &= m - 1u) {
-            const int ia = __ffs(m) - 1;
-            const int tm = tmask_at(a.runs, a.n_runs, plo + (uint64_t)ia, 0u, 1u, d2);
-            const int i = d2 ? nv - 1 - ia : ia;
-            const uint32_t clr = ~(0xFFu << ((i & 3) * 8)), put = (uint32_t)tm << ((i & 3) * 8);
-            if ((i >> 2) == 0) w0 = (w0 & clr) | put; else if ((i >> 2) == 1) w1 = (w1 & clr) | put; else if ((i >> 2) == 2) w2 = (w2 & clr) | put; else w3 = (w3 & clr) | put;
-          }
-          *reinterpret_cast<uint4*>(slab + sizeof(SlabHeader) + x0) = make_uint4(w0, w1, w2, w3);
         }
-        uint4* head = reinterpret_cast<uint4*>(slab);
-        if (s8 == 7) head[0] = make_uint4(0u, sd.contig, sd.window_k, sd.n);
-        else if (s8 == 6) head[1] = make_uint4(sd.c0, sd.cols, sd.what, (uint32_t)((ncols + 4) & ~3));
-        else if (s8 == 5) head[4] = reinterpret_cast<const uint4*>(s_qmask[g2])[0];
-        else if (s8 == 4) head[5] = reinterpret_cast<const uint4*>(s_qmask[g2])[1];
-        else if (s8 == 3) head[6] = make_uint4((uint32_t)s_gint[g2][2], sd.sel, (uint32_t)sd.jbase, 0u);
+#pragma unroll
+        for (int it = 0; it < PASSES; it++) {
+          const uint32_t q = (uint32_t)(it * 16 + (lane >> 2));
+          if (q < nj) {
+            const JobSeed sd = s_seed[wave][q];
+            const int ntb = (int)(sd.cols >> 16), ncols = (int)(sd.cols & 0xFFFFu), d2 = (int)(sd.what & 1u), g2 = (int)((sd.what >> 8) & 0xFFu), x0 = p4 * 16;
+            uint8_t* slab = a.slab + (uint64_t)sd.slab * a.slab_bytes;
+            if (x0 < ntb) {
+              const int nv = min(16, ntb - x0);
+              const uint64_t plo = d2 ? sd.gpos0 - (uint64_t)(x0 + nv - 1) : sd.gpos0 + (uint64_t)x0;
+              *reinterpret_cast<uint4*>(slab + sizeof(SlabHeader) + x0) = decode_piece(a.runs, a.n_runs, cwl[it], cwh[it], mwl[it], mwh[it], plo, nv, d2);
+            }
+            uint4* head = reinterpret_cast<uint4*>(slab);
+            if (p4 == 0) { head[0] = make_uint4(0u, sd.contig, sd.window_k, sd.n); head[6] = make_uint4((uint32_t)s_gint[g2][2], sd.sel, (uint32_t)sd.jbase, 0u); }
+            else if (p4 == 1) head[1] = make_uint4(sd.c0, sd.cols, sd.what, (uint32_t)((ncols + 4) & ~3));
+            else if (p4 == 2) head[4] = reinterpret_cast<const uint4*>(s_qmask[g2])[0];
+            else head[5] = reinterpret_cast<const uint4*>(s_qmask[g2])[1];
+          }
+        }
+        if (any_wide) {                                           // (wave-uniform) pieces 4 .. 8 of the wide strips: eight jobs per pass, a lane per piece
+          for (uint32_t q0 = 0; q0 < nj; q0 += 8u) {
+            const uint32_t q = q0 + (uint32_t)(lane >> 3);
+            const int x0 = (4 + (lane & 7)) * 16;
+            if (q < nj) {
+              const JobSeed sd = s_seed[wave][q];
+              const int ntb = (int)(sd.cols >> 16), d2 = (int)(sd.what & 1u);
+              if (x0 < ntb) {
+                const int nv = min(16, ntb - x0);
+                const uint64_t plo = d2 ? sd.gpos0 - (uint64_t)(x0 + nv - 1) : sd.gpos0 + (uint64_t)x0, phi = plo + (uint64_t)(nv - 1);
+                *reinterpret_cast<uint4*>(a.slab + (uint64_t)sd.slab * a.slab_bytes + sizeof(SlabHeader) + x0) =
+                    decode_piece(a.runs, a.n_runs, a.codes[plo >> 4], a.codes[phi >> 4], a.mask[plo >> 5], a.mask[phi >> 5], plo, nv, d2);
+              }
+            }
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -465,7 +514,7 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
 // bytes, lane x of the job's lanes loading piece x -- for the NEXT job while this one is being filled, so the load's latency hides
 // behind the fill and the wave never waits on a chain of dependent loads.
 constexpr int JOB_HEAD16 = (int)(sizeof(SlabHeader) + TB_LEN) / 16;
-static_assert((sizeof(SlabHeader) + TB_LEN) % 16 == 0 && JOB_HEAD16 <= 21, "one 16-byte piece of a job's head per lane of the job");
+static_assert((sizeof(SlabHeader) + TB_LEN) % 16 == 0 && JOB_HEAD16 < 20, "one 16-byte piece of a job's head per lane of the job, and a lane for the second slot's header");
 
 template <bool PM, int LPJ>
 __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
@@ -518,16 +567,26 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
   int* fin = s_fin[job < JOBS ? job : 0];
   int (*fin3)[PM ? STRIP_MAX_COLS + 1 : 1] = s_fin3[PM ? (job < JOBS ? job : 0) : 0];
 
-  uint64_t n_jobs = *a.job_count;
-  { const uint64_t cap = (uint64_t)a.rec_capacity * a.slots_per_rec; if (n_jobs > cap) n_jobs = cap; }
+  uint32_t n_recs = *a.rec_count;
+  if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
   const SearchDev& sp = a.sp;
+  // the jobs: round k of record i in slab k x rec_capacity + i (expand_kernel); the rounds one after the other, so that the jobs a
+  // wave's slots hold side by side are neighbours in the genome as the records are.  Most slabs of the later rounds hold no job (a
+  // second window holds the same columns for 3 % of the records): their headers say so and cost an iteration of a hundred instructions.
+  const uint64_t n_virtual = (uint64_t)n_recs * a.slots_per_rec;
+  auto slab_of = [&](uint64_t v) {                            // (no division: a handful of rounds at most)
+    uint64_t k = 0;
+    while (v >= n_recs) { v -= n_recs; k++; }
+    return k * (uint64_t)a.rec_capacity + v;
+  };
 
   const uint32_t total_jobs = gridDim.x * JOBS;
   // (lane 63 of a three-job wave belongs to no job)
-  uint64_t ji = job < JOBS ? (uint64_t)blockIdx.x * JOBS + (uint64_t)job : n_jobs;
+  uint64_t vi = job < JOBS ? (uint64_t)blockIdx.x * JOBS + (uint64_t)job : n_virtual;
   uint4 pf = make_uint4(0u, 0u, 0u, 0u);                       // piece r of the head of the job's slab, loaded a job ahead
-  if (ji < n_jobs && r < JOB_HEAD16) pf = reinterpret_cast<const uint4*>(a.slab + ji * a.slab_bytes)[r];
-  for (; ji < n_jobs; ji += total_jobs) {
+  if (vi < n_virtual && r < JOB_HEAD16) pf = reinterpret_cast<const uint4*>(a.slab + slab_of(vi) * a.slab_bytes)[r];
+  for (; vi < n_virtual; vi += total_jobs) {
+    {
     flush_items(STAGE_FLUSH);                // a job adds at most 16 candidates (x 3 per-matrix) per job of the wave
     // ---- stage the job's head in LDS: header as it is, target masks as "the bases this column matches" ----
     if (r < (int)(sizeof(SlabHeader) / 16)) {
@@ -537,10 +596,12 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
       auto conv = [](uint32_t t) { const uint32_t f = (t >> 4) & 0x01010101u; return t & 0x0F0F0F0Fu & ~(f * 0xFFu); };
       reinterpret_cast<uint4*>(tbm)[r - (int)(sizeof(SlabHeader) / 16)] = make_uint4(conv(pf.x), conv(pf.y), conv(pf.z), conv(pf.w));
     }
-    if (ji + total_jobs < n_jobs && r < JOB_HEAD16) pf = reinterpret_cast<const uint4*>(a.slab + (ji + total_jobs) * a.slab_bytes)[r];
+    if (vi + total_jobs < n_virtual && r < JOB_HEAD16) pf = reinterpret_cast<const uint4*>(a.slab + slab_of(vi + total_jobs) * a.slab_bytes)[r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if ((hd32[5] & 0xFFFFu) == 0u) continue;                  // (a record whose columns lie in no window of this call: no job in its slab)
+    const uint64_t ji = slab_of(vi);                          // the job's slab
     {
       const int c0 = (int)hd32[4];
       const int ncols = (int)(hd32[5] & 0xFFFFu), ntb = (int)(hd32[5] >> 16);
@@ -696,6 +757,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+    }
     }
   }
   flush_items(1);
