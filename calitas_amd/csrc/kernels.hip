@@ -365,10 +365,10 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
   if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
   const SearchDev& sp = a.sp;
   const int W = sp.window_size, step = sp.step;
-  const uint32_t wpb = blockDim.x / 64u, n_waves = gridDim.x * wpb;
-  for (uint32_t base = (blockIdx.x * wpb + (uint32_t)wave) * 64u; base < n_recs; base += n_waves * 64u) {   // (wave-uniform)
+  __shared__ uint32_t s_cnt[4], s_over;
+  for (uint32_t blk = blockIdx.x * 256u; blk < n_recs; blk += gridDim.x * 256u) {   // (workgroup-uniform: there are barriers inside)
     // ---- phase A: a lane per record ----
-    const uint32_t ri = base + (uint32_t)lane;
+    const uint32_t ri = blk + threadIdx.x;
     ScanRecord rec{0u, 0u};
     if (ri < n_recs) rec = a.recs[ri];
     const uint32_t cmask = rec.info & 0xFFFFu;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
           int look = jmax + sp.max_gaps + MAX_PAM_LEN;            // PAM look-ahead, clipped to the window
           if (look > n) look = n;
           const int ntb = look - c0;                              // tb[x] = column c0 + 1 + x
-          seed.slab = (uint32_t)round * a.rec_capacity + ri;
+          seed.slab = ri;                                         // (round 0; a later round's jobs get their slabs below)
           seed.contig = contig; seed.window_k = (uint32_t)k; seed.n = (uint32_t)n; seed.c0 = (uint32_t)c0;
           seed.cols = (uint32_t)ncols | ((uint32_t)ntb << 16);
           seed.what = (uint32_t)dir | ((uint32_t)gi << 8) | ((c0 == 0 ? 1u : 0u) << 16) | ((uint32_t)L << 24);
@@ -432,12 +432,26 @@ __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
       const unsigned long long bal = __ballot(have);
       const bool any_wide = __ballot(have && (seed.cols >> 16) > 64u) != 0ull;   // (both ballots in straight-line code, see above)
 
-      // A record's job of round k lives in slab k x rec_capacity + record -- a fixed place, no numbering: numbering the jobs with one
-      // returning atomic per wave and round was 3 800 atomics on one word per hg38-sized pass, 42 of the kernel's 60 us (DESIGN.md 4.7,
-      // "returning atomics on one word"); numbering only the later rounds' jobs (3 % of the records have a second window that holds
-      // the same columns) still met most waves.  A slab without a job says so in its header (ncols = 0): align_kernel looks there.
-      if (ri < n_recs && !have) reinterpret_cast<uint32_t*>(a.slab + ((uint64_t)round * a.rec_capacity + ri) * a.slab_bytes)[5] = 0u;
+      // Round 0's job lives in slab `record`; a record without one says so there (ncols = 0: align_kernel looks).  The jobs of later
+      // rounds -- a second window that holds the same columns: 3 % of the records -- are numbered behind the records' slabs
+      // (rec_capacity + k) with ONE atomic per workgroup and round.  (Numbering all jobs with an atomic per wave and round was 3 800
+      // returning atomics on one word per hg38-sized pass, 42 of the kernel's 60 us -- DESIGN.md 4.7; a fixed slab per later round
+      // instead left align_kernel 120 000 empty slabs to look into, a memory round trip each: +30 us there.)
+      if (round == 0 && ri < n_recs && !have) reinterpret_cast<uint32_t*>(a.slab + (uint64_t)ri * a.slab_bytes)[5] = 0u;
       const uint32_t nj = (uint32_t)__popcll(bal), rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (round != 0) {                                           // (workgroup-uniform)
+        if (lane == 0) s_cnt[wave] = nj;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+          s_over = tot ? atomicAdd(a.job_count, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += s_cnt[w];
+        seed.slab = a.rec_capacity + s_over + before + rank;     // (below rec_capacity x slots_per_rec: at most slots_per_rec - 1 later windows per record)
+        __syncthreads();                                          // (s_cnt / s_over are rewritten in the next round)
+      }
       if (bal == 0ull) continue;                                  // (wave-uniform)
       if (have) s_seed[wave][rank] = seed;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -570,15 +584,12 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
   uint32_t n_recs = *a.rec_count;
   if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
   const SearchDev& sp = a.sp;
-  // the jobs: round k of record i in slab k x rec_capacity + i (expand_kernel); the rounds one after the other, so that the jobs a
-  // wave's slots hold side by side are neighbours in the genome as the records are.  Most slabs of the later rounds hold no job (a
-  // second window holds the same columns for 3 % of the records): their headers say so and cost an iteration of a hundred instructions.
-  const uint64_t n_virtual = (uint64_t)n_recs * a.slots_per_rec;
-  auto slab_of = [&](uint64_t v) {                            // (no division: a handful of rounds at most)
-    uint64_t k = 0;
-    while (v >= n_recs) { v -= n_recs; k++; }
-    return k * (uint64_t)a.rec_capacity + v;
-  };
+  // the jobs: slab `record` for every scan record (its first window with candidate columns), then the slabs behind them
+  // (rec_capacity + k: the second windows, numbered by expand_kernel)
+  uint64_t n_over = *a.job_count;
+  { const uint64_t room = (uint64_t)a.rec_capacity * (a.slots_per_rec - 1u); if (n_over > room) n_over = room; }
+  const uint64_t n_virtual = (uint64_t)n_recs + n_over;
+  auto slab_of = [&](uint64_t v) { return v < n_recs ? v : (uint64_t)a.rec_capacity + (v - n_recs); };
 
   const uint32_t total_jobs = gridDim.x * JOBS;
   // (lane 63 of a three-job wave belongs to no job)
