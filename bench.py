@@ -334,7 +334,7 @@ def main():
     ap.add_argument("--prime-seconds", type=float, default=None,
                     help="untimed calls before the warm-up steps until the device runs at its sustained clocks (default 0.75 s for config 3, 0 otherwise)")
     ap.add_argument("--config", type=int, choices=[3, 4, 5], default=3, help="BASELINE config: 3 one guide (the metric's), 4 the 96-guide batch, 5 PAM-less d=8 + VCF")
-    ap.add_argument("--scale", type=float, default=None, help="genome size relative to hg38 (1.0 = 3.09 Gb; default 1.0, config 5: 0.05)")
+    ap.add_argument("--scale", type=float, default=None, help="genome size relative to hg38 (1.0 = 3.09 Gb; default 1.0)")
     ap.add_argument("--shard", choices=["contigs", "windows", "guides"], default="windows",
                     help="N>1: windows (default) = consecutive window ranges of ONE pass, equal to within a window, contigs cut where the balance asks "
                          "for it (strong scaling; every rank owns the rows of its stretch); contigs = consecutive whole-contig ranges of one pass "
@@ -369,6 +369,7 @@ def main():
                          % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank_info = {}
     def pin_this_rank():
         """N > 1: every rank on the CPUs of its GPU's NUMA node (a rank's slice is bound by host round trips, and one from the far socket
         costs a quarter more: DESIGN.md 4.7), its share of them when several GPUs hang off one node -- before anything starts a thread.
@@ -379,9 +380,12 @@ def main():
         spec = importlib.util.spec_from_file_location("_calitas_shard", os.path.join(ROOT, "calitas_amd", "shard.py"))
         shard_mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(shard_mod)
-        cpus = shard_mod.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-        if cpus and "CALITAS_THREADS" not in os.environ:
-            os.environ["CALITAS_THREADS"] = str(min(16, len(cpus)))       # the library's worker pool: one thread per CPU it may use
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        cpus = shard_mod.pin_rank(local_rank, n_local)
+        if "CALITAS_THREADS" not in os.environ:
+            # the library's worker pool: a thread per CPU the rank may use, and no more than its share of the box's CPU quota (a quota
+            # on a shared host, not a CPU set: eight ranks with sixteen workers each on sixteen cores' worth throttle each other)
+            os.environ["CALITAS_THREADS"] = str(shard_mod.worker_threads(cpus, n_local, shard_mod.cgroup_cpu_quota()))
         return cpus
 
     if args.dry_run:
@@ -400,10 +404,14 @@ def main():
             total = int(t.item())
             cpus = [None] * world
             dist.all_gather_object(cpus, sorted(os.sched_getaffinity(0)))
+            threads = [None] * world
+            dist.all_gather_object(threads, int(os.environ.get("CALITAS_THREADS", "0") or 0))
             dist.barrier()
             dist.destroy_process_group()
+        else:
+            threads = [int(os.environ.get("CALITAS_THREADS", "0") or 0)]
         if rank == 0:
-            line = {"dry_run": True, "n_gpus": world, "rank_sum": total, "local_rank": local_rank}
+            line = {"dry_run": True, "n_gpus": world, "rank_sum": total, "local_rank": local_rank, "worker_threads": threads}
             if pinned:
                 line["rank_cpus"] = cpus                          # (only when a topology was found: the affinity every rank ended up with)
             print(json.dumps(line), flush=True)
@@ -415,7 +423,7 @@ def main():
     if args.prime_seconds is None:
         args.prime_seconds = 0.75 if args.config == 3 else 0.0
     if args.scale is None:
-        args.scale = 0.05 if args.config == 5 else 1.0
+        args.scale = 1.0                                       # every config at its stated size (config 5 takes ~1.2 s per step since round 4)
 
     pinned = pin_this_rank()
 
@@ -484,13 +492,22 @@ def main():
             gl = [all_guides[(rank * gps + i) % len(all_guides)] if distinct else GUIDE0 for i in range(gps)]
         return None, gl, world * len(gl), sum(lengths) * world * len(gl)
 
-    def make_context(mine):
+    def make_context(mine, resident=None):
+        """mine: the contigs this rank's context consists of (None: all).  resident (window partition): all contigs are in the
+        context -- windowIterator's sequence, coordinates and order are the whole genome's -- but only these have their bases here."""
         t_gen = time.perf_counter()
-        names, seqs = build_genome(args.scale, device, contig_indices=mine, guides=[GUIDE0], log=None)
+        names, seqs = build_genome(args.scale, device, contig_indices=mine if resident is None else resident, guides=[GUIDE0], log=None)
         log("genome: %d contigs, %d bp on this rank, generated in %.1f s" % (len(names), sum(len(s) for s in seqs), time.perf_counter() - t_gen))
         ctx = C.Context(local_rank)
         t_set = time.perf_counter()
-        ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized")
+        if resident is not None:
+            have = dict(zip(names, seqs))
+            names = [n for n, _ in spec]
+            seqs = [have.get(n) for n in names]
+            ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized", lengths=lengths)
+            rank_info["resident_contigs"] = len(have); rank_info["resident_bases"] = sum(len(s) for s in have.values())
+        else:
+            ctx.set_reference(names, seqs, genome_build="synthetic-hg38-sized")
         log("set_reference: %.2f s (pack + upload), %d packed bytes" % (time.perf_counter() - t_set, ctx.reference_info()["packed_bytes"]))
         return ctx, names, seqs
 
@@ -553,11 +570,27 @@ def main():
         """K timed steps of one partition mode, bracketed by barrier + synchronize; the MAX over ranks is the job's time."""
         mine, my_guides, passes_per_step, bases_per_step_total = partition_mode(mode)
         contig_mode = world > 1 and mode in ("contigs", "windows")
-        ctx, names, seqs = make_context(mine)
         params_rank = params
+        resident = None
         if world > 1 and mode == "windows":
             step_w = 1000 - (len(GUIDE0) + params_kw["max_guide_diffs"] + params_kw["max_gaps_between_guide_and_pam"] - 1)
             first_w, n_w = shard.window_partition(lengths, world, step_w)[rank]
+            # every rank holds the contigs its range touches and nothing else (SURVEY 8e; a bin's halo never leaves a contig); rank 0 keeps
+            # the whole genome: it checks the gathered file and the sharded batch against single-process searches after the timed region
+            if rank != 0 and os.environ.get("CALITAS_BENCH_RESIDENT", "1") != "0":
+                resident = shard.resident_contigs(lengths, step_w, first_w, n_w)
+        ctx, names, seqs = make_context(mine, resident)
+        ranks_block = None
+        if world > 1:
+            # what every rank holds and runs with: the line says it (worker threads sized from the CPU list and the cgroup quota / ranks)
+            import torch.distributed as dist
+            info = dict(rank_info, worker_threads=int(os.environ.get("CALITAS_THREADS", "0") or 0), packed_bytes=ctx.reference_info()["packed_bytes"])
+            got = [None] * world
+            dist.all_gather_object(got, info, group=gloo)
+            ranks_block = {"worker_threads": [g.get("worker_threads") for g in got], "packed_bytes": [g.get("packed_bytes") for g in got],
+                           "resident_contigs": [g.get("resident_contigs", len(names)) for g in got]}
+            rank_info.clear()
+        if world > 1 and mode == "windows":
             params_rank = C.make_params(first_window=first_w, n_windows=n_w, **params_kw)
             loads = [shard.range_bases(lengths, step_w, 1000, f, n) for f, n in shard.window_partition(lengths, world, step_w)]
             log("window partition: bases per rank max / mean = %.4f" % (max(loads) / (sum(loads) / world)))
@@ -734,7 +767,7 @@ def main():
             os.unlink(vcf_path)
         return dict(dt=dt, acc=acc, batch_block=batch_block, last=last, phase=phase, my_guides=my_guides, passes_per_step=passes_per_step,
                     bases_per_step_total=bases_per_step_total, names=names, seqs=seqs, text=text, tiles=tiles, n_variants=n_variants,
-                    mine=mine, partition_check=partition_check)
+                    mine=mine, partition_check=partition_check, ranks=ranks_block)
 
     headline_mode = args.shard if world > 1 else "none"
     if headline_mode == "windows" and args.config != 3:
@@ -841,6 +874,8 @@ def main():
             if not m["batch_block"]["check"]["identical"]:
                 print(json.dumps(result), flush=True)
                 raise SystemExit("bench.py: a rank's text of the sharded batch differs from the single-process search")
+        if m.get("ranks"):
+            result["ranks"] = m["ranks"]                         # per rank: worker threads, packed reference bytes held, contigs resident
         if m.get("partition_check"):
             result["partition_check"] = m["partition_check"]     # the gathered hits.txt of the N ranks against one process's search
             if not m["partition_check"].get("identical", True):

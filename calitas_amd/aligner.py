@@ -180,14 +180,18 @@ class Context:
             self.contig_names.append(nm.value.decode())
             self.contig_lengths.append(ln.value)
 
-    def set_reference(self, names, seqs, genome_build="unknown"):
-        """seqs: bytes-like objects or numpy uint8 arrays holding ASCII bases; borrowed only for the call."""
+    def set_reference(self, names, seqs, genome_build="unknown", lengths=None):
+        """seqs: bytes-like objects or numpy uint8 arrays holding ASCII bases; borrowed only for the call.  seqs[i] None with
+        lengths[i] given: contig i is absent (its name and length count, its bases are not held: a process of a multi-GPU job
+        and the contigs its window range does not touch)."""
         n = len(names)
         c_names = (ctypes.c_char_p * n)(*[s.encode() for s in names])
-        c_lens = (ctypes.c_uint64 * n)(*[len(s) for s in seqs])
+        c_lens = (ctypes.c_uint64 * n)(*[(int(lengths[i]) if s is None else len(s)) for i, s in enumerate(seqs)])
         ptrs, keep = [], []
         for s in seqs:
-            if hasattr(s, "ctypes"):  # numpy array
+            if s is None:
+                ptrs.append(ctypes.c_void_p(None))
+            elif hasattr(s, "ctypes"):  # numpy array
                 keep.append(s)
                 ptrs.append(ctypes.c_void_p(s.ctypes.data))
             else:

@@ -464,6 +464,7 @@ int calitas_save_index(const calitas_ctx* ctx, const char* path) {
   calitas_ctx* c = const_cast<calitas_ctx*>(ctx);
   if (!ctx->has_ref) return fail(c, CALITAS_ESTATE, "calitas_set_reference has not been called");
   const PackedRef& r = ctx->ref;
+  if (!r.absent.empty()) return fail(c, CALITAS_EINVAL, "a reference with absent contigs (one process's share of a multi-GPU job) is not saved as an index");
   std::string names;
   for (auto& n : r.names) { names += n; names += '\n'; }
   IndexHeader h{};
@@ -524,7 +525,11 @@ int calitas_reference_info(const calitas_ctx* ctx, int32_t* n_contigs, uint64_t*
   if (!ctx || !ctx->has_ref) return CALITAS_ESTATE;
   if (n_contigs) *n_contigs = (int32_t)ctx->ref.contigs.size();
   if (total_bases) *total_bases = ctx->ref.total_bases;
-  if (packed_bytes) *packed_bytes = (ctx->ref.total_bases + 3) / 4;
+  if (packed_bytes) {                                          // 2 bits per base of the contigs that are resident here (all of them, usually)
+    uint64_t bases = 0;
+    for (size_t i = 0; i < ctx->ref.contigs.size(); i++) if (!ctx->ref.is_absent(i)) bases += ctx->ref.contigs[i].len;
+    *packed_bytes = (bases + 3) / 4;
+  }
   return CALITAS_OK;
 }
 

@@ -131,6 +131,10 @@ void pack_reference(PackedRef& out, int n_contigs, const char* const* names, con
   out.tile = (uint64_t)out.chunk * LANES_PER_TILE;
   const uint64_t T = out.tile;
 
+  // bases[i] == nullptr: contig i is absent (refpack.hpp): name and length as given, one dead tile of packed space
+  bool any_absent = false;
+  for (int i = 0; i < n_contigs; i++) any_absent = any_absent || (bases[i] == nullptr && lengths[i] != 0);
+  if (any_absent) { out.absent.assign((size_t)n_contigs, 0); for (int i = 0; i < n_contigs; i++) out.absent[(size_t)i] = bases[i] == nullptr && lengths[i] != 0; }
   uint64_t g = T;  // tile 0 is padding: the left halo of the first real tile reads it
   for (int i = 0; i < n_contigs; i++) {
     out.names.emplace_back(names[i]);
@@ -138,7 +142,7 @@ void pack_reference(PackedRef& out, int n_contigs, const char* const* names, con
     ci.gbase = g; ci.len = lengths[i];
     out.contigs.push_back(ci);
     uint64_t padded = ((lengths[i] + (uint64_t)out.chunk + T - 1) / T) * T;  // >= one chunk of padding after the contig
-    if (padded == 0) padded = T;
+    if (padded == 0 || out.is_absent((size_t)i)) padded = T;
     g += padded;
   }
   g += T;  // trailing padding tile: right halo of the last real tile
@@ -153,7 +157,7 @@ void pack_reference(PackedRef& out, int n_contigs, const char* const* names, con
   std::vector<Seg> segs;
   const uint64_t SEG = 1ull << 22;
   for (int i = 0; i < n_contigs; i++)
-    for (uint64_t off = 0; off < lengths[i]; off += SEG) segs.push_back(Seg{i, off, std::min(SEG, lengths[i] - off), {}});
+    for (uint64_t off = 0; off < lengths[i] && !out.is_absent((size_t)i); off += SEG) segs.push_back(Seg{i, off, std::min(SEG, lengths[i] - off), {}});
 
   int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
   if (nt < 1) nt = 1;
@@ -193,7 +197,7 @@ void pack_reference(PackedRef& out, int n_contigs, const char* const* names, con
   for (int i = 0; i < n_contigs; i++) {
     uint64_t t0 = out.contigs[i].gbase / T;
     uint64_t nt_c = ((lengths[i] + (uint64_t)out.chunk + T - 1) / T);
-    if (nt_c == 0) nt_c = 1;
+    if (nt_c == 0 || out.is_absent((size_t)i)) nt_c = 1;
     for (uint64_t t = 0; t < nt_c; t++) out.tiles[t0 + t].contig = (uint32_t)i;
   }
   // Coverage of [lo, hi) by exception bases / by dead bases (N or padding), from the mask words and the run table.

@@ -17,6 +17,10 @@ struct PackedRef {
   std::vector<TileInfo> tiles;        // total_packed / tile
   std::vector<uint32_t> masked_tiles; // indices of tiles with flag 1 (scanned by the exception-aware kernel variant)
   std::string genome_build = "unknown";
+  // absent[i] != 0: contig i has its name and length (the window table, the bins and every coordinate count it) but no bases here -- a
+  // process of a multi-GPU job holds the contigs its window range touches and nothing else; empty = all contigs resident
+  std::vector<uint8_t> absent;
+  bool is_absent(size_t i) const { return i < absent.size() && absent[i] != 0; }
 
   // Upper-cased base at a packed position (what the reference sees after StringUtil.toUpperCase, SearchReference.scala:67).
   char base_upper(uint64_t gpos) const;

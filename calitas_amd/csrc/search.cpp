@@ -238,6 +238,28 @@ static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
   pl.bases = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
   pl.win_lo = 0; pl.win_n = 0;
   for (auto& c : ref.contigs) pl.win_n += window_count(c.len, pl.step);
+  // contigs that are absent here (refpack.hpp: a process of a multi-GPU job holds what its window range touches): a search must not need them
+  auto absent_in = [&](uint64_t w_lo, uint64_t w_hi) -> int {      // first absent contig with a window in [w_lo, w_hi), or -1
+    uint64_t base = 0;
+    for (size_t c = 0; c < ref.contigs.size(); c++) {
+      const uint64_t nw = window_count(ref.contigs[c].len, pl.step);
+      if (ref.is_absent(c) && std::max(w_lo, base) < std::min(w_hi, base + nw)) return (int)c;
+      base += nw;
+    }
+    return -1;
+  };
+  if (!ref.absent.empty()) {
+    int bad = -1;
+    if (p.n_windows != 0 || p.first_window != 0) {
+      if (p.first_window >= 0 && p.n_windows > 0) bad = absent_in((uint64_t)p.first_window, (uint64_t)p.first_window + (uint64_t)p.n_windows);
+    } else if (p.chrom_index >= 0) {
+      if (ref.is_absent((size_t)p.chrom_index)) bad = p.chrom_index;
+    } else {
+      bad = absent_in(0, pl.win_n);
+    }
+    if (bad >= 0) return fail(ctx, CALITAS_EINVAL, "contig " + ref.names[(size_t)bad] + " is not resident in this context (it was given without bases): "
+                                                   "search a window range that leaves it out");
+  }
   if (p.n_windows != 0 || p.first_window != 0) {
     // a window range of the job: scan the tiles its windows touch, align only inside those windows
     if (p.first_window < 0 || p.n_windows <= 0 || (uint64_t)p.first_window + (uint64_t)p.n_windows > pl.win_n)

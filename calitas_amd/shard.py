@@ -270,3 +270,53 @@ def pin_rank(local_rank, n_local, root=None):
         return cpus
     except (OSError, AttributeError, ValueError):
         return None
+
+
+def cgroup_cpu_quota(root=None):
+    """The CPU quota of this process's cgroup in cores (cpu.max: quota / period; the tightest one on the way up the hierarchy), or None
+    when there is none.  A GPU box bounds a process by such a quota on a host it shares (nproc says 256, cpu.max says 16 cores'
+    worth: DESIGN.md 4.7) -- affinity does not show it.  root (or CALITAS_BENCH_SYSFS_ROOT): another tree than / (tests)."""
+    import os
+    root = root or os.environ.get("CALITAS_BENCH_SYSFS_ROOT") or "/"
+    try:
+        with open(os.path.join(root, "proc/self/cgroup")) as f:
+            lines = [ln.strip() for ln in f if ln.strip()]
+    except OSError:
+        return None
+    best = None
+    for ln in lines:
+        parts = ln.split(":", 2)
+        if len(parts) != 3 or parts[1] not in ("", "cpu", "cpu,cpuacct", "cpuacct,cpu"):
+            continue
+        d = parts[2].strip("/")
+        while True:                                            # this cgroup and every one above it
+            base = os.path.join(root, "sys/fs/cgroup", d) if d else os.path.join(root, "sys/fs/cgroup")
+            for fn in ("cpu.max", "cpu/cpu.max"):
+                try:
+                    with open(os.path.join(base, fn)) as f:
+                        q, _, per = f.read().strip().partition(" ")
+                    if q != "max" and float(per or 100000) > 0:
+                        cores = float(q) / float(per or 100000)
+                        best = cores if best is None else min(best, cores)
+                except (OSError, ValueError):
+                    pass
+            if not d:
+                break
+            d = os.path.dirname(d)
+    return best
+
+
+def worker_threads(cpus, n_local, quota=None, cap=16):
+    """Worker threads of one rank's library pool: what its CPU list allows, and no more than its share of the box's CPU quota --
+    eight ranks that each start sixteen workers on a sixteen-core quota throttle each other (a call keeps ~8 cores busy while its
+    text is expanded).  At least 2."""
+    n = len(cpus) if cpus else cap
+    if quota:
+        n = min(n, int(quota // max(1, n_local)))
+    return max(2, min(cap, n))
+
+
+def resident_contigs(lengths, step, first_window, n_windows):
+    """The contigs a process of a multi-GPU job has to hold for its window range: those the range has a window on (the halo of a
+    stretch -- a bin on either side -- never leaves a contig).  The others are given to calitas_set_reference without bases."""
+    return [ci for ci, _, _, _ in range_contigs(lengths, step, first_window, n_windows)]

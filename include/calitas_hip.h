@@ -149,7 +149,11 @@ void calitas_free(void* p);
 
 /* Replaces ReferenceSequenceIterator + windowIterator's byte[] contigs (SearchReference.scala:39-49): ASCII bases of
  * every contig, in sequence-dictionary order.  Packs to 2 bit/base + an exception-run table (N runs, IUPAC codes) and
- * uploads to HBM.  genome_build = first AS tag of the .dict or "unknown" (ReferenceHit.scala:208). */
+ * uploads to HBM.  genome_build = first AS tag of the .dict or "unknown" (ReferenceHit.scala:208).
+ * bases[i] == NULL with lengths[i] > 0: contig i is ABSENT -- its name and length count (windowIterator's sequence, the coordinates
+ * and the sort order are those of the whole dictionary) but its bases are not held here: what a process of a multi-GPU job does
+ * with the contigs its window range (calitas_params_t.first_window / n_windows) does not touch.  A search that would need an absent
+ * contig fails with CALITAS_EINVAL. */
 int calitas_set_reference(calitas_ctx* ctx, int32_t n_contigs, const char* const* names, const uint64_t* lengths,
                           const uint8_t* const* bases, const char* genome_build);
 /* Convenience: read FASTA (+ .dict next to it when present) and call calitas_set_reference. */

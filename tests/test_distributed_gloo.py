@@ -144,7 +144,8 @@ def test_bench_spawns_its_own_ranks():
                          timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
-    assert line == {"dry_run": True, "n_gpus": 2, "rank_sum": 3, "local_rank": 0}
+    threads = line.pop("worker_threads")                   # per rank: what its CPU list and its share of the cgroup's CPU quota allow
+    assert line == {"dry_run": True, "n_gpus": 2, "rank_sum": 3, "local_rank": 0} and len(threads) == 2 and all(2 <= t <= 16 for t in threads)
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, timeout=120)
     assert bad.returncode != 0 and b"WORLD_SIZE=2" in bad.stderr
@@ -411,6 +412,16 @@ def test_bench_ranks_pin_themselves_to_their_gpus_numa_node(tmp_path):
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     half = len(allowed) // 2
     assert line["rank_cpus"] == [allowed[:half], allowed[half:2 * half]]
+    assert line["worker_threads"] == [max(2, min(16, half))] * 2          # no CPU quota in the fake tree: what the CPU list allows
     plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, CALITAS_BENCH_SYSFS_ROOT=str(tmp_path / "nowhere")),
                            capture_output=True, timeout=300)
     assert plain.returncode == 0 and "rank_cpus" not in json.loads(plain.stdout.decode().strip().splitlines()[-1])
+    # a CPU quota on the way up the cgroup tree (what a GPU box has: cpu.max 600000 100000 = six cores' worth): a rank's pool gets its share of it
+    put("proc/self/cgroup", "0::/kubepods/pod1/box\n")
+    put("sys/fs/cgroup/kubepods/pod1/box/cpu.max", "max 100000\n")
+    put("sys/fs/cgroup/kubepods/pod1/cpu.max", "600000 100000\n")
+    put("sys/fs/cgroup/cpu.max", "max 100000\n")
+    quota = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, CALITAS_BENCH_SYSFS_ROOT=str(tmp_path)),
+                           capture_output=True, timeout=300)
+    assert quota.returncode == 0, quota.stderr.decode()[-2000:]
+    assert json.loads(quota.stdout.decode().strip().splitlines()[-1])["worker_threads"] == [max(2, min(half, 3))] * 2

@@ -320,3 +320,44 @@ def test_window_ranges_of_search_hits_concatenate(C, tmp_path, monkeypatch, cuts
         ctx.close()
     _, want, _ = O.search_reference(fa, GUIDE, "a", g=2, threads=4)
     assert n_whole > 60 and strip(C.read_hits(whole)) == strip(want)
+
+
+def test_a_rank_that_holds_only_the_contigs_of_its_window_range(C, tmp_path):
+    """bench.py --shard windows, ranks > 0: calitas_set_reference with the contigs the rank's window range does not touch given without
+    bases (names and lengths of the whole dictionary: windowIterator's sequence, coordinates and order stay the job's).  The rows a
+    range owns are the rows it owns on a context that holds everything; a search that would need an absent contig is refused."""
+    from calitas_amd import shard
+    rng = np.random.default_rng(77)
+    lens = [52000, 47000, 61000, 30000]
+    seqs = [planted(rng, n, [(int(p), int(rng.integers(0, 4)), bool(rng.integers(0, 2))) for p in rng.integers(200, n - 200, size=25)]).encode() for n in lens]
+    names = ["a", "b", "c", "d"]
+    step = 1000 - (len(GUIDE) + 5 + 2 - 1)
+    G = C.Guide(GUIDE)
+    pk = dict(max_gaps_between_guide_and_pam=2)
+    full = C.Context(0)
+    full.set_reference(names, seqs)
+    try:
+        whole, n_whole = full.search_hits(G, "a", C.make_params(**pk), "v0", "stamp")
+        pieces, rows = [], 0
+        for first, n in shard.window_partition(lens, 3, step):
+            held = shard.resident_contigs(lens, step, first, n)
+            assert 0 < len(held) < len(lens)
+            part = C.Context(0)
+            part.set_reference(names, [s if i in held else None for i, s in enumerate(seqs)], lengths=lens)
+            try:
+                assert part.reference_info()["packed_bytes"] == (sum(lens[i] for i in held) + 3) // 4
+                pr = C.make_params(first_window=first, n_windows=n, **pk)
+                text, k = part.search_hits(G, "a", pr, "v0", "stamp")
+                assert (text, k) == full.search_hits(G, "a", pr, "v0", "stamp")
+                pieces.append(text.partition("\n")[2]); rows += k
+                with pytest.raises(C.CalitasError, match="not resident"):
+                    part.search_hits(G, "a", C.make_params(**pk), "v0", "stamp")
+                gone = [i for i in range(len(lens)) if i not in held][0]
+                w0 = sum(shard.window_counts(lens, step)[:gone])
+                with pytest.raises(C.CalitasError, match="not resident"):
+                    part.search_hits(G, "a", C.make_params(first_window=w0, n_windows=2, **pk), "v0", "stamp")
+            finally:
+                part.close()
+        assert rows == n_whole and n_whole > 40 and whole == whole[:whole.index("\n") + 1] + "".join(pieces)
+    finally:
+        full.close()

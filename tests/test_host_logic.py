@@ -420,3 +420,51 @@ def test_every_environment_switch_is_in_the_table():
     assert not aborts, aborts                                  # the library reports, it does not stop the process
     assert used == listed, (sorted(used - listed), sorted(listed - used))
     assert "CALITAS_BINNED_SKIP" not in listed
+
+
+def test_worker_threads_and_resident_contigs_of_a_rank(tmp_path):
+    """What bench.py --gpus N gives every rank (calitas_amd/shard.py): worker threads from the rank's CPU list and its share of the
+    cgroup's CPU quota (a GPU box bounds a process by cpu.max on a shared host, not by a CPU set), and -- window partition -- the contigs
+    its range touches as the only ones whose bases it holds."""
+    from calitas_amd import shard, synth
+    assert shard.worker_threads(list(range(32)), 8, None) == 16 and shard.worker_threads(list(range(32)), 8, 16.0) == 2
+    assert shard.worker_threads(list(range(6)), 2, 16.0) == 6 and shard.worker_threads(None, 4, 16.0) == 4 and shard.worker_threads([0], 1, 0.5) == 2
+    (tmp_path / "proc/self").mkdir(parents=True)
+    (tmp_path / "proc/self/cgroup").write_text("0::/a/b\n")
+    (tmp_path / "sys/fs/cgroup/a/b").mkdir(parents=True)
+    (tmp_path / "sys/fs/cgroup/a/b/cpu.max").write_text("max 100000\n")
+    assert shard.cgroup_cpu_quota(str(tmp_path)) is None
+    (tmp_path / "sys/fs/cgroup/a/cpu.max").write_text("1600000 100000\n")
+    (tmp_path / "sys/fs/cgroup/cpu.max").write_text("3200000 100000\n")
+    assert shard.cgroup_cpu_quota(str(tmp_path)) == 16.0                      # the tightest on the way up
+    assert shard.cgroup_cpu_quota(str(tmp_path / "nowhere")) is None
+    # hg38 on 8 ranks: every rank holds 2-7 contigs (13-20 % of the bases, against an eighth owned), all 25 are held by somebody, and a rank's share is a fraction of the genome
+    L = synth.HG38_LENGTHS
+    held = [shard.resident_contigs(L, 971, f, n) for f, n in shard.window_partition(L, 8, 971)]
+    assert sorted({c for h in held for c in h}) == list(range(25)) and all(2 <= len(h) <= 7 for h in held)
+    assert max(sum(L[c] for c in h) for h in held) < 0.3 * sum(L)
+    assert all(h == sorted(h) and h == list(range(h[0], h[-1] + 1)) for h in held)   # consecutive contigs
+
+
+def test_reference_with_absent_contigs():
+    """calitas_set_reference with bases[i] == NULL: contig i keeps its name and length -- the window table, windowIterator's sequence
+    and the coordinates are the whole dictionary's -- but holds no bases here (a process of a multi-GPU job and the contigs its window
+    range does not touch).  Host-only context: the packed size shrinks to the resident contigs, the windows of a resident contig are
+    what they are in the full reference, an absent contig's bases cannot be fetched... and an index is not written from it."""
+    import numpy as np
+    import calitas_amd as C
+    rng = np.random.default_rng(3)
+    names = ["a", "b", "c"]
+    seqs = [rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=n, p=[0.24, 0.24, 0.24, 0.24, 0.04]) for n in (70000, 90000, 50000)]
+    full = C.Context(-1); full.set_reference(names, seqs)
+    part = C.Context(-1); part.set_reference(names, [None, seqs[1], None], lengths=[len(s) for s in seqs])
+    try:
+        assert part.contig_names == names and part.reference_info()["n_contigs"] == 3
+        assert part.reference_info()["total_bases"] == full.reference_info()["total_bases"]
+        assert part.reference_info()["packed_bytes"] < 0.6 * full.reference_info()["packed_bytes"]
+        assert part.window_table(1000, 971, 23, chrom_index=1) == full.window_table(1000, 971, 23, chrom_index=1)
+        assert part.fetch_bases(1, 500, 40) == full.fetch_bases(1, 500, 40)
+        with pytest.raises(C.CalitasError):
+            part.save_index("/tmp/should_not_exist.idx")
+    finally:
+        full.close(); part.close()
