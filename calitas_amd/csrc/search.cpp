@@ -238,28 +238,6 @@ static int plan_search(calitas_ctx* ctx, int32_t n_guides, const calitas_guide_t
   pl.bases = p.chrom_index >= 0 ? ref.contigs[p.chrom_index].len : ref.total_bases;
   pl.win_lo = 0; pl.win_n = 0;
   for (auto& c : ref.contigs) pl.win_n += window_count(c.len, pl.step);
-  // contigs that are absent here (refpack.hpp: a process of a multi-GPU job holds what its window range touches): a search must not need them
-  auto absent_in = [&](uint64_t w_lo, uint64_t w_hi) -> int {      // first absent contig with a window in [w_lo, w_hi), or -1
-    uint64_t base = 0;
-    for (size_t c = 0; c < ref.contigs.size(); c++) {
-      const uint64_t nw = window_count(ref.contigs[c].len, pl.step);
-      if (ref.is_absent(c) && std::max(w_lo, base) < std::min(w_hi, base + nw)) return (int)c;
-      base += nw;
-    }
-    return -1;
-  };
-  if (!ref.absent.empty()) {
-    int bad = -1;
-    if (p.n_windows != 0 || p.first_window != 0) {
-      if (p.first_window >= 0 && p.n_windows > 0) bad = absent_in((uint64_t)p.first_window, (uint64_t)p.first_window + (uint64_t)p.n_windows);
-    } else if (p.chrom_index >= 0) {
-      if (ref.is_absent((size_t)p.chrom_index)) bad = p.chrom_index;
-    } else {
-      bad = absent_in(0, pl.win_n);
-    }
-    if (bad >= 0) return fail(ctx, CALITAS_EINVAL, "contig " + ref.names[(size_t)bad] + " is not resident in this context (it was given without bases): "
-                                                   "search a window range that leaves it out");
-  }
   if (p.n_windows != 0 || p.first_window != 0) {
     // a window range of the job: scan the tiles its windows touch, align only inside those windows
     if (p.first_window < 0 || p.n_windows <= 0 || (uint64_t)p.first_window + (uint64_t)p.n_windows > pl.win_n)
@@ -393,7 +371,30 @@ static int queue_scan_inputs(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t
 
 // columnwise: round 1's column-wise scan_kernel (kernels.hip) instead of scan_rows_kernel.  Only calitas_scan_candidates_columnwise
 // asks for it -- a test hook that holds the two kernels' record sets against each other; no search path does.
+// Contigs that are absent here (refpack.hpp: a process of a multi-GPU job holds what its window range touches): a search must not need
+// one.  Checked where a plan is about to run -- the callers of a ranged search plan the whole job first and narrow it afterwards.
+static int check_resident(calitas_ctx* ctx, const SearchPlan& pl) {
+  const PackedRef& ref = ref_owner(ctx)->ref;
+  if (ref.absent.empty()) return CALITAS_OK;
+  int bad = -1;
+  if (pl.p.chrom_index >= 0) {
+    if (ref.is_absent((size_t)pl.p.chrom_index)) bad = pl.p.chrom_index;
+  } else {
+    uint64_t base = 0;
+    for (size_t c = 0; c < ref.contigs.size() && bad < 0; c++) {
+      const uint64_t nw = window_count(ref.contigs[c].len, pl.step);
+      const uint64_t t0 = ref.contigs[c].gbase / ref.tile;          // (a chunked call's lanes: contig ranges by tiles)
+      if (ref.is_absent(c) && std::max(pl.gw_lo, base) < std::min(pl.gw_hi, base + nw) && t0 >= pl.tile_lo && t0 < (uint64_t)pl.tile_lo + pl.n_tiles) bad = (int)c;
+      base += nw;
+    }
+  }
+  if (bad < 0) return CALITAS_OK;
+  return calitas_fail(ctx, CALITAS_EINVAL, "contig " + ref.names[(size_t)bad] + " is not resident in this context (it was given without bases): "
+                                           "search a window range that leaves it out");
+}
+
 static int launch_scan_stage(calitas_ctx* ctx, const SearchPlan& pl, hipStream_t stream, bool inputs_queued = false, bool columnwise = false) {
+  { int rc = check_resident(ctx, pl); if (rc) return rc; }
   if (!inputs_queued) { int rc = queue_scan_inputs(ctx, pl, stream); if (rc) return rc; }
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(ctx, pl, sa, aa);
