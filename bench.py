@@ -374,18 +374,20 @@ def main():
         """N > 1: every rank on the CPUs of its GPU's NUMA node (a rank's slice is bound by host round trips, and one from the far socket
         costs a quarter more: DESIGN.md 4.7), its share of them when several GPUs hang off one node -- before anything starts a thread.
         (calitas_amd/shard.py loaded by path: the package itself loads the HIP library, which has to come after torch.)"""
-        if world <= 1 or args.rehearse_on_one_gpu or os.environ.get("CALITAS_BENCH_PIN", "1") == "0":
+        if world <= 1:
             return None
         import importlib.util
         spec = importlib.util.spec_from_file_location("_calitas_shard", os.path.join(ROOT, "calitas_amd", "shard.py"))
         shard_mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(shard_mod)
         n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        cpus = shard_mod.pin_rank(local_rank, n_local)
+        cpus = None
+        if not (args.rehearse_on_one_gpu or os.environ.get("CALITAS_BENCH_PIN", "1") == "0"):
+            cpus = shard_mod.pin_rank(local_rank, n_local)
         if "CALITAS_THREADS" not in os.environ:
             # the library's worker pool: a thread per CPU the rank may use, and no more than its share of the box's CPU quota (a quota
             # on a shared host, not a CPU set: eight ranks with sixteen workers each on sixteen cores' worth throttle each other)
-            os.environ["CALITAS_THREADS"] = str(shard_mod.worker_threads(cpus, n_local, shard_mod.cgroup_cpu_quota()))
+            os.environ["CALITAS_THREADS"] = str(shard_mod.worker_threads(cpus or sorted(os.sched_getaffinity(0)), n_local, shard_mod.cgroup_cpu_quota()))
         return cpus
 
     if args.dry_run:
