@@ -871,6 +871,21 @@ def main():
                             "time / the measured scan time per pass (sum over the launches of a call, which share the chip with the tails)"}
         except Exception:
             pass
+        try:
+            # what stands behind the scan (expand, align, trace, the filter / hits / row kernels): the chip time of a guide's tail as the
+            # events give it, and how much of the chip's issue rate its instructions (counted in a committed counter pass) would need
+            tc = json.load(open(os.path.join(ROOT, "profiles", "r05_tail_census.json")))
+            tail_ms = (acc["align"] + acc["hitsk"]) / K / max(1, n_guides_rank)
+            winst = tc["total"]["valu_wave_inst_per_pass"]
+            result["roofline"]["tail"] = {
+                "kernel_ms_per_guide": round(tail_ms, 4), "valu_wave_inst_per_guide": winst,
+                "issue_frac": round(winst / (tail_ms * 1e-3 * 1228.8e9), 4) if tail_ms > 0 else None,
+                "counted_in_run": False, "source": "profiles/r05_tail_census.json",
+                "note": "kernel_ms = sum over the call's lanes of the kernels behind the scan (events / device stamps); the instruction count is guide #0's "
+                        "per hg38-sized pass on the per-bin tail (the random 20-mers of config 4 have ~3x its records); issue_frac = instructions / (kernel_ms x "
+                        "1228.8 G wave-inst/s): how far the tail is from being bound by issue -- it is bound by waiting"}
+        except Exception:
+            pass
         if m.get("batch_block"):
             result["batch_sharded"] = m["batch_block"]          # BASELINE config 4's shape on this partition (labelled; `value` stays the one-pass headline)
             if not m["batch_block"]["check"]["identical"]:
