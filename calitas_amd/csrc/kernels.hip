@@ -774,6 +774,231 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
   flush_items(1);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// align_pk_kernel: align_kernel with TWO jobs in every lane group, one in each 16-bit half of the lanes' registers.
+//
+// Round 5.  Alone on the chip align_kernel's waves execute vector instructions 59 % of their time at two waves per SIMD
+// (profiles/r05_pmc_align_alone_*.txt): with the prologue's dependent loads and the per-step LDS waits gone, what is left is its
+// instruction count -- ~30 vector instructions per antidiagonal step, 7.8e7 per hg38-sized pass.  A cell is score x 4 + matrix code;
+// with the reference's costs |score| <= 60 x 20, so a cell fits sixteen bits with room to spare, and v_pk_add_i16 / v_pk_max_i16 /
+// v_pk_mad_i16 do two cells per instruction: the same ~31 instructions per step now fill the strips of SIX jobs per wave (three lane
+// groups of 21 x two halves).  "Minus infinity" is the bottom of the range and the additions saturate (clamp), so a cell that is
+// out of range stays below every cell a passing alignment can go through (those lie within +-4 x max|cost| x L of zero, which the
+// host checks fits: AlignArgs::pack16); their code bits are lost, which no traceback can see.  The trace nibbles of the two jobs
+// share a byte (low nibble: the even job); each job's slab gets the rows with its header saying which nibble is its own.
+// Launched instead of align_kernel<false, 21> when the host says so; anything else (longer guides, per-matrix enumeration, costs out
+// of range, explicit targets) takes align_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+typedef short pk2 __attribute__((ext_vector_type(2)));
+typedef unsigned short upk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pk_add_sat(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(pk2, a), __builtin_bit_cast(pk2, b))); }
+__device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(pk2, a), __builtin_bit_cast(pk2, b))); }
+__device__ __forceinline__ int pk_min_u(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(upk2, a), __builtin_bit_cast(upk2, b))); }
+__device__ __forceinline__ int pk_mad(int a, int b, int c) { return __builtin_bit_cast(int, (pk2)(__builtin_bit_cast(pk2, a) * __builtin_bit_cast(pk2, b) + __builtin_bit_cast(pk2, c))); }
+__device__ __forceinline__ int pk_rep(int x) { return (int)(((uint32_t)x & 0xFFFFu) * 0x00010001u); }
+__device__ __forceinline__ int pk_half(int x, int h) { return h ? (x >> 16) : (int)(short)(x & 0xFFFF); }
+
+__global__ __launch_bounds__(64) void align_pk_kernel(AlignArgs a) {
+  CALITAS_TAIL_PRIO();
+  constexpr int LPJ = 21, GROUPS = 3, JOBS = 6, ROWS = LPJ - 1;
+  constexpr int STAGE = STAGE_FLUSH + JOBS * 16;
+  constexpr int NEG4 = -32768;                                 // "minus infinity" x 4 in sixteen bits (the additions saturate)
+  __shared__ __attribute__((aligned(16))) uint8_t s_tr[GROUPS][ROWS][TR_STRIDE];    // low nibble: the group's even job, high nibble: the odd one
+  __shared__ __attribute__((aligned(16))) uint8_t s_hd[JOBS][sizeof(SlabHeader)];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tbm[JOBS][TB_LEN];
+  __shared__ int s_fin[GROUPS][STRIP_MAX_COLS + 1];             // the bottom row's best of three, both jobs' halves
+  __shared__ uint64_t s_items[STAGE];
+  __shared__ uint32_t s_nitems;
+  const int grp = (int)(threadIdx.x >= 21) + (int)(threadIdx.x >= 42) + (int)(threadIdx.x >= 63);
+  const int r = (int)threadIdx.x - grp * LPJ;
+  const int wlane = threadIdx.x & 63;
+  if (wlane == 0) s_nitems = 0;
+  __syncthreads();
+  auto flush_items = [&](uint32_t threshold) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t n = s_nitems;
+    if (n >= threshold && n != 0) {
+      const unsigned long long act = __ballot(1);
+      const int leader = __ffsll((long long)act) - 1;
+      uint32_t base = 0;
+      if (wlane == leader) base = atomicAdd(a.item_count, n);
+      base = __shfl(base, leader);
+      const int rank = __popcll(act & ((1ull << wlane) - 1ull)), nact = __popcll(act);
+      for (uint32_t i = (uint32_t)rank; i < n; i += (uint32_t)nact)
+        if (base + i < a.item_capacity) a.items[base + i] = s_items[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (wlane == leader) s_nitems = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  };
+  const int g = grp < GROUPS ? grp : 0;
+  uint8_t (*tr)[TR_STRIDE] = s_tr[g];
+  const uint32_t* hdA = reinterpret_cast<const uint32_t*>(s_hd[2 * g]);
+  const uint32_t* hdB = reinterpret_cast<const uint32_t*>(s_hd[2 * g + 1]);
+  int* fin = s_fin[g];
+
+  uint32_t n_recs = *a.rec_count;
+  if (n_recs > a.rec_capacity) n_recs = a.rec_capacity;
+  const SearchDev& sp = a.sp;
+  uint64_t n_over = *a.job_count;
+  { const uint64_t room = (uint64_t)a.rec_capacity * (a.slots_per_rec - 1u); if (n_over > room) n_over = room; }
+  const uint64_t n_virtual = (uint64_t)n_recs + n_over;
+  auto slab_of = [&](uint64_t v) { return v < n_recs ? v : (uint64_t)a.rec_capacity + (v - n_recs); };
+
+  const uint32_t total_jobs = gridDim.x * JOBS;
+  // the group's pair of jobs: virtual jobs vi (even half) and vi + 1 (odd half)
+  uint64_t vi = grp < GROUPS ? ((uint64_t)blockIdx.x * GROUPS + (uint64_t)grp) * 2 : n_virtual;
+  uint4 pfA = make_uint4(0u, 0u, 0u, 0u), pfB = make_uint4(0u, 0u, 0u, 0u);
+  auto prefetch = [&](uint64_t v) {
+    if (r < JOB_HEAD16) {
+      pfA = reinterpret_cast<const uint4*>(a.slab + slab_of(v) * a.slab_bytes)[r];
+      if (v + 1 < n_virtual) pfB = reinterpret_cast<const uint4*>(a.slab + slab_of(v + 1) * a.slab_bytes)[r];
+      else pfB = make_uint4(0u, 0u, 0u, 0u);                    // (no odd job: a header of zeros says "no job")
+    }
+  };
+  if (vi < n_virtual) prefetch(vi);
+  for (; vi < n_virtual; vi += total_jobs) {
+    flush_items(STAGE_FLUSH);
+    // ---- stage the two heads in LDS ----
+    auto conv = [](uint32_t t) { const uint32_t f = (t >> 4) & 0x01010101u; return t & 0x0F0F0F0Fu & ~(f * 0xFFu); };
+    if (r < (int)(sizeof(SlabHeader) / 16)) {
+      reinterpret_cast<uint4*>(s_hd[2 * g])[r] = pfA;
+      reinterpret_cast<uint4*>(s_hd[2 * g + 1])[r] = pfB;
+    } else if (r < JOB_HEAD16) {
+      reinterpret_cast<uint4*>(s_tbm[2 * g])[r - (int)(sizeof(SlabHeader) / 16)] = make_uint4(conv(pfA.x), conv(pfA.y), conv(pfA.z), conv(pfA.w));
+      reinterpret_cast<uint4*>(s_tbm[2 * g + 1])[r - (int)(sizeof(SlabHeader) / 16)] = make_uint4(conv(pfB.x), conv(pfB.y), conv(pfB.z), conv(pfB.w));
+    }
+    if (vi + total_jobs < n_virtual) prefetch(vi + total_jobs);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ncolsA = (int)(hdA[5] & 0xFFFFu), ncolsB = (int)(hdB[5] & 0xFFFFu);
+    if (ncolsA == 0 && ncolsB == 0) continue;                   // (records whose columns lie in no window of this call)
+    {
+      const int L = (int)((ncolsA ? hdA[6] : hdB[6]) >> 24);    // (one protospacer length per launch: the host checked)
+      const int ncols = max(ncolsA, ncolsB);
+      const bool tbdA = ((hdA[6] >> 16) & 0xFFu) != 0u, tbdB = ((hdB[6] >> 16) & 0xFFu) != 0u;
+      const int qm = (r < L) ? ((int)reinterpret_cast<const uint8_t*>(hdA + 16)[r] | ((int)reinterpret_cast<const uint8_t*>(hdB + 16)[r] << 16)) : 0;
+
+      // ---- fill: align_kernel's, two cells per register ----
+      const int i_row = r + 1;
+      const int tgap4 = pk_rep(sp.target_gap * 4), qgap4 = pk_rep(sp.query_gap * 4);
+      const int mism_t = pk_rep(sp.mismatch * 4 + TR_DIAG), delta_t = pk_rep((sp.match - sp.mismatch) * 4);
+      const int one2 = 0x00010001, keep2 = (int)0xFFFCFFFC;
+      int curD = pk_rep(NEG4 + TR_DIAG), curL = pk_rep(NEG4 + TR_LEFT);
+      int curU = (int)(((uint32_t)((tbdA ? i_row * sp.target_gap * 4 : NEG4) + TR_UP) & 0xFFFFu) | ((uint32_t)((tbdB ? i_row * sp.target_gap * 4 : NEG4) + TR_UP) << 16));
+      if (r == LPJ - 1) { curD = pk_rep(TR_DIAG); curL = pk_rep(NEG4 + TR_LEFT); curU = pk_rep(TR_UP); }   // "row 0" for the group above
+      int curP = pk_max(pk_max(curD, curL), curU);
+      const int t_first = r + 1, t_last = r < L ? r + ncols : -1;
+      const int nsteps = ncols + L - 1;
+      int inD = pk_rep(TR_DIAG), inU = pk_rep(TR_UP), inPa = pk_rep(TR_DIAG), inPb = pk_rep(TR_DIAG);
+      auto shift_in = [](int& dst, int src) { dst = __builtin_amdgcn_update_dpp(dst, src, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); };
+      const uint32_t* tbmA = reinterpret_cast<const uint32_t*>(s_tbm[2 * g]);
+      const uint32_t* tbmB = reinterpret_cast<const uint32_t*>(s_tbm[2 * g + 1]);
+      const bool row1 = r == 0, bottom = r == L - 1;
+      uint8_t* const trow = &tr[r < ROWS ? r : ROWS - 1][0];
+      int m = 0;
+      uint32_t wA = tbmA[0], wB = tbmB[0];
+      asm volatile("" : "+v"(wA), "+v"(wB));
+      auto cell = [&](const int t, const int jj, int inPp) {
+        shift_in(inD, curD);
+        shift_in(inU, curU);
+        // the two jobs' masks of the column row 1 is at: byte jj of wA in the low half, of wB in the high half
+        const int own = (int)__builtin_amdgcn_perm(wB, wA, 0x0C000C00u | (uint32_t)jj | ((uint32_t)(4 + jj) << 16));
+        m = __builtin_amdgcn_update_dpp(own, m, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (row1) m = own;
+        const bool on = t >= t_first && t <= t_last;
+        int c = 0, tbyte = 0;
+        if (on) {
+          c = t - r;
+          const int hit = pk_min_u(qm & m, one2);             // 1 per half where the row's set meets the column's
+          const int add_t = pk_mad(hit, delta_t, mism_t);
+          const int newD = pk_add_sat(inPp & keep2, add_t);
+          const int newU = pk_add_sat(pk_max(inD, inU), tgap4);
+          const int newL = pk_add_sat(pk_max(curD, curL), qgap4);
+          // trace nibble per half: bits 0-1 where Diag came from, bit 2 Up came from Diag, bit 3 Left came from Left
+          const int tn = (inPp & 0x00030003) | ((newU & 0x00020002) << 1) | ((newL & one2) << 3);
+          tbyte = tn | (tn >> 12);                            // low nibble: the even job, high nibble: the odd one
+          curD = newD; curU = newU & keep2; curL = (newL & keep2) | one2;
+          curP = pk_max(pk_max(curD, curL), curU);
+        }
+        trow[c] = (uint8_t)tbyte;
+        fin[bottom ? c : 0] = curP;
+      };
+      shift_in(inPa, curP);
+      for (int t = 1; t <= nsteps; t += 4) {
+        const uint32_t nA = tbmA[(t + 3) >> 2], nB = tbmB[(t + 3) >> 2];
+        shift_in(inPb, curP);
+        cell(t, 0, inPa);
+        shift_in(inPa, curP);
+        cell(t + 1, 1, inPb);
+        shift_in(inPb, curP);
+        cell(t + 2, 2, inPa);
+        shift_in(inPa, curP);
+        cell(t + 3, 3, inPb);
+        wA = nA; wB = nB;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // ---- hand over, one job after the other ----
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t* hd32 = h ? hdB : hdA;
+        const int ncols_h = h ? ncolsB : ncolsA;
+        const int c0 = (int)hd32[4], ntb = (int)(hd32[5] >> 16), dir = (int)(hd32[6] & 0xFFu);
+        const int g_min_score = (int)hd32[24];
+        const uint32_t sel = ncols_h ? hd32[25] : 0u;
+        const int jb = (int)hd32[26];
+        int myb = -1;
+        {
+          const int sfirst = __ffs(sel) - 1, slast = 31 - __clz(sel);
+          int cnt = 0;
+          if (dir == 0) { for (int b = sfirst; b <= slast; b++) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
+          else          { for (int b = slast; b >= sfirst; b--) if ((sel >> b) & 1u) { if (cnt == r) myb = b; cnt++; } }
+        }
+        int j = 0, P = 0;
+        bool pass = false;
+        if (myb >= 0) {
+          j = dir ? jb - myb : jb + myb;
+          P = pk_half(fin[j - c0], h);
+          pass = (P >> 2) >= g_min_score;
+        }
+        const unsigned long long bal = __ballot(pass);
+        const uint32_t mine = (uint32_t)(bal >> (grp * LPJ)) & 0xFFFFu;
+        if (mine != 0u) {
+          const uint64_t ji = slab_of(vi + (uint64_t)h);
+          uint8_t* slab = a.slab + ji * a.slab_bytes;
+          SlabHeader* hd = reinterpret_cast<SlabHeader*>(slab);
+          const int stride = (ncols + 4) & ~3;                  // the PAIR's row length: both jobs' rows are the group's rows
+          const uint32_t tb_bytes = (uint32_t)((ntb + 3) & ~3);
+          if (r == 0) { hd->pass_mask = mine; hd->stride = (uint16_t)stride; hd->pad = (uint16_t)h; }
+          if (pass) {
+            hd->j[r] = (uint16_t)j;
+            const uint64_t where = ((ji & 0xFFFFFFFFFull) << 4) | (uint64_t)r;
+            const uint32_t slot = atomicAdd(&s_nitems, 1u);
+            if (slot < (uint32_t)STAGE) s_items[slot] = where | ((uint64_t)(P & 3) << 40) | ((uint64_t)(uint32_t)((P >> 2) + (1 << 21)) << 42);
+          }
+          if (r < L) {
+            uint32_t* drow = reinterpret_cast<uint32_t*>(slab + sizeof(SlabHeader) + tb_bytes + (uint32_t)(r * stride));
+            const uint32_t* srow = reinterpret_cast<const uint32_t*>(&tr[r][0]);
+            for (int x = 0; x < stride / 4; x++) drow[x] = srow[x];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  flush_items(1);
+}
+
 // Traceback + PAM extension of one candidate end column (item = (record x window slot) slab index << 4 | candidate slot).
 template <typename Emit>
 __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& sp, uint64_t it, const uint8_t (*s_qmask)[MAX_L],
@@ -786,7 +1011,7 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
     if (!((hd->pass_mask >> x) & 1u)) return;
     const uint8_t* tb = slab + sizeof(SlabHeader);
     const uint8_t* tr = tb + ((hd->ntb + 3) & ~3);
-    const int L = hd->L, c0 = hd->c0, n = hd->n, gi = hd->guide, stride = hd->stride;
+    const int L = hd->L, c0 = hd->c0, n = hd->n, gi = hd->guide, stride = hd->stride, nib4 = hd->pad ? 4 : 0;
     const bool true_border = hd->true_border != 0;
     const int j = hd->j[x], gscore = (int)(uint32_t)(it >> 42) - (1 << 21);   // score and start matrix travel in the item
     const int g_npams = s_gint[gi][0], g_maxd = s_gint[gi][1], g_maxp = s_gint[gi][2], g_maxf = s_gint[gi][3];
@@ -805,7 +1030,7 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
         if (!true_border || m != TR_UP) { ok = false; break; }
         op = 2; i--;                                   // 'I'; Up(i,0) traces to Up, Up(1,0) to Diag(0,0)
       } else {
-        const int t8 = tr[(i - 1) * stride + c];
+        const int t8 = (tr[(i - 1) * stride + c] >> nib4) & 15;   // (align_pk_kernel: two jobs' trace nibbles share a byte)
         if (m == TR_DIAG) {
           const int tm = tb[c - 1], q = s_qmask[gi][i - 1];
           const bool compat = (q & tm & 15) != 0;
@@ -1105,6 +1330,9 @@ hipError_t launch_align(const AlignArgs& a, uint32_t n_blocks, hipStream_t strea
   // three jobs per wave when no guide has more than 20 rows (max_guide_len 0: unknown)
   bool three = a.max_guide_len > 0 && a.max_guide_len <= 20;
   if (const char* env = TUNE_GET("CALITAS_ALIGN_LPJ")) three = three && std::atoi(env) == 21;   // (tests / measurements: 32 forces two jobs)
+  bool pack = three && !a.sp.per_matrix && a.pack16 != 0;
+  if (const char* env = TUNE_GET("CALITAS_ALIGN_PACK")) pack = pack && std::atoi(env) != 0;    // (tests / measurements: 0 = one job per lane group)
+  if (pack) { hipLaunchKernelGGL(align_pk_kernel, grid, block, 0, stream, a); return hipGetLastError(); }
   if (a.sp.per_matrix) {
     if (three) hipLaunchKernelGGL((align_kernel<true, 21>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((align_kernel<true, 32>), grid, block, 0, stream, a);

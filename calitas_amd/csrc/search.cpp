@@ -327,6 +327,14 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.rec_count = ctx->d_counters; aa.out = ctx->d_raw; aa.out_count = ctx->d_counters + 1; aa.anomalies = ctx->d_counters + 2;
   aa.trace_done = ctx->d_counters + 5; aa.job_count = ctx->d_counters + 6;
   for (int g = 0; g < pl.n_guides; g++) aa.max_guide_len = std::max<int32_t>(aa.max_guide_len, pl.gd[g].L);
+  {
+    // two jobs per lane group (align_pk_kernel): one protospacer length for all guides of the launch, and every cell a passing
+    // alignment can go through -- within +-max|cost| x L of zero -- times four, with a step's cost on top, inside sixteen bits
+    bool same_L = true;
+    for (int g = 1; g < pl.n_guides; g++) same_L = same_L && pl.gd[g].L == pl.gd[0].L;
+    const int64_t big = std::max<int64_t>(std::max<int64_t>(std::abs(pl.sc.match), std::abs(pl.sc.mismatch)), std::max<int64_t>(std::abs(pl.sc.target_gap), std::abs(pl.sc.query_gap)));
+    aa.pack16 = (same_L && aa.max_guide_len <= 20 && 4 * big * ((int64_t)aa.max_guide_len + 2) < 30000) ? 1 : 0;
+  }
   aa.rec_capacity = ctx->rec_cap; aa.out_capacity = ctx->raw_cap;
   aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
   aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
