@@ -349,7 +349,7 @@ __device__ __forceinline__ uint4 decode_piece(const Run* runs, int64_t n_runs, u
 }
 
 __global__ __launch_bounds__(256) void expand_kernel(AlignArgs a) {
-  CALITAS_TAIL_PRIO();
+  if (!a.low_prio) CALITAS_TAIL_PRIO();
   if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[0] = (unsigned long long)wall_clock64();   // (binned.hpp, BIN_BOX_STAMPS)
   __shared__ JobSeed s_seed[4][64];
   __shared__ int s_gint[MAX_GUIDES][4];                           // L, span, min_guide_score, cli_length
@@ -532,7 +532,7 @@ static_assert((sizeof(SlabHeader) + TB_LEN) % 16 == 0 && JOB_HEAD16 < 20, "one 1
 
 template <bool PM, int LPJ>
 __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
-  CALITAS_TAIL_PRIO();
+  if (!a.low_prio) CALITAS_TAIL_PRIO();
   static_assert(LPJ == 32 || LPJ == 21, "two or three jobs per wave");
   constexpr int JOBS = 64 / LPJ;            // jobs per wave (= per workgroup)
   constexpr int ROWS = LPJ == 32 ? MAX_L : LPJ - 1;   // rows a job can have
@@ -799,7 +799,7 @@ __device__ __forceinline__ int pk_rep(int x) { return (int)(((uint32_t)x & 0xFFF
 __device__ __forceinline__ int pk_half(int x, int h) { return h ? (x >> 16) : (int)(short)(x & 0xFFFF); }
 
 __global__ __launch_bounds__(64) void align_pk_kernel(AlignArgs a) {
-  CALITAS_TAIL_PRIO();
+  if (!a.low_prio) CALITAS_TAIL_PRIO();
   constexpr int LPJ = 21, GROUPS = 3, JOBS = 6, ROWS = LPJ - 1;
   constexpr int STAGE = STAGE_FLUSH + JOBS * 16;
   constexpr int NEG4 = -32768;                                 // "minus infinity" x 4 in sixteen bits (the additions saturate)
@@ -1102,7 +1102,7 @@ __device__ __forceinline__ void trace_one(const AlignArgs& a, const SearchDev& s
 // '='/'X' ops, extendAndFilterRight (SequentialGuideAligner.scala:433-492), one RawAln per (candidate, PAM).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void trace_kernel(AlignArgs a, uint32_t* box, uint32_t seq) {
-  CALITAS_TAIL_PRIO();
+  if (!a.low_prio) CALITAS_TAIL_PRIO();
   __shared__ uint8_t s_qmask[MAX_GUIDES][MAX_L];
   __shared__ uint8_t s_pam[MAX_GUIDES][MAX_PAMS][MAX_PAM_LEN];
   __shared__ uint8_t s_pamlen[MAX_GUIDES][MAX_PAMS];

@@ -60,6 +60,7 @@ struct AlignArgs {
   uint32_t bin_n;          // bins of the range (an alignment whose window starts outside is not listed: cannot happen, checked)
   uint32_t bin_shift;      // log2 of the bases per bin
   uint32_t bin_cap;
+  int32_t low_prio;                 // 1: expand / align / trace at the scan's wave priority (a tail that runs beside the next range's scan and ends no call)
   int32_t pack16;                   // 1: every guide has the same protospacer length (<= 20) and the cells fit sixteen bits: align_pk_kernel
   int32_t max_guide_len;            // longest protospacer among the guides (0 = unknown): align_kernel packs three jobs per wave up to 20
   unsigned long long* stamps;       // (binned tail) stamps[0] = the device's wall clock when align_kernel starts; may be null

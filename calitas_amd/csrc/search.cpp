@@ -339,6 +339,7 @@ static void fill_kernel_args(calitas_ctx* ctx, const SearchPlan& pl, ScanArgs& s
   aa.slab = ctx->d_slab; aa.cand_count = ctx->d_counters + 4; aa.items = ctx->d_items; aa.item_count = ctx->d_counters + 3; aa.item_capacity = ctx->item_cap;
   aa.slab_bytes = pl.slab_bytes; aa.slots_per_rec = pl.slots_per_rec; aa.tile_words = (uint32_t)(ref.tile / 16);
   aa.gw_lo = pl.gw_lo; aa.gw_hi = pl.gw_hi;
+  if (const char* e = TUNE_GET("CALITAS_TAIL_PRIO_NARROW")) aa.low_prio = (pl.narrow_tail && std::atoi(e) == 0) ? 1 : 0;
   aa.sp.window_size = p.window_size; aa.sp.step = pl.step; aa.sp.n_guides = pl.n_guides;
   aa.sp.max_guide_diffs = p.max_guide_diffs; aa.sp.max_pam_mismatches = p.max_pam_mismatches;
   aa.sp.max_gaps = p.max_gaps_between_guide_and_pam;
@@ -431,6 +432,9 @@ static void kernel_times(calitas_ctx* ctx, calitas_timing_t& tm) {
 // trace_kernel's grid makes no difference between 512 and 2048 (256 costs 0.3 ms at full size).
 // CALITAS_ALIGN_BLOCKS / CALITAS_TRACE_BLOCKS (and ..._NARROW for the ranges whose tail runs beside the next range's scan) override.
 constexpr int kAlignBlocks = 512, kTraceBlocks = 2048;
+// ... with two jobs per lane group (align_pk_kernel, round 5) a wave does the work of two: 256 units beside a scan (an eighth of the
+// genome as a rank's window range: 0.446 against 0.494 ms at 512, tools/owned_sweep.py), 384 for a tail that runs alone.
+constexpr int kAlignBlocksPackedNarrow = 256, kAlignBlocksPacked = 384;
 static int narrow_blocks(const char* e, int fallback) {   // e = the switch's value (TUNE_GET), or null
   if (e) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) return v; }
   return fallback;
@@ -478,7 +482,7 @@ static int search_run(calitas_ctx* ctx, const SearchPlan& pl, calitas_aln_t** ou
     }
     ScanArgs sa; AlignArgs aa;
     fill_kernel_args(ctx, pl, sa, aa);
-    HIP_TRY(ctx, launch_align(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_ALIGN_BLOCKS_NARROW") : TUNE_GET("CALITAS_ALIGN_BLOCKS"), kAlignBlocks), ctx->stream));
+    HIP_TRY(ctx, launch_align(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_ALIGN_BLOCKS_NARROW") : TUNE_GET("CALITAS_ALIGN_BLOCKS"), aa.pack16 && !aa.sp.per_matrix ? (pl.narrow_tail ? kAlignBlocksPackedNarrow : kAlignBlocksPacked) : kAlignBlocks), ctx->stream));
     // (trace_kernel can post the counters itself from its last workgroup -- launch_trace's `post` -- but finding the last of 2048
     // workgroups is 2048 atomics on one word, ~8 ns each: 20-30 us against the ~10 us of this launch)
     HIP_TRY(ctx, launch_trace(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_TRACE_BLOCKS_NARROW") : TUNE_GET("CALITAS_TRACE_BLOCKS"), kTraceBlocks), ctx->stream, ctx->ev[2]));
@@ -1149,7 +1153,7 @@ static int lane_rows_binned(calitas_ctx* lane, const SearchPlan& pl, bool prelau
   ScanArgs sa; AlignArgs aa;
   fill_kernel_args(lane, pl, sa, aa);
   binned_fill_align_args(lane->binned, geo, aa);
-  HIP_TRY(lane, launch_align(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_ALIGN_BLOCKS_NARROW") : TUNE_GET("CALITAS_ALIGN_BLOCKS"), kAlignBlocks), lane->stream));
+  HIP_TRY(lane, launch_align(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_ALIGN_BLOCKS_NARROW") : TUNE_GET("CALITAS_ALIGN_BLOCKS"), aa.pack16 && !aa.sp.per_matrix ? (pl.narrow_tail ? kAlignBlocksPackedNarrow : kAlignBlocksPacked) : kAlignBlocks), lane->stream));
   // (no events on these dispatches: each would hold back the kernel behind it by ~5 us; the kernels stamp the device's wall clock instead)
   HIP_TRY(lane, launch_trace(aa, narrow_blocks(pl.narrow_tail ? TUNE_GET("CALITAS_TRACE_BLOCKS_NARROW") : TUNE_GET("CALITAS_TRACE_BLOCKS"), kTraceBlocks), lane->stream, nullptr));
   HIP_TRY(lane, binned_run(lane->binned, &lane->hits, geo, hr, lane->d_raw, lane->d_guides, own->d_win_base, own->d_win, bp, lane->d_counters, lane->stream,

@@ -45,6 +45,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_LANE_SETUP", "0", "F: separate stream commands instead of the one-launch lane setup"},
   {"CALITAS_LANE_PRIO", "low | low0 | low01", "T: lanes' streams at low priority (experiment)"},
   {"CALITAS_ALIGN_LPJ", "32", "F: two jobs of 32 lanes per aligner wave even for guides of up to 20 rows"},
+  {"CALITAS_TAIL_PRIO_NARROW", "0", "T: expand / align / trace of the ranges whose tail runs beside the next range's scan at the scan's wave priority (experiment)"},
   {"CALITAS_ALIGN_PACK", "0", "F: one job per lane group in the aligner (align_kernel) where two would fit (align_pk_kernel: cells in sixteen bits)"},
   {"CALITAS_ALIGN_BLOCKS", "n", "T: align_kernel grid, units of four one-wave workgroups (default 512)"},
   {"CALITAS_ALIGN_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
