@@ -835,17 +835,17 @@ def main():
                                                           "nothing is shared between guides"}
         # instruction count and HBM traffic of the dominant kernel for this exact workload, from the committed counter passes
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")))["scan_rows_kernel"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")))["scan_rows_kernel"]
             if world == 1 and args.config in (3, 4) and args.scale == 1.0:
                 scale = 1.0 if n_guides_rank > 1 else 1.0 / launches
                 result["roofline"]["traffic"] = pm["traffic_bytes_per_pass"] * scale
-                result["roofline"]["traffic_source"] = "profiles/r04_pmc_summary.json"
+                result["roofline"]["traffic_source"] = "profiles/r05_pmc_summary.json"
                 result["roofline"]["traffic_measured_in_run"] = False
                 insts = pm["SQ_INSTS_VALU"]                                 # wave-instructions of one pass (one guide)
                 ach = insts * max(1, n_guides_rank) / (acc["scan"] / K * 1e6)   # per nanosecond
                 result["roofline"]["valu"] = {
                     "bound": "valu-issue", "achieved": ach, "unit": "G wave-inst/s", "wave_insts_per_pass": insts,
-                    "lane_ops_per_base": pm["valu_lane_ops_per_base"], "counted_in_run": False, "source": "profiles/r04_pmc_summary.json",
+                    "lane_ops_per_base": pm["valu_lane_ops_per_base"], "counted_in_run": False, "source": "profiles/r05_pmc_summary.json",
                     "peak": VALU_PEAK_GUIDE, "frac": ach / VALU_PEAK_GUIDE,
                     "peak_note": "256 CU x 4 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)",
                     "peak_measured": 1024 / pm["valu_full_rate_ns_per_wave_inst_per_simd"],
