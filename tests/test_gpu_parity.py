@@ -62,6 +62,13 @@ def product_rows(C, fasta, guide, aux=(), chrom=None, **kw):
         finally:
             del os.environ["CALITAS_ALIGN_LPJ"]
         assert text5 == text, "align_kernel with two and with three jobs per wave differ"
+        # one job per lane group (align_kernel) against two in sixteen-bit halves (align_pk_kernel, the default where the cells fit)
+        os.environ["CALITAS_ALIGN_PACK"] = "0"
+        try:
+            text7, _ = C.SearchReference(guide=guide, guide_id="a", context=ctx, auxiliary_pams=aux, chrom=chrom, **pk).run("v0", "stamp")
+        finally:
+            del os.environ["CALITAS_ALIGN_PACK"]
+        assert text7 == text, "align_kernel and align_pk_kernel differ"
         # the lane's small inputs as separate stream commands instead of the one setup launch (kernels.hpp, LaneSetupArgs)
         os.environ["CALITAS_LANE_SETUP"] = "0"
         try:
@@ -166,6 +173,12 @@ CONFIGS = [
     ("eqx-by-score", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=2, switches=2)),
     ("costs", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=2, guide_mismatch_net_cost=-100, pam_mismatch_net_cost=-200,
                                                   genome_gap_net_cost=-104, guide_gap_net_cost=-102)),
+    # costs at the edge of what align_pk_kernel's sixteen-bit cells hold (4 x max|cost| x (L + 2) < 30 000: 330 -> 29 040) and beyond it
+    # (400 -> 35 200: the search takes align_kernel): both against the oracle
+    ("costs-16bit-edge", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=2, guide_mismatch_net_cost=-660, pam_mismatch_net_cost=-700,
+                                                             genome_gap_net_cost=-650, guide_gap_net_cost=-640)),
+    ("costs-beyond-16bit", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=4, p=1, g=2, guide_mismatch_net_cost=-800, pam_mismatch_net_cost=-900,
+                                                               genome_gap_net_cost=-820, guide_gap_net_cost=-810)),
     ("per-matrix", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=2, switches=1)),
     ("per-matrix-wide-overlap", "CTTGCCCCACAGGGCAGTAAnrg", (), dict(d=5, p=1, g=3, O=100, switches=1)),
     ("per-matrix-eqx-pamless", "GTGACTTGAAGTCTCAGTATA", (), dict(d=5, O=40, switches=3)),
