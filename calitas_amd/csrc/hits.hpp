@@ -86,7 +86,9 @@ struct HitsOwn { unsigned long long lo = 0, hi = ~0ull, safe = 0; };
 
 // Where a per-contig pass gets its HitsExt from: get(contig, &ext) is called right before the contig's row stage and may block until the
 // caller has finished the contig's entries (*ext = nullptr: none).  A return value != 0 means the caller gave up: the search stops.
-struct HitsExtSource { std::function<int(int contig, const HitsExt** ext)> get; };
+// compact_rows: the entries' rows are compact (post.hpp, compact_row_strings_keep_build: no guide_id / protospacer, "\n" for a tail), and
+// so may the device's own be -- the per-contig texts then cross PCIe compact and are expanded on the host
+struct HitsExtSource { std::function<int(int contig, const HitsExt** ext)> get; bool compact_rows = false; };
 
 // d_final[0..n): accepted alignments of ONE guide in calitas_search order (device memory).  Stream-ordered except for one
 // synchronisation to learn the text size.  max_ops bounds the padded columns of any alignment of this search (it sizes the

@@ -283,6 +283,17 @@ RowStrings compact_row_strings(const RowStrings& full) {
   return c;
 }
 
+RowStrings compact_row_strings_keep_build(const RowStrings& full, std::string* cut) {
+  RowStrings c = full;
+  size_t at = full.head.find('\t');                             // head = guide_id \t protospacer \t genome_build \t
+  if (at != std::string::npos) at = full.head.find('\t', at + 1);
+  const size_t n = at == std::string::npos ? 0 : at + 1;
+  if (cut) *cut = full.head.substr(0, n);
+  c.head = full.head.substr(n);
+  c.tail = "\n";
+  return c;
+}
+
 namespace {
 
 // Rows are assembled in a buffer that stays in the first-level cache and leave it as whole 64-byte lines through non-temporal stores:

@@ -54,6 +54,9 @@ RowStrings make_row_strings(const PackedRef& ref, const GuideHost& g, const std:
 // kernels write `chromosome \t middle \n` per row -- the same kernels, half the bytes over PCIe -- and the library puts head and tail
 // back on the host's worker pool while the next text is on the bus.
 RowStrings compact_row_strings(const RowStrings& full);
+// The same with genome_build left in the rows: the variant branch's rows have one of their own ("<build>+variants" for a hit that
+// touches a variant, ReferenceHit.scala:208), so only guide_id and protospacer are cut; *cut = what was cut from the head.
+RowStrings compact_row_strings_keep_build(const RowStrings& full, std::string* cut);
 // n bytes of compact rows (`rows` of them) -> full rows at out, which has room for n + rows * (head.size() + tail.size() - 1) bytes.
 // Returns the bytes written, or (size_t)-1 when the text does not hold exactly `rows` newline-terminated rows.
 size_t expand_rows(const char* compact, size_t n, uint64_t rows, const std::string& head, const std::string& tail, char* out, WorkerPool* pool);

@@ -850,7 +850,7 @@ static int rows_late_check(calitas_ctx* lane, const LaneText& lt) {
 // (post.cpp RowExpansion) -- the call's last expansion ends ~one piece after its copy instead of a whole expansion after it.
 // *wrote: bytes written at dst, (size_t)-1 when the text does not hold lt.rows rows.
 static int compact_rows_to_host(calitas_ctx* owner, calitas_ctx* lane, LaneText& lt, size_t nbytes, char* staging, const std::string& head,
-                                const std::string& tail, char* dst, std::mutex* copy_mu, size_t* wrote) {
+                                const std::string& tail, char* dst, std::mutex* copy_mu, size_t* wrote, hipEvent_t rows_done = nullptr) {
   *wrote = 0;
   dma_open_once(owner);
   // (pieces of a sixth of the text, 256 KB to 2 MB -- less left to do behind the last piece of a short text: 2.028 against 2.001 ms)
@@ -858,14 +858,15 @@ static int compact_rows_to_host(calitas_ctx* owner, calitas_ctx* lane, LaneText&
   if (const char* e = TUNE_GET("CALITAS_COMPACT_PIECE_KB")) piece = (size_t)std::max(64, std::atoi(e)) << 10;
   const bool in_host_text = lane->binned_late_check && lt.d_text == binned_host_text(lane->binned);
   auto whole = [&]() -> int {
-    int r = text_to_host(owner, lane, staging, lt.d_text, nbytes, copy_mu, &lt.tm.hits_copy_ms);
+    int r = text_to_host(owner, lane, staging, lt.d_text, nbytes, copy_mu, &lt.tm.hits_copy_ms, rows_done);
     if (r) return r;
     *wrote = expand_rows(staging, nbytes, lt.rows, head, tail, dst, owner->pool);
     g_marks.mark("expanded");
     return CALITAS_OK;
   };
   if (!owner->dma.usable() || in_host_text || nbytes < std::min<size_t>(1u << 20, 2 * piece)) return whole();   // (a short text: one copy, then the rows)
-  HIP_TRY(lane, calitas_spin_sync(lane->stream));
+  // (rows_done: the caller recorded it behind the row kernels and other work may already be queued behind it on the stream)
+  if (rows_done) HIP_TRY(lane, calitas_spin_sync(rows_done)); else HIP_TRY(lane, calitas_spin_sync(lane->stream));
   g_marks.mark("rows-done");
   if (lane->binned_late_check && lane->mbox.host && lane->mbox.host[BIN_BOX_LATE] != 0)
     return fail(lane, CALITAS_EHIP, "binned rows kernel: a row's length differs between the two kernels (internal error)");
@@ -1414,6 +1415,13 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   std::string version, stamp;
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const RowStrings rs = make_row_strings(ref, pl.gh[0], guide_id, pl.p, version, stamp);
+  // Round 5: the per-contig texts cross PCIe compact (post.hpp) when the call builds one block and a caller's entries, if any, are
+  // compact as well -- 21.8 GB of rows at BASELINE config 5's size were 0.42-0.47 s of the reference passes on the bus.  genome_build
+  // stays in the rows (the variant branch's rows have one of their own); a text sink still gets whole rows as they come.
+  std::string cut_head;
+  bool compact = !sink && (!ext_source || ext_source->compact_rows);
+  if (const char* e = TUNE_GET("CALITAS_COMPACT_ROWS")) compact = compact && std::atoi(e) != 0;
+  const RowStrings rs_dev = compact ? compact_row_strings_keep_build(rs, &cut_head) : rs;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   rc = ensure_bin_base(ctx, pl, ctx->stream);
   if (rc) return rc;
@@ -1494,7 +1502,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       const auto t_rows = std::chrono::steady_clock::now();
       passes[i].general_tail = ext_source != nullptr;
       try {
-        sl.rc = lane_rows(ctx, passes[i], false, rs, guide_id, version, stamp, sl.lt, false, nullptr, ext_source, pass_contig[i]);
+        sl.rc = lane_rows(ctx, passes[i], false, rs_dev, guide_id, version, stamp, sl.lt, false, nullptr, ext_source, pass_contig[i]);
       } catch (const std::exception& e) {                      // (this thread has no caller to unwind to)
         sl.rc = fail(ctx, CALITAS_EHIP, std::string("a contig pass ended with an exception: ") + e.what());
       }
@@ -1532,12 +1540,36 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     bases_done += ref.contigs[c].len;
     if (lt.bytes) {
       // room for this contig, and -- extrapolating from the bases done so far -- for the rest
-      const double per_base = (double)(total - hlen + lt.bytes) / (double)std::max<uint64_t>(1, bases_done);
+      const bool expand = compact && !lt.on_host;             // (rows the host stages built are whole already)
+      const size_t full_bytes = expand ? (size_t)lt.bytes + (size_t)lt.rows * (cut_head.size() + rs.tail.size() - 1) : (size_t)lt.bytes;
+      const double per_base = (double)(total - hlen + full_bytes) / (double)std::max<uint64_t>(1, bases_done);
       const size_t guess = pl.p.chrom_index >= 0 ? 0 : (size_t)(per_base * 1.05 * (double)(ref.total_bases - bases_done));
       if (!sink) {
-        char* grown = (char*)calitas_out_grow(text, total, total + (size_t)lt.bytes + 1 + guess);
+        char* grown = (char*)calitas_out_grow(text, total, total + full_bytes + 1 + guess);
         if (!grown) { rc = fail(ctx, CALITAS_EINVAL, "out of memory"); break; }
         text = grown;
+      }
+      if (expand) {
+        // the contig's compact text over the bus in pieces into the page-locked block, the worker pool puts guide_id, protospacer and
+        // the tail back while the rest is still on its way (compact_rows_to_host); the next contig's kernels run meanwhile
+        const size_t n = (size_t)lt.bytes;
+        if (n > bounce_cap) { calitas_free(bounce); bounce = (char*)calitas_out_alloc_pinned(n); bounce_cap = bounce ? n : 0; }
+        if (!bounce) { rc = fail(ctx, CALITAS_EINVAL, "out of memory"); break; }
+        size_t wrote = 0;
+        rc = compact_rows_to_host(ctx, ctx, lt, n, bounce, cut_head, rs.tail, text + total, &copy_mu, &wrote, sl.rows_done);
+        if (rc) break;
+        if (wrote != full_bytes) { rc = fail(ctx, CALITAS_EHIP, "a contig's compact rows do not expand to the row count the device reported (internal error)"); break; }
+        if ((rc = rows_late_check(ctx, lt)) != CALITAS_OK) break;
+        total += full_bytes;
+        rows += lt.rows;
+        tm.scan_kernel_ms += lt.tm.scan_kernel_ms; tm.align_kernel_ms += lt.tm.align_kernel_ms; tm.gpu_total_ms += lt.tm.gpu_total_ms;
+        tm.host_post_ms += lt.tm.host_post_ms; tm.bases_scanned += lt.tm.bases_scanned; tm.packed_bytes += lt.tm.packed_bytes;
+        tm.scan_records += lt.tm.scan_records; tm.candidate_columns += lt.tm.candidate_columns; tm.raw_alignments += lt.tm.raw_alignments;
+        tm.accepted_alignments += lt.tm.accepted_alignments; tm.retries += lt.tm.retries; tm.hits_copy_ms += lt.tm.hits_copy_ms;
+        tm.binned_lanes += lt.tm.binned_lanes; tm.owned_general_lanes += lt.tm.owned_general_lanes;
+        { std::lock_guard<std::mutex> lk(mu); sl.state = 0; }
+        cv.notify_all();
+        continue;
       }
       if (lt.on_host) {
         if (!sink) std::memcpy(text + total, lt.host_rows.data(), (size_t)lt.bytes);

@@ -614,7 +614,9 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
 
   // the row of a kept hit (RH:210-254 with the window's own bases, SR:598-613)
   const std::string build_with_variants = ref.genome_build + "+variants";
-  auto make_row = [&](const ExtHit& h, std::string& row) {
+  // compact: without guide_id and protospacer and with "\n" for a tail (post.hpp, compact_row_strings_keep_build) -- what the device's
+  // row stage is given when the per-contig texts cross PCIe compact; genome_build stays: a row with a variant has "<build>+variants"
+  auto make_row = [&](const ExtHit& h, std::string& row, bool compact = false) {
         const Window& w = *h.w;
         const calitas_aln_t& a = *h.a;
         const int wl = w.len;
@@ -713,14 +715,16 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         auto add = [&](const std::string& s) { std::memcpy(wp, s.data(), s.size()); wp += s.size(); *wp++ = '\t'; };
         auto add_mem = [&](const char* m, size_t len) { std::memcpy(wp, m, len); wp += len; *wp++ = '\t'; };
         auto add_int = [&](long v) { wp += put_int(wp, v); *wp++ = '\t'; };
-        add(gid); add(gh.protospacer); add(build); add(ref.names[w.contig]);
+        if (!compact) { add(gid); add(gh.protospacer); }
+        add(build); add(ref.names[w.contig]);
         add_int(gstart); add_int(gend); *wp++ = (char)a.strand; *wp++ = '\t'; add_mem(unpadded_target, n_unpadded);
         add(c5_10); add(c3_10); add(pam_used); add(ids); add(descs); if (vs.empty()) *wp++ = '\t'; else add(vid); add(af);
         add_int(a.score); add_int(gmm); add_int(ggp); add_int(gmm + ggp);
         add_int(ga_count(pg, pa, n_ops, true, true, true, false)); add_int(mm + gp);
         add_mem(pg, (size_t)n_ops); add_mem(pa, (size_t)n_ops); add_mem(pt, (size_t)n_ops);
         add(c5_8); add(c3_8); add_mem(cigar, n_cigar); add(rs.proto_len); add_int((long)n_unpadded);
-        std::memcpy(wp, rs.tail.data(), rs.tail.size()); wp += rs.tail.size();                      // aligner .. time_stamp + '\n'
+        if (!compact) { std::memcpy(wp, rs.tail.data(), rs.tail.size()); wp += rs.tail.size(); }   // aligner .. time_stamp + '\n'
+        else *wp++ = '\n';                                       // (the compact tail; the cell before it keeps its tab: the full tail starts with the next field)
         if (wp > &row[row_at] && wp[-1] == '\n') wp--;
         row.resize((size_t)(wp - row.data()));
   };
@@ -875,6 +879,11 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     pub_cv.notify_all();
   };
   HitsExtSource source;
+  // Compact rows on the per-contig stream of this call: OFF unless asked for.  Measured at BASELINE config 5's size (round 5): the texts'
+  // time on the bus halves (0.40 -> 0.21 s) and the call does not get shorter (1.10-1.14 against 1.12-1.17 s) -- this branch is bound by
+  // its host threads (a 16-core quota), and putting guide_id, protospacer and the tail back into 41 million rows is more work for them
+  // (window building 0.31-0.39 -> 0.42-0.51 s, the entries' rows 0.37-0.42 -> 0.41-0.51 s).
+  source.compact_rows = device_merge && TUNE_ON("CALITAS_VARIANTS_COMPACT");
   struct JoinHelper {                                                                               // (declared behind everything the helper thread uses)
     std::thread& t; decltype(publish)& pub; size_t all;
     ~JoinHelper() { if (t.joinable()) { pub(all, true); t.join(); } }
@@ -969,7 +978,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
         buf.reserve((e - b) * 700 + 2048);                       // (+ the room make_row asks for before it knows the last row's length)
         for (size_t i = b; i < e; i++) {
           const size_t at = buf.size();
-          make_row(hits[h0 + order[i]], buf);                     // (appends)
+          make_row(hits[h0 + order[i]], buf, source.compact_rows);   // (appends)
           buf += '\n';
           row_len[i] = (uint32_t)(buf.size() - at);
         }

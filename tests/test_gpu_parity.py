@@ -559,7 +559,10 @@ def test_per_contig_passes_equal_one_pass(C, tmp_path, monkeypatch):
             want = ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp")
             assert want[1] > 10
             monkeypatch.setenv("CALITAS_SEQUENTIAL", "1")
-            assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want
+            assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want       # (the contigs' texts cross PCIe compact: round 5)
+            monkeypatch.setenv("CALITAS_COMPACT_ROWS", "0")
+            assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want       # ... and as whole rows
+            monkeypatch.delenv("CALITAS_COMPACT_ROWS")
             monkeypatch.delenv("CALITAS_SEQUENTIAL")
             monkeypatch.setenv("CALITAS_CHUNKS", "2")
             monkeypatch.setenv("CALITAS_DEVICE_BUDGET_MB", "1")          # nothing fits, not even a contig: the call fails with ENOMEM

@@ -220,6 +220,10 @@ def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_pa
     sr = C.SearchReference(**kw)
     text, n = sr.run("v0", "stamp")
     assert sr.timing["contig_passes"] == 3                      # one pass per contig, none declined
+    monkeypatch.setenv("CALITAS_VARIANTS_COMPACT", "1")          # the reference passes' texts and the entries' rows compact (off by default)
+    sc = C.SearchReference(**kw)
+    assert sc.run("v0", "stamp") == (text, n) and sc.timing["contig_passes"] == 3
+    monkeypatch.delenv("CALITAS_VARIANTS_COMPACT")
     monkeypatch.setenv("CALITAS_VARIANTS_HOST", "1")
     sh = C.SearchReference(**kw)
     text_h, n_h = sh.run("v0", "stamp")
