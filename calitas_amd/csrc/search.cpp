@@ -144,6 +144,7 @@ struct SearchPlan {
   bool narrow_tail = false;           // a range of a chunked call that is not the last: its tail shares the chip with the next scan
   bool three_ranges = false;          // a range of a call cut into three or more
   bool last_range = false;            // ... and the last of them: no scan runs beside its tail
+  int range_index = 0;                // which range of a chunked call this is
   bool general_tail = false;          // the caller brings hits of its own into the row stage (HitsExt): the general kernels take them, the bins do not
 };
 
@@ -935,6 +936,7 @@ static bool binned_possible(calitas_ctx* lane, const SearchPlan& pl) {
   bool want = !pl.three_ranges || pl.owned || pl.last_range;   // (a stretch that cuts a contig: only the bins can own it)
   if (const char* e = TUNE_GET("CALITAS_BINNED")) {
     if (std::strcmp(e, "last") == 0) want = !pl.narrow_tail;
+    else if (std::strcmp(e, "from1") == 0) want = !pl.three_ranges || pl.owned || pl.range_index >= 1;   // (experiment: every range but the first)
     else want = std::atoi(e) != 0;
   }
   if (!want) return false;
@@ -2111,7 +2113,7 @@ static int search_hits_attempt(calitas_ctx* ctx, const calitas_guide_t* guide, c
       for (int k = ranges[c].first; k < ranges[c].second; k++) { q.bases += ref.contigs[k].len; q.win_n += window_count(ref.contigs[k].len, q.step); }
       plan_bins(ctx, q, ranges[c].first, ranges[c].second);
       }
-      q.narrow_tail = c + 1 < K; q.three_ranges = K >= 3; q.last_range = K >= 3 && c + 1 == K;
+      q.narrow_tail = c + 1 < K; q.three_ranges = K >= 3; q.last_range = K >= 3 && c + 1 == K; q.range_index = (int)c;
       rc = lane_prepare(lanes[c], q);
       if (rc) ctx->err = lanes[c]->err;
     }

@@ -29,7 +29,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_VARIANTS_COMPACT", "1", "T: variant branch: the per-contig texts of the reference passes cross PCIe as compact rows (default off: the branch is bound by its host threads)"},
   {"CALITAS_SEQUENTIAL", "1", "F: calitas_search_hits as one pass per contig whatever the size"},
   {"CALITAS_SDMA", "0", "F: text copies with hipMemcpyAsync instead of the SDMA engine (dma.cpp)"},
-  {"CALITAS_BINNED", "1 | 0 | last", "T/F: the per-bin tail for every range / none / the last range only (default: calls of one or two ranges, the last range of three, every window range)"},
+  {"CALITAS_BINNED", "1 | 0 | last | from1", "T/F: the per-bin tail for every range / none / the last range only (default: calls of one or two ranges, the last range of three, every window range)"},
   {"CALITAS_BATCH_BINNED", "1", "T: guide batches on large references keep the per-bin tail (default: general kernels from 2 Gb on)"},
   {"CALITAS_OWN_GENERAL_OFF", "1", "F: a window range with a crowded bin searches its contigs whole (round 3) instead of finishing on the general kernels with HitsOwn"},
   {"CALITAS_BINNED_COMPLEX", "1", "F: every bin through the wave-per-bin kernel"},
