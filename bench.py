@@ -348,6 +348,8 @@ def main():
                          "(calitas_search_hits_batch on a range), a sample of guides checked against single-process calls; default for N > 1")
     ap.add_argument("--no-batch-sharded", dest="batch_sharded", action="store_false")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank exits 3 before the rendezvous
+    ap.add_argument("--text-block", choices=["caller", "library"], default="caller",
+                    help="--config 5: the text goes to a page-locked buffer of the bench (calitas_search_variants_into) or to a block of the library's per call")
     ap.add_argument("--no-hits", action="store_true", help="time the search only (no removeOverlaps / row building)")
     ap.add_argument("--guides-per-step", type=int, default=1,
                     help="config 3: guides each rank runs per step through calitas_search_hits_batch; the default 1 is the BASELINE metric's single-guide pass")
@@ -570,6 +572,7 @@ def main():
 
     def measure(mode, keep_text=False):
         """K timed steps of one partition mode, bracketed by barrier + synchronize; the MAX over ranks is the job's time."""
+        import numpy as np
         mine, my_guides, passes_per_step, bases_per_step_total = partition_mode(mode)
         contig_mode = world > 1 and mode in ("contigs", "windows")
         params_rank = params
@@ -607,7 +610,6 @@ def main():
         if contig_mode and len(G) == 1 and args.config == 3:
             import mmap
             import ctypes
-            import numpy as np
             slot_bytes = max(8 << 20, int(160e6 * args.scale / world) * 2)
             slot_bytes = (slot_bytes + 4095) & ~4095
             shm_path = "/dev/shm/calitas_bench_hits_%s.bin" % os.environ.get("MASTER_PORT", "0")
@@ -639,16 +641,30 @@ def main():
             dist.all_reduce(t, group=gloo)
             return int(t.item())
 
+        # config 5: the text (21.8 GB at full size) goes to a page-locked buffer of this process, as the headline's does
+        # (calitas_search_variants_into; --text-block library: a block of the library's per call, as before round 5)
+        c5_dst = {"addr": None, "cap": 0}
+        if args.config == 5 and args.text_block == "caller":
+            t_b = time.perf_counter()
+            n_first, _, _ = ctx.search_variants_raw(G[0], "bench", params, vcf_path, "bench", "bench")   # (how large the text is)
+            C._lib.lib.calitas_reap_wait()
+            cap = int(n_first * 1.02) + (64 << 20)
+            c5_dst["addr"], c5_dst["cap"] = C.Context.alloc_host(cap), cap   # (hipHostMalloc: the copy engines write into it directly)
+            log("config 5: %d bytes of text; a page-locked destination of %d bytes in %.1f s" % (n_first, cap, time.perf_counter() - t_b))
+
         def step():
             tp0 = time.perf_counter()
             if args.config == 5:
-                text, rows, nwin = ctx.search_variants_raw(G[0], "bench", params, vcf_path, "bench", "bench")
+                if c5_dst["addr"] is not None:
+                    text, rows, nwin = ctx.search_variants_into(G[0], "bench", params, vcf_path, c5_dst["addr"], c5_dst["cap"], "bench", "bench")
+                else:
+                    text, rows, nwin = ctx.search_variants_raw(G[0], "bench", params, vcf_path, "bench", "bench")
+                    phase["free_text"] += ctx.last_free_ms / 1e3   # (inside search_hits: calitas_free of the text block)
                 tp1 = time.perf_counter()
                 tm = ctx.timing()
                 tm["hits_bytes"] = text
                 tm["variant_windows"] = nwin
                 phase["search_hits"] += tp1 - tp0
-                phase["free_text"] += ctx.last_free_ms / 1e3   # (inside search_hits: calitas_free of the text block)
                 return tm, tm["accepted_alignments"], total_rows(rows)
             if len(G) > 1 and not (args.no_hits or args.two_stage):
                 # a batch of guides, pipelined through the device stages (calitas_search_hits_batch)
@@ -730,6 +746,8 @@ def main():
             else:
                 text = [ctx.search_hits(G[0], "bench", params, "bench", "bench")[0]]
         tiles = ctx.tile_census()
+        if c5_dst["addr"] is not None:
+            C.Context.free_host(c5_dst["addr"])
         if shm is not None:
             import torch.distributed as dist
             dist.barrier(group=gloo)
@@ -829,6 +847,8 @@ def main():
         if args.config == 5:
             result["config"]["variants"] = m["n_variants"]
             result["config"]["variant_windows_per_pass"] = tm.get("variant_windows", 0)
+            result["config"]["text_destination"] = ("a page-locked block (calitas_alloc_host) of the caller's, reused from step to step (calitas_search_variants_into)"
+                                                    if args.text_block == "caller" else "a block of the library's per step (calitas_search_variants), freed inside the step")
         if args.config == 4:
             result["roofline"]["g_equivalent"] = {"guides_per_step": n_guides_rank, "achieved": achieved,
                                                   "note": "every guide of the batch is a scan launch of its own over the whole slice: bytes are counted once per launch, "

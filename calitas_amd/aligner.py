@@ -261,6 +261,17 @@ class Context:
         self.last_free_ms = (time.perf_counter() - t_free) * 1e3    # (a hits.txt of tens of gigabytes: handing the block back is not free)
         return nbytes.value, rows.value, nwin.value
 
+    def search_variants_into(self, guide, guide_id, params, vcf_path, address, capacity, version=None, time_stamp=None, chrom=None):
+        """calitas_search_variants_into: the text goes to `capacity` bytes at `address` (memory of the caller, page-locked with pin_host: every
+        contig's rows then cross the bus straight to their place).  Returns (n_bytes, n_rows, n_variant_windows)."""
+        g = guide.to_c()
+        nbytes, rows, nwin = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self._h, lib.calitas_search_variants_into(self._h, ctypes.byref(g), guide_id.encode(), ctypes.byref(params), str(vcf_path).encode(),
+                                                             chrom.encode() if chrom is not None else None, None,
+                                                             version.encode() if version else None, time_stamp.encode() if time_stamp else None,
+                                                             ctypes.c_void_p(address), capacity, ctypes.byref(nbytes), ctypes.byref(rows), ctypes.byref(nwin)))
+        return nbytes.value, rows.value, nwin.value
+
     def scan_candidates(self, guides, params, columnwise=False):
         """calitas_scan_candidates: the candidate filter alone (columnwise: the same set from round 1's kernel, a test hook).  Returns a sorted list of (contig_index, contig_offset, pass, guide):
         one entry per end column whose seamless glocal bottom-row score reaches minGuideScore (pass 0 = target as is, the column
@@ -328,6 +339,19 @@ class Context:
                                                          version.encode() if version else None, time_stamp.encode() if time_stamp else None,
                                                          ctypes.c_void_p(address), capacity, ctypes.byref(nbytes), ctypes.byref(rows)))
         return nbytes.value, rows.value
+
+    @staticmethod
+    def alloc_host(nbytes):
+        """calitas_alloc_host: the address of a page-locked block of the runtime's own (free it with free_host) -- the destination the
+        *_into calls like best."""
+        p = lib.calitas_alloc_host(nbytes)
+        if not p:
+            raise MemoryError("calitas_alloc_host(%d)" % nbytes)
+        return p
+
+    @staticmethod
+    def free_host(address):
+        lib.calitas_free(ctypes.c_void_p(address))
 
     def pin_host(self, address, nbytes):
         _lib.check(self._h, lib.calitas_pin_host(self._h, ctypes.c_void_p(address), nbytes))

@@ -221,6 +221,8 @@ const char* calitas_last_error(const calitas_ctx* ctx) { return ctx ? ctx->err.c
 
 void calitas_free(void* p) { out_free(p); }
 
+void* calitas_alloc_host(uint64_t bytes) { return out_alloc_impl((size_t)bytes, true); }
+
 int calitas_create(int device_id, calitas_ctx** out) {
   if (!out) return fail(nullptr, CALITAS_EINVAL, "out is NULL");
   *out = nullptr;

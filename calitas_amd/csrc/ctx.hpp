@@ -126,7 +126,7 @@ int calitas_search_hits_stream_impl(calitas_ctx* ctx, const calitas_guide_t* gui
 // a stage left the device path and nothing is returned -- the caller merges on the host
 int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                  const char* aligner_version, const char* time_stamp, const HitsExtSource& source, char** tsv,
-                                 uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined);
+                                 uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined, char* user_dst = nullptr, uint64_t user_cap = 0);
 int calitas_side_context(calitas_ctx* ctx, calitas_ctx** side, int which = 0);
 // Work nobody waits for -- handing memory back -- on a thread of the library's own, in the order it was given (joined when the library
 // is unloaded).  A call that built millions of small objects, or a caller that frees a text of tens of gigabytes, returns at once.

@@ -199,6 +199,15 @@ __global__ __launch_bounds__(HITS_SMALL) void hits_small_kernel(HitsSmallArgs a)
   if (mine) cluster_body(i, a.s_start, a.s_end, a.s_score, a.s_cs, a.head, a.n, a.max_overlap, a.keep, a.flags);
 }
 
+// HitsExt::rows_for: which of the caller's own hits the walks kept, by entry (order[k] - n_dev), for the host to build just their rows.
+__global__ void ext_keep_kernel(const uint32_t* order, const uint8_t* keep, uint32_t n, uint32_t n_dev, uint8_t* out) {
+  CALITAS_TAIL_PRIO();
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t v = order[k];
+  if (v >= n_dev) out[v - n_dev] = keep[k];
+}
+
 // Rows in two kernels (round 4; round 2 built every middle part into a staging buffer -- mid_kernel -- and assembled the rows from it
 // once their offsets were known -- out_kernel: 350 bytes per row written and read again, 20 GB of staging for the 4.1e7 rows of a PAM-less
 // whole-genome search):
@@ -366,7 +375,8 @@ void hits_destroy(HitsWork* w) {
   (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_cs); (void)hipFree(w->wks); (void)hipFree(w->s_start); (void)hipFree(w->s_end);
   (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->head); (void)hipFree(w->temp); (void)hipFree(w->text);
   (void)hipFree(w->midlen); (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off);
-  (void)hipFree(w->d_counts); (void)hipFree(w->ext_keys); (void)hipFree(w->ext_off); (void)hipFree(w->ext_rows);
+  (void)hipFree(w->d_counts); (void)hipFree(w->ext_keys); (void)hipFree(w->ext_off); (void)hipFree(w->ext_rows); (void)hipFree(w->ext_keep);
+  if (w->h_ext_keep) (void)hipHostFree(w->h_ext_keep);
   if (w->h_counts) (void)hipHostFree(w->h_counts);
   mailbox_close(w->mbox);
   delete w;
@@ -459,19 +469,32 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   }
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
   size_t ts;
-  if (n_ext) {
-    const size_t row_bytes = (size_t)ext->row_off[n_ext];
-    TRY(grow(&w.ext_keys, w.ext_keys_cap, (size_t)n_ext)); TRY(grow(&w.ext_off, w.ext_off_cap, (size_t)n_ext + 1));
+  const bool on_demand = n_ext && ext->rows_for;       // the rows of the caller's hits once the walks have decided (hits.hpp)
+  if (on_demand && own) return hipErrorInvalidValue;
+  // the rows of the caller's hits (offsets, text) to the device: before anything runs when they came with the call, behind the walks on demand
+  auto upload_ext_rows = [&](const HitsExtRows& r) -> hipError_t {
+    if (!r.row_off || r.row_off[0] != 0) return hipErrorInvalidValue;
+    const size_t row_bytes = (size_t)r.row_off[n_ext];
+    TRY(grow(&w.ext_off, w.ext_off_cap, (size_t)n_ext + 1));
     TRY(grow(&w.ext_rows, w.ext_rows_cap, std::max<size_t>(1, row_bytes)));
-    TRY(hipMemcpyAsync(w.ext_keys, ext->keys, (size_t)n_ext * sizeof(HitsExtKey), hipMemcpyHostToDevice, stream));
-    TRY(hipMemcpyAsync(w.ext_off, ext->row_off, ((size_t)n_ext + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    if (row_bytes && ext->rows) TRY(hipMemcpyAsync(w.ext_rows, ext->rows, row_bytes, hipMemcpyHostToDevice, stream));
+    TRY(hipMemcpyAsync(w.ext_off, r.row_off, ((size_t)n_ext + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (row_bytes && r.rows) TRY(hipMemcpyAsync(w.ext_rows, r.rows, row_bytes, hipMemcpyHostToDevice, stream));
     else if (row_bytes) {
-      if (!ext->n_seg || !ext->seg || !ext->seg_off || ext->seg_off[0] != 0 || ext->seg_off[ext->n_seg] != row_bytes) return hipErrorInvalidValue;
-      for (uint32_t sg = 0; sg < ext->n_seg; sg++) {
-        const uint64_t nb = ext->seg_off[sg + 1] - ext->seg_off[sg];
-        if (nb) TRY(hipMemcpyAsync(w.ext_rows + ext->seg_off[sg], ext->seg[sg], (size_t)nb, hipMemcpyHostToDevice, stream));
+      if (!r.n_seg || !r.seg || !r.seg_off || r.seg_off[0] != 0 || r.seg_off[r.n_seg] != row_bytes) return hipErrorInvalidValue;
+      for (uint32_t sg = 0; sg < r.n_seg; sg++) {
+        const uint64_t nb = r.seg_off[sg + 1] - r.seg_off[sg];
+        if (nb) TRY(hipMemcpyAsync(w.ext_rows + r.seg_off[sg], r.seg[sg], (size_t)nb, hipMemcpyHostToDevice, stream));
       }
+    }
+    return hipSuccess;
+  };
+  if (n_ext) {
+    TRY(grow(&w.ext_keys, w.ext_keys_cap, (size_t)n_ext));
+    TRY(hipMemcpyAsync(w.ext_keys, ext->keys, (size_t)n_ext * sizeof(HitsExtKey), hipMemcpyHostToDevice, stream));
+    if (!on_demand) {
+      HitsExtRows given;
+      given.row_off = ext->row_off; given.rows = ext->rows; given.n_seg = ext->n_seg; given.seg = ext->seg; given.seg_off = ext->seg_off;
+      TRY(upload_ext_rows(given));
     }
   }
   const bool small = n_in <= HITS_SMALL && window_reach != 0 && !own;
@@ -497,6 +520,25 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
                      w.s_score, w.s_cs, w.head, w.keep);
   hipLaunchKernelGGL(cluster_kernel, grid, block, 0, stream, (const int32_t*)w.s_start, (const int32_t*)w.s_end, (const int32_t*)w.s_score,
                      (const uint32_t*)w.s_cs, (const uint8_t*)w.head, n_in, max_overlap, w.keep, d_flags, ho);
+  }
+  if (on_demand) {
+    // the walks' verdicts on the caller's hits to the host, the rows of the kept ones back: the one place where this stage waits for the
+    // host in the middle (a contig's worth of a variant search: 80 000 entries, 8 000 rows, a millisecond of the caller's workers)
+    TRY(grow(&w.ext_keep, w.ext_keep_cap, (size_t)n_ext));
+    if ((size_t)n_ext > w.h_ext_keep_cap) {
+      if (w.h_ext_keep) (void)hipHostFree(w.h_ext_keep);
+      w.h_ext_keep = nullptr; w.h_ext_keep_cap = 0;
+      const size_t cap = (size_t)n_ext + (size_t)n_ext / 4 + 4096;
+      TRY(hipHostMalloc((void**)&w.h_ext_keep, cap, hipHostMallocDefault));
+      w.h_ext_keep_cap = cap;
+    }
+    hipLaunchKernelGGL(ext_keep_kernel, grid, block, 0, stream, (const uint32_t*)w.vals2, (const uint8_t*)w.keep, n_in, n_dev, w.ext_keep);
+    TRY(hipGetLastError());
+    TRY(hipMemcpyAsync(w.h_ext_keep, w.ext_keep, (size_t)n_ext, hipMemcpyDeviceToHost, stream));
+    TRY(hipStreamSynchronize(stream));
+    HitsExtRows made;
+    if (ext->rows_for(w.h_ext_keep, &made) != 0) return hipErrorUnknown;
+    TRY(upload_ext_rows(made));
   }
   // 4: rows
   // (a row with more padded columns than a wave has lanes raises HITS_FLAG_ROW and the caller finishes on the host)

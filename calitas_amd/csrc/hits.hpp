@@ -63,6 +63,13 @@ hipError_t hits_prepare_host(HitsWork** work, const RowStrings& strings, HitsSet
 // is the one contig all of them (and all of d_final's alignments) lie on.
 constexpr uint32_t HITS_EXT_MINUS = 1, HITS_EXT_PLACED = 2;
 struct HitsExtKey { int32_t coordinate_start, end, score; uint32_t flags; };
+struct HitsExtRows {                   // what rows_for hands back: the fields of the same names below
+  const uint64_t* row_off = nullptr;
+  const char* rows = nullptr;
+  uint32_t n_seg = 0;
+  const char* const* seg = nullptr;
+  const uint64_t* seg_off = nullptr;
+};
 struct HitsExt {
   int32_t contig = 0;
   uint32_t n = 0;
@@ -75,6 +82,12 @@ struct HitsExt {
   const char* const* seg = nullptr;
   const uint64_t* seg_off = nullptr;   // n_seg + 1
   uint32_t* kept = nullptr;            // out (optional): how many of the entries were kept
+  // Rows on demand (round 5): with rows_for set, row_off / rows / seg* above are not looked at.  Nine in ten entries of a variant search
+  // repeat a reference hit and lose against it in the device's walk, so the caller is asked for rows only when the walks have decided:
+  // hits_run brings one byte per entry to the host (kept[e] != 0: entry e is in the text), calls rows_for(kept, &rows) and takes the n + 1
+  // offsets (an entry that was not kept has length 0) and the text from `rows` -- memory of the caller's that stays valid until
+  // hits_run returns.  != 0: the caller gave up, hits_run returns hipErrorUnknown.  One more host round trip per call of hits_run.
+  std::function<int(const uint8_t* kept, HitsExtRows* rows)> rows_for;
 };
 
 // The alignments given to hits_run are those of a window range of a larger job (a process's stretch of a multi-GPU partition plus the

@@ -386,6 +386,8 @@ struct HitsWork {
   HitsExtKey* ext_keys = nullptr; size_t ext_keys_cap = 0;   // the caller's own hits of this call (HitsExt)
   uint64_t* ext_off = nullptr; size_t ext_off_cap = 0;
   char* ext_rows = nullptr; size_t ext_rows_cap = 0;
+  uint8_t* ext_keep = nullptr; size_t ext_keep_cap = 0;      // HitsExt::rows_for: the walks' verdict per entry, and its page-locked copy
+  uint8_t* h_ext_keep = nullptr; size_t h_ext_keep_cap = 0;
   uint64_t* d_counts = nullptr;   // [0] text bytes, [1] low word: kept rows, high word: kept hits of the caller's own, [2] low word: flags
   uint64_t* h_counts = nullptr;   // pinned
   Mailbox mbox;                   // carries d_counts to the host (mailbox.hpp)

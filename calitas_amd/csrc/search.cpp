@@ -992,6 +992,7 @@ static int queue_lane_setup(calitas_ctx* lane, const SearchPlan& pl, const RowSt
 struct LaneDest { std::function<bool(char** dst, uint64_t* cap)> get; };
 
 constexpr int kOwnedDeclined = -1000;   // (internal) a lane of an owned range (SearchPlan::owned) met bins it leaves to the general kernels
+static double g_pass_ms[2];              // (trace only; written by the one thread that runs a sequential call's passes)
 constexpr int kExtDeclined = -1001;     // (internal) a pass that brings hits of the caller's (HitsExt) met a stage the device declines: the caller merges on the host
 
 struct LaneText;
@@ -1036,12 +1037,19 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
     hits_prepared = false;                                   // binned_run consumed the row constants
   }
   if (!hits_prepared && !TUNE_GET("CALITAS_HOST_HITS")) HIP_TRY(lane, hits_prepare(&lane->hits, rs, lane->stream));   // ahead of the lane's kernels
+  const auto t_pass0 = std::chrono::steady_clock::now();
   int rc = search_run(lane, pl, &alns, &n_alns, &dev, prelaunched, resume);
   if (rc) return rc;
   lt.tm = lane->timing;
   if (own_general && !dev.valid) { calitas_free(alns); return kOwnedDeclined; }
   const HitsExt* ext = nullptr;             // the caller's own hits of this contig: asked for now, the search kernels of the pass are behind us
+  const auto t_pass1 = std::chrono::steady_clock::now();
   if (ext_source && ext_source->get(ext_contig, &ext) != 0) { calitas_free(alns); return kExtDeclined; }
+  if (ext_source) {                         // (CALITAS_TRACE of the per-contig passes: the search kernels' part of a pass, and its wait for the caller's hits)
+    const auto t_pass2 = std::chrono::steady_clock::now();
+    g_pass_ms[0] += std::chrono::duration<double, std::milli>(t_pass1 - t_pass0).count();
+    g_pass_ms[1] += std::chrono::duration<double, std::milli>(t_pass2 - t_pass1).count();
+  }
   if (ext && !dev.valid && n_alns == 0) {   // nothing of the reference's own on this contig: the row stage still places the caller's hits
     dev.valid = true; dev.d_final = nullptr; dev.n_sel = 0; dev.crowded = true;
   }
@@ -1406,13 +1414,17 @@ static void release_scratch(calitas_ctx* ctx) {
 // and the final sort never cross a contig).
 // With a sink the pieces (header, then every contig's rows in at most 1 GB portions) are handed over as they arrive instead of being
 // collected: no text block at all, *tsv stays NULL.
+// user_dst (round 5): the text goes to user_cap bytes of the caller's -- page-locked (calitas_pin_host), so that every contig's rows
+// cross the bus straight to their place: no bounce buffer, no memcpy into fresh pages (0.4-0.6 s per 22 GB of rows), *tsv = user_dst.
 static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                   const char* aligner_version, const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows,
-                                  calitas_text_sink_t sink = nullptr, void* sink_user = nullptr, const HitsExtSource* ext_source = nullptr) {
+                                  calitas_text_sink_t sink = nullptr, void* sink_user = nullptr, const HitsExtSource* ext_source = nullptr,
+                                  char* user_dst = nullptr, uint64_t user_cap = 0) {
   const auto t_call = std::chrono::steady_clock::now();
   SearchPlan pl;
   int rc = plan_search(ctx, 1, guide, params, pl);
   if (rc) return rc;
+  if (user_dst && sink) return fail(ctx, CALITAS_EINVAL, "a text sink and a destination buffer at once");
   const PackedRef& ref = ctx->ref;
   std::string version, stamp;
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
@@ -1436,14 +1448,15 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   // reused page-locked bounce buffer and from there into the block on the worker pool (page-locking 40+ GB of pieces and
   // concatenating them afterwards took longer than the search).
   const size_t hlen = rs.header.size();
-  char* text = sink ? nullptr : (char*)calitas_out_grow(nullptr, 0, hlen + (64u << 20));
+  if (user_dst && user_cap < hlen + 1) return fail(ctx, CALITAS_EINVAL, "the destination buffer does not hold the header line");
+  char* text = sink ? nullptr : user_dst ? user_dst : (char*)calitas_out_grow(nullptr, 0, hlen + (64u << 20));
   if (!sink && !text) return fail(ctx, CALITAS_EINVAL, "out of memory");
   if (text) std::memcpy(text, rs.header.data(), hlen);
   else if (sink(rs.header.data(), hlen, sink_user) != 0) return fail(ctx, CALITAS_EIO, "the text sink reported an error");
   size_t total = hlen;
   char* bounce = nullptr;
   size_t bounce_cap = 0;
-  auto drop = [&] { calitas_free(text); calitas_free(bounce); };
+  auto drop = [&] { if (!user_dst) calitas_free(text); calitas_free(bounce); };
   calitas_timing_t tm{};
   uint64_t rows = 0;
   std::mutex copy_mu;
@@ -1451,6 +1464,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   uint64_t bases_done = 0;
   uint32_t n_passes = 0;
   double ms_rows = 0;              // inside lane_rows: kernels, their host round trips and every (re)allocation of scratch
+  double ms_grow = 0, ms_land = 0; // this thread: the text block grown, the texts copied from the bounce buffer to their place
   // The passes: one plan per selected contig.
   std::vector<SearchPlan> passes;
   std::vector<int> pass_contig;
@@ -1474,6 +1488,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     }
   }
   n_passes = (uint32_t)passes.size();
+  g_pass_ms[0] = g_pass_ms[1] = 0;
   // Two row-stage scratch sets (ctx->hits / hits_alt) take turns: a helper thread runs the device stages of pass i+1 while this thread
   // copies the text of pass i over PCIe and hands it on -- the copy is 1.5 of the 2.7 s of a PAM-less d = 8 search on an hg38-sized
   // genome, the device stages 1.0.  The sink is only ever called from this (the caller's) thread.
@@ -1546,10 +1561,18 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       const size_t full_bytes = expand ? (size_t)lt.bytes + (size_t)lt.rows * (cut_head.size() + rs.tail.size() - 1) : (size_t)lt.bytes;
       const double per_base = (double)(total - hlen + full_bytes) / (double)std::max<uint64_t>(1, bases_done);
       const size_t guess = pl.p.chrom_index >= 0 ? 0 : (size_t)(per_base * 1.05 * (double)(ref.total_bases - bases_done));
-      if (!sink) {
+      if (user_dst) {
+        if ((uint64_t)total + full_bytes + 1 > user_cap) {
+          rc = fail(ctx, CALITAS_EINVAL, "the destination buffer is too small for the text (" + std::to_string(user_cap) + " bytes; " +
+                                         std::to_string(total + full_bytes + 1) + " needed after " + std::to_string(i + 1) + " of " + std::to_string(passes.size()) + " contigs)");
+          break;
+        }
+      } else if (!sink) {
+        const auto t_grow = std::chrono::steady_clock::now();
         char* grown = (char*)calitas_out_grow(text, total, total + full_bytes + 1 + guess);
         if (!grown) { rc = fail(ctx, CALITAS_EINVAL, "out of memory"); break; }
         text = grown;
+        ms_grow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_grow).count();
       }
       if (expand) {
         // the contig's compact text over the bus in pieces into the page-locked block, the worker pool puts guide_id, protospacer and
@@ -1576,6 +1599,17 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
       if (lt.on_host) {
         if (!sink) std::memcpy(text + total, lt.host_rows.data(), (size_t)lt.bytes);
         else if (sink(lt.host_rows.data(), lt.bytes, sink_user) != 0) { rc = fail(ctx, CALITAS_EIO, "the text sink reported an error"); break; }
+      } else if (user_dst) {                            // straight to its place in the caller's page-locked buffer
+        // (in portions: one copy of a whole contig's rows -- 1.7 GB for chr1 of BASELINE config 5's shape -- held up everybody else's
+        // copies for 20-65 ms at a time: the variant half's aligner batches took 15 instead of 3 ms)
+        const size_t kPortion = 128u << 20;
+        for (size_t off = 0; off < (size_t)lt.bytes && !rc; off += kPortion) {
+          double ms = 0;
+          rc = text_to_host(ctx, ctx, text + total + off, lt.d_text + off, std::min(kPortion, (size_t)lt.bytes - off), &copy_mu, &ms, sl.rows_done);
+          lt.tm.hits_copy_ms += ms;
+        }
+        if (rc) break;
+        if ((rc = rows_late_check(ctx, lt)) != CALITAS_OK) break;
       } else {
         const size_t kPiece = 1ull << 30;             // bounce buffer: at most 1 GB page-locked
         for (size_t off = 0; off < (size_t)lt.bytes && !rc; off += kPiece) {
@@ -1583,6 +1617,38 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
           if (n > bounce_cap) { calitas_free(bounce); bounce = (char*)calitas_out_alloc_pinned(n); bounce_cap = bounce ? n : 0; }
           if (!bounce) { rc = fail(ctx, CALITAS_EINVAL, "out of memory"); break; }
           double ms = 0;
+          dma_open_once(ctx);
+          if (!sink && ctx->dma.usable() && n >= (64u << 20)) {
+            // The portion crosses the bus in 32 MB pieces queued back to back on the DMA engine, and every piece goes from the bounce
+            // buffer to its place while the ones behind it are still on their way (round 5: one copy, then one memcpy of the whole
+            // portion, was 0.4 s on the bus + 0.4-0.5 s of memcpy into fresh pages, one after the other, per 22 GB of rows -- the
+            // longest chain of a search with variants at BASELINE config 5's size).
+            if (hipError_t e = calitas_spin_sync(sl.rows_done); e != hipSuccess) { rc = fail(ctx, CALITAS_EHIP, std::string("waiting for a contig's rows: ") + hipGetErrorString(e)); break; }
+            const size_t piece = 32u << 20;
+            std::vector<unsigned long long> tickets;
+            const auto t_dma = std::chrono::steady_clock::now();
+            if (ctx->dma.start_pieces(bounce, lt.d_text + off, n, piece, tickets)) {
+              char* dst = text + total + off;
+              bool ok = true;
+              double ms_wait_dma = 0;
+              for (size_t k = 0; k < tickets.size(); k++) {
+                const auto t_w = std::chrono::steady_clock::now();
+                if (!ctx->dma.finish(tickets[k])) ok = false;     // (every ticket is waited for: nothing may land in a freed block)
+                ms_wait_dma += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w).count();
+                if (!ok) continue;
+                const size_t b0 = k * piece, nb = std::min(piece, n - b0);
+                const auto t_land = std::chrono::steady_clock::now();
+                std::lock_guard<std::mutex> host_lock(ctx->host_mu);   // the helper thread's host stages (if any) use the same pool
+                ctx->pool->for_blocks(nb, [&](size_t b, size_t e, int) { std::memcpy(dst + b0 + b, bounce + b0 + b, e - b); });
+                ms_land += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_land).count();
+              }
+              if (!ok) { rc = fail(ctx, CALITAS_EHIP, "SDMA copy failed"); break; }
+              (void)t_dma;
+              lt.tm.hits_copy_ms += ms_wait_dma;                  // (what this thread waited for the bus; the rest of the copy hid behind the memcpy)
+              continue;
+            }
+            if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] SDMA copy declined (%s), using one copy per portion\n", DmaCopier::last_reason());
+          }
           rc = text_to_host(ctx, ctx, bounce, lt.d_text + off, n, &copy_mu, &ms, sl.rows_done);
           if (rc) break;
           lt.tm.hits_copy_ms += ms;
@@ -1592,8 +1658,10 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
           }
           char* dst = text + total + off;
           const char* src = bounce;
+          const auto t_land = std::chrono::steady_clock::now();
           std::lock_guard<std::mutex> host_lock(ctx->host_mu);      // the helper thread's host stages (if any) use the same pool
           ctx->pool->for_blocks(n, [&](size_t b, size_t e, int) { std::memcpy(dst + b, src + b, e - b); });
+          ms_land += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_land).count();
         }
         if (rc) break;
         if ((rc = rows_late_check(ctx, lt)) != CALITAS_OK) break;
@@ -1615,7 +1683,10 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   stop_producer();
   if (rc) { drop(); return rc; }
   calitas_free(bounce);
-  if (!sink) {
+  if (user_dst) {
+    if ((uint64_t)total + 1 > user_cap) return fail(ctx, CALITAS_EINVAL, "the destination buffer is too small for the text");
+    text[total] = 0;
+  } else if (!sink) {
     char* grown = (char*)calitas_out_grow(text, total, total + 1);
     if (!grown) { calitas_free(text); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
     text = grown;
@@ -1625,8 +1696,8 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   ctx->timing = tm;
   ctx->last_text_bytes = total;
   if (TUNE_GET("CALITAS_TRACE"))
-    std::fprintf(stderr, "[calitas] search_hits: one pass per contig (%d), scan %.3f ms, align %.3f ms, all device stages incl. allocation %.3f ms, text copy %.3f ms (sums), call %.3f ms (%llu rows, %zu bytes)\n",
-                 n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, ms_rows, tm.hits_copy_ms,
+    std::fprintf(stderr, "[calitas] search_hits: one pass per contig (%d), scan %.3f ms, align %.3f ms, all device stages incl. allocation %.3f ms (with a caller's hits: %.3f ms up to the row stage, %.3f ms waiting for the hits), text copy %.3f ms + %.3f ms from the bounce buffer to its place + %.3f ms growing the block (sums), call %.3f ms (%llu rows, %zu bytes)\n",
+                 n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, ms_rows, g_pass_ms[0], g_pass_ms[1], tm.hits_copy_ms, ms_land, ms_grow,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), (unsigned long long)rows, total);
   *tsv = text;
   if (tsv_bytes) *tsv_bytes = total;
@@ -1736,11 +1807,11 @@ int calitas_search_hits_impl(calitas_ctx* ctx, const calitas_guide_t* guide, con
 // merges on the host instead.
 int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                  const char* aligner_version, const char* time_stamp, const HitsExtSource& source, char** tsv,
-                                 uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined) {
+                                 uint64_t* tsv_bytes, uint64_t* n_rows, bool* declined, char* user_dst, uint64_t user_cap) {
   *declined = false;
   *tsv = nullptr;
   if (!known_not_to_fit(ctx, guide, params, false)) (void)predicted_not_to_fit(ctx, guide, params);   // (sizes the passes' buffers when the search is a dense one)
-  int rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, nullptr, nullptr, &source);
+  int rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, nullptr, nullptr, &source, user_dst, user_cap);
   if (rc == kExtDeclined) { *declined = true; *tsv = nullptr; return CALITAS_ESTATE; }
   if (rc == CALITAS_ENOMEM) release_scratch(ctx);
   return rc;
@@ -2484,6 +2555,17 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
     if (!text) return fail(lane, CALITAS_EINVAL, "out of memory");
     std::memcpy(text, rs.header.data(), hlen);
     if (lt.bytes && lt.on_host) std::memcpy(text + hlen, lt.host_rows.data(), (size_t)lt.bytes);
+#ifdef CALITAS_EXPERIMENTS
+    else if (const char* mode = TUNE_GET("CALITAS_BATCH_TEXT")) {   // what the batch costs without its texts' way home (the texts are wrong)
+      if (!std::strcmp(mode, "copy") && lt.bytes) {
+        char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.bytes);
+        if (!staging) { calitas_free(text); return fail(lane, CALITAS_EINVAL, "out of memory"); }
+        int cr = text_to_host(ctx, lane, staging, lt.d_text, (size_t)lt.bytes, &copy_mu, &lt.tm.hits_copy_ms);
+        calitas_free(staging);
+        if (cr) { calitas_free(text); return cr; }
+      } else HIP_TRY(lane, calitas_spin_sync(lane->stream));
+    }
+#endif
     else if (lt.bytes && expand) {
       char* staging = (char*)calitas_out_alloc_pinned((size_t)lt.bytes);
       if (!staging) { calitas_free(text); return fail(lane, CALITAS_EINVAL, "out of memory"); }

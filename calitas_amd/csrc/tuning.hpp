@@ -27,6 +27,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_VARIANTS_HOST", "1", "F: variant branch: merge alignment records on the host (round 3) instead of bringing the variant windows' hits into the device's row stage"},
   {"CALITAS_FAIL_ALIGN_BATCH", "k", "F: variant branch: the k-th batch of variant windows (0-based) fails in the aligner stage (tests of the stages' error path)"},
   {"CALITAS_VARIANTS_COMPACT", "1", "T: variant branch: the per-contig texts of the reference passes cross PCIe as compact rows (default off: the branch is bound by its host threads)"},
+  {"CALITAS_VARIANTS_ROWS", "all", "F: calitas_search_variants makes the row of every hit of a variant window up front instead of the kept ones' on demand"},
   {"CALITAS_SEQUENTIAL", "1", "F: calitas_search_hits as one pass per contig whatever the size"},
   {"CALITAS_SDMA", "0", "F: text copies with hipMemcpyAsync instead of the SDMA engine (dma.cpp)"},
   {"CALITAS_BINNED", "1 | 0 | last | from1", "T/F: the per-bin tail for every range / none / the last range only (default: calls of one or two ranges, the last range of three, every window range)"},
@@ -38,6 +39,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_BINNED_HOST_TEXT_KB", "n", "T: ... up to this size (default 128)"},
 #ifdef CALITAS_EXPERIMENTS
   {"CALITAS_BINNED_SKIP", "1 | 2 | 3", "D: timing experiments only (the text is wrong): skip the wave-per-bin kernel / the rows"},
+  {"CALITAS_BATCH_TEXT", "skip | copy", "D: timing experiments only (the texts are wrong): a batch's rows stay on the device / cross the bus but are not expanded"},
 #endif
   {"CALITAS_TEXT_IN_PLACE_OFF", "1", "F: the last range's text takes the copy instead of being written to its final place by the rows kernel"},
   {"CALITAS_CHUNKS", "k | a:b:c", "T: contig ranges of a chunked calitas_search_hits (default 5.8:2.9:1.3 from 2 Gb, 5:3 from 600 Mb, 3:2 from 256 Mb)"},

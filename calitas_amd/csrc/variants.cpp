@@ -20,6 +20,7 @@
 // counterpart in the reference.
 //
 // VCF support is the subset the reference's path needs (fgbio vcf.api): CHROM POS ID REF ALT FILTER INFO(AF, END); plain or gzip.
+#include <sys/resource.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -518,9 +519,11 @@ struct StageThread {
 
 }  // namespace
 
-extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
-                                       const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
-                                       const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows, uint64_t* n_windows) {
+// user_dst / user_cap: calitas_search_variants_into -- the text goes to the caller's (page-locked) buffer, *tsv = user_dst on success.
+static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                                const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
+                                const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows, uint64_t* n_windows,
+                                char* user_dst, uint64_t user_cap) {
   if (!ctx) return CALITAS_EINVAL;
   if (!guide || !params || !vcf_path || !tsv) return calitas_fail(ctx, CALITAS_EINVAL, "NULL argument");
   *tsv = nullptr;
@@ -557,6 +560,12 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   const int padding = (int)gh.protospacer.size() + max_pam - 1 + d + g;                          // SR:575 (query.length - 1 + d + g)
 
   const auto t_call = std::chrono::steady_clock::now();
+  auto cpu_seconds = [] {                                                                          // (CALITAS_TRACE: how busy the call kept the process's threads)
+    rusage u{};
+    (void)getrusage(RUSAGE_SELF, &u);
+    return (double)u.ru_utime.tv_sec + (double)u.ru_stime.tv_sec + 1e-6 * ((double)u.ru_utime.tv_usec + (double)u.ru_stime.tv_usec);
+  };
+  const double cpu0 = cpu_seconds();
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   std::atomic<int> batch_serial{0};                               // (batches through align_part, for CALITAS_FAIL_ALIGN_BATCH)
   std::atomic<long long> ns_align{0};                             // (two aligner threads add to it)
@@ -566,13 +575,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   int rc = CALITAS_OK;
   calitas_ctx* actx = ctx;                                                                         // where the variant windows are aligned (below)
 
-  VarTable vcf;
-  {
-    const auto t0 = std::chrono::steady_clock::now();
-    std::string e = read_vcf(vcf_path, chrom, ctx->pool, vcf);
-    ms_parse = ms_since(t0);
-    if (!e.empty()) { calitas_free(ref_alns); return calitas_fail(ctx, CALITAS_EIO, e); }
-  }
+  VarTable vcf;                                                    // (read below, once the reference passes are under way)
   std::vector<std::string> order;                                                                 // contigs the iterator walks
   for (auto& n : ref.names) if (!chrom || n == chrom) order.push_back(n);
 
@@ -585,7 +588,22 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // of the window the variant does not touch) and lose against it there: a hit gets its key here -- lifted coordinates, score,
   // variant_description -- on the worker pool, and its row only if it is kept (make_row, called back from the row stage of hits_tsv).
   struct ExtHit { const Window* w; const calitas_aln_t* a; int gstart, tlen; std::string desc; };
-  std::vector<ExtHit> hits;
+  // (in pieces that never move: the helper thread makes rows from entries of a published contig -- through pointers taken when the contig was
+  // finished -- while the lifter thread appends the next contigs' hits)
+  struct HitList {
+    enum : size_t { kPiece = 1u << 16 };
+    std::vector<std::unique_ptr<ExtHit[]>> pieces;
+    size_t n = 0;
+    size_t size() const { return n; }
+    ExtHit& operator[](size_t i) { return pieces[i >> 16][i & (kPiece - 1)]; }
+    const ExtHit& operator[](size_t i) const { return pieces[i >> 16][i & (kPiece - 1)]; }
+    void resize(size_t m) {                                                                         // (grows only)
+      while (pieces.size() * kPiece < m) pieces.emplace_back(new ExtHit[kPiece]);
+      n = m;
+    }
+    void release() { std::vector<std::unique_ptr<ExtHit[]>>().swap(pieces); n = 0; }
+  };
+  HitList hits;
   struct Batch { std::vector<Window> wins; std::vector<Arena> arenas; };
   std::deque<Batch> kept_windows;                                                                    // the windows and alignment records behind the hits
   std::vector<calitas_aln_t*> kept_out;
@@ -865,6 +883,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     std::vector<HitsExtKey> keys; std::vector<uint64_t> row_off;
     std::vector<std::string> segs;                                // the rows' text as the workers wrote it: a block of rows each
     std::vector<const char*> seg_ptr; std::vector<uint64_t> seg_off;
+    std::vector<const ExtHit*> entry;                              // rows on demand: the entries in tie order
     HitsExt ext;
   };
   std::vector<ContigExt> cx(nc);
@@ -884,6 +903,11 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   // its host threads (a 16-core quota), and putting guide_id, protospacer and the tail back into 41 million rows is more work for them
   // (window building 0.31-0.39 -> 0.42-0.51 s, the entries' rows 0.37-0.42 -> 0.41-0.51 s).
   source.compact_rows = device_merge && TUNE_ON("CALITAS_VARIANTS_COMPACT");
+  // Rows on demand (hits.hpp, HitsExt::rows_for): an entry's row is made when the device's walk has kept it -- one in ten at BASELINE config
+  // 5's size; the rows of all two million entries were 0.37-0.42 s of the lifter thread's 0.7 s per call, and 1.1 GB on their way to the
+  // device.  CALITAS_VARIANTS_ROWS=all: every entry's row up front, as before (the two give the same bytes: tests/test_gpu_variants.py).
+  bool rows_on_demand = device_merge;
+  if (const char* e = TUNE_GET("CALITAS_VARIANTS_ROWS")) rows_on_demand = rows_on_demand && std::strcmp(e, "all") != 0;
   struct JoinHelper {                                                                               // (declared behind everything the helper thread uses)
     std::thread& t; decltype(publish)& pub; size_t all;
     ~JoinHelper() { if (t.joinable()) { pub(all, true); t.join(); } }
@@ -900,14 +924,70 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       const auto t0 = std::chrono::steady_clock::now();
       (void)hipSetDevice(ctx->device);
       try {
-        hr.rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), source, &hr.tsv, &hr.bytes, &hr.rows, &hr.declined);
+        hr.rc = calitas_search_hits_ext_impl(ctx, guide, gid, params, version.c_str(), stamp.c_str(), source, &hr.tsv, &hr.bytes, &hr.rows, &hr.declined, user_dst, user_cap);
       } catch (const std::exception& e) {                                                           // (a thread of its own has no caller to unwind to)
         hr.rc = calitas_fail(ctx, CALITAS_EHIP, std::string("the reference passes ended with an exception: ") + e.what());
       }
       hr.ms = ms_since(t0);
     });
 
-  // The entries of contig c -- hits[h0, h1), in arrival order -- for the device: the groups' walks, every entry's row and key.
+  // The rows of contig c's entries -- of those with kept[i] != 0, or of all (kept null) -- in cx[c]: consecutive blocks of entries, each
+  // written into a buffer of its own by whichever worker takes it next (the entries with variants stand at the end of the order and their
+  // rows cost 2.5 times a plain one: equal shares per worker left seven workers with all of them, 25 ms against 10 per contig); the device
+  // takes the buffers piece by piece.  An entry that is not wanted has length 0.
+  std::atomic<long long> ns_demand{0};                             // (rows on demand: the helper thread's time here)
+  std::atomic<uint64_t> rows_made{0};
+  auto make_rows = [&](size_t c, const uint8_t* kept, HitsExtRows* out) -> int {
+    const auto t0 = std::chrono::steady_clock::now();
+    ContigExt& x = cx[c];
+    const size_t n = x.entry.size();
+    const size_t T = (size_t)ctx->pool->size();
+    std::vector<uint32_t> row_len(n, 0);
+    std::vector<std::string>& local = x.segs;
+    const size_t S = std::max<size_t>(1, std::min<size_t>(4 * T, (n + 255) / 256));
+    local.assign(S, std::string());
+    std::vector<std::pair<size_t, size_t>> local_range(S, {0, 0});
+    for (size_t sg = 0; sg < S; sg++) local_range[sg] = {n * sg / S, n * (sg + 1) / S};
+    std::atomic<size_t> next_seg{0};
+    ctx->pool->run([&](int) {
+      for (;;) {
+        const size_t sg = next_seg.fetch_add(1, std::memory_order_relaxed);
+        if (sg >= S) return;
+        const size_t b = local_range[sg].first, e = local_range[sg].second;
+        size_t wanted = e - b;
+        if (kept) { wanted = 0; for (size_t i = b; i < e; i++) wanted += kept[i] != 0; }
+        if (!wanted) continue;
+        std::string& buf = local[sg];
+        buf.reserve(wanted * 700 + 2048);                        // (+ the room make_row asks for before it knows the last row's length)
+        for (size_t i = b; i < e; i++) {
+          if (kept && !kept[i]) continue;
+          const size_t at = buf.size();
+          make_row(*x.entry[i], buf, source.compact_rows);       // (appends)
+          buf += '\n';
+          row_len[i] = (uint32_t)(buf.size() - at);
+        }
+        rows_made.fetch_add(wanted, std::memory_order_relaxed);
+      }
+    });
+    x.row_off.resize(n + 1);
+    x.row_off[0] = 0;
+    for (size_t i = 0; i < n; i++) x.row_off[i + 1] = x.row_off[i] + row_len[i];
+    // the buffers in the order of their blocks are the rows' text
+    x.seg_ptr.assign(S, nullptr); x.seg_off.assign(S + 1, 0);
+    for (size_t t = 0; t < S; t++) {
+      const size_t b = local_range[t].first, e = local_range[t].second;
+      x.seg_ptr[t] = local[t].data();
+      x.seg_off[t + 1] = x.seg_off[t] + (b < e ? x.row_off[e] - x.row_off[b] : 0);
+      if (b < e && (x.seg_off[t] != x.row_off[b] || local[t].size() != x.row_off[e] - x.row_off[b]))
+        return calitas_fail(ctx, CALITAS_EINVAL, "the rows of a contig's entries are not where their offsets say (internal error)");
+    }
+    out->row_off = x.row_off.data(); out->rows = nullptr;
+    out->n_seg = (uint32_t)S; out->seg = x.seg_ptr.data(); out->seg_off = x.seg_off.data();
+    if (kept) ns_demand += (long long)(ms_since(t0) * 1e6);
+    return CALITAS_OK;
+  };
+  // The entries of contig c -- hits[h0, h1), in arrival order -- for the device: the groups' walks, every entry's key and (unless the
+  // device asks for them later: rows on demand) row.
   double ms_groups = 0, ms_make = 0, ms_blob = 0;
   auto finish_contig = [&](size_t c, size_t h0, size_t h1) -> int {
     if (h1 == h0) return CALITAS_OK;
@@ -962,49 +1042,24 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     // variants stand at the end of the order and their rows cost 2.5 times a plain one: equal shares per worker left seven workers
     // with all of them, 25 ms against 10 per contig); the device takes the buffers piece by piece
     ContigExt& x = cx[c];
-    std::vector<uint32_t> row_len(n);
-    std::vector<std::string>& local = x.segs;
-    const size_t S = std::max<size_t>(1, std::min<size_t>(4 * T, (n + 255) / 256));
-    local.assign(S, std::string());
-    std::vector<std::pair<size_t, size_t>> local_range(S, {0, 0});
-    for (size_t sg = 0; sg < S; sg++) local_range[sg] = {n * sg / S, n * (sg + 1) / S};
-    std::atomic<size_t> next_seg{0};
-    ctx->pool->run([&](int) {
-      for (;;) {
-        const size_t sg = next_seg.fetch_add(1, std::memory_order_relaxed);
-        if (sg >= S) return;
-        const size_t b = local_range[sg].first, e = local_range[sg].second;
-        std::string& buf = local[sg];
-        buf.reserve((e - b) * 700 + 2048);                       // (+ the room make_row asks for before it knows the last row's length)
-        for (size_t i = b; i < e; i++) {
-          const size_t at = buf.size();
-          make_row(hits[h0 + order[i]], buf, source.compact_rows);   // (appends)
-          buf += '\n';
-          row_len[i] = (uint32_t)(buf.size() - at);
-        }
-      }
-    });
-    ms_make += ms_since(t1);
-    const auto t2 = std::chrono::steady_clock::now();
-    x.keys.resize(n); x.row_off.resize(n + 1);
-    x.row_off[0] = 0;
+    x.entry.resize(n);
+    x.keys.resize(n);
     for (size_t i = 0; i < n; i++) {
       const ExtHit& h = hits[h0 + order[i]];
+      x.entry[i] = &h;
       x.keys[i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (i >= n_plain ? HITS_EXT_PLACED : 0u)};
-      x.row_off[i + 1] = x.row_off[i] + row_len[i];
     }
-    // the buffers in the order of their blocks are the rows' text
-    x.seg_ptr.assign(S, nullptr); x.seg_off.assign(S + 1, 0);
-    for (size_t t = 0; t < S; t++) {
-      const size_t b = local_range[t].first, e = local_range[t].second;
-      x.seg_ptr[t] = local[t].data();
-      x.seg_off[t + 1] = x.seg_off[t] + (b < e ? x.row_off[e] - x.row_off[b] : 0);
-      if (b < e && (x.seg_off[t] != x.row_off[b] || local[t].size() != x.row_off[e] - x.row_off[b]))
-        return calitas_fail(ctx, CALITAS_EINVAL, "the rows of a contig's entries are not where their offsets say (internal error)");
+    x.ext.contig = (int32_t)c; x.ext.n = (uint32_t)n; x.ext.keys = x.keys.data();
+    if (rows_on_demand) {
+      // (runs on the helper thread, in the contig's row stage on the device; cx[c] is this contig's alone from here on)
+      x.ext.rows_for = [&, c](const uint8_t* kept, HitsExtRows* out) -> int { return make_rows(c, kept, out); };
+      return CALITAS_OK;
     }
-    x.ext.contig = (int32_t)c; x.ext.n = (uint32_t)n; x.ext.keys = x.keys.data(); x.ext.row_off = x.row_off.data(); x.ext.rows = nullptr;
-    x.ext.n_seg = (uint32_t)S; x.ext.seg = x.seg_ptr.data(); x.ext.seg_off = x.seg_off.data();
-    ms_blob += ms_since(t2);
+    HitsExtRows made;
+    const int r = make_rows(c, nullptr, &made);
+    if (r) return r;
+    x.ext.row_off = made.row_off; x.ext.rows = nullptr; x.ext.n_seg = made.n_seg; x.ext.seg = made.seg; x.ext.seg_off = made.seg_off;
+    ms_make += ms_since(t1);
     return CALITAS_OK;
   };
   // The contigs before `upto` have all their windows emitted: align what is pending, finish and publish them.
@@ -1108,8 +1163,23 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   };
   finish_upto_fn = finish_upto;
 
+  // The VCF, beside the first of the reference passes (they need nothing of it before their first row stage: 0.15 s at BASELINE config
+  // 5's size that the helper thread used to sit out).
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string e = read_vcf(vcf_path, chrom, ctx->pool, vcf);
+    ms_parse = ms_since(t0);
+    if (!e.empty()) {
+      publish(nc, true);
+      if (helper.joinable()) helper.join();
+      calitas_free(hr.tsv);
+      calitas_free(ref_alns);
+      return calitas_fail(ctx, CALITAS_EIO, e);
+    }
+  }
   const int max_variants = p.max_variants;
   size_t ci = 0, i = 0;
+  const auto t_walk = std::chrono::steady_clock::now();
   while (i < vcf.size() && err.empty() && rc == CALITAS_OK) {
     std::vector<const Var*> chunk{&vcf[i]};
     const Var* last = &vcf[i];
@@ -1142,7 +1212,10 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     }
   }
   if (rc == CALITAS_OK && err.empty()) rc = finish_contigs(nc);
+  const double ms_walk = ms_since(t_walk);                         // (this thread from the first variant to the last window handed over)
+  const auto t_drain = std::chrono::steady_clock::now();
   { const int dr = drain(); if (rc == CALITAS_OK) rc = dr; }
+  const double ms_drain = ms_since(t_drain);
   if (rc != CALITAS_OK || !err.empty()) {
     publish(nc, true);
     if (helper.joinable()) helper.join();
@@ -1168,8 +1241,9 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
           std::vector<std::string>().swap(cx[k].segs);
           std::vector<HitsExtKey>().swap(cx[k].keys);
           std::vector<uint64_t>().swap(cx[k].row_off);
+          std::vector<const ExtHit*>().swap(cx[k].entry);
         } else if (k == cx.size()) {
-          std::vector<ExtHit>().swap(hits);
+          hits.release();
         } else {
           std::vector<Var*>().swap(vcf.at);
         }
@@ -1195,10 +1269,10 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
       if (n_rows) *n_rows = hr.rows;
       if (n_windows) *n_windows = windows_total;
       if (TUNE_GET("CALITAS_TRACE"))
-        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: built in %.1f ms, waiting for the aligner thread %.1f ms (align %.1f ms, keys %.1f ms there), "
-                             "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits, "
-                             "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms\n",
-                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_build, ms_wait, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, ms_variant_half, hr.ms, ms_since(t_call));
+        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: walked and handed over in %.1f ms (of that built in %.1f ms, waiting for the aligner thread %.1f ms), stages drained in %.1f ms (align %.1f ms, keys %.1f ms there), "
+                             "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits (%llu rows made, %.1f ms of them on demand), "
+                             "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms, %.2f s of CPU time\n",
+                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_walk, ms_build, ms_wait, ms_drain, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, (unsigned long long)rows_made.load(), (double)ns_demand.load() / 1e6, ms_variant_half, hr.ms, ms_since(t_call), cpu_seconds() - cpu0);
       return CALITAS_OK;
     }
     calitas_free(hr.tsv);
@@ -1230,7 +1304,8 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     }
     std::sort(keys.begin(), keys.end());
     uint64_t plain = 0, twins = 0, with_desc = 0, shown = 0;
-    for (const ExtHit& h : hits) {
+    for (size_t hk = 0; hk < hits.size(); hk++) {
+      const ExtHit& h = hits[hk];
       if (!h.desc.empty()) { with_desc++; continue; }
       plain++;
       const std::array<int64_t, 3> k{((int64_t)h.w->contig << 32) | (uint32_t)h.gstart, ((int64_t)(h.gstart + h.tlen - 1) << 8) | (uint8_t)h.a->strand, h.a->score};
@@ -1242,7 +1317,7 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     std::fprintf(stderr, "[calitas] variant-window hits: %zu, %llu with a description, %llu without, of those %llu repeat a reference hit\n", hits.size(),
                  (unsigned long long)with_desc, (unsigned long long)plain, (unsigned long long)twins);
   }
-  struct RowMaker { decltype(make_row)* fn; const std::vector<ExtHit>* hits; } maker{&make_row, &hits};
+  struct RowMaker { decltype(make_row)* fn; const HitList* hits; } maker{&make_row, &hits};
   uint64_t nr = 0;
   const auto t_merge = std::chrono::steady_clock::now();
   *tsv = hits_tsv(ref, gh, gid, p, ref_alns, n_ref, version, stamp, &nr, ctx->pool, calitas_out_alloc, ext.data(), (uint64_t)ext.size(),
@@ -1251,6 +1326,16 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
   const size_t n_vcf_records = vcf.size();
   teardown();
   if (!*tsv) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
+  if (user_dst) {                                                 // (the merge on the host built a block of the library's: into the caller's buffer)
+    const size_t len = std::strlen(*tsv);
+    if ((uint64_t)len + 1 > user_cap) {
+      calitas_free(*tsv); *tsv = nullptr;
+      return calitas_fail(ctx, CALITAS_EINVAL, "the destination buffer is too small for the text (" + std::to_string(user_cap) + " bytes; " + std::to_string(len + 1) + " needed)");
+    }
+    std::memcpy(user_dst, *tsv, len + 1);
+    calitas_free(*tsv);
+    *tsv = user_dst;
+  }
   if (tsv_bytes) *tsv_bytes = std::strlen(*tsv);
   if (n_rows) *n_rows = nr;
   if (n_windows) *n_windows = windows_total;
@@ -1259,4 +1344,20 @@ extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* 
     std::fprintf(stderr, "[calitas] search_variants: reference search %.1f ms, VCF %.1f ms (%zu records), %llu windows: align %.1f ms, rows %.1f ms, merge %.1f ms, call %.1f ms\n",
                  ms_ref, ms_parse, n_vcf_records, (unsigned long long)windows_total, (double)ns_align.load() / 1e6, ms_rows, ms_merge, ms_since(t_call));
   return CALITAS_OK;
+}
+
+extern "C" int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                                       const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
+                                       const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows, uint64_t* n_windows) {
+  return search_variants_impl(ctx, guide, guide_id, params, vcf_path, chrom, vcf_id, aligner_version, time_stamp, tsv, tsv_bytes, n_rows, n_windows, nullptr, 0);
+}
+
+extern "C" int calitas_search_variants_into(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                                            const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
+                                            const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes, uint64_t* n_rows,
+                                            uint64_t* n_windows) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!dst || dst_capacity < 2) return calitas_fail(ctx, CALITAS_EINVAL, "no destination buffer");
+  char* text = nullptr;
+  return search_variants_impl(ctx, guide, guide_id, params, vcf_path, chrom, vcf_id, aligner_version, time_stamp, &text, tsv_bytes, n_rows, n_windows, dst, dst_capacity);
 }

@@ -301,6 +301,10 @@ int calitas_search_hits_into(calitas_ctx* ctx, const calitas_guide_t* guide, con
 /* Page-locks / releases host memory the caller owns (hipHostRegister): destinations of calitas_search_hits_into. */
 int calitas_pin_host(calitas_ctx* ctx, void* p, uint64_t bytes);
 int calitas_unpin_host(calitas_ctx* ctx, void* p);
+/* A page-locked block of the runtime's own (hipHostMalloc), handed back with calitas_free: the destination the *_into calls like best --
+ * the GPU's copy engines write into such a block directly (a range that calitas_pin_host merely locked is served by the runtime's
+ * copy kernels instead).  NULL when the block cannot be had.  Meant to be reused from call to call: page-locking is not cheap. */
+void* calitas_alloc_host(uint64_t bytes);
 
 /* calitas_search_hits with the text handed to a callback instead of returned in one block (Metric.writer's output stream,
  * SearchReference.scala:646-648): `sink` receives consecutive pieces of hits.txt -- the whole text in one piece when the search fits
@@ -323,6 +327,15 @@ int calitas_search_hits_stream(calitas_ctx* ctx, const calitas_guide_t* guide, c
 int calitas_search_variants(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                             const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
                             const char* time_stamp, char** tsv, uint64_t* tsv_bytes, uint64_t* n_rows, uint64_t* n_windows);
+/* calitas_search_variants with the text delivered into a buffer of the caller (dst_capacity bytes, NUL included), as
+ * calitas_search_hits_into does for a search without variants.  A hits.txt with variants at whole-genome size is tens of gigabytes
+ * (21.8 GB for BASELINE config 5's shape): into a block of the library's it crosses the bus into a bounce buffer and is copied from there
+ * into pages nobody has touched yet; into a page-locked buffer (calitas_pin_host, once, reused from call to call) every contig's rows
+ * cross the bus straight to their place.  CALITAS_EINVAL when the buffer is too small (the message says how far the text got). */
+int calitas_search_variants_into(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
+                                 const char* vcf_path, const char* chrom, const char* vcf_id, const char* aligner_version,
+                                 const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes, uint64_t* n_rows,
+                                 uint64_t* n_windows);
 
 /* Padded strings of one alignment (Alignment.paddedString as used at SequentialGuideAligner.scala:511, plus the
  * reverse-complement handling of 5' PAM guides): each buffer must hold CALITAS_MAX_OPS+1 bytes. */

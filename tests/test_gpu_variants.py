@@ -211,7 +211,8 @@ def _dense_case(C, tmp_path, sizes, every, seed):
 @pytest.mark.parametrize("d,overlap", [(7, 10), (8, 10), (8, 25), (7, 1)])
 def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_path, monkeypatch):
     """calitas_search_variants keeps the reference's own hits on the device: the hits of variant windows enter the device's
-    removeOverlaps walk / order as key-only entries with finished rows (hits.hpp, HitsExt).  Same bytes as the host merge of
+    removeOverlaps walk / order as key-only entries, and the rows of the ones the walks keep are made on demand (hits.hpp, HitsExt::rows_for;
+    CALITAS_VARIANTS_ROWS=all: every entry comes with its finished row, as before round 5).  Same bytes as the host merge of
     alignment records (CALITAS_VARIANTS_HOST=1, the path the oracle comparisons of this file pinned), with and without a contig whose
     reference windows yield nothing, and the oracle's rows as a multiset (ties between groups: SR:656)."""
     fa, vcf = _dense_case(C, tmp_path, [("chr1", 60000), ("tiny", 90), ("chr2", 21000)], 80, seed=100 + d)
@@ -223,7 +224,13 @@ def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_pa
     monkeypatch.setenv("CALITAS_VARIANTS_COMPACT", "1")          # the reference passes' texts and the entries' rows compact (off by default)
     sc = C.SearchReference(**kw)
     assert sc.run("v0", "stamp") == (text, n) and sc.timing["contig_passes"] == 3
+    monkeypatch.setenv("CALITAS_VARIANTS_ROWS", "all")           # ... and with every entry's row made up front, compact and whole
+    sa = C.SearchReference(**kw)
+    assert sa.run("v0", "stamp") == (text, n) and sa.timing["contig_passes"] == 3
     monkeypatch.delenv("CALITAS_VARIANTS_COMPACT")
+    sa = C.SearchReference(**kw)
+    assert sa.run("v0", "stamp") == (text, n) and sa.timing["contig_passes"] == 3
+    monkeypatch.delenv("CALITAS_VARIANTS_ROWS")
     monkeypatch.setenv("CALITAS_VARIANTS_HOST", "1")
     sh = C.SearchReference(**kw)
     text_h, n_h = sh.run("v0", "stamp")
@@ -235,6 +242,51 @@ def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_pa
     _, want, _ = O.search_reference_vcf(fa, vcf, kw["guide"], "c5", d=d, p=0, g=3, O=overlap)
     key = lambda r: json.dumps(r, sort_keys=True)
     assert sorted(map(key, _norm(got))) == sorted(map(key, _norm(want)))
+
+
+@pytest.mark.parametrize("host_merge,block", [(False, "pinned"), (False, "alloc_host"), (True, "pinned")])
+def test_text_into_the_callers_page_locked_buffer(C, host_merge, block, tmp_path, monkeypatch):
+    """calitas_search_variants_into: the same bytes as calitas_search_variants, delivered into memory of the caller's -- every contig's
+    rows straight to their place over the bus when the device writes the rows, a copy of the library's block when the merge ran on the
+    host --, and CALITAS_EINVAL, not an overrun, when the buffer is too small (at the header, and in the middle of the contigs)."""
+    fa, vcf = _dense_case(C, tmp_path, [("chr1", 60000), ("tiny", 90), ("chr2", 21000)], 80, seed=107)
+    kw = dict(guide="CTTGCCCCACAGGGCAGTAA", guide_id="c5", ref=fa, variants=vcf, max_guide_diffs=7, max_pam_mismatches=0,
+              max_gaps_between_guide_and_pam=3, max_overlap=10)
+    if host_merge:
+        monkeypatch.setenv("CALITAS_VARIANTS_HOST", "1")
+    text, n = C.SearchReference(**kw).run("v0", "stamp")
+    want = text.encode()
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    params = C.make_params(max_guide_diffs=7, max_pam_mismatches=0, max_gaps_between_guide_and_pam=3, max_overlap=10)
+    g = C.Guide("CTTGCCCCACAGGGCAGTAA")
+    if block == "alloc_host":                                   # a block of the runtime's own: the copy engines' favourite
+        import ctypes
+        addr = C.Context.alloc_host(len(want) + 4096)
+        buf = np.ctypeslib.as_array((ctypes.c_uint8 * (len(want) + 4096)).from_address(addr))
+        buf[:] = 0x55
+    else:                                                       # memory of the caller's, locked in place
+        buf = np.full(len(want) + 4096, 0x55, dtype=np.uint8)
+        ctx.pin_host(buf.ctypes.data, buf.nbytes)
+    try:
+        for _ in range(2):                                      # (the buffer is reused from call to call)
+            nb, rows, nwin = ctx.search_variants_into(g, "c5", params, vcf, buf.ctypes.data, buf.nbytes, "v0", "stamp")
+            assert (nb, rows) == (len(want), n) and nwin > 0
+            assert bytes(buf[:nb]) == want and buf[nb] == 0 and buf[nb + 1] == 0x55
+        nb2, rows2, _ = ctx.search_variants_into(g, "c5", params, vcf, buf.ctypes.data, len(want) + 1, "v0", "stamp")   # exactly enough
+        assert (nb2, rows2) == (len(want), n) and bytes(buf[:nb2]) == want
+        for cap in (16, len(want) // 2, len(want)):             # too small: at the header, part of the way, by the final NUL
+            buf[:] = 0x55
+            with pytest.raises(C.CalitasError, match="too small|does not hold the header"):
+                ctx.search_variants_into(g, "c5", params, vcf, buf.ctypes.data, cap, "v0", "stamp")
+            assert (buf[cap:] == 0x55).all()                    # nothing behind the capacity was touched
+    finally:
+        if block == "alloc_host":
+            del buf
+            C.Context.free_host(addr)
+        else:
+            ctx.unpin_host(buf.ctypes.data)
+        ctx.close()
 
 
 @pytest.mark.parametrize("which", [0, 1, 2, 4])
