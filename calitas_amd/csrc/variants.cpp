@@ -20,7 +20,11 @@
 // counterpart in the reference.
 //
 // VCF support is the subset the reference's path needs (fgbio vcf.api): CHROM POS ID REF ALT FILTER INFO(AF, END); plain or gzip.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/resource.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -45,11 +49,27 @@
 
 namespace {
 
+// One element in place, more on the heap: a VCF record has one ALT and one AF value nearly always, and three million records with two
+// small heap blocks each were six million allocations per call to make -- and to hand back.
+template <typename T>
+struct Few {
+  T first{};
+  std::vector<T> rest;
+  uint32_t n = 0;
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  const T& operator[](size_t i) const { return i == 0 ? first : rest[i - 1]; }
+  template <class... A>
+  void emplace_back(A&&... a) { if (n == 0) first = T(std::forward<A>(a)...); else rest.emplace_back(std::forward<A>(a)...); n++; }
+  void push_back(const T& v) { emplace_back(v); }
+  void clear() { n = 0; rest.clear(); }
+};
+
 struct Var {
   std::string chrom, id, ref;
   int pos = 0, end = 0;                    // 1-based; fgbio Variant.end
-  std::vector<std::string> alts;
-  std::vector<float> afs;
+  Few<std::string> alts;
+  Few<float> afs;
 };
 
 struct Allele {                            // VariantAllele SR:105-110
@@ -71,6 +91,38 @@ struct Window {
 };
 struct Arena { std::vector<char> bases; std::vector<Allele> alleles; std::vector<CigarEl> cigars; };
 struct ArenaMark { size_t bases, alleles, cigars; };   // where a window's pieces start in its arena (pointers are set once the arena is complete)
+
+// strtod of p[0..n) for the numbers a VCF's AF holds.  Plain decimals of at most 15 significant digits and 22 decimal places are an
+// integer below 2^53 divided by a power of ten that a double holds exactly: one correctly rounded division, the very double strtod
+// returns (Clinger's fast path).  Everything else -- exponents, longer digit strings, inf / nan, blanks -- goes to strtod itself.
+double parse_decimal(const char* p, size_t n) {
+  static const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  size_t i = 0;
+  bool neg = false;
+  if (i < n && (p[i] == '-' || p[i] == '+')) { neg = p[i] == '-'; i++; }
+  uint64_t m = 0;
+  int digits = 0, frac = 0;
+  bool dot = false, any = false, simple = true;
+  for (; i < n; i++) {
+    const char c = p[i];
+    if (c >= '0' && c <= '9') {
+      any = true;
+      if (m != 0 || c != '0') digits++;
+      if (digits > 15) { simple = false; break; }
+      m = m * 10 + (uint64_t)(c - '0');
+      if (dot) frac++;
+    } else if (c == '.' && !dot) dot = true;
+    else { simple = false; break; }
+  }
+  if (simple && any && frac <= 22) {
+    const double v = (double)m / kPow10[frac];
+    return neg ? -v : v;
+  }
+  char num[64];
+  const size_t cl = std::min(n, sizeof(num) - 1);
+  std::memcpy(num, p, cl); num[cl] = 0;
+  return std::strtod(num, nullptr);
+}
 
 // One VCF record (a line without its newline) -> v; false for headers, short lines and other chromosomes (read_vcf of variants.py).
 bool parse_record(const char* b, const char* e, const char* chrom, size_t chrom_len, Var& v) {
@@ -124,12 +176,7 @@ bool parse_record(const char* b, const char* e, const char* chrom, size_t chrom_
           const char* c = (const char*)std::memchr(x0, ',', (size_t)(ke - x0));
           const char* const xe = c ? c : ke;
           const size_t xl = (size_t)(xe - x0);
-          if (xl != 0 && !(xl == 1 && x0[0] == '.')) {
-            char num[64];
-            const size_t cl = std::min(xl, sizeof(num) - 1);
-            std::memcpy(num, x0, cl); num[cl] = 0;
-            v.afs.push_back((float)std::strtod(num, nullptr));
-          }
+          if (xl != 0 && !(xl == 1 && x0[0] == '.')) v.afs.push_back((float)parse_decimal(x0, xl));
           if (!c) break;
           x0 = c + 1;
         }
@@ -161,18 +208,20 @@ std::string read_vcf(const char* path, const char* chrom, calitas::WorkerPool* p
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   std::string data;
   bool plain = false;
-  if (FILE* f = std::fopen(path, "rb")) {    // a plain file is read in one piece (zlib's transparent mode copies it at ~1 GB/s)
-    unsigned char magic[2] = {0, 0};
-    const size_t got = std::fread(magic, 1, 2, f);
-    if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && std::fseek(f, 0, SEEK_END) == 0) {
-      const long size = std::ftell(f);
-      if (size >= 0 && std::fseek(f, 0, SEEK_SET) == 0) {
-        data.resize((size_t)size);
-        plain = std::fread(&data[0], 1, (size_t)size, f) == (size_t)size;
-        if (!plain) data.clear();
+  // a plain file is mapped and parsed where the page cache has it (reading it into a block of the call's own was 37 ms of one thread
+  // per 127 MB before the first record was looked at; zlib's transparent mode copies at ~1 GB/s)
+  struct Mapping { void* p = MAP_FAILED; size_t n = 0; ~Mapping() { if (p != MAP_FAILED) (void)munmap(p, n); } } map;
+  {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd >= 0) {
+      unsigned char magic[2] = {0, 0};
+      struct stat st{};
+      if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 2 && ::pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+        map.p = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (map.p != MAP_FAILED) { map.n = (size_t)st.st_size; plain = true; (void)::madvise(map.p, map.n, MADV_WILLNEED); }
       }
+      ::close(fd);
     }
-    std::fclose(f);
   }
   if (!plain) {
     gzFile f = gzopen(path, "rb");           // transparent for plain text
@@ -189,19 +238,25 @@ std::string read_vcf(const char* path, const char* chrom, calitas::WorkerPool* p
   }
   const double ms_read = ms_since(t_read);
   const auto t_parse = std::chrono::steady_clock::now();
-  const size_t n = data.size(), chrom_len = chrom ? std::strlen(chrom) : 0;
+  const char* const text = plain ? (const char*)map.p : data.data();
+  const size_t n = plain ? map.n : data.size(), chrom_len = chrom ? std::strlen(chrom) : 0;
   std::vector<std::vector<Var>> parts((size_t)pool->size());
   pool->for_blocks(n, [&](size_t b, size_t e, int tid) {
-    const char* const base = data.data();
+    const char* const base = text;
     const char* const end = base + n;
     const char* p = base + b;
     if (b > 0) { const char* nl = (const char*)std::memchr(base + b - 1, '\n', n - (b - 1)); p = nl ? nl + 1 : end; }   // first line start >= b
     std::vector<Var>& mine = parts[(size_t)tid];
+    // (a record is parsed where it stays: a Var built aside and moved in, into a vector that doubled its way up, was a third of the
+    // 0.11 s the records took -- room for a record per 24 bytes, which no line with an INFO column undercuts)
+    mine.reserve((e - b) / 24 + 16);
     while (p < base + e) {
       const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
       const char* le = nl ? nl : end;
-      Var v;
-      if (parse_record(p, le, chrom, chrom_len, v)) mine.push_back(std::move(v));
+      if (p < le && *p != '#') {
+        mine.emplace_back();
+        if (!parse_record(p, le, chrom, chrom_len, mine.back())) mine.pop_back();
+      }
       p = le + 1;
     }
   });
@@ -608,10 +663,6 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   std::deque<Batch> kept_windows;                                                                    // the windows and alignment records behind the hits
   std::vector<calitas_aln_t*> kept_out;
   const size_t kBatch = 65536;
-  Batch batch;
-  batch.wins.resize(kBatch + 1);
-  batch.arenas.resize((size_t)ctx->pool->size());
-  size_t nb = 0;
   uint64_t windows_total = 0;
   std::string err;
 
@@ -808,59 +859,62 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   };
   // where a built batch goes: to the aligner thread once it runs (hand_over), through align_stage on this thread before that
   std::function<int(Batch&&, size_t)> hand_over;
-  auto flush = [&]() -> int {
-    if (nb == 0) return CALITAS_OK;
-    Batch full = std::move(batch);
-    const size_t n = nb;
-    batch = Batch();                                              // a fresh batch for the producer
-    batch.wins.resize(kBatch + 1);
-    batch.arenas.resize((size_t)ctx->pool->size());
-    nb = 0;
-    if (hand_over) return hand_over(std::move(full), n);
-    return align_stage(full, n, err);
-  };
-
   // variantWindowIterator SR:217-256 with nextChunk / reChunk SR:326-347.  The iterator itself only lists what each window is made
-  // of (variants and alleles); a full batch of windows is then built on the worker pool and handed to the GPU.
-  std::vector<uint32_t> spec_off{0};
-  std::vector<const Var*> spec_v;
-  std::vector<int> spec_a, spec_contig;
-  std::vector<uint32_t> spec_chunk;
+  // of (variants and alleles: a Spec); a full batch of windows is then built on the worker pool and handed to the GPU -- by a stage
+  // thread of its own once the stages run (round 5: this thread used to wait for every batch's build, 0.15-0.3 s per call at BASELINE
+  // config 5's size, with the list of the next batch standing still meanwhile).
+  struct Spec { std::vector<uint32_t> off{0}; std::vector<const Var*> v; std::vector<int> a, contig; std::vector<uint32_t> chunk; };
+  Spec spec;
   uint32_t chunk_serial = 0;
-  auto build_and_flush = [&]() -> int {
-    nb = spec_contig.size();
-    if (nb == 0) return CALITAS_OK;
+  StageThread* builder_p = nullptr;                               // (set once the stage threads run)
+  double ms_wait_builder = 0;                                     // this thread's waits for the builder stage (ms_wait: the later stages')
+  auto build_spec = [&](const Spec& sp, std::string& e_out) -> int {
+    const size_t n = sp.contig.size();
+    if (n == 0) return CALITAS_OK;
     const auto t_build = std::chrono::steady_clock::now();
+    Batch b;
+    b.wins.resize(n + 1);
+    b.arenas.resize((size_t)ctx->pool->size());
     std::vector<std::string> errs((size_t)ctx->pool->size());
-    ctx->pool->for_blocks(nb, [&](size_t b, size_t e, int tid) {
-      Arena& A = batch.arenas[(size_t)tid];
+    ctx->pool->for_blocks(n, [&](size_t lo, size_t hi, int tid) {
+      Arena& A = b.arenas[(size_t)tid];
       std::string tmp;
       std::vector<CigarEl> ctmp;
-      std::vector<ArenaMark> marks(e - b);
-      A.bases.reserve((e - b) * (size_t)(2 * padding + 8));
-      for (size_t k = b; k < e && errs[(size_t)tid].empty(); k++)
-        errs[(size_t)tid] = build_window(spec_v.data() + spec_off[k], spec_a.data() + spec_off[k], spec_off[k + 1] - spec_off[k], spec_contig[k], ref,
-                                         padding, A, tmp, ctmp, batch.wins[k], marks[k - b]);
-      for (size_t k = b; k < e; k++) {                           // the arena is complete: the views get their pointers
-        Window& w = batch.wins[k];
-        w.chunk = spec_chunk[k];
-        w.bases = A.bases.data() + marks[k - b].bases; w.variants = A.alleles.data() + marks[k - b].alleles; w.cigar = A.cigars.data() + marks[k - b].cigars;
+      std::vector<ArenaMark> marks(hi - lo);
+      A.bases.reserve((hi - lo) * (size_t)(2 * padding + 8));
+      for (size_t k = lo; k < hi && errs[(size_t)tid].empty(); k++)
+        errs[(size_t)tid] = build_window(sp.v.data() + sp.off[k], sp.a.data() + sp.off[k], sp.off[k + 1] - sp.off[k], sp.contig[k], ref,
+                                         padding, A, tmp, ctmp, b.wins[k], marks[k - lo]);
+      for (size_t k = lo; k < hi; k++) {                         // the arena is complete: the views get their pointers
+        Window& w = b.wins[k];
+        w.chunk = sp.chunk[k];
+        w.bases = A.bases.data() + marks[k - lo].bases; w.variants = A.alleles.data() + marks[k - lo].alleles; w.cigar = A.cigars.data() + marks[k - lo].cigars;
       }
     });
-    for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
-    spec_off.assign(1, 0u); spec_v.clear(); spec_a.clear(); spec_contig.clear(); spec_chunk.clear();
+    for (auto& e : errs) if (!e.empty() && e_out.empty()) e_out = e;
     ms_build += ms_since(t_build);
-    if (!err.empty()) { nb = 0; return CALITAS_OK; }
-    return flush();
+    if (!e_out.empty()) return CALITAS_EINVAL;
+    if (hand_over) return hand_over(std::move(b), n);
+    return align_stage(b, n, e_out);
+  };
+  auto build_and_flush = [&]() -> int {
+    if (spec.contig.empty()) return CALITAS_OK;
+    auto held = std::make_shared<Spec>(std::move(spec));
+    spec = Spec();
+    if (builder_p) return builder_p->enqueue([&, held](std::string& e) { return build_spec(*held, e); }, 2, &ms_wait_builder);
+    std::string e;
+    const int r = build_spec(*held, e);
+    if (!e.empty()) { if (err.empty()) err = e; return CALITAS_OK; }   // (the walk stops at err; the call's code is set where it ends)
+    return r;
   };
   auto emit = [&](const Var* const* vs, const int* al, size_t nv, int contig) -> int {
-    spec_v.insert(spec_v.end(), vs, vs + nv);
-    spec_a.insert(spec_a.end(), al, al + nv);
-    spec_off.push_back((uint32_t)spec_v.size());
-    spec_contig.push_back(contig);
-    spec_chunk.push_back(chunk_serial);
+    spec.v.insert(spec.v.end(), vs, vs + nv);
+    spec.a.insert(spec.a.end(), al, al + nv);
+    spec.off.push_back((uint32_t)spec.v.size());
+    spec.contig.push_back(contig);
+    spec.chunk.push_back(chunk_serial);
     windows_total++;
-    return spec_contig.size() >= kBatch ? build_and_flush() : CALITAS_OK;
+    return spec.contig.size() >= kBatch ? build_and_flush() : CALITAS_OK;
   };
   // ---- the reference windows (SR:527-561) and the merge (SR:641-648) on the device, beside the variant windows --------------------
   // The reference's own hits never leave the device.  A hit of a variant window that touches no variant joins the removeOverlaps
@@ -883,7 +937,10 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     std::vector<HitsExtKey> keys; std::vector<uint64_t> row_off;
     std::vector<std::string> segs;                                // the rows' text as the workers wrote it: a block of rows each
     std::vector<const char*> seg_ptr; std::vector<uint64_t> seg_off;
-    std::vector<const ExtHit*> entry;                              // rows on demand: the entries in tie order
+    std::vector<const ExtHit*> entry;                              // the entries in tie order: the plain ones, then the placed ones
+    std::vector<uint32_t> row_len;
+    size_t n_plain = 0;
+    std::vector<std::string> segs_placed;                          // the placed entries' rows (segs: the plain entries')
     HitsExt ext;
   };
   std::vector<ContigExt> cx(nc);
@@ -931,59 +988,61 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       hr.ms = ms_since(t0);
     });
 
-  // The rows of contig c's entries -- of those with kept[i] != 0, or of all (kept null) -- in cx[c]: consecutive blocks of entries, each
-  // written into a buffer of its own by whichever worker takes it next (the entries with variants stand at the end of the order and their
-  // rows cost 2.5 times a plain one: equal shares per worker left seven workers with all of them, 25 ms against 10 per contig); the device
-  // takes the buffers piece by piece.  An entry that is not wanted has length 0.
+  // The rows of contig c's entries [lo, hi) -- of those with kept[i] != 0, or of all (kept null) -- as consecutive blocks of entries, each
+  // written into a buffer of its own (segs) by whichever worker takes it next (the entries with variants stand at the end of the order and
+  // their rows cost 2.5 times a plain one: equal shares per worker left seven workers with all of them, 25 ms against 10 per contig); the
+  // device takes the buffers piece by piece.  x.row_len[i] = the row's length with its newline, 0 for an entry that is not wanted.
   std::atomic<long long> ns_demand{0};                             // (rows on demand: the helper thread's time here)
   std::atomic<uint64_t> rows_made{0};
-  auto make_rows = [&](size_t c, const uint8_t* kept, HitsExtRows* out) -> int {
-    const auto t0 = std::chrono::steady_clock::now();
+  auto make_rows = [&](size_t c, size_t lo, size_t hi, const uint8_t* kept, std::vector<std::string>& segs) {
     ContigExt& x = cx[c];
-    const size_t n = x.entry.size();
+    const size_t n = hi - lo;
     const size_t T = (size_t)ctx->pool->size();
-    std::vector<uint32_t> row_len(n, 0);
-    std::vector<std::string>& local = x.segs;
     const size_t S = std::max<size_t>(1, std::min<size_t>(4 * T, (n + 255) / 256));
-    local.assign(S, std::string());
-    std::vector<std::pair<size_t, size_t>> local_range(S, {0, 0});
-    for (size_t sg = 0; sg < S; sg++) local_range[sg] = {n * sg / S, n * (sg + 1) / S};
+    segs.assign(S, std::string());
+    if (n == 0) return;
     std::atomic<size_t> next_seg{0};
     ctx->pool->run([&](int) {
       for (;;) {
         const size_t sg = next_seg.fetch_add(1, std::memory_order_relaxed);
         if (sg >= S) return;
-        const size_t b = local_range[sg].first, e = local_range[sg].second;
+        const size_t b = lo + n * sg / S, e = lo + n * (sg + 1) / S;
         size_t wanted = e - b;
         if (kept) { wanted = 0; for (size_t i = b; i < e; i++) wanted += kept[i] != 0; }
         if (!wanted) continue;
-        std::string& buf = local[sg];
+        std::string& buf = segs[sg];
         buf.reserve(wanted * 700 + 2048);                        // (+ the room make_row asks for before it knows the last row's length)
         for (size_t i = b; i < e; i++) {
           if (kept && !kept[i]) continue;
           const size_t at = buf.size();
           make_row(*x.entry[i], buf, source.compact_rows);       // (appends)
           buf += '\n';
-          row_len[i] = (uint32_t)(buf.size() - at);
+          x.row_len[i] = (uint32_t)(buf.size() - at);
         }
         rows_made.fetch_add(wanted, std::memory_order_relaxed);
       }
     });
+  };
+  // ... and what the device is given: the offsets of all entries' rows in the text that the buffers -- the plain entries', then the placed
+  // ones' -- make in this order.
+  auto rows_of = [&](size_t c, HitsExtRows* out) -> int {
+    ContigExt& x = cx[c];
+    const size_t n = x.entry.size();
     x.row_off.resize(n + 1);
     x.row_off[0] = 0;
-    for (size_t i = 0; i < n; i++) x.row_off[i + 1] = x.row_off[i] + row_len[i];
-    // the buffers in the order of their blocks are the rows' text
-    x.seg_ptr.assign(S, nullptr); x.seg_off.assign(S + 1, 0);
-    for (size_t t = 0; t < S; t++) {
-      const size_t b = local_range[t].first, e = local_range[t].second;
-      x.seg_ptr[t] = local[t].data();
-      x.seg_off[t + 1] = x.seg_off[t] + (b < e ? x.row_off[e] - x.row_off[b] : 0);
-      if (b < e && (x.seg_off[t] != x.row_off[b] || local[t].size() != x.row_off[e] - x.row_off[b]))
-        return calitas_fail(ctx, CALITAS_EINVAL, "the rows of a contig's entries are not where their offsets say (internal error)");
-    }
+    for (size_t i = 0; i < n; i++) x.row_off[i + 1] = x.row_off[i] + x.row_len[i];
+    x.seg_ptr.clear(); x.seg_off.assign(1, 0);
+    for (std::vector<std::string>* group : {&x.segs, &x.segs_placed})
+      for (const std::string& sg : *group) {
+        if (sg.empty()) continue;
+        x.seg_ptr.push_back(sg.data());
+        x.seg_off.push_back(x.seg_off.back() + sg.size());
+      }
+    if (x.seg_off.back() != x.row_off[n])
+      return calitas_fail(ctx, CALITAS_EINVAL, "the rows of a contig's entries are not where their offsets say (internal error)");
+    if (x.seg_ptr.empty()) { x.seg_ptr.push_back(""); x.seg_off.push_back(0); }   // (no row at all: one empty piece)
     out->row_off = x.row_off.data(); out->rows = nullptr;
-    out->n_seg = (uint32_t)S; out->seg = x.seg_ptr.data(); out->seg_off = x.seg_off.data();
-    if (kept) ns_demand += (long long)(ms_since(t0) * 1e6);
+    out->n_seg = (uint32_t)x.seg_ptr.size(); out->seg = x.seg_ptr.data(); out->seg_off = x.seg_off.data();
     return CALITAS_OK;
   };
   // The entries of contig c -- hits[h0, h1), in arrival order -- for the device: the groups' walks, every entry's key and (unless the
@@ -1035,12 +1094,6 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     const size_t n_plain = order.size();
     for (auto& v : kept) order.insert(order.end(), v.begin(), v.end());
     const size_t n = order.size();
-    ms_groups += ms_since(t0);
-    const auto t1 = std::chrono::steady_clock::now();
-    if (!need_vid()) return calitas_fail(ctx, CALITAS_EIO, md5_err);
-    // rows: consecutive blocks of entries, each written into a buffer of its own by whichever worker takes it next (the entries with
-    // variants stand at the end of the order and their rows cost 2.5 times a plain one: equal shares per worker left seven workers
-    // with all of them, 25 ms against 10 per contig); the device takes the buffers piece by piece
     ContigExt& x = cx[c];
     x.entry.resize(n);
     x.keys.resize(n);
@@ -1050,13 +1103,39 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       x.keys[i] = HitsExtKey{h.gstart, h.gstart + h.tlen - 1, h.a->score, (h.a->strand == '-' ? HITS_EXT_MINUS : 0u) | (i >= n_plain ? HITS_EXT_PLACED : 0u)};
     }
     x.ext.contig = (int32_t)c; x.ext.n = (uint32_t)n; x.ext.keys = x.keys.data();
+    x.n_plain = n_plain;
+    x.row_len.assign(n, 0);
+    ms_groups += ms_since(t0);
+    return CALITAS_OK;
+  };
+  // ... and the rows (the finisher stage, behind the lifter: the lifter carried keys, groups and rows one after the other, 0.43-0.47 s
+  // per call at BASELINE config 5's size, and every other stage of the variant half waited for it).
+  // The placed entries -- kept by the walks of their own groups, so their rows are wanted whatever the device decides -- get their rows
+  // now; the plain ones when the device's walk has kept them (next to none: they repeat reference hits), on the helper thread inside the
+  // contig's row stage.
+  auto finish_rows = [&](size_t c) -> int {
+    ContigExt& x = cx[c];
+    const size_t n = x.entry.size(), n_plain = x.n_plain;
+    if (n == 0) return CALITAS_OK;
+    const auto t1 = std::chrono::steady_clock::now();
+    if (!need_vid()) return calitas_fail(ctx, CALITAS_EIO, md5_err);
+    make_rows(c, n_plain, n, nullptr, x.segs_placed);
     if (rows_on_demand) {
-      // (runs on the helper thread, in the contig's row stage on the device; cx[c] is this contig's alone from here on)
-      x.ext.rows_for = [&, c](const uint8_t* kept, HitsExtRows* out) -> int { return make_rows(c, kept, out); };
+      // (runs on the helper thread; cx[c] is this contig's alone from here on)
+      x.ext.rows_for = [&, c, n_plain](const uint8_t* kept, HitsExtRows* out) -> int {
+        const auto t_d = std::chrono::steady_clock::now();
+        std::fill(cx[c].row_len.begin(), cx[c].row_len.begin() + (std::ptrdiff_t)n_plain, 0u);   // (a second row stage of the same contig starts afresh)
+        make_rows(c, 0, n_plain, kept, cx[c].segs);
+        const int r = rows_of(c, out);
+        ns_demand += (long long)(ms_since(t_d) * 1e6);
+        return r;
+      };
+      ms_make += ms_since(t1);
       return CALITAS_OK;
     }
+    make_rows(c, 0, n_plain, nullptr, x.segs);
     HitsExtRows made;
-    const int r = make_rows(c, nullptr, &made);
+    const int r = rows_of(c, &made);
     if (r) return r;
     x.ext.row_off = made.row_off; x.ext.rows = nullptr; x.ext.n_seg = made.n_seg; x.ext.seg = made.seg; x.ext.seg_off = made.seg_off;
     ms_make += ms_since(t1);
@@ -1090,11 +1169,15 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     return r;
   };
   // (the lifter first: the aligners' jobs hand work to it, so it is destroyed -- joined -- after them)
-  StageThread lifter, aligner, aligner2;
+  // (... the finisher before it: the lifter's jobs hand the contigs' rows to it; and the builder last: its jobs hand work to the aligners)
+  StageThread finisher, lifter, aligner, aligner2, builder;
   const bool two_aligners = actx2 != nullptr;
   aligner.start(ctx->device);
   if (two_aligners) aligner2.start(ctx->device);
   lifter.start(-1);
+  finisher.start(-1);
+  builder.start(-1);
+  builder_p = &builder;
   // a contig's entries for the device are made on the lifter thread, behind the lift of the contig's last batch, while this thread is
   // already walking the next contig (waiting for the stages to run dry at every one of 25 contig ends was 0.22 s of the variant half)
   auto hand_over_finish = [&](size_t upto) -> int {
@@ -1122,10 +1205,12 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     }, 2, &ms_wait, [&, k] { (void)pass_turn(k, nullptr); });
   };
   auto drain = [&]() -> int {                                     // everything handed over is in hits[]
+    const int r0 = builder.drain(&ms_wait_builder, &err);
     const int ra = aligner.drain(&ms_wait, &err);
     const int rb = two_aligners ? aligner2.drain(&ms_wait, &err) : CALITAS_OK;
     const int rl = lifter.drain(&ms_wait, &err);
-    return ra ? ra : rb ? rb : rl;
+    const int rf = finisher.drain(&ms_wait, &err);
+    return r0 ? r0 : ra ? ra : rb ? rb : rl ? rl : rf;
   };
   // (every batch handed over before it has been through the aligner: finish_contigs drains first)
   auto finish_upto = [&](size_t upto) -> int {
@@ -1138,10 +1223,11 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       for (size_t c = contigs_done; c < upto; c++) {
         size_t e = h;
         while (e < hits.size() && (size_t)hits[e].w->contig == c) e++;
-        const int r = finish_contig(c, h, e);
+        int r = finish_contig(c, h, e);
         if (r) return r;
         h = e;
-        publish(c + 1, false);
+        r = finisher.enqueue([&, c](std::string&) -> int { const int rr = finish_rows(c); if (!rr) publish(c + 1, false); return rr; }, 4, nullptr);
+        if (r) return r;
       }
     }
     hits_done = hits.size();
@@ -1159,7 +1245,8 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     // thread there was at first, that thread carried 1.26 s of host work one after the other, variant half 1.54 against 1.38 s; on the
     // lifter with two aligners but a pool that let one caller in at a time, the same 1.35-1.41 s; with the pool's shares, 0.95-1.04
     // against 1.25-1.32 s, step 1.36-1.38 against 1.60-1.62 s on one box, alternating.)
-    return hand_over_finish(upto);
+    // (through the builder stage, behind the contig's last batch: the batches are numbered where they are handed on)
+    return builder.enqueue([&, upto](std::string&) -> int { return hand_over_finish(upto); }, 2, &ms_wait_builder);
   };
   finish_upto_fn = finish_upto;
 
@@ -1180,19 +1267,27 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   const int max_variants = p.max_variants;
   size_t ci = 0, i = 0;
   const auto t_walk = std::chrono::steady_clock::now();
+  // (three million chunks per call at full size: the vectors are reused, and a chunk's contig is looked up when the contig changes --
+  // a search through the 25 names per chunk was a third of this thread's 0.38 s in the loop)
+  std::vector<const Var*> chunk, sub;
+  size_t ci_of_contig = (size_t)-1;
+  int contig = -1;
   while (i < vcf.size() && err.empty() && rc == CALITAS_OK) {
-    std::vector<const Var*> chunk{&vcf[i]};
+    chunk.assign(1, &vcf[i]);
     const Var* last = &vcf[i];
     i++;
     while (i < vcf.size() && vcf[i].chrom == last->chrom && vcf[i].pos <= last->end + padding) { last = &vcf[i]; chunk.push_back(last); i++; }
     while (ci < order.size() && order[ci] != chunk[0]->chrom) ci++;
     if (ci >= order.size()) { err = "next on empty iterator (VCF contig " + chunk[0]->chrom + " not in reference order)"; break; }
-    int contig = -1;
-    for (size_t k = 0; k < ref.names.size(); k++) if (ref.names[k] == order[ci]) { contig = (int)k; break; }
+    if (ci != ci_of_contig) {
+      contig = -1;
+      for (size_t k = 0; k < ref.names.size(); k++) if (ref.names[k] == order[ci]) { contig = (int)k; break; }
+      ci_of_contig = ci;
+    }
     chunk_serial++;
     if ((size_t)contig > contigs_asked) { rc = finish_contigs((size_t)contig); if (rc || !err.empty()) break; }   // the contigs before this one are complete: their entries are made behind their last batch
     for (size_t s = 0; s < chunk.size() && err.empty() && rc == CALITAS_OK; s++) {
-      std::vector<const Var*> sub;
+      sub.clear();
       for (size_t k = s; k < chunk.size(); k++) { if (chunk[k]->pos - chunk[s]->end > padding) break; sub.push_back(chunk[k]); }
       // alleleCombos SR:351-369
       if ((int)sub.size() > max_variants || sub.size() == 1) {       // (a single variant: the same windows, without the tables)
@@ -1239,6 +1334,8 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       for (size_t k = b; k < e; k++) {
         if (k < cx.size()) {
           std::vector<std::string>().swap(cx[k].segs);
+          std::vector<std::string>().swap(cx[k].segs_placed);
+          std::vector<uint32_t>().swap(cx[k].row_len);
           std::vector<HitsExtKey>().swap(cx[k].keys);
           std::vector<uint64_t>().swap(cx[k].row_off);
           std::vector<const ExtHit*>().swap(cx[k].entry);
@@ -1269,10 +1366,10 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       if (n_rows) *n_rows = hr.rows;
       if (n_windows) *n_windows = windows_total;
       if (TUNE_GET("CALITAS_TRACE"))
-        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: walked and handed over in %.1f ms (of that built in %.1f ms, waiting for the aligner thread %.1f ms), stages drained in %.1f ms (align %.1f ms, keys %.1f ms there), "
+        std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: walked and handed over in %.1f ms (waiting for the builder stage %.1f ms; there: built in %.1f ms, waiting for the aligner threads %.1f ms), stages drained in %.1f ms (align %.1f ms, keys %.1f ms there), "
                              "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits (%llu rows made, %.1f ms of them on demand), "
                              "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms, %.2f s of CPU time\n",
-                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_walk, ms_build, ms_wait, ms_drain, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, (unsigned long long)rows_made.load(), (double)ns_demand.load() / 1e6, ms_variant_half, hr.ms, ms_since(t_call), cpu_seconds() - cpu0);
+                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_walk, ms_wait_builder, ms_build, ms_wait, ms_drain, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, (unsigned long long)rows_made.load(), (double)ns_demand.load() / 1e6, ms_variant_half, hr.ms, ms_since(t_call), cpu_seconds() - cpu0);
       return CALITAS_OK;
     }
     calitas_free(hr.tsv);
