@@ -1553,6 +1553,11 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     if (sl.rc) { rc = sl.rc; break; }
     LaneText& lt = sl.lt;
     const int c = pass_contig[i];
+    const bool trace_contigs = TUNE_GET("CALITAS_TRACE") && std::atoi(TUNE_GET("CALITAS_TRACE")) >= 3;
+    const double ms_rows_at = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    struct Said { bool on; int c; double at; uint64_t bytes; std::chrono::steady_clock::time_point t0;
+                  ~Said() { if (on) std::fprintf(stderr, "[calitas] search_hits: contig %d: rows queued at %.1f ms, %llu bytes on the host at %.1f ms\n", c, at, (unsigned long long)bytes,
+                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } } said{trace_contigs, c, ms_rows_at, lt.bytes, t_call};
     ms_rows += sl.ms;
     bases_done += ref.contigs[c].len;
     if (lt.bytes) {

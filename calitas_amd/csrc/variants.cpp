@@ -197,10 +197,28 @@ bool parse_record(const char* b, const char* e, const char* chrom, size_t chrom_
 // records is 460 MB touched for the first time by ONE thread: 0.18 of the file's 0.3 s); at[i] finds record i.
 struct VarTable {
   std::vector<std::vector<Var>> parts;
-  std::vector<Var*> at;
-  size_t size() const { return at.size(); }
+  std::vector<Var*> at;                    // room for every line of the file; at[0, ready) are there
+  // The file is parsed in waves (read_vcf) while the caller already walks the records of the waves before: have(i) waits until record i
+  // is there or the file is done.  (Behind a pointer: the table itself moves -- into the call's garbage, at the end.)
+  struct Sync { std::mutex mu; std::condition_variable cv; std::atomic<size_t> ready{0}; std::atomic<bool> done{false}; };
+  std::unique_ptr<Sync> sync{new Sync()};
+  size_t seen = 0;                         // (the consumer's copy of ready: no atomic load per record)
+  size_t size() const { return sync->ready.load(std::memory_order_acquire); }
   Var& operator[](size_t i) { return *at[i]; }
   const Var& operator[](size_t i) const { return *at[i]; }
+  bool have(size_t i) {
+    if (i < seen) return true;
+    seen = sync->ready.load(std::memory_order_acquire);
+    if (i < seen) return true;
+    std::unique_lock<std::mutex> lk(sync->mu);
+    sync->cv.wait(lk, [&] { return i < sync->ready.load(std::memory_order_acquire) || sync->done.load(std::memory_order_acquire); });
+    seen = sync->ready.load(std::memory_order_acquire);
+    return i < seen;
+  }
+  void publish(size_t ready, bool done) {
+    { std::lock_guard<std::mutex> lk(sync->mu); sync->ready.store(ready, std::memory_order_release); if (done) sync->done.store(true, std::memory_order_release); }
+    sync->cv.notify_all();
+  }
 };
 
 std::string read_vcf(const char* path, const char* chrom, calitas::WorkerPool* pool, VarTable& out) {
@@ -240,41 +258,63 @@ std::string read_vcf(const char* path, const char* chrom, calitas::WorkerPool* p
   const auto t_parse = std::chrono::steady_clock::now();
   const char* const text = plain ? (const char*)map.p : data.data();
   const size_t n = plain ? map.n : data.size(), chrom_len = chrom ? std::strlen(chrom) : 0;
-  std::vector<std::vector<Var>> parts((size_t)pool->size());
-  pool->for_blocks(n, [&](size_t b, size_t e, int tid) {
-    const char* const base = text;
-    const char* const end = base + n;
-    const char* p = base + b;
-    if (b > 0) { const char* nl = (const char*)std::memchr(base + b - 1, '\n', n - (b - 1)); p = nl ? nl + 1 : end; }   // first line start >= b
-    std::vector<Var>& mine = parts[(size_t)tid];
-    // (a record is parsed where it stays: a Var built aside and moved in, into a vector that doubled its way up, was a third of the
-    // 0.11 s the records took -- room for a record per 24 bytes, which no line with an INFO column undercuts)
-    mine.reserve((e - b) / 24 + 16);
-    while (p < base + e) {
-      const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
-      const char* le = nl ? nl : end;
-      if (p < le && *p != '#') {
-        mine.emplace_back();
-        if (!parse_record(p, le, chrom, chrom_len, mine.back())) mine.pop_back();
+  const size_t T = (size_t)pool->size();
+  // room for a pointer per line, so that the table never moves while the caller reads it
+  {
+    std::vector<size_t> lines(T, 0);
+    pool->for_blocks(n, [&](size_t b, size_t e, int tid) {
+      size_t c = 0;
+      for (const char* p = text + b; p < text + e;) {
+        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(text + e - p));
+        if (!nl) break;
+        c++; p = nl + 1;
       }
-      p = le + 1;
-    }
-  });
-  const double ms_parse = ms_since(t_parse);
-  const auto t_join = std::chrono::steady_clock::now();
+      lines[(size_t)tid] += c;
+    });
+    size_t total_lines = 1;
+    for (size_t c : lines) total_lines += c;
+    out.at.assign(total_lines, nullptr);
+  }
+  // Waves of 16 MB (at least eight): every worker takes the lines that start in its share of the wave, the wave's records are listed
+  // in file order and published, and the caller walks them while the next wave is parsed (the walk used to start when the last of
+  // three million records was in: 0.06 s into the call at BASELINE config 5's size).
+  const size_t wave = std::max<size_t>(1u << 20, std::min<size_t>(16u << 20, (n + 7) / 8));
+  const size_t n_waves = n ? (n + wave - 1) / wave : 0;
+  out.parts.assign(n_waves * T, std::vector<Var>());
   size_t total = 0;
-  for (auto& v : parts) total += v.size();
-  std::vector<size_t> part_at(parts.size() + 1, 0);
-  for (size_t t = 0; t < parts.size(); t++) part_at[t + 1] = part_at[t] + parts[t].size();
-  out.parts = std::move(parts);
-  out.at.resize(total);
-  pool->run([&](int tid) {
-    std::vector<Var>& mine = out.parts[(size_t)tid];
-    Var** dst = out.at.data() + part_at[(size_t)tid];
-    for (size_t k = 0; k < mine.size(); k++) dst[k] = &mine[k];
-  });
+  for (size_t w = 0; w < n_waves; w++) {
+    const size_t w_lo = w * wave, w_hi = std::min(n, w_lo + wave);
+    pool->for_blocks(w_hi - w_lo, [&](size_t b0, size_t e0, int tid) {
+      const size_t b = w_lo + b0, e = w_lo + e0;
+      const char* const base = text;
+      const char* const end = base + n;
+      const char* p = base + b;
+      if (b > 0) { const char* nl = (const char*)std::memchr(base + b - 1, '\n', n - (b - 1)); p = nl ? nl + 1 : end; }   // first line start >= b
+      std::vector<Var>& mine = out.parts[w * T + (size_t)tid];
+      // (a record is parsed where it stays: a Var built aside and moved in, into a vector that doubled its way up, was a third of the
+      // 0.11 s the records took -- room for a record per 24 bytes, which no line with an INFO column undercuts)
+      mine.reserve((e - b) / 24 + 16);
+      while (p < base + e) {
+        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        if (p < le && *p != '#') {
+          mine.emplace_back();
+          if (!parse_record(p, le, chrom, chrom_len, mine.back())) mine.pop_back();
+        }
+        p = le + 1;
+      }
+    });
+    for (size_t t = 0; t < T; t++) {
+      std::vector<Var>& mine = out.parts[w * T + t];
+      if (total + mine.size() > out.at.size()) { out.publish(total, true); return "the VCF holds more records than lines (internal error)"; }
+      for (size_t k = 0; k < mine.size(); k++) out.at[total + k] = &mine[k];
+      total += mine.size();
+    }
+    out.publish(total, w + 1 == n_waves);
+  }
+  if (n_waves == 0) out.publish(0, true);
   if (TUNE_GET("CALITAS_TRACE") && total >= 100000)
-    std::fprintf(stderr, "[calitas] read_vcf: %zu bytes read in %.1f ms, %zu records parsed in %.1f ms, joined in %.1f ms\n", n, ms_read, total, ms_parse, ms_since(t_join));
+    std::fprintf(stderr, "[calitas] read_vcf: %zu bytes read in %.1f ms, %zu records parsed in %.1f ms (%zu waves)\n", n, ms_read, total, ms_since(t_parse), n_waves);
   return "";
 }
 
@@ -432,36 +472,50 @@ int ga_count(const char* pg, const char* pa, int len, bool lower, bool both_side
 }
 
 
-// MD5 (RFC 1321) of a file, hex: the second half of ReferenceHit's VCF identifier "name:md5" (RH:175-183).
+// MD5 (RFC 1321) of a file, hex: the second half of ReferenceHit's VCF identifier "name:md5" (RH:175-183).  One chain of dependent
+// additions and rotations from the first byte to the last: 0.21 s per 127 MB as a loop over a step table, 0.14 s with the 64 steps
+// written out (constants and rotations as immediates, the selection functions in their three-operation forms) -- and the first row that
+// names a variant cannot be final before it is done, so at BASELINE config 5's size this is what the first contig's text waits for.
+#define CALITAS_MD5_ROL(x, s) (((x) << (s)) | ((x) >> (32 - (s))))
+#define CALITAS_MD5_F1(b, c, d) ((d) ^ ((b) & ((c) ^ (d))))
+#define CALITAS_MD5_F2(b, c, d) ((c) ^ ((d) & ((b) ^ (c))))
+#define CALITAS_MD5_F3(b, c, d) ((b) ^ (c) ^ (d))
+#define CALITAS_MD5_F4(b, c, d) ((c) ^ ((b) | ~(d)))
+#define CALITAS_MD5_STEP(f, a, b, c, d, g, k, s) a += f(b, c, d) + m[g] + (k); a = b + CALITAS_MD5_ROL(a, s);
+static void md5_block(uint32_t* h, const unsigned char* p) {
+  uint32_t m[16];
+  std::memcpy(m, p, 64);                              // (little-endian words, as on every machine this library is built for)
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+#define S1(a, b, c, d, g, k, s) CALITAS_MD5_STEP(CALITAS_MD5_F1, a, b, c, d, g, k, s)
+#define S2(a, b, c, d, g, k, s) CALITAS_MD5_STEP(CALITAS_MD5_F2, a, b, c, d, g, k, s)
+#define S3(a, b, c, d, g, k, s) CALITAS_MD5_STEP(CALITAS_MD5_F3, a, b, c, d, g, k, s)
+#define S4(a, b, c, d, g, k, s) CALITAS_MD5_STEP(CALITAS_MD5_F4, a, b, c, d, g, k, s)
+  S1(a,b,c,d,0,0xd76aa478u,7) S1(d,a,b,c,1,0xe8c7b756u,12) S1(c,d,a,b,2,0x242070dbu,17) S1(b,c,d,a,3,0xc1bdceeeu,22)
+  S1(a,b,c,d,4,0xf57c0fafu,7) S1(d,a,b,c,5,0x4787c62au,12) S1(c,d,a,b,6,0xa8304613u,17) S1(b,c,d,a,7,0xfd469501u,22)
+  S1(a,b,c,d,8,0x698098d8u,7) S1(d,a,b,c,9,0x8b44f7afu,12) S1(c,d,a,b,10,0xffff5bb1u,17) S1(b,c,d,a,11,0x895cd7beu,22)
+  S1(a,b,c,d,12,0x6b901122u,7) S1(d,a,b,c,13,0xfd987193u,12) S1(c,d,a,b,14,0xa679438eu,17) S1(b,c,d,a,15,0x49b40821u,22)
+  S2(a,b,c,d,1,0xf61e2562u,5) S2(d,a,b,c,6,0xc040b340u,9) S2(c,d,a,b,11,0x265e5a51u,14) S2(b,c,d,a,0,0xe9b6c7aau,20)
+  S2(a,b,c,d,5,0xd62f105du,5) S2(d,a,b,c,10,0x02441453u,9) S2(c,d,a,b,15,0xd8a1e681u,14) S2(b,c,d,a,4,0xe7d3fbc8u,20)
+  S2(a,b,c,d,9,0x21e1cde6u,5) S2(d,a,b,c,14,0xc33707d6u,9) S2(c,d,a,b,3,0xf4d50d87u,14) S2(b,c,d,a,8,0x455a14edu,20)
+  S2(a,b,c,d,13,0xa9e3e905u,5) S2(d,a,b,c,2,0xfcefa3f8u,9) S2(c,d,a,b,7,0x676f02d9u,14) S2(b,c,d,a,12,0x8d2a4c8au,20)
+  S3(a,b,c,d,5,0xfffa3942u,4) S3(d,a,b,c,8,0x8771f681u,11) S3(c,d,a,b,11,0x6d9d6122u,16) S3(b,c,d,a,14,0xfde5380cu,23)
+  S3(a,b,c,d,1,0xa4beea44u,4) S3(d,a,b,c,4,0x4bdecfa9u,11) S3(c,d,a,b,7,0xf6bb4b60u,16) S3(b,c,d,a,10,0xbebfbc70u,23)
+  S3(a,b,c,d,13,0x289b7ec6u,4) S3(d,a,b,c,0,0xeaa127fau,11) S3(c,d,a,b,3,0xd4ef3085u,16) S3(b,c,d,a,6,0x04881d05u,23)
+  S3(a,b,c,d,9,0xd9d4d039u,4) S3(d,a,b,c,12,0xe6db99e5u,11) S3(c,d,a,b,15,0x1fa27cf8u,16) S3(b,c,d,a,2,0xc4ac5665u,23)
+  S4(a,b,c,d,0,0xf4292244u,6) S4(d,a,b,c,7,0x432aff97u,10) S4(c,d,a,b,14,0xab9423a7u,15) S4(b,c,d,a,5,0xfc93a039u,21)
+  S4(a,b,c,d,12,0x655b59c3u,6) S4(d,a,b,c,3,0x8f0ccc92u,10) S4(c,d,a,b,10,0xffeff47du,15) S4(b,c,d,a,1,0x85845dd1u,21)
+  S4(a,b,c,d,8,0x6fa87e4fu,6) S4(d,a,b,c,15,0xfe2ce6e0u,10) S4(c,d,a,b,6,0xa3014314u,15) S4(b,c,d,a,13,0x4e0811a1u,21)
+  S4(a,b,c,d,4,0xf7537e82u,6) S4(d,a,b,c,11,0xbd3af235u,10) S4(c,d,a,b,2,0x2ad7d2bbu,15) S4(b,c,d,a,9,0xeb86d391u,21)
+#undef S1
+#undef S2
+#undef S3
+#undef S4
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+}
 std::string md5_file(const char* path, std::string& hex) {
-  static const uint32_t K[64] = {
-    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
-    0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
-    0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
-    0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
-    0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
-    0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
-  static const int R[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
-                            4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
   FILE* f = std::fopen(path, "rb");
   if (!f) return std::string("cannot read ") + path;
   uint32_t h[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
-  auto block = [&](const unsigned char* p) {
-    uint32_t m[16];
-    for (int i = 0; i < 16; i++) m[i] = (uint32_t)p[4 * i] | (uint32_t)p[4 * i + 1] << 8 | (uint32_t)p[4 * i + 2] << 16 | (uint32_t)p[4 * i + 3] << 24;
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
-    for (int i = 0; i < 64; i++) {
-      uint32_t fn; int g;
-      if (i < 16) { fn = (b & c) | (~b & d); g = i; }
-      else if (i < 32) { fn = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
-      else if (i < 48) { fn = b ^ c ^ d; g = (3 * i + 5) & 15; }
-      else { fn = c ^ (b | ~d); g = (7 * i) & 15; }
-      const uint32_t t = a + fn + K[i] + m[g];
-      a = d; d = c; c = b;
-      b = b + ((t << R[i]) | (t >> (32 - R[i])));
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
-  };
   std::vector<unsigned char> buf(1 << 20);
   uint64_t total = 0;
   size_t have = 0;                                   // bytes of an incomplete block at the start of buf
@@ -470,7 +524,7 @@ std::string md5_file(const char* path, std::string& hex) {
     total += got;
     const size_t n = have + got;
     size_t off = 0;
-    for (; off + 64 <= n; off += 64) block(buf.data() + off);
+    for (; off + 64 <= n; off += 64) md5_block(h, buf.data() + off);
     have = n - off;
     std::memmove(buf.data(), buf.data() + off, have);
     if (got == 0) break;
@@ -482,7 +536,7 @@ std::string md5_file(const char* path, std::string& hex) {
   const size_t tl = have < 56 ? 64 : 128;
   const uint64_t bits = total * 8;
   for (int i = 0; i < 8; i++) tail[tl - 8 + i] = (unsigned char)(bits >> (8 * i));
-  for (size_t off = 0; off < tl; off += 64) block(tail + off);
+  for (size_t off = 0; off < tl; off += 64) md5_block(h, tail + off);
   char out[33];
   for (int i = 0; i < 16; i++) std::snprintf(out + 2 * i, 3, "%02x", (h[i / 4] >> (8 * (i % 4))) & 0xFFu);
   hex = out;
@@ -621,6 +675,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     return (double)u.ru_utime.tv_sec + (double)u.ru_stime.tv_sec + 1e-6 * ((double)u.ru_utime.tv_usec + (double)u.ru_stime.tv_usec);
   };
   const double cpu0 = cpu_seconds();
+  const bool trace_stages = TUNE_GET("CALITAS_TRACE") && std::atoi(TUNE_GET("CALITAS_TRACE")) >= 3;   // (every batch's way through the stages)
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   std::atomic<int> batch_serial{0};                               // (batches through align_part, for CALITAS_FAIL_ALIGN_BATCH)
   std::atomic<long long> ns_align{0};                             // (two aligner threads add to it)
@@ -813,6 +868,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     int r = calitas_align_windows(actx, (int32_t)n, guides.data(), targets.data(), lens.data(), offs.data(), &ap, &res.out, &res.n_out, &res.counts);
     if (r) { if (actx != ctx) calitas_fail(ctx, r, calitas_last_error(actx)); return r; }
     ns_align += (long long)(ms_since(t0) * 1e6);
+    if (trace_stages) std::fprintf(stderr, "[calitas] search_variants: a batch (contig %d ..) aligned %.1f .. %.1f ms\n", batch.wins[0].contig, ms_since(t_call) - ms_since(t0), ms_since(t_call));
     return CALITAS_OK;
   };
   auto lift_part = [&](Batch& batch, const size_t n, const Aligned& res, std::string& err) -> int {
@@ -849,6 +905,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     for (auto& e : errs) if (!e.empty() && err.empty()) err = e;
     calitas_free(counts);
     ms_rows += ms_since(t1);
+    if (trace_stages) std::fprintf(stderr, "[calitas] search_variants: a batch (contig %d ..) lifted %.1f .. %.1f ms\n", wins[0].contig, ms_since(t_call) - ms_since(t1), ms_since(t_call));
     return CALITAS_OK;
   };
   auto align_stage = [&](Batch& batch, const size_t n, std::string& err) -> int {
@@ -893,6 +950,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     });
     for (auto& e : errs) if (!e.empty() && e_out.empty()) e_out = e;
     ms_build += ms_since(t_build);
+    if (trace_stages) std::fprintf(stderr, "[calitas] search_variants: a batch of %zu windows (contig %d ..) built %.1f .. %.1f ms\n", n, sp.contig[0], ms_since(t_call) - ms_since(t_build), ms_since(t_call));
     if (!e_out.empty()) return CALITAS_EINVAL;
     if (hand_over) return hand_over(std::move(b), n);
     return align_stage(b, n, e_out);
@@ -950,9 +1008,11 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   bool give_up = false;
   struct HelperResult { int rc = CALITAS_OK; bool declined = false; char* tsv = nullptr; uint64_t bytes = 0, rows = 0; double ms = 0; } hr;
   std::thread helper;
+  const bool trace_contigs = trace_stages;
   auto publish = [&](size_t upto, bool quit) {
     { std::lock_guard<std::mutex> lk(pub_mu); published = std::max(published, upto); give_up = give_up || quit; }
     pub_cv.notify_all();
+    if (trace_contigs) std::fprintf(stderr, "[calitas] search_variants: contigs before %zu published at %.1f ms\n", upto, ms_since(t_call));
   };
   HitsExtSource source;
   // Compact rows on the per-contig stream of this call: OFF unless asked for.  Measured at BASELINE config 5's size (round 5): the texts'
@@ -1106,6 +1166,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     x.n_plain = n_plain;
     x.row_len.assign(n, 0);
     ms_groups += ms_since(t0);
+    if (trace_stages) std::fprintf(stderr, "[calitas] search_variants: contig %zu: groups and keys %.1f .. %.1f ms\n", c, ms_since(t_call) - ms_since(t0), ms_since(t_call));
     return CALITAS_OK;
   };
   // ... and the rows (the finisher stage, behind the lifter: the lifter carried keys, groups and rows one after the other, 0.43-0.47 s
@@ -1251,19 +1312,17 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   finish_upto_fn = finish_upto;
 
   // The VCF, beside the first of the reference passes (they need nothing of it before their first row stage: 0.15 s at BASELINE config
-  // 5's size that the helper thread used to sit out).
-  {
+  // 5's size that the helper thread used to sit out) -- and beside the walk below: a thread of its own parses the file wave by wave,
+  // the walk follows it record by record (VarTable::have).
+  std::string vcf_err;
+  std::thread vcf_reader([&] {
     const auto t0 = std::chrono::steady_clock::now();
-    std::string e = read_vcf(vcf_path, chrom, ctx->pool, vcf);
+    try { vcf_err = read_vcf(vcf_path, chrom, ctx->pool, vcf); }
+    catch (const std::exception& x) { vcf_err = std::string("reading the VCF ended with an exception: ") + x.what(); }
     ms_parse = ms_since(t0);
-    if (!e.empty()) {
-      publish(nc, true);
-      if (helper.joinable()) helper.join();
-      calitas_free(hr.tsv);
-      calitas_free(ref_alns);
-      return calitas_fail(ctx, CALITAS_EIO, e);
-    }
-  }
+    vcf.publish(vcf.size(), true);                                  // (whatever happened: the walk must not wait for more)
+  });
+  struct JoinReader { std::thread& t; ~JoinReader() { if (t.joinable()) t.join(); } } join_reader{vcf_reader};
   const int max_variants = p.max_variants;
   size_t ci = 0, i = 0;
   const auto t_walk = std::chrono::steady_clock::now();
@@ -1272,11 +1331,11 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   std::vector<const Var*> chunk, sub;
   size_t ci_of_contig = (size_t)-1;
   int contig = -1;
-  while (i < vcf.size() && err.empty() && rc == CALITAS_OK) {
+  while (vcf.have(i) && err.empty() && rc == CALITAS_OK) {
     chunk.assign(1, &vcf[i]);
     const Var* last = &vcf[i];
     i++;
-    while (i < vcf.size() && vcf[i].chrom == last->chrom && vcf[i].pos <= last->end + padding) { last = &vcf[i]; chunk.push_back(last); i++; }
+    while (vcf.have(i) && vcf[i].chrom == last->chrom && vcf[i].pos <= last->end + padding) { last = &vcf[i]; chunk.push_back(last); i++; }
     while (ci < order.size() && order[ci] != chunk[0]->chrom) ci++;
     if (ci >= order.size()) { err = "next on empty iterator (VCF contig " + chunk[0]->chrom + " not in reference order)"; break; }
     if (ci != ci_of_contig) {
@@ -1306,6 +1365,8 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       }
     }
   }
+  vcf_reader.join();
+  if (!vcf_err.empty() && err.empty()) { err = vcf_err; if (rc == CALITAS_OK) rc = CALITAS_EIO; }
   if (rc == CALITAS_OK && err.empty()) rc = finish_contigs(nc);
   const double ms_walk = ms_since(t_walk);                         // (this thread from the first variant to the last window handed over)
   const auto t_drain = std::chrono::steady_clock::now();
