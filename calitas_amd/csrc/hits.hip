@@ -208,6 +208,15 @@ __global__ void ext_keep_kernel(const uint32_t* order, const uint8_t* keep, uint
   if (v >= n_dev) out[v - n_dev] = keep[k];
 }
 
+// HitsExtRows::fill_on_host: where the row of every kept entry of the caller's belongs in the text (the rows kernel leaves the hole).
+__global__ void ext_place_kernel(const uint32_t* order, const uint32_t* midlen, const uint64_t* offs, uint32_t n, uint32_t n_dev, uint64_t* place) {
+  CALITAS_TAIL_PRIO();
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t v = order[k];
+  if (v >= n_dev) place[v - n_dev] = midlen[k] == 0xFFFFFFFFu ? offs[k] : ~0ull;
+}
+
 // Rows in two kernels (round 4; round 2 built every middle part into a staging buffer -- mid_kernel -- and assembled the rows from it
 // once their offsets were known -- out_kernel: 350 bytes per row written and read again, 20 GB of staging for the 4.1e7 rows of a PAM-less
 // whole-genome search):
@@ -290,6 +299,7 @@ __global__ __launch_bounds__(256) void rows_kernel(MidArgs a, OutArgs o, char* t
     char* dst = text + uniform_ptr(o.offs)[k];
     if (want == 0xFFFFFFFFu) {
       const uint32_t e = v - a.n_dev;
+      if (!o.ext_rows) continue;                          // (fill_on_host: a hole, the caller has the row)
       const uint64_t b0 = uniform_ptr(a.ext_off)[e], nb = uniform_ptr(a.ext_off)[e + 1] - b0;
       for (uint64_t b = (uint64_t)lane; b < nb; b += 64) dst[b] = o.ext_rows[b0 + b];
       continue;
@@ -375,8 +385,9 @@ void hits_destroy(HitsWork* w) {
   (void)hipFree(w->vals); (void)hipFree(w->vals2); (void)hipFree(w->s_cs); (void)hipFree(w->wks); (void)hipFree(w->s_start); (void)hipFree(w->s_end);
   (void)hipFree(w->s_score); (void)hipFree(w->keep); (void)hipFree(w->head); (void)hipFree(w->temp); (void)hipFree(w->text);
   (void)hipFree(w->midlen); (void)hipFree(w->blob); (void)hipFree(w->names); (void)hipFree(w->name_off);
-  (void)hipFree(w->d_counts); (void)hipFree(w->ext_keys); (void)hipFree(w->ext_off); (void)hipFree(w->ext_rows); (void)hipFree(w->ext_keep);
+  (void)hipFree(w->d_counts); (void)hipFree(w->ext_keys); (void)hipFree(w->ext_off); (void)hipFree(w->ext_rows); (void)hipFree(w->ext_keep); (void)hipFree(w->ext_place);
   if (w->h_ext_keep) (void)hipHostFree(w->h_ext_keep);
+  if (w->h_ext_place) (void)hipHostFree(w->h_ext_place);
   if (w->h_counts) (void)hipHostFree(w->h_counts);
   mailbox_close(w->mbox);
   delete w;
@@ -469,6 +480,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   }
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
   size_t ts;
+  bool ext_on_host = false;                            // HitsExtRows::fill_on_host
   const bool on_demand = n_ext && ext->rows_for;       // the rows of the caller's hits once the walks have decided (hits.hpp)
   if (on_demand && own) return hipErrorInvalidValue;
   // the rows of the caller's hits (offsets, text) to the device: before anything runs when they came with the call, behind the walks on demand
@@ -478,6 +490,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
     TRY(grow(&w.ext_off, w.ext_off_cap, (size_t)n_ext + 1));
     TRY(grow(&w.ext_rows, w.ext_rows_cap, std::max<size_t>(1, row_bytes)));
     TRY(hipMemcpyAsync(w.ext_off, r.row_off, ((size_t)n_ext + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (r.fill_on_host) { ext_on_host = true; return hipSuccess; }
     if (row_bytes && r.rows) TRY(hipMemcpyAsync(w.ext_rows, r.rows, row_bytes, hipMemcpyHostToDevice, stream));
     else if (row_bytes) {
       if (!r.n_seg || !r.seg || !r.seg_off || r.seg_off[0] != 0 || r.seg_off[r.n_seg] != row_bytes) return hipErrorInvalidValue;
@@ -572,7 +585,20 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
   // it): the host's look at the counts -- a round trip of 20-30 us -- is then off the lane's critical path, as in the binned tail.  A
   // text that does not fit makes the kernel return untouched; the buffer grows and the kernel runs again.
   OutArgs oa{};
-  oa.names = w.names; oa.offs = w.offs; oa.midlen = w.midlen; oa.ext_rows = w.ext_rows; oa.late = w.mbox.dev + HITS_BOX_LATE;
+  oa.names = w.names; oa.offs = w.offs; oa.midlen = w.midlen; oa.ext_rows = ext_on_host ? nullptr : w.ext_rows; oa.late = w.mbox.dev + HITS_BOX_LATE;
+  if (ext_on_host) {
+    TRY(grow(&w.ext_place, w.ext_place_cap, (size_t)n_ext));
+    if ((size_t)n_ext > w.h_ext_place_cap) {
+      if (w.h_ext_place) (void)hipHostFree(w.h_ext_place);
+      w.h_ext_place = nullptr; w.h_ext_place_cap = 0;
+      const size_t cap = (size_t)n_ext + (size_t)n_ext / 4 + 4096;
+      TRY(hipHostMalloc((void**)&w.h_ext_place, cap * sizeof(uint64_t), hipHostMallocDefault));
+      w.h_ext_place_cap = cap;
+    }
+    hipLaunchKernelGGL(ext_place_kernel, grid, block, 0, stream, (const uint32_t*)w.vals2, (const uint32_t*)w.midlen, (const uint64_t*)w.offs, n_in, n_dev, w.ext_place);
+    TRY(hipGetLastError());
+    TRY(hipMemcpyAsync(w.h_ext_place, w.ext_place, (size_t)n_ext * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  }
   oa.counts = w.d_counts;
   const unsigned rows_per_block = 4 * ROWS_PER_WAVE;
   const dim3 rows_grid((n_in + rows_per_block - 1) / rows_per_block);
@@ -595,6 +621,7 @@ hipError_t hits_run(HitsWork** pw, const HitsRef& ref, const RawAln* d_final, ui
     TRY(hipGetLastError());
   }
   res->d_text = w.text;
+  res->ext_place = ext_on_host ? w.h_ext_place : nullptr;
   return hipSuccess;
 }
 

@@ -30,6 +30,10 @@ struct HitsResult {
   uint32_t n_rows;
   uint64_t text_bytes;   // bytes of row text at d_text
   const char* d_text;
+  // HitsExtRows::fill_on_host: per entry of the HitsExt, the offset of its row's hole in the text, ~0 for an entry that was not kept.
+  // Page-locked host memory of the work's; filled by a copy queued on the stream behind the kernels (valid once the stream has passed
+  // it -- the caller waits for the text anyway) and until the next hits_run on this work.
+  const uint64_t* ext_place;
 };
 
 constexpr uint32_t HITS_FLAG_SCORE_RANGE = 1;   // a score fell outside the sort key's range
@@ -69,6 +73,11 @@ struct HitsExtRows {                   // what rows_for hands back: the fields o
   uint32_t n_seg = 0;
   const char* const* seg = nullptr;
   const uint64_t* seg_off = nullptr;
+  // The rows stay on the host: only row_off is looked at, the rows kernel leaves a hole of the row's length for every kept entry and
+  // HitsResult::ext_place says where; the caller writes the rows into the text once it is on the host.  (Round 5: the rows of a variant
+  // search's entries carry the VCF's MD5, which takes 0.14 s per 127 MB to compute -- with the rows on the host the first contigs' texts
+  // cross the bus meanwhile; and 0.5 GB of rows per call go neither up to the device nor through its rows kernel.)
+  bool fill_on_host = false;
 };
 struct HitsExt {
   int32_t contig = 0;
@@ -88,6 +97,11 @@ struct HitsExt {
   // offsets (an entry that was not kept has length 0) and the text from `rows` -- memory of the caller's that stays valid until
   // hits_run returns.  != 0: the caller gave up, hits_run returns hipErrorUnknown.  One more host round trip per call of hits_run.
   std::function<int(const uint8_t* kept, HitsExtRows* rows)> rows_for;
+  // HitsExtRows::fill_on_host: called by whoever brought the text to the host (search.cpp, the per-contig passes) with
+  // HitsResult::ext_place and the text's address: the rows of the kept entries go to text + place[e].  stays: the text is where it will
+  // be when the call returns (a buffer of the caller's), so the callee may do the work later, on a thread of its own that it joins
+  // before its call ends (place[] is only valid during fill); otherwise the rows must be in the text when fill returns.
+  std::function<int(const uint64_t* place, char* text, bool stays)> fill;
 };
 
 // The alignments given to hits_run are those of a window range of a larger job (a process's stretch of a multi-GPU partition plus the

@@ -388,6 +388,8 @@ struct HitsWork {
   char* ext_rows = nullptr; size_t ext_rows_cap = 0;
   uint8_t* ext_keep = nullptr; size_t ext_keep_cap = 0;      // HitsExt::rows_for: the walks' verdict per entry, and its page-locked copy
   uint8_t* h_ext_keep = nullptr; size_t h_ext_keep_cap = 0;
+  uint64_t* ext_place = nullptr; size_t ext_place_cap = 0;   // HitsExtRows::fill_on_host: where every kept entry's row belongs in the text
+  uint64_t* h_ext_place = nullptr; size_t h_ext_place_cap = 0;
   uint64_t* d_counts = nullptr;   // [0] text bytes, [1] low word: kept rows, high word: kept hits of the caller's own, [2] low word: flags
   uint64_t* h_counts = nullptr;   // pinned
   Mailbox mbox;                   // carries d_counts to the host (mailbox.hpp)

@@ -836,6 +836,8 @@ struct LaneText {
   bool in_place = false;               // the rows kernel wrote the text to its final place in the caller's page-locked buffer (LaneDest)
   std::string host_rows;
   const HitsWork* rows_by = nullptr;   // the general row stage that wrote d_text (its late flags are looked at once the text has been copied)
+  const HitsExt* ext = nullptr;        // the caller's hits whose rows the caller writes into the text itself (HitsExtRows::fill_on_host) ...
+  const uint64_t* ext_place = nullptr; // ... and where (HitsResult::ext_place)
   calitas_timing_t tm{};
 };
 
@@ -1094,6 +1096,7 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
       kernel_times(lane, lt.tm);          // while out_kernel runs
       if (res.flags == 0) {
         lt.d_text = res.d_text; lt.bytes = res.text_bytes; lt.rows = res.n_rows; lt.rows_by = lane->hits;
+        if (res.ext_place) { lt.ext = ext; lt.ext_place = res.ext_place; }
         if (own_general) lt.tm.owned_general_lanes = 1;
         return CALITAS_OK;
       }
@@ -1670,6 +1673,10 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
         }
         if (rc) break;
         if ((rc = rows_late_check(ctx, lt)) != CALITAS_OK) break;
+      }
+      if (lt.ext_place) {                                 // the caller's own rows into the holes the rows kernel left for them
+        if (sink || !lt.ext || !lt.ext->fill) { rc = fail(ctx, CALITAS_EINVAL, "rows left to the caller, but nowhere to write them (internal error)"); break; }
+        if (lt.ext->fill(lt.ext_place, text + total, user_dst != nullptr) != 0) { rc = fail(ctx, CALITAS_EINVAL, "the caller's rows could not be written into the text"); break; }
       }
       total += (size_t)lt.bytes;
     }

@@ -27,7 +27,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_VARIANTS_HOST", "1", "F: variant branch: merge alignment records on the host (round 3) instead of bringing the variant windows' hits into the device's row stage"},
   {"CALITAS_FAIL_ALIGN_BATCH", "k", "F: variant branch: the k-th batch of variant windows (0-based) fails in the aligner stage (tests of the stages' error path)"},
   {"CALITAS_VARIANTS_COMPACT", "1", "T: variant branch: the per-contig texts of the reference passes cross PCIe as compact rows (default off: the branch is bound by its host threads)"},
-  {"CALITAS_VARIANTS_ROWS", "all", "F: calitas_search_variants makes the row of every hit of a variant window up front instead of the kept ones' on demand"},
+  {"CALITAS_VARIANTS_ROWS", "all | device", "F: calitas_search_variants makes the row of every hit of a variant window up front instead of the kept ones' on demand / sends the kept rows to the device instead of writing them into the text on the host"},
   {"CALITAS_SEQUENTIAL", "1", "F: calitas_search_hits as one pass per contig whatever the size"},
   {"CALITAS_SDMA", "0", "F: text copies with hipMemcpyAsync instead of the SDMA engine (dma.cpp)"},
   {"CALITAS_BINNED", "1 | 0 | last | from1", "T/F: the per-bin tail for every range / none / the last range only (default: calls of one or two ranges, the last range of three, every window range)"},

@@ -661,7 +661,10 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       vid = std::string(slash ? slash + 1 : vcf_path) + ":" + hex;
     });
   struct JoinMd5 { std::thread& t; ~JoinMd5() { if (t.joinable()) t.join(); } } join_md5{md5_thread};
-  auto need_vid = [&]() -> bool { if (md5_thread.joinable()) md5_thread.join(); return md5_err.empty(); };
+  std::mutex vid_mu;                                               // (several stages may ask; one of them joins the thread)
+  auto need_vid = [&]() -> bool { std::lock_guard<std::mutex> lk(vid_mu); if (md5_thread.joinable()) md5_thread.join(); return md5_err.empty(); };
+  // what a row holds in the identifier's place until the MD5 is known: as long as the identifier will be (name : 32 hex digits)
+  const std::string vid_placeholder = vcf_id ? std::string(vcf_id) : [&] { const char* slash = std::strrchr(vcf_path, '/'); return std::string(slash ? slash + 1 : vcf_path) + ":" + std::string(32, '0'); }();
   std::string version, stamp;
   calitas_default_version_and_stamp(aligner_version, time_stamp, version, stamp);
   const int d = p.max_guide_diffs, g = p.max_gaps_between_guide_and_pam;
@@ -740,7 +743,11 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   const std::string build_with_variants = ref.genome_build + "+variants";
   // compact: without guide_id and protospacer and with "\n" for a tail (post.hpp, compact_row_strings_keep_build) -- what the device's
   // row stage is given when the per-contig texts cross PCIe compact; genome_build stays: a row with a variant has "<build>+variants"
-  auto make_row = [&](const ExtHit& h, std::string& row, bool compact = false) {
+  // vid_use / vid_at: the identifier's text to put into the row (null: the real one -- the caller has waited for it) and where, counted
+  // from the row's first byte, it went (0: the row names no variant) -- for rows that are made before the VCF's MD5 is known.
+  auto make_row = [&](const ExtHit& h, std::string& row, bool compact = false, const std::string* vid_use = nullptr, uint32_t* vid_at = nullptr) {
+        const std::string& vid_text = vid_use ? *vid_use : vid;
+        if (vid_at) *vid_at = 0;
         const Window& w = *h.w;
         const calitas_aln_t& a = *h.a;
         const int wl = w.len;
@@ -832,7 +839,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
         const std::string& build = vs.empty() ? ref.genome_build : build_with_variants;
         const std::string& pam_used = rs.pam_used[a.pam_index + 1];
         const size_t room = gid.size() + gh.protospacer.size() + build.size() + ref.names[w.contig].size() + n_unpadded + c5_10.size() + c3_10.size() +
-                            pam_used.size() + ids.size() + descs.size() + vid.size() + af.size() + 3 * (size_t)n_ops + c5_8.size() + c3_8.size() + n_cigar +
+                            pam_used.size() + ids.size() + descs.size() + vid_text.size() + af.size() + 3 * (size_t)n_ops + c5_8.size() + c3_8.size() + n_cigar +
                             rs.proto_len.size() + rs.tail.size() + 9 * 24 + 40;
         row.resize(row_at + room);
         char* wp = &row[row_at];
@@ -842,7 +849,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
         if (!compact) { add(gid); add(gh.protospacer); }
         add(build); add(ref.names[w.contig]);
         add_int(gstart); add_int(gend); *wp++ = (char)a.strand; *wp++ = '\t'; add_mem(unpadded_target, n_unpadded);
-        add(c5_10); add(c3_10); add(pam_used); add(ids); add(descs); if (vs.empty()) *wp++ = '\t'; else add(vid); add(af);
+        add(c5_10); add(c3_10); add(pam_used); add(ids); add(descs); if (vs.empty()) *wp++ = '\t'; else { if (vid_at) *vid_at = (uint32_t)(wp - &row[row_at]); add(vid_text); } add(af);
         add_int(a.score); add_int(gmm); add_int(ggp); add_int(gmm + ggp);
         add_int(ga_count(pg, pa, n_ops, true, true, true, false)); add_int(mm + gp);
         add_mem(pg, (size_t)n_ops); add_mem(pa, (size_t)n_ops); add_mem(pt, (size_t)n_ops);
@@ -997,6 +1004,8 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     std::vector<const char*> seg_ptr; std::vector<uint64_t> seg_off;
     std::vector<const ExtHit*> entry;                              // the entries in tie order: the plain ones, then the placed ones
     std::vector<uint32_t> row_len;
+    std::vector<uint32_t> vid_off;                                 // rows filled in on the host: where a row holds the VCF's identifier (0: nowhere)
+    std::vector<const char*> row_ptr;                              // ... and where the row stands in its buffer
     size_t n_plain = 0;
     std::vector<std::string> segs_placed;                          // the placed entries' rows (segs: the plain entries')
     HitsExt ext;
@@ -1007,6 +1016,12 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   size_t published = 0;                                                                            // contigs [0, published) have their entries
   bool give_up = false;
   struct HelperResult { int rc = CALITAS_OK; bool declined = false; char* tsv = nullptr; uint64_t bytes = 0, rows = 0; double ms = 0; } hr;
+  // Rows written into the text on the host (hits.hpp, HitsExtRows::fill_on_host): when the text goes to a buffer of the caller's the
+  // copying thread of the reference passes only hands the job over -- this stage waits for the VCF's MD5 once and fills the holes.
+  // (Declared before the helper thread, whose calls hand it work: it outlives it.)
+  StageThread filler;
+  std::atomic<long long> ns_fill{0};
+  std::atomic<uint64_t> rows_filled{0};
   std::thread helper;
   const bool trace_contigs = trace_stages;
   auto publish = [&](size_t upto, bool quit) {
@@ -1025,6 +1040,12 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   // device.  CALITAS_VARIANTS_ROWS=all: every entry's row up front, as before (the two give the same bytes: tests/test_gpu_variants.py).
   bool rows_on_demand = device_merge;
   if (const char* e = TUNE_GET("CALITAS_VARIANTS_ROWS")) rows_on_demand = rows_on_demand && std::strcmp(e, "all") != 0;
+  // ... and the rows of the entries the device keeps never go to the device: the rows kernel leaves holes, the host fills them once the
+  // text is there (HitsExtRows::fill_on_host).  CALITAS_VARIANTS_ROWS=device: the kept rows go up and the rows kernel copies them, as in
+  // the first half of round 5; compact rows (CALITAS_VARIANTS_COMPACT) imply it -- a hole's place is known in the text the device wrote.
+  bool fill_on_host = rows_on_demand && !source.compact_rows;
+  if (const char* e = TUNE_GET("CALITAS_VARIANTS_ROWS")) fill_on_host = fill_on_host && std::strcmp(e, "device") != 0;
+  if (fill_on_host) filler.start(-1);
   struct JoinHelper {                                                                               // (declared behind everything the helper thread uses)
     std::thread& t; decltype(publish)& pub; size_t all;
     ~JoinHelper() { if (t.joinable()) { pub(all, true); t.join(); } }
@@ -1075,11 +1096,16 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
         for (size_t i = b; i < e; i++) {
           if (kept && !kept[i]) continue;
           const size_t at = buf.size();
-          make_row(*x.entry[i], buf, source.compact_rows);       // (appends)
+          if (fill_on_host) make_row(*x.entry[i], buf, source.compact_rows, &vid_placeholder, &x.vid_off[i]);   // (appends; the MD5 may not be there yet)
+          else make_row(*x.entry[i], buf, source.compact_rows);
           buf += '\n';
           x.row_len[i] = (uint32_t)(buf.size() - at);
         }
         rows_made.fetch_add(wanted, std::memory_order_relaxed);
+        if (fill_on_host) {                                      // (the buffer is complete: where each of its rows stands)
+          size_t acc = 0;
+          for (size_t i = b; i < e; i++) if (x.row_len[i] && (!kept || kept[i])) { x.row_ptr[i] = buf.data() + acc; acc += x.row_len[i]; }
+        }
       }
     });
   };
@@ -1091,6 +1117,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     x.row_off.resize(n + 1);
     x.row_off[0] = 0;
     for (size_t i = 0; i < n; i++) x.row_off[i + 1] = x.row_off[i] + x.row_len[i];
+    if (fill_on_host) { *out = HitsExtRows(); out->row_off = x.row_off.data(); out->fill_on_host = true; return CALITAS_OK; }
     x.seg_ptr.clear(); x.seg_off.assign(1, 0);
     for (std::vector<std::string>* group : {&x.segs, &x.segs_placed})
       for (const std::string& sg : *group) {
@@ -1165,6 +1192,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     x.ext.contig = (int32_t)c; x.ext.n = (uint32_t)n; x.ext.keys = x.keys.data();
     x.n_plain = n_plain;
     x.row_len.assign(n, 0);
+    if (fill_on_host) { x.vid_off.assign(n, 0); x.row_ptr.assign(n, nullptr); }
     ms_groups += ms_since(t0);
     if (trace_stages) std::fprintf(stderr, "[calitas] search_variants: contig %zu: groups and keys %.1f .. %.1f ms\n", c, ms_since(t_call) - ms_since(t0), ms_since(t_call));
     return CALITAS_OK;
@@ -1179,8 +1207,39 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     const size_t n = x.entry.size(), n_plain = x.n_plain;
     if (n == 0) return CALITAS_OK;
     const auto t1 = std::chrono::steady_clock::now();
-    if (!need_vid()) return calitas_fail(ctx, CALITAS_EIO, md5_err);
+    if (!fill_on_host && !need_vid()) return calitas_fail(ctx, CALITAS_EIO, md5_err);
     make_rows(c, n_plain, n, nullptr, x.segs_placed);
+    if (fill_on_host)
+      x.ext.fill = [&, c](const uint64_t* place, char* text, bool stays) -> int {
+        auto work = [&, c, text](const uint64_t* pl) -> int {
+          const auto t_f = std::chrono::steady_clock::now();
+          if (!need_vid()) return calitas_fail(ctx, CALITAS_EIO, md5_err);
+          if (vid.size() != vid_placeholder.size()) return calitas_fail(ctx, CALITAS_EINVAL, "the VCF's identifier is not as long as its placeholder (internal error)");
+          ContigExt& y = cx[c];
+          std::atomic<uint64_t> done{0};
+          ctx->pool->for_blocks(y.entry.size(), [&](size_t b, size_t e, int) {
+            uint64_t k = 0;
+            for (size_t i = b; i < e; i++) {
+              if (pl[i] == ~0ull) continue;
+              if (!y.row_ptr[i]) continue;                       // (counted below: a kept entry without a row is an error)
+              char* dst = text + pl[i];
+              std::memcpy(dst, y.row_ptr[i], y.row_len[i]);
+              if (y.vid_off[i]) std::memcpy(dst + y.vid_off[i], vid.data(), vid.size());
+              k++;
+            }
+            done += k;
+          });
+          uint64_t want = 0;
+          for (size_t i = 0; i < y.entry.size(); i++) want += pl[i] != ~0ull;
+          if (done.load() != want) return calitas_fail(ctx, CALITAS_EINVAL, "an entry the device kept has no row (internal error)");
+          rows_filled += want;
+          ns_fill += (long long)(ms_since(t_f) * 1e6);
+          return CALITAS_OK;
+        };
+        if (!stays) return work(place);
+        auto held = std::make_shared<std::vector<uint64_t>>(place, place + cx[c].entry.size());   // (place[] is the device stage's: valid during this call only)
+        return filler.enqueue([work, held](std::string&) -> int { return work(held->data()); }, 64, nullptr);
+      };
     if (rows_on_demand) {
       // (runs on the helper thread; cx[c] is this contig's alone from here on)
       x.ext.rows_for = [&, c, n_plain](const uint8_t* kept, HitsExtRows* out) -> int {
@@ -1397,6 +1456,8 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
           std::vector<std::string>().swap(cx[k].segs);
           std::vector<std::string>().swap(cx[k].segs_placed);
           std::vector<uint32_t>().swap(cx[k].row_len);
+          std::vector<uint32_t>().swap(cx[k].vid_off);
+          std::vector<const char*>().swap(cx[k].row_ptr);
           std::vector<HitsExtKey>().swap(cx[k].keys);
           std::vector<uint64_t>().swap(cx[k].row_off);
           std::vector<const ExtHit*>().swap(cx[k].entry);
@@ -1411,6 +1472,11 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   };
   if (device_merge) {
     helper.join();
+    if (fill_on_host) {                                           // the rows the filler stage still owes the text
+      std::string fe;
+      const int fr = filler.drain(nullptr, &fe);
+      if (hr.rc == CALITAS_OK && (fr || !fe.empty())) { hr.rc = fr ? fr : CALITAS_EINVAL; if (!fe.empty()) calitas_fail(ctx, hr.rc, fe); if (hr.tsv != user_dst) calitas_free(hr.tsv); hr.tsv = nullptr; }
+    }
     if (hr.rc == CALITAS_OK) {
       const size_t n_hits = hits.size(), n_vcf = vcf.size();
       if (TUNE_GET("CALITAS_FREE_NOW")) teardown();
@@ -1428,9 +1494,9 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
       if (n_windows) *n_windows = windows_total;
       if (TUNE_GET("CALITAS_TRACE"))
         std::fprintf(stderr, "[calitas] search_variants: VCF %.1f ms (%zu records), %llu windows: walked and handed over in %.1f ms (waiting for the builder stage %.1f ms; there: built in %.1f ms, waiting for the aligner threads %.1f ms), stages drained in %.1f ms (align %.1f ms, keys %.1f ms there), "
-                             "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits (%llu rows made, %.1f ms of them on demand), "
+                             "contigs finished in %.1f ms (groups %.1f + rows %.1f + blobs %.1f ms) of %zu hits (%llu rows made, %.1f ms of them on demand; %llu written into the text on the host in %.1f ms), "
                              "variant half done at %.1f ms; beside it the reference search with those hits on the device %.1f ms; call %.1f ms, %.2f s of CPU time\n",
-                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_walk, ms_wait_builder, ms_build, ms_wait, ms_drain, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, (unsigned long long)rows_made.load(), (double)ns_demand.load() / 1e6, ms_variant_half, hr.ms, ms_since(t_call), cpu_seconds() - cpu0);
+                     ms_parse, n_vcf, (unsigned long long)windows_total, ms_walk, ms_wait_builder, ms_build, ms_wait, ms_drain, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, (unsigned long long)rows_made.load(), (double)ns_demand.load() / 1e6, (unsigned long long)rows_filled.load(), (double)ns_fill.load() / 1e6, ms_variant_half, hr.ms, ms_since(t_call), cpu_seconds() - cpu0);
       return CALITAS_OK;
     }
     calitas_free(hr.tsv);
@@ -1475,6 +1541,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
     std::fprintf(stderr, "[calitas] variant-window hits: %zu, %llu with a description, %llu without, of those %llu repeat a reference hit\n", hits.size(),
                  (unsigned long long)with_desc, (unsigned long long)plain, (unsigned long long)twins);
   }
+  if (!need_vid()) { calitas_free(ref_alns); teardown(); return calitas_fail(ctx, CALITAS_EIO, md5_err); }   // (the rows below name the VCF)
   struct RowMaker { decltype(make_row)* fn; const HitList* hits; } maker{&make_row, &hits};
   uint64_t nr = 0;
   const auto t_merge = std::chrono::steady_clock::now();

@@ -211,8 +211,9 @@ def _dense_case(C, tmp_path, sizes, every, seed):
 @pytest.mark.parametrize("d,overlap", [(7, 10), (8, 10), (8, 25), (7, 1)])
 def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_path, monkeypatch):
     """calitas_search_variants keeps the reference's own hits on the device: the hits of variant windows enter the device's
-    removeOverlaps walk / order as key-only entries, and the rows of the ones the walks keep are made on demand (hits.hpp, HitsExt::rows_for;
-    CALITAS_VARIANTS_ROWS=all: every entry comes with its finished row, as before round 5).  Same bytes as the host merge of
+    removeOverlaps walk / order as key-only entries, the rows of the ones the walks keep are made on demand (hits.hpp, HitsExt::rows_for)
+    and written into the holes the rows kernel leaves in the text once it is on the host (HitsExtRows::fill_on_host;
+    CALITAS_VARIANTS_ROWS=device: the kept rows go to the device, =all: every entry comes with its finished row, as before round 5).  Same bytes as the host merge of
     alignment records (CALITAS_VARIANTS_HOST=1, the path the oracle comparisons of this file pinned), with and without a contig whose
     reference windows yield nothing, and the oracle's rows as a multiset (ties between groups: SR:656)."""
     fa, vcf = _dense_case(C, tmp_path, [("chr1", 60000), ("tiny", 90), ("chr2", 21000)], 80, seed=100 + d)
@@ -228,6 +229,9 @@ def test_reference_rows_on_the_device_equal_the_host_merge(C, d, overlap, tmp_pa
     sa = C.SearchReference(**kw)
     assert sa.run("v0", "stamp") == (text, n) and sa.timing["contig_passes"] == 3
     monkeypatch.delenv("CALITAS_VARIANTS_COMPACT")
+    sa = C.SearchReference(**kw)
+    assert sa.run("v0", "stamp") == (text, n) and sa.timing["contig_passes"] == 3
+    monkeypatch.setenv("CALITAS_VARIANTS_ROWS", "device")        # ... and with the kept rows sent to the device instead of written into the text on the host
     sa = C.SearchReference(**kw)
     assert sa.run("v0", "stamp") == (text, n) and sa.timing["contig_passes"] == 3
     monkeypatch.delenv("CALITAS_VARIANTS_ROWS")
