@@ -261,6 +261,31 @@ class Context:
         self.last_free_ms = (time.perf_counter() - t_free) * 1e3    # (a hits.txt of tens of gigabytes: handing the block back is not free)
         return nbytes.value, rows.value, nwin.value
 
+    def vcf_identifier(self, vcf_path):
+        """calitas_vcf_identifier: "name:md5" of a VCF (ReferenceHit.scala:175-183), computed by the library."""
+        out = ctypes.c_void_p()
+        _lib.check(self._h, lib.calitas_vcf_identifier(self._h, str(vcf_path).encode(), ctypes.byref(out)))
+        try:
+            return ctypes.string_at(out).decode()
+        finally:
+            lib.calitas_free(out)
+
+    def vcf_records(self, vcf_path, chrom=None):
+        """calitas_vcf_records: the records of a VCF as the variant search reads them, a list of
+        (chrom, pos, end, id, ref, [alts], [afs as the floats the search keeps])."""
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        _lib.check(self._h, lib.calitas_vcf_records(self._h, str(vcf_path).encode(), chrom.encode() if chrom is not None else None, ctypes.byref(out), ctypes.byref(n)))
+        try:
+            text = ctypes.string_at(out).decode()
+        finally:
+            lib.calitas_free(out)
+        recs = []
+        for line in text.split("\n")[:-1]:
+            c, pos, end, vid, ref, alts, afs = line.split("\t")
+            recs.append((c, int(pos), int(end), vid, ref, alts.split(","), [float(x) for x in afs.split(",")] if afs else []))
+        assert len(recs) == n.value
+        return recs
+
     def search_variants_into(self, guide, guide_id, params, vcf_path, address, capacity, version=None, time_stamp=None, chrom=None):
         """calitas_search_variants_into: the text goes to `capacity` bytes at `address` (memory of the caller, page-locked with pin_host: every
         contig's rows then cross the bus straight to their place).  Returns (n_bytes, n_rows, n_variant_windows)."""

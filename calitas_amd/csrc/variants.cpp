@@ -1586,3 +1586,51 @@ extern "C" int calitas_search_variants_into(calitas_ctx* ctx, const calitas_guid
   char* text = nullptr;
   return search_variants_impl(ctx, guide, guide_id, params, vcf_path, chrom, vcf_id, aligner_version, time_stamp, &text, tsv_bytes, n_rows, n_windows, dst, dst_capacity);
 }
+
+// ---- what the variant search knows about a VCF, on its own (callers that search many guides against one VCF; the CPU tests) ----------
+
+extern "C" int calitas_vcf_identifier(calitas_ctx* ctx, const char* vcf_path, char** id) {
+  if (!vcf_path || !id) return calitas_fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *id = nullptr;
+  std::string hex;
+  const std::string e = md5_file(vcf_path, hex);
+  if (!e.empty()) return calitas_fail(ctx, CALITAS_EIO, e);
+  const char* slash = std::strrchr(vcf_path, '/');
+  const std::string v = std::string(slash ? slash + 1 : vcf_path) + ":" + hex;
+  char* out = (char*)calitas_out_alloc(v.size() + 1);
+  if (!out) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
+  std::memcpy(out, v.c_str(), v.size() + 1);
+  *id = out;
+  return CALITAS_OK;
+}
+
+extern "C" int calitas_vcf_records(calitas_ctx* ctx, const char* vcf_path, const char* chrom, char** text, uint64_t* n_records) {
+  if (!ctx) return CALITAS_EINVAL;
+  if (!vcf_path || !text) return calitas_fail(ctx, CALITAS_EINVAL, "NULL argument");
+  *text = nullptr;
+  if (n_records) *n_records = 0;
+  VarTable vcf;
+  const std::string e = read_vcf(vcf_path, chrom, ctx->pool, vcf);
+  vcf.publish(vcf.size(), true);
+  if (!e.empty()) return calitas_fail(ctx, CALITAS_EIO, e);
+  std::string out;
+  char num[64];
+  for (size_t i = 0; vcf.have(i); i++) {                          // (through have(), as the search walks the table)
+    const Var& v = vcf[i];
+    out += v.chrom; out += '\t';
+    out += std::to_string(v.pos); out += '\t';
+    out += std::to_string(v.end); out += '\t';
+    out += v.id; out += '\t';
+    out += v.ref; out += '\t';
+    for (size_t a = 0; a < v.alts.size(); a++) { if (a) out += ','; out += v.alts[a]; }
+    out += '\t';
+    for (size_t a = 0; a < v.afs.size(); a++) { if (a) out += ','; std::snprintf(num, sizeof(num), "%.9g", (double)v.afs[a]); out += num; }
+    out += '\n';
+  }
+  char* block = (char*)calitas_out_alloc(out.size() + 1);
+  if (!block) return calitas_fail(ctx, CALITAS_EINVAL, "out of memory");
+  std::memcpy(block, out.c_str(), out.size() + 1);
+  *text = block;
+  if (n_records) *n_records = vcf.size();
+  return CALITAS_OK;
+}

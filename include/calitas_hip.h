@@ -337,6 +337,16 @@ int calitas_search_variants_into(calitas_ctx* ctx, const calitas_guide_t* guide,
                                  const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes, uint64_t* n_rows,
                                  uint64_t* n_windows);
 
+/* What calitas_search_variants knows about a VCF, on its own.
+ * calitas_vcf_identifier: the "name:md5" string of ReferenceHit.scala:175-183 (*id: a block for calitas_free) -- a caller that
+ * searches many guides against one VCF computes it once and passes it as vcf_id (0.14 s per 127 MB otherwise, per call).
+ * calitas_vcf_records: the records as the search reads them -- plain or gzip, parsed in waves on the context's worker pool, the --chrom
+ * filter applied -- one line each: CHROM, POS, end (INFO END, else POS + len(REF) - 1: fgbio Variant.end), ID ("" for "."), REF, the ALT
+ * alleles and the AF values (as %.9g of the float the search keeps) separated by commas, tab-separated.  Works on a host-only context
+ * (calitas_create(-1)); there so that the reader can be held against an independent one (tests/test_variants_host.py). */
+int calitas_vcf_identifier(calitas_ctx* ctx, const char* vcf_path, char** id);
+int calitas_vcf_records(calitas_ctx* ctx, const char* vcf_path, const char* chrom, char** text, uint64_t* n_records);
+
 /* Padded strings of one alignment (Alignment.paddedString as used at SequentialGuideAligner.scala:511, plus the
  * reverse-complement handling of 5' PAM guides): each buffer must hold CALITAS_MAX_OPS+1 bytes. */
 int calitas_padded_strings(const calitas_ctx* ctx, const calitas_guide_t* guide, const calitas_aln_t* aln, char* padded_guide,

@@ -145,3 +145,108 @@ def test_prepare_vcf_with_a_sequence_dictionary(VA, tmp_path):
     (tmp_path / "x.fai").write_text("chr1\t100\t6\t60\t61\n")
     with pytest.raises(ValueError, match="assembly"):
         PV.prepare_vcf([str(bare)], str(out), dict_path=str(tmp_path / "x.fai"))
+
+
+# ---- the library's own VCF reader and MD5 (calitas_vcf_records / calitas_vcf_identifier) on a host-only context ---------------------
+
+def _hostctx():
+    import calitas_amd as C
+    return C, C.Context(-1)
+
+
+def _float32(x):
+    with np.errstate(over="ignore"):                            # (1.8e308 is infinity as a float, in both readers)
+        return float(np.float32(float(x)))
+
+
+@pytest.mark.parametrize("n_bytes", [0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 128, (1 << 20) - 1, (1 << 20) + 3, 3 * (1 << 20) + 64])
+def test_library_md5_equals_hashlib(tmp_path, n_bytes):
+    """ReferenceHit's VCF identifier "name:md5" (ReferenceHit.scala:175-183): the library's MD5 (64 steps written out, RFC 1321 padding at
+    every length class around the 56- and 64-byte boundaries and across its 1 MB read buffer) against hashlib's."""
+    C, ctx = _hostctx()
+    p = tmp_path / ("f%d.vcf" % n_bytes)
+    p.write_bytes(np.random.default_rng(n_bytes).integers(0, 256, n_bytes, dtype=np.uint8).tobytes())
+    try:
+        assert ctx.vcf_identifier(p) == PV.vcf_identifier(p)
+        with pytest.raises(C.CalitasError):
+            ctx.vcf_identifier(tmp_path / "absent.vcf")
+    finally:
+        ctx.close()
+
+
+def _compare_with_python_reader(ctx, path, chrom=None):
+    got = ctx.vcf_records(path, chrom)
+    _, want = PV.read_vcf(str(path), chrom)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        # (an AF comes back as the %.9g of the float the search keeps: nine digits name a float exactly)
+        assert g[:6] + ([_float32(a) for a in g[6]],) == (w.chrom, w.pos, w.end, w.id, w.ref, w.alts, [_float32(a) for a in w.afs]), (g, w.line)
+    return got
+
+
+def test_library_vcf_reader_on_edge_cases(tmp_path):
+    """calitas_vcf_records (what calitas_search_variants reads: mapped file, records parsed in place, one ALT / AF held in place, AF through
+    Clinger's fast path) against the package's Python reader: headers, short lines, '.' ids, several ALTs, AF lists with '.' and empty
+    entries, exponents, long digit strings, signs, END, no INFO column, no trailing newline, the --chrom filter, gzip."""
+    C, ctx = _hostctx()
+    lines = [
+        "##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO",
+        "chr1\t10\t.\tA\tC\t.\tPASS\tAF=0.25",
+        "chr1\t20\trs1\tAC\tA,ACG,T\t.\t.\tDP=3;AF=0.5,.,1e-3;END=25",
+        "chr1\t30\trs2\tG\tT\t.\tPASS\tAF=",
+        "chr1\t40\trs3\tG\tT\t.\tPASS\tAF=.",
+        "chr1\t50\trs4\tG\tT\t.\tPASS\tAF=0.000001234,5,-0.5,+0.75,00.5,.5,5.",
+        "chr1\t60\trs5\tG\tT\t.\tPASS\tAF=0.1234567890123456789,123456789012345678,1.7976931348623157e308,4.9e-324,1e-46",
+        "chr1\t70\trs6\tG\tT\t.\tPASS\tAF=0.1;AF=0.2",
+        "chr1\t80\trs7\tG\tT\t.\tPASS",
+        "chr1\t90\trs8\tG\tT",
+        "short\tline",
+        "chr2\t5\t.\tTTT\tT\t.\tPASS\tEND=7;AF=0.33333334",
+        "chr2\t15\tlong_identifier_of_more_than_fifteen_characters\tACGTACGTACGTACGTACGT\tA,ACGTACGTACGTACGTACGTACGT\t.\tPASS\tAF=0.016,0.984",
+        "chr2\t25\t.\tA\t\t.\tPASS\tAF=0.5",
+    ]
+    p = tmp_path / "edge.vcf"
+    p.write_text("\n".join(lines))                              # (no newline behind the last record)
+    try:
+        got = _compare_with_python_reader(ctx, p)
+        assert len(got) == 12 and got[-1][5] == [""] and [_float32(a) for a in got[1][6]] == [0.5, _float32(1e-3)]
+        assert len(_compare_with_python_reader(ctx, p, "chr2")) == 3
+        assert _compare_with_python_reader(ctx, p, "chrX") == []
+        import gzip
+        gz = tmp_path / "edge.vcf.gz"
+        with gzip.open(gz, "wt") as f:
+            f.write("\n".join(lines) + "\n")
+        assert _compare_with_python_reader(ctx, gz) == got
+        empty = tmp_path / "empty.vcf"
+        empty.write_text("")
+        assert ctx.vcf_records(empty) == []
+        with pytest.raises(C.CalitasError):
+            ctx.vcf_records(tmp_path / "absent.vcf")
+    finally:
+        ctx.close()
+
+
+def test_library_vcf_reader_in_waves(tmp_path):
+    """A file of several waves (the reader parses 1-16 MB at a time and publishes the records wave by wave, every worker taking the lines
+    that start in its share): 120 000 records with random AF spellings, record for record against the Python reader."""
+    C, ctx = _hostctx()
+    rng = np.random.default_rng(77)
+    p = tmp_path / "big.vcf"
+    with open(p, "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        pos = 0
+        for i in range(120000):
+            pos += int(rng.integers(1, 50))
+            k = int(rng.integers(0, 6))
+            af = ("%.*f" % (int(rng.integers(1, 12)), rng.random()) if k < 3 else "%.3e" % rng.random() if k == 3 else
+                  "%d" % rng.integers(0, 3) if k == 4 else "%.17g" % rng.random())
+            alts = ",".join("ACGT"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 3))))
+            f.write("chr%d\t%d\trs%d\t%s\t%s\t.\tPASS\tDP=%d;AF=%s%s\n" % (1 + i // 40000, pos, i, "ACGT"[i % 4], alts, i % 97, af,
+                                                                      ",%s" % af if "," in alts else ""))
+    assert os.path.getsize(p) > 4 << 20
+    try:
+        got = _compare_with_python_reader(ctx, p)
+        assert len(got) == 120000
+        assert len(_compare_with_python_reader(ctx, p, "chr2")) == 40000
+    finally:
+        ctx.close()
