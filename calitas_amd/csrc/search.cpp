@@ -1829,14 +1829,29 @@ int calitas_search_hits_ext_impl(calitas_ctx* ctx, const calitas_guide_t* guide,
   return rc;
 }
 
-// calitas_search_hits_into: one pass (with lanes), text straight into the caller's buffer.  No per-contig mode here: a search that
-// does not fit the device answers CALITAS_ENOMEM.
+// calitas_search_hits_into: one pass (with lanes), text straight into the caller's buffer -- or, since round 5, one pass per contig when
+// the search does not fit the device (a PAM-less search at eight differences on a whole genome: tens of gigabytes of text): every
+// contig's rows then cross the bus straight to their place in the buffer (search_hits_sequential's user_dst).  A window range
+// (first_window / n_windows) stays one pass.
 int calitas_search_hits_into_impl(calitas_ctx* ctx, const calitas_guide_t* guide, const std::string& guide_id, const calitas_params_t* params,
                                   const char* aligner_version, const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes,
                                   uint64_t* n_rows) {
   if (!dst || dst_capacity < 2) return fail(ctx, CALITAS_EINVAL, "no destination buffer");
   char* text = nullptr;
-  return search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, tsv_bytes, n_rows, dst, dst_capacity);
+  if (params && (params->first_window != 0 || params->n_windows != 0))
+    return search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, tsv_bytes, n_rows, dst, dst_capacity);
+  int rc = CALITAS_ENOMEM;
+  if (!known_not_to_fit(ctx, guide, params, false) && !predicted_not_to_fit(ctx, guide, params)) {
+    rc = search_hits_attempt(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, tsv_bytes, n_rows, dst, dst_capacity);
+    if (rc != CALITAS_ENOMEM) return rc;
+    if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_hits_into: %s -- retrying with one pass per contig\n", ctx->err.c_str());
+    release_scratch(ctx);
+    (void)known_not_to_fit(ctx, guide, params, true);
+  }
+  text = nullptr;
+  rc = search_hits_sequential(ctx, guide, guide_id, params, aligner_version, time_stamp, &text, tsv_bytes, n_rows, nullptr, nullptr, nullptr, dst, dst_capacity);
+  if (rc == CALITAS_ENOMEM) release_scratch(ctx);
+  return rc;
 }
 
 // calitas_search_hits_stream: the text goes to `sink` -- in one piece when the search fits one call, header and per-contig pieces

@@ -293,8 +293,9 @@ int calitas_hits_tsv_ext(const calitas_ctx* ctx, const calitas_guide_t* guide, c
 /* calitas_search_hits with the text delivered into a buffer of the caller (dst_capacity bytes, NUL included) instead of a block of
  * the library: what a multi-process job uses to have every process's piece of hits.txt land in one shared mapping without a second
  * copy (bench.py --gpus N).  The buffer should be page-locked -- calitas_pin_host does that -- or the copy from the device falls back
- * to the runtime's staged path.  One pass only: CALITAS_ENOMEM when the search does not fit the device, CALITAS_EINVAL when the
- * buffer is too small. */
+ * to the runtime's staged path; a block from calitas_alloc_host is what the copy engines like best.  A search that does not fit the
+ * device in one pass runs one pass per contig, as calitas_search_hits does, with every contig's rows crossing the bus straight to
+ * their place in the buffer.  CALITAS_EINVAL when the buffer is too small. */
 int calitas_search_hits_into(calitas_ctx* ctx, const calitas_guide_t* guide, const char* guide_id, const calitas_params_t* params,
                              const char* aligner_version, const char* time_stamp, char* dst, uint64_t dst_capacity, uint64_t* tsv_bytes,
                              uint64_t* n_rows);

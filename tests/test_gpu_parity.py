@@ -562,6 +562,26 @@ def test_per_contig_passes_equal_one_pass(C, tmp_path, monkeypatch):
             assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want       # (the contigs' texts cross PCIe compact: round 5)
             monkeypatch.setenv("CALITAS_COMPACT_ROWS", "0")
             assert ctx.search_hits(C.Guide(guide), "a", params, "v0", "stamp") == want       # ... and as whole rows
+            # calitas_search_hits_into in the per-contig mode (round 5): every contig's rows straight to their place in the caller's block,
+            # whole rows and compact ones; a block that is too small is refused, nothing is written behind its capacity
+            import ctypes
+            wb = want[0].encode()
+            cap = len(wb) + 4096
+            addr = C.Context.alloc_host(cap)
+            buf = np.ctypeslib.as_array((ctypes.c_uint8 * cap).from_address(addr))
+            try:
+                for compact in ("0", "1"):
+                    monkeypatch.setenv("CALITAS_COMPACT_ROWS", compact)
+                    buf[:] = 0x55
+                    nb, rows = ctx.search_hits_into(C.Guide(guide), "a", params, addr, cap, "v0", "stamp")[:2]
+                    assert (nb, rows) == (len(wb), want[1]) and bytes(buf[:nb]) == wb and buf[nb] == 0 and buf[nb + 1] == 0x55
+                    buf[:] = 0x55
+                    with pytest.raises(C.CalitasError, match="too small"):
+                        ctx.search_hits_into(C.Guide(guide), "a", params, addr, len(wb) // 2, "v0", "stamp")
+                    assert (buf[len(wb) // 2:] == 0x55).all()
+            finally:
+                del buf
+                C.Context.free_host(addr)
             monkeypatch.delenv("CALITAS_COMPACT_ROWS")
             monkeypatch.delenv("CALITAS_SEQUENTIAL")
             monkeypatch.setenv("CALITAS_CHUNKS", "2")
