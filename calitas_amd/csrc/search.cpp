@@ -994,7 +994,7 @@ static int queue_lane_setup(calitas_ctx* lane, const SearchPlan& pl, const RowSt
 struct LaneDest { std::function<bool(char** dst, uint64_t* cap)> get; };
 
 constexpr int kOwnedDeclined = -1000;   // (internal) a lane of an owned range (SearchPlan::owned) met bins it leaves to the general kernels
-static double g_pass_ms[2];              // (trace only; written by the one thread that runs a sequential call's passes)
+static std::atomic<double> g_pass_ms[2]; // (trace only; written by the one thread that runs a sequential call's passes -- atomics: two contexts may run such calls at once, and the figures are then both calls')
 constexpr int kExtDeclined = -1001;     // (internal) a pass that brings hits of the caller's (HitsExt) met a stage the device declines: the caller merges on the host
 
 struct LaneText;
@@ -1049,8 +1049,8 @@ static int lane_rows(calitas_ctx* lane, const SearchPlan& pl, bool prelaunched, 
   if (ext_source && ext_source->get(ext_contig, &ext) != 0) { calitas_free(alns); return kExtDeclined; }
   if (ext_source) {                         // (CALITAS_TRACE of the per-contig passes: the search kernels' part of a pass, and its wait for the caller's hits)
     const auto t_pass2 = std::chrono::steady_clock::now();
-    g_pass_ms[0] += std::chrono::duration<double, std::milli>(t_pass1 - t_pass0).count();
-    g_pass_ms[1] += std::chrono::duration<double, std::milli>(t_pass2 - t_pass1).count();
+    g_pass_ms[0].store(g_pass_ms[0].load(std::memory_order_relaxed) + std::chrono::duration<double, std::milli>(t_pass1 - t_pass0).count(), std::memory_order_relaxed);
+    g_pass_ms[1].store(g_pass_ms[1].load(std::memory_order_relaxed) + std::chrono::duration<double, std::milli>(t_pass2 - t_pass1).count(), std::memory_order_relaxed);
   }
   if (ext && !dev.valid && n_alns == 0) {   // nothing of the reference's own on this contig: the row stage still places the caller's hits
     dev.valid = true; dev.d_final = nullptr; dev.n_sel = 0; dev.crowded = true;
@@ -1491,7 +1491,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
     }
   }
   n_passes = (uint32_t)passes.size();
-  g_pass_ms[0] = g_pass_ms[1] = 0;
+  g_pass_ms[0].store(0, std::memory_order_relaxed); g_pass_ms[1].store(0, std::memory_order_relaxed);
   // Two row-stage scratch sets (ctx->hits / hits_alt) take turns: a helper thread runs the device stages of pass i+1 while this thread
   // copies the text of pass i over PCIe and hands it on -- the copy is 1.5 of the 2.7 s of a PAM-less d = 8 search on an hg38-sized
   // genome, the device stages 1.0.  The sink is only ever called from this (the caller's) thread.
@@ -1709,7 +1709,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   ctx->last_text_bytes = total;
   if (TUNE_GET("CALITAS_TRACE"))
     std::fprintf(stderr, "[calitas] search_hits: one pass per contig (%d), scan %.3f ms, align %.3f ms, all device stages incl. allocation %.3f ms (with a caller's hits: %.3f ms up to the row stage, %.3f ms waiting for the hits), text copy %.3f ms + %.3f ms from the bounce buffer to its place + %.3f ms growing the block (sums), call %.3f ms (%llu rows, %zu bytes)\n",
-                 n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, ms_rows, g_pass_ms[0], g_pass_ms[1], tm.hits_copy_ms, ms_land, ms_grow,
+                 n_contigs, tm.scan_kernel_ms, tm.align_kernel_ms, ms_rows, g_pass_ms[0].load(std::memory_order_relaxed), g_pass_ms[1].load(std::memory_order_relaxed), tm.hits_copy_ms, ms_land, ms_grow,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), (unsigned long long)rows, total);
   *tsv = text;
   if (tsv_bytes) *tsv_bytes = total;

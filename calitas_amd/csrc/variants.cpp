@@ -1434,7 +1434,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
   if (rc != CALITAS_OK || !err.empty()) {
     publish(nc, true);
     if (helper.joinable()) helper.join();
-    calitas_free(hr.tsv);
+    if (hr.tsv != user_dst) calitas_free(hr.tsv);                 // (never the caller's own block)
     if (!err.empty()) return calitas_fail(ctx, rc != CALITAS_OK ? rc : CALITAS_EINVAL, err);   // (a stage's own text, or this thread's)
     return rc;                                                    // (the context's error text was set where the call failed)
   }
@@ -1499,7 +1499,7 @@ static int search_variants_impl(calitas_ctx* ctx, const calitas_guide_t* guide, 
                      ms_parse, n_vcf, (unsigned long long)windows_total, ms_walk, ms_wait_builder, ms_build, ms_wait, ms_drain, (double)ns_align.load() / 1e6, ms_rows, ms_finish, ms_groups, ms_make, ms_blob, n_hits, (unsigned long long)rows_made.load(), (double)ns_demand.load() / 1e6, (unsigned long long)rows_filled.load(), (double)ns_fill.load() / 1e6, ms_variant_half, hr.ms, ms_since(t_call), cpu_seconds() - cpu0);
       return CALITAS_OK;
     }
-    calitas_free(hr.tsv);
+    if (hr.tsv != user_dst) calitas_free(hr.tsv);
     if (!hr.declined) { teardown(); return hr.rc; }
     if (TUNE_GET("CALITAS_TRACE")) std::fprintf(stderr, "[calitas] search_variants: the device row stage declined, merging on the host\n");
   }
