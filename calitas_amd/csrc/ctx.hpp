@@ -87,6 +87,7 @@ struct calitas_ctx {
                                     // variant windows' alignment while the reference passes of the same call are under way (calitas_side_context)
   struct LaneThreads* lane_threads = nullptr;   // parent: the host threads that drive lanes 1.. (search.cpp)
   hipStream_t scan_stream = nullptr;
+  hipStream_t scan_more[3] = {nullptr, nullptr, nullptr};   // a batch's scans take turns on scan_stream and these (CALITAS_BATCH_SCAN_STREAMS): the next scan fills the CUs the one before it leaves as it drains
   hipStream_t copy_stream = nullptr;  // parent: the text copies of all lanes
   hipEvent_t scan_done = nullptr;   // lane: recorded on the parent's scan stream after this lane's scan
   hipEvent_t t_scan0 = nullptr, t_scan1 = nullptr;   // the two events that bracket the last scan kernel (ev[0] / ev[1], or scan_done events)

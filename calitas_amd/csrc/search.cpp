@@ -1370,6 +1370,7 @@ void calitas_destroy_lanes(calitas_ctx* ctx) {
   for (calitas_ctx* c : ctx->lanes) calitas_destroy(c);
   ctx->lanes.clear();
   if (ctx->scan_stream) { (void)hipStreamDestroy(ctx->scan_stream); ctx->scan_stream = nullptr; }
+  for (auto& st : ctx->scan_more) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
   if (ctx->copy_stream) { (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
 }
 
@@ -2534,6 +2535,15 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
   if (rc) return rc;
   rc = ensure_window_table(ctx, plans[0], ctx->scan_stream);
   if (rc) return rc;
+  int n_scan_streams = 1;
+  if (const char* e = TUNE_GET("CALITAS_BATCH_SCAN_STREAMS")) n_scan_streams = std::max(1, std::min(4, std::atoi(e)));
+  if (n_scan_streams > 1) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    for (int k = 0; k + 1 < n_scan_streams; k++)
+      if (!ctx->scan_more[k]) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_more[k], hipStreamNonBlocking, least));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->scan_stream));         // (the window table, if it was just built, is there for all of them)
+  }
   const PackedRef& ref = ctx->ref;
   std::mutex scan_mu, copy_mu;
   const bool device_rows = !TUNE_GET("CALITAS_HOST_HITS");
@@ -2563,7 +2573,8 @@ int calitas_search_hits_batch_impl(calitas_ctx* ctx, int32_t n_guides, const cal
     // for this scan
     if (device_rows) HIP_TRY(lane, queue_row_constants(lane, pl, f.rs));   // before the wait for the scan is queued
     std::lock_guard<std::mutex> lk(scan_mu);
-    return launch_scan_stage(lane, pl, ctx->scan_stream);       // records lane->scan_done
+    const int turn = g % n_scan_streams;
+    return launch_scan_stage(lane, pl, turn == 0 ? ctx->scan_stream : ctx->scan_more[turn - 1]);       // records lane->scan_done
   };
   auto run_tail = [&](calitas_ctx* lane, InFlight& f, hipEvent_t scans_done) -> int {
     HIP_TRY(lane, hipStreamWaitEvent(lane->stream, scans_done, 0));

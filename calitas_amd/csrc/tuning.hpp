@@ -56,6 +56,7 @@ constexpr Switch kSwitches[] = {
   {"CALITAS_TRACE_BLOCKS_NARROW", "n", "T: ... for the ranges whose tail runs beside the next scan"},
   {"CALITAS_FREE_NOW", "1", "F/T: calitas_free of a block of gigabytes hands its pages back before it returns (default: on the library's own thread)"},
   {"CALITAS_BATCH_LANES", "1..8", "T: guides in flight in calitas_search_hits_batch (default 5)"},
+  {"CALITAS_BATCH_SCAN_STREAMS", "1..4", "T: a batch's scans on one stream, one after the other, or taking turns on several"},
   {"CALITAS_COMPACT_ROWS", "0", "F/T: full rows over PCIe instead of compact rows + host expansion (batches, the leading ranges of a chunked call)"},
   {"CALITAS_COMPACT_LANES", "n", "T: how many leading ranges of a chunked call move compact rows (default: all of three or more, all but the last of two)"},
   {"CALITAS_COMPACT_PIECE_KB", "n", "T: compact text copied and expanded in pieces of this size (default: one piece)"},
