@@ -127,6 +127,22 @@ def test_config5_at_its_stated_size_through_properties(bench_mod, tmp_path):
             got = O.check_hits_text(tsv.value, names, 10, 16, nbytes=nbytes)
             assert got["rows"] == rows and got["out_of_order"] == 0 and got["overlapping"] == 0 and got["malformed"] == 0
             assert got["rows_with_variant"] > 500_000
+            # the same search into a page-locked block of the caller's (calitas_search_variants_into: every contig's rows straight to their
+            # place over the bus, the kept variant-window rows written into their holes by the filler stage behind the VCF's MD5): same bytes
+            import ctypes
+            import numpy as np
+            cap = nbytes + (1 << 20)
+            addr = C.Context.alloc_host(cap)
+            try:
+                nb2, rows2, nwin2 = ctx.search_variants_into(C.Guide(bench_mod.GUIDE0[:20]), "c5", C.make_params(**KW), vcf, addr, cap, "v0", "stamp")
+                assert (nb2, rows2, nwin2) == (nbytes, rows, nwin)
+                a = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(tsv.value))
+                b = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(addr))
+                step = 1 << 30
+                assert all(np.array_equal(a[o:o + step], b[o:o + step]) for o in range(0, nbytes, step))
+                del a, b
+            finally:
+                C.Context.free_host(addr)
         finally:
             C._lib.lib.calitas_free(tsv)
     finally:
