@@ -16,8 +16,28 @@
 //                            patch, refPos / baseOffset / precedingMatch, the M / I / D case split, the same `require`)
 //   allele_combos_counts   = alleleCombos(Seq[Int])                 SearchReference.scala:377-399  (denominators, group size, (allele + 1) % n)
 // They are pinned by the reference's own vectors V1-V9 (SearchReferenceTest.scala:150-295) through tests/test_variants_host.py.
-// Everything around them -- arenas, the VCF reader, the three-stage pipeline, keys and rows, the merge on the device -- has no
+// Everything around them -- arenas, the VCF reader, the pipeline of stages, keys and rows, the merge on the device -- has no
 // counterpart in the reference.
+//
+// THE THREADS OF ONE CALL (round 5), and what each of them owns.  A stage is a thread that runs jobs in the order they are handed
+// over (StageThread: two jobs waiting at most, a failed stage drops what is behind it but still pays its turns); all of them share the
+// context's worker pool for the parallel part of a job.
+//   caller       walks the VCF's records as they are published (VarTable::have), lists what every window is made of (Spec), hands a
+//                full list to the builder and, at a contig's end, the contig's "finish" behind its last batch
+//   vcf reader   maps the file, parses it in waves of 16 MB on the pool, publishes the records wave by wave
+//   md5          the VCF's identifier "name:md5" (RH:175-183); whoever needs it first joins it (need_vid)
+//   builder      build_window for a list (pool), the batch to one of the aligners
+//   aligner x2   calitas_align_windows of a batch on a side context each (device); the batches reach the lifter in the order they were built
+//   lifter       lifts a batch's alignments back, lists them as hits (HitList: pieces that never move); at a contig's end the groups' own
+//                walks, the entries' tie order and keys (finish_contig)
+//   finisher     the rows of the contig's placed entries (with a placeholder where the identifier goes), then publishes the contig
+//   helper       the reference's per-contig passes (search.cpp, calitas_search_hits_ext_impl): asks for a contig's entries when its row stage
+//                is due (HitsExtSource::get, blocks until published), makes the rows of the plain entries the device's walk kept
+//                (HitsExt::rows_for), and its copying thread hands every contig's text to ...
+//   filler       ... which waits for the identifier once and writes the kept entries' rows into the holes the rows kernel left
+//                (HitsExt::fill; on the copying thread itself when the text is in a block of the library's, which may still move)
+// cx[c] (ContigExt) is the lifter's until finish_contig(c) returns, the finisher's until it publishes c, then the helper's and the
+// filler's; hits[] grows on the lifter only, everybody else reads published contigs through the pointers in cx[c].entry.
 //
 // VCF support is the subset the reference's path needs (fgbio vcf.api): CHROM POS ID REF ALT FILTER INFO(AF, END); plain or gzip.
 #include <fcntl.h>
