@@ -155,6 +155,65 @@ JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_se
   return (*env)->NewDirectByteBuffer(env, tsv, (jlong)bytes);
 }
 
+/* Round 5.  calitas_alloc_host: a page-locked block of the runtime's own as a direct ByteBuffer -- the destination searchVariantsInto
+ * likes best (the GPU's copy engines write into it directly); kept by the caller for the life of the process, released with `free`. */
+JNIEXPORT jobject JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_allocHost(JNIEnv* env, jobject self, jlong bytes) {
+  void* p = bytes > 0 ? calitas_alloc_host((uint64_t)bytes) : NULL;
+  if (!p) { throw_state(env, "calitas_alloc_host failed"); return NULL; }
+  return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+
+/* calitas_search_variants_into: searchVariants with the text delivered into `dst` (a direct ByteBuffer, ideally from allocHost); returns
+ * the text's length in bytes.  vcfId may be null: the library then computes "name:md5" itself. */
+JNIEXPORT jlong JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_searchVariantsInto(JNIEnv* env, jobject self, jlong h,
+    jstring protospacer, jobjectArray pams, jboolean pam5, jint cliLength, jstring guideId, jintArray params, jstring vcfPath,
+    jstring chrom, jstring vcfId, jstring version, jobject dst) {
+  calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
+  calitas_guide_t g;
+  calitas_params_t p;
+  if (!read_params(env, params, &p)) return 0;
+  char* out = dst ? (char*)(*env)->GetDirectBufferAddress(env, dst) : NULL;
+  const jlong cap = dst ? (*env)->GetDirectBufferCapacity(env, dst) : 0;
+  if (!out || cap < 2) { throw_state(env, "dst: a direct ByteBuffer is needed"); return 0; }
+  const jsize np = (*env)->GetArrayLength(env, pams);
+  const char* cp[CALITAS_MAX_PAMS];
+  jstring jp[CALITAS_MAX_PAMS];
+  if (np > CALITAS_MAX_PAMS) { throw_state(env, "too many PAMs"); return 0; }
+  g.protospacer = (*env)->GetStringUTFChars(env, protospacer, NULL);
+  for (jsize i = 0; i < np; i++) { jp[i] = (jstring)(*env)->GetObjectArrayElement(env, pams, i); cp[i] = (*env)->GetStringUTFChars(env, jp[i], NULL); }
+  g.n_pams = (int32_t)np; g.pams = cp; g.pam_is_5prime = pam5 ? 1 : 0; g.cli_length = cliLength;
+  const char* gid = (*env)->GetStringUTFChars(env, guideId, NULL);
+  const char* vcf = (*env)->GetStringUTFChars(env, vcfPath, NULL);
+  const char* vid = vcfId ? (*env)->GetStringUTFChars(env, vcfId, NULL) : NULL;
+  const char* chr = chrom ? (*env)->GetStringUTFChars(env, chrom, NULL) : NULL;
+  const char* ver = version ? (*env)->GetStringUTFChars(env, version, NULL) : NULL;
+  uint64_t bytes = 0, rows = 0;
+  const int rc = calitas_search_variants_into(ctx, &g, gid, &p, vcf, chr, vid, ver, NULL, out, (uint64_t)cap, &bytes, &rows, NULL);
+  (*env)->ReleaseStringUTFChars(env, protospacer, g.protospacer);
+  for (jsize i = 0; i < np; i++) (*env)->ReleaseStringUTFChars(env, jp[i], cp[i]);
+  (*env)->ReleaseStringUTFChars(env, guideId, gid);
+  (*env)->ReleaseStringUTFChars(env, vcfPath, vcf);
+  if (vcfId) (*env)->ReleaseStringUTFChars(env, vcfId, vid);
+  if (chrom) (*env)->ReleaseStringUTFChars(env, chrom, chr);
+  if (version) (*env)->ReleaseStringUTFChars(env, version, ver);
+  if (rc != CALITAS_OK) { throw_state(env, calitas_last_error(ctx)); return 0; }
+  return (jlong)bytes;
+}
+
+/* calitas_vcf_identifier: ReferenceHit's "name:md5" of a VCF (ReferenceHit.scala:175-183), for callers that search many guides against
+ * one VCF and pass it as vcfId. */
+JNIEXPORT jstring JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_vcfIdentifier(JNIEnv* env, jobject self, jlong h, jstring vcfPath) {
+  calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
+  const char* vcf = (*env)->GetStringUTFChars(env, vcfPath, NULL);
+  char* id = NULL;
+  const int rc = calitas_vcf_identifier(ctx, vcf, &id);
+  (*env)->ReleaseStringUTFChars(env, vcfPath, vcf);
+  if (rc != CALITAS_OK) { throw_state(env, calitas_last_error(ctx)); return NULL; }
+  jstring out = (*env)->NewStringUTF(env, id);
+  calitas_free(id);
+  return out;
+}
+
 JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_free(JNIEnv* env, jobject self, jobject buffer) {
   calitas_free((*env)->GetDirectBufferAddress(env, buffer));
 }

@@ -44,6 +44,21 @@ final class NativeAligner(device: Int = 0) extends AutoCloseable {
     try { val out = new Array[Byte](buf.capacity()); buf.get(out); out } finally NativeAligner.free(buf)
   }
 
+  /** calitas_search_variants_into (round 5): the same search with hits.txt delivered into `dst` -- a direct buffer, ideally one from
+    * NativeAligner.allocHost (page-locked memory of the runtime's own, reused from call to call): every contig's rows then cross the
+    * bus once, straight to their place (0.55 s per whole-genome call against 0.9 s into a block of the library's).  Returns the
+    * text's length; SearchReference.scala:641-648 writes dst.limit(n) to --output instead of going through Metric.write.
+    * vcfId = None: the library computes "name:md5" itself (0.14 s per 127 MB, per call); vcfIdentifier below computes it once. */
+  def searchVariantsInto(guide: Guide, cliLength: Int, guideId: String, params: Array[Int], vcf: java.nio.file.Path, chrom: Option[String],
+                         vcfId: Option[String], version: String, dst: ByteBuffer): Long = {
+    val pams = (guide.pams5Prime ++ guide.pams3Prime).toArray
+    NativeAligner.searchVariantsInto(handle, guide.guide, pams, guide.pamIsFivePrime, cliLength, guideId, params, vcf.toString, chrom.orNull,
+                                     vcfId.orNull, version, dst)
+  }
+
+  /** calitas_vcf_identifier: ReferenceHit's "name:md5" (ReferenceHit.scala:175-183) as the library computes it. */
+  def vcfIdentifier(vcf: java.nio.file.Path): String = NativeAligner.vcfIdentifier(handle, vcf.toString)
+
   override def close(): Unit = NativeAligner.destroy(handle)
 }
 
@@ -61,6 +76,13 @@ object NativeAligner {
   @native private def searchVariants(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
                                      guideId: String, params: Array[Int], vcfPath: String, chrom: String, vcfId: String,
                                      version: String): ByteBuffer
+  @native private def searchVariantsInto(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
+                                         guideId: String, params: Array[Int], vcfPath: String, chrom: String, vcfId: String,
+                                         version: String, dst: ByteBuffer): Long
+  @native private def vcfIdentifier(handle: Long, vcfPath: String): String
+  /** calitas_alloc_host: a page-locked block as a direct buffer; release it with NativeAligner.release. */
+  @native def allocHost(bytes: Long): ByteBuffer
+  def release(buffer: ByteBuffer): Unit = free(buffer)
   @native private def free(buffer: ByteBuffer): Unit
 
   /** calitas_aln_t -> GuideAlignment (GuideAlignment.scala:72-88).  The padded strings follow Alignment.paddedString as used at
