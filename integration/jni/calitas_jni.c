@@ -54,6 +54,43 @@ JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_setRe
   if (rc != CALITAS_OK) throw_state(env, calitas_last_error(ctx));
 }
 
+/* Round 5: the same with the contigs' lengths given and null for the contigs this process holds no bases of (calitas_set_reference with
+ * absent contigs: what one process of a multi-GPU job does with the contigs its window range does not touch). */
+JNIEXPORT void JNICALL Java_com_editasmedicine_aligner_NativeAligner_00024_setReferenceWithLengths(JNIEnv* env, jobject self, jlong h,
+    jobjectArray names, jlongArray lengths, jobjectArray bases, jstring genomeBuild) {
+  calitas_ctx* ctx = (calitas_ctx*)(intptr_t)h;
+  const jsize n = (*env)->GetArrayLength(env, names);
+  if ((*env)->GetArrayLength(env, lengths) != n || (*env)->GetArrayLength(env, bases) != n) { throw_state(env, "names, lengths and bases differ in length"); return; }
+  const char** cnames = calloc((size_t)n, sizeof(char*));
+  uint64_t* lens = calloc((size_t)n, sizeof(uint64_t));
+  const uint8_t** ptrs = calloc((size_t)n, sizeof(uint8_t*));
+  jbyteArray* arrs = calloc((size_t)n, sizeof(jbyteArray));
+  jstring* jn = calloc((size_t)n, sizeof(jstring));
+  jlong* jl = (*env)->GetLongArrayElements(env, lengths, NULL);
+  const char* build = genomeBuild ? (*env)->GetStringUTFChars(env, genomeBuild, NULL) : "unknown";
+  int bad = 0;
+  for (jsize i = 0; i < n; i++) {
+    jn[i] = (jstring)(*env)->GetObjectArrayElement(env, names, i);
+    cnames[i] = (*env)->GetStringUTFChars(env, jn[i], NULL);
+    lens[i] = (uint64_t)jl[i];
+    arrs[i] = (jbyteArray)(*env)->GetObjectArrayElement(env, bases, i);
+    if (arrs[i]) {
+      if ((uint64_t)(*env)->GetArrayLength(env, arrs[i]) != lens[i]) bad = 1;
+      ptrs[i] = (const uint8_t*)(*env)->GetByteArrayElements(env, arrs[i], NULL);
+    }
+  }
+  const int rc = bad ? CALITAS_EINVAL : calitas_set_reference(ctx, (int32_t)n, cnames, lens, ptrs, build);
+  for (jsize i = 0; i < n; i++) {
+    if (arrs[i]) (*env)->ReleaseByteArrayElements(env, arrs[i], (jbyte*)ptrs[i], JNI_ABORT);
+    (*env)->ReleaseStringUTFChars(env, jn[i], cnames[i]);
+  }
+  (*env)->ReleaseLongArrayElements(env, lengths, jl, JNI_ABORT);
+  if (genomeBuild) (*env)->ReleaseStringUTFChars(env, genomeBuild, build);
+  free(cnames); free(lens); free(ptrs); free(arrs); free(jn);
+  if (bad) throw_state(env, "a contig's bases are not as long as its length says");
+  else if (rc != CALITAS_OK) throw_state(env, calitas_last_error(ctx));
+}
+
 /* Fills calitas_params_t from the caller's int[]: the fields in declaration order.  The struct has grown over time (13 ints at first,
  * then first_window / n_windows); an older caller's shorter array leaves the trailing fields at zero, which is their "whole job"
  * default.  Fewer than the original 13 is a caller bug.  Returns 0 on failure with a Java exception pending. */

@@ -16,6 +16,12 @@ final class NativeAligner(device: Int = 0) extends AutoCloseable {
   def setReference(names: Array[String], bases: Array[Array[Byte]], genomeBuild: String): Unit =
     NativeAligner.setReference(handle, names, bases, genomeBuild)
 
+  /** The same for one process of a multi-GPU job (round 5): every contig of the sequence dictionary with its length, `null` bases for
+    * the contigs this process's window range does not touch -- names, lengths, windowIterator's sequence and every coordinate stay
+    * those of the whole dictionary. */
+  def setReference(names: Array[String], lengths: Array[Long], bases: Array[Array[Byte]], genomeBuild: String): Unit =
+    NativeAligner.setReferenceWithLengths(handle, names, lengths, bases, genomeBuild)
+
   /** calitas_search for one guide; returns the GuideAlignments of every window in windowIterator order. */
   def search(guide: Guide, cliLength: Int, params: Array[Int], contigNames: IndexedSeq[String],
              fetch: (String, Int, Int) => Array[Byte]): IndexedSeq[GuideAlignment] = {
@@ -69,6 +75,8 @@ object NativeAligner {
   @native private def create(device: Int): Long
   @native private def destroy(handle: Long): Unit
   @native private def setReference(handle: Long, names: Array[String], bases: Array[Array[Byte]], genomeBuild: String): Unit
+  @native private def setReferenceWithLengths(handle: Long, names: Array[String], lengths: Array[Long], bases: Array[Array[Byte]],
+                                              genomeBuild: String): Unit
   @native private def search(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
                              params: Array[Int]): ByteBuffer
   @native private def searchHits(handle: Long, protospacer: String, pams: Array[String], pamIsFivePrime: Boolean, cliLength: Int,
