@@ -12,7 +12,11 @@ ctx.search_hits_batch(G, ids, p, "v", "t", decode=False)
 res = {}
 for rep in range(int(os.environ.get("SWEEP_REPS", "4"))):
     for lanes in sys.argv[2:] or ("4", "5", "6", "7", "8"):
-        os.environ[sys.argv[1] if len(sys.argv) > 1 else "CALITAS_BATCH_LANES"] = lanes
+        var = sys.argv[1] if len(sys.argv) > 1 else "CALITAS_BATCH_LANES"
+        if lanes == "-":
+            os.environ.pop(var, None)                     # ("-": the variable unset)
+        else:
+            os.environ[var] = lanes
         t = time.perf_counter(); r = ctx.search_hits_batch(G, ids, p, "v", "t", decode=False); dt = (time.perf_counter() - t) * 1e3; del r
         res.setdefault(lanes, []).append(dt)
 for k, v in res.items(): print("%s=%s: %s ms per 96 guides" % (sys.argv[1] if len(sys.argv) > 1 else "CALITAS_BATCH_LANES", k, " ".join("%.1f" % x for x in v)), flush=True)
