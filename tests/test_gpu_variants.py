@@ -355,3 +355,45 @@ def test_cpp_cli_with_variants(C, tmp_path):
     assert strip(got) == strip(want) and len(got) == e["expect"]["n"]
     ids = {r["variant_vcf"] for r in got if r["variant_vcf"]}
     assert ids == {VV.vcf_identifier(vcf)}                     # "e4.vcf:<md5>" from the library's own MD5 == hashlib's
+
+
+def test_variant_search_error_paths_and_an_empty_vcf(C, tmp_path):
+    """What the stages of calitas_search_variants do when the VCF is not what it should be (the reference passes are under way by the time
+    the file is looked at, round 5): a file that is not there, contigs out of the reference's order, a contig the reference does not have
+    -- CALITAS errors, no hang, and the context searches on afterwards; a VCF without records gives the reference search's own text."""
+    import threading
+    fa, vcf = _dense_case(C, tmp_path, [("chr1", 30000), ("chr2", 12000)], 150, seed=41)
+    kw = dict(guide="CTTGCCCCACAGGGCAGTAA", guide_id="c5", ref=fa, max_guide_diffs=6, max_pam_mismatches=0, max_gaps_between_guide_and_pam=3)
+    lines = open(vcf).read().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    recs = [l for l in lines if not l.startswith("#")]
+    swapped = tmp_path / "swapped.vcf"
+    swapped.write_text("\n".join(head + [l for l in recs if l.startswith("chr2\t")] + [l for l in recs if l.startswith("chr1\t")]) + "\n")
+    foreign = tmp_path / "foreign.vcf"
+    foreign.write_text("\n".join(head + recs[:5] + ["chrZ\t10\t.\tA\tC\t.\tPASS\tAF=0.1"]) + "\n")
+    empty = tmp_path / "empty.vcf"
+    empty.write_text("\n".join(head) + "\n")
+    ctx = C.Context(0)
+    ctx.set_reference_fasta(fa)
+    box = {}
+
+    def run(path):
+        try:
+            box["out"] = C.SearchReference(variants=str(path), context=ctx, **kw).run("v0", "stamp")
+        except Exception as e:                                  # noqa: BLE001 (the test looks at it)
+            box["err"] = e
+
+    try:
+        for path, pattern in ((tmp_path / "absent.vcf", "cannot read"), (swapped, "not in reference order"), (foreign, "not in reference order")):
+            box.clear()
+            t = threading.Thread(target=run, args=(path,), daemon=True)
+            t.start()
+            t.join(60)
+            assert not t.is_alive(), "calitas_search_variants hangs on %s" % path
+            assert isinstance(box.get("err"), C.CalitasError) and pattern in str(box["err"]), box
+        want = C.SearchReference(context=ctx, **kw).run("v0", "stamp")
+        got = C.SearchReference(variants=str(empty), context=ctx, **kw).run("v0", "stamp")
+        assert got == want and want[1] > 0
+        assert C.SearchReference(variants=vcf, context=ctx, **kw).run("v0", "stamp")[1] >= want[1]   # ... and the context is as good as new
+    finally:
+        ctx.close()
