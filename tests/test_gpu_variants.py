@@ -280,6 +280,11 @@ def test_text_into_the_callers_page_locked_buffer(C, host_merge, block, tmp_path
             assert bytes(buf[:nb]) == want and buf[nb] == 0 and buf[nb + 1] == 0x55
         nb2, rows2, _ = ctx.search_variants_into(g, "c5", params, vcf, buf.ctypes.data, len(want) + 1, "v0", "stamp")   # exactly enough
         assert (nb2, rows2) == (len(want), n) and bytes(buf[:nb2]) == want
+        monkeypatch.setenv("CALITAS_VARIANTS_COMPACT", "1")     # ... and with the per-contig texts compact on the bus, expanded into the buffer
+        buf[:] = 0x55
+        nb3, rows3, _ = ctx.search_variants_into(g, "c5", params, vcf, buf.ctypes.data, buf.nbytes, "v0", "stamp")
+        assert (nb3, rows3) == (len(want), n) and bytes(buf[:nb3]) == want and buf[nb3] == 0 and buf[nb3 + 1] == 0x55
+        monkeypatch.delenv("CALITAS_VARIANTS_COMPACT")
         for cap in (16, len(want) // 2, len(want)):             # too small: at the header, part of the way, by the final NUL
             buf[:] = 0x55
             with pytest.raises(C.CalitasError, match="too small|does not hold the header"):
