@@ -59,7 +59,7 @@ class TimingT(ctypes.Structure):
 # every symbol include/calitas_hip.h declares
 SYMBOLS = ["calitas_create", "calitas_destroy", "calitas_last_error", "calitas_free", "calitas_set_reference",
            "calitas_set_reference_fasta", "calitas_save_index", "calitas_load_index", "calitas_reference_info", "calitas_contig_name", "calitas_genome_build", "calitas_fetch_bases", "calitas_expand_rows",
-           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_into", "calitas_pin_host", "calitas_unpin_host", "calitas_alloc_host", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_scan_candidates_columnwise", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants", "calitas_search_variants_into", "calitas_vcf_identifier", "calitas_vcf_records",
+           "calitas_window_table", "calitas_search", "calitas_search_hits", "calitas_search_hits_stream", "calitas_search_hits_into", "calitas_pin_host", "calitas_unpin_host", "calitas_alloc_host", "calitas_release_parked", "calitas_search_hits_batch", "calitas_get_timing", "calitas_scan_candidates", "calitas_scan_candidates_columnwise", "calitas_contig_packed_base", "calitas_reference_tiles", "calitas_window_filter", "calitas_hits_tsv", "calitas_hits_tsv_ext", "calitas_search_variants", "calitas_search_variants_into", "calitas_vcf_identifier", "calitas_vcf_records",
            "calitas_padded_strings", "calitas_align_windows", "calitas_padded_strings_target", "calitas_version", "calitas_switches", "calitas_reap_wait"]
 
 if not os.path.exists(LIB_PATH):

@@ -143,10 +143,26 @@ void* out_alloc_impl(size_t size, bool pinned = false) {
   return h + 1;
 }
 
+// One pageable block of a gigabyte or more stays parked as well (round 5): the text of a per-contig search -- 21.8 GB for BASELINE
+// config 5's shape -- is copied into its block from a bounce buffer, and into pages nobody has touched that copy is the slowest thing the
+// call does (0.6 s; 0.13 s more to hand the pages back).  The next such search takes the block as it is (calitas_out_take_big): its pages
+// are there.  At most one, at most kBigPark bytes; calitas_release_parked() lets go of it and of everything else that is parked.
+constexpr uint64_t kBigPark = 48ull << 30;
+BlockHeader* g_big = nullptr;          // (under g_pool_mutex)
+
 void out_free(void* p) {
   if (!p) return;
   BlockHeader* h = (BlockHeader*)p - 1;
   if (h->magic != kMagic) return;     // not ours: refuse rather than corrupt the heap
+  if (!h->pinned && h->capacity >= (1ull << 30) && h->capacity <= kBigPark && !TUNE_GET("CALITAS_FREE_NOW")) {
+    BlockHeader* old = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mutex);
+      if (!g_big || g_big->capacity < h->capacity) { old = g_big; g_big = h; h = nullptr; }
+    }
+    if (old) release_block(old);
+    if (!h) return;
+  }
   // (a block of many gigabytes would only crowd the others out; small page-locked blocks are parked too: hipHostFree + hipHostMalloc
   // of the 11 KB text of an E. coli-sized call cost 0.2 ms per call, more than the search's kernels)
   if ((h->capacity >= (1u << 20) || h->pinned) && h->capacity <= kPoolBytes / 4) {
@@ -180,6 +196,35 @@ void* calitas_out_grow(void* p, size_t keep, size_t size) {
     if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
   }
   return n + 1;
+}
+// A block that turned out far larger than what it holds (a parked block of 22 GB taken for a text of 2) gives the rest back: p or its
+// new address; the first `size` bytes stay.
+void* calitas_out_shrink(void* p, size_t size) {
+  if (!p) return p;
+  BlockHeader* h = (BlockHeader*)p - 1;
+  if (h->magic != kMagic || h->pinned || h->capacity < (1ull << 30) || h->capacity <= 2 * (uint64_t)size + (256ull << 20)) return p;
+  const size_t cap = size + size / 16 + 4096;
+  BlockHeader* n = (BlockHeader*)std::realloc(h, sizeof(BlockHeader) + cap);
+  if (!n) return p;
+  n->capacity = cap;
+  return n + 1;
+}
+// The parked big block (above) if it has at least min_bytes of room, else NULL.  The caller owns it from here on (calitas_out_grow, calitas_free).
+void* calitas_out_take_big(size_t min_bytes) {
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  if (!g_big || g_big->capacity < min_bytes) return nullptr;
+  BlockHeader* h = g_big;
+  g_big = nullptr;
+  return h + 1;
+}
+extern "C" void calitas_release_parked(void) {
+  std::vector<BlockHeader*> all;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    all.swap(g_pool);
+    if (g_big) { all.push_back(g_big); g_big = nullptr; }
+  }
+  for (BlockHeader* h : all) release_block(h);
 }
 void calitas_reap_later(std::function<void()> job) { g_reaper.give(std::move(job)); }
 extern "C" void calitas_reap_wait(void) { g_reaper.wait_idle(); }

@@ -110,6 +110,8 @@ struct calitas_ctx {
 
 int calitas_fail(calitas_ctx* ctx, int code, const std::string& msg);
 void* calitas_out_alloc(size_t size);
+void* calitas_out_shrink(void* p, size_t size);  // gives back what a block has far too much of (api.cpp)
+void* calitas_out_take_big(size_t min_bytes);   // the parked pageable block of >= 1 GB, if there is one with that much room (api.cpp)
 void* calitas_out_alloc_pinned(size_t size);   // page-locked: the destination of the text copy-back
 void* calitas_out_grow(void* p, size_t keep, size_t size);   // pageable block grown in place (realloc); p may be NULL
 // search.cpp

@@ -1453,7 +1453,9 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   // concatenating them afterwards took longer than the search).
   const size_t hlen = rs.header.size();
   if (user_dst && user_cap < hlen + 1) return fail(ctx, CALITAS_EINVAL, "the destination buffer does not hold the header line");
-  char* text = sink ? nullptr : user_dst ? user_dst : (char*)calitas_out_grow(nullptr, 0, hlen + (64u << 20));
+  // (a block of the library's: the one the last such search's caller handed back, if it is still parked -- its pages are there)
+  char* text = sink ? nullptr : user_dst ? user_dst : (char*)calitas_out_take_big(hlen + (64u << 20));
+  if (!sink && !text) text = (char*)calitas_out_grow(nullptr, 0, hlen + (64u << 20));
   if (!sink && !text) return fail(ctx, CALITAS_EINVAL, "out of memory");
   if (text) std::memcpy(text, rs.header.data(), hlen);
   else if (sink(rs.header.data(), hlen, sink_user) != 0) return fail(ctx, CALITAS_EIO, "the text sink reported an error");
@@ -1702,7 +1704,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
   } else if (!sink) {
     char* grown = (char*)calitas_out_grow(text, total, total + 1);
     if (!grown) { calitas_free(text); return fail(ctx, CALITAS_EINVAL, "out of memory"); }
-    text = grown;
+    text = (char*)calitas_out_shrink(grown, total + 1);           // (a parked block taken for a much smaller text)
     text[total] = 0;
   }
   tm.hit_rows = rows; tm.hits_bytes = total; tm.lanes = 1; tm.contig_passes = n_passes;

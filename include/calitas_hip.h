@@ -302,6 +302,12 @@ int calitas_search_hits_into(calitas_ctx* ctx, const calitas_guide_t* guide, con
 /* Page-locks / releases host memory the caller owns (hipHostRegister): destinations of calitas_search_hits_into. */
 int calitas_pin_host(calitas_ctx* ctx, void* p, uint64_t bytes);
 int calitas_unpin_host(calitas_ctx* ctx, void* p);
+/* calitas_free parks the blocks it is given -- up to 24 GB of texts and arrays, and one pageable block of a gigabyte or more (the text
+ * of a whole-genome search with variants: writing 22 GB into pages nobody has touched, and handing them back, is most of what such a
+ * call costs on the host) -- for the next call of the kind to take as they are.  calitas_release_parked() returns all of it to the
+ * system; CALITAS_FREE_NOW=1 parks nothing big. */
+void calitas_release_parked(void);
+
 /* A page-locked block of the runtime's own (hipHostMalloc), handed back with calitas_free: the destination the *_into calls like best --
  * the GPU's copy engines write into such a block directly (a range that calitas_pin_host merely locked is served by the runtime's
  * copy kernels instead).  NULL when the block cannot be had.  Meant to be reused from call to call: page-locking is not cheap. */
