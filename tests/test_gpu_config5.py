@@ -144,7 +144,8 @@ def test_config5_at_its_stated_size_through_properties(bench_mod, tmp_path):
             finally:
                 C.Context.free_host(addr)
         finally:
-            C._lib.lib.calitas_free(tsv)
+            C._lib.lib.calitas_free(tsv)                          # (a block of 22 GB: parked for the next such search ...)
+            C._lib.lib.calitas_release_parked()                   # (... which is not coming: back to the system)
     finally:
         ctx.close()
         if os.path.exists(vcf):

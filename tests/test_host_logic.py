@@ -468,3 +468,21 @@ def test_reference_with_absent_contigs():
             part.save_index("/tmp/should_not_exist.idx")
     finally:
         full.close(); part.close()
+
+
+def test_release_parked_is_harmless_and_repeatable():
+    """calitas_release_parked: lets go of what calitas_free has parked (the texts' blocks); with nothing parked -- and twice in a row --
+    it does nothing."""
+    import calitas_amd as C
+    C._lib.lib.calitas_release_parked()
+    ctx = C.Context(-1)
+    try:
+        rows = b"chr1\t1\tx\n" * 4
+        import ctypes
+        out = ctypes.create_string_buffer(4 * (len(b"h\t") + len(b"t\n") - 1) + len(rows) + 8)
+        written = ctypes.c_uint64()
+        assert C._lib.lib.calitas_expand_rows(ctx._h, rows, len(rows), 4, b"h\t", b"t\n", out, len(out), ctypes.byref(written)) == 0
+    finally:
+        ctx.close()
+    C._lib.lib.calitas_release_parked()
+    C._lib.lib.calitas_release_parked()
