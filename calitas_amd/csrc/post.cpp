@@ -317,6 +317,7 @@ __attribute__((target("avx2"))) static void stream_lines_avx2(char* w, const cha
 }
 static const bool wide_stores = __builtin_cpu_supports("avx2");
 
+
 struct RowWriter {
   char* w;                                                    // where buf[0] belongs
   size_t fill = 0;
@@ -352,6 +353,18 @@ struct RowWriter {
 };
 
 }  // namespace
+
+// memcpy with non-temporal stores: for tens of megabytes that nobody reads back soon (a contig's text on its way from the bounce buffer
+// to its block), so that the destination's lines are written without being fetched first.
+void stream_copy(char* dst, const char* src, size_t n) {
+  const size_t head = std::min(n, (size_t)((64 - ((uintptr_t)dst & 63)) & 63));   // up to the destination's next 64-byte line
+  if (head) { std::memcpy(dst, src, head); dst += head; src += head; n -= head; }
+  const size_t lines = n / 64;
+  if (lines) { if (wide_stores) stream_lines_avx2(dst, src, lines); else stream_lines_sse2(dst, src, lines); }
+  const size_t done = lines * 64;
+  if (n > done) std::memcpy(dst + done, src + done, n - done);
+  _mm_sfence();
+}
 
 // The expansion as a job of pieces (WorkerPool::offer) over a text that may still be arriving.  A piece is the rows that START in one
 // 64 KB stretch of the compact text.  Whoever arrives takes the next piece, waits until its bytes are there, counts its rows, learns

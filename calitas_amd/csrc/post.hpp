@@ -53,6 +53,7 @@ RowStrings make_row_strings(const PackedRef& ref, const GuideHost& g, const std:
 // (aligner ... time_stamp, ReferenceHit.scala:99-132).  Given row constants with an empty head and "\n" for a tail, the device's row
 // kernels write `chromosome \t middle \n` per row -- the same kernels, half the bytes over PCIe -- and the library puts head and tail
 // back on the host's worker pool while the next text is on the bus.
+void stream_copy(char* dst, const char* src, size_t n);   // memcpy with non-temporal stores (large blocks nobody reads back soon)
 RowStrings compact_row_strings(const RowStrings& full);
 // The same with genome_build left in the rows: the variant branch's rows have one of their own ("<build>+variants" for a hit that
 // touches a variant, ReferenceHit.scala:208), so only guide_id and protospacer are cut; *cut = what was cut from the head.

@@ -1650,7 +1650,7 @@ static int search_hits_sequential(calitas_ctx* ctx, const calitas_guide_t* guide
                 const size_t b0 = k * piece, nb = std::min(piece, n - b0);
                 const auto t_land = std::chrono::steady_clock::now();
                 std::lock_guard<std::mutex> host_lock(ctx->host_mu);   // the helper thread's host stages (if any) use the same pool
-                ctx->pool->for_blocks(nb, [&](size_t b, size_t e, int) { std::memcpy(dst + b0 + b, bounce + b0 + b, e - b); });
+                ctx->pool->for_blocks(nb, [&](size_t b, size_t e, int) { stream_copy(dst + b0 + b, bounce + b0 + b, e - b); });
                 ms_land += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_land).count();
               }
               if (!ok) { rc = fail(ctx, CALITAS_EHIP, "SDMA copy failed"); break; }
